@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded frames/sec of the batched beam-search decoder on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): LexiconFreeDecoder + ZeroLM, CTC,
+batch = 256 utterances per GPU, T = 1000, N = 29, beam = 50, beamSizeToken = 29,
+beamThreshold = 25, logAdd = false, synthetic `ctc` emissions (SURVEY.md
+Appendix A).  A "step" = one fltx_decode_batch over that batch: decodeBegin +
+T frames + decodeEnd + back-trace of every hypothesis, inputs resident in HBM
+before the timed region, results left in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; utterances shard across ranks with no data-path
+collective (weak scaling: 256 utterances per GPU); torch.distributed is used
+only for the barrier and the max-over-ranks of the timed region.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : dominant kernel (fltx_decode_kernel) vs the HBM roofline,
+                 algorithmic bytes per SURVEY.md section 8(d) / HIP-event duration
+  cpu_baseline : the unmodified reference (oracle/_ref, kind "reference") or,
+                 if that prebuilt .so is absent, the oracle restatement (kind
+                 "port"), one thread, on a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+HBM_MEASURED_GBS = 6290.0    # same guide: 6.29 TB/s float4 copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--tokens", type=int, default=29)
+    ap.add_argument("--beam", type=int, default=50)
+    ap.add_argument("--beam-token", type=int, default=29)
+    ap.add_argument("--threads", type=int, default=0, help="threads per utterance (0 = library default)")
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3"])
+    ap.add_argument("--cpu-sample", type=int, default=64, help="utterances timed on the CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decoder has no CPU path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from text_amd import _capi, synth
+    B, T, N, K, Kt = a.batch, a.frames, a.tokens, a.beam, a.beam_token
+    if a.workload == "C3":
+        Kt = 10
+    lexicon = synth.lexicon() if a.workload == "C3" else None
+    dist_name = "lexspell" if a.workload == "C3" else "ctc"
+    u0 = rank * B  # each rank decodes its own shard of the node-wide batch
+    e_host = synth.batch(dist_name, B, T, N, lexicon=lexicon, u0=u0)
+    e_dev = torch.from_numpy(e_host).cuda()  # resident in HBM before timing
+    torch.cuda.synchronize()
+
+    ctx = _capi.Context(device=local)
+    lm = _capi.ZeroLM(ctx)
+    opt = _capi.make_options(K, Kt, 25.0)
+    trie = None
+    if a.workload == "C3":
+        W = len(lexicon[1]) - 1
+        ht = _capi.HostTrie(N, 0)
+        ht.insert_many(lexicon[0], lexicon[1], np.arange(W), np.zeros(W))
+        ht.smear(1)
+        trie = ht.upload(ctx)
+        dec = _capi.BatchDecoder(ctx, _capi.LEXICON, opt, lm, 0, N - 1, unk=W, trie=trie)
+    else:
+        dec = _capi.BatchDecoder(ctx, _capi.LEXFREE, opt, lm, 0, N - 1)
+    if a.threads:
+        dec.set("threads", a.threads)
+    Ts = np.full(B, T, dtype=np.int32)
+
+    def step():
+        dec.decode_batch(None, Ts, N, device_ptr=e_dev.data_ptr())
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kern_ms, bt_ms = [], []
+    for _ in range(a.steps):
+        step()
+        # HIP events recorded by the library on its own launch stream
+        d_ms, b_ms = dec.timing()
+        kern_ms.append(d_ms)
+        bt_ms.append(b_ms)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = dec.stats()
+    frames_total = B * T * a.steps * world
+    value = frames_total / dt
+
+    out = {
+        "metric": "decoded frames/sec (whole node), T=%d N=%d beam=%d; hyp bit-exact vs CPU" % (T, N, K),
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %s + ZeroLM CTC, batch=%d utterances/GPU, T=%d, N=%d, beam=%d, "
+                               "beamToken=%d, beamThreshold=25, logAdd=false, `%s` emissions" %
+                               (a.workload, "LexiconDecoder + 90k-word trie" if trie else "LexiconFreeDecoder",
+                                B, T, N, K, Kt, dist_name),
+                   "parallelism": "utterance-sharded x%d, no collective" % world,
+                   "threads_per_utterance": st["threads_per_utt"], "lds_bytes_per_workgroup": st["lds_bytes"]},
+    }
+    # ---- roofline of the dominant kernel (rank-local) -----------------------
+    k_ms = float(np.mean(kern_ms))
+    alg_bytes = st["algorithmic_bytes"]
+    ach = alg_bytes / (k_ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": "fltx_decode_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                       "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+                       "backtrace_kernel_ms": float(np.mean(bt_ms)),
+                       "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBS,
+                       "us_per_frame_step": k_ms * 1e3 / T}
+
+    # ---- CPU baseline + parity spot check (rank 0, N=1 only) ----------------
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt):
+    """Time the reference's CPU path on a bounded sample of the same batch and
+    compare its n-best with what the GPU produced for those utterances."""
+    from oracle import orclib
+    kind = "reference" if orclib.have_ref() else "port"
+    lib = orclib.load("ref" if kind == "reference" else "oracle")
+    opt = orclib.make_options(K, Kt, 25.0)
+    n = min(a.cpu_sample, B)
+    trie = None
+    if lexicon is not None:
+        W = len(lexicon[1]) - 1
+        trie = lib.build_trie(N, 0, lexicon[0], lexicon[1], np.arange(W), np.zeros(W), 1)
+    t_total = 0.0
+    mism = 0
+    for b in range(n):
+        lm = lib.lm_zero_create()
+        d = lib.lexicon(opt, trie, lm, 0, N - 1, W) if trie else lib.lexfree(opt, lm, 0, N - 1)
+        t0 = time.perf_counter()
+        hyps = lib.decode(d, e_host[b], T, N)  # fresh decoder per utterance, decode() only
+        t_total += time.perf_counter() - t0
+        lib.decoder_destroy(d)
+        lib.lm_destroy(lm)
+        got = dec.results(b)
+        same = len(got) == len(hyps) and all(
+            g.score == h.score and np.array_equal(g.tokens, h.tokens) and np.array_equal(g.words, h.words)
+            for g, h in zip(got, hyps))
+        mism += 0 if same else 1
+    return {"value": n * T / t_total, "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": "first %d utterances of the batch, one thread, fresh decoder per utterance, "
+                      "decode() wall time only" % n,
+            "seconds": t_total, "gpu_nbest_mismatches_on_sample": mism,
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

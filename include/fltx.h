@@ -1,0 +1,218 @@
+/*
+ * include/fltx.h -- C ABI of the MI355X-native batched beam-search decoder.
+ *
+ * This is the drop-in boundary for the hot path of flashlight/text's
+ * LexiconFreeDecoder / LexiconDecoder.  The reference
+ * has no FFI for this path (it is a header/C++ library); the functions below
+ * are what a cgo/JNI/ctypes/C++ binding of that path binds.  Each entry point
+ * cites the reference interface it replaces (paths relative to
+ * /root/reference/flashlight/lib/text/).
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int
+ * status (FLTX_OK == 0) and records a message retrievable with
+ * fltx_last_error() (thread-local).  The reference reports errors as C++
+ * exceptions (decoder/lm/LM.h:40, decoder/Trie.cpp:32,54); the C++ facade in
+ * text_amd/csrc/flashlight/ converts non-zero statuses back into the same
+ * exception types.
+ *
+ * There is NO CPU fallback behind this ABI: every decode call runs the HIP
+ * kernels in text_amd/csrc/fltx_kernels.h on a gfx950 device and fails with
+ * FLTX_ERR_HIP when no device is usable.
+ */
+#ifndef FLTX_H_
+#define FLTX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLTX_API __attribute__((visibility("default")))
+
+enum {
+  FLTX_OK = 0,
+  FLTX_ERR_INVALID = 1,     /* bad argument (std::invalid_argument) */
+  FLTX_ERR_HIP = 2,         /* HIP runtime failure / no device (std::runtime_error) */
+  FLTX_ERR_OOM = 3,         /* device allocation failed */
+  FLTX_ERR_UNSUPPORTED = 4, /* configuration the device path does not cover */
+  FLTX_ERR_RANGE = 5,       /* index out of range (std::out_of_range) */
+  FLTX_ERR_STATE = 6        /* call sequence error (e.g. results before decode) */
+};
+
+/* CriterionType, decoder/Decoder.h:16 (S2S is out of scope). */
+enum { FLTX_CRITERION_ASG = 0, FLTX_CRITERION_CTC = 1 };
+/* SmearingMode, decoder/Trie.h:21-25. */
+enum { FLTX_SMEAR_NONE = 0, FLTX_SMEAR_MAX = 1, FLTX_SMEAR_LOGADD = 2 };
+enum { FLTX_DECODER_LEXFREE = 0, FLTX_DECODER_LEXICON = 1 };
+
+/* LexiconDecoderOptions (decoder/LexiconDecoder.h:21-31); the lexicon-free
+ * decoder (decoder/LexiconFreeDecoder.h:20-28) ignores word_score/unk_score. */
+typedef struct fltx_options {
+  int32_t beam_size;
+  int32_t beam_size_token;
+  double beam_threshold;
+  double lm_weight;
+  double word_score;
+  double unk_score;
+  double sil_score;
+  int32_t log_add;
+  int32_t criterion;
+} fltx_options;
+
+typedef struct fltx_ctx fltx_ctx;         /* one HIP device + stream */
+typedef struct fltx_lm fltx_lm;           /* LM tables resident in HBM */
+typedef struct fltx_trie fltx_trie;       /* flattened lexicon trie in HBM */
+typedef struct fltx_decoder fltx_decoder; /* options + per-batch workspace */
+
+FLTX_API const char* fltx_last_error(void);
+FLTX_API const char* fltx_version(void);
+
+/* ---- context ------------------------------------------------------------ */
+/* device < 0: use the current HIP device.  stream == NULL: library-owned
+ * stream.  A caller-owned hipStream_t may be passed as void*. */
+FLTX_API int fltx_ctx_create(int device, void* stream, fltx_ctx** out);
+FLTX_API int fltx_ctx_destroy(fltx_ctx* ctx);
+FLTX_API int fltx_ctx_synchronize(fltx_ctx* ctx);
+/* the hipStream_t kernels are launched on (for event timing by the caller) */
+FLTX_API void* fltx_ctx_stream(fltx_ctx* ctx);
+
+/* ---- language models ---------------------------------------------------- */
+/* ZeroLM (decoder/lm/ZeroLM.h:22-32, ZeroLM.cpp:14-26). */
+FLTX_API int fltx_lm_zero_create(fltx_ctx* ctx, fltx_lm** out);
+/* Back-off n-gram LM with ARPA semantics, replacing the KenLM adapter
+ * (decoder/lm/KenLM.h:52-63, KenLM.cpp:32-83).  The model is passed as flat
+ * host arrays, one row per n-gram, all orders concatenated in increasing
+ * order: ngram_order[i] in 1..order, ngram_words[i*order .. i*order+order-1]
+ * = LM word ids oldest first (unused tail = -1), prob/backoff = log10 values.
+ * usr_to_lm[u] maps the decoder's word/token index u to an LM word id
+ * (KenLM.cpp:44-49); bos/eos/unk are LM ids of <s>, </s>, <unk>. */
+FLTX_API int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t n_ngrams,
+                                  const int32_t* ngram_order,
+                                  const int32_t* ngram_words,
+                                  const float* prob, const float* backoff,
+                                  const int32_t* usr_to_lm, int32_t n_usr,
+                                  int32_t bos, int32_t eos, int32_t unk,
+                                  fltx_lm** out);
+FLTX_API int fltx_lm_destroy(fltx_lm* lm);
+/* LM::start + LM::score chain + optional LM::finish on the device tables
+ * (decoder/lm/LM.h:61-78); per_word may be NULL.  Used by known-answer tests
+ * (test/decoder/DecoderTest.cpp:107-120). */
+FLTX_API int fltx_lm_score_sequence(fltx_lm* lm, const int32_t* usr_words,
+                                    int32_t n, int32_t with_finish,
+                                    float* per_word, float* total);
+
+/* ---- lexicon trie -------------------------------------------------------- */
+/* Upload an already built and smeared trie (decoder/Trie.h:64-92) as flat
+ * arrays; node 0 is the root.  child[node*n_tokens + token] = child node or
+ * -1; max_score[node] (float, after smearing); labels of node i are
+ * labels[label_off[i] .. label_off[i+1]) (at most kTrieMaxLabel = 6 each,
+ * Trie.h:19). */
+FLTX_API int fltx_trie_create(fltx_ctx* ctx, int64_t n_nodes, int32_t n_tokens,
+                              const int32_t* child, const float* max_score,
+                              const int32_t* label_off, const int32_t* labels,
+                              fltx_trie** out);
+FLTX_API int fltx_trie_destroy(fltx_trie* trie);
+
+/* Host-side trie builder with the reference's Trie semantics
+ * (decoder/Trie.h:64-92, Trie.cpp:26-101): insert / search / smear on the CPU
+ * (setup, runs once), then fltx_htrie_upload flattens it into HBM.  insert
+ * returns FLTX_ERR_RANGE for an index outside [0, max_children)
+ * (Trie.cpp:31-34 throws std::out_of_range) and silently drops labels beyond
+ * kTrieMaxLabel = 6 per node (Trie.cpp:40-46). */
+typedef struct fltx_htrie fltx_htrie;
+FLTX_API int fltx_htrie_create(int32_t max_children, int32_t root_idx, fltx_htrie** out);
+FLTX_API int fltx_htrie_destroy(fltx_htrie* t);
+FLTX_API int fltx_htrie_insert(fltx_htrie* t, const int32_t* indices, int32_t n,
+                               int32_t label, float score);
+/* *found = 0/1; max_score, n_labels, labels[<=6], scores[<=6] may be NULL */
+FLTX_API int fltx_htrie_search(fltx_htrie* t, const int32_t* indices, int32_t n,
+                               int32_t* found, float* max_score, int32_t* n_labels,
+                               int32_t* labels, float* scores);
+FLTX_API int fltx_htrie_smear(fltx_htrie* t, int32_t mode);
+FLTX_API int fltx_htrie_num_nodes(fltx_htrie* t, int64_t* n);
+FLTX_API int fltx_htrie_upload(fltx_htrie* t, fltx_ctx* ctx, fltx_trie** out);
+
+/* ---- decoder ------------------------------------------------------------- */
+/* LexiconFreeDecoder(opt, lm, sil, blank, transitions)
+ * (decoder/LexiconFreeDecoder.h:102-112) when kind == FLTX_DECODER_LEXFREE
+ * (trie NULL, unk/is_lm_token ignored);
+ * LexiconDecoder(opt, trie, lm, sil, blank, unk, transitions, isLmToken)
+ * (decoder/LexiconDecoder.h:117-133) when kind == FLTX_DECODER_LEXICON.
+ * transitions: n_tokens*n_tokens floats or NULL/0 (copied). */
+FLTX_API int fltx_decoder_create(fltx_ctx* ctx, int32_t kind,
+                                 const fltx_options* opt, const fltx_trie* trie,
+                                 const fltx_lm* lm, int32_t sil, int32_t blank,
+                                 int32_t unk, const float* transitions,
+                                 int32_t n_transitions, int32_t is_lm_token,
+                                 fltx_decoder** out);
+FLTX_API int fltx_decoder_destroy(fltx_decoder* dec);
+
+/* Batched Decoder::decode (decoder/Decoder.h:51-57) for B independent
+ * utterances: decodeBegin + decodeStep(all frames) + decodeEnd + back-trace,
+ * all on the device.  Utterance b reads T[b]*N floats (frame-major, token
+ * fastest, LexiconDecoder.cpp:69) starting at emissions + offsets[b].
+ * emissions_on_device != 0: `emissions` is a device pointer (HBM resident);
+ * otherwise it is a host pointer and is copied to the device first (the
+ * pointer is only borrowed for the duration of the call).  offsets and T are
+ * host arrays.  The call is asynchronous on the context stream; results are
+ * read with fltx_result_*, which synchronise. */
+FLTX_API int fltx_decode_batch(fltx_decoder* dec, const float* emissions,
+                               int32_t emissions_on_device,
+                               const int64_t* offsets, const int32_t* T,
+                               int32_t B, int32_t N);
+
+/* Streaming interface for B parallel streams (Decoder::decodeBegin /
+ * decodeStep / decodeEnd / prune, decoder/Decoder.h:42-61).  max_frames bounds
+ * the total frames buffered per stream between prunes. */
+FLTX_API int fltx_stream_begin(fltx_decoder* dec, int32_t B, int32_t N,
+                               int32_t max_frames);
+FLTX_API int fltx_stream_step(fltx_decoder* dec, const float* emissions,
+                              int32_t emissions_on_device,
+                              const int64_t* offsets, const int32_t* T);
+FLTX_API int fltx_stream_end(fltx_decoder* dec);
+/* Decoder::prune(lookBack) for every stream (LexiconFreeDecoder.cpp:205-227). */
+FLTX_API int fltx_stream_prune(fltx_decoder* dec, int32_t look_back);
+/* nDecodedFramesInBuffer (LexiconFreeDecoder.cpp:201-203). */
+FLTX_API int fltx_stream_frames_in_buffer(fltx_decoder* dec, int32_t b,
+                                          int32_t* n);
+
+/* ---- results (getAllFinalHypothesis / getBestHypothesis) ------------------ */
+/* Number of hypotheses of utterance b and the length (finalFrame + 1) of each
+ * tokens/words vector (decoder/Utils.h:236-247). */
+FLTX_API int fltx_result_count(fltx_decoder* dec, int32_t b, int32_t* n_hyp,
+                               int32_t* length);
+/* Copy out the first max_hyp hypotheses of utterance b, best first:
+ * scores[3*i + {0,1,2}] = score, emittingModelScore, lmScore
+ * (decoder/Utils.h:30-39); tokens/words [i*length + f]; either may be NULL. */
+FLTX_API int fltx_result_fetch(fltx_decoder* dec, int32_t b, int32_t max_hyp,
+                               double* scores, int32_t* tokens, int32_t* words,
+                               int32_t* n_copied);
+/* getBestHypothesis(lookBack) of stream b (LexiconFreeDecoder.cpp:188-194,
+ * decoder/Utils.h:268-310): *length = 0 for an empty result. */
+FLTX_API int fltx_result_best(fltx_decoder* dec, int32_t b, int32_t look_back,
+                              double* scores, int32_t* tokens, int32_t* words,
+                              int32_t capacity, int32_t* length);
+/* Device-resident results of the last batch (no host copy): pointers into HBM
+ * valid until the next decode call.  n_hyp: int32[B]; scores: double[B*K*3];
+ * tokens/words: int32 at tok_off[b] + i*(T[b]+2) + f. */
+FLTX_API int fltx_result_device(fltx_decoder* dec, const int32_t** n_hyp,
+                                const double** scores, const int32_t** tokens,
+                                const int32_t** words, const int64_t** tok_off);
+
+/* ---- introspection for bench.py ------------------------------------------ */
+/* Frames decoded and kernel launches issued by the last decode call, plus the
+ * algorithmic HBM bytes of SURVEY.md section 8(d) for it. */
+FLTX_API int fltx_decoder_stats(fltx_decoder* dec, int64_t* frames,
+                                int64_t* algorithmic_bytes, int32_t* threads_per_utt,
+                                int32_t* lds_bytes);
+/* Durations (ms) of the decode kernel and of the back-trace kernel of the last
+ * fltx_decode_batch, from HIP events recorded on the context stream. */
+FLTX_API int fltx_decoder_timing(fltx_decoder* dec, float* decode_ms, float* backtrace_ms);
+/* Tunables: "threads" (threads per utterance: 64..1024), "force_global_ws". */
+FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLTX_H_ */

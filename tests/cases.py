@@ -1,0 +1,87 @@
+"""Parity cases shared by tests/golden/make_golden.py (which runs the compiled
+REFERENCE in the dev container) and the tests (which run the oracle, the
+emulated kernels and the HIP path against the committed expectations).
+
+A case is a plain dict; inputs are regenerated bit-exactly from the spec by
+text_amd.synth, so the fixture only stores outputs.
+"""
+
+
+def case(name, kind="lexfree", dist="ctc", u=0, T=20, N=29, K=4, Kt=None, thr=25.0, lm_weight=0.0,
+         word_score=0.0, unk_score=float("-inf"), sil_score=0.0, log_add=False, crit="ctc", lexicon=None,
+         trans_seed=None, lm="zero", is_lm_token=False, size="small", label_scores=None):
+    return dict(name=name, kind=kind, dist=dist, u=u, T=T, N=N, K=K, Kt=(N if Kt is None else Kt), thr=thr,
+                lm_weight=lm_weight, word_score=word_score, unk_score=unk_score, sil_score=sil_score,
+                log_add=log_add, crit=crit, lexicon=lexicon, trans_seed=trans_seed, lm=lm,
+                is_lm_token=is_lm_token, size=size, label_scores=label_scores)
+
+
+SMALL_LEX = (300, 4242)   # (W, seed): 300-word synthetic lexicon
+NODUP_LEX = (300, 4242, True)  # same, without doubled letters (ASG: see helpers.lexicon)
+FULL_LEX = (90000, 4242)  # SURVEY.md Appendix A lexicon (513 786 trie nodes)
+
+CASES = [
+    # ---- lexicon-free, small (emulator-sized) ------------------------------
+    case("lf_ctc_t20_k4", T=20, K=4),
+    case("lf_ctc_t60_k10", T=60, K=10),
+    case("lf_ctc_t60_k10_kt5", T=60, K=10, Kt=5, u=1),
+    case("lf_uni_t40_k10", dist="uniform", T=40, K=10),
+    case("lf_ctc_t60_k10_logadd", T=60, K=10, log_add=True),
+    case("lf_ctc_t0", T=0, K=4),
+    case("lf_ctc_t1", T=1, K=4),
+    case("lf_ctc_k1", T=30, K=1),
+    case("lf_ctc_thr3", T=50, K=8, thr=3.0, u=2),
+    case("lf_ctc_sil", T=40, K=8, sil_score=-0.7, u=3),
+    case("lf_asg_t30_n8", dist="uniform", T=30, N=8, K=6, crit="asg", trans_seed=11),
+    case("lf_asg_t40_n29_kt7", dist="ctc", T=40, N=29, K=8, Kt=7, crit="asg", trans_seed=12, u=4),
+    case("lf_ctc_n4", dist="uniform", T=25, N=4, K=5),
+    # ---- lexicon-free, BASELINE shapes --------------------------------------
+    case("C1_ctc_u0", T=200, K=10, size="medium"),
+    case("C1_uniform_u0", dist="uniform", T=200, K=10, size="medium"),
+    case("C2_ctc_u0", T=1000, K=50, size="large"),
+    case("C2_ctc_u255", T=1000, K=50, u=255, size="large"),
+    case("C2_ctc_u0_kt10", T=1000, K=50, Kt=10, size="large"),
+    case("C2_ctc_u0_logadd", T=1000, K=50, log_add=True, size="large"),
+    case("C2_uniform_u0", dist="uniform", T=1000, K=50, size="large"),
+    case("lf_ctc_t300_k100", T=300, K=100, u=7, size="medium"),
+    # ---- lexicon decoder, small ---------------------------------------------
+    case("lx_spell_t40_k8", kind="lexicon", dist="lexspell", T=40, K=8, Kt=10, lexicon=SMALL_LEX),
+    case("lx_spell_t60_k12_full", kind="lexicon", dist="lexspell", T=60, K=12, lexicon=SMALL_LEX, u=1),
+    case("lx_spell_t60_k12_logadd", kind="lexicon", dist="lexspell", T=60, K=12, lexicon=SMALL_LEX, u=1,
+         log_add=True),
+    case("lx_spell_unk", kind="lexicon", dist="lexspell", T=50, K=10, lexicon=SMALL_LEX, u=2,
+         unk_score=-2.5, word_score=1.5, sil_score=-0.3),
+    case("lx_uni_t40_k10", kind="lexicon", dist="uniform", T=40, K=10, lexicon=SMALL_LEX),
+    case("lx_asg_t40", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=NODUP_LEX, crit="asg",
+         trans_seed=21, u=3),
+    case("lx_tokenlm_t40", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=SMALL_LEX, u=4,
+         is_lm_token=True, word_score=0.5),
+    case("lx_scores_t50", kind="lexicon", dist="lexspell", T=50, K=10, lexicon=SMALL_LEX, u=5,
+         lm_weight=1.5, word_score=1.0, label_scores=33),
+    case("lx_t0", kind="lexicon", dist="lexspell", T=0, K=4, lexicon=SMALL_LEX),
+    # ---- lexicon decoder, BASELINE shapes -------------------------------------
+    case("C3_spell_u0", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, size="large"),
+    case("C3_spell_u255", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, u=255,
+         size="large"),
+    case("C3_uniform_u0", kind="lexicon", dist="uniform", T=1000, K=50, Kt=10, lexicon=FULL_LEX,
+         size="large"),
+    case("C4z_spell_u0", kind="lexicon", dist="lexspell", T=1500, K=100, lexicon=FULL_LEX, size="large"),
+]
+
+BY_NAME = {c["name"]: c for c in CASES}
+
+# known answers of the unmodified reference, produced by
+# the survey session.  make_golden.py re-derives them; a mismatch means the
+# input generator deviates from the Appendix A spec.
+APPENDIX_B = {
+    "C1_ctc_u0": (10, 0x4B1C4A0FF2B8DD27, "-0x1.9ded43ep+5"),
+    "C2_ctc_u0": (50, 0x06A44F90B4527735, "-0x1.fb2154b8p+7"),
+    "C2_ctc_u255": (50, 0x78189EA6705FEFAF, "-0x1.fdf0f6c4p+7"),
+    "C2_ctc_u0_kt10": (50, 0x06A44F90B4527735, "-0x1.fb2154b8p+7"),
+    "C1_uniform_u0": (10, 0x5A8A12C2BA2E6753, "-0x1.2e682ba8p+6"),
+    "C2_uniform_u0": (50, 0x0E27A344FA89DDAA, "-0x1.6601eaaap+8"),
+    "C3_spell_u0": (35, 0xB4FA933C10141D73, "-0x1.0265c3d3p+8"),
+    "C3_spell_u255": (37, 0x2CBF5EA93CE796F9, "-0x1.e93d4208p+7"),
+    "C3_uniform_u0": (13, 0xF3B0CBE10F12C3EB, "-0x1.073519b8p+10"),
+    "C4z_spell_u0": (69, 0xE65C45F2D737271E, "-0x1.749f9bfc8p+8"),
+}

@@ -1,0 +1,153 @@
+/*
+ * tests/emu/hip_emu.h -- minimal host emulation of the HIP constructs used by
+ * text_amd/csrc/fltx_kernels.h, for debugging kernel LOGIC without a GPU.
+ *
+ * TEST INFRASTRUCTURE ONLY.  A workgroup runs as W host threads with real
+ * barriers; wave collectives exchange through a per-wave scratch.  It is slow
+ * (milliseconds per frame) and is only ever built into tests/emu/libfltx_emu.so
+ * by tests/emu/build.sh; the product library (text_amd/lib/libfltx.so) has no
+ * CPU path and never loads this.
+ */
+#pragma once
+#include <pthread.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define FLTX_DEV static inline
+#define __device__
+#define __global__
+#define __host__
+#define __forceinline__ inline
+
+struct uint4 {
+  uint32_t x, y, z, w;
+};
+struct int2 {
+  int x, y;
+};
+static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
+static inline int2 make_int2(int a, int b) { return int2{a, b}; }
+
+struct EmuDim {
+  unsigned x;
+};
+
+struct EmuWave {
+  pthread_barrier_t bar;
+  unsigned long long slot[64];
+};
+struct EmuBlock {
+  pthread_barrier_t bar;
+  std::vector<EmuWave> waves;
+};
+
+extern thread_local EmuDim threadIdx, blockIdx, blockDim;
+extern thread_local EmuBlock* emuBlock;
+
+static inline void __syncthreads() { pthread_barrier_wait(&emuBlock->bar); }
+static inline long long __double_as_longlong(double d) {
+  long long r;
+  memcpy(&r, &d, 8);
+  return r;
+}
+static inline double __longlong_as_double(long long v) {
+  double r;
+  memcpy(&r, &v, 8);
+  return r;
+}
+
+namespace fltx {
+FLTX_DEV int laneId() { return (int)(threadIdx.x & 63); }
+FLTX_DEV int waveId() { return (int)(threadIdx.x >> 6); }
+
+FLTX_DEV uint32_t atomCas32(uint32_t* p, uint32_t cmp, uint32_t val) {
+  __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;
+}
+FLTX_DEV uint32_t atomExch32(uint32_t* p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+FLTX_DEV uint32_t atomAdd32(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+FLTX_DEV uint32_t atomOr32(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+FLTX_DEV unsigned long long atomMax64(unsigned long long* p, unsigned long long v) {
+  unsigned long long cur = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+  }
+  return cur;
+}
+FLTX_DEV unsigned long long atomMin64(unsigned long long* p, unsigned long long v) {
+  unsigned long long cur = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (cur > v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+  }
+  return cur;
+}
+FLTX_DEV unsigned long long atomCas64(unsigned long long* p, unsigned long long cmp, unsigned long long val) {
+  __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;
+}
+FLTX_DEV unsigned long long loadCoherent64(const unsigned long long* p) {
+  return __atomic_load_n(p, __ATOMIC_SEQ_CST);
+}
+FLTX_DEV uint32_t ldsLoad32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+FLTX_DEV void compilerFence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+/* wave collectives: publish, barrier, read, barrier */
+FLTX_DEV EmuWave& emuWave() { return emuBlock->waves[threadIdx.x >> 6]; }
+template <class F>
+FLTX_DEV auto emuExchange(unsigned long long mine, F&& f) {
+  EmuWave& w = emuWave();
+  w.slot[threadIdx.x & 63] = mine;
+  pthread_barrier_wait(&w.bar);
+  auto r = f(w.slot);
+  pthread_barrier_wait(&w.bar);
+  return r;
+}
+FLTX_DEV unsigned long long waveBallot(bool p) {
+  return emuExchange(p ? 1ull : 0ull, [](const unsigned long long* s) {
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) {
+      m |= (s[i] & 1ull) << i;
+    }
+    return m;
+  });
+}
+FLTX_DEV int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+FLTX_DEV uint32_t waveShfl32(uint32_t v, int src) {
+  return emuExchange(v, [src](const unsigned long long* s) { return (uint32_t)s[src & 63]; });
+}
+FLTX_DEV unsigned long long waveMax64(unsigned long long v) {
+  return emuExchange(v, [](const unsigned long long* s) {
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) {
+      m = s[i] > m ? s[i] : m;
+    }
+    return m;
+  });
+}
+FLTX_DEV unsigned long long waveMin64(unsigned long long v) {
+  return emuExchange(v, [](const unsigned long long* s) {
+    unsigned long long m = ~0ull;
+    for (int i = 0; i < 64; ++i) {
+      m = s[i] < m ? s[i] : m;
+    }
+    return m;
+  });
+}
+FLTX_DEV int waveInclusiveScan(int v) {
+  const int lane = (int)(threadIdx.x & 63);
+  return emuExchange((unsigned long long)(uint32_t)v, [lane](const unsigned long long* s) {
+    int acc = 0;
+    for (int i = 0; i <= lane; ++i) {
+      acc += (int)(uint32_t)s[i];
+    }
+    return acc;
+  });
+}
+} // namespace fltx
+
+/* run fn() as a grid of nBlocks workgroups of W threads, with `ldsBytes` of
+ * zero-initialised "LDS" per workgroup */
+void emuLaunch(int nBlocks, int W, size_t ldsBytes, const std::function<void(char*)>& fn);

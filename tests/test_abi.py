@@ -1,0 +1,65 @@
+"""CPU (not gpu): the C-ABI shared library loads and exports every symbol that
+include/fltx.h declares; host-only entry points (trie builder, error paths)
+behave like the reference's.  No decode is run here -- that needs the GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+from text_amd import _capi
+
+HEADER = os.path.join(helpers.ROOT, "include", "fltx.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"FLTX_API\s+[\w\s\*]+?\b(fltx_\w+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    path = _capi.DEFAULT_LIB
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _capi.Lib(path)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib.lib, n), "libfltx.so does not export " + n
+    assert set(names) == set(_capi.Lib.SYMBOLS)
+
+
+def test_host_trie_matches_reference_semantics(lib):
+    t = _capi.HostTrie(5, 0, lib=lib)
+    t.insert([1, 2], 10, -1.0)
+    t.insert([1, 2], 11, -2.0)
+    t.insert([1, 3, 0], 12, -0.5)
+    with pytest.raises(IndexError):  # Trie.cpp:31-34 throws std::out_of_range
+        t.insert([1, 7], 13, 0.0)
+    for i in range(8):  # kTrieMaxLabel = 6: extra labels are dropped (Trie.cpp:40-46)
+        t.insert([4], 100 + i, -3.0)
+    assert len(t.search([4])["labels"]) == 6
+    assert t.search([2]) is None
+    t.smear(1)
+    # node [1,2]: own scores are log-added even in MAX mode (Trie.cpp:80-83)
+    want = np.float32(np.logaddexp(-1.0, -2.0))
+    assert np.float32(t.search([1, 2])["max_score"]) == want
+    assert np.float32(t.search([1])["max_score"]) == np.float32(-0.5)
+    assert t.num_nodes() == 6
+
+
+def test_no_device_fails_loudly(lib):
+    """Without a GPU the context cannot be created and says so (no CPU path)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_capi.FltxError) as ei:
+        _capi.Context(lib=lib)
+    assert "no CPU path" in str(ei.value) or "HIP" in str(ei.value)

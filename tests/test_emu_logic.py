@@ -1,0 +1,25 @@
+"""CPU (not gpu): the SAME kernel source as the HIP path, compiled for host
+threads (tests/emu), against the reference golden vectors.  This checks kernel
+logic only; the parity claim for the product is made by tests/test_gpu_parity.py
+on a real MI355X."""
+import pytest
+
+import cases
+import helpers
+
+SMALL = [c for c in cases.CASES if c["size"] == "small" and c["T"] <= 40]
+
+
+@pytest.mark.parametrize("c", SMALL, ids=lambda c: c["name"])
+def test_emulated_kernels_match_golden(emu_session, golden, c):
+    hyps = emu_session.run(c, threads=64)
+    tol = 1e-9 if c["log_add"] else 0.0
+    ok, why = helpers.check_against_golden(hyps, golden[c["name"]], tol)
+    assert ok, why
+
+
+def test_emulated_two_waves(emu_session, golden):
+    c = cases.BY_NAME["lf_ctc_t20_k4"]
+    hyps = emu_session.run(c, threads=128)
+    ok, why = helpers.check_against_golden(hyps, golden[c["name"]])
+    assert ok, why

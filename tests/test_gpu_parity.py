@@ -1,0 +1,96 @@
+"""GPU (-m gpu): the product path -- text_amd/lib/libfltx.so through the C ABI
+on a real MI355X -- against (a) the golden vectors produced by the compiled
+reference and (b) the oracle on the same seeded inputs.  Integer outputs
+(tokens, words) exact; scores bit-identical for max-merge, 1e-5 for logAdd
+(device libm is not glibc: SURVEY.md H3)."""
+import numpy as np
+import pytest
+
+import cases
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+ALL = cases.CASES
+
+
+@pytest.mark.parametrize("c", ALL, ids=lambda c: c["name"])
+def test_hip_matches_reference_golden(gpu_session, golden, c):
+    hyps = gpu_session.run(c)
+    tol = 1e-5 if c["log_add"] else 0.0
+    ok, why = helpers.check_against_golden(hyps, golden[c["name"]], tol)
+    assert ok, why
+
+
+@pytest.mark.parametrize("threads", [64, 128, 256, 512, 1024])
+def test_threads_per_utterance_do_not_change_results(gpu_session, golden, threads):
+    for name in ("C1_ctc_u0", "lx_spell_t60_k12_full", "lf_asg_t40_n29_kt7"):
+        c = cases.BY_NAME[name]
+        hyps = gpu_session.run(c, threads=threads)
+        ok, why = helpers.check_against_golden(hyps, golden[name])
+        assert ok, "%s @%d threads: %s" % (name, threads, why)
+
+
+def test_batch_of_ragged_utterances_matches_oracle(gpu_session, oracle_lib):
+    """B utterances of different length in one launch == B single decodes of
+    the oracle (utterances are independent: SURVEY.md section 8e)."""
+    from text_amd import synth
+    c = dict(cases.BY_NAME["C1_ctc_u0"])
+    Ts = [0, 1, 37, 200, 123, 64, 5, 199]
+    N = c["N"]
+    embs = [synth.emissions("ctc", 100 + i, T, N) for i, T in enumerate(Ts)]
+    flat = np.concatenate([e.reshape(-1) for e in embs]) if sum(Ts) else np.zeros(0, np.float32)
+    d = gpu_session.decoder(c, dict(tr=None))
+    d.decode_batch(flat, Ts, N)
+    for b, T in enumerate(Ts):
+        cb = dict(c, T=T)
+        want = helpers.run_checker(oracle_lib, cb, dict(e=embs[b], tr=None, lex=None))
+        ok, why = helpers.hyps_equal(want, d.results(b))
+        assert ok, "utterance %d (T=%d): %s" % (b, T, why)
+    d.close()
+
+
+def test_streaming_chunks_equal_offline(gpu_session, golden):
+    """decodeBegin + several decodeStep chunks + decodeEnd == decode()."""
+    c = cases.BY_NAME["C1_ctc_u0"]
+    inp = helpers.case_inputs(c)
+    d = gpu_session.decoder(c, inp)
+    d.stream_begin(1, c["N"], c["T"])
+    t = 0
+    for chunk in (1, 7, 64, 100, 28):
+        d.stream_step(np.ascontiguousarray(inp["e"][t:t + chunk]), [chunk])
+        t += chunk
+    assert t == c["T"]
+    d.stream_end()
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
+    assert ok, why
+    d.close()
+
+
+def test_c2_batch_property_checks(gpu_session, golden):
+    """Full C2 batch shape (B=256, T=1000, K=50): utterances 0 and 255 equal the
+    reference golden; every utterance returns K sorted hypotheses whose token
+    rows start and end with sil and whose am score equals the sum of the
+    emissions along the path (size-independent properties)."""
+    from text_amd import synth
+    c = cases.BY_NAME["C2_ctc_u0"]
+    B, T, N = 256, c["T"], c["N"]
+    e = synth.batch("ctc", B, T, N)
+    d = gpu_session.decoder(c, dict(tr=None))
+    d.decode_batch(e, [T] * B, N)
+    for b, name in ((0, "C2_ctc_u0"), (255, "C2_ctc_u255")):
+        ok, why = helpers.check_against_golden(d.results(b), golden[name])
+        assert ok, "%s: %s" % (name, why)
+    for b in range(0, B, 17):
+        hyps = d.results(b)
+        assert len(hyps) == c["K"]
+        sc = [h.score for h in hyps]
+        assert all(x > y for x, y in zip(sc, sc[1:]))
+        for h in hyps[:5]:
+            assert h.tokens[0] == 0 and h.tokens[-1] == 0 and len(h.tokens) == T + 2
+            path = e[b][np.arange(T), h.tokens[1:-1]].astype(np.float64)
+            acc = 0.0
+            for v in path:
+                acc += v
+            assert acc == h.am == h.score
+    d.close()

@@ -1,0 +1,429 @@
+"""ctypes binding of the C ABI in include/fltx.h (text_amd/lib/libfltx.so).
+
+This is the only way Python reaches the decoder: every decode call runs the
+HIP kernels.  If the shared library is missing or no gfx950 device is usable
+the calls raise -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libfltx.so")
+
+FLTX_OK, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_RANGE, ERR_STATE = range(7)
+CRITERION = {"asg": 0, "ctc": 1}
+LEXFREE, LEXICON = 0, 1
+
+
+class Options(C.Structure):
+    """fltx_options == LexiconDecoderOptions (decoder/LexiconDecoder.h:21-31)."""
+
+    _fields_ = [
+        ("beam_size", C.c_int32),
+        ("beam_size_token", C.c_int32),
+        ("beam_threshold", C.c_double),
+        ("lm_weight", C.c_double),
+        ("word_score", C.c_double),
+        ("unk_score", C.c_double),
+        ("sil_score", C.c_double),
+        ("log_add", C.c_int32),
+        ("criterion", C.c_int32),
+    ]
+
+
+class FltxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fltx error %d: %s" % (code, msg))
+        self.code = code
+
+
+_EXC = {ERR_INVALID: ValueError, ERR_RANGE: IndexError}
+
+
+class Lib:
+    """A loaded libfltx with typed entry points."""
+
+    SYMBOLS = [
+        "fltx_last_error", "fltx_version", "fltx_ctx_create", "fltx_ctx_destroy",
+        "fltx_ctx_synchronize", "fltx_ctx_stream", "fltx_lm_zero_create",
+        "fltx_lm_ngram_create", "fltx_lm_destroy", "fltx_lm_score_sequence",
+        "fltx_trie_create", "fltx_trie_destroy", "fltx_decoder_create",
+        "fltx_decoder_destroy", "fltx_decode_batch", "fltx_stream_begin",
+        "fltx_stream_step", "fltx_stream_end", "fltx_stream_prune",
+        "fltx_stream_frames_in_buffer", "fltx_result_count", "fltx_result_fetch",
+        "fltx_result_best", "fltx_result_device", "fltx_decoder_stats",
+        "fltx_decoder_set", "fltx_decoder_timing", "fltx_htrie_create", "fltx_htrie_destroy", "fltx_htrie_insert",
+        "fltx_htrie_search", "fltx_htrie_smear", "fltx_htrie_num_nodes", "fltx_htrie_upload",
+    ]
+
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % path)
+        self.path = path
+        L = self.lib = C.CDLL(path)
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        pvp = C.POINTER(C.c_void_p)
+        L.fltx_last_error.restype = C.c_char_p
+        L.fltx_version.restype = C.c_char_p
+        L.fltx_ctx_stream.restype = vp
+        L.fltx_ctx_stream.argtypes = [vp]
+        sig = {
+            "fltx_ctx_create": [C.c_int, vp, pvp],
+            "fltx_ctx_destroy": [vp],
+            "fltx_ctx_synchronize": [vp],
+            "fltx_lm_zero_create": [vp, pvp],
+            "fltx_lm_ngram_create": [vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, pvp],
+            "fltx_lm_destroy": [vp],
+            "fltx_lm_score_sequence": [vp, vp, i32, i32, vp, vp],
+            "fltx_trie_create": [vp, i64, i32, vp, vp, vp, vp, pvp],
+            "fltx_trie_destroy": [vp],
+            "fltx_decoder_create": [vp, i32, C.POINTER(Options), vp, vp, i32, i32, i32, vp, i32, i32, pvp],
+            "fltx_decoder_destroy": [vp],
+            "fltx_decode_batch": [vp, vp, i32, vp, vp, i32, i32],
+            "fltx_stream_begin": [vp, i32, i32, i32],
+            "fltx_stream_step": [vp, vp, i32, vp, vp],
+            "fltx_stream_end": [vp],
+            "fltx_stream_prune": [vp, i32],
+            "fltx_stream_frames_in_buffer": [vp, i32, vp],
+            "fltx_result_count": [vp, i32, vp, vp],
+            "fltx_result_fetch": [vp, i32, i32, vp, vp, vp, vp],
+            "fltx_result_best": [vp, i32, i32, vp, vp, vp, i32, vp],
+            "fltx_result_device": [vp, pvp, pvp, pvp, pvp, pvp],
+            "fltx_decoder_stats": [vp, vp, vp, vp, vp],
+            "fltx_decoder_set": [vp, C.c_char_p, i64],
+            "fltx_decoder_timing": [vp, vp, vp],
+            "fltx_htrie_create": [i32, i32, pvp],
+            "fltx_htrie_destroy": [vp],
+            "fltx_htrie_insert": [vp, vp, i32, i32, C.c_float],
+            "fltx_htrie_search": [vp, vp, i32, vp, vp, vp, vp, vp],
+            "fltx_htrie_smear": [vp, i32],
+            "fltx_htrie_num_nodes": [vp, vp],
+            "fltx_htrie_upload": [vp, vp, pvp],
+        }
+        for name, args in sig.items():
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = args
+
+    def check(self, rc):
+        if rc != FLTX_OK:
+            msg = self.lib.fltx_last_error().decode()
+            raise _EXC.get(rc, FltxError)(msg) if rc in _EXC else FltxError(rc, msg)
+
+    def version(self):
+        return self.lib.fltx_version().decode()
+
+
+_default = None
+
+
+def default_lib():
+    global _default
+    if _default is None:
+        _default = Lib()
+    return _default
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Context:
+    def __init__(self, device=-1, stream=None, lib=None):
+        self.L = lib or default_lib()
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_ctx_create(device, stream, C.byref(h)))
+        self.h = h
+
+    def synchronize(self):
+        self.L.check(self.L.lib.fltx_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return self.L.lib.fltx_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.lib.fltx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ZeroLM:
+    def __init__(self, ctx):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_lm_zero_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def score_sequence(self, words, with_finish=True):
+        return self._score(words, with_finish)
+
+    def _score(self, words, with_finish):
+        w = np.ascontiguousarray(words, dtype=np.int32)
+        per = np.zeros(len(w), dtype=np.float32)
+        tot = C.c_float(0)
+        self.L.check(self.L.lib.fltx_lm_score_sequence(self.h, _ptr(w), len(w), int(with_finish),
+                                                       _ptr(per), C.addressof(tot)))
+        return per, tot.value
+
+    def close(self):
+        if self.h:
+            self.L.lib.fltx_lm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NgramLM(ZeroLM):
+    """Flat back-off n-gram tables in HBM (replaces lm/KenLM.cpp:32-83)."""
+
+    def __init__(self, ctx, order, ngram_order, ngram_words, prob, backoff, usr_to_lm, bos, eos, unk):
+        self.ctx, self.L = ctx, ctx.L
+        no = np.ascontiguousarray(ngram_order, dtype=np.int32)
+        nw = np.ascontiguousarray(ngram_words, dtype=np.int32).reshape(len(no), order)
+        pr = np.ascontiguousarray(prob, dtype=np.float32)
+        bo = np.ascontiguousarray(backoff, dtype=np.float32)
+        um = np.ascontiguousarray(usr_to_lm, dtype=np.int32)
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_lm_ngram_create(ctx.h, order, len(no), _ptr(no), _ptr(nw), _ptr(pr),
+                                                     _ptr(bo), _ptr(um), len(um), bos, eos, unk,
+                                                     C.byref(h)))
+        self.h = h
+
+
+class Trie:
+    """Flattened, already smeared lexicon trie in HBM (decoder/Trie.h:64-92)."""
+
+    def __init__(self, ctx, child, max_score, label_off, labels):
+        self.ctx, self.L = ctx, ctx.L
+        ch = np.ascontiguousarray(child, dtype=np.int32)
+        n_nodes, n_tokens = ch.shape
+        ms = np.ascontiguousarray(max_score, dtype=np.float32)
+        lo = np.ascontiguousarray(label_off, dtype=np.int32)
+        lb = np.ascontiguousarray(labels, dtype=np.int32)
+        assert len(ms) == n_nodes and len(lo) == n_nodes + 1
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_trie_create(ctx.h, n_nodes, n_tokens, _ptr(ch), _ptr(ms), _ptr(lo),
+                                                 _ptr(lb) if len(lb) else None, C.byref(h)))
+        self.h = h
+        self.n_nodes, self.n_tokens = n_nodes, n_tokens
+
+    def close(self):
+        if self.h:
+            self.L.lib.fltx_trie_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostTrie:
+    """Host-side Trie(maxChildren, rootIdx) with insert/search/smear
+    (decoder/Trie.h:64-92); `upload` flattens it into HBM."""
+
+    def __init__(self, max_children, root_idx, lib=None):
+        self.L = lib or default_lib()
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_htrie_create(max_children, root_idx, C.byref(h)))
+        self.h = h
+
+    def insert(self, indices, label, score):
+        a = np.ascontiguousarray(indices, dtype=np.int32)
+        self.L.check(self.L.lib.fltx_htrie_insert(self.h, _ptr(a), len(a), int(label), float(score)))
+
+    def insert_many(self, spell_flat, spell_off, labels, scores):
+        sf = np.ascontiguousarray(spell_flat, dtype=np.int32)
+        f = self.L.lib.fltx_htrie_insert
+        base = sf.ctypes.data
+        for w in range(len(spell_off) - 1):
+            a, b = int(spell_off[w]), int(spell_off[w + 1])
+            self.L.check(f(self.h, base + 4 * a, b - a, int(labels[w]), float(scores[w])))
+
+    def search(self, indices):
+        a = np.ascontiguousarray(indices, dtype=np.int32)
+        found, nl = C.c_int32(0), C.c_int32(0)
+        ms = C.c_float(0)
+        labels = np.zeros(6, dtype=np.int32)
+        scores = np.zeros(6, dtype=np.float32)
+        self.L.check(self.L.lib.fltx_htrie_search(self.h, _ptr(a), len(a), C.addressof(found),
+                                                  C.addressof(ms), C.addressof(nl), _ptr(labels),
+                                                  _ptr(scores)))
+        if not found.value:
+            return None
+        return {"max_score": ms.value, "labels": labels[:nl.value].tolist(),
+                "scores": scores[:nl.value].tolist()}
+
+    def smear(self, mode=1):
+        self.L.check(self.L.lib.fltx_htrie_smear(self.h, int(mode)))
+
+    def num_nodes(self):
+        n = C.c_int64(0)
+        self.L.check(self.L.lib.fltx_htrie_num_nodes(self.h, C.addressof(n)))
+        return n.value
+
+    def upload(self, ctx):
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_htrie_upload(self.h, ctx.h, C.byref(h)))
+        t = Trie.__new__(Trie)
+        t.ctx, t.L, t.h = ctx, ctx.L, h
+        t.n_nodes, t.n_tokens = self.num_nodes(), None
+        return t
+
+    def close(self):
+        if self.h:
+            self.L.lib.fltx_htrie_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Hyp:
+    __slots__ = ("score", "am", "lm", "tokens", "words")
+
+    def __init__(self, score, am, lm, tokens, words):
+        self.score, self.am, self.lm = score, am, lm
+        self.tokens, self.words = tokens, words
+
+
+class BatchDecoder:
+    """fltx_decoder: batched LexiconFreeDecoder / LexiconDecoder on the device."""
+
+    def __init__(self, ctx, kind, options, lm, sil, blank, unk=-1, trie=None, transitions=None,
+                 is_lm_token=False):
+        self.ctx, self.L = ctx, ctx.L
+        self.kind, self.options = kind, options
+        self._keep = (lm, trie)
+        tr = None if transitions is None or len(transitions) == 0 else \
+            np.ascontiguousarray(transitions, dtype=np.float32)
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_decoder_create(
+            ctx.h, kind, C.byref(options), trie.h if trie is not None else None, lm.h, sil, blank, unk,
+            _ptr(tr), 0 if tr is None else tr.size, int(is_lm_token), C.byref(h)))
+        self.h = h
+        self.B = 0
+
+    def set(self, key, value):
+        self.L.check(self.L.lib.fltx_decoder_set(self.h, key.encode(), int(value)))
+
+    def decode_batch(self, emissions, T, N, offsets=None, device_ptr=None):
+        """emissions: host float32 array (any shape, flat layout) or None when
+        device_ptr (int) addresses HBM-resident emissions."""
+        T = np.ascontiguousarray(T, dtype=np.int32)
+        B = len(T)
+        if offsets is None:
+            offsets = np.concatenate([[0], np.cumsum(T.astype(np.int64) * N)[:-1]]).astype(np.int64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if device_ptr is not None:
+            self.L.check(self.L.lib.fltx_decode_batch(self.h, device_ptr, 1, _ptr(offsets), _ptr(T), B, N))
+        else:
+            e = np.ascontiguousarray(emissions, dtype=np.float32)
+            self.L.check(self.L.lib.fltx_decode_batch(self.h, _ptr(e), 0, _ptr(offsets), _ptr(T), B, N))
+        self.B = B
+
+    def stream_begin(self, B, N, max_frames):
+        self.L.check(self.L.lib.fltx_stream_begin(self.h, B, N, max_frames))
+        self.B = B
+        self._N = N
+
+    def stream_step(self, emissions, T, offsets=None):
+        T = np.ascontiguousarray(T, dtype=np.int32)
+        if offsets is None:
+            offsets = np.concatenate([[0], np.cumsum(T.astype(np.int64) * self._N)[:-1]]).astype(np.int64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        e = np.ascontiguousarray(emissions, dtype=np.float32)
+        self.L.check(self.L.lib.fltx_stream_step(self.h, _ptr(e), 0, _ptr(offsets), _ptr(T)))
+
+    def stream_end(self):
+        self.L.check(self.L.lib.fltx_stream_end(self.h))
+
+    def stream_prune(self, look_back=0):
+        self.L.check(self.L.lib.fltx_stream_prune(self.h, look_back))
+
+    def frames_in_buffer(self, b):
+        n = C.c_int32(0)
+        self.L.check(self.L.lib.fltx_stream_frames_in_buffer(self.h, b, C.addressof(n)))
+        return n.value
+
+    def count(self, b):
+        n, ln = C.c_int32(0), C.c_int32(0)
+        self.L.check(self.L.lib.fltx_result_count(self.h, b, C.addressof(n), C.addressof(ln)))
+        return n.value, ln.value
+
+    def results(self, b, max_hyp=None):
+        n, ln = self.count(b)
+        if max_hyp is not None:
+            n = min(n, max_hyp)
+        if n == 0:
+            return []
+        scores = np.zeros(3 * n, dtype=np.float64)
+        tokens = np.zeros((n, ln), dtype=np.int32)
+        words = np.zeros((n, ln), dtype=np.int32)
+        got = C.c_int32(0)
+        self.L.check(self.L.lib.fltx_result_fetch(self.h, b, n, _ptr(scores), _ptr(tokens), _ptr(words),
+                                                  C.addressof(got)))
+        assert got.value == n
+        return [Hyp(scores[3 * i], scores[3 * i + 1], scores[3 * i + 2], tokens[i].copy(), words[i].copy())
+                for i in range(n)]
+
+    def best(self, b, look_back=0, capacity=1 << 16):
+        scores = np.zeros(3, dtype=np.float64)
+        tokens = np.zeros(capacity, dtype=np.int32)
+        words = np.zeros(capacity, dtype=np.int32)
+        ln = C.c_int32(0)
+        self.L.check(self.L.lib.fltx_result_best(self.h, b, look_back, _ptr(scores), _ptr(tokens),
+                                                 _ptr(words), capacity, C.addressof(ln)))
+        n = ln.value
+        return Hyp(scores[0], scores[1], scores[2], tokens[:n].copy(), words[:n].copy())
+
+    def stats(self):
+        fr, by = C.c_int64(0), C.c_int64(0)
+        th, lds = C.c_int32(0), C.c_int32(0)
+        self.L.check(self.L.lib.fltx_decoder_stats(self.h, C.addressof(fr), C.addressof(by),
+                                                   C.addressof(th), C.addressof(lds)))
+        return {"frames": fr.value, "algorithmic_bytes": by.value, "threads_per_utt": th.value,
+                "lds_bytes": lds.value}
+
+    def timing(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self.L.check(self.L.lib.fltx_decoder_timing(self.h, C.addressof(a), C.addressof(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            self.L.lib.fltx_decoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_options(beam_size, beam_size_token, beam_threshold=25.0, lm_weight=0.0, word_score=0.0,
+                 unk_score=-float("inf"), sil_score=0.0, log_add=False, criterion="ctc"):
+    crit = CRITERION[criterion] if isinstance(criterion, str) else int(criterion)
+    return Options(beam_size, beam_size_token, beam_threshold, lm_weight, word_score, unk_score, sil_score,
+                   int(bool(log_add)), crit)

@@ -1,0 +1,1369 @@
+/*
+ * fltx_api.cpp -- host side of the C ABI declared in include/fltx.h:
+ * HBM allocation and layout, table flattening (n-gram LM, trie), kernel
+ * launches, result retrieval.  Compiled by hipcc (-x hip) into
+ * text_amd/lib/libfltx.so together with the kernels of fltx_kernels.h.
+ *
+ * There is no CPU decode path in this file: every decode launches the HIP
+ * kernels and fails with FLTX_ERR_HIP if that is impossible.  (The FLTX_EMU
+ * branches below exist only for tests/emu/libfltx_emu.so, a host-thread
+ * emulation used to debug kernel logic; see tests/emu/hip_emu.h.)
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "fltx.h"
+#include "fltx_kernels.h"
+
+using namespace fltx;
+
+/* ------------------------------------------------------------------------ */
+/* device back-end                                                           */
+/* ------------------------------------------------------------------------ */
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#ifdef FLTX_EMU
+typedef void* Stream;
+int devCount() { return 1; }
+int devMalloc(void** p, size_t n) {
+  *p = calloc(1, n ? n : 1);
+  return *p ? 0 : 1;
+}
+void devFree(void* p) { free(p); }
+int devMemset(void* p, int v, size_t n, Stream) {
+  memset(p, v, n);
+  return 0;
+}
+int devCopyH2D(void* d, const void* h, size_t n, Stream) {
+  memcpy(d, h, n);
+  return 0;
+}
+int devCopyD2H(void* h, const void* d, size_t n, Stream) {
+  memcpy(h, d, n);
+  return 0;
+}
+int devSync(Stream) { return 0; }
+const char* devErr() { return "emu"; }
+constexpr size_t kMaxLds = 160 * 1024;
+#else
+typedef hipStream_t Stream;
+#define HIPCHK(x)                                                              \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess)                                                      \
+      return fail(FLTX_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_));          \
+  } while (0)
+int devMalloc(void** p, size_t n) { return hipMalloc(p, n ? n : 1) == hipSuccess ? 0 : 1; }
+void devFree(void* p) { (void)hipFree(p); }
+int devMemset(void* p, int v, size_t n, Stream s) { return hipMemsetAsync(p, v, n, s) == hipSuccess ? 0 : 1; }
+int devCopyH2D(void* d, const void* h, size_t n, Stream s) {
+  return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : 1;
+}
+int devCopyD2H(void* h, const void* d, size_t n, Stream s) {
+  if (hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) != hipSuccess) {
+    return 1;
+  }
+  return hipStreamSynchronize(s) == hipSuccess ? 0 : 1;
+}
+int devSync(Stream s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : 1; }
+const char* devErr() { return hipGetErrorString(hipGetLastError()); }
+constexpr size_t kMaxLds = 160 * 1024; /* gfx950: 160 KiB LDS per CU */
+
+__global__ void fltx_decode_kernel_lds(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  decodeUtterance(P, fltx_smem);
+}
+__global__ void fltx_decode_kernel_gws(DecodeParams P) {
+  decodeUtterance(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
+}
+__global__ void fltx_backtrace_kernel(BacktraceParams P) { backtraceUtterance(P); }
+#endif
+
+/* growable device buffer */
+struct DBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DBuf() {
+    if (p) {
+      devFree(p);
+    }
+  }
+  /* returns 0 ok; `grew` tells the caller the contents are fresh (zeroed) */
+  int ensure(size_t n, Stream s, bool zero, bool* grew = nullptr) {
+    if (grew) {
+      *grew = false;
+    }
+    if (n <= cap) {
+      return 0;
+    }
+    if (p) {
+      devSync(s);
+      devFree(p);
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = n + n / 8;
+    if (devMalloc(&p, want)) {
+      p = nullptr;
+      return 1;
+    }
+    cap = want;
+    if (zero && devMemset(p, 0, want, s)) {
+      return 1;
+    }
+    if (grew) {
+      *grew = true;
+    }
+    return 0;
+  }
+  template <class T>
+  T* as() const {
+    return (T*)p;
+  }
+};
+
+uint32_t nextPow2(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) {
+    p <<= 1;
+  }
+  return (uint32_t)p;
+}
+
+} // namespace
+
+/* ------------------------------------------------------------------------ */
+/* objects                                                                   */
+/* ------------------------------------------------------------------------ */
+struct fltx_ctx {
+  int device = 0;
+  Stream stream = nullptr;
+  bool ownStream = false;
+};
+
+struct fltx_lm {
+  fltx_ctx* ctx = nullptr;
+  int kind = 0; /* 0 zero, 1 ngram */
+  int order = 0;
+  int32_t bos = 0, eos = 0, unk = 0, nUsr = 0;
+  uint32_t mask = 0;
+  DBuf tab, backoff, usrToLm;
+  /* host copies for fltx_lm_score_sequence */
+  std::vector<NgramSlot> hTab;
+  std::vector<float> hBackoff;
+  std::vector<int32_t> hUsr;
+};
+
+struct fltx_trie {
+  fltx_ctx* ctx = nullptr;
+  int64_t nNodes = 0;
+  int32_t nTokens = 0;
+  DBuf child, info, labels;
+};
+
+struct fltx_decoder {
+  fltx_ctx* ctx = nullptr;
+  int kind = 0;
+  fltx_options opt{};
+  const fltx_trie* trie = nullptr;
+  const fltx_lm* lm = nullptr;
+  int sil = 0, blank = 0, unk = 0, isLmToken = 0;
+  int nTrans = 0;
+  DBuf transitions;
+  /* tunables */
+  int threads = 256;
+  int forceGlobalWs = 0;
+  /* batch state */
+  int B = 0, N = 0;
+  bool streaming = false, ended = false, haveResults = false;
+  int maxFrames = 0;
+  std::vector<int32_t> T;       /* frames given in the last step */
+  std::vector<int32_t> frames;  /* host mirror of uttFrame after sync */
+  std::vector<int64_t> histOff; /* records */
+  int64_t histRecords = 0;
+  uint32_t stateCap = 0;
+  uint32_t epoch = 0;
+  int CAP = 0, HS = 0, NB = 0;
+  size_t wsBytes = 0;
+  bool wsInLds = true;
+  /* device buffers */
+  DBuf emis, emOff, stepT, histOffD, histPT, histW, stateTab, stateCtx;
+  DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
+  DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
+  DBuf tokens, words;
+  /* host caches of the last results */
+  std::vector<int32_t> hN, hFrame, hStatus;
+  bool resultsSynced = false;
+  bool backtraced = false;
+  int64_t statFrames = 0, statBytes = 0;
+#ifndef FLTX_EMU
+  /* HIP events on the launch stream bracketing the two kernels of the last
+   * fltx_decode_batch (bench.py's roofline leg reads them) */
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+#endif
+  bool timed = false;
+};
+
+/* ------------------------------------------------------------------------ */
+extern "C" {
+
+const char* fltx_last_error(void) { return g_err.c_str(); }
+/* internal: lets the other translation units record an error message */
+__attribute__((visibility("hidden"))) int fltx_set_error_(int code, const char* msg) {
+  g_err = msg ? msg : "";
+  return code;
+}
+const char* fltx_version(void) {
+#ifdef FLTX_EMU
+  return "fltx 0.1 (host-thread emulation, tests only)";
+#else
+  return "fltx 0.1 (HIP gfx950)";
+#endif
+}
+
+int fltx_ctx_create(int device, void* stream, fltx_ctx** out) {
+  if (!out) {
+    return fail(FLTX_ERR_INVALID, "fltx_ctx_create: out is null");
+  }
+  auto* c = new fltx_ctx();
+#ifndef FLTX_EMU
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    delete c;
+    return fail(FLTX_ERR_HIP, "fltx_ctx_create: no HIP device available (this library has no CPU path)");
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) {
+      delete c;
+      return fail(FLTX_ERR_HIP, "hipGetDevice failed");
+    }
+  }
+  if (device >= n) {
+    delete c;
+    return fail(FLTX_ERR_INVALID, "fltx_ctx_create: device %d out of range (%d devices)", device, n);
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    delete c;
+    return fail(FLTX_ERR_HIP, "hipSetDevice(%d) failed", device);
+  }
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return fail(FLTX_ERR_HIP, "hipStreamCreate failed");
+    }
+    c->ownStream = true;
+  }
+#else
+  (void)device;
+  (void)stream;
+#endif
+  *out = c;
+  return FLTX_OK;
+}
+
+int fltx_ctx_destroy(fltx_ctx* ctx) {
+  if (!ctx) {
+    return FLTX_OK;
+  }
+#ifndef FLTX_EMU
+  if (ctx->ownStream) {
+    (void)hipStreamDestroy(ctx->stream);
+  }
+#endif
+  delete ctx;
+  return FLTX_OK;
+}
+
+int fltx_ctx_synchronize(fltx_ctx* ctx) {
+  if (!ctx) {
+    return fail(FLTX_ERR_INVALID, "null ctx");
+  }
+  return devSync(ctx->stream) ? fail(FLTX_ERR_HIP, "stream synchronize failed: %s", devErr()) : FLTX_OK;
+}
+
+void* fltx_ctx_stream(fltx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+/* ---- LM ------------------------------------------------------------------ */
+int fltx_lm_zero_create(fltx_ctx* ctx, fltx_lm** out) {
+  if (!ctx || !out) {
+    return fail(FLTX_ERR_INVALID, "fltx_lm_zero_create: null argument");
+  }
+  auto* lm = new fltx_lm();
+  lm->ctx = ctx;
+  lm->kind = 0;
+  *out = lm;
+  return FLTX_OK;
+}
+
+int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t nNgrams, const int32_t* ngOrder,
+                         const int32_t* ngWords, const float* prob, const float* backoff,
+                         const int32_t* usrToLm, int32_t nUsr, int32_t bos, int32_t eos,
+                         int32_t unk, fltx_lm** out) {
+  if (!ctx || !out || !ngOrder || !ngWords || !prob || !backoff || nNgrams <= 0) {
+    return fail(FLTX_ERR_INVALID, "fltx_lm_ngram_create: null argument");
+  }
+  if (order < 1 || order > kMaxNgramOrder) {
+    return fail(FLTX_ERR_UNSUPPORTED, "n-gram order %d outside 1..%d (FL_TEXT_KENLM_MAX_ORDER)", order,
+                kMaxNgramOrder);
+  }
+  /* forward trie of n-grams: node id per n-gram, (context node, word) -> node */
+  struct HostNode {
+    float prob;
+    float backoff;
+    bool phantom;
+  };
+  std::vector<HostNode> nodes(1, HostNode{0, 0, true}); /* node 0 = empty context */
+  std::unordered_map<uint64_t, uint32_t> kids;
+  kids.reserve((size_t)nNgrams * 2);
+  std::vector<uint32_t> entCtx, entWord, entNode;
+  auto childOf = [&](uint32_t ctxNode, uint32_t word, bool create) -> uint32_t {
+    uint64_t k = ((uint64_t)ctxNode << 32) | word;
+    auto it = kids.find(k);
+    if (it != kids.end()) {
+      return it->second;
+    }
+    if (!create) {
+      return 0;
+    }
+    uint32_t id = (uint32_t)nodes.size();
+    nodes.push_back(HostNode{0, 0, true});
+    kids.emplace(k, id);
+    entCtx.push_back(ctxNode);
+    entWord.push_back(word);
+    entNode.push_back(id);
+    return id;
+  };
+  for (int64_t i = 0; i < nNgrams; ++i) {
+    int k = ngOrder[i];
+    if (k < 1 || k > order) {
+      return fail(FLTX_ERR_INVALID, "n-gram %lld has order %d", (long long)i, k);
+    }
+    const int32_t* wds = ngWords + i * order;
+    uint32_t node = 0;
+    for (int j = 0; j < k; ++j) {
+      if (wds[j] < 0) {
+        return fail(FLTX_ERR_INVALID, "n-gram %lld has a negative word id", (long long)i);
+      }
+      node = childOf(node, (uint32_t)wds[j], true); /* missing prefixes become phantoms */
+    }
+    nodes[node].prob = prob[i];
+    nodes[node].backoff = backoff[i];
+    nodes[node].phantom = false;
+  }
+  if (nodes.size() >= 0x7FFFFFFFull) {
+    return fail(FLTX_ERR_UNSUPPORTED, "too many n-grams");
+  }
+  auto* lm = new fltx_lm();
+  lm->ctx = ctx;
+  lm->kind = 1;
+  lm->order = order;
+  lm->bos = bos;
+  lm->eos = eos;
+  lm->unk = unk;
+  lm->nUsr = nUsr;
+  uint32_t cap = nextPow2((uint64_t)entNode.size() * 2 + 16);
+  lm->mask = cap - 1;
+  lm->hTab.assign(cap, NgramSlot{0, kEmpty, 0, 0.0f});
+  for (size_t e = 0; e < entNode.size(); ++e) {
+    uint32_t s = hashKey(entCtx[e], entWord[e], 0x5bd1e995u, 0) & lm->mask;
+    while (lm->hTab[s].word != kEmpty) {
+      s = (s + 1) & lm->mask;
+    }
+    const HostNode& nd = nodes[entNode[e]];
+    lm->hTab[s] = NgramSlot{entCtx[e], entWord[e], entNode[e] | (nd.phantom ? kPhantomNode : 0u), nd.prob};
+  }
+  lm->hBackoff.resize(nodes.size());
+  for (size_t i = 0; i < nodes.size(); ++i) {
+    lm->hBackoff[i] = nodes[i].phantom ? 0.0f : nodes[i].backoff;
+  }
+  lm->hUsr.assign(usrToLm, usrToLm + (usrToLm ? nUsr : 0));
+  Stream st = ctx->stream;
+  if (lm->tab.ensure(sizeof(NgramSlot) * cap, st, false) ||
+      lm->backoff.ensure(sizeof(float) * nodes.size(), st, false) ||
+      lm->usrToLm.ensure(sizeof(int32_t) * std::max<size_t>(1, lm->hUsr.size()), st, false)) {
+    delete lm;
+    return fail(FLTX_ERR_OOM, "n-gram tables: device allocation failed");
+  }
+  if (devCopyH2D(lm->tab.p, lm->hTab.data(), sizeof(NgramSlot) * cap, st) ||
+      devCopyH2D(lm->backoff.p, lm->hBackoff.data(), sizeof(float) * nodes.size(), st) ||
+      (!lm->hUsr.empty() && devCopyH2D(lm->usrToLm.p, lm->hUsr.data(), sizeof(int32_t) * lm->hUsr.size(), st)) ||
+      devSync(st)) {
+    delete lm;
+    return fail(FLTX_ERR_HIP, "n-gram tables: upload failed");
+  }
+  *out = lm;
+  return FLTX_OK;
+}
+
+int fltx_lm_destroy(fltx_lm* lm) {
+  delete lm;
+  return FLTX_OK;
+}
+
+/* host walk over the same flat tables the kernels use (known-answer checks of
+ * the table builder; decode-time scoring always happens on the device) */
+int fltx_lm_score_sequence(fltx_lm* lm, const int32_t* usrWords, int32_t n, int32_t withFinish,
+                           float* perWord, float* total) {
+  if (!lm || (!usrWords && n > 0)) {
+    return fail(FLTX_ERR_INVALID, "fltx_lm_score_sequence: null argument");
+  }
+  float tot = 0;
+  if (lm->kind == 0) {
+    for (int i = 0; i < n; ++i) {
+      if (perWord) {
+        perWord[i] = 0.0f;
+      }
+    }
+    if (total) {
+      *total = 0;
+    }
+    return FLTX_OK;
+  }
+  const int L = lm->order - 1;
+  auto find = [&](uint32_t ctx, uint32_t word, uint32_t& node, float& pr) {
+    uint32_t s = hashKey(ctx, word, 0x5bd1e995u, 0) & lm->mask;
+    for (;;) {
+      const NgramSlot& e = lm->hTab[s];
+      if (e.word == kEmpty) {
+        return false;
+      }
+      if (e.ctx == ctx && e.word == word) {
+        node = e.node;
+        pr = e.prob;
+        return true;
+      }
+      s = (s + 1) & lm->mask;
+    }
+  };
+  std::vector<int32_t> ctx(std::max(L, 1), 0), nxt(std::max(L, 1), 0);
+  {
+    uint32_t nd;
+    float pr;
+    if (L > 0 && find(0, (uint32_t)lm->bos, nd, pr)) {
+      ctx[0] = (int32_t)(nd & ~kPhantomNode);
+    }
+  }
+  auto score = [&](uint32_t word) {
+    std::vector<uint32_t> nodes(L + 1, 0);
+    std::vector<char> found(L + 1, 0);
+    float prob = 0;
+    int longest = -1;
+    for (int k = 0; k <= L; ++k) {
+      uint32_t c = k == 0 ? 0u : (uint32_t)ctx[k - 1];
+      if (k > 0 && c == 0) {
+        continue;
+      }
+      float pr;
+      if (find(c, word, nodes[k], pr)) {
+        found[k] = 1;
+        if (!(nodes[k] & kPhantomNode)) {
+          longest = k;
+          prob = pr;
+        }
+        nodes[k] &= ~kPhantomNode;
+      }
+    }
+    if (longest < 0) {
+      uint32_t nd = 0;
+      if (!find(0, (uint32_t)lm->unk, nd, prob)) {
+        prob = -100.0f;
+      }
+      nodes[0] = nd & ~kPhantomNode;
+      found[0] = 1;
+      longest = 0;
+    }
+    for (int j = longest + 1; j <= L; ++j) {
+      uint32_t c = (uint32_t)ctx[j - 1];
+      if (c != 0) {
+        prob += lm->hBackoff[c];
+      }
+    }
+    for (int j = 0; j < L; ++j) {
+      nxt[j] = (j <= longest && found[j]) ? (int32_t)nodes[j] : 0;
+    }
+    ctx = nxt;
+    return prob;
+  };
+  for (int i = 0; i < n; ++i) {
+    int u = usrWords[i];
+    if (u < 0 || u >= lm->nUsr) {
+      return fail(FLTX_ERR_RANGE, "[ngram LM] Invalid user token index: %d", u); /* KenLM.cpp:66-69 */
+    }
+    float s = score((uint32_t)lm->hUsr[u]);
+    if (perWord) {
+      perWord[i] = s;
+    }
+    tot += s;
+  }
+  if (withFinish) {
+    tot += score((uint32_t)lm->eos);
+  }
+  if (total) {
+    *total = tot;
+  }
+  return FLTX_OK;
+}
+
+/* ---- trie ---------------------------------------------------------------- */
+int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32_t* child,
+                     const float* maxScore, const int32_t* labelOff, const int32_t* labels,
+                     fltx_trie** out) {
+  if (!ctx || !out || !child || !maxScore || !labelOff || nNodes <= 0 || nTokens <= 0) {
+    return fail(FLTX_ERR_INVALID, "fltx_trie_create: null or empty argument");
+  }
+  if (nNodes >= (1ll << 31)) {
+    return fail(FLTX_ERR_UNSUPPORTED, "trie too large");
+  }
+  std::vector<TrieNodeInfo> info((size_t)nNodes);
+  for (int64_t i = 0; i < nNodes; ++i) {
+    int nc = 0;
+    for (int t = 0; t < nTokens; ++t) {
+      int32_t c = child[i * nTokens + t];
+      if (c >= nNodes) {
+        return fail(FLTX_ERR_RANGE, "trie child index %d out of range", c);
+      }
+      nc += c >= 0;
+    }
+    int nl = labelOff[i + 1] - labelOff[i];
+    if (nl < 0 || nl > 6) {
+      return fail(FLTX_ERR_INVALID, "trie node %lld has %d labels (kTrieMaxLabel = 6)", (long long)i, nl);
+    }
+    info[i] = TrieNodeInfo{maxScore[i], labelOff[i], nl, nc};
+  }
+  auto* t = new fltx_trie();
+  t->ctx = ctx;
+  t->nNodes = nNodes;
+  t->nTokens = nTokens;
+  Stream st = ctx->stream;
+  size_t nLab = (size_t)labelOff[nNodes];
+  if (t->child.ensure(sizeof(int32_t) * (size_t)nNodes * nTokens, st, false) ||
+      t->info.ensure(sizeof(TrieNodeInfo) * (size_t)nNodes, st, false) ||
+      t->labels.ensure(sizeof(int32_t) * std::max<size_t>(1, nLab), st, false)) {
+    delete t;
+    return fail(FLTX_ERR_OOM, "trie: device allocation failed");
+  }
+  if (devCopyH2D(t->child.p, child, sizeof(int32_t) * (size_t)nNodes * nTokens, st) ||
+      devCopyH2D(t->info.p, info.data(), sizeof(TrieNodeInfo) * (size_t)nNodes, st) ||
+      (nLab && devCopyH2D(t->labels.p, labels, sizeof(int32_t) * nLab, st)) || devSync(st)) {
+    delete t;
+    return fail(FLTX_ERR_HIP, "trie: upload failed");
+  }
+  *out = t;
+  return FLTX_OK;
+}
+
+int fltx_trie_destroy(fltx_trie* t) {
+  delete t;
+  return FLTX_OK;
+}
+
+/* ---- decoder ------------------------------------------------------------- */
+int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, const fltx_trie* trie,
+                        const fltx_lm* lm, int32_t sil, int32_t blank, int32_t unk,
+                        const float* transitions, int32_t nTrans, int32_t isLmToken,
+                        fltx_decoder** out) {
+  if (!ctx || !opt || !lm || !out) {
+    return fail(FLTX_ERR_INVALID, "fltx_decoder_create: null argument");
+  }
+  if (kind != FLTX_DECODER_LEXFREE && kind != FLTX_DECODER_LEXICON) {
+    return fail(FLTX_ERR_INVALID, "unknown decoder kind %d", kind);
+  }
+  if (kind == FLTX_DECODER_LEXICON && !trie) {
+    return fail(FLTX_ERR_INVALID, "lexicon decoder needs a trie");
+  }
+  if (opt->beam_size < 1 || opt->beam_size_token < 1) {
+    return fail(FLTX_ERR_INVALID, "beam_size and beam_size_token must be >= 1");
+  }
+  if (opt->beam_size > 0x7FFFFF) {
+    return fail(FLTX_ERR_UNSUPPORTED, "beam_size too large");
+  }
+  if (opt->criterion != FLTX_CRITERION_ASG && opt->criterion != FLTX_CRITERION_CTC) {
+    return fail(FLTX_ERR_UNSUPPORTED, "criterion %d not supported (ASG, CTC only)", opt->criterion);
+  }
+  auto* d = new fltx_decoder();
+  d->ctx = ctx;
+  d->kind = kind;
+  d->opt = *opt;
+  d->trie = trie;
+  d->lm = lm;
+  d->sil = sil;
+  d->blank = blank;
+  d->unk = unk;
+  d->isLmToken = isLmToken ? 1 : 0;
+  if (transitions && nTrans > 0) {
+    d->nTrans = nTrans;
+    if (d->transitions.ensure(sizeof(float) * (size_t)nTrans, ctx->stream, false) ||
+        devCopyH2D(d->transitions.p, transitions, sizeof(float) * (size_t)nTrans, ctx->stream) ||
+        devSync(ctx->stream)) {
+      delete d;
+      return fail(FLTX_ERR_HIP, "transitions upload failed");
+    }
+  }
+  *out = d;
+  return FLTX_OK;
+}
+
+int fltx_decoder_destroy(fltx_decoder* d) {
+  if (d) {
+    devSync(d->ctx->stream);
+#ifndef FLTX_EMU
+    for (int i = 0; i < 3; ++i) {
+      if (d->ev[i]) {
+        (void)hipEventDestroy(d->ev[i]);
+      }
+    }
+#endif
+  }
+  delete d;
+  return FLTX_OK;
+}
+
+int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
+  if (!d || !key) {
+    return fail(FLTX_ERR_INVALID, "null argument");
+  }
+  if (!strcmp(key, "threads")) {
+    if (value < 64 || value > 1024 || (value & 63)) {
+      return fail(FLTX_ERR_INVALID, "threads must be a multiple of 64 in 64..1024");
+    }
+    d->threads = (int)value;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "force_global_ws")) {
+    d->forceGlobalWs = value != 0;
+    return FLTX_OK;
+  }
+  return fail(FLTX_ERR_INVALID, "unknown tunable '%s'", key);
+}
+
+} /* extern "C" */
+
+namespace {
+
+/* geometry + buffers for B streams of up to maxFrames frames (plus seed and
+ * decodeEnd slots) */
+int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstCaseCap) {
+  Stream st = d->ctx->stream;
+  const int K = d->opt.beam_size;
+  if (d->kind == FLTX_DECODER_LEXICON && d->trie->nTokens != N) {
+    return fail(FLTX_ERR_INVALID, "N = %d but the trie was built for %d tokens", N, d->trie->nTokens);
+  }
+  if (d->nTrans && d->nTrans != N * N) {
+    return fail(FLTX_ERR_INVALID, "transitions has %d entries, expected N*N = %d", d->nTrans, N * N);
+  }
+  if (d->opt.criterion == FLTX_CRITERION_ASG && !d->nTrans) {
+    return fail(FLTX_ERR_INVALID, "ASG criterion needs N*N transitions");
+  }
+  if (d->sil < 0 || d->sil >= N) {
+    return fail(FLTX_ERR_RANGE, "sil index %d outside [0, %d)", d->sil, N);
+  }
+  if (d->opt.criterion == FLTX_CRITERION_CTC && (d->blank < 0 || d->blank >= N)) {
+    return fail(FLTX_ERR_RANGE, "blank index %d outside [0, %d)", d->blank, N);
+  }
+  d->B = B;
+  d->N = N;
+  d->histOff.resize(B + 1);
+  int64_t off = 0;
+  int maxT = 0;
+  for (int b = 0; b < B; ++b) {
+    if (Tmax[b] < 0) {
+      return fail(FLTX_ERR_INVALID, "T[%d] = %d is negative", b, Tmax[b]);
+    }
+    d->histOff[b] = off;
+    off += (int64_t)(Tmax[b] + 2) * K;
+    maxT = std::max(maxT, Tmax[b]);
+  }
+  d->histOff[B] = off;
+  d->histRecords = off;
+  uint64_t wantStates = 2ull * ((uint64_t)K * (uint64_t)(maxT + 2) + 2);
+  uint32_t cap = nextPow2(std::max<uint64_t>(wantStates, 1024));
+  if (cap > (1u << 24)) {
+    return fail(FLTX_ERR_UNSUPPORTED, "K * T = %llu exceeds the 2^23 LM states per utterance this build indexes",
+                (unsigned long long)K * (maxT + 2));
+  }
+  /* candidate capacity */
+  const int nTok = std::min(d->opt.beam_size_token, N);
+  int64_t worst = d->kind == FLTX_DECODER_LEXFREE ? (int64_t)K * nTok : (int64_t)K * ((int64_t)nTok * 8 + 2);
+  worst = std::max<int64_t>(worst, K);
+  int64_t capC = worst;
+  d->NB = 1024;
+  Ws tmp;
+  auto bytesFor = [&](int64_t c) {
+    int hs = (int)nextPow2((uint64_t)c * 2);
+    return carveWs(tmp, nullptr, K, (int)c, std::max(hs, 64), d->NB, N);
+  };
+  bool lds = !d->forceGlobalWs;
+  if (lds && bytesFor(capC) > kMaxLds) {
+    if (d->kind == FLTX_DECODER_LEXICON && !forceWorstCaseCap) {
+      /* trie fan-out is sparse: size for the LDS and retry in HBM on overflow */
+      int64_t c = capC;
+      while (c > K && bytesFor(c) > kMaxLds) {
+        c = c * 3 / 4;
+      }
+      if (c >= std::max<int64_t>(K * 4, 64) && bytesFor(c) <= kMaxLds) {
+        capC = c;
+      } else {
+        lds = false;
+      }
+    } else {
+      lds = false;
+    }
+  }
+  d->CAP = (int)capC;
+  d->HS = std::max((int)nextPow2((uint64_t)capC * 2), 64);
+  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N);
+  d->wsInLds = lds;
+  /* buffers */
+  bool grewTab = false;
+  int rc = 0;
+  rc |= d->histOffD.ensure(sizeof(int64_t) * (B + 1), st, false);
+  rc |= d->histPT.ensure(sizeof(int2) * (size_t)off, st, false);
+  if (d->kind == FLTX_DECODER_LEXICON) {
+    rc |= d->histW.ensure(sizeof(int32_t) * (size_t)off, st, false);
+  }
+  if (cap != d->stateCap) {
+    /* geometry changed: stale keys would hash to other slots; start clean */
+    d->stateTab.cap = 0;
+    if (d->stateTab.p) {
+      devSync(st);
+      devFree(d->stateTab.p);
+      d->stateTab.p = nullptr;
+    }
+    d->stateCap = cap;
+    d->epoch = 0;
+  }
+  rc |= d->stateTab.ensure(sizeof(unsigned long long) * (size_t)B * cap, st, true, &grewTab);
+  if (grewTab) {
+    d->epoch = 0;
+  }
+  if (d->lm->kind == 1) {
+    rc |= d->stateCtx.ensure(sizeof(int32_t) * (size_t)B * cap * std::max(1, d->lm->order - 1), st, false);
+  }
+  size_t bk = (size_t)B * K;
+  rc |= d->gScore.ensure(8 * bk, st, false) | d->gAm.ensure(8 * bk, st, false) | d->gLm.ensure(8 * bk, st, false);
+  rc |= d->gState.ensure(4 * bk, st, false) | d->gSPar.ensure(4 * bk, st, false) | d->gSEdge.ensure(4 * bk, st, false);
+  rc |= d->gLex.ensure(4 * bk, st, false) | d->gTokPb.ensure(4 * bk, st, false);
+  rc |= d->uttNBeam.ensure(4 * (size_t)B, st, true) | d->uttFrame.ensure(4 * (size_t)B, st, true);
+  rc |= d->uttTotal.ensure(4 * (size_t)B, st, true) | d->uttStatus.ensure(4 * (size_t)B, st, true);
+  rc |= d->outN.ensure(4 * (size_t)B, st, true) | d->outScores.ensure(8 * bk * 3, st, false);
+  rc |= d->emOff.ensure(sizeof(int64_t) * (size_t)B, st, false) | d->stepT.ensure(4 * (size_t)B, st, false);
+  if (!lds) {
+    rc |= d->gws.ensure(d->wsBytes * (size_t)B, st, false);
+  }
+  if (rc) {
+    return fail(FLTX_ERR_OOM, "device allocation failed (B=%d K=%d T<=%d)", B, K, maxT);
+  }
+  if (devCopyH2D(d->histOffD.p, d->histOff.data(), sizeof(int64_t) * (B + 1), st)) {
+    return fail(FLTX_ERR_HIP, "upload failed");
+  }
+  return FLTX_OK;
+}
+
+void fillParams(fltx_decoder* d, DecodeParams& P) {
+  memset(&P, 0, sizeof(P));
+  P.K = d->opt.beam_size;
+  P.Kt = d->opt.beam_size_token;
+  P.beamThreshold = d->opt.beam_threshold;
+  P.lmWeight = d->opt.lm_weight;
+  P.wordScore = d->opt.word_score;
+  P.unkScore = d->opt.unk_score;
+  P.silScore = d->opt.sil_score;
+  P.logAdd = d->opt.log_add;
+  P.criterion = d->opt.criterion;
+  P.sil = d->sil;
+  P.blank = d->blank;
+  P.unk = d->unk;
+  P.isLmToken = d->isLmToken;
+  P.kind = d->kind;
+  P.N = d->N;
+  P.transitions = d->nTrans ? d->transitions.as<float>() : nullptr;
+  if (d->trie) {
+    P.trieChild = d->trie->child.as<int32_t>();
+    P.trieInfo = d->trie->info.as<TrieNodeInfo>();
+    P.trieLabels = d->trie->labels.as<int32_t>();
+  }
+  P.lmKind = d->lm->kind;
+  P.lmOrder = d->lm->order;
+  P.ngTab = d->lm->tab.as<NgramSlot>();
+  P.ngMask = d->lm->mask;
+  P.ngBackoff = d->lm->backoff.as<float>();
+  P.usrToLm = d->lm->usrToLm.as<int32_t>();
+  P.nUsr = d->lm->nUsr;
+  P.lmBos = d->lm->bos;
+  P.lmEos = d->lm->eos;
+  P.lmUnk = d->lm->unk;
+  P.stateCtx = d->stateCtx.as<int32_t>();
+  P.emOff = d->emOff.as<int64_t>();
+  P.stepT = d->stepT.as<int32_t>();
+  P.uttNBeam = d->uttNBeam.as<int32_t>();
+  P.uttFrame = d->uttFrame.as<int32_t>();
+  P.uttTotal = d->uttTotal.as<int32_t>();
+  P.uttStatus = d->uttStatus.as<int32_t>();
+  P.gScore = d->gScore.as<double>();
+  P.gAm = d->gAm.as<double>();
+  P.gLm = d->gLm.as<double>();
+  P.gState = d->gState.as<uint32_t>();
+  P.gSPar = d->gSPar.as<uint32_t>();
+  P.gSEdge = d->gSEdge.as<int32_t>();
+  P.gLex = d->gLex.as<uint32_t>();
+  P.gTokPb = d->gTokPb.as<uint32_t>();
+  P.histPT = d->histPT.as<int2>();
+  P.histW = d->histW.as<int32_t>();
+  P.histOff = d->histOffD.as<int64_t>();
+  P.stateTab = d->stateTab.as<unsigned long long>();
+  P.stateCap = d->stateCap;
+  P.epoch = d->epoch;
+  P.CAP = d->CAP;
+  P.HS = d->HS;
+  P.NB = d->NB;
+  P.gws = d->wsInLds ? nullptr : d->gws.as<char>();
+  P.gwsStride = (int64_t)d->wsBytes;
+  P.outN = d->outN.as<int32_t>();
+  P.outScores = d->outScores.as<double>();
+}
+
+int launchDecode(fltx_decoder* d, const DecodeParams& P) {
+  const int W = d->threads;
+#ifdef FLTX_EMU
+  const DecodeParams* pp = &P;
+  emuLaunch(d->B, W, d->wsInLds ? d->wsBytes : 16, [pp](char* smem) {
+    decodeUtterance(*pp, pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem);
+  });
+  return FLTX_OK;
+#else
+  for (int i = 0; i < 3; ++i) {
+    if (!d->ev[i]) {
+      HIPCHK(hipEventCreate(&d->ev[i]));
+    }
+  }
+  HIPCHK(hipEventRecord(d->ev[0], d->ctx->stream));
+  if (d->wsInLds) {
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lds,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));
+    hipLaunchKernelGGL(fltx_decode_kernel_lds, dim3(d->B), dim3(W), d->wsBytes, d->ctx->stream, P);
+  } else {
+    hipLaunchKernelGGL(fltx_decode_kernel_gws, dim3(d->B), dim3(W), 0, d->ctx->stream, P);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(d->ev[1], d->ctx->stream));
+  d->timed = false;
+  return FLTX_OK;
+#endif
+}
+
+int bumpEpoch(fltx_decoder* d) {
+  if (d->epoch >= 65535u) {
+    if (devMemset(d->stateTab.p, 0, sizeof(unsigned long long) * (size_t)d->B * d->stateCap, d->ctx->stream)) {
+      return fail(FLTX_ERR_HIP, "state table reset failed");
+    }
+    d->epoch = 0;
+  }
+  d->epoch += 1;
+  return FLTX_OK;
+}
+
+int uploadStep(fltx_decoder* d, const float* emissions, int onDevice, const int64_t* offsets,
+               const int32_t* T, DecodeParams& P) {
+  Stream st = d->ctx->stream;
+  const int B = d->B, N = d->N;
+  std::vector<int64_t> offs(B, 0);
+  int64_t maxEnd = 0;
+  for (int b = 0; b < B; ++b) {
+    offs[b] = offsets ? offsets[b] : 0;
+    if (offs[b] < 0) {
+      return fail(FLTX_ERR_INVALID, "offsets[%d] is negative", b);
+    }
+    maxEnd = std::max<int64_t>(maxEnd, offs[b] + (int64_t)T[b] * N);
+  }
+  if (maxEnd > 0 && !emissions) {
+    return fail(FLTX_ERR_INVALID, "emissions is null");
+  }
+  if (onDevice) {
+    P.emissions = emissions;
+  } else {
+    if (d->emis.ensure(sizeof(float) * (size_t)std::max<int64_t>(maxEnd, 1), st, false)) {
+      return fail(FLTX_ERR_OOM, "emissions staging allocation failed");
+    }
+    if (maxEnd > 0 && devCopyH2D(d->emis.p, emissions, sizeof(float) * (size_t)maxEnd, st)) {
+      return fail(FLTX_ERR_HIP, "emissions upload failed");
+    }
+    P.emissions = d->emis.as<float>();
+  }
+  if (devCopyH2D(d->emOff.p, offs.data(), sizeof(int64_t) * B, st) ||
+      devCopyH2D(d->stepT.p, T, sizeof(int32_t) * B, st)) {
+    return fail(FLTX_ERR_HIP, "batch descriptor upload failed");
+  }
+#ifndef FLTX_EMU
+  /* the H2D copies above read pageable host memory that only lives for this
+   * call (offs); make sure they have been consumed */
+  if (devSync(st)) {
+    return fail(FLTX_ERR_HIP, "stream synchronize failed");
+  }
+#endif
+  return FLTX_OK;
+}
+
+int syncResults(fltx_decoder* d) {
+  if (d->resultsSynced) {
+    return FLTX_OK;
+  }
+  Stream st = d->ctx->stream;
+  const int B = d->B;
+  d->hN.resize(B);
+  d->hFrame.resize(B);
+  d->hStatus.resize(B);
+  if (devCopyD2H(d->hN.data(), d->uttNBeam.p, 4 * (size_t)B, st) ||
+      devCopyD2H(d->hFrame.data(), d->uttFrame.p, 4 * (size_t)B, st) ||
+      devCopyD2H(d->hStatus.data(), d->uttStatus.p, 4 * (size_t)B, st)) {
+    return fail(FLTX_ERR_HIP, "result copy failed: %s", devErr());
+  }
+  d->resultsSynced = true;
+  return FLTX_OK;
+}
+
+int launchBacktrace(fltx_decoder* d) {
+  Stream st = d->ctx->stream;
+  if (d->tokens.ensure(4 * (size_t)std::max<int64_t>(d->histRecords, 1), st, false)) {
+    return fail(FLTX_ERR_OOM, "token buffer allocation failed");
+  }
+  if (d->kind == FLTX_DECODER_LEXICON &&
+      d->words.ensure(4 * (size_t)std::max<int64_t>(d->histRecords, 1), st, false)) {
+    return fail(FLTX_ERR_OOM, "word buffer allocation failed");
+  }
+  BacktraceParams Q;
+  memset(&Q, 0, sizeof(Q));
+  Q.K = d->opt.beam_size;
+  Q.kind = d->kind;
+  Q.histPT = d->histPT.as<int2>();
+  Q.histW = d->histW.as<int32_t>();
+  Q.histOff = d->histOffD.as<int64_t>();
+  Q.uttFrame = d->uttFrame.as<int32_t>();
+  Q.uttNBeam = d->uttNBeam.as<int32_t>();
+  Q.tokOff = d->histOffD.as<int64_t>();
+  Q.tokens = d->tokens.as<int32_t>();
+  Q.words = d->kind == FLTX_DECODER_LEXICON ? d->words.as<int32_t>() : nullptr;
+  Q.nbest = 0;
+#ifdef FLTX_EMU
+  const BacktraceParams* qq = &Q;
+  emuLaunch(d->B, 64, 16, [qq](char*) { backtraceUtterance(*qq); });
+#else
+  hipLaunchKernelGGL(fltx_backtrace_kernel, dim3(d->B), dim3(64), 0, st, Q);
+  HIPCHK(hipGetLastError());
+  if (d->ev[2]) {
+    HIPCHK(hipEventRecord(d->ev[2], st));
+    d->timed = true;
+  }
+#endif
+  d->backtraced = true;
+  return FLTX_OK;
+}
+
+void accountBytes(fltx_decoder* d, const int32_t* T) {
+  /* B_frame = 4N + 8K (+ 4*K*Kt + 8K + 4K for the
+   * lexicon decoder), epilogue 16 * H * (T + 2) with H = K as the bound */
+  const int64_t K = d->opt.beam_size, N = d->N;
+  const int64_t Kt = std::min<int64_t>(d->opt.beam_size_token, N);
+  int64_t frames = 0, bytes = 0;
+  for (int b = 0; b < d->B; ++b) {
+    frames += T[b];
+    int64_t per = 4 * N + 8 * K;
+    if (d->kind == FLTX_DECODER_LEXICON) {
+      per += 4 * K * Kt + 8 * K + 4 * K;
+    }
+    bytes += per * T[b] + 16 * K * (T[b] + 2);
+  }
+  d->statFrames = frames;
+  d->statBytes = bytes;
+}
+
+} // namespace
+
+extern "C" {
+
+int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice, const int64_t* offsets,
+                      const int32_t* T, int32_t B, int32_t N) {
+  if (!d || !T || B <= 0 || N <= 0) {
+    return fail(FLTX_ERR_INVALID, "fltx_decode_batch: bad argument");
+  }
+  d->streaming = false;
+  d->haveResults = false;
+  d->resultsSynced = false;
+  d->backtraced = false;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    int rc = prepare(d, B, N, T, attempt == 1);
+    if (rc) {
+      return rc;
+    }
+    if ((rc = bumpEpoch(d))) {
+      return rc;
+    }
+    DecodeParams P;
+    fillParams(d, P);
+    if ((rc = uploadStep(d, emissions, onDevice, offsets, T, P))) {
+      return rc;
+    }
+    P.doBegin = 1;
+    P.doEnd = 1;
+    if ((rc = launchDecode(d, P))) {
+      return rc;
+    }
+    if (d->kind == FLTX_DECODER_LEXICON && d->wsInLds && attempt == 0) {
+      /* the LDS sizing of the lexicon decoder is optimistic: check for a
+       * candidate overflow and, if any, redo the batch with an HBM workspace */
+      d->resultsSynced = false;
+      if ((rc = syncResults(d))) {
+        return rc;
+      }
+      bool overflow = false;
+      for (int b = 0; b < B; ++b) {
+        overflow |= (d->hStatus[b] & ST_CAND_OVERFLOW) != 0;
+      }
+      if (overflow) {
+        d->forceGlobalWs = 1;
+        d->resultsSynced = false;
+        continue;
+      }
+    }
+    break;
+  }
+  int rc = launchBacktrace(d);
+  if (rc) {
+    return rc;
+  }
+  d->T.assign(T, T + B);
+  accountBytes(d, T);
+  d->haveResults = true;
+  d->ended = true;
+  return FLTX_OK;
+}
+
+int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) {
+  if (!d || B <= 0 || N <= 0 || maxFrames < 0) {
+    return fail(FLTX_ERR_INVALID, "fltx_stream_begin: bad argument");
+  }
+  std::vector<int32_t> Tm(B, maxFrames);
+  int rc = prepare(d, B, N, Tm.data(), true);
+  if (rc) {
+    return rc;
+  }
+  if ((rc = bumpEpoch(d))) {
+    return rc;
+  }
+  d->maxFrames = maxFrames;
+  d->streaming = true;
+  d->ended = false;
+  d->haveResults = false;
+  d->resultsSynced = false;
+  d->backtraced = false;
+  d->frames.assign(B, 0);
+  DecodeParams P;
+  fillParams(d, P);
+  std::vector<int32_t> zeroT(B, 0);
+  if ((rc = uploadStep(d, nullptr, 1, nullptr, zeroT.data(), P))) {
+    return rc;
+  }
+  P.doBegin = 1;
+  P.doEnd = 0;
+  if ((rc = launchDecode(d, P))) {
+    return rc;
+  }
+  d->haveResults = true;
+  return FLTX_OK;
+}
+
+int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, const int64_t* offsets,
+                     const int32_t* T) {
+  if (!d || !T) {
+    return fail(FLTX_ERR_INVALID, "fltx_stream_step: bad argument");
+  }
+  if (!d->streaming || d->ended) {
+    return fail(FLTX_ERR_STATE, "fltx_stream_step: call fltx_stream_begin first");
+  }
+  for (int b = 0; b < d->B; ++b) {
+    if (T[b] < 0 || d->frames[b] + T[b] > d->maxFrames) {
+      return fail(FLTX_ERR_RANGE, "stream %d: %d buffered + %d new frames exceed max_frames %d", b,
+                  d->frames[b], T[b], d->maxFrames);
+    }
+  }
+  DecodeParams P;
+  fillParams(d, P);
+  int rc = uploadStep(d, emissions, onDevice, offsets, T, P);
+  if (rc) {
+    return rc;
+  }
+  P.doBegin = 0;
+  P.doEnd = 0;
+  if ((rc = launchDecode(d, P))) {
+    return rc;
+  }
+  for (int b = 0; b < d->B; ++b) {
+    d->frames[b] += T[b];
+  }
+  d->resultsSynced = false;
+  d->backtraced = false;
+  return FLTX_OK;
+}
+
+int fltx_stream_end(fltx_decoder* d) {
+  if (!d) {
+    return fail(FLTX_ERR_INVALID, "null decoder");
+  }
+  if (!d->streaming || d->ended) {
+    return fail(FLTX_ERR_STATE, "fltx_stream_end: no open stream");
+  }
+  DecodeParams P;
+  fillParams(d, P);
+  std::vector<int32_t> zeroT(d->B, 0);
+  int rc = uploadStep(d, nullptr, 1, nullptr, zeroT.data(), P);
+  if (rc) {
+    return rc;
+  }
+  P.doBegin = 0;
+  P.doEnd = 1;
+  if ((rc = launchDecode(d, P))) {
+    return rc;
+  }
+  d->ended = true;
+  d->resultsSynced = false;
+  d->backtraced = false;
+  return FLTX_OK;
+}
+
+int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
+  (void)lookBack;
+  if (!d) {
+    return fail(FLTX_ERR_INVALID, "null decoder");
+  }
+  return fail(FLTX_ERR_UNSUPPORTED, "fltx_stream_prune: not implemented in this round");
+}
+
+int fltx_stream_frames_in_buffer(fltx_decoder* d, int32_t b, int32_t* n) {
+  if (!d || !n || b < 0 || b >= d->B) {
+    return fail(FLTX_ERR_INVALID, "bad argument");
+  }
+  int rc = syncResults(d);
+  if (rc) {
+    return rc;
+  }
+  *n = d->hFrame[b] + 1;
+  return FLTX_OK;
+}
+
+static int checkStatus(fltx_decoder* d, int b) {
+  int s = d->hStatus[b];
+  if (s & ST_CAND_OVERFLOW) {
+    return fail(FLTX_ERR_UNSUPPORTED, "utterance %d: candidate buffer overflow (CAP=%d)", b, d->CAP);
+  }
+  if (s & ST_TABLE_FULL) {
+    return fail(FLTX_ERR_UNSUPPORTED, "utterance %d: LM-state table full (cap=%u)", b, d->stateCap);
+  }
+  if (s & ST_SELECT_FALLBACK) {
+    return fail(FLTX_ERR_UNSUPPORTED, "utterance %d: top-K select did not converge (non-finite scores?)", b);
+  }
+  return FLTX_OK;
+}
+
+int fltx_result_count(fltx_decoder* d, int32_t b, int32_t* nHyp, int32_t* length) {
+  if (!d || b < 0 || b >= d->B) {
+    return fail(FLTX_ERR_INVALID, "fltx_result_count: bad argument");
+  }
+  if (!d->haveResults) {
+    return fail(FLTX_ERR_STATE, "no decode has been run");
+  }
+  int rc = syncResults(d);
+  if (rc) {
+    return rc;
+  }
+  if ((rc = checkStatus(d, b))) {
+    return rc;
+  }
+  int ff = d->hFrame[b];
+  int n = d->hN[b];
+  /* LexiconDecoder.cpp:276-280: nothing before the first frame */
+  if (d->kind == FLTX_DECODER_LEXICON && ff < 1) {
+    n = 0;
+  }
+  if (nHyp) {
+    *nHyp = n;
+  }
+  if (length) {
+    *length = ff + 1;
+  }
+  return FLTX_OK;
+}
+
+int fltx_result_fetch(fltx_decoder* d, int32_t b, int32_t maxHyp, double* scores, int32_t* tokens,
+                      int32_t* words, int32_t* nCopied) {
+  int32_t n = 0, len = 0;
+  int rc = fltx_result_count(d, b, &n, &len);
+  if (rc) {
+    return rc;
+  }
+  n = std::min(n, maxHyp);
+  if (nCopied) {
+    *nCopied = n;
+  }
+  if (n <= 0) {
+    return FLTX_OK;
+  }
+  Stream st = d->ctx->stream;
+  const int K = d->opt.beam_size;
+  if (scores) {
+    /* beam slots are score-sorted; after decodeEnd they are the final n-best */
+    std::vector<double> sc((size_t)n), am((size_t)n), lm((size_t)n);
+    if (d->ended) {
+      if (devCopyD2H(scores, d->outScores.as<double>() + (size_t)b * K * 3, 8 * 3 * (size_t)n, st)) {
+        return fail(FLTX_ERR_HIP, "score copy failed");
+      }
+    } else {
+      if (devCopyD2H(sc.data(), d->gScore.as<double>() + (size_t)b * K, 8 * (size_t)n, st) ||
+          devCopyD2H(am.data(), d->gAm.as<double>() + (size_t)b * K, 8 * (size_t)n, st) ||
+          devCopyD2H(lm.data(), d->gLm.as<double>() + (size_t)b * K, 8 * (size_t)n, st)) {
+        return fail(FLTX_ERR_HIP, "score copy failed");
+      }
+      for (int i = 0; i < n; ++i) {
+        scores[3 * i] = sc[i];
+        scores[3 * i + 1] = am[i];
+        scores[3 * i + 2] = lm[i];
+      }
+    }
+  }
+  if (tokens || words) {
+    if (!d->backtraced && (rc = launchBacktrace(d))) {
+      return rc;
+    }
+    const int64_t base = d->histOff[b];
+    if (tokens && devCopyD2H(tokens, d->tokens.as<int32_t>() + base, 4 * (size_t)n * len, st)) {
+      return fail(FLTX_ERR_HIP, "token copy failed");
+    }
+    if (words) {
+      if (d->kind == FLTX_DECODER_LEXICON) {
+        if (devCopyD2H(words, d->words.as<int32_t>() + base, 4 * (size_t)n * len, st)) {
+          return fail(FLTX_ERR_HIP, "word copy failed");
+        }
+      } else {
+        std::fill(words, words + (size_t)n * len, -1); /* LexiconFreeDecoder.h:80-82 */
+      }
+    }
+  }
+  return FLTX_OK;
+}
+
+int fltx_result_best(fltx_decoder* d, int32_t b, int32_t lookBack, double* scores, int32_t* tokens,
+                     int32_t* words, int32_t capacity, int32_t* length) {
+  (void)scores;
+  (void)tokens;
+  (void)words;
+  (void)capacity;
+  (void)length;
+  (void)lookBack;
+  (void)b;
+  if (!d) {
+    return fail(FLTX_ERR_INVALID, "null decoder");
+  }
+  return fail(FLTX_ERR_UNSUPPORTED, "fltx_result_best: not implemented in this round");
+}
+
+int fltx_result_device(fltx_decoder* d, const int32_t** nHyp, const double** scores,
+                       const int32_t** tokens, const int32_t** words, const int64_t** tokOff) {
+  if (!d || !d->haveResults) {
+    return fail(FLTX_ERR_STATE, "no decode has been run");
+  }
+  if (!d->backtraced) {
+    int rc = launchBacktrace(d);
+    if (rc) {
+      return rc;
+    }
+  }
+  if (nHyp) {
+    *nHyp = d->outN.as<int32_t>();
+  }
+  if (scores) {
+    *scores = d->outScores.as<double>();
+  }
+  if (tokens) {
+    *tokens = d->tokens.as<int32_t>();
+  }
+  if (words) {
+    *words = d->kind == FLTX_DECODER_LEXICON ? d->words.as<int32_t>() : nullptr;
+  }
+  if (tokOff) {
+    *tokOff = d->histOffD.as<int64_t>();
+  }
+  return FLTX_OK;
+}
+
+int fltx_decoder_timing(fltx_decoder* d, float* decodeMs, float* backtraceMs) {
+  if (!d) {
+    return fail(FLTX_ERR_INVALID, "null decoder");
+  }
+#ifdef FLTX_EMU
+  if (decodeMs) {
+    *decodeMs = 0;
+  }
+  if (backtraceMs) {
+    *backtraceMs = 0;
+  }
+  return FLTX_OK;
+#else
+  if (!d->timed) {
+    return fail(FLTX_ERR_STATE, "no timed decode_batch has been run");
+  }
+  HIPCHK(hipEventSynchronize(d->ev[2]));
+  float a = 0, b = 0;
+  HIPCHK(hipEventElapsedTime(&a, d->ev[0], d->ev[1]));
+  HIPCHK(hipEventElapsedTime(&b, d->ev[1], d->ev[2]));
+  if (decodeMs) {
+    *decodeMs = a;
+  }
+  if (backtraceMs) {
+    *backtraceMs = b;
+  }
+  return FLTX_OK;
+#endif
+}
+
+int fltx_decoder_stats(fltx_decoder* d, int64_t* frames, int64_t* bytes, int32_t* threads,
+                       int32_t* ldsBytes) {
+  if (!d) {
+    return fail(FLTX_ERR_INVALID, "null decoder");
+  }
+  if (frames) {
+    *frames = d->statFrames;
+  }
+  if (bytes) {
+    *bytes = d->statBytes;
+  }
+  if (threads) {
+    *threads = d->threads;
+  }
+  if (ldsBytes) {
+    *ldsBytes = d->wsInLds ? (int32_t)d->wsBytes : 0;
+  }
+  return FLTX_OK;
+}
+
+} /* extern "C" */

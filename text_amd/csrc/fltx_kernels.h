@@ -1,0 +1,1323 @@
+/*
+ * fltx_kernels.h -- the MI355X beam-search engine (device code).
+ *
+ * One workgroup (W = 64..1024 threads, wave64) owns one utterance for the
+ * whole launch and walks its T frames serially; utterances are independent,
+ * so a batch is B workgroups and a node is 8 devices x B/8 (no collective).
+ * Per frame the workgroup restates, data-parallel, what the reference does
+ * with std::vector / std::sort / shared_ptr tries:
+ *
+ *   reference (flashlight/lib/text/decoder/)        here
+ *   ---------------------------------------------   -------------------------
+ *   LexiconFreeDecoder::decodeStep  .cpp:30-125     genLexFree()
+ *   LexiconDecoder::decodeStep      .cpp:32-229     genLexicon()
+ *   candidatesAdd                   Utils.h:131-144 pushCandidate(): record in
+ *                                                   LDS + insert into an LDS
+ *                                                   hash keyed by the merge key
+ *   candidatesStore step 1 (filter) Utils.h:160-165 foldGroups(): threshold on
+ *   candidatesStore step 2 (merge)  Utils.h:167-198   members, max / ordered
+ *                                                     log-add per hash chain
+ *   candidatesStore step 3 (prune)  Utils.h:200-220 selectTopK(): exact
+ *                                                   histogram select on f64
+ *   candidatesStore step 4 (move)   Utils.h:222-224 buildBeam(): rank-sort the
+ *                                                   survivors, write the next
+ *                                                   beam + back-pointers
+ *   LMState::child / compare        lm/LM.h:24-49   LM-state id = slot of
+ *                                                   (parent id, edge) in a
+ *                                                   per-utterance HBM hash
+ *   Trie children.find / labels     Trie.h:30-55    flat child table gather
+ *   decodeEnd                       .cpp:127-158 /  genEnd() + same machinery
+ *                                   .cpp:231-274
+ *   getAllHypothesis back-trace     Utils.h:229-266 fltx_backtrace_kernel
+ *
+ * Identity of LM states (the hard part): the reference merges on
+ * the ADDRESS of a memoised LMState trie node.  Here a state is named by the
+ * pair (parent state id, edge label); two candidates reach the same state iff
+ * the pairs are equal, so merging never needs a table probe.  Only the <= K
+ * survivors per frame that entered a new state resolve their id with one
+ * lookup-or-insert in the utterance's HBM table, which memoises every state a
+ * survivor ever held -- exactly the states whose identity can be observed.
+ *
+ * Scores are IEEE double, accumulated in the reference's order; the library is
+ * built with -ffp-contract=off so `s + w * l` stays mul + add.
+ *
+ * No MFMA: the path is gather / scan / select.  The bound is HBM (emission
+ * rows in, back-pointer records out); see DESIGN.md for the byte accounting.
+ */
+#pragma once
+#include "fltx_rt.h"
+
+namespace fltx {
+
+/* ------------------------------------------------------------------------ */
+/* data layout                                                               */
+/* ------------------------------------------------------------------------ */
+struct TrieNodeInfo { /* 16 B, one gather per visited trie node */
+  float maxScore;   /* TrieNode::maxScore after the host smear (Trie.h:54) */
+  int32_t labOff;   /* first label in trieLabels */
+  int32_t nLabels;  /* TrieNode::labels.size() (<= 6, Trie.h:19) */
+  int32_t nChildren;
+};
+
+struct NgramSlot { /* 16 B open-addressing slot: (context node, word) -> n-gram */
+  uint32_t ctx;    /* node id of the context n-gram (0 = empty context) */
+  uint32_t word;   /* LM word id; 0xFFFFFFFF = empty slot */
+  uint32_t node;   /* node id of this n-gram */
+  float prob;      /* log10 p */
+};
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kNoParent = 0x00FFFFFFu; /* parent id of the root LM state */
+constexpr uint32_t kNewState = 0x80000000u; /* cSrc flag: candidate enters a new LM state */
+constexpr uint32_t kPrevBlank = 0x80000000u; /* tokPb flag */
+constexpr int kFinishEdge = -1;              /* KenLM::finish child key (KenLM.cpp:79) */
+constexpr uint32_t kPhantomNode = 0x80000000u; /* NgramSlot.node: navigation-only prefix */
+constexpr int kMaxNgramOrder = 6;            /* FL_TEXT_KENLM_MAX_ORDER (lm/CMakeLists.txt:3) */
+
+enum { ST_OK = 0, ST_CAND_OVERFLOW = 1, ST_TABLE_FULL = 2, ST_SELECT_FALLBACK = 4 };
+
+struct DecodeParams {
+  /* options (LexiconDecoderOptions, LexiconDecoder.h:21-31) */
+  int32_t K, Kt;
+  double beamThreshold, lmWeight, wordScore, unkScore, silScore;
+  int32_t logAdd, criterion;
+  int32_t sil, blank, unk, isLmToken, kind, N;
+  const float* transitions; /* [N*N] or null */
+  /* flat trie */
+  const int32_t* trieChild; /* [nNodes*N] */
+  const TrieNodeInfo* trieInfo;
+  const int32_t* trieLabels;
+  /* LM */
+  int32_t lmKind; /* 0 ZeroLM, 1 n-gram */
+  int32_t lmOrder;
+  const NgramSlot* ngTab;
+  uint32_t ngMask;
+  const float* ngBackoff;   /* [node] back-off weight, 0 when absent */
+  const int32_t* usrToLm;
+  int32_t nUsr;
+  int32_t lmBos, lmEos, lmUnk;
+  int32_t* stateCtx;        /* [B*stateCap*(lmOrder-1)] suffix node ids per LM state */
+  /* batch */
+  const float* emissions;
+  const int64_t* emOff;
+  const int32_t* stepT;
+  int32_t doBegin, doEnd;
+  /* persistent per-utterance state (HBM) */
+  int32_t* uttNBeam;
+  int32_t* uttFrame;  /* index of the newest frame in the buffer */
+  int32_t* uttTotal;  /* nDecodedFrames_ (for the ASG first-frame rule) */
+  int32_t* uttStatus;
+  double* gScore;
+  double* gAm;
+  double* gLm;
+  uint32_t* gState;
+  uint32_t* gSPar;
+  int32_t* gSEdge;
+  uint32_t* gLex;
+  uint32_t* gTokPb;
+  /* history: one {parent, token} (+ word) record per surviving slot per frame */
+  int2* histPT;
+  int32_t* histW;
+  const int64_t* histOff;
+  /* LM-state identity table */
+  unsigned long long* stateTab;
+  uint32_t stateCap; /* per utterance, power of two */
+  uint32_t epoch;    /* 1..65535, bumped per decodeBegin */
+  /* workspace geometry */
+  int32_t CAP, HS, NB;
+  char* gws;          /* global workspace (big configurations), or null */
+  int64_t gwsStride;
+  /* results of decodeEnd */
+  int32_t* outN;
+  double* outScores;
+};
+
+struct Ws {
+  /* beam, double buffered */
+  double* bScore[2];
+  double* bAm[2];
+  double* bLm[2];
+  uint32_t* bState[2];
+  uint32_t* bSPar[2];
+  int32_t* bSEdge[2];
+  uint32_t* bLex[2];
+  uint32_t* bTokPb[2];
+  /* candidate records */
+  double* cScore;
+  uint4* cKey;     /* {state parent, state edge, lex node, token | prevBlank<<31} */
+  uint32_t* cSrc;  /* parent slot | kNewState */
+  int32_t* cAux;   /* word label or -1 */
+  float* cLm;      /* LM score delta (float, as the reference holds it) */
+  uint32_t* cOrd;  /* deterministic generation order (tie-break) */
+  uint32_t* cNext; /* hash chain */
+  uint32_t* head;  /* [HS] */
+  uint32_t* lead;  /* group leaders (candidate index), later survivors */
+  uint8_t* lstat;  /* per leader: 0 dropped, 1 active, 2 taken */
+  uint16_t* lbin;
+  uint32_t* small; /* boundary-bin members */
+  uint32_t* hist;  /* [NB] */
+  float* erow[2];  /* emission row, double buffered */
+  int32_t* tokIdx; /* token short-list */
+  uint32_t* wtmp;  /* [32] per-wave scratch for block scans */
+  unsigned long long* red; /* [4] block reductions */
+  int32_t* sc;     /* [16] block scalars */
+};
+
+enum { SC_NCAND = 0, SC_NLEAD = 1, SC_NSURV = 2, SC_BSTAR = 3, SC_CUM = 4, SC_M = 5,
+       SC_NSMALL = 6, SC_STATUS = 7, SC_NEED = 8, SC_DONE = 9 };
+
+#ifndef FLTX_HD
+#ifdef FLTX_EMU
+#define FLTX_HD inline
+#else
+#define FLTX_HD __host__ __device__ inline
+#endif
+#endif
+
+FLTX_HD size_t alignUp(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+/* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
+ * base == nullptr it only computes the size (host side). */
+FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N) {
+  size_t off = 0;
+#define FLTX_CARVE(field, type, count)                       \
+  off = alignUp(off, 16);                                    \
+  field = (type*)(base ? base + off : nullptr);              \
+  off += sizeof(type) * (size_t)(count);
+  for (int i = 0; i < 2; ++i) {
+    FLTX_CARVE(w.bScore[i], double, K)
+    FLTX_CARVE(w.bAm[i], double, K)
+    FLTX_CARVE(w.bLm[i], double, K)
+    FLTX_CARVE(w.bState[i], uint32_t, K)
+    FLTX_CARVE(w.bSPar[i], uint32_t, K)
+    FLTX_CARVE(w.bSEdge[i], int32_t, K)
+    FLTX_CARVE(w.bLex[i], uint32_t, K)
+    FLTX_CARVE(w.bTokPb[i], uint32_t, K)
+    FLTX_CARVE(w.erow[i], float, N)
+  }
+  FLTX_CARVE(w.cScore, double, CAP)
+  FLTX_CARVE(w.cKey, uint4, CAP)
+  FLTX_CARVE(w.cSrc, uint32_t, CAP)
+  FLTX_CARVE(w.cAux, int32_t, CAP)
+  FLTX_CARVE(w.cLm, float, CAP)
+  FLTX_CARVE(w.cOrd, uint32_t, CAP)
+  FLTX_CARVE(w.cNext, uint32_t, CAP)
+  FLTX_CARVE(w.head, uint32_t, HS)
+  FLTX_CARVE(w.lead, uint32_t, CAP)
+  FLTX_CARVE(w.lstat, uint8_t, CAP)
+  FLTX_CARVE(w.lbin, uint16_t, CAP)
+  FLTX_CARVE(w.small, uint32_t, CAP)
+  FLTX_CARVE(w.hist, uint32_t, NB)
+  FLTX_CARVE(w.tokIdx, int32_t, N)
+  FLTX_CARVE(w.wtmp, uint32_t, 32)
+  FLTX_CARVE(w.red, unsigned long long, 4)
+  FLTX_CARVE(w.sc, int32_t, 16)
+#undef FLTX_CARVE
+  return alignUp(off, 16);
+}
+
+FLTX_HD uint32_t hashKey(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  uint32_t h = a * 0x9E3779B1u;
+  h = (h ^ (h >> 15)) + b * 0x85EBCA77u;
+  h = (h ^ (h >> 13)) + c * 0xC2B2AE3Du;
+  h = (h ^ (h >> 16)) + d * 0x27D4EB2Fu;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  return h;
+}
+
+#ifndef FLTX_HOST_ONLY
+/* ------------------------------------------------------------------------ */
+/* block-level primitives                                                    */
+/* ------------------------------------------------------------------------ */
+/* exclusive prefix sum of v over the workgroup; *total = block sum.
+ * Contains two barriers; wtmp has >= nWaves+1 entries. */
+FLTX_DEV int blockExclusiveScan(int v, uint32_t* wtmp, int* total) {
+  const int lane = laneId(), wave = waveId();
+  const int nW = ((int)blockDim.x + 63) >> 6;
+  int inc = waveInclusiveScan(v);
+  if (lane == 63) {
+    wtmp[wave] = (uint32_t)inc;
+  }
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < nW; ++i) {
+    int x = (int)wtmp[i];
+    if (i < wave) {
+      base += x;
+    }
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+/* max / min of an f64 over the workgroup (2 barriers) */
+FLTX_DEV double blockMaxF64(double v, unsigned long long* slot) {
+  if (threadIdx.x == 0) {
+    *slot = 0ull;
+  }
+  __syncthreads();
+  unsigned long long k = waveMax64(f64Key(v));
+  if (laneId() == 0) {
+    atomMax64(slot, k);
+  }
+  __syncthreads();
+  return f64FromKey(*slot);
+}
+FLTX_DEV double blockMinF64(double v, unsigned long long* slot) {
+  if (threadIdx.x == 0) {
+    *slot = ~0ull;
+  }
+  __syncthreads();
+  unsigned long long k = waveMin64(f64Key(v));
+  if (laneId() == 0) {
+    atomMin64(slot, k);
+  }
+  __syncthreads();
+  return f64FromKey(*slot);
+}
+
+/* ------------------------------------------------------------------------ */
+/* candidate records + merge hash (candidatesAdd, Utils.h:131-144)            */
+/* ------------------------------------------------------------------------ */
+
+/* Append one candidate and chain it into the merge hash.  Every lane of the
+ * wave must call this together (`valid` masks lanes without a candidate): the
+ * record index comes from one wave-aggregated LDS atomic. */
+FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
+                            double score, uint32_t kp, uint32_t ke, uint32_t klex,
+                            uint32_t ktp, uint32_t src, int32_t aux, float lm,
+                            uint32_t ord, unsigned long long& bestKey) {
+  valid = valid && (score == score); /* NaN never enters (Utils.h:138-143) */
+  const unsigned long long m = waveBallot(valid);
+  if (m == 0ull) {
+    return;
+  }
+  const int lane = laneId();
+  const int leader = __builtin_ctzll(m);
+  uint32_t base = 0;
+  if (lane == leader) {
+    base = atomAdd32((uint32_t*)&w.sc[SC_NCAND], (uint32_t)popc64(m));
+  }
+  base = waveShfl32(base, leader);
+  if (!valid) {
+    return;
+  }
+  const uint32_t ci = base + (uint32_t)popc64(m & ((1ull << lane) - 1ull));
+  if (ci >= (uint32_t)P.CAP) {
+    atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_CAND_OVERFLOW);
+    return;
+  }
+  const unsigned long long sk = f64Key(score);
+  bestKey = sk > bestKey ? sk : bestKey;
+  w.cScore[ci] = score;
+  w.cKey[ci] = make_uint4(kp, ke, klex, ktp);
+  w.cSrc[ci] = src;
+  w.cAux[ci] = aux;
+  w.cLm[ci] = lm;
+  w.cOrd[ci] = ord;
+  compilerFence();
+  uint32_t s = hashKey(kp, ke, klex, ktp) & (uint32_t)(P.HS - 1);
+  for (;;) {
+    uint32_t cur = ldsLoad32(&w.head[s]);
+    if (cur == kEmpty) {
+      cur = atomCas32(&w.head[s], kEmpty, ci);
+      if (cur == kEmpty) {
+        w.cNext[ci] = kEmpty;
+        break;
+      }
+    }
+    const uint4 k = w.cKey[cur];
+    if (k.x == kp && k.y == ke && k.z == klex && k.w == ktp) {
+      const uint32_t old = atomExch32(&w.head[s], ci);
+      w.cNext[ci] = old;
+      break;
+    }
+    s = (s + 1) & (uint32_t)(P.HS - 1);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* n-gram LM on flat tables (replaces KenLM BaseScore, lm/KenLM.cpp:63-83)    */
+/* ------------------------------------------------------------------------ */
+FLTX_DEV bool ngFind(const DecodeParams& P, uint32_t ctx, uint32_t word, uint32_t& node,
+                     float& prob) {
+  uint32_t s = hashKey(ctx, word, 0x5bd1e995u, 0) & P.ngMask;
+  for (;;) {
+    const NgramSlot e = P.ngTab[s];
+    if (e.word == kEmpty) {
+      return false;
+    }
+    if (e.ctx == ctx && e.word == word) {
+      node = e.node;
+      prob = e.prob;
+      return true;
+    }
+    s = (s + 1) & P.ngMask;
+  }
+}
+
+/* ctxIn[j] = node id of the suffix n-gram made of the last j+1 context words
+ * (0 = absent), j < order-1.  Returns log10 p(word | context) summed in float:
+ * longest match first, then the back-off weights of the skipped contexts from
+ * the shortest to the longest (KenLM FullScore order, see oracle/arpa_lm.h). */
+FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t word,
+                       int32_t* ctxOut) {
+  const int L = P.lmOrder - 1;
+  uint32_t nodes[kMaxNgramOrder];
+  float probs[kMaxNgramOrder];
+  bool found[kMaxNgramOrder];
+  /* k = number of context words used; context node for k == 0 is 0 */
+  int longest = -1;
+  for (int k = 0; k <= L; ++k) {
+    found[k] = false;
+    nodes[k] = 0;
+    probs[k] = 0.0f;
+  }
+  for (int k = 0; k <= L; ++k) {
+    const uint32_t c = (k == 0) ? 0u : (uint32_t)ctxIn[k - 1];
+    if (k > 0 && c == 0u) {
+      continue; /* this suffix of the context is not an n-gram of the model */
+    }
+    if (ngFind(P, c, word, nodes[k], probs[k])) {
+      found[k] = true;
+      if (!(nodes[k] & kPhantomNode)) {
+        longest = k;
+      }
+      nodes[k] &= ~kPhantomNode;
+    }
+  }
+  float prob;
+  uint32_t w = word;
+  if (longest < 0) { /* not even a unigram: score <unk> */
+    w = (uint32_t)P.lmUnk;
+    uint32_t n0;
+    if (!ngFind(P, 0u, w, n0, prob)) {
+      prob = -100.0f;
+      n0 = 0;
+    }
+    nodes[0] = n0;
+    found[0] = true;
+    longest = 0;
+  } else {
+    prob = probs[longest];
+  }
+  for (int j = longest + 1; j <= L; ++j) {
+    const uint32_t c = (uint32_t)ctxIn[j - 1];
+    if (c != 0u) {
+      prob += P.ngBackoff[c];
+    }
+  }
+  if (ctxOut) {
+    for (int j = 0; j < L; ++j) {
+      /* suffix of length j+1 of (context, word) = n-gram (last j ctx words, word) */
+      ctxOut[j] = (j <= longest && found[j]) ? (int32_t)nodes[j] : 0;
+    }
+  }
+  return prob;
+}
+
+/* LM::score for the hypothesis in beam slot h (state id sid). */
+FLTX_DEV float lmScoreDev(const DecodeParams& P, int b, uint32_t sid, int usr) {
+  if (P.lmKind == 0) {
+    return 0.0f;
+  }
+  const int L = P.lmOrder - 1;
+  const int32_t* ctx = P.stateCtx + ((size_t)b * P.stateCap + sid) * L;
+  const uint32_t word = (usr >= 0 && usr < P.nUsr) ? (uint32_t)P.usrToLm[usr] : (uint32_t)P.lmUnk;
+  return ngScore(P, ctx, word, nullptr);
+}
+FLTX_DEV float lmFinishDev(const DecodeParams& P, int b, uint32_t sid) {
+  if (P.lmKind == 0) {
+    return 0.0f;
+  }
+  const int L = P.lmOrder - 1;
+  const int32_t* ctx = P.stateCtx + ((size_t)b * P.stateCap + sid) * L;
+  return ngScore(P, ctx, (uint32_t)P.lmEos, nullptr);
+}
+
+/* ------------------------------------------------------------------------ */
+/* LM-state identity: lookup-or-insert (parent id, edge) -> id in HBM          */
+/* (LMState::child, lm/LM.h:24-34).  Key = epoch:16 | parent:24 | edge+1:24.  */
+/* ------------------------------------------------------------------------ */
+FLTX_DEV uint32_t stateChild(const DecodeParams& P, int b, uint32_t par, int32_t edge,
+                             uint32_t* status, bool& fresh) {
+  unsigned long long* tab = P.stateTab + (size_t)b * P.stateCap;
+  const unsigned long long key = ((unsigned long long)P.epoch << 48) |
+      ((unsigned long long)(par & 0xFFFFFFu) << 24) | (unsigned long long)((uint32_t)(edge + 1) & 0xFFFFFFu);
+  const uint32_t mask = P.stateCap - 1;
+  uint32_t s = hashKey(par, (uint32_t)edge, 0x9747b28cu, 0) & mask;
+  fresh = false;
+  for (uint32_t probes = 0; probes < P.stateCap; ++probes) {
+    if (s == 0) { /* id 0 is the root state */
+      s = 1;
+    }
+    unsigned long long cur = loadCoherent64(&tab[s]);
+    for (;;) {
+      if (cur == key) {
+        return s;
+      }
+      if ((cur >> 48) == (unsigned long long)P.epoch) {
+        break; /* live entry of another state: next slot */
+      }
+      const unsigned long long old = atomCas64(&tab[s], cur, key);
+      if (old == cur) {
+        fresh = true;
+        return s;
+      }
+      cur = old; /* lost the race: re-examine what is there now */
+    }
+    s = (s + 1) & mask;
+  }
+  atomOr32(status, ST_TABLE_FULL);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* candidate generation                                                      */
+/* ------------------------------------------------------------------------ */
+struct FrameCtx {
+  int b;         /* utterance */
+  int cur;       /* beam buffer holding hyp_[frame] */
+  int nBeam;
+  int nTok;      /* min(beamSizeToken, N) */
+  bool useTrans; /* ASG and global frame > 0 */
+  const float* e; /* emission row in LDS */
+};
+
+/* LexiconFreeDecoder::decodeStep inner loops (LexiconFreeDecoder.cpp:54-112) */
+FLTX_DEV void genLexFree(const DecodeParams& P, const Ws& w, const FrameCtx& f,
+                         unsigned long long& bestKey) {
+  const int total = f.nBeam * f.nTok;
+  const int W = (int)blockDim.x;
+  const bool ctc = P.criterion == 1;
+  const int rounds = (total + W - 1) / W;
+  for (int it = 0; it < rounds; ++it) {
+    const int i = it * W + (int)threadIdx.x;
+    const bool valid = i < total;
+    double score = 0;
+    uint32_t kp = 0, ke = 0, ktp = 0, src = 0;
+    float lm = 0.0f;
+    if (valid) {
+      const int h = i / f.nTok, r = i - h * f.nTok;
+      const int n = (f.nTok == P.N) ? r : w.tokIdx[r];
+      const uint32_t tp = w.bTokPb[f.cur][h];
+      const int prevTok = (int)(tp & 0x7FFFFFFFu);
+      const bool prevBlank = (tp & kPrevBlank) != 0;
+      score = w.bScore[f.cur][h] + (double)f.e[n]; /* :64, transition excluded */
+      if (n == P.sil) {
+        score += P.silScore;
+      }
+      src = (uint32_t)h;
+      const bool newTok = ctc ? (n != P.blank && (n != prevTok || prevBlank)) : (n != prevTok);
+      if (newTok) { /* :69-85 */
+        lm = lmScoreDev(P, f.b, w.bState[f.cur][h], n);
+        score = score + P.lmWeight * (double)lm;
+        kp = w.bState[f.cur][h];
+        ke = (uint32_t)n;
+        ktp = (uint32_t)n;
+        src |= kNewState;
+      } else { /* blank :86-97 / repeat :98-110 keep the LM state */
+        kp = w.bSPar[f.cur][h];
+        ke = (uint32_t)w.bSEdge[f.cur][h];
+        ktp = (uint32_t)n | ((ctc && n == P.blank) ? kPrevBlank : 0u);
+      }
+    }
+    pushCandidate(P, w, valid, score, kp, ke, 0u, ktp, src, -1, lm, (uint32_t)i, bestKey);
+  }
+}
+
+/* LexiconDecoder::decodeStep inner loops (LexiconDecoder.cpp:55-215).  Work
+ * item = (hypothesis, r): r < nTok tries the r-th short-listed token as a trie
+ * child, r == nTok is "same node" (2), r == nTok+1 is CTC blank (3). */
+FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
+                         unsigned long long& bestKey) {
+  const int per = f.nTok + 2;
+  const int total = f.nBeam * per;
+  const int W = (int)blockDim.x;
+  const bool ctc = P.criterion == 1;
+  const bool hasUnk = P.unkScore > -__builtin_huge_val();
+  const int rounds = (total + W - 1) / W;
+  for (int it = 0; it < rounds; ++it) {
+    const int i = it * W + (int)threadIdx.x;
+    const bool valid = i < total;
+    /* up to 1 extend + 6 labels (or 1 unk) candidates per item, pushed in
+     * lock-step so the wave-aggregated append stays convergent */
+    bool cExt = false, cStay = false;
+    int nLab = 0, labOff = 0;
+    bool cUnk = false;
+    int h = 0, n = 0;
+    uint32_t childId = 0;
+    double base = 0, amDelta = 0;
+    float lmTok = 0.0f, lexMax = 0.0f, childMax = 0.0f;
+    uint32_t sid = 0, spar = 0, lexId = 0;
+    int32_t sedge = 0;
+    bool stayBlank = false;
+    if (valid) {
+      h = i / per;
+      const int r = i - h * per;
+      const uint32_t tp = w.bTokPb[f.cur][h];
+      const int prevTok = (int)(tp & 0x7FFFFFFFu);
+      const bool prevBlank = (tp & kPrevBlank) != 0;
+      lexId = w.bLex[f.cur][h];
+      sid = w.bState[f.cur][h];
+      spar = w.bSPar[f.cur][h];
+      sedge = w.bSEdge[f.cur][h];
+      const bool atRoot = lexId == 0u;
+      const double hs = w.bScore[f.cur][h];
+      if (r < f.nTok) { /* (1) children, :62-165 */
+        n = (f.nTok == P.N) ? r : w.tokIdx[r];
+        const int32_t c = P.trieChild[(size_t)lexId * P.N + n];
+        if (c >= 0) {
+          childId = (uint32_t)c;
+          const TrieNodeInfo ci = P.trieInfo[c];
+          lexMax = atRoot ? 0.0f : P.trieInfo[lexId].maxScore; /* :58-59 */
+          childMax = ci.maxScore;
+          amDelta = (double)f.e[n];
+          if (f.useTrans) {
+            amDelta += (double)P.transitions[(size_t)n * P.N + prevTok];
+          }
+          base = hs + amDelta;
+          if (n == P.sil) {
+            base += P.silScore;
+          }
+          if (P.isLmToken) {
+            lmTok = lmScoreDev(P, f.b, sid, n); /* :82-86 */
+          }
+          cExt = (!ctc || prevBlank || n != prevTok) && ci.nChildren > 0; /* :89-91 */
+          if (!(atRoot && prevTok == n)) { /* :114-122 */
+            nLab = ci.nLabels;
+            labOff = ci.labOff;
+          }
+          cUnk = ci.nLabels == 0 && hasUnk; /* :145 */
+        }
+      } else if (r == f.nTok) { /* (2) same lexicon node, :168-194 */
+        if (!ctc || !prevBlank || atRoot) {
+          cStay = true;
+          n = atRoot ? P.sil : prevTok;
+          amDelta = (double)f.e[n];
+          if (f.useTrans) {
+            amDelta += (double)P.transitions[(size_t)n * P.N + prevTok];
+          }
+          base = hs + amDelta;
+          if (n == P.sil) {
+            base += P.silScore;
+          }
+        }
+      } else if (ctc) { /* (3) blank, :197-213 */
+        cStay = true;
+        stayBlank = true;
+        n = P.blank;
+        base = hs + (double)f.e[n];
+      }
+    }
+    const uint32_t ordBase = (uint32_t)i << 3;
+    /* (1a) extend into the child node */
+    {
+      float l = P.isLmToken ? lmTok : (childMax - lexMax); /* float subtraction, :94 */
+      double sc = base + P.lmWeight * (double)l;
+      uint32_t kp = P.isLmToken ? sid : spar;
+      uint32_t ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
+      uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u);
+      pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, -1, l, ordBase, bestKey);
+    }
+    /* (1b) word ends: one candidate per label of the child */
+    for (int j = 0; j < 6; ++j) {
+      const bool on = j < nLab;
+      if (waveBallot(on) == 0ull) {
+        break;
+      }
+      double sc = 0;
+      float l = 0.0f;
+      int label = -1;
+      uint32_t kp = 0, ke = 0;
+      if (on) {
+        label = P.trieLabels[labOff + j];
+        if (!P.isLmToken) {
+          l = lmScoreDev(P, f.b, sid, label) - lexMax; /* float subtraction, :127 */
+          kp = sid;
+          ke = (uint32_t)label;
+        } else {
+          l = lmTok;
+          kp = sid;
+          ke = (uint32_t)n;
+        }
+        sc = base + P.lmWeight * (double)l + P.wordScore;
+      }
+      pushCandidate(P, w, on, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, label, l,
+                    ordBase + 1 + (uint32_t)j, bestKey);
+    }
+    /* (1c) unknown word */
+    if (waveBallot(cUnk) != 0ull) {
+      float l = 0.0f;
+      uint32_t kp = sid, ke = (uint32_t)n;
+      if (cUnk) {
+        if (!P.isLmToken) {
+          l = lmScoreDev(P, f.b, sid, P.unk) - lexMax;
+          ke = (uint32_t)P.unk;
+        } else {
+          l = lmTok;
+        }
+      }
+      double sc = base + P.lmWeight * (double)l + P.unkScore;
+      pushCandidate(P, w, cUnk, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, P.unk, l,
+                    ordBase + 7, bestKey);
+    }
+    /* (2)/(3) stay / blank keep state and node */
+    pushCandidate(P, w, cStay, base, spar, (uint32_t)sedge, lexId,
+                  (uint32_t)n | (stayBlank ? kPrevBlank : 0u), (uint32_t)h, -1, 0.0f, ordBase,
+                  bestKey);
+  }
+}
+
+/* decodeEnd candidates (LexiconFreeDecoder.cpp:127-146, LexiconDecoder.cpp:231-262) */
+FLTX_DEV void genEnd(const DecodeParams& P, const Ws& w, const FrameCtx& f,
+                     unsigned long long& bestKey) {
+  const int W = (int)blockDim.x;
+  /* nice ending: only root-node hypotheses finish if any exists */
+  bool nice = false;
+  if (P.kind == 1) {
+    for (int h = 0; h < f.nBeam; ++h) {
+      if (w.bLex[f.cur][h] == 0u) {
+        nice = true;
+        break;
+      }
+    }
+  }
+  const bool finishChild = P.lmKind != 0; /* KenLM::finish -> child(-1); ZeroLM -> same */
+  const int rounds = (f.nBeam + W - 1) / W;
+  for (int it = 0; it < rounds; ++it) {
+    const int h = it * W + (int)threadIdx.x;
+    bool valid = h < f.nBeam;
+    double sc = 0;
+    float l = 0.0f;
+    uint32_t kp = 0, ke = 0, lex = 0, src = 0;
+    if (valid) {
+      lex = w.bLex[f.cur][h];
+      if (P.kind == 1 && nice && lex != 0u) {
+        valid = false;
+      }
+    }
+    if (valid) {
+      const uint32_t sid = w.bState[f.cur][h];
+      l = lmFinishDev(P, f.b, sid);
+      sc = w.bScore[f.cur][h] + P.lmWeight * (double)l;
+      if (finishChild) {
+        kp = sid;
+        ke = (uint32_t)kFinishEdge;
+        src = (uint32_t)h | kNewState;
+      } else {
+        kp = w.bSPar[f.cur][h];
+        ke = (uint32_t)w.bSEdge[f.cur][h];
+        src = (uint32_t)h;
+      }
+    }
+    pushCandidate(P, w, valid, sc, kp, ke, lex, (uint32_t)P.sil, src, -1, l, (uint32_t)h, bestKey);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* fold hash chains into groups (candidatesStore steps 1-2, Utils.h:160-198)  */
+/* ------------------------------------------------------------------------ */
+FLTX_DEV void foldGroups(const DecodeParams& P, const Ws& w, double thr) {
+  const int W = (int)blockDim.x;
+  const int rounds = (P.HS + W - 1) / W;
+  for (int it = 0; it < rounds; ++it) {
+    const int s = it * W + (int)threadIdx.x;
+    uint32_t bestIdx = kEmpty;
+    double acc = 0;
+    if (s < P.HS) {
+      const uint32_t hd = w.head[s];
+      if (hd != kEmpty) {
+        /* best member: highest score, ties to the earliest generated */
+        uint32_t bestOrd = 0;
+        for (uint32_t m = hd; m != kEmpty; m = w.cNext[m]) {
+          const double sc = w.cScore[m];
+          if (!(sc >= thr)) {
+            continue;
+          }
+          const uint32_t o = w.cOrd[m];
+          if (bestIdx == kEmpty || sc > acc || (sc == acc && o < bestOrd)) {
+            bestIdx = m;
+            acc = sc;
+            bestOrd = o;
+          }
+        }
+        if (bestIdx != kEmpty && P.logAdd) {
+          /* Utils.h:186-193: members in descending score order, folded
+           * left to right: acc = max + log1p(exp(min - max)) */
+          double prevS = acc;
+          uint32_t prevO = bestOrd;
+          for (;;) {
+            uint32_t nxt = kEmpty;
+            double ns = 0;
+            uint32_t no = 0;
+            for (uint32_t m = hd; m != kEmpty; m = w.cNext[m]) {
+              const double sc = w.cScore[m];
+              if (!(sc >= thr)) {
+                continue;
+              }
+              const uint32_t o = w.cOrd[m];
+              /* strictly after (prevS, prevO) in (score desc, ord asc) order */
+              if (!(sc < prevS || (sc == prevS && o > prevO))) {
+                continue;
+              }
+              if (nxt == kEmpty || sc > ns || (sc == ns && o < no)) {
+                nxt = m;
+                ns = sc;
+                no = o;
+              }
+            }
+            if (nxt == kEmpty) {
+              break;
+            }
+            const double mx = acc > ns ? acc : ns;
+            const double mn = acc > ns ? ns : acc;
+            acc = mx + log1p(exp(mn - mx));
+            prevS = ns;
+            prevO = no;
+          }
+        }
+      }
+    }
+    /* compact the leaders */
+    const bool isLead = bestIdx != kEmpty;
+    const unsigned long long m = waveBallot(isLead);
+    if (m != 0ull) {
+      const int lane = laneId();
+      const int leader = __builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) {
+        base = atomAdd32((uint32_t*)&w.sc[SC_NLEAD], (uint32_t)popc64(m));
+      }
+      base = waveShfl32(base, leader);
+      if (isLead) {
+        const uint32_t li = base + (uint32_t)popc64(m & ((1ull << lane) - 1ull));
+        w.lead[li] = bestIdx;
+        w.cScore[bestIdx] = acc; /* group score lives in the leader's record */
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* exact top-K of the group leaders (candidatesStore step 3, Utils.h:200-220) */
+/* Order: score descending, ties by generation order.  Histogram select over  */
+/* [lo, hi] narrowed until the boundary bin is small, then an exact rank.     */
+/* ------------------------------------------------------------------------ */
+FLTX_DEV bool precedes(double sa, uint32_t oa, double sb, uint32_t ob) {
+  return sa > sb || (sa == sb && oa < ob);
+}
+
+FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  if (nLead <= K) {
+    for (int i = tid; i < nLead; i += W) {
+      w.lstat[i] = 2;
+    }
+    __syncthreads();
+    return;
+  }
+  for (int i = tid; i < nLead; i += W) {
+    w.lstat[i] = 1;
+  }
+  if (tid == 0) {
+    w.sc[SC_NEED] = K;
+    w.sc[SC_DONE] = 0;
+  }
+  __syncthreads();
+  const int SMALL = W < 256 ? 256 : W;
+  for (int pass = 0; pass < 64; ++pass) {
+    /* range of the active set */
+    double mx = -__builtin_huge_val(), mn = __builtin_huge_val();
+    int cnt = 0;
+    for (int i = tid; i < nLead; i += W) {
+      if (w.lstat[i] == 1) {
+        const double sc = w.cScore[w.lead[i]];
+        mx = sc > mx ? sc : mx;
+        mn = (sc < mn && sc > -__builtin_huge_val()) ? sc : mn; /* -inf falls in the last bin */
+        ++cnt;
+      }
+    }
+    const double hi = blockMaxF64(mx, &w.red[0]);
+    const double lo = blockMinF64(mn, &w.red[1]);
+    int active;
+    blockExclusiveScan(cnt, w.wtmp, &active);
+    const int need = w.sc[SC_NEED];
+    const double scale = (double)P.NB / (hi - lo);
+    if (active <= SMALL || !(hi > lo) || !(scale > 0.0) || !(scale < 1e300)) {
+      /* exact rank inside the active set */
+      if (tid == 0) {
+        w.sc[SC_NSMALL] = 0;
+      }
+      __syncthreads();
+      for (int i = tid; i < nLead; i += W) {
+        if (w.lstat[i] == 1) {
+          const uint32_t p = atomAdd32((uint32_t*)&w.sc[SC_NSMALL], 1u);
+          w.small[p] = (uint32_t)i;
+        }
+      }
+      __syncthreads();
+      for (int j = tid; j < active; j += W) {
+        const uint32_t li = w.small[j];
+        const uint32_t c = w.lead[li];
+        const double sc = w.cScore[c];
+        const uint32_t o = w.cOrd[c];
+        int rank = 0;
+        for (int q = 0; q < active; ++q) {
+          const uint32_t c2 = w.lead[w.small[q]];
+          rank += precedes(w.cScore[c2], w.cOrd[c2], sc, o) ? 1 : 0;
+        }
+        w.lstat[li] = rank < need ? 2 : 0;
+      }
+      __syncthreads();
+      return;
+    }
+    /* histogram pass: bin 0 holds the highest scores */
+    for (int i = tid; i < P.NB; i += W) {
+      w.hist[i] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < nLead; i += W) {
+      if (w.lstat[i] == 1) {
+        const double sc = w.cScore[w.lead[i]];
+        const double x = (hi - sc) * scale;
+        int bin = (x < (double)P.NB) ? (int)x : P.NB - 1; /* also catches inf / NaN */
+        bin = bin < 0 ? 0 : bin;
+        w.lbin[i] = (uint16_t)bin;
+        atomAdd32(&w.hist[bin], 1u);
+      }
+    }
+    __syncthreads();
+    /* locate the bin where the cumulative count reaches `need` */
+    const int per = (P.NB + W - 1) / W;
+    int mine = 0;
+    for (int q = 0; q < per; ++q) {
+      const int bi = tid * per + q;
+      if (bi < P.NB) {
+        mine += (int)w.hist[bi];
+      }
+    }
+    int tot;
+    const int before = blockExclusiveScan(mine, w.wtmp, &tot);
+    if (before < need && before + mine >= need) {
+      int cum = before;
+      for (int q = 0; q < per; ++q) {
+        const int bi = tid * per + q;
+        const int c = (int)w.hist[bi];
+        if (cum + c >= need) {
+          w.sc[SC_BSTAR] = bi;
+          w.sc[SC_CUM] = cum;
+          w.sc[SC_M] = c;
+          break;
+        }
+        cum += c;
+      }
+    }
+    __syncthreads();
+    const int bstar = w.sc[SC_BSTAR], cum = w.sc[SC_CUM], mcnt = w.sc[SC_M];
+    for (int i = tid; i < nLead; i += W) {
+      if (w.lstat[i] == 1) {
+        const int bin = (int)w.lbin[i];
+        if (bin < bstar) {
+          w.lstat[i] = 2;
+        } else if (bin > bstar) {
+          w.lstat[i] = 0;
+        } else if (cum + mcnt == need) {
+          w.lstat[i] = 2;
+        }
+      }
+    }
+    __syncthreads();
+    if (cum + mcnt == need) {
+      return;
+    }
+    if (tid == 0) {
+      w.sc[SC_NEED] = need - cum;
+    }
+    __syncthreads();
+  }
+  /* unreachable for finite inputs: each pass narrows [lo, hi] */
+  if (tid == 0) {
+    atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_SELECT_FALLBACK);
+  }
+  __syncthreads();
+}
+
+/* ------------------------------------------------------------------------ */
+/* survivors -> next beam + history (candidatesStore step 4, Utils.h:222-224) */
+/* The beam is kept sorted (score desc, generation order) so the layout is a   */
+/* deterministic function of the inputs; decodeEnd needs the sort anyway       */
+/* (returnSorted, Utils.h:213-219).                                           */
+/* ------------------------------------------------------------------------ */
+FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, int nLead,
+                       int frameOut, bool isEnd) {
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  const int nxt = f.cur ^ 1;
+  /* compact survivors (indices into lead[]) into small[] */
+  if (tid == 0) {
+    w.sc[SC_NSURV] = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < nLead; i += W) {
+    if (w.lstat[i] == 2) {
+      const uint32_t p = atomAdd32((uint32_t*)&w.sc[SC_NSURV], 1u);
+      w.small[p] = (uint32_t)i;
+    }
+  }
+  __syncthreads();
+  const int nS = w.sc[SC_NSURV];
+  const int64_t hbase = P.histOff[f.b] + (int64_t)frameOut * P.K;
+  for (int j = tid; j < nS; j += W) {
+    const uint32_t c = w.lead[w.small[j]];
+    const double sc = w.cScore[c];
+    const uint32_t o = w.cOrd[c];
+    int rank = 0;
+    for (int q = 0; q < nS; ++q) {
+      const uint32_t c2 = w.lead[w.small[q]];
+      rank += precedes(w.cScore[c2], w.cOrd[c2], sc, o) ? 1 : 0;
+    }
+    const uint4 key = w.cKey[c];
+    const uint32_t src = w.cSrc[c];
+    const int h = (int)(src & 0x7FFFFFFFu);
+    const int n = (int)(key.w & 0x7FFFFFFFu);
+    const float lmd = w.cLm[c];
+    /* emitting-model score: recompute the candidate's delta (LexiconFree:
+     * transition goes into am only, :59-64; Lexicon: am == score delta) */
+    double am = w.bAm[f.cur][h];
+    if (!isEnd) {
+      double d = (double)f.e[n];
+      const bool isBlankCand = (key.w & kPrevBlank) != 0;
+      if (f.useTrans && !(P.kind == 1 && isBlankCand)) {
+        const int prevTok = (int)(w.bTokPb[f.cur][h] & 0x7FFFFFFFu);
+        d += (double)P.transitions[(size_t)n * P.N + prevTok];
+      }
+      am += d;
+    }
+    uint32_t sid;
+    if (src & kNewState) {
+      bool fresh;
+      sid = stateChild(P, f.b, key.x, (int32_t)key.y, (uint32_t*)&w.sc[SC_STATUS], fresh);
+      if (fresh && P.lmKind != 0) {
+        /* materialise the n-gram context of the new state */
+        const int L = P.lmOrder - 1;
+        const int32_t* cin = P.stateCtx + ((size_t)f.b * P.stateCap + key.x) * L;
+        int32_t* cout = P.stateCtx + ((size_t)f.b * P.stateCap + sid) * L;
+        const int32_t edge = (int32_t)key.y;
+        uint32_t word;
+        if (edge == kFinishEdge) {
+          word = (uint32_t)P.lmEos;
+        } else {
+          word = (edge >= 0 && edge < P.nUsr) ? (uint32_t)P.usrToLm[edge] : (uint32_t)P.lmUnk;
+        }
+        int32_t tmp[kMaxNgramOrder];
+        ngScore(P, cin, word, tmp);
+        for (int q = 0; q < L; ++q) {
+          cout[q] = tmp[q];
+        }
+      }
+    } else {
+      sid = w.bState[f.cur][h];
+    }
+    w.bScore[nxt][rank] = sc;
+    w.bAm[nxt][rank] = am;
+    w.bLm[nxt][rank] = w.bLm[f.cur][h] + (double)lmd;
+    w.bState[nxt][rank] = sid;
+    w.bSPar[nxt][rank] = key.x;
+    w.bSEdge[nxt][rank] = (int32_t)key.y;
+    w.bLex[nxt][rank] = key.z;
+    w.bTokPb[nxt][rank] = key.w;
+    P.histPT[hbase + rank] = make_int2(h, n);
+    if (P.kind == 1) {
+      P.histW[hbase + rank] = w.cAux[c];
+    }
+  }
+  __syncthreads();
+  return nS;
+}
+
+/* top-beamSizeToken tokens of the row (LexiconFreeDecoder.cpp:42-51): rank by
+ * emission descending, ties to the lower index. */
+FLTX_DEV void tokenShortlist(const DecodeParams& P, const Ws& w, const float* e, int nTok) {
+  const int W = (int)blockDim.x;
+  for (int n = (int)threadIdx.x; n < P.N; n += W) {
+    const float v = e[n];
+    int rank = 0;
+    for (int m = 0; m < P.N; ++m) {
+      const float o = e[m];
+      rank += (o > v || (o == v && m < n)) ? 1 : 0;
+    }
+    if (rank < nTok) {
+      w.tokIdx[rank] = n;
+    }
+  }
+}
+
+/* one frame (or decodeEnd when isEnd): returns the new beam size */
+FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frameOut, bool isEnd) {
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  for (int i = tid; i < P.HS; i += W) {
+    w.head[i] = kEmpty;
+  }
+  if (tid == 0) {
+    w.sc[SC_NCAND] = 0;
+    w.sc[SC_NLEAD] = 0;
+    w.red[2] = 0ull;
+  }
+  if (!isEnd && f.nTok < P.N) {
+    tokenShortlist(P, w, f.e, f.nTok);
+  }
+  __syncthreads();
+  unsigned long long bestKey = 0ull;
+  if (isEnd) {
+    genEnd(P, w, f, bestKey);
+  } else if (P.kind == 0) {
+    genLexFree(P, w, f, bestKey);
+  } else {
+    genLexicon(P, w, f, bestKey);
+  }
+  bestKey = waveMax64(bestKey);
+  if (laneId() == 0 && bestKey != 0ull) {
+    atomMax64(&w.red[2], bestKey);
+  }
+  __syncthreads();
+  int nCand = w.sc[SC_NCAND];
+  nCand = nCand > P.CAP ? P.CAP : nCand;
+  if (nCand == 0) {
+    return 0;
+  }
+  const double best = f64FromKey(w.red[2]);
+  const double thr = best - P.beamThreshold; /* Utils.h:219 call sites */
+#ifdef FLTX_EMU_TRACE
+  if (threadIdx.x == 0 && getenv("FLTX_TRACE_FRAME") && atoi(getenv("FLTX_TRACE_FRAME")) == frameOut) {
+    printf("frame %d: nCand %d best %.6f\n", frameOut, nCand, best);
+    for (int i = 0; i < nCand; ++i) {
+      const uint4 k = w.cKey[i];
+      printf("  cand %3d score %.6f key(%u,%d,%u,%u|%d) src %u aux %d ord %u\n", i, w.cScore[i], k.x,
+             (int)k.y, k.z, k.w & 0x7FFFFFFFu, (int)(k.w >> 31), w.cSrc[i] & 0x7FFFFFFFu, w.cAux[i],
+             w.cOrd[i]);
+    }
+  }
+  __syncthreads();
+#endif
+  foldGroups(P, w, thr);
+  __syncthreads();
+  const int nLead = w.sc[SC_NLEAD];
+  selectTopK(P, w, nLead, P.K);
+  return buildBeam(P, w, f, nLead, frameOut, isEnd);
+}
+
+/* ------------------------------------------------------------------------ */
+/* the decode kernel: grid = utterances, block = W threads                   */
+/* ------------------------------------------------------------------------ */
+FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
+  const int b = (int)blockIdx.x;
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  Ws w;
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N);
+  int cur = 0;
+  int nBeam, frame, total;
+  if (tid == 0) {
+    w.sc[SC_STATUS] = 0;
+  }
+  if (P.doBegin) {
+    /* decodeBegin (LexiconFreeDecoder.cpp:20-28, LexiconDecoder.cpp:21-30) */
+    if (tid == 0) {
+      w.bScore[0][0] = 0.0;
+      w.bAm[0][0] = 0.0;
+      w.bLm[0][0] = 0.0;
+      w.bState[0][0] = 0u;
+      w.bSPar[0][0] = kNoParent;
+      w.bSEdge[0][0] = 0;
+      w.bLex[0][0] = 0u;
+      w.bTokPb[0][0] = (uint32_t)P.sil;
+      const int64_t hb = P.histOff[b];
+      P.histPT[hb] = make_int2(-1, P.sil);
+      if (P.kind == 1) {
+        P.histW[hb] = -1;
+      }
+      if (P.lmKind != 0) { /* KenLM::start(false): context = <s> (KenLM.cpp:57) */
+        const int L = P.lmOrder - 1;
+        int32_t* c0 = P.stateCtx + (size_t)b * P.stateCap * L;
+        uint32_t node = 0;
+        float pr;
+        const bool ok = ngFind(P, 0u, (uint32_t)P.lmBos, node, pr);
+        for (int q = 0; q < L; ++q) {
+          c0[q] = (q == 0 && ok) ? (int32_t)node : 0;
+        }
+      }
+    }
+    nBeam = 1;
+    frame = 0;
+    total = 0;
+  } else {
+    nBeam = P.uttNBeam[b];
+    frame = P.uttFrame[b];
+    total = P.uttTotal[b];
+    for (int i = tid; i < nBeam; i += W) {
+      const size_t g = (size_t)b * P.K + i;
+      w.bScore[0][i] = P.gScore[g];
+      w.bAm[0][i] = P.gAm[g];
+      w.bLm[0][i] = P.gLm[g];
+      w.bState[0][i] = P.gState[g];
+      w.bSPar[0][i] = P.gSPar[g];
+      w.bSEdge[0][i] = P.gSEdge[g];
+      w.bLex[0][i] = P.gLex[g];
+      w.bTokPb[0][i] = P.gTokPb[g];
+    }
+  }
+  const int T = P.stepT ? P.stepT[b] : 0;
+  const float* em = P.emissions ? P.emissions + P.emOff[b] : nullptr;
+  const int N = P.N;
+  const int nTok = P.Kt < N ? P.Kt : N;
+  /* stage row 0; afterwards row t+1 is prefetched into registers while frame
+   * t is processed and parked in the other LDS row buffer at its end */
+  constexpr int PF = 4;
+  float pre[PF];
+  const bool regPrefetch = N <= PF * W;
+  if (T > 0) {
+    for (int n = tid; n < N; n += W) {
+      w.erow[0][n] = em[n];
+    }
+  }
+  __syncthreads();
+  FrameCtx f;
+  f.b = b;
+  f.nTok = nTok;
+  for (int t = 0; t < T; ++t) {
+    const int rb = t & 1;
+    if (t + 1 < T) {
+      const float* nx = em + (size_t)(t + 1) * N;
+      if (regPrefetch) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+          const int n = tid + q * W;
+          pre[q] = n < N ? nx[n] : 0.0f;
+        }
+      }
+    }
+    f.cur = cur;
+    f.nBeam = nBeam;
+    f.e = w.erow[rb];
+    f.useTrans = (P.criterion == 0) && (total + t > 0) && P.transitions != nullptr;
+    nBeam = runFrame(P, w, f, frame + t + 1, false);
+    cur ^= 1; /* with nBeam == 0 either buffer is equally empty */
+    if (t + 1 < T) {
+      if (regPrefetch) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+          const int n = tid + q * W;
+          if (n < N) {
+            w.erow[rb ^ 1][n] = pre[q];
+          }
+        }
+      } else {
+        const float* nx = em + (size_t)(t + 1) * N;
+        for (int n = tid; n < N; n += W) {
+          w.erow[rb ^ 1][n] = nx[n];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  frame += T;
+  total += T;
+  if (P.doEnd) {
+    f.cur = cur;
+    f.nBeam = nBeam;
+    f.e = w.erow[0];
+    f.useTrans = false;
+    nBeam = nBeam > 0 ? runFrame(P, w, f, frame + 1, true) : 0;
+    cur ^= 1;
+    frame += 1;
+    total += 1;
+    for (int i = tid; i < nBeam; i += W) {
+      const size_t g = ((size_t)b * P.K + i) * 3;
+      P.outScores[g + 0] = w.bScore[cur][i];
+      P.outScores[g + 1] = w.bAm[cur][i];
+      P.outScores[g + 2] = w.bLm[cur][i];
+    }
+    if (tid == 0) {
+      P.outN[b] = nBeam;
+    }
+  }
+  /* park the beam in HBM for the next decodeStep / prune / best */
+  for (int i = tid; i < nBeam; i += W) {
+    const size_t g = (size_t)b * P.K + i;
+    P.gScore[g] = w.bScore[cur][i];
+    P.gAm[g] = w.bAm[cur][i];
+    P.gLm[g] = w.bLm[cur][i];
+    P.gState[g] = w.bState[cur][i];
+    P.gSPar[g] = w.bSPar[cur][i];
+    P.gSEdge[g] = w.bSEdge[cur][i];
+    P.gLex[g] = w.bLex[cur][i];
+    P.gTokPb[g] = w.bTokPb[cur][i];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    P.uttNBeam[b] = nBeam;
+    P.uttFrame[b] = frame;
+    P.uttTotal[b] = total;
+    P.uttStatus[b] = P.doBegin ? w.sc[SC_STATUS] : (P.uttStatus[b] | w.sc[SC_STATUS]);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* back-trace (getAllHypothesis, Utils.h:229-266): hypothesis k of utterance  */
+/* b walks parent slots from frame `finalFrame` down to 0.                    */
+/* ------------------------------------------------------------------------ */
+struct BacktraceParams {
+  int32_t K, kind;
+  const int2* histPT;
+  const int32_t* histW;
+  const int64_t* histOff;
+  const int32_t* uttFrame; /* final frame index per utterance */
+  const int32_t* uttNBeam;
+  const int64_t* tokOff;   /* output offset of utterance b (int32 elements) */
+  int32_t* tokens;
+  int32_t* words;
+  int32_t nbest;           /* <= 0: all */
+};
+
+FLTX_DEV void backtraceUtterance(const BacktraceParams& P) {
+  const int b = (int)blockIdx.x;
+  const int ff = P.uttFrame[b];
+  int nh = P.uttNBeam[b];
+  if (P.nbest > 0 && nh > P.nbest) {
+    nh = P.nbest;
+  }
+  const int len = ff + 1;
+  for (int k = (int)threadIdx.x; k < nh; k += (int)blockDim.x) {
+    int slot = k;
+    int32_t* tk = P.tokens + P.tokOff[b] + (int64_t)k * len;
+    int32_t* wd = P.words ? P.words + P.tokOff[b] + (int64_t)k * len : nullptr;
+    for (int fr = ff; fr >= 0; --fr) {
+      const int64_t idx = P.histOff[b] + (int64_t)fr * P.K + slot;
+      const int2 pt = P.histPT[idx];
+      tk[fr] = pt.y;
+      if (wd) {
+        wd[fr] = P.kind == 1 ? P.histW[idx] : -1;
+      }
+      slot = pt.x;
+      if (slot < 0) {
+        for (int q = fr - 1; q >= 0; --q) { /* pruned history: leave -1 */
+          tk[q] = -1;
+          if (wd) {
+            wd[q] = -1;
+          }
+        }
+        break;
+      }
+    }
+  }
+}
+#endif /* !FLTX_HOST_ONLY */
+
+} // namespace fltx

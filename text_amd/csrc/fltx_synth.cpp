@@ -141,6 +141,14 @@ int fltx_synth_emissions(int dist, uint64_t S, uint64_t u, int T, int N,
   return -1;
 }
 
+/* n floats lo + (hi-lo) * r24 * 2^-24 (float ops), e.g. ASG transitions */
+void fltx_synth_floats(uint64_t seed, int64_t n, float lo, float hi, float* out) {
+  SplitMix64 g(seed);
+  for (int64_t i = 0; i < n; ++i) {
+    out[i] = lo + (hi - lo) * ((float)g.r24() * 0x1p-24f);
+  }
+}
+
 /* Synthetic lexicon: W unique spellings of 2..12 letters (tokens 1..27)
  * followed by token 0 (sil).  spell_off must hold W+1 entries; spell_flat
  * capacity `cap` tokens.  Returns the total number of tokens written, or -1

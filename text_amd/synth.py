@@ -34,7 +34,15 @@ def lib():
         _lib.fltx_synth_lexicon.restype = C.c_int64
         _lib.fltx_synth_lexicon.argtypes = [C.c_uint64, C.c_int64, C.c_void_p,
                                             C.c_int64, C.c_void_p]
+        _lib.fltx_synth_floats.restype = None
+        _lib.fltx_synth_floats.argtypes = [C.c_uint64, C.c_int64, C.c_float, C.c_float, C.c_void_p]
     return _lib
+
+
+def floats(seed, n, lo=0.0, hi=1.0):
+    out = np.empty(n, dtype=np.float32)
+    lib().fltx_synth_floats(seed, n, lo, hi, out.ctypes.data)
+    return out
 
 
 def emissions(dist, u, T, N, S=1, lexicon=None, out=None):
