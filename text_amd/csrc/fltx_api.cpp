@@ -25,6 +25,18 @@
 
 using namespace fltx;
 
+#ifndef FLTX_EMU
+/* kernels: global scope, external linkage (the runtime resolves them by name) */
+__global__ void fltx_decode_kernel_lds(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  decodeUtterance(P, fltx_smem);
+}
+__global__ void fltx_decode_kernel_gws(DecodeParams P) {
+  decodeUtterance(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
+}
+__global__ void fltx_backtrace_kernel(BacktraceParams P) { backtraceUtterance(P); }
+#endif
+
 /* ------------------------------------------------------------------------ */
 /* device back-end                                                           */
 /* ------------------------------------------------------------------------ */
@@ -89,14 +101,6 @@ int devSync(Stream s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : 1; }
 const char* devErr() { return hipGetErrorString(hipGetLastError()); }
 constexpr size_t kMaxLds = 160 * 1024; /* gfx950: 160 KiB LDS per CU */
 
-__global__ void fltx_decode_kernel_lds(DecodeParams P) {
-  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  decodeUtterance(P, fltx_smem);
-}
-__global__ void fltx_decode_kernel_gws(DecodeParams P) {
-  decodeUtterance(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
-}
-__global__ void fltx_backtrace_kernel(BacktraceParams P) { backtraceUtterance(P); }
 #endif
 
 /* growable device buffer */
