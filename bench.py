@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--workload", default="C2", choices=["C2", "C3"])
     ap.add_argument("--cpu-sample", type=int, default=64, help="utterances timed on the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
     return ap.parse_args()
 
 
@@ -124,6 +125,17 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if a.profile and rank == 0:
+        dec.set("profile", 1)
+        step()
+        ctx.synchronize()
+        pr = dec.profile().astype(np.float64)
+        names = ["A2(combine)", "B(eval+bin)", "C(prefix)", "D(shortlist)", "E(build)", "row", "A1(relations)", "-"]
+        tot = pr[:8].sum()
+        sys.stderr.write("phase split (shader clocks, %% of %.3g): " % tot + ", ".join(
+            "%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, pr[:8])) +
+            " | clocks/frame/utt %.0f\n" % (tot / (B * T)))
+        dec.set("profile", 0)
     st = dec.stats()
     frames_total = B * T * a.steps * world
     value = frames_total / dt

@@ -209,7 +209,11 @@ FLTX_API int fltx_decoder_stats(fltx_decoder* dec, int64_t* frames,
 /* Durations (ms) of the decode kernel and of the back-trace kernel of the last
  * fltx_decode_batch, from HIP events recorded on the context stream. */
 FLTX_API int fltx_decoder_timing(fltx_decoder* dec, float* decode_ms, float* backtrace_ms);
-/* Tunables: "threads" (threads per utterance: 64..1024), "force_global_ws". */
+/* Phase profile of the last launch (after fltx_decoder_set(dec,"profile",1)):
+ * out[8] shader clocks summed over the batch. */
+FLTX_API int fltx_decoder_profile(fltx_decoder* dec, uint64_t* out);
+/* Tunables: "threads" (threads per utterance: 64..1024), "force_global_ws",
+ * "dense" (0 = use the generic hash merge for lexicon-free frames too). */
 FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
 
 #ifdef __cplusplus

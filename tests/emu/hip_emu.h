@@ -93,6 +93,7 @@ FLTX_DEV unsigned long long loadCoherent64(const unsigned long long* p) {
 }
 FLTX_DEV uint32_t ldsLoad32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 FLTX_DEV void compilerFence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+FLTX_DEV void ldsBarrier() { __syncthreads(); }
 
 /* wave collectives: publish, barrier, read, barrier */
 FLTX_DEV EmuWave& emuWave() { return emuBlock->waves[threadIdx.x >> 6]; }
@@ -118,6 +119,7 @@ FLTX_DEV int popc64(unsigned long long m) { return __builtin_popcountll(m); }
 FLTX_DEV uint32_t waveShfl32(uint32_t v, int src) {
   return emuExchange(v, [src](const unsigned long long* s) { return (uint32_t)s[src & 63]; });
 }
+FLTX_DEV uint32_t waveReadLane32(uint32_t v, int src) { return waveShfl32(v, src); }
 FLTX_DEV unsigned long long waveMax64(unsigned long long v) {
   return emuExchange(v, [](const unsigned long long* s) {
     unsigned long long m = 0;

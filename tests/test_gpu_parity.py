@@ -94,3 +94,24 @@ def test_c2_batch_property_checks(gpu_session, golden):
                 acc += v
             assert acc == h.am == h.score
     d.close()
+
+
+LEXFREE = [c for c in cases.CASES if c["kind"] == "lexfree"]
+
+
+@pytest.mark.parametrize("mode", ["hash", "dense"])
+@pytest.mark.parametrize("c", LEXFREE, ids=lambda c: c["name"])
+def test_generic_engine_equals_lean_kernel(gpu_session, golden, c, mode):
+    """Lexicon-free + ZeroLM frames normally run the lean register-resident
+    step (fltx_lean.h).  The generic engine -- with its dense merge, and with
+    the hash merge the lexicon decoder uses -- must give the same n-best."""
+    inp = helpers.case_inputs(c)
+    d = gpu_session.decoder(c, inp)
+    d.set("lean", 0)
+    if mode == "hash":
+        d.set("dense", 0)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    tol = 1e-5 if c["log_add"] else 0.0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
+    d.close()
+    assert ok, why

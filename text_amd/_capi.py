@@ -54,7 +54,7 @@ class Lib:
         "fltx_stream_step", "fltx_stream_end", "fltx_stream_prune",
         "fltx_stream_frames_in_buffer", "fltx_result_count", "fltx_result_fetch",
         "fltx_result_best", "fltx_result_device", "fltx_decoder_stats",
-        "fltx_decoder_set", "fltx_decoder_timing", "fltx_htrie_create", "fltx_htrie_destroy", "fltx_htrie_insert",
+        "fltx_decoder_set", "fltx_decoder_timing", "fltx_decoder_profile", "fltx_htrie_create", "fltx_htrie_destroy", "fltx_htrie_insert",
         "fltx_htrie_search", "fltx_htrie_smear", "fltx_htrie_num_nodes", "fltx_htrie_upload",
     ]
 
@@ -97,6 +97,7 @@ class Lib:
             "fltx_decoder_stats": [vp, vp, vp, vp, vp],
             "fltx_decoder_set": [vp, C.c_char_p, i64],
             "fltx_decoder_timing": [vp, vp, vp],
+            "fltx_decoder_profile": [vp, vp],
             "fltx_htrie_create": [i32, i32, pvp],
             "fltx_htrie_destroy": [vp],
             "fltx_htrie_insert": [vp, vp, i32, i32, C.c_float],
@@ -404,6 +405,11 @@ class BatchDecoder:
                                                    C.addressof(th), C.addressof(lds)))
         return {"frames": fr.value, "algorithmic_bytes": by.value, "threads_per_utt": th.value,
                 "lds_bytes": lds.value}
+
+    def profile(self):
+        out = np.zeros(8, dtype=np.uint64)
+        self.L.check(self.L.lib.fltx_decoder_profile(self.h, _ptr(out)))
+        return out
 
     def timing(self):
         a, b = C.c_float(0), C.c_float(0)

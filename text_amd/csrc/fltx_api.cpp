@@ -27,12 +27,17 @@ using namespace fltx;
 
 #ifndef FLTX_EMU
 /* kernels: global scope, external linkage (the runtime resolves them by name) */
-__global__ void fltx_decode_kernel_lds(DecodeParams P) {
+/* One instantiation per workgroup size so that __launch_bounds__ gives the
+ * register allocator the real budget (256 threads = 1 wave per SIMD = up to
+ * 512 VGPRs; the 1024-thread default would cap it at 128 and spill). */
+template <int W, int GMAX>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_lds(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  decodeUtterance(P, fltx_smem);
+  decodeUtterance<GMAX>(P, fltx_smem);
 }
-__global__ void fltx_decode_kernel_gws(DecodeParams P) {
-  decodeUtterance(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
+template <int W>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_gws(DecodeParams P) {
+  decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
 }
 __global__ void fltx_backtrace_kernel(BacktraceParams P) { backtraceUtterance(P); }
 #endif
@@ -195,7 +200,8 @@ struct fltx_decoder {
   int nTrans = 0;
   DBuf transitions;
   /* tunables */
-  int threads = 256;
+  int threads = 0; /* 0 = pick per configuration (prepare()) */
+  int userThreads = 0;
   int forceGlobalWs = 0;
   /* batch state */
   int B = 0, N = 0;
@@ -207,14 +213,16 @@ struct fltx_decoder {
   int64_t histRecords = 0;
   uint32_t stateCap = 0;
   uint32_t epoch = 0;
-  int CAP = 0, HS = 0, NB = 0;
+  int CAP = 0, HS = 0, NB = 0, SCAP = 0, dense = 0, noDense = 0;
+  int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
   size_t wsBytes = 0;
   bool wsInLds = true;
   /* device buffers */
   DBuf emis, emOff, stepT, histOffD, histPT, histW, stateTab, stateCtx;
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
-  DBuf tokens, words;
+  DBuf tokens, words, prof;
+  int profile = 0;
   /* host caches of the last results */
   std::vector<int32_t> hN, hFrame, hStatus;
   bool resultsSynced = false;
@@ -650,10 +658,23 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     return fail(FLTX_ERR_INVALID, "null argument");
   }
   if (!strcmp(key, "threads")) {
-    if (value < 64 || value > 1024 || (value & 63)) {
-      return fail(FLTX_ERR_INVALID, "threads must be a multiple of 64 in 64..1024");
+    if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) {
+      return fail(FLTX_ERR_INVALID, "threads must be 64, 128, 256, 512 or 1024");
     }
+    d->userThreads = (int)value;
     d->threads = (int)value;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "profile")) {
+    d->profile = value != 0;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "lean")) { /* 0: lexicon-free + ZeroLM frames use the generic engine */
+    d->noLean = value == 0;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "dense")) { /* 0: force the generic hash merge for lexicon-free frames */
+    d->noDense = value == 0;
     return FLTX_OK;
   }
   if (!strcmp(key, "force_global_ws")) {
@@ -704,20 +725,45 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   d->histRecords = off;
   uint64_t wantStates = 2ull * ((uint64_t)K * (uint64_t)(maxT + 2) + 2);
   uint32_t cap = nextPow2(std::max<uint64_t>(wantStates, 1024));
-  if (cap > (1u << 24)) {
+  if (cap > (1u << 23)) {
     return fail(FLTX_ERR_UNSUPPORTED, "K * T = %llu exceeds the 2^23 LM states per utterance this build indexes",
                 (unsigned long long)K * (maxT + 2));
   }
   /* candidate capacity */
   const int nTok = std::min(d->opt.beam_size_token, N);
-  int64_t worst = d->kind == FLTX_DECODER_LEXFREE ? (int64_t)K * nTok : (int64_t)K * ((int64_t)nTok * 8 + 2);
+  /* lexicon-free frames merge through the dense (hash-free) path: one slot per
+   * (LM state, token) group plus one per orphan repeat; the hash is then only
+   * used by decodeEnd (<= K candidates) */
+  d->dense = (d->kind == FLTX_DECODER_LEXFREE && !d->noDense) ? 1 : 0;
+  /* threads per utterance: the frame step is latency bound, so more waves per
+   * utterance win as long as the batch does not fill the CUs on its own
+   * (measured on C2: 256 -> 15.3 ms, 512 -> 13.0 ms per 256-utterance batch) */
+  if (!d->userThreads) {
+    d->threads = (d->kind == FLTX_DECODER_LEXFREE && B <= 512) ? 512 : 256;
+  }
+  /* lean frame step (fltx_lean.h): lexicon-free + ZeroLM, groups held in registers */
+  d->lean = 0;
+  if (d->dense && !d->noLean && !d->forceGlobalWs && d->lm->kind == 0 && K < 32000) {
+    const int64_t groups = (int64_t)K * (nTok + 1);
+    const int64_t per = (groups + d->threads - 1) / d->threads;
+    d->lean = per <= 6 ? 6 : (per <= 12 ? 12 : 0);
+  }
+  int64_t worst = d->kind == FLTX_DECODER_LEXFREE ? (int64_t)K * (nTok + (d->dense ? 1 : 0))
+                                                  : (int64_t)K * ((int64_t)nTok * 8 + 2);
+  if (d->lean) {
+    worst = K; /* no candidate records at all */
+  }
   worst = std::max<int64_t>(worst, K);
   int64_t capC = worst;
   d->NB = 1024;
+  d->SCAP = K + 256;
   Ws tmp;
+  auto hsFor = [&](int64_t c) {
+    int64_t keys = d->dense ? K : c;
+    return std::max((int)nextPow2((uint64_t)keys * 2), 64);
+  };
   auto bytesFor = [&](int64_t c) {
-    int hs = (int)nextPow2((uint64_t)c * 2);
-    return carveWs(tmp, nullptr, K, (int)c, std::max(hs, 64), d->NB, N);
+    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense);
   };
   bool lds = !d->forceGlobalWs;
   if (lds && bytesFor(capC) > kMaxLds) {
@@ -737,8 +783,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     }
   }
   d->CAP = (int)capC;
-  d->HS = std::max((int)nextPow2((uint64_t)capC * 2), 64);
-  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N);
+  d->HS = hsFor(capC);
+  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense);
   d->wsInLds = lds;
   /* buffers */
   bool grewTab = false;
@@ -843,18 +889,33 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.CAP = d->CAP;
   P.HS = d->HS;
   P.NB = d->NB;
+  P.SCAP = d->SCAP;
+  P.dense = d->dense;
   P.gws = d->wsInLds ? nullptr : d->gws.as<char>();
   P.gwsStride = (int64_t)d->wsBytes;
   P.outN = d->outN.as<int32_t>();
   P.outScores = d->outScores.as<double>();
+  P.prof = nullptr;
+  if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {
+    devMemset(d->prof.p, 0, 8 * 8 * (size_t)d->B, d->ctx->stream);
+    P.prof = d->prof.as<unsigned long long>();
+  }
 }
 
 int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   const int W = d->threads;
 #ifdef FLTX_EMU
   const DecodeParams* pp = &P;
-  emuLaunch(d->B, W, d->wsInLds ? d->wsBytes : 16, [pp](char* smem) {
-    decodeUtterance(*pp, pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem);
+  const int gmax = d->lean;
+  emuLaunch(d->B, W, d->wsInLds ? d->wsBytes : 16, [pp, gmax](char* smem) {
+    char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
+    if (gmax == 6) {
+      decodeUtterance<6>(*pp, base);
+    } else if (gmax == 12) {
+      decodeUtterance<12>(*pp, base);
+    } else {
+      decodeUtterance<0>(*pp, base);
+    }
   });
   return FLTX_OK;
 #else
@@ -864,13 +925,35 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     }
   }
   HIPCHK(hipEventRecord(d->ev[0], d->ctx->stream));
-  if (d->wsInLds) {
-    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lds,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));
-    hipLaunchKernelGGL(fltx_decode_kernel_lds, dim3(d->B), dim3(W), d->wsBytes, d->ctx->stream, P);
-  } else {
-    hipLaunchKernelGGL(fltx_decode_kernel_gws, dim3(d->B), dim3(W), 0, d->ctx->stream, P);
+#define FLTX_LAUNCH_LDS(WW, GG)                                                                  \
+  do {                                                                                           \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lds<WW, GG>,                      \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
+    hipLaunchKernelGGL((fltx_decode_kernel_lds<WW, GG>), dim3(d->B), dim3(WW), d->wsBytes,       \
+                       d->ctx->stream, P);                                                       \
+  } while (0)
+#define FLTX_LAUNCH(WW)                                                                          \
+  do {                                                                                           \
+    if (!d->wsInLds) {                                                                           \
+      hipLaunchKernelGGL(fltx_decode_kernel_gws<WW>, dim3(d->B), dim3(WW), 0, d->ctx->stream, P); \
+    } else if (d->lean == 6) {                                                                   \
+      FLTX_LAUNCH_LDS(WW, 6);                                                                    \
+    } else if (d->lean == 12) {                                                                  \
+      FLTX_LAUNCH_LDS(WW, 12);                                                                   \
+    } else {                                                                                     \
+      FLTX_LAUNCH_LDS(WW, 0);                                                                    \
+    }                                                                                            \
+  } while (0)
+  switch (W) {
+    case 64: FLTX_LAUNCH(64); break;
+    case 128: FLTX_LAUNCH(128); break;
+    case 256: FLTX_LAUNCH(256); break;
+    case 512: FLTX_LAUNCH(512); break;
+    case 1024: FLTX_LAUNCH(1024); break;
+    default: return fail(FLTX_ERR_INVALID, "threads per utterance must be 64, 128, 256, 512 or 1024");
   }
+#undef FLTX_LAUNCH
+#undef FLTX_LAUNCH_LDS
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(d->ev[1], d->ctx->stream));
   d->timed = false;
@@ -1034,19 +1117,28 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     if ((rc = launchDecode(d, P))) {
       return rc;
     }
-    if (d->kind == FLTX_DECODER_LEXICON && d->wsInLds && attempt == 0) {
-      /* the LDS sizing of the lexicon decoder is optimistic: check for a
-       * candidate overflow and, if any, redo the batch with an HBM workspace */
+    if (attempt == 0 && ((d->kind == FLTX_DECODER_LEXICON && d->wsInLds) || d->lean)) {
+      /* optimistic fast paths: the LDS sizing of the lexicon decoder assumes a
+       * sparse trie fan-out, and the lean lexicon-free step assumes the K-th
+       * best score can be isolated by one histogram pass.  Both flag the rare
+       * miss; redo the batch on the general path (HBM workspace / generic
+       * engine), which has no such assumption. */
       d->resultsSynced = false;
       if ((rc = syncResults(d))) {
         return rc;
       }
-      bool overflow = false;
+      bool redo = false;
       for (int b = 0; b < B; ++b) {
-        overflow |= (d->hStatus[b] & ST_CAND_OVERFLOW) != 0;
+        if ((d->hStatus[b] & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON) {
+          d->forceGlobalWs = 1;
+          redo = true;
+        }
+        if ((d->hStatus[b] & ST_SELECT_FALLBACK) && d->lean) {
+          d->noLean = 1;
+          redo = true;
+        }
       }
-      if (overflow) {
-        d->forceGlobalWs = 1;
+      if (redo) {
         d->resultsSynced = false;
         continue;
       }
@@ -1316,6 +1408,29 @@ int fltx_result_device(fltx_decoder* d, const int32_t** nHyp, const double** sco
   }
   if (tokOff) {
     *tokOff = d->histOffD.as<int64_t>();
+  }
+  return FLTX_OK;
+}
+
+/* phase profile of the last launch: out[8] = shader clocks summed over the
+ * utterances of the batch (0 prep, 1 generate, 2 fold, 3 select, 4 build,
+ * 5 row hand-over) */
+int fltx_decoder_profile(fltx_decoder* d, uint64_t* out) {
+  if (!d || !out) {
+    return fail(FLTX_ERR_INVALID, "null argument");
+  }
+  if (!d->profile || !d->prof.p) {
+    return fail(FLTX_ERR_STATE, "profiling is off: fltx_decoder_set(dec, \"profile\", 1)");
+  }
+  std::vector<unsigned long long> h(8 * (size_t)d->B);
+  if (devCopyD2H(h.data(), d->prof.p, 8 * h.size(), d->ctx->stream)) {
+    return fail(FLTX_ERR_HIP, "profile copy failed");
+  }
+  for (int i = 0; i < 8; ++i) {
+    out[i] = 0;
+  }
+  for (size_t i = 0; i < h.size(); ++i) {
+    out[i & 7] += h[i];
   }
   return FLTX_OK;
 }

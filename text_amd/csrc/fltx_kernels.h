@@ -124,24 +124,30 @@ struct DecodeParams {
   uint32_t stateCap; /* per utterance, power of two */
   uint32_t epoch;    /* 1..65535, bumped per decodeBegin */
   /* workspace geometry */
-  int32_t CAP, HS, NB;
+  int32_t CAP, HS, NB, SCAP;
+  int32_t dense; /* 1: lexicon-free frames use the hash-free dense merge */
   char* gws;          /* global workspace (big configurations), or null */
   int64_t gwsStride;
   /* results of decodeEnd */
   int32_t* outN;
   double* outScores;
+  /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
+  unsigned long long* prof;
 };
 
 struct Ws {
   /* beam, double buffered */
-  double* bScore[2];
-  double* bAm[2];
-  double* bLm[2];
-  uint32_t* bState[2];
-  uint32_t* bSPar[2];
-  int32_t* bSEdge[2];
-  uint32_t* bLex[2];
-  uint32_t* bTokPb[2];
+  /* (each array holds both buffers: index = buffer * K + slot; no arrays of
+   * pointers here -- a runtime-indexed pointer array would push this whole
+   * struct into scratch memory) */
+  double* bScore;
+  double* bAm;
+  double* bLm;
+  uint32_t* bState;
+  uint32_t* bSPar;
+  int32_t* bSEdge;
+  uint32_t* bLex;
+  uint32_t* bTokPb;
   /* candidate records */
   double* cScore;
   uint4* cKey;     /* {state parent, state edge, lex node, token | prevBlank<<31} */
@@ -154,9 +160,24 @@ struct Ws {
   uint32_t* lead;  /* group leaders (candidate index), later survivors */
   uint8_t* lstat;  /* per leader: 0 dropped, 1 active, 2 taken */
   uint16_t* lbin;
-  uint32_t* small; /* boundary-bin members */
+  uint32_t* small; /* boundary-bin members (slow select path) */
+  unsigned long long* sKey; /* [SCAP] compact short-list: order-preserving score key */
+  uint32_t* sOrd;  /* [SCAP] generation order (tie-break) */
+  uint32_t* sIdx;  /* [SCAP] candidate index */
+  uint32_t* sSrc;  /* [SCAP] source slot | kNewState (lean path) */
+  uint32_t* sBin;  /* [SCAP] histogram bin of the entry (lean path) */
+  uint32_t* sNext; /* [SCAP] next entry of the same bin (lean path) */
+  uint32_t* bhead; /* [NB] first short-list entry of a bin (lean path) */
+  uint32_t* hcum;  /* [NB] number of candidates in better bins (lean path) */
+  int32_t* pMate;  /* [16*64] per-wave partial relation results (lean path) */
+  int32_t* pPar;   /* [16*64] */
+  uint32_t* surv;  /* [K] candidate index of the survivor with rank r */
+  int32_t* dMate;  /* [K] dense merge: the other hypothesis in the same LM state */
+  int32_t* dPar;   /* [K] dense merge: representative slot of the parent LM state */
+  int16_t* dRep;   /* [K*N] dense merge: slot whose repeat feeds group (state, token) */
+  uint8_t* dIn;    /* [N] token is in this frame's short-list */
   uint32_t* hist;  /* [NB] */
-  float* erow[2];  /* emission row, double buffered */
+  float* erow;     /* [2*N] emission row, double buffered */
   int32_t* tokIdx; /* token short-list */
   uint32_t* wtmp;  /* [32] per-wave scratch for block scans */
   unsigned long long* red; /* [4] block reductions */
@@ -178,23 +199,22 @@ FLTX_HD size_t alignUp(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
-FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N) {
+FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
+                       int dense) {
   size_t off = 0;
 #define FLTX_CARVE(field, type, count)                       \
   off = alignUp(off, 16);                                    \
   field = (type*)(base ? base + off : nullptr);              \
   off += sizeof(type) * (size_t)(count);
-  for (int i = 0; i < 2; ++i) {
-    FLTX_CARVE(w.bScore[i], double, K)
-    FLTX_CARVE(w.bAm[i], double, K)
-    FLTX_CARVE(w.bLm[i], double, K)
-    FLTX_CARVE(w.bState[i], uint32_t, K)
-    FLTX_CARVE(w.bSPar[i], uint32_t, K)
-    FLTX_CARVE(w.bSEdge[i], int32_t, K)
-    FLTX_CARVE(w.bLex[i], uint32_t, K)
-    FLTX_CARVE(w.bTokPb[i], uint32_t, K)
-    FLTX_CARVE(w.erow[i], float, N)
-  }
+  FLTX_CARVE(w.bScore, double, 2 * K)
+  FLTX_CARVE(w.bAm, double, 2 * K)
+  FLTX_CARVE(w.bLm, double, 2 * K)
+  FLTX_CARVE(w.bState, uint32_t, 2 * K)
+  FLTX_CARVE(w.bSPar, uint32_t, 2 * K)
+  FLTX_CARVE(w.bSEdge, int32_t, 2 * K)
+  FLTX_CARVE(w.bLex, uint32_t, 2 * K)
+  FLTX_CARVE(w.bTokPb, uint32_t, 2 * K)
+  FLTX_CARVE(w.erow, float, 2 * N)
   FLTX_CARVE(w.cScore, double, CAP)
   FLTX_CARVE(w.cKey, uint4, CAP)
   FLTX_CARVE(w.cSrc, uint32_t, CAP)
@@ -207,6 +227,21 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N)
   FLTX_CARVE(w.lstat, uint8_t, CAP)
   FLTX_CARVE(w.lbin, uint16_t, CAP)
   FLTX_CARVE(w.small, uint32_t, CAP)
+  FLTX_CARVE(w.sKey, unsigned long long, SCAP)
+  FLTX_CARVE(w.sOrd, uint32_t, SCAP)
+  FLTX_CARVE(w.sIdx, uint32_t, SCAP)
+  FLTX_CARVE(w.sSrc, uint32_t, SCAP)
+  FLTX_CARVE(w.sBin, uint32_t, dense ? SCAP : 0)
+  FLTX_CARVE(w.sNext, uint32_t, dense ? SCAP : 0)
+  FLTX_CARVE(w.bhead, uint32_t, dense ? NB : 0)
+  FLTX_CARVE(w.hcum, uint32_t, dense ? NB : 0)
+  FLTX_CARVE(w.pMate, int32_t, dense ? 16 * 64 : 0)
+  FLTX_CARVE(w.pPar, int32_t, dense ? 16 * 64 : 0)
+  FLTX_CARVE(w.surv, uint32_t, K)
+  FLTX_CARVE(w.dMate, int32_t, dense ? K : 0)
+  FLTX_CARVE(w.dPar, int32_t, dense ? K : 0)
+  FLTX_CARVE(w.dRep, int16_t, dense ? (size_t)K * N : 0)
+  FLTX_CARVE(w.dIn, uint8_t, N)
   FLTX_CARVE(w.hist, uint32_t, NB)
   FLTX_CARVE(w.tokIdx, int32_t, N)
   FLTX_CARVE(w.wtmp, uint32_t, 32)
@@ -479,7 +514,26 @@ FLTX_DEV uint32_t stateChild(const DecodeParams& P, int b, uint32_t par, int32_t
 /* ------------------------------------------------------------------------ */
 /* candidate generation                                                      */
 /* ------------------------------------------------------------------------ */
+#ifdef FLTX_EMU
+FLTX_DEV unsigned long long devClock() { return 0ull; }
+#else
+FLTX_DEV unsigned long long devClock() { return __builtin_readcyclecounter(); }
+#endif
+/* accumulate the time since the previous mark into profile slot i (thread 0,
+ * register accumulators: a global read-modify-write per mark would stall the
+ * wave for ~2k clocks and distort what it measures) */
+#define FLTX_PROF(i)                                                   \
+  do {                                                                 \
+    if (P.prof && threadIdx.x == 0) {                                  \
+      const unsigned long long t_ = devClock();                        \
+      f.acc[(i)] += t_ - f.t0;                                         \
+      f.t0 = t_;                                                       \
+    }                                                                  \
+  } while (0)
+
 struct FrameCtx {
+  unsigned long long t0;
+  unsigned long long acc[8];
   int b;         /* utterance */
   int cur;       /* beam buffer holding hyp_[frame] */
   int nBeam;
@@ -504,29 +558,292 @@ FLTX_DEV void genLexFree(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     if (valid) {
       const int h = i / f.nTok, r = i - h * f.nTok;
       const int n = (f.nTok == P.N) ? r : w.tokIdx[r];
-      const uint32_t tp = w.bTokPb[f.cur][h];
+      const uint32_t tp = w.bTokPb[(f.cur) * P.K + h];
       const int prevTok = (int)(tp & 0x7FFFFFFFu);
       const bool prevBlank = (tp & kPrevBlank) != 0;
-      score = w.bScore[f.cur][h] + (double)f.e[n]; /* :64, transition excluded */
+      score = w.bScore[(f.cur) * P.K + h] + (double)f.e[n]; /* :64, transition excluded */
       if (n == P.sil) {
         score += P.silScore;
       }
       src = (uint32_t)h;
       const bool newTok = ctc ? (n != P.blank && (n != prevTok || prevBlank)) : (n != prevTok);
       if (newTok) { /* :69-85 */
-        lm = lmScoreDev(P, f.b, w.bState[f.cur][h], n);
+        lm = lmScoreDev(P, f.b, w.bState[(f.cur) * P.K + h], n);
         score = score + P.lmWeight * (double)lm;
-        kp = w.bState[f.cur][h];
+        kp = w.bState[(f.cur) * P.K + h];
         ke = (uint32_t)n;
         ktp = (uint32_t)n;
         src |= kNewState;
       } else { /* blank :86-97 / repeat :98-110 keep the LM state */
-        kp = w.bSPar[f.cur][h];
-        ke = (uint32_t)w.bSEdge[f.cur][h];
+        kp = w.bSPar[(f.cur) * P.K + h];
+        ke = (uint32_t)w.bSEdge[(f.cur) * P.K + h];
         ktp = (uint32_t)n | ((ctc && n == P.blank) ? kPrevBlank : 0u);
       }
     }
     pushCandidate(P, w, valid, score, kp, ke, 0u, ktp, src, -1, lm, (uint32_t)i, bestKey);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Dense (hash-free) merge for the lexicon-free decoder.                      */
+/*                                                                            */
+/* With key = (LM state, token, prevBlank) (LexiconFreeDecoder.h:68-78) the    */
+/* candidates of a frame fall into groups that can be enumerated without any  */
+/* search, because a beam holds at most two hypotheses per LM state S --       */
+/* (S, edge(S), pb=0) and, for CTC, (S, blank, pb=1):                          */
+/*   G[S][n], n != blank : the "new token n" candidates of the <= 2            */
+/*        hypotheses in state S, plus the *repeat* candidate of the hypothesis */
+/*        (child(S,n), n, 0) if that one is in the beam (its state's parent is */
+/*        S and its edge is n, so the keys coincide);                          */
+/*   G[S][blank] (CTC)   : the blank candidates of the <= 2 hypotheses in S;   */
+/*   orphan[h]           : the repeat candidate of a hypothesis whose parent   */
+/*        state has no hypothesis in the beam (nothing to merge with).         */
+/* One thread evaluates one group: <= 3 member scores, max or ordered log-add. */
+/* Records are written at the dense index g = rep*nTok + r (orphans after      */
+/* them) and only the groups that pass the threshold become leaders, so the    */
+/* prune and beam-build stages are shared with the generic hash path.          */
+/* Equal to the generic path by construction; tests run both.                  */
+/* ------------------------------------------------------------------------ */
+struct DenseMember {
+  double s;
+  uint32_t ord;
+  uint32_t src;
+  float lm;
+};
+
+FLTX_DEV void denseConsider(DenseMember& best, int& nMem, DenseMember* mem, const DenseMember& m) {
+  mem[nMem++] = m;
+  if (nMem == 1 || m.s > best.s || (m.s == best.s && m.ord < best.ord)) {
+    best = m;
+  }
+}
+
+/* Evaluate dense group g.  Returns false when the group has no member (that
+ * passes `thr` when useThr).  score = max, or the ordered log-add when logAdd. */
+FLTX_DEV bool denseEval(const DecodeParams& P, const Ws& w, const FrameCtx& f, int g, bool useThr,
+                        double thr, double& score, DenseMember& best, uint4& key) {
+  const bool ctc = P.criterion == 1;
+  const int cur = f.cur;
+  const int nGroups = f.nBeam * f.nTok;
+  DenseMember mem[3];
+  int nMem = 0;
+  if (g >= nGroups) { /* orphan repeat of hypothesis h */
+    const int h = g - nGroups;
+    if (h >= f.nBeam) {
+      return false;
+    }
+    const uint32_t tp = w.bTokPb[(cur) * P.K + h];
+    const int t = (int)(tp & 0x7FFFFFFFu);
+    if ((tp & kPrevBlank) || (ctc && t == P.blank) || w.dPar[h] >= 0 || !w.dIn[t]) {
+      return false;
+    }
+    int r = t;
+    if (f.nTok != P.N) { /* position of t in the short-list (for the generation order) */
+      for (r = 0; r < f.nTok && w.tokIdx[r] != t; ++r) {
+      }
+    }
+    double s = w.bScore[(cur) * P.K + h] + (double)f.e[t];
+    if (t == P.sil) {
+      s += P.silScore;
+    }
+    if (s != s || (useThr && !(s >= thr))) {
+      return false;
+    }
+    best = DenseMember{s, (uint32_t)(h * f.nTok + r), (uint32_t)h, 0.0f};
+    score = s;
+    key = make_uint4(w.bSPar[(cur) * P.K + h], (uint32_t)w.bSEdge[(cur) * P.K + h], 0u, (uint32_t)t);
+    return true;
+  }
+  const int rep = g / f.nTok, r = g - rep * f.nTok;
+  const int mate = w.dMate[rep];
+  if (mate >= 0 && mate < rep) {
+    return false; /* the lower slot of the pair evaluates the state's groups */
+  }
+  const int n = (f.nTok == P.N) ? r : w.tokIdx[r];
+  const double en = (double)f.e[n];
+  const uint32_t sid = w.bState[(cur) * P.K + rep];
+  if (ctc && n == P.blank) { /* LexiconFreeDecoder.cpp:86-97 */
+    for (int q = 0; q < 2; ++q) {
+      const int h = q == 0 ? rep : mate;
+      if (h < 0) {
+        continue;
+      }
+      double s = w.bScore[(cur) * P.K + h] + en;
+      if (n == P.sil) {
+        s += P.silScore;
+      }
+      if (s != s || (useThr && !(s >= thr))) {
+        continue;
+      }
+      denseConsider(best, nMem, mem, DenseMember{s, (uint32_t)(h * f.nTok + r), (uint32_t)h, 0.0f});
+    }
+    key = make_uint4(w.bSPar[(cur) * P.K + rep], (uint32_t)w.bSEdge[(cur) * P.K + rep], 0u, (uint32_t)n | kPrevBlank);
+  } else {
+    float lm = 0.0f;
+    bool haveLm = false;
+    for (int q = 0; q < 2; ++q) { /* new token n from the hypotheses in state S, :69-85 */
+      const int h = q == 0 ? rep : mate;
+      if (h < 0) {
+        continue;
+      }
+      const uint32_t tp = w.bTokPb[(cur) * P.K + h];
+      const int prevTok = (int)(tp & 0x7FFFFFFFu);
+      const bool prevBlank = (tp & kPrevBlank) != 0;
+      const bool newTok = ctc ? (n != prevTok || prevBlank) : (n != prevTok);
+      if (!newTok) {
+        continue; /* a repeat of h: belongs to h's own state group */
+      }
+      if (!haveLm) {
+        lm = lmScoreDev(P, f.b, sid, n);
+        haveLm = true;
+      }
+      double s = w.bScore[(cur) * P.K + h] + en;
+      if (n == P.sil) {
+        s += P.silScore;
+      }
+      s = s + P.lmWeight * (double)lm;
+      if (s != s || (useThr && !(s >= thr))) {
+        continue;
+      }
+      denseConsider(best, nMem, mem, DenseMember{s, (uint32_t)(h * f.nTok + r), (uint32_t)h | kNewState, lm});
+    }
+    const int hr = (int)w.dRep[rep * P.N + n]; /* repeat of (child(S,n), n, 0), :98-110 */
+    if (hr >= 0) {
+      double s = w.bScore[(cur) * P.K + hr] + en;
+      if (n == P.sil) {
+        s += P.silScore;
+      }
+      if (!(s != s || (useThr && !(s >= thr)))) {
+        denseConsider(best, nMem, mem, DenseMember{s, (uint32_t)(hr * f.nTok + r), (uint32_t)hr, 0.0f});
+      }
+    }
+    key = make_uint4(sid, (uint32_t)n, 0u, (uint32_t)n);
+  }
+  if (nMem == 0) {
+    return false;
+  }
+  score = best.s;
+  if (P.logAdd && nMem > 1) { /* Utils.h:186-193: descending order, left to right */
+    for (int a = 0; a < nMem; ++a) { /* tiny insertion sort by (score desc, ord asc) */
+      for (int c = a + 1; c < nMem; ++c) {
+        if (mem[c].s > mem[a].s || (mem[c].s == mem[a].s && mem[c].ord < mem[a].ord)) {
+          const DenseMember t = mem[a];
+          mem[a] = mem[c];
+          mem[c] = t;
+        }
+      }
+    }
+    double acc = mem[0].s;
+    for (int a = 1; a < nMem; ++a) {
+      const double mx = acc > mem[a].s ? acc : mem[a].s;
+      const double mn = acc > mem[a].s ? mem[a].s : acc;
+      acc = mx + log1p(exp(mn - mx));
+    }
+    score = acc;
+  }
+  return true;
+}
+
+/* per-frame relation tables: mate (same LM state), parent representative,
+ * repeat table; two barriers */
+FLTX_DEV void densePrepare(const DecodeParams& P, const Ws& w, const FrameCtx& f) {
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  const int cur = f.cur;
+  const bool ctc = P.criterion == 1;
+  for (int i = tid; i < f.nBeam * P.N; i += W) {
+    w.dRep[i] = (int16_t)-1;
+  }
+  for (int n = tid; n < P.N; n += W) {
+    w.dIn[n] = (f.nTok == P.N) ? 1 : 0;
+  }
+  for (int h = tid; h < f.nBeam; h += W) {
+    const uint32_t sid = w.bState[(cur) * P.K + h];
+    const uint32_t sp = w.bSPar[(cur) * P.K + h];
+    int mate = -1, par = -1;
+    for (int h2 = 0; h2 < f.nBeam; ++h2) {
+      const uint32_t s2 = w.bState[(cur) * P.K + h2];
+      if (s2 == sid && h2 != h) {
+        mate = h2;
+      }
+      if (s2 == sp && par < 0) {
+        par = h2; /* lowest slot in the parent state = its representative */
+      }
+    }
+    w.dMate[h] = mate;
+    w.dPar[h] = par;
+  }
+  __syncthreads();
+  if (f.nTok != P.N) {
+    for (int r = tid; r < f.nTok; r += W) {
+      w.dIn[w.tokIdx[r]] = 1;
+    }
+  }
+  for (int h = tid; h < f.nBeam; h += W) {
+    const uint32_t tp = w.bTokPb[(cur) * P.K + h];
+    const int t = (int)(tp & 0x7FFFFFFFu);
+    const int par = w.dPar[h];
+    if (!(tp & kPrevBlank) && !(ctc && t == P.blank) && par >= 0 && w.bSEdge[(cur) * P.K + h] == t) {
+      w.dRep[par * P.N + t] = (int16_t)h;
+    } else if (!(tp & kPrevBlank) && !(ctc && t == P.blank) && par >= 0) {
+      w.dPar[h] = -1; /* cannot happen (edge == token when pb == 0); stay correct anyway */
+    }
+  }
+  __syncthreads();
+}
+
+/* Phase 1: best score over all candidates.  Phase 2 (after the threshold is
+ * known): leaders with complete records. */
+FLTX_DEV void genLexFreeDense(const DecodeParams& P, const Ws& w, const FrameCtx& f,
+                              unsigned long long& bestKey) {
+  const int W = (int)blockDim.x;
+  const int total = f.nBeam * f.nTok + f.nBeam;
+  for (int g = (int)threadIdx.x; g < total; g += W) {
+    double sc;
+    DenseMember best;
+    uint4 key;
+    /* the threshold applies per member, but the best candidate of the frame
+     * is a single member, so the un-thresholded member maximum is what
+     * candidatesAdd tracks (Utils.h:138-140) */
+    const bool saveLog = false;
+    (void)saveLog;
+    if (denseEval(P, w, f, g, false, 0.0, sc, best, key)) {
+      const unsigned long long k = f64Key(best.s);
+      bestKey = k > bestKey ? k : bestKey;
+    }
+  }
+}
+
+FLTX_DEV void denseLeaders(const DecodeParams& P, const Ws& w, const FrameCtx& f, double thr) {
+  const int W = (int)blockDim.x;
+  const int total = f.nBeam * f.nTok + f.nBeam;
+  const int rounds = (total + W - 1) / W;
+  for (int it = 0; it < rounds; ++it) {
+    const int g = it * W + (int)threadIdx.x;
+    double sc = 0;
+    DenseMember best;
+    uint4 key;
+    const bool isLead = g < total && denseEval(P, w, f, g, true, thr, sc, best, key);
+    const unsigned long long m = waveBallot(isLead);
+    if (m != 0ull) {
+      const int lane = laneId();
+      const int leader = __builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) {
+        base = atomAdd32((uint32_t*)&w.sc[SC_NLEAD], (uint32_t)popc64(m));
+      }
+      base = waveShfl32(base, leader);
+      if (isLead) {
+        const uint32_t li = base + (uint32_t)popc64(m & ((1ull << lane) - 1ull));
+        w.lead[li] = (uint32_t)g;
+        w.cScore[g] = sc;
+        w.cKey[g] = key;
+        w.cSrc[g] = best.src;
+        w.cAux[g] = -1;
+        w.cLm[g] = best.lm;
+        w.cOrd[g] = best.ord;
+      }
+    }
   }
 }
 
@@ -559,15 +876,15 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     if (valid) {
       h = i / per;
       const int r = i - h * per;
-      const uint32_t tp = w.bTokPb[f.cur][h];
+      const uint32_t tp = w.bTokPb[(f.cur) * P.K + h];
       const int prevTok = (int)(tp & 0x7FFFFFFFu);
       const bool prevBlank = (tp & kPrevBlank) != 0;
-      lexId = w.bLex[f.cur][h];
-      sid = w.bState[f.cur][h];
-      spar = w.bSPar[f.cur][h];
-      sedge = w.bSEdge[f.cur][h];
+      lexId = w.bLex[(f.cur) * P.K + h];
+      sid = w.bState[(f.cur) * P.K + h];
+      spar = w.bSPar[(f.cur) * P.K + h];
+      sedge = w.bSEdge[(f.cur) * P.K + h];
       const bool atRoot = lexId == 0u;
-      const double hs = w.bScore[f.cur][h];
+      const double hs = w.bScore[(f.cur) * P.K + h];
       if (r < f.nTok) { /* (1) children, :62-165 */
         n = (f.nTok == P.N) ? r : w.tokIdx[r];
         const int32_t c = P.trieChild[(size_t)lexId * P.N + n];
@@ -681,7 +998,7 @@ FLTX_DEV void genEnd(const DecodeParams& P, const Ws& w, const FrameCtx& f,
   bool nice = false;
   if (P.kind == 1) {
     for (int h = 0; h < f.nBeam; ++h) {
-      if (w.bLex[f.cur][h] == 0u) {
+      if (w.bLex[(f.cur) * P.K + h] == 0u) {
         nice = true;
         break;
       }
@@ -696,22 +1013,22 @@ FLTX_DEV void genEnd(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     float l = 0.0f;
     uint32_t kp = 0, ke = 0, lex = 0, src = 0;
     if (valid) {
-      lex = w.bLex[f.cur][h];
+      lex = w.bLex[(f.cur) * P.K + h];
       if (P.kind == 1 && nice && lex != 0u) {
         valid = false;
       }
     }
     if (valid) {
-      const uint32_t sid = w.bState[f.cur][h];
+      const uint32_t sid = w.bState[(f.cur) * P.K + h];
       l = lmFinishDev(P, f.b, sid);
-      sc = w.bScore[f.cur][h] + P.lmWeight * (double)l;
+      sc = w.bScore[(f.cur) * P.K + h] + P.lmWeight * (double)l;
       if (finishChild) {
         kp = sid;
         ke = (uint32_t)kFinishEdge;
         src = (uint32_t)h | kNewState;
       } else {
-        kp = w.bSPar[f.cur][h];
-        ke = (uint32_t)w.bSEdge[f.cur][h];
+        kp = w.bSPar[(f.cur) * P.K + h];
+        ke = (uint32_t)w.bSEdge[(f.cur) * P.K + h];
         src = (uint32_t)h;
       }
     }
@@ -948,40 +1265,167 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
   __syncthreads();
 }
 
+/* Fast path of the prune: ONE histogram pass over the leaders locates the bin
+ * holding the K-th best score; every leader in that bin or a better one goes
+ * to a compact short-list (K + a few entries, contiguous u64 keys) on which an
+ * exact rank by (score desc, generation order) is computed.  rank < K survive
+ * and the rank IS the slot in the next beam.  Falls back to the iterative
+ * selectTopK() when the short-list would not fit (degenerate distributions).
+ * Returns the number of survivors; w.surv[r] = candidate index of rank r. */
+FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K) {
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  if (nLead <= 0) {
+    return 0;
+  }
+  const int nS = nLead < K ? nLead : K;
+  int L = 0;
+  const int direct = P.SCAP < 128 ? P.SCAP : 128;
+  bool slow = false;
+  if (nLead <= direct) {
+    for (int i = tid; i < nLead; i += W) {
+      const uint32_t c = w.lead[i];
+      w.sKey[i] = f64Key(w.cScore[c]);
+      w.sOrd[i] = w.cOrd[c];
+      w.sIdx[i] = c;
+    }
+    L = nLead;
+    __syncthreads();
+  } else {
+    /* range of the leaders' scores (-inf is parked in the last bin) */
+    unsigned long long kmax = 0ull, kmin = ~0ull;
+    for (int i = tid; i < nLead; i += W) {
+      const double sc = w.cScore[w.lead[i]];
+      const unsigned long long k = f64Key(sc);
+      kmax = k > kmax ? k : kmax;
+      if (sc > -__builtin_huge_val()) {
+        kmin = k < kmin ? k : kmin;
+      }
+    }
+    if (tid == 0) {
+      w.red[0] = 0ull;
+      w.red[1] = ~0ull;
+      w.sc[SC_NSMALL] = 0;
+    }
+    for (int i = tid; i < P.NB; i += W) {
+      w.hist[i] = 0;
+    }
+    __syncthreads();
+    kmax = waveMax64(kmax);
+    kmin = waveMin64(kmin);
+    if (laneId() == 0) {
+      atomMax64(&w.red[0], kmax);
+      atomMin64(&w.red[1], kmin);
+    }
+    __syncthreads();
+    const double hi = f64FromKey(w.red[0]);
+    const double lo = w.red[1] == ~0ull ? hi : f64FromKey(w.red[1]);
+    const double scale = (double)P.NB / (hi - lo);
+    if (!(hi > lo) || !(scale > 0.0) || !(scale < 1e300)) {
+      slow = true;
+    } else {
+      for (int i = tid; i < nLead; i += W) {
+        const double sc = w.cScore[w.lead[i]];
+        const double x = (hi - sc) * scale;
+        int bin = (x < (double)P.NB) ? (int)x : P.NB - 1;
+        bin = bin < 0 ? 0 : bin;
+        w.lbin[i] = (uint16_t)bin;
+        atomAdd32(&w.hist[bin], 1u);
+      }
+      __syncthreads();
+      const int per = (P.NB + W - 1) / W;
+      int mine = 0;
+      for (int q = 0; q < per; ++q) {
+        const int bi = tid * per + q;
+        if (bi < P.NB) {
+          mine += (int)w.hist[bi];
+        }
+      }
+      int tot;
+      const int before = blockExclusiveScan(mine, w.wtmp, &tot);
+      if (before < K && before + mine >= K) {
+        int cum = before;
+        for (int q = 0; q < per; ++q) {
+          const int bi = tid * per + q;
+          const int c = (int)w.hist[bi];
+          if (cum + c >= K) {
+            w.sc[SC_BSTAR] = bi;
+            w.sc[SC_CUM] = cum + c;
+            break;
+          }
+          cum += c;
+        }
+      }
+      __syncthreads();
+      const int bstar = w.sc[SC_BSTAR];
+      L = w.sc[SC_CUM];
+      if (L > P.SCAP) {
+        slow = true;
+      } else {
+        for (int i = tid; i < nLead; i += W) {
+          if ((int)w.lbin[i] <= bstar) {
+            const uint32_t p = atomAdd32((uint32_t*)&w.sc[SC_NSMALL], 1u);
+            const uint32_t c = w.lead[i];
+            w.sKey[p] = f64Key(w.cScore[c]);
+            w.sOrd[p] = w.cOrd[c];
+            w.sIdx[p] = c;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (slow) {
+      selectTopK(P, w, nLead, K);
+      if (tid == 0) {
+        w.sc[SC_NSMALL] = 0;
+      }
+      __syncthreads();
+      for (int i = tid; i < nLead; i += W) {
+        if (w.lstat[i] == 2) {
+          const uint32_t p = atomAdd32((uint32_t*)&w.sc[SC_NSMALL], 1u);
+          const uint32_t c = w.lead[i];
+          w.sKey[p] = f64Key(w.cScore[c]);
+          w.sOrd[p] = w.cOrd[c];
+          w.sIdx[p] = c;
+        }
+      }
+      __syncthreads();
+      L = nS;
+    }
+  }
+  /* exact rank on the short-list: contiguous, broadcast LDS reads */
+  for (int j = tid; j < L; j += W) {
+    const unsigned long long k = w.sKey[j];
+    const uint32_t o = w.sOrd[j];
+    int rank = 0;
+    for (int q = 0; q < L; ++q) {
+      const unsigned long long k2 = w.sKey[q];
+      const uint32_t o2 = w.sOrd[q];
+      rank += (k2 > k || (k2 == k && o2 < o)) ? 1 : 0;
+    }
+    if (rank < K) {
+      w.surv[rank] = w.sIdx[j];
+    }
+  }
+  __syncthreads();
+  return nS;
+}
+
 /* ------------------------------------------------------------------------ */
 /* survivors -> next beam + history (candidatesStore step 4, Utils.h:222-224) */
 /* The beam is kept sorted (score desc, generation order) so the layout is a   */
 /* deterministic function of the inputs; decodeEnd needs the sort anyway       */
 /* (returnSorted, Utils.h:213-219).                                           */
 /* ------------------------------------------------------------------------ */
-FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, int nLead,
+FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, int nS,
                        int frameOut, bool isEnd) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   const int nxt = f.cur ^ 1;
-  /* compact survivors (indices into lead[]) into small[] */
-  if (tid == 0) {
-    w.sc[SC_NSURV] = 0;
-  }
-  __syncthreads();
-  for (int i = tid; i < nLead; i += W) {
-    if (w.lstat[i] == 2) {
-      const uint32_t p = atomAdd32((uint32_t*)&w.sc[SC_NSURV], 1u);
-      w.small[p] = (uint32_t)i;
-    }
-  }
-  __syncthreads();
-  const int nS = w.sc[SC_NSURV];
   const int64_t hbase = P.histOff[f.b] + (int64_t)frameOut * P.K;
-  for (int j = tid; j < nS; j += W) {
-    const uint32_t c = w.lead[w.small[j]];
+  for (int rank = tid; rank < nS; rank += W) {
+    const uint32_t c = w.surv[rank];
     const double sc = w.cScore[c];
-    const uint32_t o = w.cOrd[c];
-    int rank = 0;
-    for (int q = 0; q < nS; ++q) {
-      const uint32_t c2 = w.lead[w.small[q]];
-      rank += precedes(w.cScore[c2], w.cOrd[c2], sc, o) ? 1 : 0;
-    }
     const uint4 key = w.cKey[c];
     const uint32_t src = w.cSrc[c];
     const int h = (int)(src & 0x7FFFFFFFu);
@@ -989,12 +1433,12 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
     const float lmd = w.cLm[c];
     /* emitting-model score: recompute the candidate's delta (LexiconFree:
      * transition goes into am only, :59-64; Lexicon: am == score delta) */
-    double am = w.bAm[f.cur][h];
+    double am = w.bAm[(f.cur) * P.K + h];
     if (!isEnd) {
       double d = (double)f.e[n];
       const bool isBlankCand = (key.w & kPrevBlank) != 0;
       if (f.useTrans && !(P.kind == 1 && isBlankCand)) {
-        const int prevTok = (int)(w.bTokPb[f.cur][h] & 0x7FFFFFFFu);
+        const int prevTok = (int)(w.bTokPb[(f.cur) * P.K + h] & 0x7FFFFFFFu);
         d += (double)P.transitions[(size_t)n * P.N + prevTok];
       }
       am += d;
@@ -1022,16 +1466,16 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
         }
       }
     } else {
-      sid = w.bState[f.cur][h];
+      sid = w.bState[(f.cur) * P.K + h];
     }
-    w.bScore[nxt][rank] = sc;
-    w.bAm[nxt][rank] = am;
-    w.bLm[nxt][rank] = w.bLm[f.cur][h] + (double)lmd;
-    w.bState[nxt][rank] = sid;
-    w.bSPar[nxt][rank] = key.x;
-    w.bSEdge[nxt][rank] = (int32_t)key.y;
-    w.bLex[nxt][rank] = key.z;
-    w.bTokPb[nxt][rank] = key.w;
+    w.bScore[(nxt) * P.K + rank] = sc;
+    w.bAm[(nxt) * P.K + rank] = am;
+    w.bLm[(nxt) * P.K + rank] = w.bLm[(f.cur) * P.K + h] + (double)lmd;
+    w.bState[(nxt) * P.K + rank] = sid;
+    w.bSPar[(nxt) * P.K + rank] = key.x;
+    w.bSEdge[(nxt) * P.K + rank] = (int32_t)key.y;
+    w.bLex[(nxt) * P.K + rank] = key.z;
+    w.bTokPb[(nxt) * P.K + rank] = key.w;
     P.histPT[hbase + rank] = make_int2(h, n);
     if (P.kind == 1) {
       P.histW[hbase + rank] = w.cAux[c];
@@ -1074,9 +1518,14 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
     tokenShortlist(P, w, f.e, f.nTok);
   }
   __syncthreads();
+  FLTX_PROF(0);
+  const bool dense = !isEnd && P.kind == 0 && P.dense != 0;
   unsigned long long bestKey = 0ull;
   if (isEnd) {
     genEnd(P, w, f, bestKey);
+  } else if (dense) {
+    densePrepare(P, w, f);
+    genLexFreeDense(P, w, f, bestKey);
   } else if (P.kind == 0) {
     genLexFree(P, w, f, bestKey);
   } else {
@@ -1087,41 +1536,41 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
     atomMax64(&w.red[2], bestKey);
   }
   __syncthreads();
-  int nCand = w.sc[SC_NCAND];
-  nCand = nCand > P.CAP ? P.CAP : nCand;
-  if (nCand == 0) {
-    return 0;
+  if (w.red[2] == 0ull) {
+    return 0; /* no candidate at all */
   }
   const double best = f64FromKey(w.red[2]);
   const double thr = best - P.beamThreshold; /* Utils.h:219 call sites */
-#ifdef FLTX_EMU_TRACE
-  if (threadIdx.x == 0 && getenv("FLTX_TRACE_FRAME") && atoi(getenv("FLTX_TRACE_FRAME")) == frameOut) {
-    printf("frame %d: nCand %d best %.6f\n", frameOut, nCand, best);
-    for (int i = 0; i < nCand; ++i) {
-      const uint4 k = w.cKey[i];
-      printf("  cand %3d score %.6f key(%u,%d,%u,%u|%d) src %u aux %d ord %u\n", i, w.cScore[i], k.x,
-             (int)k.y, k.z, k.w & 0x7FFFFFFFu, (int)(k.w >> 31), w.cSrc[i] & 0x7FFFFFFFu, w.cAux[i],
-             w.cOrd[i]);
-    }
+  FLTX_PROF(1);
+  if (dense) {
+    denseLeaders(P, w, f, thr);
+  } else {
+    foldGroups(P, w, thr);
   }
   __syncthreads();
-#endif
-  foldGroups(P, w, thr);
-  __syncthreads();
+  FLTX_PROF(2);
   const int nLead = w.sc[SC_NLEAD];
-  selectTopK(P, w, nLead, P.K);
-  return buildBeam(P, w, f, nLead, frameOut, isEnd);
+  const int nS = selectAndRank(P, w, nLead, P.K);
+  FLTX_PROF(3);
+  const int nB = buildBeam(P, w, f, nS, frameOut, isEnd);
+  FLTX_PROF(4);
+  return nB;
 }
 
+#include "fltx_lean.h"
+
 /* ------------------------------------------------------------------------ */
-/* the decode kernel: grid = utterances, block = W threads                   */
+/* the decode kernel: grid = utterances, block = W threads.                  */
+/* GMAX == 0: generic engine; GMAX > 0: lean lexicon-free + ZeroLM frame step */
+/* with up to GMAX candidate groups per thread (fltx_lean.h).                 */
 /* ------------------------------------------------------------------------ */
+template <int GMAX>
 FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const int b = (int)blockIdx.x;
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
-  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N);
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {
@@ -1130,14 +1579,14 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   if (P.doBegin) {
     /* decodeBegin (LexiconFreeDecoder.cpp:20-28, LexiconDecoder.cpp:21-30) */
     if (tid == 0) {
-      w.bScore[0][0] = 0.0;
-      w.bAm[0][0] = 0.0;
-      w.bLm[0][0] = 0.0;
-      w.bState[0][0] = 0u;
-      w.bSPar[0][0] = kNoParent;
-      w.bSEdge[0][0] = 0;
-      w.bLex[0][0] = 0u;
-      w.bTokPb[0][0] = (uint32_t)P.sil;
+      w.bScore[(0) * P.K + 0] = 0.0;
+      w.bAm[(0) * P.K + 0] = 0.0;
+      w.bLm[(0) * P.K + 0] = 0.0;
+      w.bState[(0) * P.K + 0] = 0u;
+      w.bSPar[(0) * P.K + 0] = kNoParent;
+      w.bSEdge[(0) * P.K + 0] = 0;
+      w.bLex[(0) * P.K + 0] = 0u;
+      w.bTokPb[(0) * P.K + 0] = (uint32_t)P.sil;
       const int64_t hb = P.histOff[b];
       P.histPT[hb] = make_int2(-1, P.sil);
       if (P.kind == 1) {
@@ -1163,14 +1612,14 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     total = P.uttTotal[b];
     for (int i = tid; i < nBeam; i += W) {
       const size_t g = (size_t)b * P.K + i;
-      w.bScore[0][i] = P.gScore[g];
-      w.bAm[0][i] = P.gAm[g];
-      w.bLm[0][i] = P.gLm[g];
-      w.bState[0][i] = P.gState[g];
-      w.bSPar[0][i] = P.gSPar[g];
-      w.bSEdge[0][i] = P.gSEdge[g];
-      w.bLex[0][i] = P.gLex[g];
-      w.bTokPb[0][i] = P.gTokPb[g];
+      w.bScore[(0) * P.K + i] = P.gScore[g];
+      w.bAm[(0) * P.K + i] = P.gAm[g];
+      w.bLm[(0) * P.K + i] = P.gLm[g];
+      w.bState[(0) * P.K + i] = P.gState[g];
+      w.bSPar[(0) * P.K + i] = P.gSPar[g];
+      w.bSEdge[(0) * P.K + i] = P.gSEdge[g];
+      w.bLex[(0) * P.K + i] = P.gLex[g];
+      w.bTokPb[(0) * P.K + i] = P.gTokPb[g];
     }
   }
   const int T = P.stepT ? P.stepT[b] : 0;
@@ -1184,13 +1633,22 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const bool regPrefetch = N <= PF * W;
   if (T > 0) {
     for (int n = tid; n < N; n += W) {
-      w.erow[0][n] = em[n];
+      w.erow[n] = em[n];
     }
   }
   __syncthreads();
   FrameCtx f;
   f.b = b;
   f.nTok = nTok;
+  f.t0 = devClock();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    f.acc[q] = 0ull;
+  }
+  LeanMap<(GMAX > 0 ? GMAX : 1)> lmap;
+  if constexpr (GMAX > 0) {
+    leanMapInit(P, nTok, lmap);
+  }
   for (int t = 0; t < T; ++t) {
     const int rb = t & 1;
     if (t + 1 < T) {
@@ -1205,9 +1663,13 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     }
     f.cur = cur;
     f.nBeam = nBeam;
-    f.e = w.erow[rb];
+    f.e = w.erow + rb * P.N;
     f.useTrans = (P.criterion == 0) && (total + t > 0) && P.transitions != nullptr;
-    nBeam = runFrame(P, w, f, frame + t + 1, false);
+    if constexpr (GMAX > 0) {
+      nBeam = runFrameLean<GMAX>(P, w, f, lmap, frame + t + 1);
+    } else {
+      nBeam = runFrame(P, w, f, frame + t + 1, false);
+    }
     cur ^= 1; /* with nBeam == 0 either buffer is equally empty */
     if (t + 1 < T) {
       if (regPrefetch) {
@@ -1215,50 +1677,65 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
         for (int q = 0; q < PF; ++q) {
           const int n = tid + q * W;
           if (n < N) {
-            w.erow[rb ^ 1][n] = pre[q];
+            w.erow[(rb ^ 1) * P.N + n] = pre[q];
           }
         }
       } else {
         const float* nx = em + (size_t)(t + 1) * N;
         for (int n = tid; n < N; n += W) {
-          w.erow[rb ^ 1][n] = nx[n];
+          w.erow[(rb ^ 1) * P.N + n] = nx[n];
         }
       }
     }
-    __syncthreads();
+    if constexpr (GMAX > 0) {
+      ldsBarrier(); /* the row hand-over is LDS only; back-pointer stores stay in flight */
+    } else {
+      __syncthreads();
+    }
+    FLTX_PROF(5);
   }
   frame += T;
   total += T;
   if (P.doEnd) {
     f.cur = cur;
     f.nBeam = nBeam;
-    f.e = w.erow[0];
+    f.e = w.erow;
     f.useTrans = false;
-    nBeam = nBeam > 0 ? runFrame(P, w, f, frame + 1, true) : 0;
+    if constexpr (GMAX > 0) {
+      nBeam = nBeam > 0 ? runEndLean(P, w, f, frame + 1) : 0;
+    } else {
+      nBeam = nBeam > 0 ? runFrame(P, w, f, frame + 1, true) : 0;
+    }
     cur ^= 1;
     frame += 1;
     total += 1;
     for (int i = tid; i < nBeam; i += W) {
       const size_t g = ((size_t)b * P.K + i) * 3;
-      P.outScores[g + 0] = w.bScore[cur][i];
-      P.outScores[g + 1] = w.bAm[cur][i];
-      P.outScores[g + 2] = w.bLm[cur][i];
+      P.outScores[g + 0] = w.bScore[(cur) * P.K + i];
+      P.outScores[g + 1] = w.bAm[(cur) * P.K + i];
+      P.outScores[g + 2] = GMAX > 0 ? 0.0 : w.bLm[(cur) * P.K + i]; /* ZeroLM: lmScore stays 0 */
     }
     if (tid == 0) {
       P.outN[b] = nBeam;
     }
   }
+  if (P.prof && tid == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      P.prof[(size_t)b * 8 + q] = f.acc[q];
+    }
+  }
   /* park the beam in HBM for the next decodeStep / prune / best */
   for (int i = tid; i < nBeam; i += W) {
     const size_t g = (size_t)b * P.K + i;
-    P.gScore[g] = w.bScore[cur][i];
-    P.gAm[g] = w.bAm[cur][i];
-    P.gLm[g] = w.bLm[cur][i];
-    P.gState[g] = w.bState[cur][i];
-    P.gSPar[g] = w.bSPar[cur][i];
-    P.gSEdge[g] = w.bSEdge[cur][i];
-    P.gLex[g] = w.bLex[cur][i];
-    P.gTokPb[g] = w.bTokPb[cur][i];
+    P.gScore[g] = w.bScore[(cur) * P.K + i];
+    P.gAm[g] = w.bAm[(cur) * P.K + i];
+    P.gLm[g] = GMAX > 0 ? 0.0 : w.bLm[(cur) * P.K + i];
+    P.gState[g] = w.bState[(cur) * P.K + i];
+    P.gSPar[g] = w.bSPar[(cur) * P.K + i];
+    P.gSEdge[g] = w.bSEdge[(cur) * P.K + i];
+    P.gLex[g] = GMAX > 0 ? 0u : w.bLex[(cur) * P.K + i];
+    P.gTokPb[g] = w.bTokPb[(cur) * P.K + i];
   }
   __syncthreads();
   if (tid == 0) {

@@ -58,11 +58,23 @@ FLTX_DEV uint32_t ldsLoad32(const uint32_t* p) {
 /* LDS instructions of one wave execute in program order; this only stops the
  * compiler from reordering the record write past the publishing atomic. */
 FLTX_DEV void compilerFence() { __asm__ volatile("" ::: "memory"); }
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+ * vmcnt, i.e. waits for every global load/store in flight (~2k clocks for the
+ * emission prefetch, the back-pointer stores ...); the frame step exchanges
+ * data between threads through LDS only, so those stay in flight. */
+FLTX_DEV void ldsBarrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 /* ---- wave-level primitives (wave64) --------------------------------------- */
 FLTX_DEV unsigned long long waveBallot(bool p) { return __ballot(p); }
 FLTX_DEV int popc64(unsigned long long m) { return __popcll(m); }
-FLTX_DEV uint32_t waveShfl32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+/* src must be wave-uniform: v_readlane_b32 (VALU) instead of ds_bpermute (LDS crossbar) */
+FLTX_DEV uint32_t waveShfl32(uint32_t v, int src) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
+}
+/* broadcast lane `src` (must be wave-uniform) -- v_readlane_b32 */
+FLTX_DEV uint32_t waveReadLane32(uint32_t v, int src) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+}
 FLTX_DEV int waveShflUpI(int v, int d) { return __shfl_up(v, d, 64); }
 FLTX_DEV unsigned long long waveShflXor64(unsigned long long v, int m) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -85,33 +97,47 @@ FLTX_DEV double f64FromKey(unsigned long long k) {
 }
 
 #ifndef FLTX_EMU
+/* Wave64 scans/reductions on the DPP data path (VALU speed) instead of
+ * ds_bpermute shuffles (LDS crossbar, ~100 clocks per step on a latency-bound
+ * wave).  gfx9-family pattern: Hillis-Steele inside each row of 16 lanes with
+ * row_shr:1,2,4,8, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into
+ * rows 2 and 3.  Lanes without a source read the identity (old = 0). */
+template <int CTRL, int ROWMASK>
+FLTX_DEV uint32_t dppTake(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true);
+}
+template <int CTRL, int ROWMASK>
+FLTX_DEV unsigned long long dppTake64(unsigned long long v) {
+  const uint32_t lo = dppTake<CTRL, ROWMASK>((uint32_t)v);
+  const uint32_t hi = dppTake<CTRL, ROWMASK>((uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+#define FLTX_DPP_SCAN(v, OP, TAKE)                 \
+  v = OP(v, TAKE<0x111, 0xf>(v)); /* row_shr:1 */  \
+  v = OP(v, TAKE<0x112, 0xf>(v)); /* row_shr:2 */  \
+  v = OP(v, TAKE<0x114, 0xf>(v)); /* row_shr:4 */  \
+  v = OP(v, TAKE<0x118, 0xf>(v)); /* row_shr:8 */  \
+  v = OP(v, TAKE<0x142, 0xa>(v)); /* row_bcast:15 -> rows 1,3 */ \
+  v = OP(v, TAKE<0x143, 0xc>(v)); /* row_bcast:31 -> rows 2,3 */
+FLTX_DEV unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+FLTX_DEV uint32_t uadd32(uint32_t a, uint32_t b) { return a + b; }
+FLTX_DEV unsigned long long waveBcastLast64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+/* max over the wave, result in every lane (0 is the identity: keys are unsigned) */
 FLTX_DEV unsigned long long waveMax64(unsigned long long v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    unsigned long long o = waveShflXor64(v, m);
-    v = o > v ? o : v;
-  }
-  return v;
+  FLTX_DPP_SCAN(v, umax64, dppTake64)
+  return waveBcastLast64(v);
 }
-FLTX_DEV unsigned long long waveMin64(unsigned long long v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    unsigned long long o = waveShflXor64(v, m);
-    v = o < v ? o : v;
-  }
-  return v;
-}
-/* inclusive scan of an int across the wave */
+/* min over the wave: max of the complement */
+FLTX_DEV unsigned long long waveMin64(unsigned long long v) { return ~waveMax64(~v); }
+/* inclusive prefix sum of a non-negative int across the wave */
 FLTX_DEV int waveInclusiveScan(int v) {
-  int lane = laneId();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int o = waveShflUpI(v, d);
-    if (lane >= d) {
-      v += o;
-    }
-  }
-  return v;
+  uint32_t x = (uint32_t)v;
+  FLTX_DPP_SCAN(x, uadd32, dppTake)
+  return (int)x;
 }
 #endif /* !FLTX_EMU */
 
