@@ -79,6 +79,8 @@ FLTX_API void* fltx_ctx_stream(fltx_ctx* ctx);
 
 /* ---- language models ---------------------------------------------------- */
 /* ZeroLM (decoder/lm/ZeroLM.h:22-32, ZeroLM.cpp:14-26). */
+/* (ctx may be NULL for both LM constructors: tables are built on the host and
+ * uploaded when a decoder is created.) */
 FLTX_API int fltx_lm_zero_create(fltx_ctx* ctx, fltx_lm** out);
 /* Back-off n-gram LM with ARPA semantics, replacing the KenLM adapter
  * (decoder/lm/KenLM.h:52-63, KenLM.cpp:32-83).  The model is passed as flat
@@ -94,6 +96,11 @@ FLTX_API int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t n_ngrams
                                   const int32_t* usr_to_lm, int32_t n_usr,
                                   int32_t bos, int32_t eos, int32_t unk,
                                   fltx_lm** out);
+/* KenLM(path, usrTknDict) for ARPA text models (decoder/lm/KenLM.cpp:32-50):
+ * parse the file on the host, map every '\n'-separated entry of usr_words
+ * (index = user dictionary index) to an LM word id, unknown strings to <unk>.
+ * No device is needed until a decoder is created with the LM. */
+FLTX_API int fltx_lm_arpa_load(const char* path, const char* usr_words, fltx_lm** out);
 FLTX_API int fltx_lm_destroy(fltx_lm* lm);
 /* LM::start + LM::score chain + optional LM::finish on the device tables
  * (decoder/lm/LM.h:61-78); per_word may be NULL.  Used by known-answer tests

@@ -59,6 +59,22 @@ CASES = [
     case("lx_scores_t50", kind="lexicon", dist="lexspell", T=50, K=10, lexicon=SMALL_LEX, u=5,
          lm_weight=1.5, word_score=1.0, label_scores=33),
     case("lx_t0", kind="lexicon", dist="lexspell", T=0, K=4, lexicon=SMALL_LEX),
+    # ---- n-gram LM (ARPA semantics, standing in for KenLM) --------------------
+    # lm = ("ngram", order, seed): synthetic model over the lexicon words (word LM)
+    # or over the tokens (token LM); trie label scores = lm.score(start, word).
+    case("ng_word_t40_k10", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=SMALL_LEX, u=6,
+         lm=("ngram", 3, 7), lm_weight=1.3, word_score=0.7, sil_score=-0.2),
+    case("ng_word_t60_k16_4g", kind="lexicon", dist="lexspell", T=60, K=16, lexicon=SMALL_LEX, u=7,
+         lm=("ngram", 4, 8), lm_weight=2.0, word_score=2.0, sil_score=-1.0),
+    case("ng_word_unk_t40", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=SMALL_LEX, u=8,
+         lm=("ngram", 3, 9), lm_weight=1.0, unk_score=-3.0),
+    case("ng_word_logadd_t40", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=SMALL_LEX, u=9,
+         lm=("ngram", 3, 10), lm_weight=1.0, word_score=1.0, log_add=True),
+    case("ng_tok_lexfree_t40", dist="ctc", T=40, K=10, u=10, lm=("ngram", 3, 11), lm_weight=0.8),
+    case("ng_tok_lexfree_kt8", dist="ctc", T=40, K=10, Kt=8, u=11, lm=("ngram", 4, 12), lm_weight=1.5,
+         sil_score=-0.4),
+    case("ng_tok_lexicon_t40", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=SMALL_LEX, u=12,
+         lm=("ngram", 3, 13), lm_weight=0.9, word_score=0.5, is_lm_token=True),
     # ---- lexicon decoder, BASELINE shapes -------------------------------------
     case("C3_spell_u0", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, size="large"),
     case("C3_spell_u255", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, u=255,
@@ -66,6 +82,11 @@ CASES = [
     case("C3_uniform_u0", kind="lexicon", dist="uniform", T=1000, K=50, Kt=10, lexicon=FULL_LEX,
          size="large"),
     case("C4z_spell_u0", kind="lexicon", dist="lexspell", T=1500, K=100, lexicon=FULL_LEX, size="large"),
+    # C4: Lexicon + 90k trie + synthetic 4-gram word LM, T=1500, beam=100 (BASELINE.json configs[3])
+    case("C4_spell_u0", kind="lexicon", dist="lexspell", T=1500, K=100, lexicon=FULL_LEX, size="large",
+         lm=("ngram", 4, 4242), lm_weight=2.0, word_score=2.0, sil_score=-1.0),
+    case("C4_spell_u255", kind="lexicon", dist="lexspell", T=1500, K=100, lexicon=FULL_LEX, size="large",
+         u=255, lm=("ngram", 4, 4242), lm_weight=2.0, word_score=2.0, sil_score=-1.0),
 ]
 
 BY_NAME = {c["name"]: c for c in CASES}

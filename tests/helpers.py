@@ -56,6 +56,54 @@ def case_inputs(c):
     return out
 
 
+# ---- n-gram LM plumbing -----------------------------------------------------
+NGRAM_DIR = os.path.join(ROOT, "gpurun_out", "ngram_cache")
+
+
+def lm_vocab(c, inp):
+    """user-index -> word list the LM is built over (KenLM.cpp:44-49)."""
+    import ngram_synth
+    if c["kind"] == "lexicon" and not c["is_lm_token"]:
+        return ngram_synth.words(inp["W"]) + ["<unk>"]  # word ids 0..W-1, unk = W
+    return ngram_synth.words(c["N"], "t")
+
+
+def arpa_path(c, inp):
+    """Deterministic synthetic ARPA file for a case (cached on disk)."""
+    import ngram_synth
+    _, order, seed = c["lm"]
+    vocab = lm_vocab(c, inp)
+    big = len(vocab) > 10000
+    counts = (0, 200000, 100000, 50000) if big else (0, 3000, 1500, 800)
+    os.makedirs(NGRAM_DIR, exist_ok=True)
+    path = os.path.join(NGRAM_DIR, "lm_o%d_s%d_v%d.arpa" % (order, seed, len(vocab)))
+    if not os.path.exists(path):
+        ngram_synth.write_arpa(path + ".tmp", [w for w in vocab if w != "<unk>"], order, counts, seed)
+        os.replace(path + ".tmp", path)
+    return path, vocab
+
+
+def checker_lm(lib, c, inp):
+    if c["lm"] == "zero":
+        return lib.lm_zero_create()
+    path, vocab = arpa_path(c, inp)
+    lm = lib.lm_arpa_create(path.encode(), "\n".join(vocab).encode())
+    assert lm, "lm_arpa_create failed"
+    return lm
+
+
+def checker_word_scores(lib, lm, W):
+    """trie label scores = lm.score(start, word) (DecoderTest.cpp:137-146)."""
+    out = np.zeros(W, dtype=np.float32)
+    one = np.zeros(1, dtype=np.float32)
+    w1 = np.zeros(1, dtype=np.int32)
+    for w in range(W):
+        w1[0] = w
+        lib.lm_score_sequence(lm, orclib._ip(w1), 1, 0, orclib._fp(one))
+        out[w] = one[0]
+    return out
+
+
 def run_checker(lib, c, inp=None):
     """Run a case through oracle/liboracle.so or oracle/_ref/libfltref.so."""
     inp = inp or case_inputs(c)
@@ -63,14 +111,17 @@ def run_checker(lib, c, inp=None):
                               c["sil_score"], c["log_add"], c["crit"])
     N = c["N"]
     blank = N - 1 if c["crit"] == "ctc" else -1
-    lm = lib.lm_zero_create()
+    lm = checker_lm(lib, c, inp)
     trie = None
     try:
         if c["kind"] == "lexfree":
             dec = lib.lexfree(opt, lm, 0, blank, inp["tr"])
         else:
             sf, so = inp["lex"]
-            trie = lib.build_trie(N, 0, sf, so, inp["labels"], inp["scores"], smear=1)
+            scores = inp["scores"]
+            if c["lm"] != "zero" and not c["is_lm_token"]:
+                scores = checker_word_scores(lib, lm, inp["W"])
+            trie = lib.build_trie(N, 0, sf, so, inp["labels"], scores, smear=1)
             dec = lib.lexicon(opt, trie, lm, 0, blank, inp["W"], inp["tr"], c["is_lm_token"])
         hyps = lib.decode(dec, inp["e"], c["T"], N)
         lib.decoder_destroy(dec)
@@ -89,13 +140,29 @@ class FltxSession:
         self.ctx = _capi.Context(device=device, lib=self.lib)
         self.zero = _capi.ZeroLM(self.ctx)
         self._tries = {}
+        self._lms = {}
+
+    def lm_for(self, c, inp):
+        if c["lm"] == "zero":
+            return self.zero
+        path, vocab = arpa_path(c, inp)
+        key = (path,)
+        if key not in self._lms:
+            self._lms[key] = _capi.ArpaLM(path, vocab, lib=self.lib)
+        return self._lms[key]
 
     def trie_for(self, c, inp):
-        key = (c["lexicon"], c["N"], c["label_scores"])
+        word_lm = c["lm"] != "zero" and not c["is_lm_token"]
+        key = (c["lexicon"], c["N"], c["label_scores"], c["lm"] if word_lm else None)
         if key not in self._tries:
             ht = _capi.HostTrie(c["N"], 0, lib=self.lib)
             sf, so = inp["lex"]
-            ht.insert_many(sf, so, inp["labels"], inp["scores"])
+            scores = inp["scores"]
+            if word_lm:  # lm.score(start, word) through the product's own tables
+                lm = self.lm_for(c, inp)
+                scores = np.array([lm.score_sequence([w], False)[0][0] for w in range(inp["W"])],
+                                  dtype=np.float32)
+            ht.insert_many(sf, so, inp["labels"], scores)
             ht.smear(1)
             self._tries[key] = (ht, ht.upload(self.ctx))
         return self._tries[key][1]
@@ -105,7 +172,7 @@ class FltxSession:
                                  c["sil_score"], c["log_add"], c["crit"])
         N = c["N"]
         blank = N - 1 if c["crit"] == "ctc" else -1
-        lm = lm or self.zero
+        lm = lm or self.lm_for(c, inp)
         if c["kind"] == "lexfree":
             d = _capi.BatchDecoder(self.ctx, _capi.LEXFREE, opt, lm, 0, blank, transitions=inp["tr"])
         else:

@@ -48,7 +48,7 @@ class Lib:
     SYMBOLS = [
         "fltx_last_error", "fltx_version", "fltx_ctx_create", "fltx_ctx_destroy",
         "fltx_ctx_synchronize", "fltx_ctx_stream", "fltx_lm_zero_create",
-        "fltx_lm_ngram_create", "fltx_lm_destroy", "fltx_lm_score_sequence",
+        "fltx_lm_ngram_create", "fltx_lm_arpa_load", "fltx_lm_destroy", "fltx_lm_score_sequence",
         "fltx_trie_create", "fltx_trie_destroy", "fltx_decoder_create",
         "fltx_decoder_destroy", "fltx_decode_batch", "fltx_stream_begin",
         "fltx_stream_step", "fltx_stream_end", "fltx_stream_prune",
@@ -78,6 +78,7 @@ class Lib:
             "fltx_ctx_synchronize": [vp],
             "fltx_lm_zero_create": [vp, pvp],
             "fltx_lm_ngram_create": [vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, pvp],
+            "fltx_lm_arpa_load": [C.c_char_p, C.c_char_p, pvp],
             "fltx_lm_destroy": [vp],
             "fltx_lm_score_sequence": [vp, vp, i32, i32, vp, vp],
             "fltx_trie_create": [vp, i64, i32, vp, vp, vp, vp, pvp],
@@ -161,10 +162,10 @@ class Context:
 
 
 class ZeroLM:
-    def __init__(self, ctx):
-        self.ctx, self.L = ctx, ctx.L
+    def __init__(self, ctx=None, lib=None):
+        self.ctx, self.L = ctx, (ctx.L if ctx is not None else (lib or default_lib()))
         h = C.c_void_p()
-        self.L.check(self.L.lib.fltx_lm_zero_create(ctx.h, C.byref(h)))
+        self.L.check(self.L.lib.fltx_lm_zero_create(ctx.h if ctx is not None else None, C.byref(h)))
         self.h = h
 
     def score_sequence(self, words, with_finish=True):
@@ -193,17 +194,27 @@ class ZeroLM:
 class NgramLM(ZeroLM):
     """Flat back-off n-gram tables in HBM (replaces lm/KenLM.cpp:32-83)."""
 
-    def __init__(self, ctx, order, ngram_order, ngram_words, prob, backoff, usr_to_lm, bos, eos, unk):
-        self.ctx, self.L = ctx, ctx.L
+    def __init__(self, ctx, order, ngram_order, ngram_words, prob, backoff, usr_to_lm, bos, eos, unk, lib=None):
+        self.ctx, self.L = ctx, (ctx.L if ctx is not None else (lib or default_lib()))
         no = np.ascontiguousarray(ngram_order, dtype=np.int32)
         nw = np.ascontiguousarray(ngram_words, dtype=np.int32).reshape(len(no), order)
         pr = np.ascontiguousarray(prob, dtype=np.float32)
         bo = np.ascontiguousarray(backoff, dtype=np.float32)
         um = np.ascontiguousarray(usr_to_lm, dtype=np.int32)
         h = C.c_void_p()
-        self.L.check(self.L.lib.fltx_lm_ngram_create(ctx.h, order, len(no), _ptr(no), _ptr(nw), _ptr(pr),
+        self.L.check(self.L.lib.fltx_lm_ngram_create(ctx.h if ctx is not None else None, order, len(no), _ptr(no), _ptr(nw), _ptr(pr),
                                                      _ptr(bo), _ptr(um), len(um), bos, eos, unk,
                                                      C.byref(h)))
+        self.h = h
+
+
+class ArpaLM(ZeroLM):
+    """KenLM(path, usr_token_dict) for ARPA text models (lm/KenLM.cpp:32-50)."""
+
+    def __init__(self, path, usr_words, lib=None):
+        self.ctx, self.L = None, lib or default_lib()
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_lm_arpa_load(path.encode(), "\n".join(usr_words).encode(), C.byref(h)))
         self.h = h
 
 

@@ -177,6 +177,7 @@ struct fltx_lm {
   int32_t bos = 0, eos = 0, unk = 0, nUsr = 0;
   uint32_t mask = 0;
   DBuf tab, backoff, usrToLm;
+  bool uploaded = false;
   /* host copies for fltx_lm_score_sequence */
   std::vector<NgramSlot> hTab;
   std::vector<float> hBackoff;
@@ -320,7 +321,7 @@ void* fltx_ctx_stream(fltx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr
 
 /* ---- LM ------------------------------------------------------------------ */
 int fltx_lm_zero_create(fltx_ctx* ctx, fltx_lm** out) {
-  if (!ctx || !out) {
+  if (!out) {
     return fail(FLTX_ERR_INVALID, "fltx_lm_zero_create: null argument");
   }
   auto* lm = new fltx_lm();
@@ -334,7 +335,7 @@ int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t nNgrams, const in
                          const int32_t* ngWords, const float* prob, const float* backoff,
                          const int32_t* usrToLm, int32_t nUsr, int32_t bos, int32_t eos,
                          int32_t unk, fltx_lm** out) {
-  if (!ctx || !out || !ngOrder || !ngWords || !prob || !backoff || nNgrams <= 0) {
+  if (!out || !ngOrder || !ngWords || !prob || !backoff || nNgrams <= 0) {
     return fail(FLTX_ERR_INVALID, "fltx_lm_ngram_create: null argument");
   }
   if (order < 1 || order > kMaxNgramOrder) {
@@ -412,20 +413,7 @@ int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t nNgrams, const in
     lm->hBackoff[i] = nodes[i].phantom ? 0.0f : nodes[i].backoff;
   }
   lm->hUsr.assign(usrToLm, usrToLm + (usrToLm ? nUsr : 0));
-  Stream st = ctx->stream;
-  if (lm->tab.ensure(sizeof(NgramSlot) * cap, st, false) ||
-      lm->backoff.ensure(sizeof(float) * nodes.size(), st, false) ||
-      lm->usrToLm.ensure(sizeof(int32_t) * std::max<size_t>(1, lm->hUsr.size()), st, false)) {
-    delete lm;
-    return fail(FLTX_ERR_OOM, "n-gram tables: device allocation failed");
-  }
-  if (devCopyH2D(lm->tab.p, lm->hTab.data(), sizeof(NgramSlot) * cap, st) ||
-      devCopyH2D(lm->backoff.p, lm->hBackoff.data(), sizeof(float) * nodes.size(), st) ||
-      (!lm->hUsr.empty() && devCopyH2D(lm->usrToLm.p, lm->hUsr.data(), sizeof(int32_t) * lm->hUsr.size(), st)) ||
-      devSync(st)) {
-    delete lm;
-    return fail(FLTX_ERR_HIP, "n-gram tables: upload failed");
-  }
+  /* the tables go to HBM when a decoder is created on a context */
   *out = lm;
   return FLTX_OK;
 }
@@ -592,6 +580,28 @@ int fltx_trie_destroy(fltx_trie* t) {
   return FLTX_OK;
 }
 
+/* upload the flat n-gram tables to the context's device (once) */
+static int lmEnsureUploaded(fltx_lm* lm, fltx_ctx* ctx) {
+  if (lm->kind == 0 || lm->uploaded) {
+    return FLTX_OK;
+  }
+  Stream st = ctx->stream;
+  const size_t cap = lm->hTab.size(), nn = lm->hBackoff.size();
+  if (lm->tab.ensure(sizeof(NgramSlot) * cap, st, false) || lm->backoff.ensure(sizeof(float) * nn, st, false) ||
+      lm->usrToLm.ensure(sizeof(int32_t) * std::max<size_t>(1, lm->hUsr.size()), st, false)) {
+    return fail(FLTX_ERR_OOM, "n-gram tables: device allocation failed");
+  }
+  if (devCopyH2D(lm->tab.p, lm->hTab.data(), sizeof(NgramSlot) * cap, st) ||
+      devCopyH2D(lm->backoff.p, lm->hBackoff.data(), sizeof(float) * nn, st) ||
+      (!lm->hUsr.empty() && devCopyH2D(lm->usrToLm.p, lm->hUsr.data(), sizeof(int32_t) * lm->hUsr.size(), st)) ||
+      devSync(st)) {
+    return fail(FLTX_ERR_HIP, "n-gram tables: upload failed");
+  }
+  lm->ctx = ctx;
+  lm->uploaded = true;
+  return FLTX_OK;
+}
+
 /* ---- decoder ------------------------------------------------------------- */
 int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, const fltx_trie* trie,
                         const fltx_lm* lm, int32_t sil, int32_t blank, int32_t unk,
@@ -614,6 +624,12 @@ int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, co
   }
   if (opt->criterion != FLTX_CRITERION_ASG && opt->criterion != FLTX_CRITERION_CTC) {
     return fail(FLTX_ERR_UNSUPPORTED, "criterion %d not supported (ASG, CTC only)", opt->criterion);
+  }
+  {
+    int rcu = lmEnsureUploaded(const_cast<fltx_lm*>(lm), ctx);
+    if (rcu) {
+      return rcu;
+    }
   }
   auto* d = new fltx_decoder();
   d->ctx = ctx;

@@ -266,16 +266,37 @@ FLTX_HD uint32_t hashKey(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
 /* ------------------------------------------------------------------------ */
 /* block-level primitives                                                    */
 /* ------------------------------------------------------------------------ */
+/* Workgroup barrier for code whose workspace may live in HBM (big beams).
+ * There the counters and hash heads are updated with L2 atomics, which do not
+ * refresh this CU's vector L1, so a plain load after the barrier could hit a
+ * stale line: make the barrier an agent-scope release/acquire (buffer_wbl2 +
+ * buffer_inv, ~3.5 us -- only the slow big-beam path pays it).  With the
+ * workspace in LDS it is a plain barrier. */
+FLTX_DEV void wsBarrier(const DecodeParams& P) {
+#ifndef FLTX_EMU
+  if (P.gws != nullptr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* my stores are in L2 */
+    __syncthreads();
+    /* invalidate AFTER the barrier: the L1 is shared by the waves of the CU, so
+     * a wave that is still loading before its barrier can re-populate lines
+     * another wave already dropped */
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return;
+  }
+#endif
+  __syncthreads();
+}
+
 /* exclusive prefix sum of v over the workgroup; *total = block sum.
  * Contains two barriers; wtmp has >= nWaves+1 entries. */
-FLTX_DEV int blockExclusiveScan(int v, uint32_t* wtmp, int* total) {
+FLTX_DEV int blockExclusiveScan(const DecodeParams& P, int v, uint32_t* wtmp, int* total) {
   const int lane = laneId(), wave = waveId();
   const int nW = ((int)blockDim.x + 63) >> 6;
   int inc = waveInclusiveScan(v);
   if (lane == 63) {
     wtmp[wave] = (uint32_t)inc;
   }
-  __syncthreads();
+  wsBarrier(P);
   int base = 0, tot = 0;
   for (int i = 0; i < nW; ++i) {
     int x = (int)wtmp[i];
@@ -284,34 +305,34 @@ FLTX_DEV int blockExclusiveScan(int v, uint32_t* wtmp, int* total) {
     }
     tot += x;
   }
-  __syncthreads();
+  wsBarrier(P);
   *total = tot;
   return base + inc - v;
 }
 
 /* max / min of an f64 over the workgroup (2 barriers) */
-FLTX_DEV double blockMaxF64(double v, unsigned long long* slot) {
+FLTX_DEV double blockMaxF64(const DecodeParams& P, double v, unsigned long long* slot) {
   if (threadIdx.x == 0) {
     *slot = 0ull;
   }
-  __syncthreads();
+  wsBarrier(P);
   unsigned long long k = waveMax64(f64Key(v));
   if (laneId() == 0) {
     atomMax64(slot, k);
   }
-  __syncthreads();
+  wsBarrier(P);
   return f64FromKey(*slot);
 }
-FLTX_DEV double blockMinF64(double v, unsigned long long* slot) {
+FLTX_DEV double blockMinF64(const DecodeParams& P, double v, unsigned long long* slot) {
   if (threadIdx.x == 0) {
     *slot = ~0ull;
   }
-  __syncthreads();
+  wsBarrier(P);
   unsigned long long k = waveMin64(f64Key(v));
   if (laneId() == 0) {
     atomMin64(slot, k);
   }
-  __syncthreads();
+  wsBarrier(P);
   return f64FromKey(*slot);
 }
 
@@ -355,6 +376,14 @@ FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
   w.cLm[ci] = lm;
   w.cOrd[ci] = ord;
   compilerFence();
+#ifndef FLTX_EMU
+  if (P.gws != nullptr) {
+    /* workspace in HBM: the record must have reached L2 before the atomic
+     * below publishes its index to the other waves (in LDS the pipeline order
+     * of one wave's ds_write / ds_cmpst already guarantees this) */
+    __threadfence();
+  }
+#endif
   uint32_t s = hashKey(kp, ke, klex, ktp) & (uint32_t)(P.HS - 1);
   for (;;) {
     uint32_t cur = ldsLoad32(&w.head[s]);
@@ -365,7 +394,19 @@ FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
         break;
       }
     }
-    const uint4 k = w.cKey[cur];
+    uint4 k;
+#ifndef FLTX_EMU
+    if (P.gws != nullptr) { /* another wave's record: read it at L2, not from a stale L1 line */
+      const uint32_t* kq = (const uint32_t*)&w.cKey[cur];
+      k.x = __hip_atomic_load(kq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      k.y = __hip_atomic_load(kq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      k.z = __hip_atomic_load(kq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      k.w = __hip_atomic_load(kq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
+#endif
+    {
+      k = w.cKey[cur];
+    }
     if (k.x == kp && k.y == ke && k.z == klex && k.w == ktp) {
       const uint32_t old = atomExch32(&w.head[s], ci);
       w.cNext[ci] = old;
@@ -773,7 +814,7 @@ FLTX_DEV void densePrepare(const DecodeParams& P, const Ws& w, const FrameCtx& f
     w.dMate[h] = mate;
     w.dPar[h] = par;
   }
-  __syncthreads();
+  wsBarrier(P);
   if (f.nTok != P.N) {
     for (int r = tid; r < f.nTok; r += W) {
       w.dIn[w.tokIdx[r]] = 1;
@@ -789,7 +830,7 @@ FLTX_DEV void densePrepare(const DecodeParams& P, const Ws& w, const FrameCtx& f
       w.dPar[h] = -1; /* cannot happen (edge == token when pb == 0); stay correct anyway */
     }
   }
-  __syncthreads();
+  wsBarrier(P);
 }
 
 /* Phase 1: best score over all candidates.  Phase 2 (after the threshold is
@@ -1136,7 +1177,7 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
     for (int i = tid; i < nLead; i += W) {
       w.lstat[i] = 2;
     }
-    __syncthreads();
+    wsBarrier(P);
     return;
   }
   for (int i = tid; i < nLead; i += W) {
@@ -1146,7 +1187,7 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
     w.sc[SC_NEED] = K;
     w.sc[SC_DONE] = 0;
   }
-  __syncthreads();
+  wsBarrier(P);
   const int SMALL = W < 256 ? 256 : W;
   for (int pass = 0; pass < 64; ++pass) {
     /* range of the active set */
@@ -1160,10 +1201,10 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
         ++cnt;
       }
     }
-    const double hi = blockMaxF64(mx, &w.red[0]);
-    const double lo = blockMinF64(mn, &w.red[1]);
+    const double hi = blockMaxF64(P, mx, &w.red[0]);
+    const double lo = blockMinF64(P, mn, &w.red[1]);
     int active;
-    blockExclusiveScan(cnt, w.wtmp, &active);
+    blockExclusiveScan(P, cnt, w.wtmp, &active);
     const int need = w.sc[SC_NEED];
     const double scale = (double)P.NB / (hi - lo);
     if (active <= SMALL || !(hi > lo) || !(scale > 0.0) || !(scale < 1e300)) {
@@ -1171,14 +1212,14 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
       if (tid == 0) {
         w.sc[SC_NSMALL] = 0;
       }
-      __syncthreads();
+      wsBarrier(P);
       for (int i = tid; i < nLead; i += W) {
         if (w.lstat[i] == 1) {
           const uint32_t p = atomAdd32((uint32_t*)&w.sc[SC_NSMALL], 1u);
           w.small[p] = (uint32_t)i;
         }
       }
-      __syncthreads();
+      wsBarrier(P);
       for (int j = tid; j < active; j += W) {
         const uint32_t li = w.small[j];
         const uint32_t c = w.lead[li];
@@ -1191,14 +1232,14 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
         }
         w.lstat[li] = rank < need ? 2 : 0;
       }
-      __syncthreads();
+      wsBarrier(P);
       return;
     }
     /* histogram pass: bin 0 holds the highest scores */
     for (int i = tid; i < P.NB; i += W) {
       w.hist[i] = 0;
     }
-    __syncthreads();
+    wsBarrier(P);
     for (int i = tid; i < nLead; i += W) {
       if (w.lstat[i] == 1) {
         const double sc = w.cScore[w.lead[i]];
@@ -1209,7 +1250,7 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
         atomAdd32(&w.hist[bin], 1u);
       }
     }
-    __syncthreads();
+    wsBarrier(P);
     /* locate the bin where the cumulative count reaches `need` */
     const int per = (P.NB + W - 1) / W;
     int mine = 0;
@@ -1220,7 +1261,7 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
       }
     }
     int tot;
-    const int before = blockExclusiveScan(mine, w.wtmp, &tot);
+    const int before = blockExclusiveScan(P, mine, w.wtmp, &tot);
     if (before < need && before + mine >= need) {
       int cum = before;
       for (int q = 0; q < per; ++q) {
@@ -1235,7 +1276,7 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
         cum += c;
       }
     }
-    __syncthreads();
+    wsBarrier(P);
     const int bstar = w.sc[SC_BSTAR], cum = w.sc[SC_CUM], mcnt = w.sc[SC_M];
     for (int i = tid; i < nLead; i += W) {
       if (w.lstat[i] == 1) {
@@ -1249,20 +1290,20 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
         }
       }
     }
-    __syncthreads();
+    wsBarrier(P);
     if (cum + mcnt == need) {
       return;
     }
     if (tid == 0) {
       w.sc[SC_NEED] = need - cum;
     }
-    __syncthreads();
+    wsBarrier(P);
   }
   /* unreachable for finite inputs: each pass narrows [lo, hi] */
   if (tid == 0) {
     atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_SELECT_FALLBACK);
   }
-  __syncthreads();
+  wsBarrier(P);
 }
 
 /* Fast path of the prune: ONE histogram pass over the leaders locates the bin
@@ -1282,7 +1323,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
   int L = 0;
   const int direct = P.SCAP < 128 ? P.SCAP : 128;
   bool slow = false;
-  if (nLead <= direct) {
+  if (nLead <= direct || nLead <= K) { /* everything survives or the list is tiny: rank it directly */
     for (int i = tid; i < nLead; i += W) {
       const uint32_t c = w.lead[i];
       w.sKey[i] = f64Key(w.cScore[c]);
@@ -1290,7 +1331,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
       w.sIdx[i] = c;
     }
     L = nLead;
-    __syncthreads();
+    wsBarrier(P);
   } else {
     /* range of the leaders' scores (-inf is parked in the last bin) */
     unsigned long long kmax = 0ull, kmin = ~0ull;
@@ -1310,14 +1351,14 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
     for (int i = tid; i < P.NB; i += W) {
       w.hist[i] = 0;
     }
-    __syncthreads();
+    wsBarrier(P);
     kmax = waveMax64(kmax);
     kmin = waveMin64(kmin);
     if (laneId() == 0) {
       atomMax64(&w.red[0], kmax);
       atomMin64(&w.red[1], kmin);
     }
-    __syncthreads();
+    wsBarrier(P);
     const double hi = f64FromKey(w.red[0]);
     const double lo = w.red[1] == ~0ull ? hi : f64FromKey(w.red[1]);
     const double scale = (double)P.NB / (hi - lo);
@@ -1332,7 +1373,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
         w.lbin[i] = (uint16_t)bin;
         atomAdd32(&w.hist[bin], 1u);
       }
-      __syncthreads();
+      wsBarrier(P);
       const int per = (P.NB + W - 1) / W;
       int mine = 0;
       for (int q = 0; q < per; ++q) {
@@ -1342,7 +1383,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
         }
       }
       int tot;
-      const int before = blockExclusiveScan(mine, w.wtmp, &tot);
+      const int before = blockExclusiveScan(P, mine, w.wtmp, &tot);
       if (before < K && before + mine >= K) {
         int cum = before;
         for (int q = 0; q < per; ++q) {
@@ -1356,7 +1397,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
           cum += c;
         }
       }
-      __syncthreads();
+      wsBarrier(P);
       const int bstar = w.sc[SC_BSTAR];
       L = w.sc[SC_CUM];
       if (L > P.SCAP) {
@@ -1371,7 +1412,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
             w.sIdx[p] = c;
           }
         }
-        __syncthreads();
+        wsBarrier(P);
       }
     }
     if (slow) {
@@ -1379,7 +1420,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
       if (tid == 0) {
         w.sc[SC_NSMALL] = 0;
       }
-      __syncthreads();
+      wsBarrier(P);
       for (int i = tid; i < nLead; i += W) {
         if (w.lstat[i] == 2) {
           const uint32_t p = atomAdd32((uint32_t*)&w.sc[SC_NSMALL], 1u);
@@ -1389,7 +1430,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
           w.sIdx[p] = c;
         }
       }
-      __syncthreads();
+      wsBarrier(P);
       L = nS;
     }
   }
@@ -1407,7 +1448,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
       w.surv[rank] = w.sIdx[j];
     }
   }
-  __syncthreads();
+  wsBarrier(P);
   return nS;
 }
 
@@ -1481,7 +1522,7 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
       P.histW[hbase + rank] = w.cAux[c];
     }
   }
-  __syncthreads();
+  wsBarrier(P);
   return nS;
 }
 
@@ -1517,7 +1558,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   if (!isEnd && f.nTok < P.N) {
     tokenShortlist(P, w, f.e, f.nTok);
   }
-  __syncthreads();
+  wsBarrier(P);
   FLTX_PROF(0);
   const bool dense = !isEnd && P.kind == 0 && P.dense != 0;
   unsigned long long bestKey = 0ull;
@@ -1535,7 +1576,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   if (laneId() == 0 && bestKey != 0ull) {
     atomMax64(&w.red[2], bestKey);
   }
-  __syncthreads();
+  wsBarrier(P);
   if (w.red[2] == 0ull) {
     return 0; /* no candidate at all */
   }
@@ -1547,7 +1588,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   } else {
     foldGroups(P, w, thr);
   }
-  __syncthreads();
+  wsBarrier(P);
   FLTX_PROF(2);
   const int nLead = w.sc[SC_NLEAD];
   const int nS = selectAndRank(P, w, nLead, P.K);
@@ -1636,7 +1677,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       w.erow[n] = em[n];
     }
   }
-  __syncthreads();
+  wsBarrier(P);
   FrameCtx f;
   f.b = b;
   f.nTok = nTok;
@@ -1690,7 +1731,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     if constexpr (GMAX > 0) {
       ldsBarrier(); /* the row hand-over is LDS only; back-pointer stores stay in flight */
     } else {
-      __syncthreads();
+      wsBarrier(P);
     }
     FLTX_PROF(5);
   }
@@ -1737,7 +1778,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     P.gLex[g] = GMAX > 0 ? 0u : w.bLex[(cur) * P.K + i];
     P.gTokPb[g] = w.bTokPb[(cur) * P.K + i];
   }
-  __syncthreads();
+  wsBarrier(P);
   if (tid == 0) {
     P.uttNBeam[b] = nBeam;
     P.uttFrame[b] = frame;

@@ -345,7 +345,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
         mn = grp[j].s < mn ? grp[j].s : mn;
       }
     }
-    lo = blockMinF64(mn, &w.red[1]);
+    lo = blockMinF64(P, mn, &w.red[1]);
   }
   double scale = (double)P.NB / (best - lo);
   if (!(best > lo) || !(scale > 0.0) || !(scale < 1e300)) {
