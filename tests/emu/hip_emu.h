@@ -50,6 +50,7 @@ extern thread_local EmuDim threadIdx, blockIdx, blockDim;
 extern thread_local EmuBlock* emuBlock;
 
 static inline void __syncthreads() { pthread_barrier_wait(&emuBlock->bar); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline long long __double_as_longlong(double d) {
   long long r;
   memcpy(&r, &d, 8);

@@ -40,6 +40,10 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_gws(DecodeParams P) {
   decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
 }
 __global__ void fltx_backtrace_kernel(BacktraceParams P) { backtraceUtterance(P); }
+__global__ void fltx_streamop_kernel(StreamOpParams Q) {
+  __shared__ int32_t sh[4];
+  streamOpUtterance(Q, sh);
+}
 #endif
 
 /* ------------------------------------------------------------------------ */
@@ -222,7 +226,8 @@ struct fltx_decoder {
   DBuf emis, emOff, stepT, histOffD, histPT, histW, stateTab, stateCtx;
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
-  DBuf tokens, words, prof;
+  DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
+  int keepScores = 0;
   int profile = 0;
   /* host caches of the last results */
   std::vector<int32_t> hN, hFrame, hStatus;
@@ -681,6 +686,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->threads = (int)value;
     return FLTX_OK;
   }
+  if (!strcmp(key, "keep_scores")) { /* record {score, am, lm} per history slot (getBestHypothesis) */
+    d->keepScores = value != 0;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "profile")) {
     d->profile = value != 0;
     return FLTX_OK;
@@ -810,6 +819,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (d->kind == FLTX_DECODER_LEXICON) {
     rc |= d->histW.ensure(sizeof(int32_t) * (size_t)off, st, false);
   }
+  if (d->keepScores) {
+    rc |= d->histS.ensure(sizeof(double) * 3 * (size_t)off, st, false);
+  }
   if (cap != d->stateCap) {
     /* geometry changed: stale keys would hash to other slots; start clean */
     d->stateTab.cap = 0;
@@ -898,6 +910,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.gTokPb = d->gTokPb.as<uint32_t>();
   P.histPT = d->histPT.as<int2>();
   P.histW = d->histW.as<int32_t>();
+  P.histS = d->keepScores ? d->histS.as<double>() : nullptr;
   P.histOff = d->histOffD.as<int64_t>();
   P.stateTab = d->stateTab.as<unsigned long long>();
   P.stateCap = d->stateCap;
@@ -1177,6 +1190,7 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
     return fail(FLTX_ERR_INVALID, "fltx_stream_begin: bad argument");
   }
   std::vector<int32_t> Tm(B, maxFrames);
+  d->keepScores = 1; /* streams serve getBestHypothesis(lookBack) of ancestors */
   int rc = prepare(d, B, N, Tm.data(), true);
   if (rc) {
     return rc;
@@ -1264,13 +1278,58 @@ int fltx_stream_end(fltx_decoder* d) {
   return FLTX_OK;
 }
 
-int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
-  (void)lookBack;
-  if (!d) {
-    return fail(FLTX_ERR_INVALID, "null decoder");
-  }
-  return fail(FLTX_ERR_UNSUPPORTED, "fltx_stream_prune: not implemented in this round");
+static int launchStreamOp(fltx_decoder* d, int op, int lookBack, int cap) {
+  StreamOpParams Q;
+  memset(&Q, 0, sizeof(Q));
+  Q.K = d->opt.beam_size;
+  Q.kind = d->kind;
+  Q.op = op;
+  Q.lookBack = lookBack;
+  Q.histPT = d->histPT.as<int2>();
+  Q.histW = d->histW.as<int32_t>();
+  Q.histS = d->keepScores ? d->histS.as<double>() : nullptr;
+  Q.histOff = d->histOffD.as<int64_t>();
+  Q.uttFrame = d->uttFrame.as<int32_t>();
+  Q.uttNBeam = d->uttNBeam.as<int32_t>();
+  Q.gScore = d->gScore.as<double>();
+  Q.outLen = d->bestLen.as<int32_t>();
+  Q.outScores = d->bestScores.as<double>();
+  Q.outTok = d->bestTok.as<int32_t>();
+  Q.outWrd = d->bestWrd.as<int32_t>();
+  Q.cap = cap;
+#ifdef FLTX_EMU
+  const StreamOpParams* qq = &Q;
+  emuLaunch(d->B, 64, 16, [qq](char* sm) { streamOpUtterance(*qq, (int32_t*)sm); });
+#else
+  hipLaunchKernelGGL(fltx_streamop_kernel, dim3(d->B), dim3(64), 0, d->ctx->stream, Q);
+  HIPCHK(hipGetLastError());
+#endif
+  return FLTX_OK;
 }
+
+int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
+  if (!d || lookBack < 0) {
+    return fail(FLTX_ERR_INVALID, "fltx_stream_prune: bad argument");
+  }
+  if (!d->streaming) {
+    return fail(FLTX_ERR_STATE, "fltx_stream_prune: call fltx_stream_begin first");
+  }
+  int rc = launchStreamOp(d, 1, lookBack, 0);
+  if (rc) {
+    return rc;
+  }
+  d->resultsSynced = false;
+  d->backtraced = false;
+  if ((rc = syncResults(d))) {
+    return rc;
+  }
+  for (int b = 0; b < d->B; ++b) {
+    d->frames[b] = d->hFrame[b]; /* frames still buffered */
+  }
+  return FLTX_OK;
+}
+
+static int checkStatus(fltx_decoder* d, int b);
 
 int fltx_stream_frames_in_buffer(fltx_decoder* d, int32_t b, int32_t* n) {
   if (!d || !n || b < 0 || b >= d->B) {
@@ -1386,17 +1445,64 @@ int fltx_result_fetch(fltx_decoder* d, int32_t b, int32_t maxHyp, double* scores
 
 int fltx_result_best(fltx_decoder* d, int32_t b, int32_t lookBack, double* scores, int32_t* tokens,
                      int32_t* words, int32_t capacity, int32_t* length) {
-  (void)scores;
-  (void)tokens;
-  (void)words;
-  (void)capacity;
-  (void)length;
-  (void)lookBack;
-  (void)b;
-  if (!d) {
-    return fail(FLTX_ERR_INVALID, "null decoder");
+  if (!d || b < 0 || b >= d->B || lookBack < 0 || !length) {
+    return fail(FLTX_ERR_INVALID, "fltx_result_best: bad argument");
   }
-  return fail(FLTX_ERR_UNSUPPORTED, "fltx_result_best: not implemented in this round");
+  if (!d->haveResults) {
+    return fail(FLTX_ERR_STATE, "no decode has been run");
+  }
+  if (!d->keepScores) {
+    return fail(FLTX_ERR_STATE,
+                "getBestHypothesis needs the per-frame score history: use the streaming calls or "
+                "fltx_decoder_set(dec, \"keep_scores\", 1) before decoding");
+  }
+  int rc = syncResults(d);
+  if (rc) {
+    return rc;
+  }
+  if ((rc = checkStatus(d, b))) {
+    return rc;
+  }
+  int maxLen = 0;
+  for (int i = 0; i < d->B; ++i) {
+    maxLen = std::max(maxLen, d->hFrame[i] + 1);
+  }
+  Stream st = d->ctx->stream;
+  if (d->bestLen.ensure(4 * (size_t)d->B, st, true) || d->bestScores.ensure(24 * (size_t)d->B, st, true) ||
+      d->bestTok.ensure(4 * (size_t)d->B * maxLen, st, false) ||
+      d->bestWrd.ensure(4 * (size_t)d->B * maxLen, st, false)) {
+    return fail(FLTX_ERR_OOM, "best-hypothesis buffers: allocation failed");
+  }
+  if ((rc = launchStreamOp(d, 0, lookBack, maxLen))) {
+    return rc;
+  }
+  int32_t len = 0;
+  if (devCopyD2H(&len, d->bestLen.as<int32_t>() + b, 4, st)) {
+    return fail(FLTX_ERR_HIP, "copy failed");
+  }
+  *length = len;
+  if (len == 0) {
+    return FLTX_OK; /* empty DecodeResult */
+  }
+  if (len > capacity) {
+    return fail(FLTX_ERR_RANGE, "fltx_result_best: capacity %d < length %d", capacity, len);
+  }
+  if (scores && devCopyD2H(scores, d->bestScores.as<double>() + 3 * (size_t)b, 24, st)) {
+    return fail(FLTX_ERR_HIP, "copy failed");
+  }
+  if (tokens && devCopyD2H(tokens, d->bestTok.as<int32_t>() + (size_t)b * maxLen, 4 * (size_t)len, st)) {
+    return fail(FLTX_ERR_HIP, "copy failed");
+  }
+  if (words) {
+    if (d->kind == FLTX_DECODER_LEXICON) {
+      if (devCopyD2H(words, d->bestWrd.as<int32_t>() + (size_t)b * maxLen, 4 * (size_t)len, st)) {
+        return fail(FLTX_ERR_HIP, "copy failed");
+      }
+    } else {
+      std::fill(words, words + len, -1);
+    }
+  }
+  return FLTX_OK;
 }
 
 int fltx_result_device(fltx_decoder* d, const int32_t** nHyp, const double** scores,

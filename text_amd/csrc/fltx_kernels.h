@@ -118,6 +118,8 @@ struct DecodeParams {
   /* history: one {parent, token} (+ word) record per surviving slot per frame */
   int2* histPT;
   int32_t* histW;
+  double* histS;      /* optional {score, am, lm} per record (streaming: getBestHypothesis
+                         of an ancestor reports the ancestor's scores, Utils.h:236-238) */
   const int64_t* histOff;
   /* LM-state identity table */
   unsigned long long* stateTab;
@@ -1521,6 +1523,12 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
     if (P.kind == 1) {
       P.histW[hbase + rank] = w.cAux[c];
     }
+    if (P.histS) {
+      double* hs = P.histS + 3 * (hbase + rank);
+      hs[0] = sc;
+      hs[1] = am;
+      hs[2] = w.bLm[(f.cur) * P.K + h] + (double)lmd;
+    }
   }
   wsBarrier(P);
   return nS;
@@ -1632,6 +1640,11 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       P.histPT[hb] = make_int2(-1, P.sil);
       if (P.kind == 1) {
         P.histW[hb] = -1;
+      }
+      if (P.histS) {
+        P.histS[3 * hb] = 0.0;
+        P.histS[3 * hb + 1] = 0.0;
+        P.histS[3 * hb + 2] = 0.0;
       }
       if (P.lmKind != 0) { /* KenLM::start(false): context = <s> (KenLM.cpp:57) */
         const int L = P.lmOrder - 1;
@@ -1834,6 +1847,154 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P) {
         break;
       }
     }
+  }
+}
+/* ------------------------------------------------------------------------ */
+/* streaming helpers on the device-resident history:                         */
+/*   op 0: getBestHypothesis(lookBack)  (LexiconFreeDecoder.cpp:188-194,       */
+/*         LexiconDecoder.cpp:285-293, findBestAncestor Utils.h:268-310)       */
+/*   op 1: prune(lookBack)              (LexiconFreeDecoder.cpp:205-227,       */
+/*         pruneAndNormalize Utils.h:312-342)                                  */
+/* ------------------------------------------------------------------------ */
+struct StreamOpParams {
+  int32_t K, kind, op, lookBack;
+  int2* histPT;
+  int32_t* histW;
+  double* histS;
+  const int64_t* histOff;
+  int32_t* uttFrame;
+  const int32_t* uttNBeam;
+  double* gScore;     /* current beam scores (normalised by prune) */
+  /* op 0 outputs */
+  int32_t* outLen;    /* [B] length of the result (0 = empty DecodeResult) */
+  double* outScores;  /* [B*3] */
+  int32_t* outTok;    /* [B*cap] */
+  int32_t* outWrd;
+  int32_t cap;
+};
+
+constexpr int kLookBackLimit = 100; /* Utils.h:28 */
+
+FLTX_DEV void streamOpUtterance(const StreamOpParams& Q, int32_t* sh) {
+  const int b = (int)blockIdx.x;
+  const int tid = (int)threadIdx.x, W = (int)blockDim.x;
+  const int64_t base = Q.histOff[b];
+  const int ff = Q.uttFrame[b];
+  const int nB = Q.uttNBeam[b];
+  /* sh[0] = frame of the ancestor, sh[1] = slot (-1 none), sh[2] = steps n, sh[3] = go */
+  if (tid == 0) {
+    int f = ff, s = nB > 0 ? 0 : -1, n = 0; /* the beam is sorted: slot 0 is the best */
+    bool go = true;
+    if (Q.op == 1 && ff - Q.lookBack < 1) {
+      go = false; /* not enough decoded frames to prune */
+    }
+    if (Q.op == 0 && Q.kind == 1 && ff - Q.lookBack < 1) {
+      go = false; /* LexiconDecoder.cpp:286-288 */
+      s = -1;
+    }
+    if (go) {
+      auto parentOf = [&](int fr, int sl) { return fr == 0 ? -1 : Q.histPT[base + (int64_t)fr * Q.K + sl].x; };
+      while (s >= 0 && n < Q.lookBack) {
+        ++n;
+        s = parentOf(f, s);
+        --f;
+      }
+      const int maxLookBack = Q.lookBack + kLookBackLimit;
+      while (s >= 0) {
+        bool complete = true; /* LexiconFreeDecoder.h:84-86 */
+        if (Q.kind == 1) {    /* LexiconDecoder.h:97-99 */
+          const int p = parentOf(f, s);
+          complete = p < 0 || Q.histW[base + (int64_t)(f - 1) * Q.K + p] >= 0;
+        }
+        if (complete) {
+          break;
+        }
+        ++n;
+        s = parentOf(f, s);
+        --f;
+        if (n == maxLookBack) {
+          break;
+        }
+      }
+    }
+    sh[0] = f;
+    sh[1] = s;
+    sh[2] = n;
+    sh[3] = go ? 1 : 0;
+  }
+  __syncthreads();
+  const int f = sh[0], s0 = sh[1], n = sh[2];
+  const bool go = sh[3] != 0;
+  if (Q.op == 0) {
+    if (!go || s0 < 0) {
+      if (tid == 0) {
+        Q.outLen[b] = 0;
+      }
+      return;
+    }
+    const int len = f + 1;
+    if (tid == 0) {
+      Q.outLen[b] = len;
+      const int64_t r = base + (int64_t)f * Q.K + s0;
+      if (Q.histS) {
+        Q.outScores[3 * b] = Q.histS[3 * r];
+        Q.outScores[3 * b + 1] = Q.histS[3 * r + 1];
+        Q.outScores[3 * b + 2] = Q.histS[3 * r + 2];
+      }
+      if (len <= Q.cap) {
+        int sl = s0;
+        for (int fr = f; fr >= 0; --fr) {
+          const int64_t idx = base + (int64_t)fr * Q.K + (sl < 0 ? 0 : sl);
+          const int2 pt = Q.histPT[idx];
+          Q.outTok[(int64_t)b * Q.cap + fr] = sl < 0 ? -1 : pt.y;
+          Q.outWrd[(int64_t)b * Q.cap + fr] = (sl < 0 || Q.kind != 1) ? -1 : Q.histW[idx];
+          sl = sl < 0 ? -1 : (fr == 0 ? -1 : pt.x);
+        }
+      }
+    }
+    return;
+  }
+  /* prune */
+  if (!go || s0 < 0) {
+    return;
+  }
+  const int startFrame = ff - n;
+  if (startFrame < 1) {
+    return;
+  }
+  for (int i = 0; i <= n; ++i) {
+    for (int k = tid; k < Q.K; k += W) {
+      const int64_t src = base + (int64_t)(startFrame + i) * Q.K + k;
+      const int64_t dst = base + (int64_t)i * Q.K + k;
+      int2 pt = Q.histPT[src];
+      if (i == 0) {
+        pt.x = -1; /* avoid further back-tracking (Utils.h:325-327) */
+      }
+      Q.histPT[dst] = pt;
+      if (Q.kind == 1) {
+        Q.histW[dst] = Q.histW[src];
+      }
+      if (Q.histS) {
+        Q.histS[3 * dst] = Q.histS[3 * src];
+        Q.histS[3 * dst + 1] = Q.histS[3 * src + 1];
+        Q.histS[3 * dst + 2] = Q.histS[3 * src + 2];
+      }
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  /* avoid score under/overflow: subtract the largest score of the newest frame
+   * (Utils.h:329-341); the beam is sorted, so that is slot 0 */
+  const double largest = nB > 0 ? Q.gScore[(size_t)b * Q.K] : 0.0;
+  __syncthreads();
+  for (int k = tid; k < nB; k += W) {
+    Q.gScore[(size_t)b * Q.K + k] -= largest;
+    if (Q.histS) {
+      Q.histS[3 * (base + (int64_t)n * Q.K + k)] -= largest;
+    }
+  }
+  if (tid == 0) {
+    Q.uttFrame[b] = n;
   }
 }
 #endif /* !FLTX_HOST_ONLY */

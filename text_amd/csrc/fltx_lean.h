@@ -490,6 +490,12 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
     w.bSEdge[no + rank] = (int32_t)ke;
     w.bTokPb[no + rank] = ktp;
     P.histPT[hbase + rank] = make_int2(h, n);
+    if (P.histS) {
+      double* hs = P.histS + 3 * (hbase + rank);
+      hs[0] = f64FromKey(k);
+      hs[1] = am;
+      hs[2] = 0.0;
+    }
   }
   ldsBarrier(); /* 6 */
   FLTX_PROF(4);
@@ -572,6 +578,12 @@ FLTX_DEV int runEndLean(const DecodeParams& P, const Ws& w, FrameCtx& f, int fra
     w.bSEdge[no + rank] = w.bSEdge[co + h];
     w.bTokPb[no + rank] = (uint32_t)P.sil;
     P.histPT[hbase + rank] = make_int2(h, P.sil);
+    if (P.histS) {
+      double* hs = P.histS + 3 * (hbase + rank);
+      hs[0] = f64FromKey(k);
+      hs[1] = w.bAm[co + h];
+      hs[2] = 0.0;
+    }
   }
   __syncthreads();
   return L;
