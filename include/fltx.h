@@ -109,6 +109,15 @@ FLTX_API int fltx_lm_score_sequence(fltx_lm* lm, const int32_t* usr_words,
                                     int32_t n, int32_t with_finish,
                                     float* per_word, float* total);
 
+/* Explicit-state LM::start / LM::score / LM::finish on the host copy of the
+ * flat tables (decoder/lm/LM.h:61-78), for the C++ facade's LM objects (trie
+ * label scores, known-answer checks).  A state is fltx_lm_state_size() int32
+ * context node ids (0 for ZeroLM).  usr_idx == -1 scores </s> (finish). */
+FLTX_API int fltx_lm_state_size(fltx_lm* lm, int32_t* n);
+FLTX_API int fltx_lm_start(fltx_lm* lm, int32_t start_with_nothing, int32_t* ctx_out);
+FLTX_API int fltx_lm_step(fltx_lm* lm, const int32_t* ctx_in, int32_t usr_idx, int32_t* ctx_out,
+                          float* score);
+
 /* ---- lexicon trie -------------------------------------------------------- */
 /* Upload an already built and smeared trie (decoder/Trie.h:64-92) as flat
  * arrays; node 0 is the root.  child[node*n_tokens + token] = child node or

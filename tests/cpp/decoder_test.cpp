@@ -1,0 +1,243 @@
+/*
+ * tests/cpp/decoder_test.cpp -- the reference's DecoderTest
+ * (flashlight/lib/text/test/decoder/DecoderTest.cpp:57-195) written against
+ * the fl::lib::text facade of this repo, plus checks of the streaming calls,
+ * the additive decodeBatch() and the error behaviour.  Same class names, same
+ * call sequence, same assertions and tolerances as the reference test; the
+ * lexicon (word ids + spellings) comes from the committed dump of the
+ * reference's loadWords/createWordDict/tkn2Idx.
+ *
+ *   decoder_test <dir with TN.bin emission.bin transition.bin lm.arpa lexicon_dump.txt>
+ */
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "flashlight/lib/text/decoder/LexiconDecoder.h"
+#include "flashlight/lib/text/decoder/LexiconFreeDecoder.h"
+#include "flashlight/lib/text/decoder/Trie.h"
+#include "flashlight/lib/text/decoder/lm/KenLM.h"
+#include "flashlight/lib/text/decoder/lm/ZeroLM.h"
+
+using namespace fl::lib::text;
+
+static int g_fail = 0;
+#define ASSERT_TRUE(c)                                                     \
+  do {                                                                     \
+    if (!(c)) {                                                            \
+      std::cerr << "FAILED " << __FILE__ << ":" << __LINE__ << ": " #c "\n"; \
+      ++g_fail;                                                            \
+    }                                                                      \
+  } while (0)
+#define ASSERT_NEAR(a, b, tol) ASSERT_TRUE(std::fabs((double)(a) - (double)(b)) <= (tol))
+#define ASSERT_EQ(a, b) ASSERT_TRUE((a) == (b))
+
+template <class T>
+std::vector<T> readBin(const std::string& path, size_t n) {
+  std::vector<T> v(n);
+  std::ifstream f(path, std::ios::binary);
+  f.read((char*)v.data(), n * sizeof(T));
+  return v;
+}
+
+struct CustomLM : LM { /* an LM with no device form */
+  LMStatePtr start(bool) override { return std::make_shared<LMState>(); }
+  std::pair<LMStatePtr, float> score(const LMStatePtr& s, const int i) override {
+    return {s->child<LMState>(i), -1.0f};
+  }
+  std::pair<LMStatePtr, float> finish(const LMStatePtr& s) override { return {s, 0.0f}; }
+};
+
+static bool sameResult(const DecodeResult& a, const DecodeResult& b) {
+  return a.score == b.score && a.emittingModelScore == b.emittingModelScore && a.lmScore == b.lmScore &&
+      a.tokens == b.tokens && a.words == b.words;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    std::cerr << "usage: decoder_test <data dir>\n";
+    return 2;
+  }
+  const std::string dir = std::string(argv[1]) + "/";
+  auto tn = readBin<int>(dir + "TN.bin", 2);
+  const int T = tn[0], N = tn[1];
+  auto emission = readBin<float>(dir + "emission.bin", (size_t)T * N);
+  auto transitions = readBin<float>(dir + "transition.bin", (size_t)N * N);
+  std::cout << "[Serialization] Loaded emissions [" << T << " x " << N << "]\n";
+
+  /* lexicon dump: header, then "<word idx>\t<word>\t<token idx...>", then "#words" + one word per line */
+  std::ifstream lf(dir + "lexicon_dump.txt");
+  int nTok, nWord, silIdx, unkIdx;
+  lf >> nTok >> nWord >> silIdx >> unkIdx;
+  std::string line;
+  std::getline(lf, line);
+  std::vector<std::tuple<int, std::string, std::vector<int>>> entries;
+  while (std::getline(lf, line) && line != "#words") {
+    std::istringstream ss(line);
+    std::string a, w, sp;
+    std::getline(ss, a, '\t');
+    std::getline(ss, w, '\t');
+    std::getline(ss, sp);
+    std::istringstream ts(sp);
+    std::vector<int> idx;
+    int x;
+    while (ts >> x) {
+      idx.push_back(x);
+    }
+    entries.emplace_back(std::atoi(a.c_str()), w, idx);
+  }
+  Dictionary wordDict;
+  while (std::getline(lf, line)) {
+    wordDict.addEntry(line);
+  }
+  wordDict.setDefaultIndex(unkIdx);
+  std::cout << "[Dictionary] Number of words: " << wordDict.indexSize() << "\n";
+  ASSERT_EQ((int)wordDict.indexSize(), nWord);
+
+  /* -------- Build Language Model (DecoderTest.cpp:102-120) -------- */
+  auto lm = std::make_shared<KenLM>(dir + "lm.arpa", wordDict);
+  std::vector<std::string> sentence{"the", "cat", "sat", "on", "the", "mat"};
+  auto inState = lm->start(false);
+  float totalScore = 0, lmScore = 0;
+  std::vector<float> lmScoreTarget{-1.05971, -4.19448, -3.33383, -2.76726, -1.16237, -4.64589};
+  for (size_t i = 0; i < sentence.size(); i++) {
+    std::tie(inState, lmScore) = lm->score(inState, wordDict.getIndex(sentence[i]));
+    ASSERT_NEAR(lmScore, lmScoreTarget[i], 1e-5);
+    totalScore += lmScore;
+  }
+  std::tie(inState, lmScore) = lm->finish(inState);
+  totalScore += lmScore;
+  ASSERT_NEAR(totalScore, -19.5123, 1e-5);
+
+  /* -------- Build Trie (DecoderTest.cpp:122-155) -------- */
+  int blankIdx = -1;
+  auto trie = std::make_shared<Trie>(nTok, silIdx);
+  auto startState = lm->start(false);
+  std::vector<std::string> letters{"|", "'", "a", "b", "c", "d", "e", "f", "g", "h", "i", "j", "k", "l", "m",
+                                   "n", "o", "p", "q", "r", "s", "t", "u", "v", "w", "x", "y", "z", "<1>"};
+  for (const auto& e : entries) {
+    float score = -1;
+    LMStatePtr dummyState;
+    std::tie(dummyState, score) = lm->score(startState, std::get<0>(e));
+    trie->insert(std::get<2>(e), std::get<0>(e), score);
+  }
+  trie->smear(SmearingMode::MAX);
+  std::vector<float> trieScoreTarget{-1.05971, -2.87742, -2.64553, -3.05081, -1.05971, -3.08968};
+  for (size_t i = 0; i < sentence.size(); i++) {
+    std::vector<int> wt;
+    for (char ch : sentence[i]) {
+      for (size_t k = 0; k < letters.size(); ++k) {
+        if (letters[k] == std::string(1, ch)) {
+          wt.push_back((int)k);
+        }
+      }
+    }
+    auto node = trie->search(wt);
+    ASSERT_TRUE(node != nullptr);
+    if (node) {
+      ASSERT_NEAR(node->maxScore, trieScoreTarget[i], 1e-5);
+    }
+  }
+
+  /* -------- Build Decoder + Run (DecoderTest.cpp:157-194) -------- */
+  LexiconDecoderOptions decoderOpt{2500, 25000, 100.0, 2.0, 2.0, -std::numeric_limits<float>::infinity(),
+                                   -1, false, CriterionType::ASG};
+  LexiconDecoder decoder(decoderOpt, trie, lm, silIdx, blankIdx, unkIdx, transitions, false);
+  auto results = decoder.decode(emission.data(), T, N);
+  int n_hyp = (int)results.size();
+  ASSERT_EQ(n_hyp, 16); // only one with nice ending
+  std::vector<float> hypScoreTarget{-284.0998, -284.108, -284.119, -284.127, -284.296};
+  for (int i = 0; i < std::min(n_hyp, 5); i++) {
+    std::cout << results[i].score << "\n";
+    ASSERT_NEAR(results[i].score, hypScoreTarget[i], 1e-3);
+  }
+  /* getBestHypothesis() after decode() is the first n-best entry */
+  if (n_hyp > 0) {
+    ASSERT_TRUE(sameResult(decoder.getBestHypothesis(), results[0]));
+    ASSERT_EQ((int)results[0].tokens.size(), T + 2);
+  }
+
+  /* -------- lexicon-free CTC + ZeroLM: offline == streaming == batched -------- */
+  auto zero = std::make_shared<ZeroLM>();
+  LexiconFreeDecoderOptions fopt{20, N, 25.0, 0.0, 0.0, false, CriterionType::CTC};
+  LexiconFreeDecoder fdec(fopt, zero, silIdx, N - 1, {});
+  auto off = fdec.decode(emission.data(), T, N);
+  ASSERT_EQ((int)off.size(), 20);
+  fdec.decodeBegin();
+  int t = 0;
+  for (int chunk : {1, 30, 64, 140}) {
+    fdec.decodeStep(emission.data() + (size_t)t * N, chunk, N);
+    t += chunk;
+    ASSERT_EQ(fdec.nDecodedFramesInBuffer(), t + 1);
+  }
+  ASSERT_EQ(t, T);
+  auto bestMid = fdec.getBestHypothesis();
+  ASSERT_EQ((int)bestMid.tokens.size(), T + 1);
+  fdec.decodeEnd();
+  auto str = fdec.getAllFinalHypothesis();
+  ASSERT_EQ(str.size(), off.size());
+  for (size_t i = 0; i < std::min(str.size(), off.size()); ++i) {
+    ASSERT_TRUE(sameResult(str[i], off[i]));
+  }
+  /* three utterances (prefixes of the fixture) in one launch */
+  std::vector<int> Ts{T, 100, 37};
+  std::vector<float> packed;
+  for (int tt : Ts) {
+    packed.insert(packed.end(), emission.begin(), emission.begin() + (size_t)tt * N);
+  }
+  auto batch = fdec.decodeBatch(packed.data(), Ts, N);
+  ASSERT_EQ(batch.size(), Ts.size());
+  for (size_t b = 0; b < Ts.size(); ++b) {
+    auto one = fdec.decode(emission.data(), Ts[b], N);
+    ASSERT_EQ(batch[b].size(), one.size());
+    for (size_t i = 0; i < std::min(one.size(), batch[b].size()); ++i) {
+      ASSERT_TRUE(sameResult(batch[b][i], one[i]));
+    }
+  }
+  /* prune keeps the stream consistent: frames in buffer shrink to lookBack + 1 */
+  fdec.decodeBegin();
+  fdec.decodeStep(emission.data(), 120, N);
+  fdec.prune(10);
+  ASSERT_EQ(fdec.nDecodedFramesInBuffer(), 11);
+  fdec.decodeStep(emission.data() + (size_t)120 * N, T - 120, N);
+  fdec.decodeEnd();
+  auto pr = fdec.getAllFinalHypothesis();
+  ASSERT_EQ(pr.size(), off.size());
+  if (!pr.empty() && !off.empty()) { /* same best path over the frames still buffered */
+    std::vector<int> tailA(pr[0].tokens.end() - 50, pr[0].tokens.end());
+    std::vector<int> tailB(off[0].tokens.end() - 50, off[0].tokens.end());
+    ASSERT_TRUE(tailA == tailB);
+  }
+
+  /* -------- error behaviour -------- */
+  bool threw = false;
+  try {
+    trie->insert({1, nTok + 3}, 0, 0.0f); /* Trie.cpp:31-34 */
+  } catch (const std::out_of_range&) {
+    threw = true;
+  }
+  ASSERT_TRUE(threw);
+  threw = false;
+  try {
+    lm->score(lm->start(false), nWord + 5); /* KenLM.cpp:66-69 */
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  ASSERT_TRUE(threw);
+  threw = false;
+  try {
+    LexiconFreeDecoder bad(fopt, std::make_shared<CustomLM>(), silIdx, N - 1, {});
+  } catch (const std::runtime_error&) {
+    threw = true; /* no device tables and no CPU fallback */
+  }
+  ASSERT_TRUE(threw);
+
+  std::cout << (g_fail ? "FAILED" : "PASSED") << " (" << g_fail << " failures)\n";
+  return g_fail ? 1 : 0;
+}

@@ -48,7 +48,7 @@ class Lib:
     SYMBOLS = [
         "fltx_last_error", "fltx_version", "fltx_ctx_create", "fltx_ctx_destroy",
         "fltx_ctx_synchronize", "fltx_ctx_stream", "fltx_lm_zero_create",
-        "fltx_lm_ngram_create", "fltx_lm_arpa_load", "fltx_lm_destroy", "fltx_lm_score_sequence",
+        "fltx_lm_ngram_create", "fltx_lm_arpa_load", "fltx_lm_state_size", "fltx_lm_start", "fltx_lm_step", "fltx_lm_destroy", "fltx_lm_score_sequence",
         "fltx_trie_create", "fltx_trie_destroy", "fltx_decoder_create",
         "fltx_decoder_destroy", "fltx_decode_batch", "fltx_stream_begin",
         "fltx_stream_step", "fltx_stream_end", "fltx_stream_prune",
@@ -79,6 +79,9 @@ class Lib:
             "fltx_lm_zero_create": [vp, pvp],
             "fltx_lm_ngram_create": [vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, pvp],
             "fltx_lm_arpa_load": [C.c_char_p, C.c_char_p, pvp],
+            "fltx_lm_state_size": [vp, vp],
+            "fltx_lm_start": [vp, i32, vp],
+            "fltx_lm_step": [vp, vp, i32, vp, vp],
             "fltx_lm_destroy": [vp],
             "fltx_lm_score_sequence": [vp, vp, i32, i32, vp, vp],
             "fltx_trie_create": [vp, i64, i32, vp, vp, vp, vp, pvp],

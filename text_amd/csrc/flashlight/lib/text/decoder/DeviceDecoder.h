@@ -1,0 +1,195 @@
+/*
+ * decoder/DeviceDecoder.h -- shared implementation of the two decoder facades
+ * on top of the C ABI: one stream (B = 1) for the reference's single-utterance
+ * calls, plus the additive batched entry point decodeBatch().
+ */
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "flashlight/lib/text/decoder/Decoder.h"
+#include "flashlight/lib/text/decoder/Fltx.h"
+
+namespace fl {
+namespace lib {
+namespace text {
+namespace detail {
+
+class DeviceDecoder {
+ public:
+  /* frames a single stream may hold between prune() calls */
+  static constexpr int kDefaultMaxStreamFrames = 1 << 15;
+
+  DeviceDecoder() = default;
+  ~DeviceDecoder() {
+    if (h_) {
+      fltx_decoder_destroy(h_);
+    }
+  }
+  DeviceDecoder(const DeviceDecoder&) = delete;
+  DeviceDecoder& operator=(const DeviceDecoder&) = delete;
+
+  void create(int kind, const fltx_options& opt, const fltx_trie* trie, const LMPtr& lm, int sil, int blank,
+              int unk, const std::vector<float>& transitions, bool isLmToken) {
+    if (!lm || !lm->deviceHandle()) {
+      throw std::runtime_error(
+          "[decoder] this LM has no device tables (ZeroLM and KenLM/ARPA are supported); "
+          "the MI355X decoder has no CPU path to fall back to");
+    }
+    check(fltx_decoder_create(ctx_->h, kind, &opt, trie, lm->deviceHandle(), sil, blank, unk,
+                              transitions.empty() ? nullptr : transitions.data(), (int32_t)transitions.size(),
+                              isLmToken ? 1 : 0, &h_));
+    check(fltx_decoder_set(h_, "keep_scores", 1));
+    sil_ = sil;
+    blank_ = blank;
+    nTrans_ = (int)transitions.size();
+  }
+
+  fltx_ctx* ctx() const { return ctx_->h; }
+
+  void begin() {
+    pendingBegin_ = true;
+    open_ = false;
+  }
+
+  void step(const float* emissions, int T, int N) {
+    ensureOpen(N);
+    const int64_t off = 0;
+    const int32_t t32 = T;
+    check(fltx_stream_step(h_, emissions, 0, &off, &t32));
+  }
+
+  void end() {
+    ensureOpen(guessN());
+    check(fltx_stream_end(h_));
+  }
+
+  std::vector<DecodeResult> decodeOne(const float* emissions, int T, int N) {
+    const int64_t off = 0;
+    const int32_t t32 = T;
+    check(fltx_decode_batch(h_, emissions, 0, &off, &t32, 1, N));
+    open_ = true;
+    pendingBegin_ = false;
+    return results(0);
+  }
+
+  std::vector<std::vector<DecodeResult>> decodeBatch(const float* emissions, const std::vector<int64_t>& offsets,
+                                                     const std::vector<int>& T, int N, bool onDevice) {
+    std::vector<int32_t> t32(T.begin(), T.end());
+    check(fltx_decode_batch(h_, emissions, onDevice ? 1 : 0, offsets.empty() ? nullptr : offsets.data(),
+                            t32.data(), (int32_t)t32.size(), N));
+    open_ = true;
+    pendingBegin_ = false;
+    std::vector<std::vector<DecodeResult>> out(T.size());
+    for (size_t b = 0; b < T.size(); ++b) {
+      out[b] = results((int)b);
+    }
+    return out;
+  }
+
+  void prune(int lookBack) {
+    if (!open_) {
+      return;
+    }
+    check(fltx_stream_prune(h_, lookBack));
+  }
+
+  int framesInBuffer() const {
+    if (!open_) {
+      return pendingBegin_ ? 1 : 0;
+    }
+    int32_t n = 0;
+    check(fltx_stream_frames_in_buffer(h_, 0, &n));
+    return n;
+  }
+
+  int nHypothesis() const {
+    if (!open_) {
+      return pendingBegin_ ? 1 : 0;
+    }
+    int32_t n = 0, len = 0;
+    check(fltx_result_count(h_, 0, &n, &len));
+    return n;
+  }
+
+  DecodeResult best(int lookBack) const {
+    if (!open_) {
+      return DecodeResult();
+    }
+    int32_t n = 0, len = 0;
+    check(fltx_result_count(h_, 0, &n, &len));
+    std::vector<int32_t> tok(len), wrd(len);
+    double sc[3] = {0, 0, 0};
+    int32_t got = 0;
+    check(fltx_result_best(h_, 0, lookBack, sc, tok.data(), wrd.data(), len, &got));
+    DecodeResult r(got);
+    if (got > 0) {
+      r.score = sc[0];
+      r.emittingModelScore = sc[1];
+      r.lmScore = sc[2];
+      std::copy(tok.begin(), tok.begin() + got, r.tokens.begin());
+      std::copy(wrd.begin(), wrd.begin() + got, r.words.begin());
+    }
+    return r;
+  }
+
+  std::vector<DecodeResult> results(int b) const {
+    std::vector<DecodeResult> out;
+    if (!open_) {
+      return out;
+    }
+    int32_t n = 0, len = 0;
+    check(fltx_result_count(h_, b, &n, &len));
+    if (n <= 0) {
+      return out;
+    }
+    std::vector<double> sc(3 * (size_t)n);
+    std::vector<int32_t> tok((size_t)n * len), wrd((size_t)n * len);
+    int32_t got = 0;
+    check(fltx_result_fetch(h_, b, n, sc.data(), tok.data(), wrd.data(), &got));
+    out.reserve(got);
+    for (int i = 0; i < got; ++i) {
+      DecodeResult r(len);
+      r.score = sc[3 * i];
+      r.emittingModelScore = sc[3 * i + 1];
+      r.lmScore = sc[3 * i + 2];
+      std::copy(tok.begin() + (size_t)i * len, tok.begin() + (size_t)(i + 1) * len, r.tokens.begin());
+      std::copy(wrd.begin() + (size_t)i * len, wrd.begin() + (size_t)(i + 1) * len, r.words.begin());
+      out.push_back(std::move(r));
+    }
+    return out;
+  }
+
+  void setMaxStreamFrames(int n) { maxFrames_ = n; }
+
+ private:
+  int guessN() const {
+    if (nTrans_ > 0) {
+      int n = 1;
+      while (n * n < nTrans_) {
+        ++n;
+      }
+      return n;
+    }
+    return std::max(sil_, blank_) + 1;
+  }
+  void ensureOpen(int N) {
+    if (pendingBegin_ || !open_) {
+      check(fltx_stream_begin(h_, 1, N, maxFrames_));
+      pendingBegin_ = false;
+      open_ = true;
+    }
+  }
+
+  std::shared_ptr<Context> ctx_ = Context::get();
+  fltx_decoder* h_ = nullptr;
+  bool pendingBegin_ = false, open_ = false;
+  int maxFrames_ = kDefaultMaxStreamFrames;
+  int sil_ = 0, blank_ = 0, nTrans_ = 0;
+};
+
+} // namespace detail
+} // namespace text
+} // namespace lib
+} // namespace fl

@@ -532,6 +532,117 @@ int fltx_lm_score_sequence(fltx_lm* lm, const int32_t* usrWords, int32_t n, int3
   return FLTX_OK;
 }
 
+/* LM::start / LM::score / LM::finish on explicit states (decoder/lm/LM.h:61-78),
+ * host walk over the flat tables.  A state is lmOrder-1 context node ids. */
+static bool lmFind(const fltx_lm* lm, uint32_t ctx, uint32_t word, uint32_t& node, float& pr) {
+  uint32_t s = hashKey(ctx, word, 0x5bd1e995u, 0) & lm->mask;
+  for (;;) {
+    const NgramSlot& e = lm->hTab[s];
+    if (e.word == kEmpty) {
+      return false;
+    }
+    if (e.ctx == ctx && e.word == word) {
+      node = e.node;
+      pr = e.prob;
+      return true;
+    }
+    s = (s + 1) & lm->mask;
+  }
+}
+
+int fltx_lm_state_size(fltx_lm* lm, int32_t* n) {
+  if (!lm || !n) {
+    return fail(FLTX_ERR_INVALID, "null argument");
+  }
+  *n = lm->kind == 0 ? 0 : std::max(1, lm->order - 1);
+  return FLTX_OK;
+}
+
+int fltx_lm_start(fltx_lm* lm, int32_t startWithNothing, int32_t* ctxOut) {
+  if (!lm) {
+    return fail(FLTX_ERR_INVALID, "null lm");
+  }
+  if (lm->kind == 0) {
+    return FLTX_OK;
+  }
+  const int L = std::max(1, lm->order - 1);
+  for (int j = 0; j < L; ++j) {
+    ctxOut[j] = 0;
+  }
+  uint32_t nd;
+  float pr;
+  if (!startWithNothing && lm->order > 1 && lmFind(lm, 0, (uint32_t)lm->bos, nd, pr)) {
+    ctxOut[0] = (int32_t)(nd & ~kPhantomNode); /* BeginSentenceWrite, KenLM.cpp:57 */
+  }
+  return FLTX_OK;
+}
+
+/* usr_idx >= 0: LM::score; usr_idx == -1: LM::finish (scores </s>) */
+int fltx_lm_step(fltx_lm* lm, const int32_t* ctxIn, int32_t usrIdx, int32_t* ctxOut, float* score) {
+  if (!lm || !score) {
+    return fail(FLTX_ERR_INVALID, "null argument");
+  }
+  if (lm->kind == 0) {
+    *score = 0.0f;
+    return FLTX_OK;
+  }
+  uint32_t word;
+  if (usrIdx == -1) {
+    word = (uint32_t)lm->eos;
+  } else {
+    if (usrIdx < 0 || usrIdx >= lm->nUsr) {
+      return fail(FLTX_ERR_RANGE, "[ngram LM] Invalid user token index: %d", usrIdx); /* KenLM.cpp:66-69 */
+    }
+    word = (uint32_t)lm->hUsr[usrIdx];
+  }
+  const int L = lm->order - 1;
+  uint32_t nodes[kMaxNgramOrder] = {0};
+  bool found[kMaxNgramOrder] = {false};
+  float prob = 0;
+  int longest = -1;
+  for (int k = 0; k <= L; ++k) {
+    const uint32_t c = k == 0 ? 0u : (uint32_t)ctxIn[k - 1];
+    if (k > 0 && c == 0) {
+      continue;
+    }
+    float pr;
+    if (lmFind(lm, c, word, nodes[k], pr)) {
+      found[k] = true;
+      if (!(nodes[k] & kPhantomNode)) {
+        longest = k;
+        prob = pr;
+      }
+      nodes[k] &= ~kPhantomNode;
+    }
+  }
+  if (longest < 0) {
+    uint32_t nd = 0;
+    if (!lmFind(lm, 0, (uint32_t)lm->unk, nd, prob)) {
+      prob = -100.0f;
+    }
+    nodes[0] = nd & ~kPhantomNode;
+    found[0] = true;
+    longest = 0;
+  }
+  for (int j = longest + 1; j <= L; ++j) {
+    const uint32_t c = (uint32_t)ctxIn[j - 1];
+    if (c != 0) {
+      prob += lm->hBackoff[c];
+    }
+  }
+  if (ctxOut) {
+    int32_t tmp[kMaxNgramOrder];
+    for (int j = 0; j < L; ++j) {
+      tmp[j] = (j <= longest && found[j]) ? (int32_t)nodes[j] : 0;
+    }
+    for (int j = 0; j < std::max(1, L); ++j) {
+      ctxOut[j] = j < L ? tmp[j] : 0;
+    }
+  }
+  *score = prob;
+  return FLTX_OK;
+}
+
 /* ---- trie ---------------------------------------------------------------- */
 int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32_t* child,
                      const float* maxScore, const int32_t* labelOff, const int32_t* labels,
