@@ -130,7 +130,7 @@ def main():
         step()
         ctx.synchronize()
         pr = dec.profile().astype(np.float64)
-        names = ["A2(combine)", "B(eval+bin)", "C(prefix)", "D(shortlist)", "E(build)", "row", "A1(relations)", "-"]
+        names = ["A2(combine)", "B(eval+bin)", "C(prefix)", "D(shortlist)", "E(build)", "row", "A1(relations)", "E-rank"]
         tot = pr[:8].sum()
         sys.stderr.write("phase split (shader clocks, %% of %.3g): " % tot + ", ".join(
             "%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, pr[:8])) +

@@ -85,6 +85,10 @@ FLTX_DEV unsigned long long atomMin64(unsigned long long* p, unsigned long long 
   }
   return cur;
 }
+FLTX_DEV unsigned long long atomOr64(unsigned long long* p, unsigned long long v) {
+  return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST);
+}
+FLTX_DEV uint32_t loadCoherent32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 FLTX_DEV unsigned long long atomCas64(unsigned long long* p, unsigned long long cmp, unsigned long long val) {
   __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
   return cmp;

@@ -226,6 +226,8 @@ struct fltx_decoder {
   DBuf emis, emOff, stepT, histOffD, histPT, histW, stateTab, stateCtx;
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
+  DBuf childTab, maskTab, uttNextId, gMask;
+  int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   int keepScores = 0;
   int profile = 0;
@@ -879,7 +881,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   /* lean frame step (fltx_lean.h): lexicon-free + ZeroLM, groups held in registers */
   d->lean = 0;
-  if (d->dense && !d->noLean && !d->forceGlobalWs && d->lm->kind == 0 && K < 32000) {
+  if (d->dense && !d->noLean && !d->forceGlobalWs && d->lm->kind == 0 && K < 32000 && N <= 64) {
     const int64_t groups = (int64_t)K * (nTok + 1);
     const int64_t per = (groups + d->threads - 1) / d->threads;
     d->lean = per <= 6 ? 6 : (per <= 12 ? 12 : 0);
@@ -962,6 +964,13 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (!lds) {
     rc |= d->gws.ensure(d->wsBytes * (size_t)B, st, false);
   }
+  if (d->lean) {
+    d->idCap = (int64_t)K * (maxT + 2) + 2;
+    rc |= d->childTab.ensure(4 * (size_t)B * d->idCap * N, st, false);
+    rc |= d->maskTab.ensure(8 * (size_t)B * d->idCap, st, false);
+    rc |= d->uttNextId.ensure(4 * (size_t)B, st, true);
+    rc |= d->gMask.ensure(8 * bk, st, false);
+  }
   if (rc) {
     return fail(FLTX_ERR_OOM, "device allocation failed (B=%d K=%d T<=%d)", B, K, maxT);
   }
@@ -1035,6 +1044,11 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.gwsStride = (int64_t)d->wsBytes;
   P.outN = d->outN.as<int32_t>();
   P.outScores = d->outScores.as<double>();
+  P.childTab = d->childTab.as<uint32_t>();
+  P.maskTab = d->maskTab.as<unsigned long long>();
+  P.idCap = d->idCap;
+  P.uttNextId = d->uttNextId.as<int32_t>();
+  P.gMask = d->gMask.as<unsigned long long>();
   P.prof = nullptr;
   if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {
     devMemset(d->prof.p, 0, 8 * 8 * (size_t)d->B, d->ctx->stream);

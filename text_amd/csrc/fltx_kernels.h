@@ -133,6 +133,17 @@ struct DecodeParams {
   /* results of decodeEnd */
   int32_t* outN;
   double* outScores;
+  /* lean path: LM-state ids are allocated per utterance from a counter; a
+   * state's children are remembered in childTab[id*N + token] and the set of
+   * tokens that already have a child in maskTab[id], so a state that dropped
+   * out of the beam and is re-entered later gets its old id back without any
+   * hash (lm/LM.h:24-34 memoisation).  Written fire-and-forget, read only on
+   * that rare re-entry. */
+  uint32_t* childTab;           /* [B*idCap*N] */
+  unsigned long long* maskTab;  /* [B*idCap] */
+  int64_t idCap;
+  int32_t* uttNextId;
+  unsigned long long* gMask;    /* [B*K] parked masks of the beam slots */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
 };
@@ -167,10 +178,17 @@ struct Ws {
   uint32_t* sOrd;  /* [SCAP] generation order (tie-break) */
   uint32_t* sIdx;  /* [SCAP] candidate index */
   uint32_t* sSrc;  /* [SCAP] source slot | kNewState (lean path) */
+  uint4* sEnt;     /* [SCAP] lean short-list entry {key lo, key hi, order, group} */
   uint32_t* sBin;  /* [SCAP] histogram bin of the entry (lean path) */
   uint32_t* sNext; /* [SCAP] next entry of the same bin (lean path) */
   uint32_t* bhead; /* [NB] first short-list entry of a bin (lean path) */
   uint32_t* hcum;  /* [NB] number of candidates in better bins (lean path) */
+  int16_t* dKid;   /* [K*N] lean: any slot whose state is child(state of rep, token) */
+  unsigned long long* bMask;   /* [2K] lean: edges of the slot's LM state that already have a child state */
+  unsigned long long* addMask; /* [K] lean: edges added this frame, per old-beam representative */
+  unsigned long long* eBase;   /* [K] lean: new slot's mask before this frame's additions */
+  int32_t* eRep;   /* [K] lean: old-beam representative of the new slot's state, -1 = fresh */
+  int32_t* bPar;   /* [K] lean: parent slot of the new slot (for the coalesced history write) */
   int32_t* pMate;  /* [16*64] per-wave partial relation results (lean path) */
   int32_t* pPar;   /* [16*64] */
   uint32_t* surv;  /* [K] candidate index of the survivor with rank r */
@@ -187,7 +205,7 @@ struct Ws {
 };
 
 enum { SC_NCAND = 0, SC_NLEAD = 1, SC_NSURV = 2, SC_BSTAR = 3, SC_CUM = 4, SC_M = 5,
-       SC_NSMALL = 6, SC_STATUS = 7, SC_NEED = 8, SC_DONE = 9 };
+       SC_NSMALL = 6, SC_STATUS = 7, SC_NEED = 8, SC_DONE = 9, SC_NEXTID = 10 };
 
 #ifndef FLTX_HD
 #ifdef FLTX_EMU
@@ -233,10 +251,17 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.sOrd, uint32_t, SCAP)
   FLTX_CARVE(w.sIdx, uint32_t, SCAP)
   FLTX_CARVE(w.sSrc, uint32_t, SCAP)
+  FLTX_CARVE(w.sEnt, uint4, dense ? SCAP : 0)
   FLTX_CARVE(w.sBin, uint32_t, dense ? SCAP : 0)
   FLTX_CARVE(w.sNext, uint32_t, dense ? SCAP : 0)
-  FLTX_CARVE(w.bhead, uint32_t, dense ? NB : 0)
-  FLTX_CARVE(w.hcum, uint32_t, dense ? NB : 0)
+  FLTX_CARVE(w.bhead, uint32_t, dense ? NB + NB / 16 + 1 : 0)
+  FLTX_CARVE(w.hcum, uint32_t, dense ? NB + NB / 16 + 1 : 0)
+  FLTX_CARVE(w.dKid, int16_t, dense ? (size_t)K * N : 0)
+  FLTX_CARVE(w.bMask, unsigned long long, dense ? 2 * K : 0)
+  FLTX_CARVE(w.addMask, unsigned long long, dense ? K : 0)
+  FLTX_CARVE(w.eBase, unsigned long long, dense ? K : 0)
+  FLTX_CARVE(w.eRep, int32_t, dense ? K : 0)
+  FLTX_CARVE(w.bPar, int32_t, dense ? K : 0)
   FLTX_CARVE(w.pMate, int32_t, dense ? 16 * 64 : 0)
   FLTX_CARVE(w.pPar, int32_t, dense ? 16 * 64 : 0)
   FLTX_CARVE(w.surv, uint32_t, K)
@@ -244,7 +269,7 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.dPar, int32_t, dense ? K : 0)
   FLTX_CARVE(w.dRep, int16_t, dense ? (size_t)K * N : 0)
   FLTX_CARVE(w.dIn, uint8_t, N)
-  FLTX_CARVE(w.hist, uint32_t, NB)
+  FLTX_CARVE(w.hist, uint32_t, NB + NB / 16 + 1)
   FLTX_CARVE(w.tokIdx, int32_t, N)
   FLTX_CARVE(w.wtmp, uint32_t, 32)
   FLTX_CARVE(w.red, unsigned long long, 4)
@@ -577,6 +602,7 @@ FLTX_DEV unsigned long long devClock() { return __builtin_readcyclecounter(); }
 struct FrameCtx {
   unsigned long long t0;
   unsigned long long acc[8];
+  int64_t histBase; /* P.histOff[b], loaded once per launch */
   int b;         /* utterance */
   int cur;       /* beam buffer holding hyp_[frame] */
   int nBeam;
@@ -1465,7 +1491,7 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   const int nxt = f.cur ^ 1;
-  const int64_t hbase = P.histOff[f.b] + (int64_t)frameOut * P.K;
+  const int64_t hbase = f.histBase + (int64_t)frameOut * P.K;
   for (int rank = tid; rank < nS; rank += W) {
     const uint32_t c = w.surv[rank];
     const double sc = w.cScore[c];
@@ -1636,6 +1662,11 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       w.bSEdge[(0) * P.K + 0] = 0;
       w.bLex[(0) * P.K + 0] = 0u;
       w.bTokPb[(0) * P.K + 0] = (uint32_t)P.sil;
+      if constexpr (GMAX > 0) {
+        w.bMask[0] = 0ull;
+        w.sc[SC_NEXTID] = 1;
+        P.maskTab[(size_t)b * P.idCap] = 0ull;
+      }
       const int64_t hb = P.histOff[b];
       P.histPT[hb] = make_int2(-1, P.sil);
       if (P.kind == 1) {
@@ -1674,6 +1705,14 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       w.bSEdge[(0) * P.K + i] = P.gSEdge[g];
       w.bLex[(0) * P.K + i] = P.gLex[g];
       w.bTokPb[(0) * P.K + i] = P.gTokPb[g];
+      if constexpr (GMAX > 0) {
+        w.bMask[i] = P.gMask[g];
+      }
+    }
+    if constexpr (GMAX > 0) {
+      if (tid == 0) {
+        w.sc[SC_NEXTID] = P.uttNextId[b];
+      }
     }
   }
   const int T = P.stepT ? P.stepT[b] : 0;
@@ -1694,6 +1733,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   FrameCtx f;
   f.b = b;
   f.nTok = nTok;
+  f.histBase = P.histOff[b];
   f.t0 = devClock();
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -1790,12 +1830,18 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     P.gSEdge[g] = w.bSEdge[(cur) * P.K + i];
     P.gLex[g] = GMAX > 0 ? 0u : w.bLex[(cur) * P.K + i];
     P.gTokPb[g] = w.bTokPb[(cur) * P.K + i];
+    if constexpr (GMAX > 0) {
+      P.gMask[g] = w.bMask[(cur) * P.K + i];
+    }
   }
   wsBarrier(P);
   if (tid == 0) {
     P.uttNBeam[b] = nBeam;
     P.uttFrame[b] = frame;
     P.uttTotal[b] = total;
+    if constexpr (GMAX > 0) {
+      P.uttNextId[b] = w.sc[SC_NEXTID];
+    }
     P.uttStatus[b] = P.doBegin ? w.sc[SC_STATUS] : (P.uttStatus[b] | w.sc[SC_STATUS]);
   }
 }

@@ -30,6 +30,10 @@
  */
 #pragma once
 
+/* histogram arrays are indexed with one pad word per 16 bins so that a lane
+ * reading its 16 consecutive bins hits 16 different LDS banks */
+#define FLTX_HB(b) ((b) + ((b) >> 4))
+
 struct LeanGroup {
   double s;
   uint32_t src; /* parent slot | kNewState */
@@ -209,10 +213,13 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
   /* ---- phase A: clears, per-wave partial relations, frame best ---------------- */
   for (int i = tid; i < f.nBeam * P.N; i += W) {
     w.dRep[i] = (int16_t)-1;
+    w.dKid[i] = (int16_t)-1;
+  }
+  for (int i = tid; i < f.nBeam; i += W) {
+    w.addMask[i] = 0ull;
   }
   for (int i = tid; i < P.NB; i += W) {
-    w.hist[i] = 0;
-    w.bhead[i] = kEmpty;
+    w.hist[FLTX_HB(i)] = 0;
   }
   for (int n = tid; n < P.N; n += W) {
     w.dIn[n] = (f.nTok == P.N) ? 1 : 0;
@@ -299,6 +306,9 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
     if (!(tp & kPrevBlank) && !(ctc && t == P.blank) && par >= 0) {
       w.dRep[par * P.N + t] = (int16_t)h;
     }
+    if (par >= 0) { /* some slot of the child state child(state of par, edge) */
+      w.dKid[par * P.N + w.bSEdge[co + h]] = (int16_t)h;
+    }
   }
   if (f.nTok != P.N) {
     for (int r = tid; r < f.nTok; r += W) {
@@ -347,47 +357,68 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
     }
     lo = blockMinF64(P, mn, &w.red[1]);
   }
-  double scale = (double)P.NB / (best - lo);
-  if (!(best > lo) || !(scale > 0.0) || !(scale < 1e300)) {
-    scale = 0.0; /* degenerate range: everything lands in bin 0 */
+  /* Two-segment monotone binning of d = best - score over [0, range]: the
+   * K-th best score is what the histogram has to isolate, so the part of the
+   * range where it is expected gets 3/4 of the bins (short short-list) and the
+   * rest shares the last quarter.  Each segment is floor(d * const): monotone in d, which is
+   * all the exact rank needs.  NB is 1024 on this path (16 bins per lane). */
+  const double range = best - lo;
+  const int NF = (P.NB * 3) / 4;
+  /* fine segment = a little more than the current beam's own spread (best to
+   * K-th score): the next beam's K-th best lands there unless the frame is
+   * unusual, and then the coarse segment still ranks it exactly */
+  double cut = range * (1.0 / 16.0);
+  if (f.nBeam >= K) {
+    const double spread = (w.bScore[co] - w.bScore[co + f.nBeam - 1]) * 1.25 + 1e-3;
+    cut = spread < range * 0.9 ? spread : range * 0.9;
+  }
+  double sF = (double)NF / cut, sC = (double)(P.NB - NF) / (range - cut);
+  if (!(range > 0.0) || !(sF > 0.0) || !(sF < 1e300) || !(sC > 0.0) || !(sC < 1e300)) {
+    cut = __builtin_huge_val(); /* degenerate range: everything lands in bin 0 */
+    sF = 0.0;
+    sC = 0.0;
   }
 #pragma unroll
   for (int j = 0; j < GMAX; ++j) {
     bins[j] = 0;
     if (grp[j].valid) {
-      const double x = (best - grp[j].s) * scale;
+      const double d = best - grp[j].s;
+      const double x = d < cut ? d * sF : (double)NF + (d - cut) * sC;
       int bin = (x < (double)P.NB) ? (int)x : P.NB - 1; /* also catches inf / NaN */
       bin = bin < 0 ? 0 : bin;
       bins[j] = bin;
-      atomAdd32(&w.hist[bin], 1u);
+      atomAdd32(&w.hist[FLTX_HB(bin)], 1u);
     }
   }
   FLTX_PROF(1);
   ldsBarrier(); /* 3 */
   /* ---- phase C: wave 0 turns counts into prefixes up to the K-th best's bin --- */
   if (wave == 0) {
-    const int per = (P.NB + 63) / 64;
+    constexpr int PER = 16; /* NB / 64; the skewed index makes lane*16+q conflict-free */
+    int c[PER];
     int mine = 0;
-    for (int q = 0; q < per; ++q) {
-      const int bi = lane * per + q;
-      mine += bi < P.NB ? (int)w.hist[bi] : 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      c[q] = (int)w.hist[FLTX_HB(lane * PER + q)];
+      mine += c[q];
     }
     const int inc = waveInclusiveScan(mine);
     int cum = inc - mine;
-    if (cum < K) { /* my bins start before the crossing: publish their prefixes */
-      for (int q = 0; q < per; ++q) {
-        const int bi = lane * per + q;
-        if (bi >= P.NB) {
-          break;
-        }
-        const int c = (int)w.hist[bi];
-        w.hcum[bi] = (uint32_t)cum;
-        cum += c;
-        if (cum >= K) {
-          w.sc[SC_BSTAR] = bi;
+    if (cum < K) { /* my bins start before the crossing: publish their exclusive prefixes
+                      (one past the crossing bin, so phase E knows every bin's extent) */
+      bool done = false;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        w.hcum[FLTX_HB(lane * PER + q)] = (uint32_t)cum;
+        cum += c[q];
+        if (!done && cum >= K) {
+          w.sc[SC_BSTAR] = lane * PER + q;
           w.sc[SC_CUM] = cum;
-          break;
+          done = true;
         }
+      }
+      if (lane < 63) {
+        w.hcum[FLTX_HB((lane + 1) * PER)] = (uint32_t)cum; /* first bin of the next lane */
       }
     }
     if (lane == 63 && inc < K) { /* fewer than K candidates: keep them all */
@@ -404,46 +435,42 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
     }
     return 0;
   }
-  /* ---- phase D: short-list entries, chained per bin --------------------------- */
+  /* ---- phase D: counting sort of the short-list by bin ---------------------------- */
+  /* position = (candidates in better bins) + a ticket inside the bin; the bin's
+   * count in hist[] doubles as the ticket counter (counted down) */
 #pragma unroll
   for (int j = 0; j < GMAX; ++j) {
-    const bool on = grp[j].valid && bins[j] <= bstar;
-    const unsigned long long m = waveBallot(on);
-    if (m != 0ull) {
-      const int leader = __builtin_ctzll(m);
-      uint32_t base = 0;
-      if (lane == leader) {
-        base = atomAdd32((uint32_t*)&w.sc[SC_NSMALL], (uint32_t)popc64(m));
-      }
-      base = waveShfl32(base, leader);
-      if (on) {
-        const uint32_t p = base + (uint32_t)popc64(m & ((1ull << lane) - 1ull));
-        w.sKey[p] = f64Key(grp[j].s);
-        w.sOrd[p] = grp[j].ord;
-        w.sIdx[p] = (uint32_t)(j * W + tid);
-        w.sSrc[p] = grp[j].src;
-        w.sBin[p] = (uint32_t)bins[j];
-        compilerFence();
-        w.sNext[p] = atomExch32(&w.bhead[bins[j]], p);
-      }
+    if (grp[j].valid && bins[j] <= bstar) {
+      const int hb = FLTX_HB(bins[j]);
+      const uint32_t p = w.hcum[hb] + (atomAdd32(&w.hist[hb], 0xFFFFFFFFu) - 1u);
+      const unsigned long long key = f64Key(grp[j].s);
+      w.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), grp[j].ord, (uint32_t)bins[j]);
+      w.sIdx[p] = (uint32_t)(j * W + tid);
+      w.sSrc[p] = grp[j].src;
     }
   }
   ldsBarrier(); /* 5 */
   FLTX_PROF(3);
   const int nS = L < K ? L : K;
-  const int64_t hbase = P.histOff[f.b] + (int64_t)frameOut * P.K;
+  const int64_t hbase = f.histBase + (int64_t)frameOut * P.K;
   const int nG = P.K * f.nTok;
   /* ---- phase E: entry p ranks itself; rank < K builds beam slot `rank` ---------- */
   for (int p = tid; p < L; p += W) {
-    const unsigned long long k = w.sKey[p];
-    const uint32_t o = w.sOrd[p];
-    const uint32_t bin = w.sBin[p];
-    int rank = (int)w.hcum[bin];
-    for (uint32_t q = w.bhead[bin]; q != kEmpty; q = w.sNext[q]) {
-      const unsigned long long k2 = w.sKey[q];
-      const uint32_t o2 = w.sOrd[q];
-      rank += (k2 > k || (k2 == k && o2 < o)) ? 1 : 0;
+    const uint4 me = w.sEnt[p];
+    const unsigned long long k = ((unsigned long long)me.y << 32) | me.x;
+    const uint32_t o = me.z;
+    /* exact rank = candidates in better bins + members of my bin that precede
+     * me; a bin's members are contiguous after the counting sort */
+    const int bin = (int)me.w;
+    const int lo = (int)w.hcum[FLTX_HB(bin)];
+    const int hi = bin >= bstar ? L : (int)w.hcum[FLTX_HB(bin + 1)];
+    int rank = lo;
+    for (int q = lo; q < hi; ++q) {
+      const uint4 e = w.sEnt[q];
+      const unsigned long long k2 = ((unsigned long long)e.y << 32) | e.x;
+      rank += (k2 > k || (k2 == k && e.z < o)) ? 1 : 0;
     }
+    FLTX_PROF(7);
     if (rank >= K) {
       continue;
     }
@@ -476,12 +503,40 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
       const int prevTok = (int)(w.bTokPb[co + h] & 0x7FFFFFFFu);
       am = w.bAm[co + h] + ((double)f.e[n] + (double)P.transitions[(size_t)n * P.N + prevTok]);
     }
+    /* LM-state id of the new slot, without a global round trip in the common
+     * cases (see DecodeParams::childTab) */
     uint32_t sid;
+    unsigned long long base;
+    int repSlot;
     if (src & kNewState) {
-      bool fresh;
-      sid = stateChild(P, f.b, kp, (int32_t)ke, (uint32_t*)&w.sc[SC_STATUS], fresh);
+      const int rep = g / f.nTok;
+      const int kid = (int)w.dKid[rep * P.N + n];
+      if (kid >= 0) { /* the state is in the beam: take its id from that slot */
+        const int km = w.dMate[kid];
+        sid = w.bState[co + kid];
+        base = w.bMask[co + kid];
+        repSlot = (km >= 0 && km < kid) ? km : kid;
+      } else if ((w.bMask[co + rep] >> n) & 1ull) { /* existed, dropped out: rare re-entry */
+        sid = loadCoherent32(&P.childTab[((size_t)f.b * P.idCap + kp) * P.N + n]);
+        base = loadCoherent64(&P.maskTab[(size_t)f.b * P.idCap + sid]);
+        repSlot = -1;
+      } else { /* first time this state is materialised */
+        sid = atomAdd32((uint32_t*)&w.sc[SC_NEXTID], 1u);
+        if ((int64_t)sid >= P.idCap) {
+          atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_TABLE_FULL);
+          sid = 0;
+        }
+        base = 0ull;
+        repSlot = -1;
+        atomOr64(&w.addMask[rep], 1ull << n);
+        P.childTab[((size_t)f.b * P.idCap + kp) * P.N + n] = sid;
+        P.maskTab[(size_t)f.b * P.idCap + sid] = 0ull;
+      }
     } else {
+      const int hm = w.dMate[h];
       sid = w.bState[co + h];
+      base = w.bMask[co + h];
+      repSlot = (hm >= 0 && hm < h) ? hm : h;
     }
     w.bScore[no + rank] = f64FromKey(k);
     w.bAm[no + rank] = am;
@@ -489,15 +544,31 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
     w.bSPar[no + rank] = kp;
     w.bSEdge[no + rank] = (int32_t)ke;
     w.bTokPb[no + rank] = ktp;
-    P.histPT[hbase + rank] = make_int2(h, n);
+    w.eBase[rank] = base;
+    w.eRep[rank] = repSlot;
+    w.bPar[rank] = h;
+  }
+  ldsBarrier(); /* 6 */
+  /* ---- phase E2: masks incl. this frame's additions; coalesced history write --- */
+  for (int r = tid; r < nS; r += W) {
+    const int rs = w.eRep[r];
+    w.bMask[no + r] = w.eBase[r] | (rs >= 0 ? w.addMask[rs] : 0ull);
+    const int n = (int)(w.bTokPb[no + r] & 0x7FFFFFFFu);
+    P.histPT[hbase + r] = make_int2(w.bPar[r], n);
     if (P.histS) {
-      double* hs = P.histS + 3 * (hbase + rank);
-      hs[0] = f64FromKey(k);
-      hs[1] = am;
+      double* hs = P.histS + 3 * (hbase + r);
+      hs[0] = w.bScore[no + r];
+      hs[1] = w.bAm[no + r];
       hs[2] = 0.0;
     }
   }
-  ldsBarrier(); /* 6 */
+  for (int r = tid; r < f.nBeam; r += W) { /* persist the grown masks of the old states */
+    const unsigned long long add = w.addMask[r];
+    if (add != 0ull) {
+      P.maskTab[(size_t)f.b * P.idCap + w.bState[co + r]] = w.bMask[co + r] | add;
+    }
+  }
+  ldsBarrier(); /* 7 */
   FLTX_PROF(4);
   return nS;
 }
@@ -560,7 +631,7 @@ FLTX_DEV int runEndLean(const DecodeParams& P, const Ws& w, FrameCtx& f, int fra
   }
   __syncthreads();
   const int L = w.sc[SC_NSMALL];
-  const int64_t hbase = P.histOff[f.b] + (int64_t)frameOut * P.K;
+  const int64_t hbase = f.histBase + (int64_t)frameOut * P.K;
   for (int j = tid; j < L; j += W) {
     const unsigned long long k = w.sKey[j];
     const uint32_t o = w.sOrd[j];
@@ -577,6 +648,7 @@ FLTX_DEV int runEndLean(const DecodeParams& P, const Ws& w, FrameCtx& f, int fra
     w.bSPar[no + rank] = w.bSPar[co + h];
     w.bSEdge[no + rank] = w.bSEdge[co + h];
     w.bTokPb[no + rank] = (uint32_t)P.sil;
+    w.bMask[no + rank] = w.bMask[co + h];
     P.histPT[hbase + rank] = make_int2(h, P.sil);
     if (P.histS) {
       double* hs = P.histS + 3 * (hbase + rank);

@@ -42,6 +42,7 @@ FLTX_DEV unsigned long long atomMax64(unsigned long long* p, unsigned long long 
 FLTX_DEV unsigned long long atomMin64(unsigned long long* p, unsigned long long v) {
   return atomicMin(p, v);
 }
+FLTX_DEV unsigned long long atomOr64(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
 FLTX_DEV unsigned long long atomCas64(unsigned long long* p, unsigned long long cmp,
                                       unsigned long long val) {
   return atomicCAS(p, cmp, val);
@@ -50,6 +51,9 @@ FLTX_DEV unsigned long long atomCas64(unsigned long long* p, unsigned long long 
  * L2 atomics by this workgroup, so it must never be read through the
  * non-coherent vector L1 (MI355X_MICROARCH.md, inter-workgroup visibility). */
 FLTX_DEV unsigned long long loadCoherent64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+FLTX_DEV uint32_t loadCoherent32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 FLTX_DEV uint32_t ldsLoad32(const uint32_t* p) {
