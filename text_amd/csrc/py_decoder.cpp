@@ -1,0 +1,244 @@
+/*
+ * py_decoder.cpp -- pybind11 module with the Python surface of the reference's
+ * decoder bindings (bindings/python/flashlight/lib/text/_decoder.cpp:167-441,
+ * _dictionary.cpp:33-60, decoder/_kenlm.cpp:19-25) over this repo's facade
+ * classes, so `from flashlight.lib.text.decoder import ...` code runs on the
+ * MI355X path (see text_amd/compat/).  Same class names, constructor keywords,
+ * method names, raw-address emissions (`ndarray.ctypes.data`) and pickle
+ * support; seq2seq classes are out of scope.  Additive: decode_batch().
+ */
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <limits>
+
+#include "flashlight/lib/text/decoder/LexiconDecoder.h"
+#include "flashlight/lib/text/decoder/LexiconFreeDecoder.h"
+#include "flashlight/lib/text/decoder/Trie.h"
+#include "flashlight/lib/text/decoder/lm/KenLM.h"
+#include "flashlight/lib/text/decoder/lm/ZeroLM.h"
+#include "flashlight/lib/text/dictionary/Utils.h"
+
+namespace py = pybind11;
+using namespace fl::lib::text;
+using namespace py::literals;
+
+namespace {
+
+/* Python subclasses of LM (the reference's PyLM trampoline, _decoder.cpp:39-56).
+ * They work for host-side scoring; a decoder refuses them (no device tables,
+ * no CPU decode path). */
+class PyLM : public LM {
+ public:
+  using LM::LM;
+  using LMOutput = std::pair<LMStatePtr, float>;
+  LMStatePtr start(bool startWithNothing) override {
+    PYBIND11_OVERRIDE_PURE(LMStatePtr, LM, start, startWithNothing);
+  }
+  LMOutput score(const LMStatePtr& state, const int usrTokenIdx) override {
+    PYBIND11_OVERRIDE_PURE(LMOutput, LM, score, state, usrTokenIdx);
+  }
+  LMOutput finish(const LMStatePtr& state) override { PYBIND11_OVERRIDE_PURE(LMOutput, LM, finish, state); }
+};
+
+const float* asPtr(uintptr_t p) { return reinterpret_cast<const float*>(p); }
+
+template <class Dec>
+void bindDecoderMethods(py::class_<Dec>& c) {
+  c.def("decode_begin", &Dec::decodeBegin)
+      .def("decode_step", [](Dec& d, uintptr_t e, int T, int N) { d.decodeStep(asPtr(e), T, N); },
+           "emissions"_a, "T"_a, "N"_a)
+      .def("decode_end", &Dec::decodeEnd)
+      .def("decode", [](Dec& d, uintptr_t e, int T, int N) { return d.decode(asPtr(e), T, N); },
+           "emissions"_a, "T"_a, "N"_a)
+      .def("prune", &Dec::prune, "look_back"_a = 0)
+      .def("get_best_hypothesis", &Dec::getBestHypothesis, "look_back"_a = 0)
+      .def("get_all_final_hypothesis", &Dec::getAllFinalHypothesis)
+      .def("n_hypothesis", &Dec::nHypothesis)
+      .def("n_decoded_frames_in_buffer", &Dec::nDecodedFramesInBuffer)
+      /* additive: B utterances packed back to back at `emissions` */
+      .def("decode_batch",
+           [](Dec& d, uintptr_t e, const std::vector<int>& T, int N, bool onDevice) {
+             return d.decodeBatch(asPtr(e), T, N, {}, onDevice);
+           },
+           "emissions"_a, "T"_a, "N"_a, "on_device"_a = false);
+}
+
+} // namespace
+
+PYBIND11_MODULE(flashlight_lib_text_decoder, m) {
+  m.doc() = "flashlight/text decoder bindings backed by the MI355X kernels (libfltx)";
+
+  py::enum_<SmearingMode>(m, "SmearingMode")
+      .value("NONE", SmearingMode::NONE)
+      .value("MAX", SmearingMode::MAX)
+      .value("LOGADD", SmearingMode::LOGADD);
+
+  py::class_<TrieNode, TrieNodePtr>(m, "TrieNode")
+      .def(py::init<int>(), "idx"_a)
+      .def_readwrite("children", &TrieNode::children)
+      .def_readwrite("idx", &TrieNode::idx)
+      .def_readwrite("labels", &TrieNode::labels)
+      .def_readwrite("scores", &TrieNode::scores)
+      .def_readwrite("max_score", &TrieNode::maxScore);
+
+  py::class_<Trie, TriePtr>(m, "Trie")
+      .def(py::init<int, int>(), "max_children"_a, "root_idx"_a)
+      .def("get_root", &Trie::getRoot, py::return_value_policy::reference_internal)
+      .def("insert", &Trie::insert, "indices"_a, "label"_a, "score"_a)
+      .def("search", &Trie::search, "indices"_a)
+      .def("smear", &Trie::smear, "smear_mode"_a);
+
+  py::class_<LM, LMPtr, PyLM>(m, "LM")
+      .def(py::init<>())
+      .def("start", &LM::start, "start_with_nothing"_a)
+      .def("score", &LM::score, "state"_a, "usr_token_idx"_a)
+      .def("finish", &LM::finish, "state"_a);
+
+  py::class_<LMState, LMStatePtr>(m, "LMState")
+      .def(py::init<>())
+      .def_readwrite("children", &LMState::children)
+      .def("compare", &LMState::compare, "state"_a)
+      .def("child", &LMState::child<LMState>, "usr_index"_a);
+
+  py::class_<ZeroLM, ZeroLMPtr, LM>(m, "ZeroLM").def(py::init<>());
+  py::class_<KenLM, KenLMPtr, LM>(m, "KenLM")
+      .def(py::init<const std::string&, const Dictionary&>(), "path"_a, "usr_token_dict"_a);
+
+  py::enum_<CriterionType>(m, "CriterionType")
+      .value("ASG", CriterionType::ASG)
+      .value("CTC", CriterionType::CTC)
+      .value("S2S", CriterionType::S2S);
+
+  py::class_<LexiconDecoderOptions>(m, "LexiconDecoderOptions")
+      .def(py::init<const int, const int, const double, const double, const double, const double,
+                    const double, const bool, const CriterionType>(),
+           "beam_size"_a, "beam_size_token"_a, "beam_threshold"_a, "lm_weight"_a, "word_score"_a,
+           "unk_score"_a, "sil_score"_a, "log_add"_a, "criterion_type"_a)
+      .def_readwrite("beam_size", &LexiconDecoderOptions::beamSize)
+      .def_readwrite("beam_size_token", &LexiconDecoderOptions::beamSizeToken)
+      .def_readwrite("beam_threshold", &LexiconDecoderOptions::beamThreshold)
+      .def_readwrite("lm_weight", &LexiconDecoderOptions::lmWeight)
+      .def_readwrite("word_score", &LexiconDecoderOptions::wordScore)
+      .def_readwrite("unk_score", &LexiconDecoderOptions::unkScore)
+      .def_readwrite("sil_score", &LexiconDecoderOptions::silScore)
+      .def_readwrite("log_add", &LexiconDecoderOptions::logAdd)
+      .def_readwrite("criterion_type", &LexiconDecoderOptions::criterionType)
+      .def(py::pickle(
+          [](const LexiconDecoderOptions& p) {
+            return py::make_tuple(p.beamSize, p.beamSizeToken, p.beamThreshold, p.lmWeight, p.wordScore,
+                                  p.unkScore, p.silScore, p.logAdd, p.criterionType);
+          },
+          [](py::tuple t) {
+            if (t.size() != 9) {
+              throw std::runtime_error(
+                  "Cannot run __setstate__ on LexiconDecoderOptions - insufficient arguments provided.");
+            }
+            return LexiconDecoderOptions{t[0].cast<int>(),    t[1].cast<int>(),    t[2].cast<double>(),
+                                         t[3].cast<double>(), t[4].cast<double>(), t[5].cast<double>(),
+                                         t[6].cast<double>(), t[7].cast<bool>(),   t[8].cast<CriterionType>()};
+          }));
+
+  py::class_<LexiconFreeDecoderOptions>(m, "LexiconFreeDecoderOptions")
+      .def(py::init<const int, const int, const double, const double, const double, const bool,
+                    const CriterionType>(),
+           "beam_size"_a, "beam_size_token"_a, "beam_threshold"_a, "lm_weight"_a, "sil_score"_a, "log_add"_a,
+           "criterion_type"_a)
+      .def_readwrite("beam_size", &LexiconFreeDecoderOptions::beamSize)
+      .def_readwrite("beam_size_token", &LexiconFreeDecoderOptions::beamSizeToken)
+      .def_readwrite("beam_threshold", &LexiconFreeDecoderOptions::beamThreshold)
+      .def_readwrite("lm_weight", &LexiconFreeDecoderOptions::lmWeight)
+      .def_readwrite("sil_score", &LexiconFreeDecoderOptions::silScore)
+      .def_readwrite("log_add", &LexiconFreeDecoderOptions::logAdd)
+      .def_readwrite("criterion_type", &LexiconFreeDecoderOptions::criterionType)
+      .def(py::pickle(
+          [](const LexiconFreeDecoderOptions& p) {
+            return py::make_tuple(p.beamSize, p.beamSizeToken, p.beamThreshold, p.lmWeight, p.silScore,
+                                  p.logAdd, p.criterionType);
+          },
+          [](py::tuple t) {
+            if (t.size() != 7) {
+              throw std::runtime_error(
+                  "Cannot run __setstate__ on LexiconFreeDecoderOptions - insufficient arguments provided.");
+            }
+            return LexiconFreeDecoderOptions{t[0].cast<int>(),    t[1].cast<int>(),  t[2].cast<double>(),
+                                             t[3].cast<double>(), t[4].cast<double>(), t[5].cast<bool>(),
+                                             t[6].cast<CriterionType>()};
+          }));
+
+  py::class_<DecodeResult>(m, "DecodeResult")
+      .def(py::init<int>(), "length"_a)
+      .def_readwrite("score", &DecodeResult::score)
+      .def_readwrite("emittingModelScore", &DecodeResult::emittingModelScore)
+      .def_readwrite("lmScore", &DecodeResult::lmScore)
+      .def_readwrite("words", &DecodeResult::words)
+      .def_readwrite("tokens", &DecodeResult::tokens);
+
+  py::class_<LexiconDecoder> lex(m, "LexiconDecoder");
+  lex.def(py::init<LexiconDecoderOptions, const TriePtr, const LMPtr, const int, const int, const int,
+                   const std::vector<float>&, const bool>(),
+          "options"_a, "trie"_a, "lm"_a, "sil_token_idx"_a, "blank_token_idx"_a, "unk_token_idx"_a,
+          "transitions"_a, "is_token_lm"_a);
+  bindDecoderMethods(lex);
+
+  py::class_<LexiconFreeDecoder> lf(m, "LexiconFreeDecoder");
+  lf.def(py::init<LexiconFreeDecoderOptions, const LMPtr, const int, const int, const std::vector<float>&>(),
+         "options"_a, "lm"_a, "sil_token_idx"_a, "blank_token_idx"_a, "transitions"_a)
+      .def("get_options", &LexiconFreeDecoder::getOptions)
+      .def("get_sil_idx", &LexiconFreeDecoder::getSilIdx)
+      .def("get_blank_idx", &LexiconFreeDecoder::getBlankIdx)
+      .def("get_transitions", &LexiconFreeDecoder::getTransitions)
+      .def(py::pickle(
+          /* as the reference (_decoder.cpp:409-441): only a stateless decoder over ZeroLM pickles */
+          [](const LexiconFreeDecoder& d) {
+            if (!std::dynamic_pointer_cast<ZeroLM>(d.getLMPtr())) {
+              throw std::runtime_error("LexiconFreeDecoder.__getstate__: only decoders using ZeroLM can be pickled");
+            }
+            return py::make_tuple(d.getOptions(), d.getSilIdx(), d.getBlankIdx(), d.getTransitions());
+          },
+          [](py::tuple t) {
+            if (t.size() != 4) {
+              throw std::runtime_error("Cannot run __setstate__ on LexiconFreeDecoder - insufficient arguments provided.");
+            }
+            return std::make_unique<LexiconFreeDecoder>(t[0].cast<LexiconFreeDecoderOptions>(),
+                                                        std::make_shared<ZeroLM>(), t[1].cast<int>(),
+                                                        t[2].cast<int>(), t[3].cast<std::vector<float>>());
+          }));
+  bindDecoderMethods(lf);
+
+  /* ---- dictionary (bindings/python/flashlight/lib/text/_dictionary.cpp:33-60) ---- */
+  py::class_<Dictionary>(m, "Dictionary")
+      .def(py::init<>())
+      .def(py::init([](const std::string& filename) { return loadDictionary(filename); }), "filename"_a)
+      .def(py::init<const std::vector<std::string>&>(), "tkns"_a)
+      .def("entry_size", &Dictionary::entrySize)
+      .def("index_size", &Dictionary::indexSize)
+      .def("add_entry", [](Dictionary& d, const std::string& e, int idx) { d.addEntry(e, idx); }, "entry"_a, "idx"_a)
+      .def("add_entry", [](Dictionary& d, const std::string& e) { d.addEntry(e); }, "entry"_a)
+      .def("get_entry", &Dictionary::getEntry, "idx"_a)
+      .def("set_default_index", &Dictionary::setDefaultIndex, "idx"_a)
+      .def("get_index", &Dictionary::getIndex, "entry"_a)
+      .def("contains", &Dictionary::contains, "entry"_a)
+      .def("map_entries_to_indices",
+           [](const Dictionary& d, const std::vector<std::string>& es) {
+             std::vector<int> out;
+             for (const auto& e : es) {
+               out.push_back(d.getIndex(e));
+             }
+             return out;
+           },
+           "entries"_a)
+      .def("map_indices_to_entries",
+           [](const Dictionary& d, const std::vector<int>& is) {
+             std::vector<std::string> out;
+             for (int i : is) {
+               out.push_back(d.getEntry(i));
+             }
+             return out;
+           },
+           "indices"_a);
+  m.def("create_word_dict", &createWordDict, "lexicon"_a);
+  m.def("load_words", &loadWords, "filename"_a, "max_words"_a = -1);
+  m.def("pack_replabels", &packReplabels, "tokens"_a, "dict"_a, "max_reps"_a);
+  m.def("tkn_to_idx", &tkn2Idx, "spelling"_a, "token_dict"_a, "maxReps"_a);
+}
