@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=64, help="utterances timed on the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
+    ap.add_argument("--set", action="append", default=[], help="decoder tunable key=value (repeatable)")
     return ap.parse_args()
 
 
@@ -97,6 +98,9 @@ def main():
         dec = _capi.BatchDecoder(ctx, _capi.LEXFREE, opt, lm, 0, N - 1)
     if a.threads:
         dec.set("threads", a.threads)
+    for kv in a.set:
+        k, v = kv.split("=")
+        dec.set(k, int(v))
     Ts = np.full(B, T, dtype=np.int32)
 
     def step():

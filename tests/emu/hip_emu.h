@@ -51,6 +51,16 @@ extern thread_local EmuBlock* emuBlock;
 
 static inline void __syncthreads() { pthread_barrier_wait(&emuBlock->bar); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline float __uint_as_float(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline uint32_t __float_as_uint(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
 static inline long long __double_as_longlong(double d) {
   long long r;
   memcpy(&r, &d, 8);

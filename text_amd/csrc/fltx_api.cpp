@@ -192,7 +192,7 @@ struct fltx_trie {
   fltx_ctx* ctx = nullptr;
   int64_t nNodes = 0;
   int32_t nTokens = 0;
-  DBuf child, info, labels;
+  DBuf edge, labels;
 };
 
 struct fltx_decoder {
@@ -226,7 +226,8 @@ struct fltx_decoder {
   DBuf emis, emOff, stepT, histOffD, histPT, histW, stateTab, stateCtx;
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
-  DBuf childTab, maskTab, uttNextId, gMask;
+  DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
+  int rowCache = 0, noRowCache = 1; /* measured slower on C3 (LDS pressure): opt-in */
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   int keepScores = 0;
@@ -655,21 +656,37 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
   if (nNodes >= (1ll << 31)) {
     return fail(FLTX_ERR_UNSUPPORTED, "trie too large");
   }
-  std::vector<TrieNodeInfo> info((size_t)nNodes);
+  if (nNodes >= (1ll << 28) || (int64_t)labelOff[nNodes] >= (1ll << 28)) {
+    return fail(FLTX_ERR_UNSUPPORTED, "trie too large for the packed edge records");
+  }
+  std::vector<int32_t> nKids((size_t)nNodes, 0);
   for (int64_t i = 0; i < nNodes; ++i) {
-    int nc = 0;
     for (int t = 0; t < nTokens; ++t) {
-      int32_t c = child[i * nTokens + t];
+      const int32_t c = child[i * nTokens + t];
       if (c >= nNodes) {
         return fail(FLTX_ERR_RANGE, "trie child index %d out of range", c);
       }
-      nc += c >= 0;
+      nKids[i] += c >= 0;
     }
-    int nl = labelOff[i + 1] - labelOff[i];
+    const int nl = labelOff[i + 1] - labelOff[i];
     if (nl < 0 || nl > 6) {
       return fail(FLTX_ERR_INVALID, "trie node %lld has %d labels (kTrieMaxLabel = 6)", (long long)i, nl);
     }
-    info[i] = TrieNodeInfo{maxScore[i], labelOff[i], nl, nc};
+  }
+  std::vector<TrieEdge> edge((size_t)nNodes * nTokens);
+  for (int64_t i = 0; i < nNodes; ++i) {
+    for (int t = 0; t < nTokens; ++t) {
+      const int32_t c = child[i * nTokens + t];
+      TrieEdge e{-1, 0.0f, -1, 0u};
+      if (c >= 0) {
+        const int nl = labelOff[c + 1] - labelOff[c];
+        e.child = c;
+        e.childMax = maxScore[c];
+        e.label0 = nl > 0 ? labels[labelOff[c]] : -1;
+        e.meta = (uint32_t)nl | (nKids[c] > 0 ? 8u : 0u) | ((uint32_t)labelOff[c] << 4);
+      }
+      edge[(size_t)i * nTokens + t] = e;
+    }
   }
   auto* t = new fltx_trie();
   t->ctx = ctx;
@@ -677,14 +694,12 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
   t->nTokens = nTokens;
   Stream st = ctx->stream;
   size_t nLab = (size_t)labelOff[nNodes];
-  if (t->child.ensure(sizeof(int32_t) * (size_t)nNodes * nTokens, st, false) ||
-      t->info.ensure(sizeof(TrieNodeInfo) * (size_t)nNodes, st, false) ||
+  if (t->edge.ensure(sizeof(TrieEdge) * edge.size(), st, false) ||
       t->labels.ensure(sizeof(int32_t) * std::max<size_t>(1, nLab), st, false)) {
     delete t;
     return fail(FLTX_ERR_OOM, "trie: device allocation failed");
   }
-  if (devCopyH2D(t->child.p, child, sizeof(int32_t) * (size_t)nNodes * nTokens, st) ||
-      devCopyH2D(t->info.p, info.data(), sizeof(TrieNodeInfo) * (size_t)nNodes, st) ||
+  if (devCopyH2D(t->edge.p, edge.data(), sizeof(TrieEdge) * edge.size(), st) ||
       (nLab && devCopyH2D(t->labels.p, labels, sizeof(int32_t) * nLab, st)) || devSync(st)) {
     delete t;
     return fail(FLTX_ERR_HIP, "trie: upload failed");
@@ -807,6 +822,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->profile = value != 0;
     return FLTX_OK;
   }
+  if (!strcmp(key, "row_cache")) { /* 1: cache the beam slots' trie child rows in LDS (default off) */
+    d->noRowCache = value == 0;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "lean")) { /* 0: lexicon-free + ZeroLM frames use the generic engine */
     d->noLean = value == 0;
     return FLTX_OK;
@@ -877,7 +896,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
    * utterance win as long as the batch does not fill the CUs on its own
    * (measured on C2: 256 -> 15.3 ms, 512 -> 13.0 ms per 256-utterance batch) */
   if (!d->userThreads) {
-    d->threads = (d->kind == FLTX_DECODER_LEXFREE && B <= 512) ? 512 : 256;
+    d->threads = B <= 512 ? 512 : 256; /* C3: 256 -> 13.2 M frames/s, 512 -> 15.2 M */
   }
   /* lean frame step (fltx_lean.h): lexicon-free + ZeroLM, groups held in registers */
   d->lean = 0;
@@ -895,13 +914,17 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   int64_t capC = worst;
   d->NB = 1024;
   d->SCAP = K + 256;
+  /* lexicon decoder: cache the beam slots' child rows in LDS when the prefetch
+   * registers cover the beam (16 slots per wave) */
+  d->rowCache = (d->kind == FLTX_DECODER_LEXICON && !d->noRowCache && !d->forceGlobalWs && N <= 64 &&
+                 K <= 16 * (d->threads / 64)) ? 1 : 0;
   Ws tmp;
   auto hsFor = [&](int64_t c) {
     int64_t keys = d->dense ? K : c;
     return std::max((int)nextPow2((uint64_t)keys * 2), 64);
   };
   auto bytesFor = [&](int64_t c) {
-    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense);
+    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->rowCache);
   };
   bool lds = !d->forceGlobalWs;
   if (lds && bytesFor(capC) > kMaxLds) {
@@ -920,9 +943,12 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       lds = false;
     }
   }
+  if (!lds) {
+    d->rowCache = 0; /* HBM workspace: gather the edges where they are */
+  }
   d->CAP = (int)capC;
   d->HS = hsFor(capC);
-  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense);
+  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->rowCache);
   d->wsInLds = lds;
   /* buffers */
   bool grewTab = false;
@@ -956,7 +982,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   size_t bk = (size_t)B * K;
   rc |= d->gScore.ensure(8 * bk, st, false) | d->gAm.ensure(8 * bk, st, false) | d->gLm.ensure(8 * bk, st, false);
   rc |= d->gState.ensure(4 * bk, st, false) | d->gSPar.ensure(4 * bk, st, false) | d->gSEdge.ensure(4 * bk, st, false);
-  rc |= d->gLex.ensure(4 * bk, st, false) | d->gTokPb.ensure(4 * bk, st, false);
+  rc |= d->gLex.ensure(4 * bk, st, false) | d->gTokPb.ensure(4 * bk, st, false) | d->gLexMax.ensure(4 * bk, st, false);
   rc |= d->uttNBeam.ensure(4 * (size_t)B, st, true) | d->uttFrame.ensure(4 * (size_t)B, st, true);
   rc |= d->uttTotal.ensure(4 * (size_t)B, st, true) | d->uttStatus.ensure(4 * (size_t)B, st, true);
   rc |= d->outN.ensure(4 * (size_t)B, st, true) | d->outScores.ensure(8 * bk * 3, st, false);
@@ -999,8 +1025,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.N = d->N;
   P.transitions = d->nTrans ? d->transitions.as<float>() : nullptr;
   if (d->trie) {
-    P.trieChild = d->trie->child.as<int32_t>();
-    P.trieInfo = d->trie->info.as<TrieNodeInfo>();
+    P.trieEdge = d->trie->edge.as<TrieEdge>();
     P.trieLabels = d->trie->labels.as<int32_t>();
   }
   P.lmKind = d->lm->kind;
@@ -1040,6 +1065,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.NB = d->NB;
   P.SCAP = d->SCAP;
   P.dense = d->dense;
+  P.rowCache = d->rowCache;
+  P.gLexMax = d->gLexMax.as<float>();
   P.gws = d->wsInLds ? nullptr : d->gws.as<char>();
   P.gwsStride = (int64_t)d->wsBytes;
   P.outN = d->outN.as<int32_t>();

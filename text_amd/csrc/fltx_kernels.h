@@ -59,6 +59,16 @@ struct TrieNodeInfo { /* 16 B, one gather per visited trie node */
   int32_t nChildren;
 };
 
+/* One 16-byte record per (trie node, token): everything candidate generation
+ * needs about the child reached by that token, so a hypothesis' whole child row
+ * is one contiguous N*16-byte read (prefetched a frame ahead into LDS). */
+struct TrieEdge {
+  int32_t child;   /* child node id, -1 = no such child */
+  float childMax;  /* child's TrieNode::maxScore (Trie.h:54) */
+  int32_t label0;  /* child's first label, -1 if none */
+  uint32_t meta;   /* nLabels:3 | hasChildren:1 | labOff:28 */
+};
+
 struct NgramSlot { /* 16 B open-addressing slot: (context node, word) -> n-gram */
   uint32_t ctx;    /* node id of the context n-gram (0 = empty context) */
   uint32_t word;   /* LM word id; 0xFFFFFFFF = empty slot */
@@ -66,9 +76,15 @@ struct NgramSlot { /* 16 B open-addressing slot: (context node, word) -> n-gram 
   float prob;      /* log10 p */
 };
 
+/* histogram arrays are indexed with one pad word per 16 bins so that a lane
+ * reading its 16 consecutive bins hits 16 different LDS banks */
+#define FLTX_HB(b) ((b) + ((b) >> 4))
+
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kNoParent = 0x00FFFFFFu; /* parent id of the root LM state */
 constexpr uint32_t kNewState = 0x80000000u; /* cSrc flag: candidate enters a new LM state */
+constexpr uint32_t kExtend = 0x40000000u;   /* cSrc flag: cAux holds the child's maxScore bits */
+constexpr uint32_t kSrcMask = 0x3FFFFFFFu;
 constexpr uint32_t kPrevBlank = 0x80000000u; /* tokPb flag */
 constexpr int kFinishEdge = -1;              /* KenLM::finish child key (KenLM.cpp:79) */
 constexpr uint32_t kPhantomNode = 0x80000000u; /* NgramSlot.node: navigation-only prefix */
@@ -84,9 +100,9 @@ struct DecodeParams {
   int32_t sil, blank, unk, isLmToken, kind, N;
   const float* transitions; /* [N*N] or null */
   /* flat trie */
-  const int32_t* trieChild; /* [nNodes*N] */
-  const TrieNodeInfo* trieInfo;
+  const TrieEdge* trieEdge; /* [nNodes*N] */
   const int32_t* trieLabels;
+  int32_t rowCache;         /* 1: child rows of the beam slots are cached in LDS */
   /* LM */
   int32_t lmKind; /* 0 ZeroLM, 1 n-gram */
   int32_t lmOrder;
@@ -110,6 +126,7 @@ struct DecodeParams {
   double* gScore;
   double* gAm;
   double* gLm;
+  float* gLexMax;
   uint32_t* gState;
   uint32_t* gSPar;
   int32_t* gSEdge;
@@ -161,6 +178,8 @@ struct Ws {
   int32_t* bSEdge;
   uint32_t* bLex;
   uint32_t* bTokPb;
+  float* bLexMax;  /* [2K] maxScore of the slot's trie node, 0 at the root (LexiconDecoder.cpp:58-59) */
+  uint4* rowEdge;  /* [K*N] cached TrieEdge rows of the current beam (lexicon decoder) */
   /* candidate records */
   double* cScore;
   uint4* cKey;     /* {state parent, state edge, lex node, token | prevBlank<<31} */
@@ -220,7 +239,7 @@ FLTX_HD size_t alignUp(size_t x, size_t a) { return (x + a - 1) / a * a; }
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
-                       int dense) {
+                       int dense, int rowCache) {
   size_t off = 0;
 #define FLTX_CARVE(field, type, count)                       \
   off = alignUp(off, 16);                                    \
@@ -234,6 +253,8 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.bSEdge, int32_t, 2 * K)
   FLTX_CARVE(w.bLex, uint32_t, 2 * K)
   FLTX_CARVE(w.bTokPb, uint32_t, 2 * K)
+  FLTX_CARVE(w.bLexMax, float, 2 * K)
+  FLTX_CARVE(w.rowEdge, uint4, rowCache ? (size_t)K * N : 0)
   FLTX_CARVE(w.erow, float, 2 * N)
   FLTX_CARVE(w.cScore, double, CAP)
   FLTX_CARVE(w.cKey, uint4, CAP)
@@ -251,11 +272,11 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.sOrd, uint32_t, SCAP)
   FLTX_CARVE(w.sIdx, uint32_t, SCAP)
   FLTX_CARVE(w.sSrc, uint32_t, SCAP)
-  FLTX_CARVE(w.sEnt, uint4, dense ? SCAP : 0)
+  FLTX_CARVE(w.sEnt, uint4, SCAP)
   FLTX_CARVE(w.sBin, uint32_t, dense ? SCAP : 0)
   FLTX_CARVE(w.sNext, uint32_t, dense ? SCAP : 0)
   FLTX_CARVE(w.bhead, uint32_t, dense ? NB + NB / 16 + 1 : 0)
-  FLTX_CARVE(w.hcum, uint32_t, dense ? NB + NB / 16 + 1 : 0)
+  FLTX_CARVE(w.hcum, uint32_t, NB + NB / 16 + 1)
   FLTX_CARVE(w.dKid, int16_t, dense ? (size_t)K * N : 0)
   FLTX_CARVE(w.bMask, unsigned long long, dense ? 2 * K : 0)
   FLTX_CARVE(w.addMask, unsigned long long, dense ? K : 0)
@@ -418,6 +439,7 @@ FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
       cur = atomCas32(&w.head[s], kEmpty, ci);
       if (cur == kEmpty) {
         w.cNext[ci] = kEmpty;
+        w.small[ci] = s; /* chain owner: foldGroups starts from head[s] */
         break;
       }
     }
@@ -598,6 +620,16 @@ FLTX_DEV unsigned long long devClock() { return __builtin_readcyclecounter(); }
       f.t0 = t_;                                                       \
     }                                                                  \
   } while (0)
+
+/* child rows of the next beam, loaded at the end of a frame and parked in
+ * registers until the next frame writes them to LDS: the ~2k-clock global
+ * latency overlaps the frame hand-over instead of stalling candidate generation.
+ * Lane = token, slot = wave + q * nWaves. */
+constexpr int kRowPF = 16;
+struct RowPF {
+  uint4 e[kRowPF];
+  bool valid;
+};
 
 struct FrameCtx {
   unsigned long long t0;
@@ -933,7 +965,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     /* up to 1 extend + 6 labels (or 1 unk) candidates per item, pushed in
      * lock-step so the wave-aggregated append stays convergent */
     bool cExt = false, cStay = false;
-    int nLab = 0, labOff = 0;
+    int nLab = 0, labOff = 0, lab0 = -1;
     bool cUnk = false;
     int h = 0, n = 0;
     uint32_t childId = 0;
@@ -956,12 +988,20 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       const double hs = w.bScore[(f.cur) * P.K + h];
       if (r < f.nTok) { /* (1) children, :62-165 */
         n = (f.nTok == P.N) ? r : w.tokIdx[r];
-        const int32_t c = P.trieChild[(size_t)lexId * P.N + n];
-        if (c >= 0) {
-          childId = (uint32_t)c;
-          const TrieNodeInfo ci = P.trieInfo[c];
-          lexMax = atRoot ? 0.0f : P.trieInfo[lexId].maxScore; /* :58-59 */
-          childMax = ci.maxScore;
+        TrieEdge ed;
+        if (P.rowCache) {
+          const uint4 q = w.rowEdge[h * P.N + n];
+          ed.child = (int32_t)q.x;
+          ed.childMax = __uint_as_float(q.y);
+          ed.label0 = (int32_t)q.z;
+          ed.meta = q.w;
+        } else {
+          ed = P.trieEdge[(size_t)lexId * P.N + n];
+        }
+        if (ed.child >= 0) {
+          childId = (uint32_t)ed.child;
+          lexMax = w.bLexMax[(f.cur) * P.K + h]; /* :58-59 */
+          childMax = ed.childMax;
           amDelta = (double)f.e[n];
           if (f.useTrans) {
             amDelta += (double)P.transitions[(size_t)n * P.N + prevTok];
@@ -973,12 +1013,14 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
           if (P.isLmToken) {
             lmTok = lmScoreDev(P, f.b, sid, n); /* :82-86 */
           }
-          cExt = (!ctc || prevBlank || n != prevTok) && ci.nChildren > 0; /* :89-91 */
+          const int nl = (int)(ed.meta & 7u);
+          cExt = (!ctc || prevBlank || n != prevTok) && (ed.meta & 8u) != 0; /* :89-91 */
           if (!(atRoot && prevTok == n)) { /* :114-122 */
-            nLab = ci.nLabels;
-            labOff = ci.labOff;
+            nLab = nl;
+            labOff = (int)(ed.meta >> 4);
+            lab0 = ed.label0;
           }
-          cUnk = ci.nLabels == 0 && hasUnk; /* :145 */
+          cUnk = nl == 0 && hasUnk; /* :145 */
         }
       } else if (r == f.nTok) { /* (2) same lexicon node, :168-194 */
         if (!ctc || !prevBlank || atRoot) {
@@ -1007,8 +1049,9 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       double sc = base + P.lmWeight * (double)l;
       uint32_t kp = P.isLmToken ? sid : spar;
       uint32_t ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
-      uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u);
-      pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, -1, l, ordBase, bestKey);
+      uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u) | kExtend;
+      pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, (int32_t)__float_as_uint(childMax), l,
+                    ordBase, bestKey);
     }
     /* (1b) word ends: one candidate per label of the child */
     for (int j = 0; j < 6; ++j) {
@@ -1021,7 +1064,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       int label = -1;
       uint32_t kp = 0, ke = 0;
       if (on) {
-        label = P.trieLabels[labOff + j];
+        label = j == 0 ? lab0 : P.trieLabels[labOff + j];
         if (!P.isLmToken) {
           l = lmScoreDev(P, f.b, sid, label) - lexMax; /* float subtraction, :127 */
           kp = sid;
@@ -1108,15 +1151,17 @@ FLTX_DEV void genEnd(const DecodeParams& P, const Ws& w, const FrameCtx& f,
 /* ------------------------------------------------------------------------ */
 /* fold hash chains into groups (candidatesStore steps 1-2, Utils.h:160-198)  */
 /* ------------------------------------------------------------------------ */
-FLTX_DEV void foldGroups(const DecodeParams& P, const Ws& w, double thr) {
+FLTX_DEV void foldGroups(const DecodeParams& P, const Ws& w, double thr, int nCand) {
   const int W = (int)blockDim.x;
-  const int rounds = (P.HS + W - 1) / W;
+  /* one thread per hash chain: the chain's first inserter (the only member
+   * whose next pointer is empty) recorded its slot in small[] */
+  const int rounds = (nCand + W - 1) / W;
   for (int it = 0; it < rounds; ++it) {
-    const int s = it * W + (int)threadIdx.x;
+    const int ci = it * W + (int)threadIdx.x;
     uint32_t bestIdx = kEmpty;
     double acc = 0;
-    if (s < P.HS) {
-      const uint32_t hd = w.head[s];
+    if (ci < nCand && w.cNext[ci] == kEmpty) {
+      const uint32_t hd = w.head[w.small[ci]];
       if (hd != kEmpty) {
         /* best member: highest score, ties to the earliest generated */
         uint32_t bestOrd = 0;
@@ -1375,9 +1420,11 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
       w.red[0] = 0ull;
       w.red[1] = ~0ull;
       w.sc[SC_NSMALL] = 0;
+      w.sc[SC_BSTAR] = P.NB - 1;
+      w.sc[SC_CUM] = 0;
     }
     for (int i = tid; i < P.NB; i += W) {
-      w.hist[i] = 0;
+      w.hist[FLTX_HB(i)] = 0;
     }
     wsBarrier(P);
     kmax = waveMax64(kmax);
@@ -1390,7 +1437,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
     const double hi = f64FromKey(w.red[0]);
     const double lo = w.red[1] == ~0ull ? hi : f64FromKey(w.red[1]);
     const double scale = (double)P.NB / (hi - lo);
-    if (!(hi > lo) || !(scale > 0.0) || !(scale < 1e300)) {
+    if (!(hi > lo) || !(scale > 0.0) || !(scale < 1e300) || P.NB != 1024) {
       slow = true;
     } else {
       for (int i = tid; i < nLead; i += W) {
@@ -1399,30 +1446,38 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
         int bin = (x < (double)P.NB) ? (int)x : P.NB - 1;
         bin = bin < 0 ? 0 : bin;
         w.lbin[i] = (uint16_t)bin;
-        atomAdd32(&w.hist[bin], 1u);
+        atomAdd32(&w.hist[FLTX_HB(bin)], 1u);
       }
       wsBarrier(P);
-      const int per = (P.NB + W - 1) / W;
-      int mine = 0;
-      for (int q = 0; q < per; ++q) {
-        const int bi = tid * per + q;
-        if (bi < P.NB) {
-          mine += (int)w.hist[bi];
+      /* wave 0: counts -> exclusive prefixes up to the bin of the K-th best
+       * (16 bins per lane, held in registers; see fltx_lean.h phase C) */
+      if (waveId() == 0) {
+        constexpr int PER = 16;
+        const int lane = laneId();
+        int c[PER];
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          c[q] = (int)w.hist[FLTX_HB(lane * PER + q)];
+          mine += c[q];
         }
-      }
-      int tot;
-      const int before = blockExclusiveScan(P, mine, w.wtmp, &tot);
-      if (before < K && before + mine >= K) {
-        int cum = before;
-        for (int q = 0; q < per; ++q) {
-          const int bi = tid * per + q;
-          const int c = (int)w.hist[bi];
-          if (cum + c >= K) {
-            w.sc[SC_BSTAR] = bi;
-            w.sc[SC_CUM] = cum + c;
-            break;
+        const int inc = waveInclusiveScan(mine);
+        int cum = inc - mine;
+        if (cum < K) {
+          bool done = false;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            w.hcum[FLTX_HB(lane * PER + q)] = (uint32_t)cum;
+            cum += c[q];
+            if (!done && cum >= K) {
+              w.sc[SC_BSTAR] = lane * PER + q;
+              w.sc[SC_CUM] = cum;
+              done = true;
+            }
           }
-          cum += c;
+          if (lane < 63) {
+            w.hcum[FLTX_HB((lane + 1) * PER)] = (uint32_t)cum;
+          }
         }
       }
       wsBarrier(P);
@@ -1431,16 +1486,37 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
       if (L > P.SCAP) {
         slow = true;
       } else {
+        /* counting sort by bin: position = better-bin count + ticket in the bin */
         for (int i = tid; i < nLead; i += W) {
-          if ((int)w.lbin[i] <= bstar) {
-            const uint32_t p = atomAdd32((uint32_t*)&w.sc[SC_NSMALL], 1u);
+          const int bin = (int)w.lbin[i];
+          if (bin <= bstar) {
+            const int hb = FLTX_HB(bin);
+            const uint32_t p = w.hcum[hb] + (atomAdd32(&w.hist[hb], 0xFFFFFFFFu) - 1u);
             const uint32_t c = w.lead[i];
-            w.sKey[p] = f64Key(w.cScore[c]);
-            w.sOrd[p] = w.cOrd[c];
+            const unsigned long long key = f64Key(w.cScore[c]);
+            w.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), w.cOrd[c], (uint32_t)bin);
             w.sIdx[p] = c;
           }
         }
         wsBarrier(P);
+        for (int p = tid; p < L; p += W) {
+          const uint4 me = w.sEnt[p];
+          const unsigned long long k = ((unsigned long long)me.y << 32) | me.x;
+          const int bin = (int)me.w;
+          const int lo2 = (int)w.hcum[FLTX_HB(bin)];
+          const int hi2 = bin >= bstar ? L : (int)w.hcum[FLTX_HB(bin + 1)];
+          int rank = lo2;
+          for (int q = lo2; q < hi2; ++q) {
+            const uint4 e = w.sEnt[q];
+            const unsigned long long k2 = ((unsigned long long)e.y << 32) | e.x;
+            rank += (k2 > k || (k2 == k && e.z < me.z)) ? 1 : 0;
+          }
+          if (rank < K) {
+            w.surv[rank] = w.sIdx[p];
+          }
+        }
+        wsBarrier(P);
+        return nS;
       }
     }
     if (slow) {
@@ -1497,7 +1573,7 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
     const double sc = w.cScore[c];
     const uint4 key = w.cKey[c];
     const uint32_t src = w.cSrc[c];
-    const int h = (int)(src & 0x7FFFFFFFu);
+    const int h = (int)(src & kSrcMask);
     const int n = (int)(key.w & 0x7FFFFFFFu);
     const float lmd = w.cLm[c];
     /* emitting-model score: recompute the candidate's delta (LexiconFree:
@@ -1544,10 +1620,14 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
     w.bSPar[(nxt) * P.K + rank] = key.x;
     w.bSEdge[(nxt) * P.K + rank] = (int32_t)key.y;
     w.bLex[(nxt) * P.K + rank] = key.z;
+    /* maxScore of the slot's node: the child's when the candidate advanced in
+     * the trie, the parent's when it stayed, 0 back at the root */
+    w.bLexMax[(nxt) * P.K + rank] = (src & kExtend) ? __uint_as_float((uint32_t)w.cAux[c])
+                                                    : (key.z == 0u ? 0.0f : w.bLexMax[(f.cur) * P.K + h]);
     w.bTokPb[(nxt) * P.K + rank] = key.w;
     P.histPT[hbase + rank] = make_int2(h, n);
     if (P.kind == 1) {
-      P.histW[hbase + rank] = w.cAux[c];
+      P.histW[hbase + rank] = (src & kExtend) ? -1 : w.cAux[c];
     }
     if (P.histS) {
       double* hs = P.histS + 3 * (hbase + rank);
@@ -1578,7 +1658,7 @@ FLTX_DEV void tokenShortlist(const DecodeParams& P, const Ws& w, const float* e,
 }
 
 /* one frame (or decodeEnd when isEnd): returns the new beam size */
-FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frameOut, bool isEnd) {
+FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, RowPF& rpf, int frameOut, bool isEnd) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   for (int i = tid; i < P.HS; i += W) {
@@ -1591,6 +1671,21 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   }
   if (!isEnd && f.nTok < P.N) {
     tokenShortlist(P, w, f.e, f.nTok);
+  }
+  if (!isEnd && P.kind == 1 && P.rowCache) {
+    /* child rows of this beam: from the registers the previous frame filled,
+     * or straight from HBM on the first frame of a launch */
+    const int lane = laneId(), wave = waveId(), nW = (W + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < kRowPF; ++q) {
+      const int slot = wave + q * nW;
+      if (slot < f.nBeam && lane < P.N) {
+        const uint4 v = rpf.valid
+            ? rpf.e[q]
+            : ((const uint4*)P.trieEdge)[(size_t)w.bLex[(f.cur) * P.K + slot] * P.N + lane];
+        w.rowEdge[slot * P.N + lane] = v;
+      }
+    }
   }
   wsBarrier(P);
   FLTX_PROF(0);
@@ -1620,7 +1715,9 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   if (dense) {
     denseLeaders(P, w, f, thr);
   } else {
-    foldGroups(P, w, thr);
+    int nCand = w.sc[SC_NCAND];
+    nCand = nCand > P.CAP ? P.CAP : nCand;
+    foldGroups(P, w, thr, nCand);
   }
   wsBarrier(P);
   FLTX_PROF(2);
@@ -1628,6 +1725,18 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   const int nS = selectAndRank(P, w, nLead, P.K);
   FLTX_PROF(3);
   const int nB = buildBeam(P, w, f, nS, frameOut, isEnd);
+  if (!isEnd && P.kind == 1 && P.rowCache) {
+    const int lane = laneId(), wave = waveId(), nW = (W + 63) >> 6;
+    const int nxt = f.cur ^ 1;
+#pragma unroll
+    for (int q = 0; q < kRowPF; ++q) {
+      const int slot = wave + q * nW;
+      if (slot < nB && lane < P.N) {
+        rpf.e[q] = ((const uint4*)P.trieEdge)[(size_t)w.bLex[(nxt) * P.K + slot] * P.N + lane];
+      }
+    }
+    rpf.valid = true;
+  }
   FLTX_PROF(4);
   return nB;
 }
@@ -1645,7 +1754,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
-  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense);
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.rowCache);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {
@@ -1661,6 +1770,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       w.bSPar[(0) * P.K + 0] = kNoParent;
       w.bSEdge[(0) * P.K + 0] = 0;
       w.bLex[(0) * P.K + 0] = 0u;
+      w.bLexMax[0] = 0.0f;
       w.bTokPb[(0) * P.K + 0] = (uint32_t)P.sil;
       if constexpr (GMAX > 0) {
         w.bMask[0] = 0ull;
@@ -1704,6 +1814,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       w.bSPar[(0) * P.K + i] = P.gSPar[g];
       w.bSEdge[(0) * P.K + i] = P.gSEdge[g];
       w.bLex[(0) * P.K + i] = P.gLex[g];
+      w.bLexMax[i] = P.gLexMax[g];
       w.bTokPb[(0) * P.K + i] = P.gTokPb[g];
       if constexpr (GMAX > 0) {
         w.bMask[i] = P.gMask[g];
@@ -1739,6 +1850,8 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   for (int q = 0; q < 8; ++q) {
     f.acc[q] = 0ull;
   }
+  RowPF rpf;
+  rpf.valid = false;
   LeanMap<(GMAX > 0 ? GMAX : 1)> lmap;
   if constexpr (GMAX > 0) {
     leanMapInit(P, nTok, lmap);
@@ -1762,7 +1875,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     if constexpr (GMAX > 0) {
       nBeam = runFrameLean<GMAX>(P, w, f, lmap, frame + t + 1);
     } else {
-      nBeam = runFrame(P, w, f, frame + t + 1, false);
+      nBeam = runFrame(P, w, f, rpf, frame + t + 1, false);
     }
     cur ^= 1; /* with nBeam == 0 either buffer is equally empty */
     if (t + 1 < T) {
@@ -1798,7 +1911,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     if constexpr (GMAX > 0) {
       nBeam = nBeam > 0 ? runEndLean(P, w, f, frame + 1) : 0;
     } else {
-      nBeam = nBeam > 0 ? runFrame(P, w, f, frame + 1, true) : 0;
+      nBeam = nBeam > 0 ? runFrame(P, w, f, rpf, frame + 1, true) : 0;
     }
     cur ^= 1;
     frame += 1;
@@ -1829,6 +1942,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     P.gSPar[g] = w.bSPar[(cur) * P.K + i];
     P.gSEdge[g] = w.bSEdge[(cur) * P.K + i];
     P.gLex[g] = GMAX > 0 ? 0u : w.bLex[(cur) * P.K + i];
+    P.gLexMax[g] = GMAX > 0 ? 0.0f : w.bLexMax[(cur) * P.K + i];
     P.gTokPb[g] = w.bTokPb[(cur) * P.K + i];
     if constexpr (GMAX > 0) {
       P.gMask[g] = w.bMask[(cur) * P.K + i];

@@ -30,10 +30,6 @@
  */
 #pragma once
 
-/* histogram arrays are indexed with one pad word per 16 bins so that a lane
- * reading its 16 consecutive bins hits 16 different LDS banks */
-#define FLTX_HB(b) ((b) + ((b) >> 4))
-
 struct LeanGroup {
   double s;
   uint32_t src; /* parent slot | kNewState */
