@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=64, help="utterances timed on the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=-1, help="override the CUDA device (default: LOCAL_RANK)")
     ap.add_argument("--set", action="append", default=[], help="decoder tunable key=value (repeatable)")
     return ap.parse_args()
 
@@ -65,12 +67,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decoder has no CPU path")
+    if a.device >= 0:
+        local = a.device
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
 
     from text_amd import _capi, synth
     B, T, N, K, Kt = a.batch, a.frames, a.tokens, a.beam, a.beam_token
@@ -126,7 +133,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if a.profile and rank == 0:
@@ -172,6 +179,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt)
     if rank == 0:
         print(json.dumps(out))
+    dec.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -126,6 +126,26 @@ class Lib:
 
 _default = None
 
+# Live handles are destroyed explicitly at interpreter exit, decoders first and
+# contexts last, while the HIP runtime is still loaded (garbage-collection order
+# at shutdown is arbitrary and the runtime aborts if it is torn down first).
+import atexit
+import weakref
+
+_live = {"dec": weakref.WeakSet(), "trie": weakref.WeakSet(), "lm": weakref.WeakSet(), "ctx": weakref.WeakSet()}
+
+
+def _close_all():
+    for kind in ("dec", "trie", "lm", "ctx"):
+        for obj in list(_live[kind]):
+            try:
+                obj.close()
+            except Exception:
+                pass
+
+
+atexit.register(_close_all)
+
 
 def default_lib():
     global _default
@@ -144,6 +164,7 @@ class Context:
         h = C.c_void_p()
         self.L.check(self.L.lib.fltx_ctx_create(device, stream, C.byref(h)))
         self.h = h
+        _live["ctx"].add(self)
 
     def synchronize(self):
         self.L.check(self.L.lib.fltx_ctx_synchronize(self.h))
@@ -170,6 +191,7 @@ class ZeroLM:
         h = C.c_void_p()
         self.L.check(self.L.lib.fltx_lm_zero_create(ctx.h if ctx is not None else None, C.byref(h)))
         self.h = h
+        _live["lm"].add(self)
 
     def score_sequence(self, words, with_finish=True):
         return self._score(words, with_finish)
@@ -209,6 +231,7 @@ class NgramLM(ZeroLM):
                                                      _ptr(bo), _ptr(um), len(um), bos, eos, unk,
                                                      C.byref(h)))
         self.h = h
+        _live["lm"].add(self)
 
 
 class ArpaLM(ZeroLM):
@@ -219,6 +242,7 @@ class ArpaLM(ZeroLM):
         h = C.c_void_p()
         self.L.check(self.L.lib.fltx_lm_arpa_load(path.encode(), "\n".join(usr_words).encode(), C.byref(h)))
         self.h = h
+        _live["lm"].add(self)
 
 
 class Trie:
@@ -237,6 +261,7 @@ class Trie:
                                                  _ptr(lb) if len(lb) else None, C.byref(h)))
         self.h = h
         self.n_nodes, self.n_tokens = n_nodes, n_tokens
+        _live["trie"].add(self)
 
     def close(self):
         if self.h:
@@ -300,6 +325,7 @@ class HostTrie:
         t = Trie.__new__(Trie)
         t.ctx, t.L, t.h = ctx, ctx.L, h
         t.n_nodes, t.n_tokens = self.num_nodes(), None
+        _live["trie"].add(t)
         return t
 
     def close(self):
@@ -338,6 +364,7 @@ class BatchDecoder:
             _ptr(tr), 0 if tr is None else tr.size, int(is_lm_token), C.byref(h)))
         self.h = h
         self.B = 0
+        _live["dec"].add(self)
 
     def set(self, key, value):
         self.L.check(self.L.lib.fltx_decoder_set(self.h, key.encode(), int(value)))
