@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--beam-token", type=int, default=29)
     ap.add_argument("--threads", type=int, default=0, help="threads per utterance (0 = library default)")
     ap.add_argument("--workload", default="C2", choices=["C2", "C3"])
-    ap.add_argument("--cpu-sample", type=int, default=64, help="utterances timed on the CPU baseline")
+    ap.add_argument("--cpu-sample", type=int, default=160, help="utterances timed on the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
@@ -168,11 +168,18 @@ def main():
     alg_bytes = st["algorithmic_bytes"]
     ach = alg_bytes / (k_ms * 1e-3) / 1e9
     out["roofline"] = {"bound": "hbm", "kernel": "fltx_decode_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                        "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                        "backtrace_kernel_ms": float(np.mean(bt_ms)),
                        "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBS,
                        "us_per_frame_step": k_ms * 1e3 / T}
+
+    # HBM traffic per launch comes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    # over this same command (tools/pmc_traffic.py); it is quoted only for the geometry it was
+    # measured on.
+    tr = pmc_traffic(a.workload, st["threads_per_utt"], B, T, N, K)
+    if tr is not None:
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
 
     # ---- CPU baseline + parity spot check (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not a.no_cpu:
@@ -182,6 +189,23 @@ def main():
     dec.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, threads, B, T, N, K):
+    import glob
+    want = "%s threads=%d batch=%d T=%d N=%d beam=%d" % (workload, threads, B, T, N, K)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", "hbm_traffic_*.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("workload") != want:
+            continue
+        for name, k in rec["kernels"].items():
+            if "fltx_decode_kernel" in name:
+                return k["hbm_bytes_per_launch"], os.path.relpath(path, here)
+    return None
 
 
 def cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt):
