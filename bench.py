@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=160, help="utterances timed on the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
+    ap.add_argument("--profile-waves", default="0", help="comma-separated wave indices to sample with --profile")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=-1, help="override the CUDA device (default: LOCAL_RANK)")
     ap.add_argument("--set", action="append", default=[], help="decoder tunable key=value (repeatable)")
@@ -136,15 +137,22 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if a.profile and rank == 0:
+    for pw in ([int(x) for x in a.profile_waves.split(",")] if (a.profile and rank == 0) else []):
         dec.set("profile", 1)
+        dec.set("profile_wave", pw)
         step()
         ctx.synchronize()
         pr = dec.profile().astype(np.float64)
         names = ["A2(combine)", "B(eval+bin)", "C(prefix)", "D(shortlist)", "E(build)", "row", "A1(relations)", "E-rank"]
+        order = list(range(8))
+        if dec.get("engine") == 3:  # fltx_lane.h marks, in program order
+            names = ["best+bins", "eval+hist", "bar1+prefix", "scatter", "build", "row+bar3", "load+relations", "bar2+rank"]
+            order = [6, 0, 1, 2, 3, 7, 4, 5]
+        names = [names[i] for i in order]
+        pr = pr[order]
         tot = pr[:8].sum()
-        sys.stderr.write("phase split (shader clocks, %% of %.3g): " % tot + ", ".join(
-            "%s %.1f%%" % (n, 100 * v / tot) for n, v in zip(names, pr[:8])) +
+        sys.stderr.write("wave %d phase split (shader clocks, %% of %.3g): " % (pw, tot) + ", ".join(
+            "%s %.0f" % (n, v / (B * T)) for n, v in zip(names, pr[:8])) +
             " | clocks/frame/utt %.0f\n" % (tot / (B * T)))
         dec.set("profile", 0)
     st = dec.stats()

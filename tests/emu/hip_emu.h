@@ -121,6 +121,7 @@ FLTX_DEV auto emuExchange(unsigned long long mine, F&& f) {
   pthread_barrier_wait(&w.bar);
   return r;
 }
+FLTX_DEV void waveSync() { pthread_barrier_wait(&emuWave().bar); }
 FLTX_DEV unsigned long long waveBallot(bool p) {
   return emuExchange(p ? 1ull : 0ull, [](const unsigned long long* s) {
     unsigned long long m = 0;
@@ -144,6 +145,7 @@ FLTX_DEV unsigned long long waveMax64(unsigned long long v) {
     return m;
   });
 }
+FLTX_DEV uint32_t waveMax32(uint32_t v) { return (uint32_t)waveMax64((unsigned long long)v); }
 FLTX_DEV unsigned long long waveMin64(unsigned long long v) {
   return emuExchange(v, [](const unsigned long long* s) {
     unsigned long long m = ~0ull;

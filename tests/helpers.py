@@ -188,6 +188,7 @@ class FltxSession:
         d = self.decoder(c, inp, threads)
         d.decode_batch(inp["e"], [c["T"]], c["N"])
         out = d.results(0)
+        self.last_engine = d.get("engine")
         d.close()
         return out
 

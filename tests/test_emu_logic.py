@@ -23,3 +23,20 @@ def test_emulated_two_waves(emu_session, golden):
     hyps = emu_session.run(c, threads=128)
     ok, why = helpers.check_against_golden(hyps, golden[c["name"]])
     assert ok, why
+
+
+LANE = ["lf_ctc_t20_k4", "lf_ctc_t60_k10", "lf_uni_t40_k10", "lf_ctc_t1", "lf_ctc_k1",
+        "lf_ctc_thr3", "lf_ctc_sil", "lf_asg_t30_n8", "lf_ctc_n4"]
+
+
+@pytest.mark.parametrize("name", LANE)
+def test_emulated_lane_per_slot_kernel(emu_session, golden, name):
+    """fltx_lane.h (beam <= 64, all tokens considered): 4 waves cover N = 29 with 8
+    tokens per wave; small N runs it with one wave too."""
+    c = cases.BY_NAME[name]
+    threads = 256 if c["N"] > 8 else 64
+    hyps = emu_session.run(c, threads=threads)
+    assert emu_session.last_engine == 3
+    tol = 1e-9 if c["log_add"] else 0.0
+    ok, why = helpers.check_against_golden(hyps, golden[c["name"]], tol)
+    assert ok, why

@@ -99,18 +99,24 @@ def test_c2_batch_property_checks(gpu_session, golden):
 LEXFREE = [c for c in cases.CASES if c["kind"] == "lexfree"]
 
 
-@pytest.mark.parametrize("mode", ["hash", "dense"])
+@pytest.mark.parametrize("mode", ["hash", "dense", "lean"])
 @pytest.mark.parametrize("c", LEXFREE, ids=lambda c: c["name"])
 def test_generic_engine_equals_lean_kernel(gpu_session, golden, c, mode):
-    """Lexicon-free + ZeroLM frames normally run the lean register-resident
-    step (fltx_lean.h).  The generic engine -- with its dense merge, and with
-    the hash merge the lexicon decoder uses -- must give the same n-best."""
+    """Lexicon-free + ZeroLM frames normally run the lane-per-slot step
+    (fltx_lane.h, beam <= 64) or the lean register-resident step
+    (fltx_lean.h).  The generic engine -- with its dense merge, and with the
+    hash merge the lexicon decoder uses -- and the lean step where the lane step
+    is the default must give the same n-best."""
     inp = helpers.case_inputs(c)
     d = gpu_session.decoder(c, inp)
-    d.set("lean", 0)
+    if mode == "lean":
+        d.set("lane", 0)
+    else:
+        d.set("lean", 0)
     if mode == "hash":
         d.set("dense", 0)
     d.decode_batch(inp["e"], [c["T"]], c["N"])
+    assert d.get("engine") == {"hash": 0, "dense": 1, "lean": 2}[mode] or c["lm"] != "zero"
     tol = 1e-5 if c["log_add"] else 0.0
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
     d.close()

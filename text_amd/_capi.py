@@ -54,7 +54,7 @@ class Lib:
         "fltx_stream_step", "fltx_stream_end", "fltx_stream_prune",
         "fltx_stream_frames_in_buffer", "fltx_result_count", "fltx_result_fetch",
         "fltx_result_best", "fltx_result_device", "fltx_decoder_stats",
-        "fltx_decoder_set", "fltx_decoder_timing", "fltx_decoder_profile", "fltx_htrie_create", "fltx_htrie_destroy", "fltx_htrie_insert",
+        "fltx_decoder_set", "fltx_decoder_get", "fltx_decoder_timing", "fltx_decoder_profile", "fltx_htrie_create", "fltx_htrie_destroy", "fltx_htrie_insert",
         "fltx_htrie_search", "fltx_htrie_smear", "fltx_htrie_num_nodes", "fltx_htrie_upload",
     ]
 
@@ -100,6 +100,7 @@ class Lib:
             "fltx_result_device": [vp, pvp, pvp, pvp, pvp, pvp],
             "fltx_decoder_stats": [vp, vp, vp, vp, vp],
             "fltx_decoder_set": [vp, C.c_char_p, i64],
+            "fltx_decoder_get": [vp, C.c_char_p, vp],
             "fltx_decoder_timing": [vp, vp, vp],
             "fltx_decoder_profile": [vp, vp],
             "fltx_htrie_create": [i32, i32, pvp],
@@ -438,6 +439,11 @@ class BatchDecoder:
                                                  _ptr(words), capacity, C.addressof(ln)))
         n = ln.value
         return Hyp(scores[0], scores[1], scores[2], tokens[:n].copy(), words[:n].copy())
+
+    def get(self, key):
+        v = C.c_int64(0)
+        self.L.check(self.L.lib.fltx_decoder_get(self.h, key.encode(), C.addressof(v)))
+        return v.value
 
     def stats(self):
         fr, by = C.c_int64(0), C.c_int64(0)

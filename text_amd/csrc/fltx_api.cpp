@@ -35,6 +35,11 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_lds(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   decodeUtterance<GMAX>(P, fltx_smem);
 }
+template <int W, int GT>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  decodeUtterance<1, GT>(P, fltx_smem);
+}
 template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gws(DecodeParams P) {
   decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
@@ -220,6 +225,7 @@ struct fltx_decoder {
   uint32_t epoch = 0;
   int CAP = 0, HS = 0, NB = 0, SCAP = 0, dense = 0, noDense = 0;
   int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
+  int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
   size_t wsBytes = 0;
   bool wsInLds = true;
   /* device buffers */
@@ -231,7 +237,7 @@ struct fltx_decoder {
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   int keepScores = 0;
-  int profile = 0;
+  int profile = 0, profWave = 0;
   /* host caches of the last results */
   std::vector<int32_t> hN, hFrame, hStatus;
   bool resultsSynced = false;
@@ -802,6 +808,24 @@ int fltx_decoder_destroy(fltx_decoder* d) {
   return FLTX_OK;
 }
 
+int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
+  if (!d || !key || !value) {
+    return fail(FLTX_ERR_INVALID, "fltx_decoder_get: null argument");
+  }
+  if (!strcmp(key, "engine")) {
+    *value = d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0));
+  } else if (!strcmp(key, "lane")) {
+    *value = d->lane;
+  } else if (!strcmp(key, "threads")) {
+    *value = d->threads;
+  } else if (!strcmp(key, "lds")) {
+    *value = d->wsInLds ? 1 : 0;
+  } else {
+    return fail(FLTX_ERR_INVALID, "fltx_decoder_get: unknown key '%s'", key);
+  }
+  return FLTX_OK;
+}
+
 int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   if (!d || !key) {
     return fail(FLTX_ERR_INVALID, "null argument");
@@ -818,6 +842,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->keepScores = value != 0;
     return FLTX_OK;
   }
+  if (!strcmp(key, "profile_wave")) {
+    d->profWave = (int)value;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "profile")) {
     d->profile = value != 0;
     return FLTX_OK;
@@ -828,6 +856,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "lean")) { /* 0: lexicon-free + ZeroLM frames use the generic engine */
     d->noLean = value == 0;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "lane")) { /* 0: beams <= 64 use the lean kernel instead of the lane-per-slot kernel */
+    d->noLane = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "dense")) { /* 0: force the generic hash merge for lexicon-free frames */
@@ -905,6 +937,13 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const int64_t per = (groups + d->threads - 1) / d->threads;
     d->lean = per <= 6 ? 6 : (per <= 12 ? 12 : 0);
   }
+  /* lane-per-slot frame step (fltx_lane.h): beam and token set fit one wave's lanes */
+  d->lane = 0;
+  if (d->lean && !d->noLane && K <= 64 && N <= 64 && nTok == N && d->opt.beam_threshold < 1e6 && !d->opt.log_add) {
+    const int nW = d->threads / 64;
+    const int per = (N + nW - 1) / nW;
+    d->lane = per <= 4 ? 4 : (per <= 8 ? 8 : 0);
+  }
   int64_t worst = d->kind == FLTX_DECODER_LEXFREE ? (int64_t)K * (nTok + (d->dense ? 1 : 0))
                                                   : (int64_t)K * ((int64_t)nTok * 8 + 2);
   if (d->lean) {
@@ -924,7 +963,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     return std::max((int)nextPow2((uint64_t)keys * 2), 64);
   };
   auto bytesFor = [&](int64_t c) {
-    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->rowCache);
+    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->rowCache, d->lane);
   };
   bool lds = !d->forceGlobalWs;
   if (lds && bytesFor(capC) > kMaxLds) {
@@ -948,7 +987,10 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   d->CAP = (int)capC;
   d->HS = hsFor(capC);
-  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->rowCache);
+  if (!lds) {
+    d->lane = 0;
+  }
+  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->rowCache, d->lane);
   d->wsInLds = lds;
   /* buffers */
   bool grewTab = false;
@@ -1065,6 +1107,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.NB = d->NB;
   P.SCAP = d->SCAP;
   P.dense = d->dense;
+  P.lane = d->lane;
   P.rowCache = d->rowCache;
   P.gLexMax = d->gLexMax.as<float>();
   P.gws = d->wsInLds ? nullptr : d->gws.as<char>();
@@ -1077,6 +1120,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.uttNextId = d->uttNextId.as<int32_t>();
   P.gMask = d->gMask.as<unsigned long long>();
   P.prof = nullptr;
+  P.profThread = 64 * d->profWave;
   if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {
     devMemset(d->prof.p, 0, 8 * 8 * (size_t)d->B, d->ctx->stream);
     P.prof = d->prof.as<unsigned long long>();
@@ -1088,9 +1132,14 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
 #ifdef FLTX_EMU
   const DecodeParams* pp = &P;
   const int gmax = d->lean;
-  emuLaunch(d->B, W, d->wsInLds ? d->wsBytes : 16, [pp, gmax](char* smem) {
+  const int gt = d->lane;
+  emuLaunch(d->B, W, d->wsInLds ? d->wsBytes : 16, [pp, gmax, gt](char* smem) {
     char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
-    if (gmax == 6) {
+    if (gt == 4) {
+      decodeUtterance<1, 4>(*pp, base);
+    } else if (gt == 8) {
+      decodeUtterance<1, 8>(*pp, base);
+    } else if (gmax == 6) {
       decodeUtterance<6>(*pp, base);
     } else if (gmax == 12) {
       decodeUtterance<12>(*pp, base);
@@ -1113,10 +1162,21 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     hipLaunchKernelGGL((fltx_decode_kernel_lds<WW, GG>), dim3(d->B), dim3(WW), d->wsBytes,       \
                        d->ctx->stream, P);                                                       \
   } while (0)
+#define FLTX_LAUNCH_LANE(WW, GG)                                                                 \
+  do {                                                                                           \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lane<WW, GG>,                     \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
+    hipLaunchKernelGGL((fltx_decode_kernel_lane<WW, GG>), dim3(d->B), dim3(WW), d->wsBytes,      \
+                       d->ctx->stream, P);                                                       \
+  } while (0)
 #define FLTX_LAUNCH(WW)                                                                          \
   do {                                                                                           \
     if (!d->wsInLds) {                                                                           \
       hipLaunchKernelGGL(fltx_decode_kernel_gws<WW>, dim3(d->B), dim3(WW), 0, d->ctx->stream, P); \
+    } else if (d->lane == 4) {                                                                   \
+      FLTX_LAUNCH_LANE(WW, 4);                                                                   \
+    } else if (d->lane == 8) {                                                                   \
+      FLTX_LAUNCH_LANE(WW, 8);                                                                   \
     } else if (d->lean == 6) {                                                                   \
       FLTX_LAUNCH_LDS(WW, 6);                                                                    \
     } else if (d->lean == 12) {                                                                  \
@@ -1135,6 +1195,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   }
 #undef FLTX_LAUNCH
 #undef FLTX_LAUNCH_LDS
+#undef FLTX_LAUNCH_LANE
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(d->ev[1], d->ctx->stream));
   d->timed = false;

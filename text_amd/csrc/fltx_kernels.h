@@ -145,6 +145,7 @@ struct DecodeParams {
   /* workspace geometry */
   int32_t CAP, HS, NB, SCAP;
   int32_t dense; /* 1: lexicon-free frames use the hash-free dense merge */
+  int32_t lane;  /* >0: lane-per-slot frame step (fltx_lane.h), value = tokens per wave */
   char* gws;          /* global workspace (big configurations), or null */
   int64_t gwsStride;
   /* results of decodeEnd */
@@ -163,6 +164,7 @@ struct DecodeParams {
   unsigned long long* gMask;    /* [B*K] parked masks of the beam slots */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
+  int32_t profThread; /* the thread whose clock is sampled (lane 0 of the wave under study) */
 };
 
 struct Ws {
@@ -208,6 +210,11 @@ struct Ws {
   unsigned long long* eBase;   /* [K] lean: new slot's mask before this frame's additions */
   int32_t* eRep;   /* [K] lean: old-beam representative of the new slot's state, -1 = fresh */
   int32_t* bPar;   /* [K] lean: parent slot of the new slot (for the coalesced history write) */
+  unsigned long long* relTab; /* [K*(N+1)] lane path: new slots per LM-state descriptor (bit = slot) */
+  unsigned long long* repTab; /* [K] lane path: tokens repeated by children of old slot x's state */
+  uint4* bRec;     /* [2K] lane path: {score, token|prevBlank, state descriptor | parent descriptor << 16} */
+  uint32_t* wcum;  /* [16*256] lane path: per-wave copy of the histogram prefix */
+  uint32_t* tick;  /* [256] lane path: scatter tickets per bin */
   int32_t* pMate;  /* [16*64] per-wave partial relation results (lean path) */
   int32_t* pPar;   /* [16*64] */
   uint32_t* surv;  /* [K] candidate index of the survivor with rank r */
@@ -224,7 +231,7 @@ struct Ws {
 };
 
 enum { SC_NCAND = 0, SC_NLEAD = 1, SC_NSURV = 2, SC_BSTAR = 3, SC_CUM = 4, SC_M = 5,
-       SC_NSMALL = 6, SC_STATUS = 7, SC_NEED = 8, SC_DONE = 9, SC_NEXTID = 10 };
+       SC_NSMALL = 6, SC_STATUS = 7, SC_NEED = 8, SC_DONE = 9, SC_NEXTID = 10, SC_RELSLOW = 11 };
 
 #ifndef FLTX_HD
 #ifdef FLTX_EMU
@@ -239,7 +246,7 @@ FLTX_HD size_t alignUp(size_t x, size_t a) { return (x + a - 1) / a * a; }
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
-                       int dense, int rowCache) {
+                       int dense, int rowCache, int lane) {
   size_t off = 0;
 #define FLTX_CARVE(field, type, count)                       \
   off = alignUp(off, 16);                                    \
@@ -283,6 +290,11 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.eBase, unsigned long long, dense ? K : 0)
   FLTX_CARVE(w.eRep, int32_t, dense ? K : 0)
   FLTX_CARVE(w.bPar, int32_t, dense ? K : 0)
+  FLTX_CARVE(w.relTab, unsigned long long, lane ? (size_t)K * (N + 1) : 0)
+  FLTX_CARVE(w.repTab, unsigned long long, lane ? K : 0)
+  FLTX_CARVE(w.bRec, uint4, lane ? 2 * K : 0)
+  FLTX_CARVE(w.wcum, uint32_t, lane ? 16 * 256 : 0)
+  FLTX_CARVE(w.tick, uint32_t, lane ? 256 : 0)
   FLTX_CARVE(w.pMate, int32_t, dense ? 16 * 64 : 0)
   FLTX_CARVE(w.pPar, int32_t, dense ? 16 * 64 : 0)
   FLTX_CARVE(w.surv, uint32_t, K)
@@ -614,7 +626,7 @@ FLTX_DEV unsigned long long devClock() { return __builtin_readcyclecounter(); }
  * wave for ~2k clocks and distort what it measures) */
 #define FLTX_PROF(i)                                                   \
   do {                                                                 \
-    if (P.prof && threadIdx.x == 0) {                                  \
+    if (P.prof && (int)threadIdx.x == P.profThread) {                  \
       const unsigned long long t_ = devClock();                        \
       f.acc[(i)] += t_ - f.t0;                                         \
       f.t0 = t_;                                                       \
@@ -1742,19 +1754,20 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, RowPF& rp
 }
 
 #include "fltx_lean.h"
+#include "fltx_lane.h"
 
 /* ------------------------------------------------------------------------ */
 /* the decode kernel: grid = utterances, block = W threads.                  */
 /* GMAX == 0: generic engine; GMAX > 0: lean lexicon-free + ZeroLM frame step */
 /* with up to GMAX candidate groups per thread (fltx_lean.h).                 */
 /* ------------------------------------------------------------------------ */
-template <int GMAX>
+template <int GMAX, int GT = 0>
 FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const int b = (int)blockIdx.x;
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
-  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.rowCache);
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.rowCache, P.lane);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {
@@ -1829,6 +1842,30 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const int T = P.stepT ? P.stepT[b] : 0;
   const float* em = P.emissions ? P.emissions + P.emOff[b] : nullptr;
   const int N = P.N;
+  LaneCarry lcarry;
+  laneCarryInit(lcarry);
+  if constexpr (GT > 0) { /* relation tables start empty; the first frame compares state ids */
+    for (int i = tid; i < P.K * (N + 1); i += W) {
+      w.relTab[i] = 0ull;
+    }
+    for (int i = tid; i < P.K; i += W) {
+      w.repTab[i] = 0ull;
+      w.addMask[i] = 0ull;
+    }
+    for (int i = tid; i < nBeam; i += W) { /* descriptors unknown: the first frame compares ids */
+      w.bRec[i] = laneRec(w.bScore[i], w.bTokPb[i], -1, -1);
+    }
+    for (int i = tid; i < P.K * N; i += W) {
+      w.dKid[i] = (int16_t)-1;
+    }
+    for (int i = tid; i < kLaneNB; i += W) {
+      w.hist[i] = 0u;
+      w.tick[i] = 0u;
+    }
+    if (tid == 0) {
+      w.sc[SC_RELSLOW] = 1;
+    }
+  }
   const int nTok = P.Kt < N ? P.Kt : N;
   /* stage row 0; afterwards row t+1 is prefetched into registers while frame
    * t is processed and parked in the other LDS row buffer at its end */
@@ -1853,7 +1890,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   RowPF rpf;
   rpf.valid = false;
   LeanMap<(GMAX > 0 ? GMAX : 1)> lmap;
-  if constexpr (GMAX > 0) {
+  if constexpr (GMAX > 0 && GT == 0) {
     leanMapInit(P, nTok, lmap);
   }
   for (int t = 0; t < T; ++t) {
@@ -1872,7 +1909,9 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     f.nBeam = nBeam;
     f.e = w.erow + rb * P.N;
     f.useTrans = (P.criterion == 0) && (total + t > 0) && P.transitions != nullptr;
-    if constexpr (GMAX > 0) {
+    if constexpr (GT > 0) {
+      nBeam = runFrameLane<GT>(P, w, f, lcarry, frame + t + 1);
+    } else if constexpr (GMAX > 0) {
       nBeam = runFrameLean<GMAX>(P, w, f, lmap, frame + t + 1);
     } else {
       nBeam = runFrame(P, w, f, rpf, frame + t + 1, false);
@@ -1903,6 +1942,12 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   }
   frame += T;
   total += T;
+  if constexpr (GT > 0) { /* epilogue of the last frame's build */
+    f.cur = cur;
+    f.nBeam = nBeam;
+    laneFlush(P, w, f, lcarry);
+    ldsBarrier();
+  }
   if (P.doEnd) {
     f.cur = cur;
     f.nBeam = nBeam;
@@ -1926,7 +1971,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       P.outN[b] = nBeam;
     }
   }
-  if (P.prof && tid == 0) {
+  if (P.prof && tid == P.profThread) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       P.prof[(size_t)b * 8 + q] = f.acc[q];

@@ -1,0 +1,540 @@
+/*
+ * fltx_lane.h -- "lane = beam slot" frame step for the headline configuration:
+ * LexiconFreeDecoder + ZeroLM, max-merge (logAdd = false), beam <= 64 and <= 64
+ * tokens (C2: beam 50, 29 tokens), included by fltx_kernels.h.
+ *
+ * Same candidates, same merge groups and the same selection as fltx_lean.h
+ * (LexiconFreeDecoder.cpp:30-125), bit-identical results; what changes is the
+ * shape of the work.  The frame step is a serial chain T long whose cost is the
+ * number of instructions a wave issues between barriers, so:
+ *   * every wave keeps the WHOLE beam in registers, hypothesis h in lane h
+ *     (score, token, and the scores/tokens of the <= 3 related hypotheses it
+ *     can merge with), and evaluates the candidates of "its" tokens
+ *     (token n belongs to wave n mod #waves) with no memory access at all:
+ *     e[n] is wave-uniform, everything else is lane-local;
+ *   * the merge of LexiconFreeDecoder.cpp:101-103 needs no table: a group has
+ *     <= 3 members -- the hypothesis of an LM state and its blank/non-blank
+ *     twin ("mate"), plus the repeat of the child state's hypothesis -- and a
+ *     group with a repeat is evaluated by the repeat's own lane, which carries
+ *     the parent's and the parent's mate's scores in registers;
+ *   * who is whose mate / parent is NOT searched per frame: the thread that
+ *     builds new slot r records a descriptor of r's LM state in terms of the
+ *     old beam ("same state as old slot o" or "new child (o, token)") and ORs
+ *     bit r into relTab[descriptor]; next frame a lane reads the two masks of
+ *     its own and its parent's descriptor and has mate / parent / parent's
+ *     mate by ctz.  The one case this cannot see -- an LM state that dropped
+ *     out of the beam and re-enters -- raises a flag and the next frame derives
+ *     the relations from the state ids by lane broadcast instead;
+ *   * histogram prefix, K-th-bin search and scatter positions are computed by
+ *     every wave redundantly from the shared counts: no "wave 0 works, the
+ *     rest waits" section and no barrier between prefix and scatter;
+ *   * the epilogue of the build (state masks, history records) is deferred to
+ *     the next frame's first phase and done by one otherwise idle wave.
+ * Three barriers per frame (the third is the row hand-over of the caller).
+ */
+#pragma once
+
+constexpr int kLaneNB = 256; /* histogram bins (K <= 64 candidates survive: 4 bins per lane) */
+
+struct LaneCarry {
+  int oldKid;      /* dKid entry this lane set for the current beam, -1 none (kid wave only) */
+  int64_t pendHb;  /* history offset of the beam built by the previous frame, -1 = nothing pending */
+  int pendOldN;    /* size of the beam it was built from */
+  bool repHere;    /* this wave evaluates the repeat group of this lane's slot (fixed for the launch) */
+};
+
+/* The repeat groups (one per slot) are spread over the waves other than the
+ * last one, which has the deferred epilogue to do. */
+FLTX_DEV void laneCarryInit(LaneCarry& c) {
+  const int nW = (int)blockDim.x >> 6;
+  const int lane = laneId();
+  c.oldKid = -1;
+  c.pendHb = -1;
+  c.pendOldN = 0;
+  c.repHere = nW == 1 ? true : (lane % (nW - 1)) == waveId();
+}
+
+/* beam record read by every wave at the start of a frame: one 16-byte LDS load
+ * brings the score, the token and the two LM-state descriptors of a slot */
+FLTX_DEV uint4 laneRec(double s, uint32_t tokpb, int D, int PD) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+  return make_uint4((uint32_t)b, (uint32_t)(b >> 32), tokpb, (uint32_t)(D + 1) | ((uint32_t)(PD + 1) << 16));
+}
+FLTX_DEV double laneRecScore(const uint4& r) {
+  return __longlong_as_double((long long)(((unsigned long long)r.y << 32) | r.x));
+}
+
+/* deferred epilogue of the previous frame's build (phase E2 of fltx_lean.h):
+ * final child-edge masks of the new slots, the {parent, token} history records
+ * as one coalesced store, and the grown masks of the old states.  Done by the
+ * last wave, which has the fewest tokens to evaluate. */
+FLTX_DEV void laneFlush(const DecodeParams& P, const Ws& w, const FrameCtx& f, LaneCarry& c) {
+  if (c.pendHb < 0) {
+    return;
+  }
+  const int nW = (int)blockDim.x >> 6;
+  const int lane = laneId();
+  const int K = P.K;
+  const int co = f.cur * K, no = (f.cur ^ 1) * K;
+  if (waveId() == nW - 1) {
+    const int r = lane;
+    if (r < f.nBeam) {
+      const int rs = w.eRep[r];
+      w.bMask[co + r] = w.eBase[r] | (rs >= 0 ? w.addMask[rs] : 0ull);
+      const int n = (int)(w.bTokPb[co + r] & 0x7FFFFFFFu);
+      P.histPT[c.pendHb + r] = make_int2(w.bPar[r], n);
+      if (P.histS) {
+        double* hs = P.histS + 3 * (c.pendHb + r);
+        hs[0] = w.bScore[co + r];
+        hs[1] = w.bAm[co + r];
+        hs[2] = 0.0;
+      }
+    }
+    if (r < c.pendOldN) {
+      const unsigned long long add = w.addMask[r];
+      if (add != 0ull) {
+        P.maskTab[(size_t)f.b * P.idCap + w.bState[no + r]] = w.bMask[no + r] | add;
+      }
+    }
+    waveSync();
+    if (r < K) {
+      w.addMask[r] = 0ull;
+    }
+  }
+  c.pendHb = -1;
+}
+
+FLTX_DEV uint32_t laneBit(unsigned long long m, int n) { /* n is wave-uniform at the call sites */
+  return (uint32_t)(m >> n) & 1u;
+}
+
+template <int GT>
+FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneCarry& c, int frameOut) {
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  const int lane = laneId(), wave = waveId();
+  const int nW = W >> 6;
+  const int K = P.K, N = P.N, KN = K * N;
+  const int co = f.cur * K, no = (f.cur ^ 1) * K;
+  const bool ctc = P.criterion == 1;
+  const int nBeam = f.nBeam;
+  const int kWave = nW >= 3 ? nW - 2 : 0;
+  /* ---- phase 1: beam into lanes, relations, evaluation, histogram ---------------- */
+  laneFlush(P, w, f, c);
+  if (nBeam == 0) {
+    return 0;
+  }
+  const bool live = lane < nBeam;
+  const int hc = live ? lane : 0;
+  const uint4 meRec = w.bRec[co + hc];
+  const double score = laneRecScore(meRec);
+  const uint32_t tokpb = meRec.z;
+  const int tok = (int)(tokpb & 0x7FFFFFFFu);
+  const bool pb = (tokpb & kPrevBlank) != 0;
+  const bool rp = live && !pb && !(ctc && tok == P.blank); /* has a repeat candidate */
+  const int D = live ? (int)(meRec.w & 0xFFFFu) - 1 : -1;
+  int mate = -1, par = -1, pm = -1;
+  unsigned long long repMask = 0ull;
+  if (w.sc[SC_RELSLOW] == 0) {
+    const int PD = live ? (int)(meRec.w >> 16) - 1 : -1;
+    const unsigned long long mD = D >= 0 ? w.relTab[D] : 0ull;
+    const unsigned long long mP = PD >= 0 ? w.relTab[PD] : 0ull;
+    repMask = D >= KN ? w.repTab[D - KN] : 0ull;
+    const unsigned long long oth = mD & ~(1ull << lane);
+    mate = oth ? __builtin_ctzll(oth) : -1;
+    par = mP ? __builtin_ctzll(mP) : -1;
+    const unsigned long long pr = mP & (mP - 1ull);
+    pm = pr ? __builtin_ctzll(pr) : -1;
+  } else {
+    /* first frame of a launch, or an LM state re-entered the beam: compare ids */
+    const uint32_t sid = live ? w.bState[co + lane] : 0xFFFFFFFEu;
+    const uint32_t sp = live ? w.bSPar[co + lane] : 0xFFFFFFFDu;
+    for (int h2 = 0; h2 < nBeam; ++h2) {
+      const uint32_t s2 = waveReadLane32(sid, h2);
+      mate = (s2 == sid && h2 != lane) ? h2 : mate;
+      if (s2 == sp) {
+        if (par < 0) {
+          par = h2;
+        } else if (pm < 0) {
+          pm = h2;
+        }
+      }
+    }
+    for (int h2 = 0; h2 < nBeam; ++h2) {
+      const int p2 = (int)waveReadLane32((uint32_t)par, h2);
+      const uint32_t t2 = waveReadLane32(rp ? (uint32_t)tok : 0xFFFFFFFFu, h2);
+      if (p2 == lane && t2 != 0xFFFFFFFFu) {
+        repMask |= 1ull << t2;
+      }
+    }
+  }
+  if (wave == kWave) { /* what the builders of phase 3 look up */
+    if (c.oldKid >= 0) {
+      w.dKid[c.oldKid] = (int16_t)-1;
+    }
+    waveSync();
+    int kid = -1;
+    if (live) {
+      w.dMate[lane] = mate;
+      w.dPar[lane] = par;
+      if (par >= 0) {
+        kid = par * N + w.bSEdge[co + lane];
+        w.dKid[kid] = (int16_t)lane;
+      }
+    }
+    c.oldKid = kid;
+  }
+  const int mi = mate >= 0 ? mate : hc, pi = par >= 0 ? par : hc, qi = pm >= 0 ? pm : hc;
+  const uint4 mRec = w.bRec[co + mi], pRec = w.bRec[co + pi], qRec = w.bRec[co + qi];
+  const float eTok = f.e[tok < N ? tok : 0];
+  const float eLane = f.e[lane < N ? lane : 0];
+  const float eSil = f.e[P.sil];
+  float eJ[GT]; /* emissions of this wave's tokens (wave-uniform), all in flight with the loads above */
+#pragma unroll
+  for (int j = 0; j < GT; ++j) {
+    const int n = wave + j * nW;
+    eJ[j] = f.e[n < N ? n : 0];
+  }
+  const double a0 = w.bScore[co];
+  const double aLast = w.bScore[co + nBeam - 1];
+  FLTX_PROF(6);
+  /* best candidate of the frame: best hypothesis (slot 0, the beam is sorted)
+   * with its best token.  fl(a0 + e) is monotone in e for a finite a0, so the
+   * maximum over the tokens other than sil is a0 + max e: a 32-bit reduction. */
+  double best = 0.0;
+  bool any = false;
+  if (a0 - a0 == 0.0) {
+    uint32_t ek = 0u;
+    if (lane < N && lane != P.sil && eLane == eLane) {
+      ek = f32Key(eLane);
+    }
+    ek = waveMax32(ek);
+    if (ek != 0u) {
+      best = a0 + (double)f32FromKey(ek);
+      any = true;
+    }
+    const double sS = (a0 + (double)eSil) + P.silScore;
+    if (sS == sS && (!any || sS > best)) {
+      best = sS;
+      any = true;
+    }
+  } else {
+    unsigned long long bk = 0ull;
+    if (lane < N) {
+      const double s = leanScore(P, a0, lane, (double)eLane);
+      if (s == s) {
+        bk = f64Key(s);
+      }
+    }
+    bk = waveMax64(bk);
+    any = bk != 0ull;
+    best = f64FromKey(bk);
+  }
+  if (!any) {
+    return 0;
+  }
+  const double thr = best - P.beamThreshold;
+  if (!(best - thr < 1e6)) { /* threshold too wide for the fixed bins: general path */
+    if (tid == 0) {
+      atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_SELECT_FALLBACK);
+    }
+    return 0;
+  }
+  /* Two-segment monotone binning of d = best - score over [0, range] (see
+   * fltx_lean.h), in float: any function that is monotone in the score and the
+   * same in every wave gives exact ranks. */
+  const float rangeF = (float)(best - thr);
+  const float NFf = (float)((kLaneNB * 3) / 4);
+  /* fine segment = a little more than the current beam's own spread (best to
+   * worst score): the next beam's scores land there unless the frame is
+   * unusual, and then the coarse segment still ranks them exactly */
+  float cutF = (float)(a0 - aLast) * 1.25f + 1e-3f;
+  cutF = cutF > rangeF * 0.125f ? cutF : rangeF * 0.125f;
+  cutF = cutF < rangeF * 0.9f ? cutF : rangeF * 0.9f;
+  float sF = NFf / cutF, sC = ((float)kLaneNB - NFf) / (rangeF - cutF);
+  if (!(rangeF > 0.0f) || !(sF > 0.0f) || !(sF < 1e30f) || !(sC > 0.0f) || !(sC < 1e30f)) {
+    cutF = __builtin_huge_valf(); /* degenerate range: everything lands in bin 0 */
+    sF = 0.0f;
+    sC = 0.0f;
+  }
+  FLTX_PROF(0);
+  const bool owner = live && !(mate >= 0 && mate < lane); /* the lower slot of a pair owns the state's groups */
+  const double mScore = laneRecScore(mRec), pScore = laneRecScore(pRec), qScore = laneRecScore(qRec);
+  const int mtok = (int)(mRec.z & 0x7FFFFFFFu), ptok = (int)(pRec.z & 0x7FFFFFFFu), qtok = (int)(qRec.z & 0x7FFFFFFFu);
+  const bool mpb = (mRec.z & kPrevBlank) != 0, ppb = (pRec.z & kPrevBlank) != 0, qpb = (qRec.z & kPrevBlank) != 0;
+  /* tokens for which my / my mate's extension is a candidate of a group I
+   * evaluate: not the own repeat (it keeps the LM state and belongs to another
+   * group) and not a token repeated by a child state's hypothesis (that group
+   * is evaluated by the child's lane below) */
+  const unsigned long long allTok = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
+  const bool rpM = mate >= 0 && !mpb && !(ctc && mtok == P.blank);
+  const unsigned long long maskA = owner ? (allTok & ~repMask & ~(rp ? 1ull << tok : 0ull)) : 0ull;
+  const unsigned long long maskB = (owner && mate >= 0) ? (allTok & ~repMask & ~(rpM ? 1ull << mtok : 0ull)) : 0ull;
+  double cs[GT + 1];
+  int cbin[GT + 1];
+  uint32_t validBits = 0u, pickBits = 0u;
+#pragma unroll
+  for (int j = 0; j < GT; ++j) {
+    const int n = wave + j * nW; /* wave-uniform */
+    cs[j] = 0.0;
+    cbin[j] = 0;
+    if (n < N) {
+      const double en = (double)eJ[j];
+      double sA = score + en, sB = mScore + en;
+      if (n == P.sil) {
+        sA = sA + P.silScore;
+        sB = sB + P.silScore;
+      }
+      const bool okA = laneBit(maskA, n) != 0u && (sA >= thr);
+      const bool okB = laneBit(maskB, n) != 0u && (sB >= thr);
+      const bool pickB = okB && (!okA || sB > sA); /* a tie goes to the lower slot: me */
+      cs[j] = pickB ? sB : sA;
+      validBits |= ((okA || okB) ? 1u : 0u) << j;
+      pickBits |= (pickB ? 1u : 0u) << j;
+    }
+  }
+  uint32_t who = 0u; /* winner of my repeat's group: 0 parent, 1 parent's mate, 2 my repeat */
+  { /* the group of my repeat: parent's new-token candidates + my repeat; or the orphan repeat */
+    const int n = tok;
+    const double en = (double)eTok;
+    const bool here = rp && c.repHere;
+    double sR = score + en, sA = pScore + en, sB = qScore + en;
+    if (n == P.sil) {
+      sR = sR + P.silScore;
+      sA = sA + P.silScore;
+      sB = sB + P.silScore;
+    }
+    const bool newA = ctc ? (n != ptok || ppb) : (n != ptok);
+    const bool newB = ctc ? (n != qtok || qpb) : (n != qtok);
+    const bool okR = here && (sR >= thr);
+    const bool okA = here && par >= 0 && newA && (sA >= thr);
+    const bool okB = here && pm >= 0 && newB && (sB >= thr);
+    /* max-merge (Utils.h:194-196; logAdd decodes use fltx_lean.h): best member,
+     * a tie goes to the earlier generated one = the lower slot */
+    const bool tB = okB && (!okA || sB > sA); /* par < pm: a tie goes to the parent */
+    double s = tB ? sB : sA;
+    const int slot = tB ? qi : pi;
+    const bool v = okA || okB;
+    const bool tR = okR && (!v || sR > s || (sR == s && lane < slot));
+    s = tR ? sR : s;
+    who = tR ? 2u : (tB ? 1u : 0u);
+    cs[GT] = s;
+    cbin[GT] = 0;
+    validBits |= ((okA || okB || okR) ? 1u : 0u) << GT;
+  }
+#pragma unroll
+  for (int j = 0; j <= GT; ++j) {
+    if ((validBits >> j) & 1u) {
+      const float d = (float)(best - cs[j]);
+      const float x = d < cutF ? d * sF : NFf + (d - cutF) * sC;
+      int bin = (x < (float)kLaneNB) ? (int)x : kLaneNB - 1; /* also catches inf / NaN */
+      bin = bin < 0 ? 0 : bin;
+      cbin[j] = bin;
+      atomAdd32(&w.hist[bin], 1u);
+    }
+  }
+  FLTX_PROF(1);
+  ldsBarrier(); /* 1 */
+  /* ---- phase 2: every wave: prefix of the counts, K-th best's bin, scatter -------- */
+  if (wave == (nW > 1 ? 1 : 0)) { /* the relation tables have been read by everyone */
+    if (D >= 0) {
+      w.relTab[D] = 0ull;
+    }
+    if (lane < K) {
+      w.repTab[lane] = 0ull;
+    }
+    if (lane == 0) {
+      w.sc[SC_RELSLOW] = 0;
+    }
+  }
+  const uint4 cq = ((const uint4*)w.hist)[lane];
+  const int mineCnt = (int)(cq.x + cq.y + cq.z + cq.w);
+  const int inc = waveInclusiveScan(mineCnt);
+  const int e0 = inc - mineCnt, e1 = e0 + (int)cq.x, e2 = e1 + (int)cq.y, e3 = e2 + (int)cq.z;
+  const int total = (int)waveReadLane32((uint32_t)inc, 63);
+  const unsigned long long cm = waveBallot(e0 < K && inc >= K);
+  int bstar = kLaneNB - 1, L = total;
+  {
+    const int q = e1 >= K ? 0 : (e2 >= K ? 1 : (e3 >= K ? 2 : 3));
+    const int cumAt = q == 0 ? e1 : (q == 1 ? e2 : (q == 2 ? e3 : inc));
+    const int X = cm ? __builtin_ctzll(cm) : 0;
+    const uint32_t both = waveReadLane32((uint32_t)(4 * lane + q) | ((uint32_t)cumAt << 16), X);
+    if (cm) {
+      bstar = (int)(both & 0xFFFFu);
+      L = (int)(both >> 16);
+    }
+  }
+  FLTX_PROF(2);
+  ((uint4*)(w.wcum + wave * kLaneNB))[lane] = make_uint4((uint32_t)e0, (uint32_t)e1, (uint32_t)e2, (uint32_t)e3);
+  waveSync();
+  if (L > P.SCAP) { /* degenerate score distribution: let the host use the general path */
+    if (tid == 0) {
+      atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_SELECT_FALLBACK);
+    }
+    return 0;
+  }
+  /* short-listed candidates of this lane, one per loop trip: about K of the
+   * (GT + 1) * W candidate slots are, so the trip count is 1-2, not GT + 1 */
+  uint32_t todo = 0u;
+#pragma unroll
+  for (int j = 0; j <= GT; ++j) {
+    todo |= (((validBits >> j) & 1u) && cbin[j] <= bstar) ? (1u << j) : 0u;
+  }
+  while (waveBallot(todo != 0u) != 0ull) {
+    if (todo != 0u) {
+      const int j = __builtin_ctz(todo);
+      todo &= todo - 1u;
+      double sj = cs[GT];
+      int bin = cbin[GT];
+#pragma unroll
+      for (int i = 0; i < GT; ++i) {
+        sj = j == i ? cs[i] : sj;
+        bin = j == i ? cbin[i] : bin;
+      }
+      const uint32_t lo = w.wcum[wave * kLaneNB + bin];
+      const uint32_t cnt = w.hist[bin];
+      const uint32_t p = lo + atomAdd32(&w.tick[bin], 1u);
+      int n, slot, rep;
+      uint32_t flag, orphan = 0u;
+      if (j < GT) {
+        n = wave + j * nW;
+        slot = ((pickBits >> j) & 1u) ? mi : lane;
+        flag = (ctc && n == P.blank) ? 0u : kNewState;
+        rep = lane;
+      } else {
+        n = tok;
+        slot = who == 0u ? pi : (who == 1u ? qi : lane);
+        flag = who < 2u ? kNewState : 0u;
+        rep = par >= 0 ? par : lane;
+        orphan = par >= 0 ? 0u : 1u;
+      }
+      const unsigned long long key = f64Key(sj);
+      w.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(slot * N + n), lo | ((lo + cnt) << 16));
+      /* group: representative slot, token, orphan flag; source slot | kNewState */
+      w.sIdx[p] = (uint32_t)rep | ((uint32_t)n << 8) | (orphan << 16);
+      w.sSrc[p] = (uint32_t)slot | flag;
+    }
+  }
+  FLTX_PROF(3);
+  ldsBarrier(); /* 2 */
+  /* ---- phase 3: entry p ranks itself; rank < K builds beam slot `rank` ------------- */
+  const int nS = L < K ? L : K;
+  const int64_t hbase = f.histBase + (int64_t)frameOut * K;
+  for (int i = nW > 1 ? tid - 64 : tid; i >= 0 && i < kLaneNB; i += (nW > 1 ? W - 64 : W)) {
+    w.hist[i] = 0u;
+    w.tick[i] = 0u;
+  }
+  for (int p = tid; p < L; p += W) {
+    const uint4 me = w.sEnt[p];
+    const uint32_t gi = w.sIdx[p];
+    const uint32_t src = w.sSrc[p];
+    const unsigned long long k = ((unsigned long long)me.y << 32) | me.x;
+    const uint32_t o = me.z;
+    const int lo = (int)(me.w & 0xFFFFu), hi = (int)(me.w >> 16);
+    /* exact rank = entries in better bins + members of my bin that precede me;
+     * a bin's members are contiguous after the counting sort.  Four entries per
+     * round trip: the loop length is the largest bin of the wave over four. */
+    int rank = lo;
+    for (int q = lo; q < hi; q += 4) {
+      uint4 e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = w.sEnt[q + i < L ? q + i : L - 1];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned long long k2 = ((unsigned long long)e[i].y << 32) | e[i].x;
+        rank += (q + i < hi && (k2 > k || (k2 == k && e[i].z < o))) ? 1 : 0;
+      }
+    }
+    FLTX_PROF(7);
+    if (rank >= K) {
+      continue;
+    }
+    const int h = (int)(src & 0x7FFFFFFFu);
+    const int rep = (int)(gi & 0xFFu), n = (int)((gi >> 8) & 0xFFu);
+    const bool orphan = (gi >> 16) != 0u;
+    const bool newState = (src & kNewState) != 0u;
+    /* everything any case below needs, loaded up front (one LDS round trip) */
+    const uint32_t sparRep = w.bSPar[co + rep], sidRep = w.bState[co + rep];
+    const int32_t sedgeRep = w.bSEdge[co + rep];
+    const unsigned long long maskRep = w.bMask[co + rep];
+    const double amH = w.bAm[co + h];
+    const float eN = f.e[n];
+    const int kid = newState ? (int)w.dKid[rep * N + n] : -1;
+    const int hm = w.dMate[h];
+    const uint32_t sidH = w.bState[co + h];
+    const unsigned long long maskH = w.bMask[co + h];
+    const int kidc = kid >= 0 ? kid : 0;
+    const int km = w.dMate[kidc];
+    const uint32_t sidK = w.bState[co + kidc];
+    const unsigned long long maskK = w.bMask[co + kidc];
+    const bool keep = orphan || (ctc && n == P.blank); /* the new slot stays in rep's LM state */
+    const uint32_t kp = keep ? sparRep : sidRep;
+    const uint32_t ke = keep ? (uint32_t)sedgeRep : (uint32_t)n;
+    const uint32_t ktp = (uint32_t)n | ((!orphan && ctc && n == P.blank) ? kPrevBlank : 0u);
+    double am = amH + (double)eN;
+    if (f.useTrans) { /* ASG: transition enters am only (LexiconFreeDecoder.cpp:59-64) */
+      const int prevTok = (int)(w.bTokPb[co + h] & 0x7FFFFFFFu);
+      am = amH + ((double)eN + (double)P.transitions[(size_t)n * N + prevTok]);
+    }
+    uint32_t sid;
+    unsigned long long base;
+    int repSlot;
+    if (!newState) {
+      sid = sidH;
+      base = maskH;
+      repSlot = (hm >= 0 && hm < h) ? hm : h;
+    } else if (kid >= 0) { /* the state is in the beam: take its id from that slot */
+      sid = sidK;
+      base = maskK;
+      repSlot = (km >= 0 && km < kid) ? km : kid;
+    } else if ((maskRep >> n) & 1ull) { /* existed, dropped out: rare re-entry */
+      sid = loadCoherent32(&P.childTab[((size_t)f.b * P.idCap + kp) * N + n]);
+      base = loadCoherent64(&P.maskTab[(size_t)f.b * P.idCap + sid]);
+      repSlot = -1;
+      w.sc[SC_RELSLOW] = 1; /* its children may be in the beam: relations by id next frame */
+    } else { /* first time this state is materialised */
+      sid = atomAdd32((uint32_t*)&w.sc[SC_NEXTID], 1u);
+      if ((int64_t)sid >= P.idCap) {
+        atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_TABLE_FULL);
+        sid = 0;
+      }
+      base = 0ull;
+      repSlot = -1;
+      atomOr64(&w.addMask[rep], 1ull << n);
+      P.childTab[((size_t)f.b * P.idCap + kp) * N + n] = sid;
+      P.maskTab[(size_t)f.b * P.idCap + sid] = 0ull;
+    }
+    /* descriptor of the new slot's LM state and of its parent state, in terms of
+     * the old beam: equal descriptors <=> same state (see the header) */
+    int Dn, PDn;
+    if (repSlot >= 0) {
+      const int po = w.dPar[repSlot];
+      Dn = KN + repSlot;
+      PDn = po >= 0 ? KN + po : -1;
+    } else {
+      Dn = rep * N + n;
+      PDn = KN + rep;
+    }
+    atomOr64(&w.relTab[Dn], 1ull << rank);
+    if (PDn >= 0 && !(ktp & kPrevBlank) && !(ctc && n == P.blank)) {
+      atomOr64(&w.repTab[PDn - KN], 1ull << n);
+    }
+    const double sc = f64FromKey(k);
+    w.bRec[no + rank] = laneRec(sc, ktp, Dn, PDn);
+    w.bScore[no + rank] = sc;
+    w.bAm[no + rank] = am;
+    w.bState[no + rank] = sid;
+    w.bSPar[no + rank] = kp;
+    w.bSEdge[no + rank] = (int32_t)ke;
+    w.bTokPb[no + rank] = ktp;
+    w.eBase[rank] = base;
+    w.eRep[rank] = repSlot;
+    w.bPar[rank] = h;
+  }
+  c.pendHb = hbase;
+  c.pendOldN = nBeam;
+  FLTX_PROF(4);
+  return nS; /* the caller's row hand-over barrier closes the frame */
+}

@@ -69,6 +69,14 @@ FLTX_DEV void compilerFence() { __asm__ volatile("" ::: "memory"); }
 FLTX_DEV void ldsBarrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 /* ---- wave-level primitives (wave64) --------------------------------------- */
+/* LDS writes of this wave issued before the call are visible to its reads after
+ * it: the LDS queue of a wave is in order, this only stops the compiler from
+ * moving the accesses across */
+FLTX_DEV void waveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 FLTX_DEV unsigned long long waveBallot(bool p) { return __ballot(p); }
 FLTX_DEV int popc64(unsigned long long m) { return __popcll(m); }
 /* src must be wave-uniform: v_readlane_b32 (VALU) instead of ds_bpermute (LDS crossbar) */
@@ -98,6 +106,15 @@ FLTX_DEV unsigned long long f64Key(double d) {
 FLTX_DEV double f64FromKey(unsigned long long k) {
   unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
   return __longlong_as_double((long long)b);
+}
+
+/* order-preserving map float -> u32 */
+FLTX_DEV uint32_t f32Key(float x) {
+  const uint32_t b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+FLTX_DEV float f32FromKey(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
 #ifndef FLTX_EMU
@@ -134,6 +151,11 @@ FLTX_DEV unsigned long long waveBcastLast64(unsigned long long v) {
 FLTX_DEV unsigned long long waveMax64(unsigned long long v) {
   FLTX_DPP_SCAN(v, umax64, dppTake64)
   return waveBcastLast64(v);
+}
+FLTX_DEV uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+FLTX_DEV uint32_t waveMax32(uint32_t v) {
+  FLTX_DPP_SCAN(v, umax32, dppTake)
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 /* min over the wave: max of the complement */
 FLTX_DEV unsigned long long waveMin64(unsigned long long v) { return ~waveMax64(~v); }
