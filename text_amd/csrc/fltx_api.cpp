@@ -175,6 +175,7 @@ uint32_t nextPow2(uint64_t v) {
 /* ------------------------------------------------------------------------ */
 struct fltx_ctx {
   int device = 0;
+  int numCUs = 256; /* MI355X; read from the device at creation */
   Stream stream = nullptr;
   bool ownStream = false;
 };
@@ -294,6 +295,12 @@ int fltx_ctx_create(int device, void* stream, fltx_ctx** out) {
     return fail(FLTX_ERR_HIP, "hipSetDevice(%d) failed", device);
   }
   c->device = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) {
+      c->numCUs = cus;
+    }
+  }
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -928,7 +935,12 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
    * utterance win as long as the batch does not fill the CUs on its own
    * (measured on C2: 256 -> 15.3 ms, 512 -> 13.0 ms per 256-utterance batch) */
   if (!d->userThreads) {
-    d->threads = B <= 512 ? 512 : 256; /* C3: 256 -> 13.2 M frames/s, 512 -> 15.2 M */
+    /* one workgroup per CU: give it two waves per SIMD; more utterances than
+     * CUs: 256 threads, so that several utterances share a CU (C2 at B=512:
+     * 512 threads cannot co-reside (VGPRs), 256 can) */
+    d->threads = B <= d->ctx->numCUs * (d->kind == FLTX_DECODER_LEXICON ? 2 : 1) ? 512 : 256;
+    /* (the lexicon decoder's workspace fills a CU's LDS either way: C3 at B=512, 256 threads
+     * 13.2 M frames/s, 512 threads 15.5 M) */
   }
   /* lean frame step (fltx_lean.h): lexicon-free + ZeroLM, groups held in registers */
   d->lean = 0;

@@ -213,8 +213,8 @@ struct Ws {
   unsigned long long* relTab; /* [K*(N+1)] lane path: new slots per LM-state descriptor (bit = slot) */
   unsigned long long* repTab; /* [K] lane path: tokens repeated by children of old slot x's state */
   uint4* bRec;     /* [2K] lane path: {score, token|prevBlank, state descriptor | parent descriptor << 16} */
-  uint32_t* wcum;  /* [16*256] lane path: per-wave copy of the histogram prefix */
-  uint32_t* tick;  /* [256] lane path: scatter tickets per bin */
+  uint32_t* wcum;  /* [16*256] lane path: per-wave copy of the histogram prefix (512 x u16 per wave) */
+  uint32_t* tick;  /* [512] lane path: scatter tickets per bin */
   int32_t* pMate;  /* [16*64] per-wave partial relation results (lean path) */
   int32_t* pPar;   /* [16*64] */
   uint32_t* surv;  /* [K] candidate index of the survivor with rank r */
@@ -243,23 +243,66 @@ enum { SC_NCAND = 0, SC_NLEAD = 1, SC_NSURV = 2, SC_BSTAR = 3, SC_CUM = 4, SC_M 
 
 FLTX_HD size_t alignUp(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+/* Lane-per-slot path (fltx_lane.h): the per-frame state sits at FIXED offsets
+ * from the start of the workgroup's LDS (sized for its limits, beam <= 64), so
+ * the frame step addresses it with immediate offsets instead of one base
+ * register per array.  The Ws pointers of these fields point into this block,
+ * which is how the code shared with the other engines (begin / end / parking)
+ * sees the same data.  Three variable-size tables follow it. */
+constexpr int kLaneK = 64;      /* largest beam */
+constexpr int kLaneSCAP = 320;  /* short-list capacity: beam + 256 */
+struct LaneLds {
+  uint4 bRec[2 * kLaneK];
+  double bScore[2 * kLaneK];
+  double bAm[2 * kLaneK];
+  unsigned long long bMask[2 * kLaneK];
+  unsigned long long addMask[kLaneK];
+  unsigned long long eBase[kLaneK];
+  unsigned long long repTab[kLaneK];
+  uint4 sEnt[kLaneSCAP];
+  uint32_t hist[512];
+  uint32_t tick[512];
+  uint32_t bState[2 * kLaneK];
+  uint32_t bSPar[2 * kLaneK];
+  uint32_t bTokPb[2 * kLaneK];
+  int32_t bSEdge[2 * kLaneK];
+  int32_t eRep[kLaneK];
+  int32_t bPar[kLaneK];
+  int32_t dMate[kLaneK];
+  int32_t dPar[kLaneK];
+  uint32_t sIdx[kLaneSCAP];
+  uint32_t sSrc[kLaneSCAP];
+  int32_t sc[16];
+};
+
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
                        int dense, int rowCache, int lane) {
   size_t off = 0;
+  LaneLds* const LL = (lane && base) ? (LaneLds*)base : nullptr;
+  if (lane) {
+    off = alignUp(sizeof(LaneLds), 16);
+  }
 #define FLTX_CARVE(field, type, count)                       \
   off = alignUp(off, 16);                                    \
   field = (type*)(base ? base + off : nullptr);              \
   off += sizeof(type) * (size_t)(count);
-  FLTX_CARVE(w.bScore, double, 2 * K)
-  FLTX_CARVE(w.bAm, double, 2 * K)
+  /* a field of the fixed lane block in lane mode, carved like the rest otherwise */
+#define FLTX_CARVE_L(field, type, count, member)             \
+  if (lane) {                                                \
+    field = LL ? (type*)LL->member : nullptr;                \
+  } else {                                                   \
+    FLTX_CARVE(field, type, count)                           \
+  }
+  FLTX_CARVE_L(w.bScore, double, 2 * K, bScore)
+  FLTX_CARVE_L(w.bAm, double, 2 * K, bAm)
   FLTX_CARVE(w.bLm, double, 2 * K)
-  FLTX_CARVE(w.bState, uint32_t, 2 * K)
-  FLTX_CARVE(w.bSPar, uint32_t, 2 * K)
-  FLTX_CARVE(w.bSEdge, int32_t, 2 * K)
+  FLTX_CARVE_L(w.bState, uint32_t, 2 * K, bState)
+  FLTX_CARVE_L(w.bSPar, uint32_t, 2 * K, bSPar)
+  FLTX_CARVE_L(w.bSEdge, int32_t, 2 * K, bSEdge)
   FLTX_CARVE(w.bLex, uint32_t, 2 * K)
-  FLTX_CARVE(w.bTokPb, uint32_t, 2 * K)
+  FLTX_CARVE_L(w.bTokPb, uint32_t, 2 * K, bTokPb)
   FLTX_CARVE(w.bLexMax, float, 2 * K)
   FLTX_CARVE(w.rowEdge, uint4, rowCache ? (size_t)K * N : 0)
   FLTX_CARVE(w.erow, float, 2 * N)
@@ -277,36 +320,37 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.small, uint32_t, CAP)
   FLTX_CARVE(w.sKey, unsigned long long, SCAP)
   FLTX_CARVE(w.sOrd, uint32_t, SCAP)
-  FLTX_CARVE(w.sIdx, uint32_t, SCAP)
-  FLTX_CARVE(w.sSrc, uint32_t, SCAP)
-  FLTX_CARVE(w.sEnt, uint4, SCAP)
-  FLTX_CARVE(w.sBin, uint32_t, dense ? SCAP : 0)
-  FLTX_CARVE(w.sNext, uint32_t, dense ? SCAP : 0)
-  FLTX_CARVE(w.bhead, uint32_t, dense ? NB + NB / 16 + 1 : 0)
-  FLTX_CARVE(w.hcum, uint32_t, NB + NB / 16 + 1)
+  FLTX_CARVE_L(w.sIdx, uint32_t, SCAP, sIdx)
+  FLTX_CARVE_L(w.sSrc, uint32_t, SCAP, sSrc)
+  FLTX_CARVE_L(w.sEnt, uint4, SCAP, sEnt)
+  FLTX_CARVE(w.sBin, uint32_t, (dense && !lane) ? SCAP : 0)
+  FLTX_CARVE(w.sNext, uint32_t, (dense && !lane) ? SCAP : 0)
+  FLTX_CARVE(w.bhead, uint32_t, (dense && !lane) ? NB + NB / 16 + 1 : 0)
+  FLTX_CARVE(w.hcum, uint32_t, lane ? 0 : NB + NB / 16 + 1)
   FLTX_CARVE(w.dKid, int16_t, dense ? (size_t)K * N : 0)
-  FLTX_CARVE(w.bMask, unsigned long long, dense ? 2 * K : 0)
-  FLTX_CARVE(w.addMask, unsigned long long, dense ? K : 0)
-  FLTX_CARVE(w.eBase, unsigned long long, dense ? K : 0)
-  FLTX_CARVE(w.eRep, int32_t, dense ? K : 0)
-  FLTX_CARVE(w.bPar, int32_t, dense ? K : 0)
+  FLTX_CARVE_L(w.bMask, unsigned long long, dense ? 2 * K : 0, bMask)
+  FLTX_CARVE_L(w.addMask, unsigned long long, dense ? K : 0, addMask)
+  FLTX_CARVE_L(w.eBase, unsigned long long, dense ? K : 0, eBase)
+  FLTX_CARVE_L(w.eRep, int32_t, dense ? K : 0, eRep)
+  FLTX_CARVE_L(w.bPar, int32_t, dense ? K : 0, bPar)
   FLTX_CARVE(w.relTab, unsigned long long, lane ? (size_t)K * (N + 1) : 0)
-  FLTX_CARVE(w.repTab, unsigned long long, lane ? K : 0)
-  FLTX_CARVE(w.bRec, uint4, lane ? 2 * K : 0)
+  FLTX_CARVE_L(w.repTab, unsigned long long, lane ? K : 0, repTab)
+  FLTX_CARVE_L(w.bRec, uint4, lane ? 2 * K : 0, bRec)
   FLTX_CARVE(w.wcum, uint32_t, lane ? 16 * 256 : 0)
-  FLTX_CARVE(w.tick, uint32_t, lane ? 256 : 0)
-  FLTX_CARVE(w.pMate, int32_t, dense ? 16 * 64 : 0)
-  FLTX_CARVE(w.pPar, int32_t, dense ? 16 * 64 : 0)
+  FLTX_CARVE_L(w.tick, uint32_t, lane ? 512 : 0, tick)
+  FLTX_CARVE(w.pMate, int32_t, (dense && !lane) ? 16 * 64 : 0)
+  FLTX_CARVE(w.pPar, int32_t, (dense && !lane) ? 16 * 64 : 0)
   FLTX_CARVE(w.surv, uint32_t, K)
-  FLTX_CARVE(w.dMate, int32_t, dense ? K : 0)
-  FLTX_CARVE(w.dPar, int32_t, dense ? K : 0)
-  FLTX_CARVE(w.dRep, int16_t, dense ? (size_t)K * N : 0)
+  FLTX_CARVE_L(w.dMate, int32_t, dense ? K : 0, dMate)
+  FLTX_CARVE_L(w.dPar, int32_t, dense ? K : 0, dPar)
+  FLTX_CARVE(w.dRep, int16_t, (dense && !lane) ? (size_t)K * N : 0)
   FLTX_CARVE(w.dIn, uint8_t, N)
-  FLTX_CARVE(w.hist, uint32_t, NB + NB / 16 + 1)
+  FLTX_CARVE_L(w.hist, uint32_t, NB + NB / 16 + 1, hist)
   FLTX_CARVE(w.tokIdx, int32_t, N)
   FLTX_CARVE(w.wtmp, uint32_t, 32)
   FLTX_CARVE(w.red, unsigned long long, 4)
-  FLTX_CARVE(w.sc, int32_t, 16)
+  FLTX_CARVE_L(w.sc, int32_t, 16, sc)
+#undef FLTX_CARVE_L
 #undef FLTX_CARVE
   return alignUp(off, 16);
 }
@@ -1910,7 +1954,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     f.e = w.erow + rb * P.N;
     f.useTrans = (P.criterion == 0) && (total + t > 0) && P.transitions != nullptr;
     if constexpr (GT > 0) {
-      nBeam = runFrameLane<GT>(P, w, f, lcarry, frame + t + 1);
+      nBeam = runFrameLane<GT>(P, w, *(LaneLds*)wsBase, f, lcarry, frame + t + 1);
     } else if constexpr (GMAX > 0) {
       nBeam = runFrameLean<GMAX>(P, w, f, lmap, frame + t + 1);
     } else {
@@ -1945,7 +1989,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   if constexpr (GT > 0) { /* epilogue of the last frame's build */
     f.cur = cur;
     f.nBeam = nBeam;
-    laneFlush(P, w, f, lcarry);
+    laneFlush(P, *(LaneLds*)wsBase, f, lcarry);
     ldsBarrier();
   }
   if (P.doEnd) {

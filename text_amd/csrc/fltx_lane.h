@@ -34,7 +34,7 @@
  */
 #pragma once
 
-constexpr int kLaneNB = 256; /* histogram bins (K <= 64 candidates survive: 4 bins per lane) */
+constexpr int kLaneNB = 512; /* histogram bins: 8 per lane of the prefix scan */
 
 struct LaneCarry {
   int oldKid;      /* dKid entry this lane set for the current beam, -1 none (kid wave only) */
@@ -68,7 +68,7 @@ FLTX_DEV double laneRecScore(const uint4& r) {
  * final child-edge masks of the new slots, the {parent, token} history records
  * as one coalesced store, and the grown masks of the old states.  Done by the
  * last wave, which has the fewest tokens to evaluate. */
-FLTX_DEV void laneFlush(const DecodeParams& P, const Ws& w, const FrameCtx& f, LaneCarry& c) {
+FLTX_DEV void laneFlush(const DecodeParams& P, LaneLds& S, const FrameCtx& f, LaneCarry& c) {
   if (c.pendHb < 0) {
     return;
   }
@@ -79,29 +79,44 @@ FLTX_DEV void laneFlush(const DecodeParams& P, const Ws& w, const FrameCtx& f, L
   if (waveId() == nW - 1) {
     const int r = lane;
     if (r < f.nBeam) {
-      const int rs = w.eRep[r];
-      w.bMask[co + r] = w.eBase[r] | (rs >= 0 ? w.addMask[rs] : 0ull);
-      const int n = (int)(w.bTokPb[co + r] & 0x7FFFFFFFu);
-      P.histPT[c.pendHb + r] = make_int2(w.bPar[r], n);
+      const int rs = S.eRep[r];
+      S.bMask[co + r] = S.eBase[r] | (rs >= 0 ? S.addMask[rs] : 0ull);
+      const int n = (int)(S.bTokPb[co + r] & 0x7FFFFFFFu);
+      P.histPT[c.pendHb + r] = make_int2(S.bPar[r], n);
       if (P.histS) {
         double* hs = P.histS + 3 * (c.pendHb + r);
-        hs[0] = w.bScore[co + r];
-        hs[1] = w.bAm[co + r];
+        hs[0] = S.bScore[co + r];
+        hs[1] = S.bAm[co + r];
         hs[2] = 0.0;
       }
     }
     if (r < c.pendOldN) {
-      const unsigned long long add = w.addMask[r];
+      const unsigned long long add = S.addMask[r];
       if (add != 0ull) {
-        P.maskTab[(size_t)f.b * P.idCap + w.bState[no + r]] = w.bMask[no + r] | add;
+        P.maskTab[(size_t)f.b * P.idCap + S.bState[no + r]] = S.bMask[no + r] | add;
       }
     }
     waveSync();
     if (r < K) {
-      w.addMask[r] = 0ull;
+      S.addMask[r] = 0ull;
     }
   }
   c.pendHb = -1;
+}
+
+/* token j of a wave: the waves other than the last share the first
+ * (nW - 1) * GT tokens round-robin; the last wave, which also runs the deferred
+ * epilogue and the look-up tables of the builders, takes what is left */
+template <int GT>
+FLTX_DEV int laneToken(int wave, int nW, int j) {
+  if (nW == 1) {
+    return j;
+  }
+  return wave < nW - 1 ? wave + j * (nW - 1) : (nW - 1) * GT + j;
+}
+template <int GT>
+FLTX_DEV bool laneTokenValid(int wave, int nW, int n, int N) {
+  return n < N && (nW == 1 || wave == nW - 1 || n < (nW - 1) * GT);
 }
 
 FLTX_DEV uint32_t laneBit(unsigned long long m, int n) { /* n is wave-uniform at the call sites */
@@ -109,7 +124,7 @@ FLTX_DEV uint32_t laneBit(unsigned long long m, int n) { /* n is wave-uniform at
 }
 
 template <int GT>
-FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneCarry& c, int frameOut) {
+FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameCtx& f, LaneCarry& c, int frameOut) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   const int lane = laneId(), wave = waveId();
@@ -118,15 +133,15 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
   const int co = f.cur * K, no = (f.cur ^ 1) * K;
   const bool ctc = P.criterion == 1;
   const int nBeam = f.nBeam;
-  const int kWave = nW >= 3 ? nW - 2 : 0;
+  const int kWave = nW - 1;
   /* ---- phase 1: beam into lanes, relations, evaluation, histogram ---------------- */
-  laneFlush(P, w, f, c);
+  laneFlush(P, S, f, c);
   if (nBeam == 0) {
     return 0;
   }
   const bool live = lane < nBeam;
   const int hc = live ? lane : 0;
-  const uint4 meRec = w.bRec[co + hc];
+  const uint4 meRec = S.bRec[co + hc];
   const double score = laneRecScore(meRec);
   const uint32_t tokpb = meRec.z;
   const int tok = (int)(tokpb & 0x7FFFFFFFu);
@@ -135,11 +150,11 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
   const int D = live ? (int)(meRec.w & 0xFFFFu) - 1 : -1;
   int mate = -1, par = -1, pm = -1;
   unsigned long long repMask = 0ull;
-  if (w.sc[SC_RELSLOW] == 0) {
+  if (S.sc[SC_RELSLOW] == 0) {
     const int PD = live ? (int)(meRec.w >> 16) - 1 : -1;
     const unsigned long long mD = D >= 0 ? w.relTab[D] : 0ull;
     const unsigned long long mP = PD >= 0 ? w.relTab[PD] : 0ull;
-    repMask = D >= KN ? w.repTab[D - KN] : 0ull;
+    repMask = D >= KN ? S.repTab[D - KN] : 0ull;
     const unsigned long long oth = mD & ~(1ull << lane);
     mate = oth ? __builtin_ctzll(oth) : -1;
     par = mP ? __builtin_ctzll(mP) : -1;
@@ -147,8 +162,8 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
     pm = pr ? __builtin_ctzll(pr) : -1;
   } else {
     /* first frame of a launch, or an LM state re-entered the beam: compare ids */
-    const uint32_t sid = live ? w.bState[co + lane] : 0xFFFFFFFEu;
-    const uint32_t sp = live ? w.bSPar[co + lane] : 0xFFFFFFFDu;
+    const uint32_t sid = live ? S.bState[co + lane] : 0xFFFFFFFEu;
+    const uint32_t sp = live ? S.bSPar[co + lane] : 0xFFFFFFFDu;
     for (int h2 = 0; h2 < nBeam; ++h2) {
       const uint32_t s2 = waveReadLane32(sid, h2);
       mate = (s2 == sid && h2 != lane) ? h2 : mate;
@@ -175,28 +190,28 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
     waveSync();
     int kid = -1;
     if (live) {
-      w.dMate[lane] = mate;
-      w.dPar[lane] = par;
+      S.dMate[lane] = mate;
+      S.dPar[lane] = par;
       if (par >= 0) {
-        kid = par * N + w.bSEdge[co + lane];
+        kid = par * N + S.bSEdge[co + lane];
         w.dKid[kid] = (int16_t)lane;
       }
     }
     c.oldKid = kid;
   }
   const int mi = mate >= 0 ? mate : hc, pi = par >= 0 ? par : hc, qi = pm >= 0 ? pm : hc;
-  const uint4 mRec = w.bRec[co + mi], pRec = w.bRec[co + pi], qRec = w.bRec[co + qi];
+  const uint4 mRec = S.bRec[co + mi], pRec = S.bRec[co + pi], qRec = S.bRec[co + qi];
   const float eTok = f.e[tok < N ? tok : 0];
   const float eLane = f.e[lane < N ? lane : 0];
   const float eSil = f.e[P.sil];
   float eJ[GT]; /* emissions of this wave's tokens (wave-uniform), all in flight with the loads above */
 #pragma unroll
   for (int j = 0; j < GT; ++j) {
-    const int n = wave + j * nW;
+    const int n = laneToken<GT>(wave, nW, j);
     eJ[j] = f.e[n < N ? n : 0];
   }
-  const double a0 = w.bScore[co];
-  const double aLast = w.bScore[co + nBeam - 1];
+  const double a0 = S.bScore[co];
+  const double aLast = S.bScore[co + nBeam - 1];
   FLTX_PROF(6);
   /* best candidate of the frame: best hypothesis (slot 0, the beam is sorted)
    * with its best token.  fl(a0 + e) is monotone in e for a finite a0, so the
@@ -236,7 +251,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
   const double thr = best - P.beamThreshold;
   if (!(best - thr < 1e6)) { /* threshold too wide for the fixed bins: general path */
     if (tid == 0) {
-      atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_SELECT_FALLBACK);
+      atomOr32((uint32_t*)&S.sc[SC_STATUS], ST_SELECT_FALLBACK);
     }
     return 0;
   }
@@ -275,10 +290,10 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
   uint32_t validBits = 0u, pickBits = 0u;
 #pragma unroll
   for (int j = 0; j < GT; ++j) {
-    const int n = wave + j * nW; /* wave-uniform */
+    const int n = laneToken<GT>(wave, nW, j); /* wave-uniform */
     cs[j] = 0.0;
     cbin[j] = 0;
-    if (n < N) {
+    if (laneTokenValid<GT>(wave, nW, n, N)) {
       const double en = (double)eJ[j];
       double sA = score + en, sB = mScore + en;
       if (n == P.sil) {
@@ -330,7 +345,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
       int bin = (x < (float)kLaneNB) ? (int)x : kLaneNB - 1; /* also catches inf / NaN */
       bin = bin < 0 ? 0 : bin;
       cbin[j] = bin;
-      atomAdd32(&w.hist[bin], 1u);
+      atomAdd32(&S.hist[bin], 1u);
     }
   }
   FLTX_PROF(1);
@@ -341,35 +356,53 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
       w.relTab[D] = 0ull;
     }
     if (lane < K) {
-      w.repTab[lane] = 0ull;
+      S.repTab[lane] = 0ull;
     }
     if (lane == 0) {
-      w.sc[SC_RELSLOW] = 0;
+      S.sc[SC_RELSLOW] = 0;
     }
   }
-  const uint4 cq = ((const uint4*)w.hist)[lane];
-  const int mineCnt = (int)(cq.x + cq.y + cq.z + cq.w);
+  static_assert(kLaneNB == 512, "the prefix below handles 8 bins per lane");
+  const uint4 cq0 = ((const uint4*)S.hist)[2 * lane], cq1 = ((const uint4*)S.hist)[2 * lane + 1];
+  const int mineCnt = (int)(cq0.x + cq0.y + cq0.z + cq0.w + cq1.x + cq1.y + cq1.z + cq1.w);
   const int inc = waveInclusiveScan(mineCnt);
-  const int e0 = inc - mineCnt, e1 = e0 + (int)cq.x, e2 = e1 + (int)cq.y, e3 = e2 + (int)cq.z;
+  int pre[9]; /* exclusive prefix of my 8 bins, and the inclusive total after them */
+  pre[0] = inc - mineCnt;
+  pre[1] = pre[0] + (int)cq0.x;
+  pre[2] = pre[1] + (int)cq0.y;
+  pre[3] = pre[2] + (int)cq0.z;
+  pre[4] = pre[3] + (int)cq0.w;
+  pre[5] = pre[4] + (int)cq1.x;
+  pre[6] = pre[5] + (int)cq1.y;
+  pre[7] = pre[6] + (int)cq1.z;
+  pre[8] = inc;
   const int total = (int)waveReadLane32((uint32_t)inc, 63);
-  const unsigned long long cm = waveBallot(e0 < K && inc >= K);
+  const unsigned long long cm = waveBallot(pre[0] < K && inc >= K);
   int bstar = kLaneNB - 1, L = total;
   {
-    const int q = e1 >= K ? 0 : (e2 >= K ? 1 : (e3 >= K ? 2 : 3));
-    const int cumAt = q == 0 ? e1 : (q == 1 ? e2 : (q == 2 ? e3 : inc));
+    int q = 7, cumAt = inc; /* first of my bins whose inclusive count reaches K */
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {
+      const bool hit = pre[i + 1] >= K;
+      q = hit ? i : q;
+      cumAt = hit ? pre[i + 1] : cumAt;
+    }
     const int X = cm ? __builtin_ctzll(cm) : 0;
-    const uint32_t both = waveReadLane32((uint32_t)(4 * lane + q) | ((uint32_t)cumAt << 16), X);
+    const uint32_t both = waveReadLane32((uint32_t)(8 * lane + q) | ((uint32_t)cumAt << 16), X);
     if (cm) {
       bstar = (int)(both & 0xFFFFu);
       L = (int)(both >> 16);
     }
   }
   FLTX_PROF(2);
-  ((uint4*)(w.wcum + wave * kLaneNB))[lane] = make_uint4((uint32_t)e0, (uint32_t)e1, (uint32_t)e2, (uint32_t)e3);
+  /* this wave's copy of the prefixes, 16 bits each (L <= SCAP is checked below) */
+  ((uint4*)(w.wcum + wave * (kLaneNB / 2)))[lane] =
+      make_uint4((uint32_t)pre[0] | ((uint32_t)pre[1] << 16), (uint32_t)pre[2] | ((uint32_t)pre[3] << 16),
+                 (uint32_t)pre[4] | ((uint32_t)pre[5] << 16), (uint32_t)pre[6] | ((uint32_t)pre[7] << 16));
   waveSync();
   if (L > P.SCAP) { /* degenerate score distribution: let the host use the general path */
     if (tid == 0) {
-      atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_SELECT_FALLBACK);
+      atomOr32((uint32_t*)&S.sc[SC_STATUS], ST_SELECT_FALLBACK);
     }
     return 0;
   }
@@ -391,13 +424,13 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
         sj = j == i ? cs[i] : sj;
         bin = j == i ? cbin[i] : bin;
       }
-      const uint32_t lo = w.wcum[wave * kLaneNB + bin];
-      const uint32_t cnt = w.hist[bin];
-      const uint32_t p = lo + atomAdd32(&w.tick[bin], 1u);
+      const uint32_t lo = ((const uint16_t*)(w.wcum + wave * (kLaneNB / 2)))[bin];
+      const uint32_t cnt = S.hist[bin];
+      const uint32_t p = lo + atomAdd32(&S.tick[bin], 1u);
       int n, slot, rep;
       uint32_t flag, orphan = 0u;
       if (j < GT) {
-        n = wave + j * nW;
+        n = laneToken<GT>(wave, nW, j);
         slot = ((pickBits >> j) & 1u) ? mi : lane;
         flag = (ctc && n == P.blank) ? 0u : kNewState;
         rep = lane;
@@ -409,129 +442,138 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, FrameCtx& f, LaneC
         orphan = par >= 0 ? 0u : 1u;
       }
       const unsigned long long key = f64Key(sj);
-      w.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(slot * N + n), lo | ((lo + cnt) << 16));
+      S.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(slot * N + n), lo | ((lo + cnt) << 16));
       /* group: representative slot, token, orphan flag; source slot | kNewState */
-      w.sIdx[p] = (uint32_t)rep | ((uint32_t)n << 8) | (orphan << 16);
-      w.sSrc[p] = (uint32_t)slot | flag;
+      S.sIdx[p] = (uint32_t)rep | ((uint32_t)n << 8) | (orphan << 16);
+      S.sSrc[p] = (uint32_t)slot | flag;
     }
   }
   FLTX_PROF(3);
   ldsBarrier(); /* 2 */
   /* ---- phase 3: entry p ranks itself; rank < K builds beam slot `rank` ------------- */
+  /* Only ~K entries exist, one wave's worth, and what a new slot needs falls in
+   * two independent halves, so two waves build concurrently (on different
+   * SIMDs): wave 0 writes what the next frame's first phase reads (score,
+   * token, LM-state descriptors, relation masks), wave 1 everything the next
+   * build and the history need (am, LM-state id, child-edge masks, parent).
+   * The other waves reset the histogram. */
   const int nS = L < K ? L : K;
   const int64_t hbase = f.histBase + (int64_t)frameOut * K;
-  for (int i = nW > 1 ? tid - 64 : tid; i >= 0 && i < kLaneNB; i += (nW > 1 ? W - 64 : W)) {
-    w.hist[i] = 0u;
-    w.tick[i] = 0u;
+  const int bWave = nW > 1 ? 1 : 0;
+  if (nW <= 2 || wave >= 2) {
+    const int t0 = nW > 2 ? tid - 128 : tid, st = nW > 2 ? W - 128 : W;
+    for (int i = t0; i < kLaneNB; i += st) {
+      S.hist[i] = 0u;
+      S.tick[i] = 0u;
+    }
   }
-  for (int p = tid; p < L; p += W) {
-    const uint4 me = w.sEnt[p];
-    const uint32_t gi = w.sIdx[p];
-    const uint32_t src = w.sSrc[p];
-    const unsigned long long k = ((unsigned long long)me.y << 32) | me.x;
-    const uint32_t o = me.z;
-    const int lo = (int)(me.w & 0xFFFFu), hi = (int)(me.w >> 16);
-    /* exact rank = entries in better bins + members of my bin that precede me;
-     * a bin's members are contiguous after the counting sort.  Four entries per
-     * round trip: the loop length is the largest bin of the wave over four. */
-    int rank = lo;
-    for (int q = lo; q < hi; q += 4) {
-      uint4 e[4];
+  if (wave == 0 || wave == bWave) {
+    for (int p = lane; p < L; p += 64) {
+      const uint4 me = S.sEnt[p];
+      const uint32_t gi = S.sIdx[p];
+      const uint32_t src = S.sSrc[p];
+      const unsigned long long k = ((unsigned long long)me.y << 32) | me.x;
+      const uint32_t o = me.z;
+      const int lo = (int)(me.w & 0xFFFFu), hi = (int)(me.w >> 16);
+      /* exact rank = entries in better bins + members of my bin that precede me;
+       * a bin's members are contiguous after the counting sort.  Four entries per
+       * round trip: the loop length is the largest bin of the wave over four. */
+      int rank = lo;
+      for (int q = lo; q < hi; q += 4) {
+        uint4 e[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        e[i] = w.sEnt[q + i < L ? q + i : L - 1];
-      }
+        for (int i = 0; i < 4; ++i) {
+          e[i] = S.sEnt[q + i < L ? q + i : L - 1];
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned long long k2 = ((unsigned long long)e[i].y << 32) | e[i].x;
-        rank += (q + i < hi && (k2 > k || (k2 == k && e[i].z < o))) ? 1 : 0;
+        for (int i = 0; i < 4; ++i) {
+          const unsigned long long k2 = ((unsigned long long)e[i].y << 32) | e[i].x;
+          rank += (q + i < hi && (k2 > k || (k2 == k && e[i].z < o))) ? 1 : 0;
+        }
+      }
+      FLTX_PROF(7);
+      if (rank >= K) {
+        continue;
+      }
+      const int h = (int)(src & 0x7FFFFFFFu);
+      const int rep = (int)(gi & 0xFFu), n = (int)((gi >> 8) & 0xFFu);
+      const bool orphan = (gi >> 16) != 0u;
+      const bool newState = (src & kNewState) != 0u;
+      const bool blankTok = ctc && n == P.blank;
+      const uint32_t ktp = (uint32_t)n | ((!orphan && blankTok) ? kPrevBlank : 0u);
+      /* old-beam slot that represents the new slot's LM state, -1 = a state that
+       * is not in the old beam */
+      const int kid = newState ? (int)w.dKid[rep * N + n] : -1;
+      const int same = newState ? kid : h;
+      const int samec = same >= 0 ? same : 0;
+      const int sm = S.dMate[samec];
+      const int repSlot = same < 0 ? -1 : ((sm >= 0 && sm < same) ? sm : same);
+      if (wave == 0) {
+        /* descriptor of the new slot's LM state and of its parent state, in terms
+         * of the old beam: equal descriptors <=> same state (see the header) */
+        int Dn, PDn;
+        if (repSlot >= 0) {
+          const int po = S.dPar[repSlot];
+          Dn = KN + repSlot;
+          PDn = po >= 0 ? KN + po : -1;
+        } else {
+          Dn = rep * N + n;
+          PDn = KN + rep;
+        }
+        atomOr64(&w.relTab[Dn], 1ull << rank);
+        if (PDn >= 0 && !(ktp & kPrevBlank) && !blankTok) {
+          atomOr64(&S.repTab[PDn - KN], 1ull << n);
+        }
+        const double sc = f64FromKey(k);
+        S.bRec[no + rank] = laneRec(sc, ktp, Dn, PDn);
+        S.bScore[no + rank] = sc;
+        S.bTokPb[no + rank] = ktp;
+      }
+      if (wave == bWave) {
+        const uint32_t sparRep = S.bSPar[co + rep], sidRep = S.bState[co + rep];
+        const int32_t sedgeRep = S.bSEdge[co + rep];
+        const unsigned long long maskRep = S.bMask[co + rep];
+        const double amH = S.bAm[co + h];
+        const float eN = f.e[n];
+        const uint32_t sidS = S.bState[co + samec];
+        const unsigned long long maskS = S.bMask[co + samec];
+        const bool keep = orphan || blankTok; /* the new slot stays in rep's LM state */
+        const uint32_t kp = keep ? sparRep : sidRep;
+        const uint32_t ke = keep ? (uint32_t)sedgeRep : (uint32_t)n;
+        double am = amH + (double)eN;
+        if (f.useTrans) { /* ASG: transition enters am only (LexiconFreeDecoder.cpp:59-64) */
+          const int prevTok = (int)(S.bTokPb[co + h] & 0x7FFFFFFFu);
+          am = amH + ((double)eN + (double)P.transitions[(size_t)n * N + prevTok]);
+        }
+        uint32_t sid;
+        unsigned long long base;
+        if (same >= 0) { /* the state is in the old beam: take its id from that slot */
+          sid = sidS;
+          base = maskS;
+        } else if ((maskRep >> n) & 1ull) { /* existed, dropped out: rare re-entry */
+          sid = loadCoherent32(&P.childTab[((size_t)f.b * P.idCap + kp) * N + n]);
+          base = loadCoherent64(&P.maskTab[(size_t)f.b * P.idCap + sid]);
+          S.sc[SC_RELSLOW] = 1; /* its children may be in the beam: relations by id next frame */
+        } else { /* first time this state is materialised */
+          sid = atomAdd32((uint32_t*)&S.sc[SC_NEXTID], 1u);
+          if ((int64_t)sid >= P.idCap) {
+            atomOr32((uint32_t*)&S.sc[SC_STATUS], ST_TABLE_FULL);
+            sid = 0;
+          }
+          base = 0ull;
+          atomOr64(&S.addMask[rep], 1ull << n);
+          P.childTab[((size_t)f.b * P.idCap + kp) * N + n] = sid;
+          P.maskTab[(size_t)f.b * P.idCap + sid] = 0ull;
+        }
+        S.bAm[no + rank] = am;
+        S.bState[no + rank] = sid;
+        S.bSPar[no + rank] = kp;
+        S.bSEdge[no + rank] = (int32_t)ke;
+        S.eBase[rank] = base;
+        S.eRep[rank] = repSlot;
+        S.bPar[rank] = h;
       }
     }
-    FLTX_PROF(7);
-    if (rank >= K) {
-      continue;
-    }
-    const int h = (int)(src & 0x7FFFFFFFu);
-    const int rep = (int)(gi & 0xFFu), n = (int)((gi >> 8) & 0xFFu);
-    const bool orphan = (gi >> 16) != 0u;
-    const bool newState = (src & kNewState) != 0u;
-    /* everything any case below needs, loaded up front (one LDS round trip) */
-    const uint32_t sparRep = w.bSPar[co + rep], sidRep = w.bState[co + rep];
-    const int32_t sedgeRep = w.bSEdge[co + rep];
-    const unsigned long long maskRep = w.bMask[co + rep];
-    const double amH = w.bAm[co + h];
-    const float eN = f.e[n];
-    const int kid = newState ? (int)w.dKid[rep * N + n] : -1;
-    const int hm = w.dMate[h];
-    const uint32_t sidH = w.bState[co + h];
-    const unsigned long long maskH = w.bMask[co + h];
-    const int kidc = kid >= 0 ? kid : 0;
-    const int km = w.dMate[kidc];
-    const uint32_t sidK = w.bState[co + kidc];
-    const unsigned long long maskK = w.bMask[co + kidc];
-    const bool keep = orphan || (ctc && n == P.blank); /* the new slot stays in rep's LM state */
-    const uint32_t kp = keep ? sparRep : sidRep;
-    const uint32_t ke = keep ? (uint32_t)sedgeRep : (uint32_t)n;
-    const uint32_t ktp = (uint32_t)n | ((!orphan && ctc && n == P.blank) ? kPrevBlank : 0u);
-    double am = amH + (double)eN;
-    if (f.useTrans) { /* ASG: transition enters am only (LexiconFreeDecoder.cpp:59-64) */
-      const int prevTok = (int)(w.bTokPb[co + h] & 0x7FFFFFFFu);
-      am = amH + ((double)eN + (double)P.transitions[(size_t)n * N + prevTok]);
-    }
-    uint32_t sid;
-    unsigned long long base;
-    int repSlot;
-    if (!newState) {
-      sid = sidH;
-      base = maskH;
-      repSlot = (hm >= 0 && hm < h) ? hm : h;
-    } else if (kid >= 0) { /* the state is in the beam: take its id from that slot */
-      sid = sidK;
-      base = maskK;
-      repSlot = (km >= 0 && km < kid) ? km : kid;
-    } else if ((maskRep >> n) & 1ull) { /* existed, dropped out: rare re-entry */
-      sid = loadCoherent32(&P.childTab[((size_t)f.b * P.idCap + kp) * N + n]);
-      base = loadCoherent64(&P.maskTab[(size_t)f.b * P.idCap + sid]);
-      repSlot = -1;
-      w.sc[SC_RELSLOW] = 1; /* its children may be in the beam: relations by id next frame */
-    } else { /* first time this state is materialised */
-      sid = atomAdd32((uint32_t*)&w.sc[SC_NEXTID], 1u);
-      if ((int64_t)sid >= P.idCap) {
-        atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_TABLE_FULL);
-        sid = 0;
-      }
-      base = 0ull;
-      repSlot = -1;
-      atomOr64(&w.addMask[rep], 1ull << n);
-      P.childTab[((size_t)f.b * P.idCap + kp) * N + n] = sid;
-      P.maskTab[(size_t)f.b * P.idCap + sid] = 0ull;
-    }
-    /* descriptor of the new slot's LM state and of its parent state, in terms of
-     * the old beam: equal descriptors <=> same state (see the header) */
-    int Dn, PDn;
-    if (repSlot >= 0) {
-      const int po = w.dPar[repSlot];
-      Dn = KN + repSlot;
-      PDn = po >= 0 ? KN + po : -1;
-    } else {
-      Dn = rep * N + n;
-      PDn = KN + rep;
-    }
-    atomOr64(&w.relTab[Dn], 1ull << rank);
-    if (PDn >= 0 && !(ktp & kPrevBlank) && !(ctc && n == P.blank)) {
-      atomOr64(&w.repTab[PDn - KN], 1ull << n);
-    }
-    const double sc = f64FromKey(k);
-    w.bRec[no + rank] = laneRec(sc, ktp, Dn, PDn);
-    w.bScore[no + rank] = sc;
-    w.bAm[no + rank] = am;
-    w.bState[no + rank] = sid;
-    w.bSPar[no + rank] = kp;
-    w.bSEdge[no + rank] = (int32_t)ke;
-    w.bTokPb[no + rank] = ktp;
-    w.eBase[rank] = base;
-    w.eRep[rank] = repSlot;
-    w.bPar[rank] = h;
   }
   c.pendHb = hbase;
   c.pendOldN = nBeam;
