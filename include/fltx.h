@@ -231,7 +231,7 @@ FLTX_API int fltx_decoder_profile(fltx_decoder* dec, uint64_t* out);
 /* Tunables: "threads" (threads per utterance: 64..1024), "force_global_ws",
  * "dense" (0 = use the generic hash merge for lexicon-free frames too), "lean" /
  * "lane" (0 = do not use that specialised lexicon-free + ZeroLM frame step),
- * "row_cache", "keep_scores", "profile". */
+ * "keep_scores", "profile", "profile_wave". */
 FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
 /* Geometry chosen for the last batch: "engine" (0 generic hash merge, 1 generic
  * dense merge, 2 lean register-resident step, 3 lane-per-slot step), "lane"

@@ -234,7 +234,6 @@ struct fltx_decoder {
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
-  int rowCache = 0, noRowCache = 1; /* measured slower on C3 (LDS pressure): opt-in */
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   int keepScores = 0;
@@ -857,10 +856,6 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->profile = value != 0;
     return FLTX_OK;
   }
-  if (!strcmp(key, "row_cache")) { /* 1: cache the beam slots' trie child rows in LDS (default off) */
-    d->noRowCache = value == 0;
-    return FLTX_OK;
-  }
   if (!strcmp(key, "lean")) { /* 0: lexicon-free + ZeroLM frames use the generic engine */
     d->noLean = value == 0;
     return FLTX_OK;
@@ -965,17 +960,13 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   int64_t capC = worst;
   d->NB = 1024;
   d->SCAP = K + 256;
-  /* lexicon decoder: cache the beam slots' child rows in LDS when the prefetch
-   * registers cover the beam (16 slots per wave) */
-  d->rowCache = (d->kind == FLTX_DECODER_LEXICON && !d->noRowCache && !d->forceGlobalWs && N <= 64 &&
-                 K <= 16 * (d->threads / 64)) ? 1 : 0;
   Ws tmp;
   auto hsFor = [&](int64_t c) {
     int64_t keys = d->dense ? K : c;
     return std::max((int)nextPow2((uint64_t)keys * 2), 64);
   };
   auto bytesFor = [&](int64_t c) {
-    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->rowCache, d->lane);
+    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->lane);
   };
   bool lds = !d->forceGlobalWs;
   if (lds && bytesFor(capC) > kMaxLds) {
@@ -994,15 +985,12 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       lds = false;
     }
   }
-  if (!lds) {
-    d->rowCache = 0; /* HBM workspace: gather the edges where they are */
-  }
   d->CAP = (int)capC;
   d->HS = hsFor(capC);
   if (!lds) {
     d->lane = 0;
   }
-  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->rowCache, d->lane);
+  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane);
   d->wsInLds = lds;
   /* buffers */
   bool grewTab = false;
@@ -1120,7 +1108,6 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.SCAP = d->SCAP;
   P.dense = d->dense;
   P.lane = d->lane;
-  P.rowCache = d->rowCache;
   P.gLexMax = d->gLexMax.as<float>();
   P.gws = d->wsInLds ? nullptr : d->gws.as<char>();
   P.gwsStride = (int64_t)d->wsBytes;

@@ -102,7 +102,6 @@ struct DecodeParams {
   /* flat trie */
   const TrieEdge* trieEdge; /* [nNodes*N] */
   const int32_t* trieLabels;
-  int32_t rowCache;         /* 1: child rows of the beam slots are cached in LDS */
   /* LM */
   int32_t lmKind; /* 0 ZeroLM, 1 n-gram */
   int32_t lmOrder;
@@ -181,7 +180,6 @@ struct Ws {
   uint32_t* bLex;
   uint32_t* bTokPb;
   float* bLexMax;  /* [2K] maxScore of the slot's trie node, 0 at the root (LexiconDecoder.cpp:58-59) */
-  uint4* rowEdge;  /* [K*N] cached TrieEdge rows of the current beam (lexicon decoder) */
   /* candidate records */
   double* cScore;
   uint4* cKey;     /* {state parent, state edge, lex node, token | prevBlank<<31} */
@@ -278,7 +276,7 @@ struct LaneLds {
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
-                       int dense, int rowCache, int lane) {
+                       int dense, int lane) {
   size_t off = 0;
   LaneLds* const LL = (lane && base) ? (LaneLds*)base : nullptr;
   if (lane) {
@@ -304,7 +302,6 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.bLex, uint32_t, 2 * K)
   FLTX_CARVE_L(w.bTokPb, uint32_t, 2 * K, bTokPb)
   FLTX_CARVE(w.bLexMax, float, 2 * K)
-  FLTX_CARVE(w.rowEdge, uint4, rowCache ? (size_t)K * N : 0)
   FLTX_CARVE(w.erow, float, 2 * N)
   FLTX_CARVE(w.cScore, double, CAP)
   FLTX_CARVE(w.cKey, uint4, CAP)
@@ -375,8 +372,25 @@ FLTX_HD uint32_t hashKey(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
  * refresh this CU's vector L1, so a plain load after the barrier could hit a
  * stale line: make the barrier an agent-scope release/acquire (buffer_wbl2 +
  * buffer_inv, ~3.5 us -- only the slow big-beam path pays it).  With the
- * workspace in LDS it is a plain barrier. */
+ * workspace in LDS it waits for this wave's LDS operations only (ldsBarrier):
+ * __syncthreads() would also drain the global loads of the emission-row
+ * prefetch (~2k clocks) and the history stores at every barrier. */
 FLTX_DEV void wsBarrier(const DecodeParams& P) {
+#ifndef FLTX_EMU
+  if (P.gws != nullptr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* my stores are in L2 */
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return;
+  }
+#endif
+  ldsBarrier();
+}
+/* The same, where threads exchange data through GLOBAL memory across it (the
+ * n-gram context of a new LM state is written by the thread that builds the
+ * slot and read by other threads in later frames): also waits for the wave's
+ * outstanding global stores. */
+FLTX_DEV void wsBarrierMem(const DecodeParams& P) {
 #ifndef FLTX_EMU
   if (P.gws != nullptr) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* my stores are in L2 */
@@ -450,8 +464,11 @@ FLTX_DEV double blockMinF64(const DecodeParams& P, double v, unsigned long long*
 FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
                             double score, uint32_t kp, uint32_t ke, uint32_t klex,
                             uint32_t ktp, uint32_t src, int32_t aux, float lm,
-                            uint32_t ord, unsigned long long& bestKey) {
-  valid = valid && (score == score); /* NaN never enters (Utils.h:138-143) */
+                            uint32_t ord, unsigned long long& bestKey, double preThr = -__builtin_huge_val()) {
+  /* NaN never enters (Utils.h:138-143); preThr is (a lower bound of the frame's
+   * best score) - beamThreshold: what is below can not survive candidatesStore
+   * (Utils.h:160-170), so it is not even recorded */
+  valid = valid && (score >= preThr);
   const unsigned long long m = waveBallot(valid);
   if (m == 0ull) {
     return;
@@ -676,16 +693,6 @@ FLTX_DEV unsigned long long devClock() { return __builtin_readcyclecounter(); }
       f.t0 = t_;                                                       \
     }                                                                  \
   } while (0)
-
-/* child rows of the next beam, loaded at the end of a frame and parked in
- * registers until the next frame writes them to LDS: the ~2k-clock global
- * latency overlaps the frame hand-over instead of stalling candidate generation.
- * Lane = token, slot = wave + q * nWaves. */
-constexpr int kRowPF = 16;
-struct RowPF {
-  uint4 e[kRowPF];
-  bool valid;
-};
 
 struct FrameCtx {
   unsigned long long t0;
@@ -1008,13 +1015,16 @@ FLTX_DEV void denseLeaders(const DecodeParams& P, const Ws& w, const FrameCtx& f
  * item = (hypothesis, r): r < nTok tries the r-th short-listed token as a trie
  * child, r == nTok is "same node" (2), r == nTok+1 is CTC blank (3). */
 FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
-                         unsigned long long& bestKey) {
+                         unsigned long long& bestKey, double preThr) {
   const int per = f.nTok + 2;
-  const int total = f.nBeam * per;
+  const int total = f.nBeam * f.nTok; /* (hypothesis, token) items; the 2 stay / blank items per
+                                         hypothesis ride along in the first round */
   const int W = (int)blockDim.x;
   const bool ctc = P.criterion == 1;
   const bool hasUnk = P.unkScore > -__builtin_huge_val();
-  const int rounds = (total + W - 1) / W;
+  int rounds = (total + W - 1) / W;
+  const int stayRounds = (2 * f.nBeam + W - 1) / W;
+  rounds = rounds > stayRounds ? rounds : stayRounds;
   for (int it = 0; it < rounds; ++it) {
     const int i = it * W + (int)threadIdx.x;
     const bool valid = i < total;
@@ -1029,10 +1039,11 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     float lmTok = 0.0f, lexMax = 0.0f, childMax = 0.0f;
     uint32_t sid = 0, spar = 0, lexId = 0;
     int32_t sedge = 0;
-    bool stayBlank = false;
-    if (valid) {
-      h = i / per;
-      const int r = i - h * per;
+    uint32_t ordI = 0;
+    if (valid) { /* (1) children, :62-165 */
+      h = i / f.nTok;
+      const int r = i - h * f.nTok;
+      ordI = (uint32_t)(h * per + r);
       const uint32_t tp = w.bTokPb[(f.cur) * P.K + h];
       const int prevTok = (int)(tp & 0x7FFFFFFFu);
       const bool prevBlank = (tp & kPrevBlank) != 0;
@@ -1042,63 +1053,72 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       sedge = w.bSEdge[(f.cur) * P.K + h];
       const bool atRoot = lexId == 0u;
       const double hs = w.bScore[(f.cur) * P.K + h];
-      if (r < f.nTok) { /* (1) children, :62-165 */
-        n = (f.nTok == P.N) ? r : w.tokIdx[r];
-        TrieEdge ed;
-        if (P.rowCache) {
-          const uint4 q = w.rowEdge[h * P.N + n];
-          ed.child = (int32_t)q.x;
-          ed.childMax = __uint_as_float(q.y);
-          ed.label0 = (int32_t)q.z;
-          ed.meta = q.w;
-        } else {
-          ed = P.trieEdge[(size_t)lexId * P.N + n];
+      n = (f.nTok == P.N) ? r : w.tokIdx[r];
+      const TrieEdge ed = P.trieEdge[(size_t)lexId * P.N + n]; /* one 16-byte gather */
+      if (ed.child >= 0) {
+        childId = (uint32_t)ed.child;
+        lexMax = w.bLexMax[(f.cur) * P.K + h]; /* :58-59 */
+        childMax = ed.childMax;
+        amDelta = (double)f.e[n];
+        if (f.useTrans) {
+          amDelta += (double)P.transitions[(size_t)n * P.N + prevTok];
         }
-        if (ed.child >= 0) {
-          childId = (uint32_t)ed.child;
-          lexMax = w.bLexMax[(f.cur) * P.K + h]; /* :58-59 */
-          childMax = ed.childMax;
-          amDelta = (double)f.e[n];
-          if (f.useTrans) {
-            amDelta += (double)P.transitions[(size_t)n * P.N + prevTok];
-          }
-          base = hs + amDelta;
-          if (n == P.sil) {
-            base += P.silScore;
-          }
-          if (P.isLmToken) {
-            lmTok = lmScoreDev(P, f.b, sid, n); /* :82-86 */
-          }
-          const int nl = (int)(ed.meta & 7u);
-          cExt = (!ctc || prevBlank || n != prevTok) && (ed.meta & 8u) != 0; /* :89-91 */
-          if (!(atRoot && prevTok == n)) { /* :114-122 */
-            nLab = nl;
-            labOff = (int)(ed.meta >> 4);
-            lab0 = ed.label0;
-          }
-          cUnk = nl == 0 && hasUnk; /* :145 */
+        base = hs + amDelta;
+        if (n == P.sil) {
+          base += P.silScore;
         }
-      } else if (r == f.nTok) { /* (2) same lexicon node, :168-194 */
-        if (!ctc || !prevBlank || atRoot) {
-          cStay = true;
-          n = atRoot ? P.sil : prevTok;
-          amDelta = (double)f.e[n];
-          if (f.useTrans) {
-            amDelta += (double)P.transitions[(size_t)n * P.N + prevTok];
-          }
-          base = hs + amDelta;
-          if (n == P.sil) {
-            base += P.silScore;
-          }
+        if (P.isLmToken) {
+          lmTok = lmScoreDev(P, f.b, sid, n); /* :82-86 */
         }
-      } else if (ctc) { /* (3) blank, :197-213 */
-        cStay = true;
-        stayBlank = true;
-        n = P.blank;
-        base = hs + (double)f.e[n];
+        const int nl = (int)(ed.meta & 7u);
+        cExt = (!ctc || prevBlank || n != prevTok) && (ed.meta & 8u) != 0; /* :89-91 */
+        if (!(atRoot && prevTok == n)) { /* :114-122 */
+          nLab = nl;
+          labOff = (int)(ed.meta >> 4);
+          lab0 = ed.label0;
+        }
+        cUnk = nl == 0 && hasUnk; /* :145 */
       }
     }
-    const uint32_t ordBase = (uint32_t)i << 3;
+    /* (2) same lexicon node, :168-194, and (3) blank, :197-213: item j of this round */
+    bool stayBlank = false;
+    int hS = 0, nS = 0;
+    double baseS = 0;
+    uint32_t sparS = 0, lexS = 0, ordS = 0;
+    int32_t sedgeS = 0;
+    if (i < 2 * f.nBeam) {
+      hS = i >> 1;
+      const uint32_t tp = w.bTokPb[(f.cur) * P.K + hS];
+      const int prevTok = (int)(tp & 0x7FFFFFFFu);
+      const bool prevBlank = (tp & kPrevBlank) != 0;
+      lexS = w.bLex[(f.cur) * P.K + hS];
+      sparS = w.bSPar[(f.cur) * P.K + hS];
+      sedgeS = w.bSEdge[(f.cur) * P.K + hS];
+      const bool atRoot = lexS == 0u;
+      const double hs = w.bScore[(f.cur) * P.K + hS];
+      if ((i & 1) == 0) {
+        ordS = (uint32_t)(hS * per + f.nTok);
+        if (!ctc || !prevBlank || atRoot) {
+          cStay = true;
+          nS = atRoot ? P.sil : prevTok;
+          double ad = (double)f.e[nS];
+          if (f.useTrans) {
+            ad += (double)P.transitions[(size_t)nS * P.N + prevTok];
+          }
+          baseS = hs + ad;
+          if (nS == P.sil) {
+            baseS += P.silScore;
+          }
+        }
+      } else if (ctc) {
+        ordS = (uint32_t)(hS * per + f.nTok + 1);
+        cStay = true;
+        stayBlank = true;
+        nS = P.blank;
+        baseS = hs + (double)f.e[nS];
+      }
+    }
+    const uint32_t ordBase = ordI << 3;
     /* (1a) extend into the child node */
     {
       float l = P.isLmToken ? lmTok : (childMax - lexMax); /* float subtraction, :94 */
@@ -1107,7 +1127,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       uint32_t ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
       uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u) | kExtend;
       pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, (int32_t)__float_as_uint(childMax), l,
-                    ordBase, bestKey);
+                    ordBase, bestKey, preThr);
     }
     /* (1b) word ends: one candidate per label of the child */
     for (int j = 0; j < 6; ++j) {
@@ -1133,7 +1153,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
         sc = base + P.lmWeight * (double)l + P.wordScore;
       }
       pushCandidate(P, w, on, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, label, l,
-                    ordBase + 1 + (uint32_t)j, bestKey);
+                    ordBase + 1 + (uint32_t)j, bestKey, preThr);
     }
     /* (1c) unknown word */
     if (waveBallot(cUnk) != 0ull) {
@@ -1149,12 +1169,12 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       }
       double sc = base + P.lmWeight * (double)l + P.unkScore;
       pushCandidate(P, w, cUnk, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, P.unk, l,
-                    ordBase + 7, bestKey);
+                    ordBase + 7, bestKey, preThr);
     }
     /* (2)/(3) stay / blank keep state and node */
-    pushCandidate(P, w, cStay, base, spar, (uint32_t)sedge, lexId,
-                  (uint32_t)n | (stayBlank ? kPrevBlank : 0u), (uint32_t)h, -1, 0.0f, ordBase,
-                  bestKey);
+    pushCandidate(P, w, cStay, baseS, sparS, (uint32_t)sedgeS, lexS,
+                  (uint32_t)nS | (stayBlank ? kPrevBlank : 0u), (uint32_t)hS, -1, 0.0f, ordS << 3,
+                  bestKey, preThr);
   }
 }
 
@@ -1233,6 +1253,7 @@ FLTX_DEV void foldGroups(const DecodeParams& P, const Ws& w, double thr, int nCa
             bestOrd = o;
           }
         }
+        w.head[w.small[ci]] = kEmpty; /* leave the table empty for the next frame */
         if (bestIdx != kEmpty && P.logAdd) {
           /* Utils.h:186-193: members in descending score order, folded
            * left to right: acc = max + log1p(exp(min - max)) */
@@ -1442,7 +1463,8 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
  * and the rank IS the slot in the next beam.  Falls back to the iterative
  * selectTopK() when the short-list would not fit (degenerate distributions).
  * Returns the number of survivors; w.surv[r] = candidate index of rank r. */
-FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K) {
+FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K, double best, double thr,
+                           double spread) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   if (nLead <= 0) {
@@ -1462,19 +1484,12 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
     L = nLead;
     wsBarrier(P);
   } else {
-    /* range of the leaders' scores (-inf is parked in the last bin) */
-    unsigned long long kmax = 0ull, kmin = ~0ull;
-    for (int i = tid; i < nLead; i += W) {
-      const double sc = w.cScore[w.lead[i]];
-      const unsigned long long k = f64Key(sc);
-      kmax = k > kmax ? k : kmax;
-      if (sc > -__builtin_huge_val()) {
-        kmin = k < kmin ? k : kmin;
-      }
-    }
+    /* Bins over [best - beamThreshold, best]: the leaders already passed the
+     * threshold (foldGroups), so no pass over them is needed to find the range.
+     * Two monotone segments as in fltx_lean.h: 3/4 of the bins cover a little
+     * more than the current beam's own spread, where the next beam's K-th best
+     * is expected; the rest of the range shares the last quarter. */
     if (tid == 0) {
-      w.red[0] = 0ull;
-      w.red[1] = ~0ull;
       w.sc[SC_NSMALL] = 0;
       w.sc[SC_BSTAR] = P.NB - 1;
       w.sc[SC_CUM] = 0;
@@ -1483,22 +1498,19 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
       w.hist[FLTX_HB(i)] = 0;
     }
     wsBarrier(P);
-    kmax = waveMax64(kmax);
-    kmin = waveMin64(kmin);
-    if (laneId() == 0) {
-      atomMax64(&w.red[0], kmax);
-      atomMin64(&w.red[1], kmin);
-    }
-    wsBarrier(P);
-    const double hi = f64FromKey(w.red[0]);
-    const double lo = w.red[1] == ~0ull ? hi : f64FromKey(w.red[1]);
-    const double scale = (double)P.NB / (hi - lo);
-    if (!(hi > lo) || !(scale > 0.0) || !(scale < 1e300) || P.NB != 1024) {
+    const double range = best - thr;
+    const int NF = (P.NB * 3) / 4;
+    double cut = spread * 1.25 + 1e-3;
+    cut = cut > range * 0.125 ? cut : range * 0.125;
+    cut = cut < range * 0.9 ? cut : range * 0.9;
+    const double sF = (double)NF / cut, sC = (double)(P.NB - NF) / (range - cut);
+    if (!(range > 0.0) || !(range < 1e6) || !(sF > 0.0) || !(sF < 1e300) || !(sC > 0.0) || !(sC < 1e300) ||
+        P.NB != 1024) {
       slow = true;
     } else {
       for (int i = tid; i < nLead; i += W) {
-        const double sc = w.cScore[w.lead[i]];
-        const double x = (hi - sc) * scale;
+        const double d = best - w.cScore[w.lead[i]];
+        const double x = d < cut ? d * sF : (double)NF + (d - cut) * sC;
         int bin = (x < (double)P.NB) ? (int)x : P.NB - 1;
         bin = bin < 0 ? 0 : bin;
         w.lbin[i] = (uint16_t)bin;
@@ -1562,10 +1574,17 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
           const int lo2 = (int)w.hcum[FLTX_HB(bin)];
           const int hi2 = bin >= bstar ? L : (int)w.hcum[FLTX_HB(bin + 1)];
           int rank = lo2;
-          for (int q = lo2; q < hi2; ++q) {
-            const uint4 e = w.sEnt[q];
-            const unsigned long long k2 = ((unsigned long long)e.y << 32) | e.x;
-            rank += (k2 > k || (k2 == k && e.z < me.z)) ? 1 : 0;
+          for (int q = lo2; q < hi2; q += 4) { /* four entries per LDS round trip */
+            uint4 e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              e[u] = w.sEnt[q + u < L ? q + u : L - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const unsigned long long k2 = ((unsigned long long)e[u].y << 32) | e[u].x;
+              rank += (q + u < hi2 && (k2 > k || (k2 == k && e[u].z < me.z))) ? 1 : 0;
+            }
           }
           if (rank < K) {
             w.surv[rank] = w.sIdx[p];
@@ -1594,7 +1613,43 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K)
       L = nS;
     }
   }
-  /* exact rank on the short-list: contiguous, broadcast LDS reads */
+  /* exact rank on the short-list by all pairs, the pairs spread over the whole
+   * workgroup: entry j is compared with a slice of the list by each of
+   * W / L threads and the partial counts meet in LDS */
+  const int parts = L > 0 && W / L > 1 ? W / L : 1;
+  if (parts > 1) {
+    for (int j = tid; j < L; j += W) {
+      w.small[j] = 0u;
+    }
+    wsBarrier(P);
+    const int per = (L + parts - 1) / parts;
+    const int j = tid % L, c = tid / L;
+    if (c < parts) {
+      const unsigned long long k = w.sKey[j];
+      const uint32_t o = w.sOrd[j];
+      const int q0 = c * per;
+      int q1 = q0 + per;
+      q1 = q1 > L ? L : q1;
+      uint32_t cnt = 0;
+      for (int q = q0; q < q1; ++q) {
+        const unsigned long long k2 = w.sKey[q];
+        const uint32_t o2 = w.sOrd[q];
+        cnt += (k2 > k || (k2 == k && o2 < o)) ? 1u : 0u;
+      }
+      if (cnt != 0u) {
+        atomAdd32(&w.small[j], cnt);
+      }
+    }
+    wsBarrier(P);
+    for (int j2 = tid; j2 < L; j2 += W) {
+      const int rank = (int)w.small[j2];
+      if (rank < K) {
+        w.surv[rank] = w.sIdx[j2];
+      }
+    }
+    wsBarrier(P);
+    return nS;
+  }
   for (int j = tid; j < L; j += W) {
     const unsigned long long k = w.sKey[j];
     const uint32_t o = w.sOrd[j];
@@ -1700,6 +1755,22 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
  * emission descending, ties to the lower index. */
 FLTX_DEV void tokenShortlist(const DecodeParams& P, const Ws& w, const float* e, int nTok) {
   const int W = (int)blockDim.x;
+  if (P.N <= 64) {
+    /* lane m holds e[m]; a wave takes token n (its emission is a uniform LDS
+     * read) and the number of lanes that beat it is its rank: one ballot per
+     * token, the tokens spread over the waves */
+    const int m = laneId(), nW = (W + 63) >> 6;
+    const float o = m < P.N ? e[m] : 0.0f;
+    for (int n = waveId(); n < P.N; n += nW) {
+      const float v = e[n];
+      const unsigned long long beat = waveBallot(m < P.N && (o > v || (o == v && m < n)));
+      const int rank = popc64(beat);
+      if (m == 0 && rank < nTok) {
+        w.tokIdx[rank] = n;
+      }
+    }
+    return;
+  }
   for (int n = (int)threadIdx.x; n < P.N; n += W) {
     const float v = e[n];
     int rank = 0;
@@ -1714,12 +1785,11 @@ FLTX_DEV void tokenShortlist(const DecodeParams& P, const Ws& w, const float* e,
 }
 
 /* one frame (or decodeEnd when isEnd): returns the new beam size */
-FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, RowPF& rpf, int frameOut, bool isEnd) {
+FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frameOut, bool isEnd) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
-  for (int i = tid; i < P.HS; i += W) {
-    w.head[i] = kEmpty;
-  }
+  /* (the merge hash is empty here: foldGroups resets the slots it used, the
+   * kernel prologue cleared it once) */
   if (tid == 0) {
     w.sc[SC_NCAND] = 0;
     w.sc[SC_NLEAD] = 0;
@@ -1727,21 +1797,6 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, RowPF& rp
   }
   if (!isEnd && f.nTok < P.N) {
     tokenShortlist(P, w, f.e, f.nTok);
-  }
-  if (!isEnd && P.kind == 1 && P.rowCache) {
-    /* child rows of this beam: from the registers the previous frame filled,
-     * or straight from HBM on the first frame of a launch */
-    const int lane = laneId(), wave = waveId(), nW = (W + 63) >> 6;
-#pragma unroll
-    for (int q = 0; q < kRowPF; ++q) {
-      const int slot = wave + q * nW;
-      if (slot < f.nBeam && lane < P.N) {
-        const uint4 v = rpf.valid
-            ? rpf.e[q]
-            : ((const uint4*)P.trieEdge)[(size_t)w.bLex[(f.cur) * P.K + slot] * P.N + lane];
-        w.rowEdge[slot * P.N + lane] = v;
-      }
-    }
   }
   wsBarrier(P);
   FLTX_PROF(0);
@@ -1755,7 +1810,30 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, RowPF& rp
   } else if (P.kind == 0) {
     genLexFree(P, w, f, bestKey);
   } else {
-    genLexicon(P, w, f, bestKey);
+    /* a candidate that always exists bounds the frame's best score from below:
+     * slot 0 (the best hypothesis) taking the blank (CTC, :197-213) or staying
+     * in its node (ASG, :168-194) */
+    double lb;
+    {
+      const int o = f.cur * P.K;
+      const double hs = w.bScore[o];
+      if (P.criterion == 1) {
+        lb = hs + (double)f.e[P.blank];
+      } else {
+        const int prevTok = (int)(w.bTokPb[o] & 0x7FFFFFFFu);
+        const int n0 = w.bLex[o] == 0u ? P.sil : prevTok;
+        double ad = (double)f.e[n0];
+        if (f.useTrans) {
+          ad += (double)P.transitions[(size_t)n0 * P.N + prevTok];
+        }
+        lb = hs + ad;
+        if (n0 == P.sil) {
+          lb += P.silScore;
+        }
+      }
+    }
+    const double preThr = lb == lb ? lb - P.beamThreshold : -__builtin_huge_val();
+    genLexicon(P, w, f, bestKey, preThr);
   }
   bestKey = waveMax64(bestKey);
   if (laneId() == 0 && bestKey != 0ull) {
@@ -1778,21 +1856,10 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, RowPF& rp
   wsBarrier(P);
   FLTX_PROF(2);
   const int nLead = w.sc[SC_NLEAD];
-  const int nS = selectAndRank(P, w, nLead, P.K);
+  const double spread = f.nBeam > 0 ? w.bScore[f.cur * P.K] - w.bScore[f.cur * P.K + f.nBeam - 1] : 0.0;
+  const int nS = selectAndRank(P, w, nLead, P.K, best, thr, spread);
   FLTX_PROF(3);
   const int nB = buildBeam(P, w, f, nS, frameOut, isEnd);
-  if (!isEnd && P.kind == 1 && P.rowCache) {
-    const int lane = laneId(), wave = waveId(), nW = (W + 63) >> 6;
-    const int nxt = f.cur ^ 1;
-#pragma unroll
-    for (int q = 0; q < kRowPF; ++q) {
-      const int slot = wave + q * nW;
-      if (slot < nB && lane < P.N) {
-        rpf.e[q] = ((const uint4*)P.trieEdge)[(size_t)w.bLex[(nxt) * P.K + slot] * P.N + lane];
-      }
-    }
-    rpf.valid = true;
-  }
   FLTX_PROF(4);
   return nB;
 }
@@ -1811,11 +1878,16 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
-  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.rowCache, P.lane);
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {
     w.sc[SC_STATUS] = 0;
+  }
+  if constexpr (GT == 0) { /* the merge hash starts empty; foldGroups keeps it so */
+    for (int i = tid; i < P.HS; i += W) {
+      w.head[i] = kEmpty;
+    }
   }
   if (P.doBegin) {
     /* decodeBegin (LexiconFreeDecoder.cpp:20-28, LexiconDecoder.cpp:21-30) */
@@ -1921,7 +1993,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       w.erow[n] = em[n];
     }
   }
-  wsBarrier(P);
+  wsBarrierMem(P); /* also publishes the root LM state's n-gram context */
   FrameCtx f;
   f.b = b;
   f.nTok = nTok;
@@ -1931,8 +2003,6 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   for (int q = 0; q < 8; ++q) {
     f.acc[q] = 0ull;
   }
-  RowPF rpf;
-  rpf.valid = false;
   LeanMap<(GMAX > 0 ? GMAX : 1)> lmap;
   if constexpr (GMAX > 0 && GT == 0) {
     leanMapInit(P, nTok, lmap);
@@ -1958,7 +2028,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     } else if constexpr (GMAX > 0) {
       nBeam = runFrameLean<GMAX>(P, w, f, lmap, frame + t + 1);
     } else {
-      nBeam = runFrame(P, w, f, rpf, frame + t + 1, false);
+      nBeam = runFrame(P, w, f, frame + t + 1, false);
     }
     cur ^= 1; /* with nBeam == 0 either buffer is equally empty */
     if (t + 1 < T) {
@@ -1979,6 +2049,8 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     }
     if constexpr (GMAX > 0) {
       ldsBarrier(); /* the row hand-over is LDS only; back-pointer stores stay in flight */
+    } else if (P.lmKind != 0) {
+      wsBarrierMem(P); /* n-gram contexts of the new LM states, read by next frame's scoring */
     } else {
       wsBarrier(P);
     }
@@ -2000,7 +2072,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     if constexpr (GMAX > 0) {
       nBeam = nBeam > 0 ? runEndLean(P, w, f, frame + 1) : 0;
     } else {
-      nBeam = nBeam > 0 ? runFrame(P, w, f, rpf, frame + 1, true) : 0;
+      nBeam = nBeam > 0 ? runFrame(P, w, f, frame + 1, true) : 0;
     }
     cur ^= 1;
     frame += 1;
