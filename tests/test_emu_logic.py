@@ -40,3 +40,22 @@ def test_emulated_lane_per_slot_kernel(emu_session, golden, name):
     tol = 1e-9 if c["log_add"] else 0.0
     ok, why = helpers.check_against_golden(hyps, golden[c["name"]], tol)
     assert ok, why
+
+
+LEX_SMALL = [c for c in cases.CASES if c["kind"] == "lexicon" and c["size"] == "small" and c["T"] <= 40
+             and not c["log_add"]]
+
+
+@pytest.mark.parametrize("c", LEX_SMALL, ids=lambda c: c["name"])
+def test_emulated_score_cut_is_exact_or_retried(emu_session, golden, c):
+    """Lexicon decoder, cut-off generation (runFrame): with the cut forced down to
+    K + 1 candidates either the kept ones still form K groups (exact by
+    construction) or the kernel flags the frame and the batch is redone without
+    the cut -- the n-best must equal the reference's in both cases."""
+    inp = helpers.case_inputs(c)
+    d = emu_session.decoder(c, inp, 64)
+    d.set("cut_m", c["K"] + 1)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
+    d.close()
+    assert ok, why

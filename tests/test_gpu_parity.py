@@ -178,3 +178,25 @@ def test_decodertest_replay_on_device(gpu_session, tmp_path):
     ok, why = helpers.check_against_golden(hyps, exp["nbest"])
     assert ok, why
     dec.close()
+
+
+LEX_CUT = [c for c in cases.CASES if c["kind"] == "lexicon" and not c["log_add"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["tight", "off"])
+@pytest.mark.parametrize("c", LEX_CUT, ids=lambda c: c["name"])
+def test_lexicon_score_cut(gpu_session, golden, c, mode):
+    """The lexicon decoder scores every candidate first and materialises only the
+    best 2K + 64 (runFrame, cut-off generation).  Same n-best with the cut
+    forced down to K + 1 (exact, or flagged and redone) and with the cut off."""
+    inp = helpers.case_inputs(c)
+    d = gpu_session.decoder(c, inp)
+    if mode == "tight":
+        d.set("cut_m", c["K"] + 1)
+    else:
+        d.set("cut", 0)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], 0.0)
+    d.close()
+    assert ok, why

@@ -227,6 +227,7 @@ struct fltx_decoder {
   int CAP = 0, HS = 0, NB = 0, SCAP = 0, dense = 0, noDense = 0;
   int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
+  int CAP2 = 0, cutM = 0, noCut = 0, userCutM = 0; /* lexicon decoder: slim score-pass list + cut-off (runFrame) */
   size_t wsBytes = 0;
   bool wsInLds = true;
   /* device buffers */
@@ -826,6 +827,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->threads;
   } else if (!strcmp(key, "lds")) {
     *value = d->wsInLds ? 1 : 0;
+  } else if (!strcmp(key, "cut")) {
+    *value = d->cutM;
   } else {
     return fail(FLTX_ERR_INVALID, "fltx_decoder_get: unknown key '%s'", key);
   }
@@ -858,6 +861,14 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "lean")) { /* 0: lexicon-free + ZeroLM frames use the generic engine */
     d->noLean = value == 0;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "cut_m")) { /* testing: number of best candidates kept by the cut (default 2K + 64) */
+    d->userCutM = (int)value;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "cut")) { /* 0: the lexicon decoder materialises every candidate (no score-pass cut) */
+    d->noCut = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "lane")) { /* 0: beams <= 64 use the lean kernel instead of the lane-per-slot kernel */
@@ -969,17 +980,49 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->lane);
   };
   bool lds = !d->forceGlobalWs;
-  if (lds && bytesFor(capC) > kMaxLds) {
+  d->CAP2 = 0;
+  d->cutM = 0;
+  const bool forceCut = d->userCutM > 0 && d->kind == FLTX_DECODER_LEXICON && !forceWorstCaseCap; /* tests */
+  if (lds && (bytesFor(capC) > kMaxLds || forceCut)) {
     if (d->kind == FLTX_DECODER_LEXICON && !forceWorstCaseCap) {
       /* trie fan-out is sparse: size for the LDS and retry in HBM on overflow */
       int64_t c = capC;
       while (c > K && bytesFor(c) > kMaxLds) {
         c = c * 3 / 4;
       }
-      if (c >= std::max<int64_t>(K * 4, 64) && bytesFor(c) <= kMaxLds) {
-        capC = c;
-      } else {
-        lds = false;
+      const bool fits = c >= std::max<int64_t>(K * 4, 64) && bytesFor(c) <= kMaxLds;
+      /* About K * (nTok + 2) candidates pass the pre-filter in a frame (measured:
+       * C3 mean 280 / max 580 of 600, beam 100 x 29 tokens mean 1300 / max 2900
+       * of 3100).  With room for 1.5x that, build every candidate's record in
+       * one pass.  Otherwise (max-merge only) score every candidate into a slim
+       * {score, order} list first and build records only for the best
+       * cutM = 2K + 64 of them (runFrame): the record area then holds a few
+       * hundred entries and the slim list takes what is left of the LDS. */
+      const int64_t expect = (int64_t)K * (nTok + 2) * 3 / 2;
+      bool cut = false;
+      if ((!fits || c < expect || forceCut) && !d->noCut && !d->opt.log_add) {
+        const int64_t M = d->userCutM > 0 ? std::max<int64_t>(d->userCutM, K) : 2 * (int64_t)K + 64;
+        const int64_t capRec = std::max<int64_t>(2 * M, 512);
+        auto bytesCut = [&](int64_t c2) {
+          return carveWs(tmp, nullptr, K, (int)capRec, hsFor(capRec), d->NB, N, d->SCAP, d->dense, d->lane, (int)c2);
+        };
+        int64_t c2 = std::min<int64_t>(worst, 16384);
+        while (c2 > 4 * M && bytesCut(c2) > kMaxLds) {
+          c2 = c2 * 7 / 8;
+        }
+        if (bytesCut(c2) <= kMaxLds && c2 >= std::min<int64_t>(4 * M, worst)) {
+          d->CAP2 = (int)c2;
+          d->cutM = (int)M;
+          capC = capRec;
+          cut = true;
+        }
+      }
+      if (!cut) {
+        if (fits) {
+          capC = c;
+        } else {
+          lds = false;
+        }
       }
     } else {
       lds = false;
@@ -990,7 +1033,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (!lds) {
     d->lane = 0;
   }
-  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane);
+  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2);
   d->wsInLds = lds;
   /* buffers */
   bool grewTab = false;
@@ -1108,6 +1151,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.SCAP = d->SCAP;
   P.dense = d->dense;
   P.lane = d->lane;
+  P.CAP2 = d->CAP2;
+  P.cutM = d->cutM;
   P.gLexMax = d->gLexMax.as<float>();
   P.gws = d->wsInLds ? nullptr : d->gws.as<char>();
   P.gwsStride = (int64_t)d->wsBytes;
@@ -1372,6 +1417,10 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
       for (int b = 0; b < B; ++b) {
         if ((d->hStatus[b] & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON) {
           d->forceGlobalWs = 1;
+          redo = true;
+        }
+        if ((d->hStatus[b] & ST_CUT_RETRY) && d->CAP2) { /* the score cut left fewer than K groups */
+          d->noCut = 1;
           redo = true;
         }
         if ((d->hStatus[b] & ST_SELECT_FALLBACK) && d->lean) {

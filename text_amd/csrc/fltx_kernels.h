@@ -90,7 +90,7 @@ constexpr int kFinishEdge = -1;              /* KenLM::finish child key (KenLM.c
 constexpr uint32_t kPhantomNode = 0x80000000u; /* NgramSlot.node: navigation-only prefix */
 constexpr int kMaxNgramOrder = 6;            /* FL_TEXT_KENLM_MAX_ORDER (lm/CMakeLists.txt:3) */
 
-enum { ST_OK = 0, ST_CAND_OVERFLOW = 1, ST_TABLE_FULL = 2, ST_SELECT_FALLBACK = 4 };
+enum { ST_OK = 0, ST_CAND_OVERFLOW = 1, ST_TABLE_FULL = 2, ST_SELECT_FALLBACK = 4, ST_CUT_RETRY = 8 };
 
 struct DecodeParams {
   /* options (LexiconDecoderOptions, LexiconDecoder.h:21-31) */
@@ -143,6 +143,9 @@ struct DecodeParams {
   uint32_t epoch;    /* 1..65535, bumped per decodeBegin */
   /* workspace geometry */
   int32_t CAP, HS, NB, SCAP;
+  int32_t CAP2;  /* >0: lexicon decoder scores all candidates into slim {score, order} records first and
+                    materialises only the best cutM of them (see runFrame); capacity of that list */
+  int32_t cutM;
   int32_t dense; /* 1: lexicon-free frames use the hash-free dense merge */
   int32_t lane;  /* >0: lane-per-slot frame step (fltx_lane.h), value = tokens per wave */
   char* gws;          /* global workspace (big configurations), or null */
@@ -188,6 +191,8 @@ struct Ws {
   float* cLm;      /* LM score delta (float, as the reference holds it) */
   uint32_t* cOrd;  /* deterministic generation order (tie-break) */
   uint32_t* cNext; /* hash chain */
+  double* zScore;  /* [CAP2] score pass of the lexicon decoder: candidate score ... */
+  uint32_t* zOrd;  /* [CAP2] ... and generation order = (item, sub-candidate), enough to rebuild it */
   uint32_t* head;  /* [HS] */
   uint32_t* lead;  /* group leaders (candidate index), later survivors */
   uint8_t* lstat;  /* per leader: 0 dropped, 1 active, 2 taken */
@@ -229,7 +234,7 @@ struct Ws {
 };
 
 enum { SC_NCAND = 0, SC_NLEAD = 1, SC_NSURV = 2, SC_BSTAR = 3, SC_CUM = 4, SC_M = 5,
-       SC_NSMALL = 6, SC_STATUS = 7, SC_NEED = 8, SC_DONE = 9, SC_NEXTID = 10, SC_RELSLOW = 11 };
+       SC_NSMALL = 6, SC_STATUS = 7, SC_NEED = 8, SC_DONE = 9, SC_NEXTID = 10, SC_RELSLOW = 11, SC_NSLIM = 12, SC_CUT = 13, SC_BM = 14 };
 
 #ifndef FLTX_HD
 #ifdef FLTX_EMU
@@ -276,7 +281,7 @@ struct LaneLds {
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
-                       int dense, int lane) {
+                       int dense, int lane, int CAP2 = 0) {
   size_t off = 0;
   LaneLds* const LL = (lane && base) ? (LaneLds*)base : nullptr;
   if (lane) {
@@ -310,6 +315,8 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.cLm, float, CAP)
   FLTX_CARVE(w.cOrd, uint32_t, CAP)
   FLTX_CARVE(w.cNext, uint32_t, CAP)
+  FLTX_CARVE(w.zScore, double, CAP2)
+  FLTX_CARVE(w.zOrd, uint32_t, CAP2)
   FLTX_CARVE(w.head, uint32_t, HS)
   FLTX_CARVE(w.lead, uint32_t, CAP)
   FLTX_CARVE(w.lstat, uint8_t, CAP)
@@ -536,6 +543,37 @@ FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
     }
     s = (s + 1) & (uint32_t)(P.HS - 1);
   }
+}
+
+/* Score pass of the lexicon decoder: remember only the score and the
+ * generation order of a candidate (the order encodes hypothesis, token and
+ * which of the item's candidates it is, so the full record can be rebuilt). */
+FLTX_DEV void pushSlim(const DecodeParams& P, const Ws& w, bool valid, double score, uint32_t ord,
+                       unsigned long long& bestKey, double preThr) {
+  valid = valid && (score >= preThr);
+  const unsigned long long m = waveBallot(valid);
+  if (m == 0ull) {
+    return;
+  }
+  const int lane = laneId();
+  const int leader = __builtin_ctzll(m);
+  uint32_t base = 0;
+  if (lane == leader) {
+    base = atomAdd32((uint32_t*)&w.sc[SC_NSLIM], (uint32_t)popc64(m));
+  }
+  base = waveShfl32(base, leader);
+  if (!valid) {
+    return;
+  }
+  const uint32_t ci = base + (uint32_t)popc64(m & ((1ull << lane) - 1ull));
+  if (ci >= (uint32_t)P.CAP2) {
+    atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_CAND_OVERFLOW);
+    return;
+  }
+  const unsigned long long sk = f64Key(score);
+  bestKey = sk > bestKey ? sk : bestKey;
+  w.zScore[ci] = score;
+  w.zOrd[ci] = ord;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1014,6 +1052,7 @@ FLTX_DEV void denseLeaders(const DecodeParams& P, const Ws& w, const FrameCtx& f
 /* LexiconDecoder::decodeStep inner loops (LexiconDecoder.cpp:55-215).  Work
  * item = (hypothesis, r): r < nTok tries the r-th short-listed token as a trie
  * child, r == nTok is "same node" (2), r == nTok+1 is CTC blank (3). */
+template <bool SLIM>
 FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
                          unsigned long long& bestKey, double preThr) {
   const int per = f.nTok + 2;
@@ -1126,8 +1165,12 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       uint32_t kp = P.isLmToken ? sid : spar;
       uint32_t ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
       uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u) | kExtend;
-      pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, (int32_t)__float_as_uint(childMax), l,
-                    ordBase, bestKey, preThr);
+      if constexpr (SLIM) {
+        pushSlim(P, w, cExt, sc, ordBase, bestKey, preThr);
+      } else {
+        pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, (int32_t)__float_as_uint(childMax), l,
+                      ordBase, bestKey, preThr);
+      }
     }
     /* (1b) word ends: one candidate per label of the child */
     for (int j = 0; j < 6; ++j) {
@@ -1152,8 +1195,12 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
         }
         sc = base + P.lmWeight * (double)l + P.wordScore;
       }
-      pushCandidate(P, w, on, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, label, l,
-                    ordBase + 1 + (uint32_t)j, bestKey, preThr);
+      if constexpr (SLIM) {
+        pushSlim(P, w, on, sc, ordBase + 1 + (uint32_t)j, bestKey, preThr);
+      } else {
+        pushCandidate(P, w, on, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, label, l,
+                      ordBase + 1 + (uint32_t)j, bestKey, preThr);
+      }
     }
     /* (1c) unknown word */
     if (waveBallot(cUnk) != 0ull) {
@@ -1168,14 +1215,108 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
         }
       }
       double sc = base + P.lmWeight * (double)l + P.unkScore;
-      pushCandidate(P, w, cUnk, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, P.unk, l,
-                    ordBase + 7, bestKey, preThr);
+      if constexpr (SLIM) {
+        pushSlim(P, w, cUnk, sc, ordBase + 7, bestKey, preThr);
+      } else {
+        pushCandidate(P, w, cUnk, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, P.unk, l,
+                      ordBase + 7, bestKey, preThr);
+      }
     }
     /* (2)/(3) stay / blank keep state and node */
-    pushCandidate(P, w, cStay, baseS, sparS, (uint32_t)sedgeS, lexS,
-                  (uint32_t)nS | (stayBlank ? kPrevBlank : 0u), (uint32_t)hS, -1, 0.0f, ordS << 3,
-                  bestKey, preThr);
+    if constexpr (SLIM) {
+      pushSlim(P, w, cStay, baseS, ordS << 3, bestKey, preThr);
+    } else {
+      pushCandidate(P, w, cStay, baseS, sparS, (uint32_t)sedgeS, lexS,
+                    (uint32_t)nS | (stayBlank ? kPrevBlank : 0u), (uint32_t)hS, -1, 0.0f, ordS << 3,
+                    bestKey, preThr);
+    }
   }
+}
+
+/* Second pass of the lexicon decoder's cut-off generation: the slim records
+ * whose score reaches the cut (bin <= bM of the linear histogram over
+ * [thr, best]) are rebuilt into full candidate records and merged.  The order
+ * value tells which candidate of which (hypothesis, token) item a record is;
+ * its fields are recomputed exactly as genLexicon does, the score is the one
+ * the score pass stored. */
+FLTX_DEV void genLexiconSelected(const DecodeParams& P, const Ws& w, const FrameCtx& f, int nSlim, int bM,
+                                 double best, double thr, double scale) {
+  const int W = (int)blockDim.x;
+  const int per = f.nTok + 2;
+  const bool ctc = P.criterion == 1;
+  const int rounds = (nSlim + W - 1) / W;
+  unsigned long long dummy = 0ull;
+  for (int it = 0; it < rounds; ++it) {
+    const int i = it * W + (int)threadIdx.x;
+    bool on = i < nSlim;
+    double sc = 0;
+    uint32_t ord = 0, kp = 0, ke = 0, klex = 0, ktp = 0, src = 0;
+    int32_t aux = -1;
+    float l = 0.0f;
+    if (on) {
+      sc = w.zScore[i];
+      ord = w.zOrd[i];
+      on = sc >= thr;
+      if (on) {
+        const double x = (best - sc) * scale;
+        int bin = (x < (double)P.NB) ? (int)x : P.NB - 1;
+        bin = bin < 0 ? 0 : bin;
+        if (bin > bM) { /* a candidate that would pass the threshold is left out: noted for the check */
+          on = false;
+          w.sc[SC_CUT] = 1;
+        }
+      }
+    }
+    if (on) {
+      const int item = (int)(ord >> 3), sub = (int)(ord & 7u);
+      const int h = item / per, r = item - h * per;
+      const int o = f.cur * P.K + h;
+      const uint32_t tp = w.bTokPb[o];
+      const int prevTok = (int)(tp & 0x7FFFFFFFu);
+      const uint32_t lexId = w.bLex[o];
+      const uint32_t sid = w.bState[o], spar = w.bSPar[o];
+      const int32_t sedge = w.bSEdge[o];
+      if (r >= f.nTok) { /* stay (:168-194) or blank (:197-213): keep state and node */
+        const bool blank = r > f.nTok;
+        const int n = blank ? P.blank : (lexId == 0u ? P.sil : prevTok);
+        kp = spar;
+        ke = (uint32_t)sedge;
+        klex = lexId;
+        ktp = (uint32_t)n | (blank ? kPrevBlank : 0u);
+        src = (uint32_t)h;
+      } else {
+        const int n = (f.nTok == P.N) ? r : w.tokIdx[r];
+        const TrieEdge ed = P.trieEdge[(size_t)lexId * P.N + n];
+        const float lexMax = w.bLexMax[o];
+        const float lmTok = P.isLmToken ? lmScoreDev(P, f.b, sid, n) : 0.0f;
+        ktp = (uint32_t)n;
+        if (sub == 0) { /* extend into the child node (:89-112) */
+          l = P.isLmToken ? lmTok : (ed.childMax - lexMax);
+          kp = P.isLmToken ? sid : spar;
+          ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
+          klex = (uint32_t)ed.child;
+          src = (uint32_t)h | (P.isLmToken ? kNewState : 0u) | kExtend;
+          aux = (int32_t)__float_as_uint(ed.childMax);
+        } else { /* word end (:114-143) or unknown word (:145-165): back to the root */
+          const int j = sub - 1;
+          const int label = sub == 7 ? P.unk : (j == 0 ? ed.label0 : P.trieLabels[(int)(ed.meta >> 4) + j]);
+          if (!P.isLmToken) {
+            l = lmScoreDev(P, f.b, sid, label) - lexMax;
+            ke = (uint32_t)label;
+          } else {
+            l = lmTok;
+            ke = (uint32_t)n;
+          }
+          kp = sid;
+          klex = 0u;
+          src = (uint32_t)h | kNewState;
+          aux = label;
+        }
+      }
+    }
+    pushCandidate(P, w, on, sc, kp, ke, klex, ktp, src, aux, l, ord, dummy);
+  }
+  (void)ctc;
 }
 
 /* decodeEnd candidates (LexiconFreeDecoder.cpp:127-146, LexiconDecoder.cpp:231-262) */
@@ -1793,7 +1934,15 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   if (tid == 0) {
     w.sc[SC_NCAND] = 0;
     w.sc[SC_NLEAD] = 0;
+    w.sc[SC_NSLIM] = 0;
+    w.sc[SC_CUT] = 0;
+    w.sc[SC_BM] = P.NB - 1;
     w.red[2] = 0ull;
+  }
+  if (!isEnd && P.kind == 1 && P.CAP2 > 0) {
+    for (int i = tid; i < P.NB; i += W) {
+      w.hist[FLTX_HB(i)] = 0;
+    }
   }
   if (!isEnd && f.nTok < P.N) {
     tokenShortlist(P, w, f.e, f.nTok);
@@ -1833,7 +1982,11 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
       }
     }
     const double preThr = lb == lb ? lb - P.beamThreshold : -__builtin_huge_val();
-    genLexicon(P, w, f, bestKey, preThr);
+    if (P.CAP2 > 0) {
+      genLexicon<true>(P, w, f, bestKey, preThr);
+    } else {
+      genLexicon<false>(P, w, f, bestKey, preThr);
+    }
   }
   bestKey = waveMax64(bestKey);
   if (laneId() == 0 && bestKey != 0ull) {
@@ -1845,6 +1998,62 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   }
   const double best = f64FromKey(w.red[2]);
   const double thr = best - P.beamThreshold; /* Utils.h:219 call sites */
+  if (!isEnd && P.kind == 1 && P.CAP2 > 0) {
+    /* Cut-off generation.  Every candidate has been scored; only the best cutM
+     * of them (plus the rest of the last histogram bin) become records and
+     * enter the merge.  Exact whenever the merge still yields K groups: a
+     * candidate that is left out scores strictly below every one that is kept,
+     * so it can neither lead one of the top K groups nor be the best member of
+     * a kept group (max-merge).  The check after the fold flags the other case
+     * and the host repeats the batch without the cut. */
+    int nSlim = w.sc[SC_NSLIM];
+    nSlim = nSlim > P.CAP2 ? P.CAP2 : nSlim;
+    const double range = best - thr;
+    const double scale = (double)P.NB / range;
+    int bM = P.NB - 1;
+    if (nSlim > P.cutM && range > 0.0 && scale > 0.0 && scale < 1e300) {
+      for (int i = tid; i < nSlim; i += W) {
+        const double sc = w.zScore[i];
+        if (sc >= thr) {
+          const double x = (best - sc) * scale;
+          int bin = (x < (double)P.NB) ? (int)x : P.NB - 1;
+          bin = bin < 0 ? 0 : bin;
+          atomAdd32(&w.hist[FLTX_HB(bin)], 1u);
+        }
+      }
+      wsBarrier(P);
+      if (waveId() == 0) { /* bin in which the cutM-th best candidate lies */
+        constexpr int PER = 16;
+        const int lane = laneId();
+        int c[PER];
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          c[q] = (int)w.hist[FLTX_HB(lane * PER + q)];
+          mine += c[q];
+        }
+        const int inc = waveInclusiveScan(mine);
+        int cum = inc - mine;
+        if (cum < P.cutM && inc >= P.cutM) {
+          int bq = PER - 1;
+          bool done = false;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            cum += c[q];
+            if (!done && cum >= P.cutM) {
+              bq = q;
+              done = true;
+            }
+          }
+          w.sc[SC_BM] = lane * PER + bq;
+        }
+      }
+      wsBarrier(P);
+      bM = w.sc[SC_BM];
+    }
+    genLexiconSelected(P, w, f, nSlim, bM, best, thr, scale);
+    wsBarrier(P);
+  }
   FLTX_PROF(1);
   if (dense) {
     denseLeaders(P, w, f, thr);
@@ -1856,6 +2065,9 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   wsBarrier(P);
   FLTX_PROF(2);
   const int nLead = w.sc[SC_NLEAD];
+  if (!isEnd && P.kind == 1 && P.CAP2 > 0 && w.sc[SC_CUT] != 0 && nLead < P.K && tid == 0) {
+    atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_CUT_RETRY); /* the cut left fewer than K groups */
+  }
   const double spread = f.nBeam > 0 ? w.bScore[f.cur * P.K] - w.bScore[f.cur * P.K + f.nBeam - 1] : 0.0;
   const int nS = selectAndRank(P, w, nLead, P.K, best, thr, spread);
   FLTX_PROF(3);
@@ -1878,7 +2090,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
-  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane);
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane, P.CAP2);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Time one parity case (tests/cases.py) as a batch of identical-shape utterances on the GPU.
+
+Usage: tools/bench_case.py CASE [batch] [steps]   e.g. tools/bench_case.py C4_spell_u0 256 3
+Used for the secondary workloads quoted in DESIGN.md (C3 / C4); bench.py stays the contract bench.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+import helpers  # noqa: E402
+from text_amd import synth  # noqa: E402
+
+
+def main():
+    name = sys.argv[1]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    c = cases.BY_NAME[name]
+    s = helpers.FltxSession(None)
+    inp = helpers.case_inputs(c)
+    d = s.decoder(c, inp)
+    lex = inp.get("lex") if c["dist"] == "lexspell" else None
+    e = synth.batch(c["dist"], B, c["T"], c["N"], lexicon=lex, u0=0)
+    Ts = np.full(B, c["T"], dtype=np.int32)
+    d.decode_batch(e, Ts, c["N"])
+    ms = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        d.decode_batch(e, Ts, c["N"])
+        s.ctx.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    k, b = d.timing()
+    print("%s batch=%d T=%d K=%d: engine %d threads %d, decode kernel %.2f ms, backtrace %.2f ms, "
+          "wall/batch %.2f ms (incl. H2D), %.2f M frames/s (kernel)" %
+          (name, B, c["T"], c["K"], d.get("engine"), d.get("threads"), k, b, min(ms), B * c["T"] / k / 1e3))
+    d.close()
+
+
+if __name__ == "__main__":
+    main()
