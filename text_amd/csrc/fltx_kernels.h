@@ -1064,9 +1064,32 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
   int rounds = (total + W - 1) / W;
   const int stayRounds = (2 * f.nBeam + W - 1) / W;
   rounds = rounds > stayRounds ? rounds : stayRounds;
+  /* the trie gather of round it + 1 is issued before round it's candidates are
+   * pushed, so its ~2k-clock HBM latency overlaps the appends instead of
+   * stalling every round */
+  uint4 edPre = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+  {
+    const int i0 = (int)threadIdx.x;
+    if (i0 < total) {
+      const int h0 = i0 / f.nTok;
+      const int r0 = i0 - h0 * f.nTok;
+      const int n0 = (f.nTok == P.N) ? r0 : w.tokIdx[r0];
+      edPre = ((const uint4*)P.trieEdge)[(size_t)w.bLex[(f.cur) * P.K + h0] * P.N + n0];
+    }
+  }
   for (int it = 0; it < rounds; ++it) {
     const int i = it * W + (int)threadIdx.x;
     const bool valid = i < total;
+    const uint4 edNow = edPre;
+    {
+      const int i1 = i + W;
+      if (i1 < total) {
+        const int h1 = i1 / f.nTok;
+        const int r1 = i1 - h1 * f.nTok;
+        const int n1 = (f.nTok == P.N) ? r1 : w.tokIdx[r1];
+        edPre = ((const uint4*)P.trieEdge)[(size_t)w.bLex[(f.cur) * P.K + h1] * P.N + n1];
+      }
+    }
     /* up to 1 extend + 6 labels (or 1 unk) candidates per item, pushed in
      * lock-step so the wave-aggregated append stays convergent */
     bool cExt = false, cStay = false;
@@ -1093,7 +1116,11 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       const bool atRoot = lexId == 0u;
       const double hs = w.bScore[(f.cur) * P.K + h];
       n = (f.nTok == P.N) ? r : w.tokIdx[r];
-      const TrieEdge ed = P.trieEdge[(size_t)lexId * P.N + n]; /* one 16-byte gather */
+      TrieEdge ed; /* one 16-byte gather, issued a round ahead */
+      ed.child = (int32_t)edNow.x;
+      ed.childMax = __uint_as_float(edNow.y);
+      ed.label0 = (int32_t)edNow.z;
+      ed.meta = edNow.w;
       if (ed.child >= 0) {
         childId = (uint32_t)ed.child;
         lexMax = w.bLexMax[(f.cur) * P.K + h]; /* :58-59 */
@@ -1244,28 +1271,63 @@ FLTX_DEV void genLexiconSelected(const DecodeParams& P, const Ws& w, const Frame
   const int W = (int)blockDim.x;
   const int per = f.nTok + 2;
   const bool ctc = P.criterion == 1;
-  const int rounds = (nSlim + W - 1) / W;
+  const int lane = laneId();
+  /* compact the indices of the records that make the cut (wave-aggregated
+   * append into lead[]), so that rebuilding them takes ceil(#kept / W) rounds
+   * of trie gathers, not ceil(nSlim / W) */
+  {
+    const int rounds = (nSlim + W - 1) / W;
+    for (int it = 0; it < rounds; ++it) {
+      const int i = it * W + (int)threadIdx.x;
+      bool on = i < nSlim;
+      if (on) {
+        const double sc = w.zScore[i];
+        on = sc >= thr;
+        if (on) {
+          const double x = (best - sc) * scale;
+          int bin = (x < (double)P.NB) ? (int)x : P.NB - 1;
+          bin = bin < 0 ? 0 : bin;
+          if (bin > bM) { /* a candidate that would pass the threshold is left out: noted for the check */
+            on = false;
+            w.sc[SC_CUT] = 1;
+          }
+        }
+      }
+      const unsigned long long m = waveBallot(on);
+      if (m != 0ull) {
+        const int leader = __builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == leader) {
+          base = atomAdd32((uint32_t*)&w.sc[SC_NSMALL], (uint32_t)popc64(m));
+        }
+        base = waveShfl32(base, leader);
+        if (on) {
+          const uint32_t pos = base + (uint32_t)popc64(m & ((1ull << lane) - 1ull));
+          if (pos < (uint32_t)P.CAP) {
+            w.lead[pos] = (uint32_t)i;
+          } else {
+            atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_CAND_OVERFLOW);
+          }
+        }
+      }
+    }
+  }
+  wsBarrier(P);
+  int nSel = w.sc[SC_NSMALL];
+  nSel = nSel > P.CAP ? P.CAP : nSel;
+  const int rounds = (nSel + W - 1) / W;
   unsigned long long dummy = 0ull;
   for (int it = 0; it < rounds; ++it) {
     const int i = it * W + (int)threadIdx.x;
-    bool on = i < nSlim;
+    const bool on = i < nSel;
     double sc = 0;
     uint32_t ord = 0, kp = 0, ke = 0, klex = 0, ktp = 0, src = 0;
     int32_t aux = -1;
     float l = 0.0f;
     if (on) {
-      sc = w.zScore[i];
-      ord = w.zOrd[i];
-      on = sc >= thr;
-      if (on) {
-        const double x = (best - sc) * scale;
-        int bin = (x < (double)P.NB) ? (int)x : P.NB - 1;
-        bin = bin < 0 ? 0 : bin;
-        if (bin > bM) { /* a candidate that would pass the threshold is left out: noted for the check */
-          on = false;
-          w.sc[SC_CUT] = 1;
-        }
-      }
+      const uint32_t zi = w.lead[i];
+      sc = w.zScore[zi];
+      ord = w.zOrd[zi];
     }
     if (on) {
       const int item = (int)(ord >> 3), sub = (int)(ord & 7u);
@@ -1935,6 +1997,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
     w.sc[SC_NCAND] = 0;
     w.sc[SC_NLEAD] = 0;
     w.sc[SC_NSLIM] = 0;
+    w.sc[SC_NSMALL] = 0;
     w.sc[SC_CUT] = 0;
     w.sc[SC_BM] = P.NB - 1;
     w.red[2] = 0ull;

@@ -25,7 +25,7 @@ def main():
     c = cases.BY_NAME[name]
     s = helpers.FltxSession(None)
     inp = helpers.case_inputs(c)
-    d = s.decoder(c, inp)
+    d = s.decoder(c, inp, int(os.environ["FLTX_THREADS"]) if os.environ.get("FLTX_THREADS") else None)
     lex = inp.get("lex") if c["dist"] == "lexspell" else None
     e = synth.batch(c["dist"], B, c["T"], c["N"], lexicon=lex, u0=0)
     Ts = np.full(B, c["T"], dtype=np.int32)
@@ -37,6 +37,14 @@ def main():
         s.ctx.synchronize()
         ms.append((time.perf_counter() - t0) * 1e3)
     k, b = d.timing()
+    if os.environ.get("FLTX_PROFILE"):
+        d.set("profile", 1)
+        d.decode_batch(e, Ts, c["N"])
+        s.ctx.synchronize()
+        pr = d.profile().astype(np.float64) / (B * c["T"])
+        print("  clocks/frame/utt by phase [prep, generate, fold, select, build, row, -, -]:",
+              " ".join("%.0f" % v for v in pr), "total %.0f" % pr.sum())
+        d.set("profile", 0)
     print("%s batch=%d T=%d K=%d: engine %d threads %d, decode kernel %.2f ms, backtrace %.2f ms, "
           "wall/batch %.2f ms (incl. H2D), %.2f M frames/s (kernel)" %
           (name, B, c["T"], c["K"], d.get("engine"), d.get("threads"), k, b, min(ms), B * c["T"] / k / 1e3))
