@@ -44,7 +44,10 @@ template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gws(DecodeParams P) {
   decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
 }
-__global__ void fltx_backtrace_kernel(BacktraceParams P) { backtraceUtterance(P); }
+__global__ void __launch_bounds__(256) fltx_backtrace_kernel(BacktraceParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_bt_smem[];
+  backtraceUtterance(P, fltx_bt_smem);
+}
 __global__ void fltx_streamop_kernel(StreamOpParams Q) {
   __shared__ int32_t sh[4];
   streamOpUtterance(Q, sh);
@@ -1339,11 +1342,26 @@ int launchBacktrace(fltx_decoder* d) {
   Q.tokens = d->tokens.as<int32_t>();
   Q.words = d->kind == FLTX_DECODER_LEXICON ? d->words.as<int32_t>() : nullptr;
   Q.nbest = 0;
+  /* frames per LDS chunk: records in ({parent, token} 8 B, word 4 B) + token and word tiles out */
+#ifdef FLTX_EMU
+  const int btThreads = 64;
+#else
+  const int btThreads = 256;
+#endif
+  const size_t perFrame = (size_t)Q.K * (8 + (d->kind == FLTX_DECODER_LEXICON ? 4 : 0) + 8);
+  int F = (int)std::min<size_t>((size_t)96 * 1024 / perFrame, 512);
+  if (F < 8 || Q.K > 4 * btThreads) {
+    F = 0;
+  }
+  Q.F = F;
+  const size_t btLds = F > 0 ? (size_t)F * perFrame + 16 : 16;
 #ifdef FLTX_EMU
   const BacktraceParams* qq = &Q;
-  emuLaunch(d->B, 64, 16, [qq](char*) { backtraceUtterance(*qq); });
+  emuLaunch(d->B, btThreads, btLds, [qq](char* smem) { backtraceUtterance(*qq, smem); });
 #else
-  hipLaunchKernelGGL(fltx_backtrace_kernel, dim3(d->B), dim3(64), 0, st, Q);
+  HIPCHK(hipFuncSetAttribute((const void*)fltx_backtrace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)btLds));
+  hipLaunchKernelGGL(fltx_backtrace_kernel, dim3(d->B), dim3(btThreads), btLds, st, Q);
   HIPCHK(hipGetLastError());
   if (d->ev[2]) {
     HIPCHK(hipEventRecord(d->ev[2], st));

@@ -2411,38 +2411,101 @@ struct BacktraceParams {
   int32_t* tokens;
   int32_t* words;
   int32_t nbest;           /* <= 0: all */
+  int32_t F;               /* frames per LDS chunk (0: walk straight through HBM) */
 };
 
-FLTX_DEV void backtraceUtterance(const BacktraceParams& P) {
+/* A parent-pointer walk is a chain of T dependent loads; straight from HBM that
+ * is T x ~1 us per hypothesis and the token rows come out as strided 4-byte
+ * stores.  Instead the history is taken F frames at a time, newest first: the
+ * chunk's {parent, token} (and word) records are copied to LDS with coalesced
+ * loads, every hypothesis walks its F steps there (~100 clocks each), drops its
+ * tokens into an LDS tile, and the tile leaves as row-contiguous stores. */
+FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
   const int b = (int)blockIdx.x;
+  const int W = (int)blockDim.x, tid = (int)threadIdx.x;
   const int ff = P.uttFrame[b];
   int nh = P.uttNBeam[b];
   if (P.nbest > 0 && nh > P.nbest) {
     nh = P.nbest;
   }
   const int len = ff + 1;
-  for (int k = (int)threadIdx.x; k < nh; k += (int)blockDim.x) {
-    int slot = k;
-    int32_t* tk = P.tokens + P.tokOff[b] + (int64_t)k * len;
-    int32_t* wd = P.words ? P.words + P.tokOff[b] + (int64_t)k * len : nullptr;
-    for (int fr = ff; fr >= 0; --fr) {
-      const int64_t idx = P.histOff[b] + (int64_t)fr * P.K + slot;
-      const int2 pt = P.histPT[idx];
-      tk[fr] = pt.y;
-      if (wd) {
-        wd[fr] = P.kind == 1 ? P.histW[idx] : -1;
-      }
-      slot = pt.x;
-      if (slot < 0) {
-        for (int q = fr - 1; q >= 0; --q) { /* pruned history: leave -1 */
-          tk[q] = -1;
-          if (wd) {
-            wd[q] = -1;
-          }
+  const int K = P.K;
+  const bool lex = P.kind == 1;
+  const int64_t hb = P.histOff[b], ob = P.tokOff[b];
+  if (P.F <= 0) { /* beam too large for a useful chunk: one thread per hypothesis through HBM */
+    for (int k = tid; k < nh; k += W) {
+      int slot = k;
+      int32_t* tk = P.tokens + ob + (int64_t)k * len;
+      int32_t* wd = P.words ? P.words + ob + (int64_t)k * len : nullptr;
+      for (int fr = ff; fr >= 0; --fr) {
+        int tokv = -1, wv = -1;
+        if (slot >= 0) {
+          const int64_t idx = hb + (int64_t)fr * K + slot;
+          const int2 pt = P.histPT[idx];
+          tokv = pt.y;
+          wv = lex ? P.histW[idx] : -1;
+          slot = pt.x;
         }
-        break;
+        tk[fr] = tokv; /* pruned history: -1 below the cut */
+        if (wd) {
+          wd[fr] = wv;
+        }
       }
     }
+    return;
+  }
+  const int F = P.F;
+  int2* cPT = (int2*)smem;                                  /* [F][K] */
+  int32_t* cW = (int32_t*)(cPT + (size_t)F * K);            /* [F][K] (lexicon decoder) */
+  int32_t* oT = cW + (lex ? (size_t)F * K : 0);             /* [nh][F] */
+  int32_t* oW = oT + (size_t)F * K;                         /* [nh][F] */
+  int slot[4]; /* hypotheses tid, tid + W, ... (nh <= 4 W is checked by the host) */
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    slot[q] = tid + q * W;
+  }
+  for (int hi = ff; hi >= 0; hi -= F) {
+    const int lo = hi - F + 1 > 0 ? hi - F + 1 : 0;
+    const int nf = hi - lo + 1;
+    const int64_t src = hb + (int64_t)lo * K;
+    for (int i = tid; i < nf * K; i += W) {
+      cPT[i] = P.histPT[src + i];
+      if (lex) {
+        cW[i] = P.histW[src + i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = tid + q * W;
+      if (k < nh) {
+        int s = slot[q];
+        for (int j = nf - 1; j >= 0; --j) {
+          int tokv = -1, wv = -1;
+          if (s >= 0) {
+            const int2 pt = cPT[j * K + s];
+            tokv = pt.y;
+            wv = lex ? cW[j * K + s] : -1;
+            s = pt.x;
+          }
+          oT[k * F + j] = tokv;
+          if (P.words) {
+            oW[k * F + j] = wv;
+          }
+        }
+        slot[q] = s;
+      }
+    }
+    __syncthreads();
+    for (int k = tid >> 6; k < nh; k += W >> 6) { /* a wave per row: contiguous stores */
+      for (int j = tid & 63; j < nf; j += 64) {
+        P.tokens[ob + (int64_t)k * len + lo + j] = oT[k * F + j];
+        if (P.words) {
+          P.words[ob + (int64_t)k * len + lo + j] = oW[k * F + j];
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 /* ------------------------------------------------------------------------ */

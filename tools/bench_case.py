@@ -48,6 +48,35 @@ def main():
     print("%s batch=%d T=%d K=%d: engine %d threads %d, decode kernel %.2f ms, backtrace %.2f ms, "
           "wall/batch %.2f ms (incl. H2D), %.2f M frames/s (kernel)" %
           (name, B, c["T"], c["K"], d.get("engine"), d.get("threads"), k, b, min(ms), B * c["T"] / k / 1e3))
+    ncpu = int(os.environ.get("FLTX_CPU", "0"))
+    if ncpu > 0:  # reference (oracle/_ref) on the host, one thread, same utterances; n-best compared
+        from oracle import orclib
+        lib = orclib.load("ref" if orclib.have_ref() else "oracle")
+        opt = orclib.make_options(c["K"], c["Kt"], c["thr"], c["lm_weight"], c["word_score"], c["unk_score"],
+                                  c["sil_score"], c["log_add"], c["crit"])
+        N = c["N"]
+        blank = N - 1 if c["crit"] == "ctc" else -1
+        lm = helpers.checker_lm(lib, c, inp)
+        trie = None
+        if c["kind"] == "lexicon":
+            sf, so = inp["lex"]
+            scores = inp["scores"]
+            if c["lm"] != "zero" and not c["is_lm_token"]:
+                scores = helpers.checker_word_scores(lib, lm, inp["W"])
+            trie = lib.build_trie(N, 0, sf, so, inp["labels"], scores, smear=1)
+        tt, mism = 0.0, 0
+        for b in range(min(ncpu, B)):
+            dec = (lib.lexfree(opt, lm, 0, blank, inp["tr"]) if c["kind"] == "lexfree" else
+                   lib.lexicon(opt, trie, lm, 0, blank, inp["W"], inp["tr"], c["is_lm_token"]))
+            t0 = time.perf_counter()
+            hyps = lib.decode(dec, e[b], c["T"], N)
+            tt += time.perf_counter() - t0
+            lib.decoder_destroy(dec)
+            ok, _ = helpers.hyps_equal(d.results(b), hyps, 1e-5 if c["log_add"] else 0.0)
+            mism += 0 if ok else 1
+        n = min(ncpu, B)
+        print("  reference CPU, 1 thread: %.1f k frames/s over %d utterances (%.1f s); GPU n-best mismatches: %d; "
+              "GPU/CPU-thread = %.0fx" % (n * c["T"] / tt / 1e3, n, tt, mism, (B * c["T"] / k * 1e3) / (n * c["T"] / tt)))
     d.close()
 
 
