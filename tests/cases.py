@@ -35,6 +35,11 @@ CASES = [
     case("lf_asg_t30_n8", dist="uniform", T=30, N=8, K=6, crit="asg", trans_seed=11),
     case("lf_asg_t40_n29_kt7", dist="ctc", T=40, N=29, K=8, Kt=7, crit="asg", trans_seed=12, u=4),
     case("lf_ctc_n4", dist="uniform", T=25, N=4, K=5),
+    # wider token sets / beams at the limits of the lane-per-slot step (beam <= 64, <= 64 tokens)
+    case("lf_uni_n40_k20", dist="uniform", T=30, N=40, K=20, u=5),
+    case("lf_uni_n64_k64", dist="uniform", T=24, N=64, K=64, u=6),
+    case("lf_ctc_n29_k64", T=40, N=29, K=64, u=8),
+    case("lf_ctc_n29_k65", T=40, N=29, K=65, u=8),
     # ---- lexicon-free, BASELINE shapes --------------------------------------
     case("C1_ctc_u0", T=200, K=10, size="medium"),
     case("C1_uniform_u0", dist="uniform", T=200, K=10, size="medium"),

@@ -46,7 +46,13 @@ def perturb_heap(n):
 
 def synthetic(ref):
     out = {}
+    only = [x for x in os.environ.get("GOLDEN_ONLY", "").split(",") if x]
+    if only:  # add cases without touching the vectors already committed
+        with gzip.open(os.path.join(HERE, "synthetic_expected.json.gz"), "rt") as f:
+            out = json.load(f)
     for c in cases.CASES:
+        if only and c["name"] not in only:
+            continue
         inp = helpers.case_inputs(c)
         h1 = helpers.run_checker(ref, c, inp)
         keep = perturb_heap(33333)
@@ -157,4 +163,5 @@ if __name__ == "__main__":
     orclib.build("ref")
     ref_lib = orclib.load("ref")
     synthetic(ref_lib)
-    decodertest(ref_lib)
+    if not os.environ.get("GOLDEN_ONLY"):
+        decodertest(ref_lib)

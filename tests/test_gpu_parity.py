@@ -200,3 +200,22 @@ def test_lexicon_score_cut(gpu_session, golden, c, mode):
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], 0.0)
     d.close()
     assert ok, why
+
+
+@pytest.mark.parametrize("name,engine", [("lf_ctc_t60_k10", 3), ("lf_uni_n64_k64", 3), ("lf_ctc_n29_k64", 3),
+                                         ("lf_ctc_n29_k65", 2), ("lf_ctc_t60_k10_logadd", 2),
+                                         ("lf_ctc_t60_k10_kt5", 2)])
+def test_engine_selection(gpu_session, golden, name, engine):
+    """Which frame step serves which configuration: lane-per-slot (3) for
+    lexicon-free + ZeroLM max-merge with beam <= 64 over the full token set,
+    the lean step (2) beyond that, for logAdd and for a token short-list."""
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    d = gpu_session.decoder(c, inp)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    got = d.get("engine")
+    tol = 1e-5 if c["log_add"] else 0.0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
+    d.close()
+    assert got == engine
+    assert ok, why
