@@ -201,7 +201,7 @@ struct fltx_trie {
   fltx_ctx* ctx = nullptr;
   int64_t nNodes = 0;
   int32_t nTokens = 0;
-  DBuf edge, labels;
+  DBuf edge, labels, mask;
 };
 
 struct fltx_decoder {
@@ -230,6 +230,7 @@ struct fltx_decoder {
   int CAP = 0, HS = 0, NB = 0, SCAP = 0, dense = 0, noDense = 0;
   int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
+  int itemCap = 0, noItems = 0; /* lexicon decoder: list of existing (hypothesis, token) children */
   int CAP2 = 0, cutM = 0, noCut = 0, userCutM = 0; /* lexicon decoder: slim score-pass list + cut-off (runFrame) */
   size_t wsBytes = 0;
   bool wsInLds = true;
@@ -704,12 +705,31 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
       edge[(size_t)i * nTokens + t] = e;
     }
   }
+  /* per node: which tokens have a child (the generic engine lists only those) */
+  std::vector<unsigned long long> cmask;
+  if (nTokens <= 64) {
+    cmask.assign((size_t)nNodes, 0ull);
+    for (int64_t i = 0; i < nNodes; ++i) {
+      for (int t = 0; t < nTokens; ++t) {
+        if (child[i * nTokens + t] >= 0) {
+          cmask[(size_t)i] |= 1ull << t;
+        }
+      }
+    }
+  }
   auto* t = new fltx_trie();
   t->ctx = ctx;
   t->nNodes = nNodes;
   t->nTokens = nTokens;
   Stream st = ctx->stream;
   size_t nLab = (size_t)labelOff[nNodes];
+  if (!cmask.empty()) {
+    if (t->mask.ensure(8 * cmask.size(), st, false) ||
+        devCopyH2D(t->mask.p, cmask.data(), 8 * cmask.size(), st)) {
+      delete t;
+      return fail(FLTX_ERR_OOM, "trie: child-mask upload failed");
+    }
+  }
   if (t->edge.ensure(sizeof(TrieEdge) * edge.size(), st, false) ||
       t->labels.ensure(sizeof(int32_t) * std::max<size_t>(1, nLab), st, false)) {
     delete t;
@@ -866,6 +886,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noLean = value == 0;
     return FLTX_OK;
   }
+  if (!strcmp(key, "items")) { /* 0: the lexicon decoder walks the full hypothesis x token grid */
+    d->noItems = value ? 0 : 1;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "cut_m")) { /* testing: number of best candidates kept by the cut (default 2K + 64) */
     d->userCutM = (int)value;
     return FLTX_OK;
@@ -979,8 +1003,15 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     int64_t keys = d->dense ? K : c;
     return std::max((int)nextPow2((uint64_t)keys * 2), 64);
   };
+  /* lexicon decoder: generate from a list of the (hypothesis, token) pairs that
+   * have a child in the trie when the full grid would take several rounds */
+  d->itemCap = 0;
+  if (d->kind == FLTX_DECODER_LEXICON && !d->noItems && !d->forceGlobalWs && N <= 64 && d->trie &&
+      d->trie->mask.p && (int64_t)K * nTok > d->threads && (int64_t)K * nTok <= (1 << 20)) {
+    d->itemCap = K * nTok;
+  }
   auto bytesFor = [&](int64_t c) {
-    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->lane);
+    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->lane, 0, d->itemCap);
   };
   bool lds = !d->forceGlobalWs;
   d->CAP2 = 0;
@@ -1007,7 +1038,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         const int64_t M = d->userCutM > 0 ? std::max<int64_t>(d->userCutM, K) : 2 * (int64_t)K + 64;
         const int64_t capRec = std::max<int64_t>(2 * M, 512);
         auto bytesCut = [&](int64_t c2) {
-          return carveWs(tmp, nullptr, K, (int)capRec, hsFor(capRec), d->NB, N, d->SCAP, d->dense, d->lane, (int)c2);
+          return carveWs(tmp, nullptr, K, (int)capRec, hsFor(capRec), d->NB, N, d->SCAP, d->dense, d->lane, (int)c2,
+                         d->itemCap);
         };
         int64_t c2 = std::min<int64_t>(worst, 16384);
         while (c2 > 4 * M && bytesCut(c2) > kMaxLds) {
@@ -1036,7 +1068,10 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (!lds) {
     d->lane = 0;
   }
-  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2);
+  if (!lds) {
+    d->itemCap = 0;
+  }
+  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap);
   d->wsInLds = lds;
   /* buffers */
   bool grewTab = false;
@@ -1114,6 +1149,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.transitions = d->nTrans ? d->transitions.as<float>() : nullptr;
   if (d->trie) {
     P.trieEdge = d->trie->edge.as<TrieEdge>();
+    P.trieMask = d->trie->mask.p ? d->trie->mask.as<unsigned long long>() : nullptr;
+    P.itemCap = P.trieMask ? d->itemCap : 0;
     P.trieLabels = d->trie->labels.as<int32_t>();
   }
   P.lmKind = d->lm->kind;

@@ -102,6 +102,8 @@ struct DecodeParams {
   /* flat trie */
   const TrieEdge* trieEdge; /* [nNodes*N] */
   const int32_t* trieLabels;
+  const unsigned long long* trieMask; /* [nNodes] bit n set <=> the node has a child for token n (N <= 64), or null */
+  int32_t itemCap;                    /* capacity of the (hypothesis, token) item list = K * min(Kt, N), 0 = unused */
   /* LM */
   int32_t lmKind; /* 0 ZeroLM, 1 n-gram */
   int32_t lmOrder;
@@ -191,6 +193,9 @@ struct Ws {
   float* cLm;      /* LM score delta (float, as the reference holds it) */
   uint32_t* cOrd;  /* deterministic generation order (tie-break) */
   uint32_t* cNext; /* hash chain */
+  unsigned long long* bLexMask; /* [K] child-token mask of the slot's trie node (this frame) */
+  uint32_t* itemList; /* [itemCap] existing (hypothesis << 8 | token) children of the beam's trie nodes */
+  uint8_t* tokPos;    /* [N] position of a token in this frame's short-list */
   double* zScore;  /* [CAP2] score pass of the lexicon decoder: candidate score ... */
   uint32_t* zOrd;  /* [CAP2] ... and generation order = (item, sub-candidate), enough to rebuild it */
   uint32_t* head;  /* [HS] */
@@ -281,7 +286,7 @@ struct LaneLds {
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
-                       int dense, int lane, int CAP2 = 0) {
+                       int dense, int lane, int CAP2 = 0, int itemCap = 0) {
   size_t off = 0;
   LaneLds* const LL = (lane && base) ? (LaneLds*)base : nullptr;
   if (lane) {
@@ -315,6 +320,9 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.cLm, float, CAP)
   FLTX_CARVE(w.cOrd, uint32_t, CAP)
   FLTX_CARVE(w.cNext, uint32_t, CAP)
+  FLTX_CARVE(w.bLexMask, unsigned long long, itemCap ? K : 0)
+  FLTX_CARVE(w.itemList, uint32_t, itemCap)
+  FLTX_CARVE(w.tokPos, uint8_t, itemCap ? N : 0)
   FLTX_CARVE(w.zScore, double, CAP2)
   FLTX_CARVE(w.zOrd, uint32_t, CAP2)
   FLTX_CARVE(w.head, uint32_t, HS)
@@ -1054,10 +1062,13 @@ FLTX_DEV void denseLeaders(const DecodeParams& P, const Ws& w, const FrameCtx& f
  * child, r == nTok is "same node" (2), r == nTok+1 is CTC blank (3). */
 template <bool SLIM>
 FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
-                         unsigned long long& bestKey, double preThr) {
+                         unsigned long long& bestKey, double preThr, int nItems) {
   const int per = f.nTok + 2;
-  const int total = f.nBeam * f.nTok; /* (hypothesis, token) items; the 2 stay / blank items per
-                                         hypothesis ride along in the first round */
+  /* (hypothesis, token) items: the nItems existing children listed in itemList
+   * (nItems >= 0), or the full nBeam x nTok grid; the 2 stay / blank items per
+   * hypothesis ride along in the first round(s) */
+  const bool listed = nItems >= 0;
+  const int total = listed ? nItems : f.nBeam * f.nTok;
   const int W = (int)blockDim.x;
   const bool ctc = P.criterion == 1;
   const bool hasUnk = P.unkScore > -__builtin_huge_val();
@@ -1071,9 +1082,16 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
   {
     const int i0 = (int)threadIdx.x;
     if (i0 < total) {
-      const int h0 = i0 / f.nTok;
-      const int r0 = i0 - h0 * f.nTok;
-      const int n0 = (f.nTok == P.N) ? r0 : w.tokIdx[r0];
+      int h0, n0;
+      if (listed) {
+        const uint32_t code = w.itemList[i0];
+        h0 = (int)(code >> 8);
+        n0 = (int)(code & 0xFFu);
+      } else {
+        h0 = i0 / f.nTok;
+        const int r0 = i0 - h0 * f.nTok;
+        n0 = (f.nTok == P.N) ? r0 : w.tokIdx[r0];
+      }
       edPre = ((const uint4*)P.trieEdge)[(size_t)w.bLex[(f.cur) * P.K + h0] * P.N + n0];
     }
   }
@@ -1084,9 +1102,16 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     {
       const int i1 = i + W;
       if (i1 < total) {
-        const int h1 = i1 / f.nTok;
-        const int r1 = i1 - h1 * f.nTok;
-        const int n1 = (f.nTok == P.N) ? r1 : w.tokIdx[r1];
+        int h1, n1;
+        if (listed) {
+          const uint32_t code = w.itemList[i1];
+          h1 = (int)(code >> 8);
+          n1 = (int)(code & 0xFFu);
+        } else {
+          h1 = i1 / f.nTok;
+          const int r1 = i1 - h1 * f.nTok;
+          n1 = (f.nTok == P.N) ? r1 : w.tokIdx[r1];
+        }
         edPre = ((const uint4*)P.trieEdge)[(size_t)w.bLex[(f.cur) * P.K + h1] * P.N + n1];
       }
     }
@@ -1103,8 +1128,17 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     int32_t sedge = 0;
     uint32_t ordI = 0;
     if (valid) { /* (1) children, :62-165 */
-      h = i / f.nTok;
-      const int r = i - h * f.nTok;
+      int r;
+      if (listed) {
+        const uint32_t code = w.itemList[i];
+        h = (int)(code >> 8);
+        n = (int)(code & 0xFFu);
+        r = (f.nTok == P.N) ? n : (int)w.tokPos[n];
+      } else {
+        h = i / f.nTok;
+        r = i - h * f.nTok;
+        n = (f.nTok == P.N) ? r : w.tokIdx[r];
+      }
       ordI = (uint32_t)(h * per + r);
       const uint32_t tp = w.bTokPb[(f.cur) * P.K + h];
       const int prevTok = (int)(tp & 0x7FFFFFFFu);
@@ -1115,7 +1149,6 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       sedge = w.bSEdge[(f.cur) * P.K + h];
       const bool atRoot = lexId == 0u;
       const double hs = w.bScore[(f.cur) * P.K + h];
-      n = (f.nTok == P.N) ? r : w.tokIdx[r];
       TrieEdge ed; /* one 16-byte gather, issued a round ahead */
       ed.child = (int32_t)edNow.x;
       ed.childMax = __uint_as_float(edNow.y);
@@ -1970,6 +2003,10 @@ FLTX_DEV void tokenShortlist(const DecodeParams& P, const Ws& w, const float* e,
       const int rank = popc64(beat);
       if (m == 0 && rank < nTok) {
         w.tokIdx[rank] = n;
+        if (P.itemCap) {
+          w.tokPos[n] = (uint8_t)rank;
+          atomOr64(&w.red[3], 1ull << n);
+        }
       }
     }
     return;
@@ -2010,6 +2047,12 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   if (!isEnd && f.nTok < P.N) {
     tokenShortlist(P, w, f.e, f.nTok);
   }
+  const bool listItems = !isEnd && P.kind == 1 && P.itemCap > 0;
+  if (listItems) { /* which tokens lead anywhere from each slot's trie node (one 8-byte load per slot) */
+    for (int h = tid; h < f.nBeam; h += W) {
+      w.bLexMask[h] = P.trieMask[w.bLex[f.cur * P.K + h]];
+    }
+  }
   wsBarrier(P);
   FLTX_PROF(0);
   const bool dense = !isEnd && P.kind == 0 && P.dense != 0;
@@ -2045,10 +2088,40 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
       }
     }
     const double preThr = lb == lb ? lb - P.beamThreshold : -__builtin_huge_val();
+    int nItems = -1;
+    if (listItems) {
+      /* A trie node has a child for few of the tokens: list the (hypothesis,
+       * token) pairs that exist (bit masks, one prefix sum) and generate from
+       * the list -- a round of W items then carries W real candidates' worth of
+       * work instead of mostly empty edges. */
+      const unsigned long long tokMask =
+          f.nTok == P.N ? (P.N >= 64 ? ~0ull : ((1ull << P.N) - 1ull)) : w.red[3];
+      int run = 0;
+      for (int base = 0; base < f.nBeam; base += W) {
+        const int h = base + tid;
+        unsigned long long m = h < f.nBeam ? (w.bLexMask[h] & tokMask) : 0ull;
+        int tot = 0;
+        int pos = run + blockExclusiveScan(P, popc64(m), w.wtmp, &tot);
+        while (m != 0ull) { /* slot h lists its own children: a few stores per thread */
+          const int n = __builtin_ctzll(m);
+          m &= m - 1ull;
+          if (pos < P.itemCap) {
+            w.itemList[pos] = ((uint32_t)h << 8) | (uint32_t)n;
+          }
+          ++pos;
+        }
+        run += tot;
+      }
+      wsBarrier(P);
+      nItems = run > P.itemCap ? P.itemCap : run;
+      if (tid == 0) {
+        w.red[3] = 0ull; /* next frame's short-list mask starts empty */
+      }
+    }
     if (P.CAP2 > 0) {
-      genLexicon<true>(P, w, f, bestKey, preThr);
+      genLexicon<true>(P, w, f, bestKey, preThr, nItems);
     } else {
-      genLexicon<false>(P, w, f, bestKey, preThr);
+      genLexicon<false>(P, w, f, bestKey, preThr, nItems);
     }
   }
   bestKey = waveMax64(bestKey);
@@ -2153,7 +2226,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
-  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane, P.CAP2);
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane, P.CAP2, P.itemCap);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {
@@ -2162,6 +2235,9 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   if constexpr (GT == 0) { /* the merge hash starts empty; foldGroups keeps it so */
     for (int i = tid; i < P.HS; i += W) {
       w.head[i] = kEmpty;
+    }
+    if (tid == 0) {
+      w.red[3] = 0ull;
     }
   }
   if (P.doBegin) {
