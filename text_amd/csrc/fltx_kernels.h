@@ -1060,14 +1060,14 @@ FLTX_DEV void denseLeaders(const DecodeParams& P, const Ws& w, const FrameCtx& f
 /* LexiconDecoder::decodeStep inner loops (LexiconDecoder.cpp:55-215).  Work
  * item = (hypothesis, r): r < nTok tries the r-th short-listed token as a trie
  * child, r == nTok is "same node" (2), r == nTok+1 is CTC blank (3). */
-template <bool SLIM>
+template <bool SLIM, bool LISTED>
 FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
                          unsigned long long& bestKey, double preThr, int nItems) {
   const int per = f.nTok + 2;
   /* (hypothesis, token) items: the nItems existing children listed in itemList
    * (nItems >= 0), or the full nBeam x nTok grid; the 2 stay / blank items per
    * hypothesis ride along in the first round(s) */
-  const bool listed = nItems >= 0;
+  constexpr bool listed = LISTED;
   const int total = listed ? nItems : f.nBeam * f.nTok;
   const int W = (int)blockDim.x;
   const bool ctc = P.criterion == 1;
@@ -2119,9 +2119,15 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
       }
     }
     if (P.CAP2 > 0) {
-      genLexicon<true>(P, w, f, bestKey, preThr, nItems);
+      if (listItems) {
+        genLexicon<true, true>(P, w, f, bestKey, preThr, nItems);
+      } else {
+        genLexicon<true, false>(P, w, f, bestKey, preThr, nItems);
+      }
+    } else if (listItems) {
+      genLexicon<false, true>(P, w, f, bestKey, preThr, nItems);
     } else {
-      genLexicon<false>(P, w, f, bestKey, preThr, nItems);
+      genLexicon<false, false>(P, w, f, bestKey, preThr, nItems);
     }
   }
   bestKey = waveMax64(bestKey);
