@@ -607,58 +607,95 @@ FLTX_DEV bool ngFind(const DecodeParams& P, uint32_t ctx, uint32_t word, uint32_
 /* ctxIn[j] = node id of the suffix n-gram made of the last j+1 context words
  * (0 = absent), j < order-1.  Returns log10 p(word | context) summed in float:
  * longest match first, then the back-off weights of the skipped contexts from
- * the shortest to the longest (KenLM FullScore order, see oracle/arpa_lm.h). */
+ * the shortest to the longest (KenLM FullScore order, see oracle/arpa_lm.h).
+ *
+ * The look-ups for the different context lengths do not depend on each other,
+ * only the choice among their results does: all first probes and all back-off
+ * weights are loaded at once (one HBM/L2 round trip instead of up to
+ * 2 * order dependent ones), and everything is indexed statically so that it
+ * stays in registers (a dynamically indexed local array lives in scratch
+ * memory). */
 FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t word,
                        int32_t* ctxOut) {
   const int L = P.lmOrder - 1;
+  uint32_t c[kMaxNgramOrder];     /* context node for k context words (k = 0: none) */
+  uint32_t slot[kMaxNgramOrder];
+  NgramSlot e[kMaxNgramOrder];
+  float bo[kMaxNgramOrder];
+  bool act[kMaxNgramOrder];
+#pragma unroll
+  for (int k = 0; k < kMaxNgramOrder; ++k) {
+    c[k] = (k >= 1 && k <= L) ? (uint32_t)ctxIn[k - 1] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxNgramOrder; ++k) {
+    /* k context words; a suffix of the context that is not an n-gram of the model is skipped */
+    act[k] = k <= L && (k == 0 || c[k] != 0u);
+    slot[k] = hashKey(c[k], word, 0x5bd1e995u, 0) & P.ngMask;
+    e[k].ctx = 0u;
+    e[k].word = kEmpty;
+    e[k].node = 0u;
+    e[k].prob = 0.0f;
+    bo[k] = 0.0f;
+    if (act[k]) {
+      e[k] = P.ngTab[slot[k]];
+    }
+    if (k >= 1 && k <= L && c[k] != 0u) {
+      bo[k] = P.ngBackoff[c[k]];
+    }
+  }
   uint32_t nodes[kMaxNgramOrder];
-  float probs[kMaxNgramOrder];
   bool found[kMaxNgramOrder];
-  /* k = number of context words used; context node for k == 0 is 0 */
   int longest = -1;
-  for (int k = 0; k <= L; ++k) {
+  float prob = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kMaxNgramOrder; ++k) {
     found[k] = false;
-    nodes[k] = 0;
-    probs[k] = 0.0f;
-  }
-  for (int k = 0; k <= L; ++k) {
-    const uint32_t c = (k == 0) ? 0u : (uint32_t)ctxIn[k - 1];
-    if (k > 0 && c == 0u) {
-      continue; /* this suffix of the context is not an n-gram of the model */
-    }
-    if (ngFind(P, c, word, nodes[k], probs[k])) {
-      found[k] = true;
-      if (!(nodes[k] & kPhantomNode)) {
-        longest = k;
+    nodes[k] = 0u;
+    if (act[k]) {
+      for (;;) { /* open addressing: the first probe almost always decides */
+        if (e[k].word == kEmpty) {
+          break;
+        }
+        if (e[k].ctx == c[k] && e[k].word == word) {
+          found[k] = true;
+          break;
+        }
+        slot[k] = (slot[k] + 1) & P.ngMask;
+        e[k] = P.ngTab[slot[k]];
       }
-      nodes[k] &= ~kPhantomNode;
+      if (found[k]) {
+        if (!(e[k].node & kPhantomNode)) {
+          longest = k;
+          prob = e[k].prob;
+        }
+        nodes[k] = e[k].node & ~kPhantomNode;
+      }
     }
   }
-  float prob;
-  uint32_t w = word;
   if (longest < 0) { /* not even a unigram: score <unk> */
-    w = (uint32_t)P.lmUnk;
     uint32_t n0;
-    if (!ngFind(P, 0u, w, n0, prob)) {
+    if (!ngFind(P, 0u, (uint32_t)P.lmUnk, n0, prob)) {
       prob = -100.0f;
       n0 = 0;
     }
     nodes[0] = n0;
     found[0] = true;
     longest = 0;
-  } else {
-    prob = probs[longest];
   }
-  for (int j = longest + 1; j <= L; ++j) {
-    const uint32_t c = (uint32_t)ctxIn[j - 1];
-    if (c != 0u) {
-      prob += P.ngBackoff[c];
+#pragma unroll
+  for (int j = 1; j < kMaxNgramOrder; ++j) {
+    if (j > longest && j <= L && c[j] != 0u) {
+      prob += bo[j];
     }
   }
   if (ctxOut) {
-    for (int j = 0; j < L; ++j) {
-      /* suffix of length j+1 of (context, word) = n-gram (last j ctx words, word) */
-      ctxOut[j] = (j <= longest && found[j]) ? (int32_t)nodes[j] : 0;
+#pragma unroll
+    for (int j = 0; j < kMaxNgramOrder - 1; ++j) {
+      if (j < L) {
+        /* suffix of length j+1 of (context, word) = n-gram (last j ctx words, word) */
+        ctxOut[j] = (j <= longest && found[j]) ? (int32_t)nodes[j] : 0;
+      }
     }
   }
   return prob;
@@ -1951,11 +1988,7 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
         } else {
           word = (edge >= 0 && edge < P.nUsr) ? (uint32_t)P.usrToLm[edge] : (uint32_t)P.lmUnk;
         }
-        int32_t tmp[kMaxNgramOrder];
-        ngScore(P, cin, word, tmp);
-        for (int q = 0; q < L; ++q) {
-          cout[q] = tmp[q];
-        }
+        ngScore(P, cin, word, cout); /* reads its whole input context before it writes */
       }
     } else {
       sid = w.bState[(f.cur) * P.K + h];
