@@ -198,6 +198,7 @@ struct Ws {
   uint8_t* tokPos;    /* [N] position of a token in this frame's short-list */
   double* zScore;  /* [CAP2] score pass of the lexicon decoder: candidate score ... */
   uint32_t* zOrd;  /* [CAP2] ... and generation order = (item, sub-candidate), enough to rebuild it */
+  float* zLm;      /* [CAP2] ... and its LM score delta, so that the rebuild does not score it again */
   uint32_t* head;  /* [HS] */
   uint32_t* lead;  /* group leaders (candidate index), later survivors */
   uint8_t* lstat;  /* per leader: 0 dropped, 1 active, 2 taken */
@@ -325,6 +326,7 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.tokPos, uint8_t, itemCap ? N : 0)
   FLTX_CARVE(w.zScore, double, CAP2)
   FLTX_CARVE(w.zOrd, uint32_t, CAP2)
+  FLTX_CARVE(w.zLm, float, CAP2)
   FLTX_CARVE(w.head, uint32_t, HS)
   FLTX_CARVE(w.lead, uint32_t, CAP)
   FLTX_CARVE(w.lstat, uint8_t, CAP)
@@ -556,7 +558,7 @@ FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
 /* Score pass of the lexicon decoder: remember only the score and the
  * generation order of a candidate (the order encodes hypothesis, token and
  * which of the item's candidates it is, so the full record can be rebuilt). */
-FLTX_DEV void pushSlim(const DecodeParams& P, const Ws& w, bool valid, double score, uint32_t ord,
+FLTX_DEV void pushSlim(const DecodeParams& P, const Ws& w, bool valid, double score, uint32_t ord, float lm,
                        unsigned long long& bestKey, double preThr) {
   valid = valid && (score >= preThr);
   const unsigned long long m = waveBallot(valid);
@@ -582,6 +584,7 @@ FLTX_DEV void pushSlim(const DecodeParams& P, const Ws& w, bool valid, double sc
   bestKey = sk > bestKey ? sk : bestKey;
   w.zScore[ci] = score;
   w.zOrd[ci] = ord;
+  w.zLm[ci] = lm;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1263,7 +1266,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       uint32_t ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
       uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u) | kExtend;
       if constexpr (SLIM) {
-        pushSlim(P, w, cExt, sc, ordBase, bestKey, preThr);
+        pushSlim(P, w, cExt, sc, ordBase, l, bestKey, preThr);
       } else {
         pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, (int32_t)__float_as_uint(childMax), l,
                       ordBase, bestKey, preThr);
@@ -1293,7 +1296,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
         sc = base + P.lmWeight * (double)l + P.wordScore;
       }
       if constexpr (SLIM) {
-        pushSlim(P, w, on, sc, ordBase + 1 + (uint32_t)j, bestKey, preThr);
+        pushSlim(P, w, on, sc, ordBase + 1 + (uint32_t)j, l, bestKey, preThr);
       } else {
         pushCandidate(P, w, on, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, label, l,
                       ordBase + 1 + (uint32_t)j, bestKey, preThr);
@@ -1313,7 +1316,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       }
       double sc = base + P.lmWeight * (double)l + P.unkScore;
       if constexpr (SLIM) {
-        pushSlim(P, w, cUnk, sc, ordBase + 7, bestKey, preThr);
+        pushSlim(P, w, cUnk, sc, ordBase + 7, l, bestKey, preThr);
       } else {
         pushCandidate(P, w, cUnk, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, P.unk, l,
                       ordBase + 7, bestKey, preThr);
@@ -1321,7 +1324,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     }
     /* (2)/(3) stay / blank keep state and node */
     if constexpr (SLIM) {
-      pushSlim(P, w, cStay, baseS, ordS << 3, bestKey, preThr);
+      pushSlim(P, w, cStay, baseS, ordS << 3, 0.0f, bestKey, preThr);
     } else {
       pushCandidate(P, w, cStay, baseS, sparS, (uint32_t)sedgeS, lexS,
                     (uint32_t)nS | (stayBlank ? kPrevBlank : 0u), (uint32_t)hS, -1, 0.0f, ordS << 3,
@@ -1398,6 +1401,7 @@ FLTX_DEV void genLexiconSelected(const DecodeParams& P, const Ws& w, const Frame
       const uint32_t zi = w.lead[i];
       sc = w.zScore[zi];
       ord = w.zOrd[zi];
+      l = w.zLm[zi]; /* as computed by the score pass */
     }
     if (on) {
       const int item = (int)(ord >> 3), sub = (int)(ord & 7u);
@@ -1419,11 +1423,8 @@ FLTX_DEV void genLexiconSelected(const DecodeParams& P, const Ws& w, const Frame
       } else {
         const int n = (f.nTok == P.N) ? r : w.tokIdx[r];
         const TrieEdge ed = P.trieEdge[(size_t)lexId * P.N + n];
-        const float lexMax = w.bLexMax[o];
-        const float lmTok = P.isLmToken ? lmScoreDev(P, f.b, sid, n) : 0.0f;
         ktp = (uint32_t)n;
         if (sub == 0) { /* extend into the child node (:89-112) */
-          l = P.isLmToken ? lmTok : (ed.childMax - lexMax);
           kp = P.isLmToken ? sid : spar;
           ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
           klex = (uint32_t)ed.child;
@@ -1432,13 +1433,7 @@ FLTX_DEV void genLexiconSelected(const DecodeParams& P, const Ws& w, const Frame
         } else { /* word end (:114-143) or unknown word (:145-165): back to the root */
           const int j = sub - 1;
           const int label = sub == 7 ? P.unk : (j == 0 ? ed.label0 : P.trieLabels[(int)(ed.meta >> 4) + j]);
-          if (!P.isLmToken) {
-            l = lmScoreDev(P, f.b, sid, label) - lexMax;
-            ke = (uint32_t)label;
-          } else {
-            l = lmTok;
-            ke = (uint32_t)n;
-          }
+          ke = !P.isLmToken ? (uint32_t)label : (uint32_t)n;
           kp = sid;
           klex = 0u;
           src = (uint32_t)h | kNewState;
