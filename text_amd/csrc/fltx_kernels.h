@@ -198,7 +198,9 @@ struct Ws {
   uint8_t* tokPos;    /* [N] position of a token in this frame's short-list */
   double* zScore;  /* [CAP2] score pass of the lexicon decoder: candidate score ... */
   uint32_t* zOrd;  /* [CAP2] ... and generation order = (item, sub-candidate), enough to rebuild it */
-  float* zLm;      /* [CAP2] ... and its LM score delta, so that the rebuild does not score it again */
+  float* zLm;      /* [CAP2] ... its LM score delta (extend candidates of a word LM: the child's maxScore,
+                      from which the delta is re-derived), so that the rebuild does not score it again ... */
+  int32_t* zAux;   /* [CAP2] ... and the child node (extend) or word label (word end): no second trie gather */
   uint32_t* head;  /* [HS] */
   uint32_t* lead;  /* group leaders (candidate index), later survivors */
   uint8_t* lstat;  /* per leader: 0 dropped, 1 active, 2 taken */
@@ -327,6 +329,7 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.zScore, double, CAP2)
   FLTX_CARVE(w.zOrd, uint32_t, CAP2)
   FLTX_CARVE(w.zLm, float, CAP2)
+  FLTX_CARVE(w.zAux, int32_t, CAP2)
   FLTX_CARVE(w.head, uint32_t, HS)
   FLTX_CARVE(w.lead, uint32_t, CAP)
   FLTX_CARVE(w.lstat, uint8_t, CAP)
@@ -559,7 +562,7 @@ FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
  * generation order of a candidate (the order encodes hypothesis, token and
  * which of the item's candidates it is, so the full record can be rebuilt). */
 FLTX_DEV void pushSlim(const DecodeParams& P, const Ws& w, bool valid, double score, uint32_t ord, float lm,
-                       unsigned long long& bestKey, double preThr) {
+                       int32_t aux, unsigned long long& bestKey, double preThr) {
   valid = valid && (score >= preThr);
   const unsigned long long m = waveBallot(valid);
   if (m == 0ull) {
@@ -585,6 +588,7 @@ FLTX_DEV void pushSlim(const DecodeParams& P, const Ws& w, bool valid, double sc
   w.zScore[ci] = score;
   w.zOrd[ci] = ord;
   w.zLm[ci] = lm;
+  w.zAux[ci] = aux;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1266,7 +1270,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       uint32_t ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
       uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u) | kExtend;
       if constexpr (SLIM) {
-        pushSlim(P, w, cExt, sc, ordBase, l, bestKey, preThr);
+        pushSlim(P, w, cExt, sc, ordBase, P.isLmToken ? l : childMax, (int32_t)childId, bestKey, preThr);
       } else {
         pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, (int32_t)__float_as_uint(childMax), l,
                       ordBase, bestKey, preThr);
@@ -1296,7 +1300,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
         sc = base + P.lmWeight * (double)l + P.wordScore;
       }
       if constexpr (SLIM) {
-        pushSlim(P, w, on, sc, ordBase + 1 + (uint32_t)j, l, bestKey, preThr);
+        pushSlim(P, w, on, sc, ordBase + 1 + (uint32_t)j, l, label, bestKey, preThr);
       } else {
         pushCandidate(P, w, on, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, label, l,
                       ordBase + 1 + (uint32_t)j, bestKey, preThr);
@@ -1316,7 +1320,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       }
       double sc = base + P.lmWeight * (double)l + P.unkScore;
       if constexpr (SLIM) {
-        pushSlim(P, w, cUnk, sc, ordBase + 7, l, bestKey, preThr);
+        pushSlim(P, w, cUnk, sc, ordBase + 7, l, P.unk, bestKey, preThr);
       } else {
         pushCandidate(P, w, cUnk, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, P.unk, l,
                       ordBase + 7, bestKey, preThr);
@@ -1324,7 +1328,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     }
     /* (2)/(3) stay / blank keep state and node */
     if constexpr (SLIM) {
-      pushSlim(P, w, cStay, baseS, ordS << 3, 0.0f, bestKey, preThr);
+      pushSlim(P, w, cStay, baseS, ordS << 3, 0.0f, -1, bestKey, preThr);
     } else {
       pushCandidate(P, w, cStay, baseS, sparS, (uint32_t)sedgeS, lexS,
                     (uint32_t)nS | (stayBlank ? kPrevBlank : 0u), (uint32_t)hS, -1, 0.0f, ordS << 3,
@@ -1395,13 +1399,14 @@ FLTX_DEV void genLexiconSelected(const DecodeParams& P, const Ws& w, const Frame
     const bool on = i < nSel;
     double sc = 0;
     uint32_t ord = 0, kp = 0, ke = 0, klex = 0, ktp = 0, src = 0;
-    int32_t aux = -1;
+    int32_t aux = -1, zaux = -1;
     float l = 0.0f;
     if (on) {
       const uint32_t zi = w.lead[i];
       sc = w.zScore[zi];
       ord = w.zOrd[zi];
       l = w.zLm[zi]; /* as computed by the score pass */
+      zaux = w.zAux[zi];
     }
     if (on) {
       const int item = (int)(ord >> 3), sub = (int)(ord & 7u);
@@ -1420,6 +1425,24 @@ FLTX_DEV void genLexiconSelected(const DecodeParams& P, const Ws& w, const Frame
         klex = lexId;
         ktp = (uint32_t)n | (blank ? kPrevBlank : 0u);
         src = (uint32_t)h;
+      } else if (!P.isLmToken) { /* word LM: everything needed is in the slim record */
+        const int n = (f.nTok == P.N) ? r : w.tokIdx[r];
+        ktp = (uint32_t)n;
+        if (sub == 0) { /* extend into the child node (:89-112) */
+          const float childMax = l;
+          l = childMax - w.bLexMax[o]; /* float subtraction, :94, as in the score pass */
+          kp = spar;
+          ke = (uint32_t)sedge;
+          klex = (uint32_t)zaux;
+          src = (uint32_t)h | kExtend;
+          aux = (int32_t)__float_as_uint(childMax);
+        } else { /* word end (:114-143) or unknown word (:145-165): back to the root */
+          ke = (uint32_t)zaux;
+          kp = sid;
+          klex = 0u;
+          src = (uint32_t)h | kNewState;
+          aux = zaux;
+        }
       } else {
         const int n = (f.nTok == P.N) ? r : w.tokIdx[r];
         const TrieEdge ed = P.trieEdge[(size_t)lexId * P.N + n];
