@@ -852,6 +852,12 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->wsInLds ? 1 : 0;
   } else if (!strcmp(key, "cut")) {
     *value = d->cutM;
+  } else if (!strcmp(key, "cap")) {
+    *value = d->CAP;
+  } else if (!strcmp(key, "cap2")) {
+    *value = d->CAP2;
+  } else if (!strcmp(key, "items")) {
+    *value = d->itemCap;
   } else {
     return fail(FLTX_ERR_INVALID, "fltx_decoder_get: unknown key '%s'", key);
   }
@@ -1007,11 +1013,12 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
    * have a child in the trie when the full grid would take several rounds */
   d->itemCap = 0;
   if (d->kind == FLTX_DECODER_LEXICON && !d->noItems && !d->forceGlobalWs && N <= 64 && d->trie &&
-      d->trie->mask.p && (int64_t)K * nTok > d->threads && (int64_t)K * nTok <= (1 << 20)) {
+      d->trie->mask.p && (int64_t)K * nTok > d->threads && K <= 1024) {
     d->itemCap = K * nTok;
   }
   auto bytesFor = [&](int64_t c) {
-    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->lane, 0, d->itemCap);
+    return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->lane, 0, d->itemCap,
+                   d->threads / 64);
   };
   bool lds = !d->forceGlobalWs;
   d->CAP2 = 0;
@@ -1039,7 +1046,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         const int64_t capRec = std::max<int64_t>(2 * M, 512);
         auto bytesCut = [&](int64_t c2) {
           return carveWs(tmp, nullptr, K, (int)capRec, hsFor(capRec), d->NB, N, d->SCAP, d->dense, d->lane, (int)c2,
-                         d->itemCap);
+                         d->itemCap, d->threads / 64);
         };
         int64_t c2 = std::min<int64_t>(worst, 16384);
         while (c2 > 4 * M && bytesCut(c2) > kMaxLds) {
@@ -1071,7 +1078,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (!lds) {
     d->itemCap = 0;
   }
-  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap);
+  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap,
+                       d->threads / 64);
   d->wsInLds = lds;
   /* buffers */
   bool grewTab = false;

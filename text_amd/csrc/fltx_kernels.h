@@ -194,7 +194,8 @@ struct Ws {
   uint32_t* cOrd;  /* deterministic generation order (tie-break) */
   uint32_t* cNext; /* hash chain */
   unsigned long long* bLexMask; /* [K] child-token mask of the slot's trie node (this frame) */
-  uint32_t* itemList; /* [itemCap] existing (hypothesis << 8 | token) children of the beam's trie nodes */
+  uint16_t* itemList; /* [itemCap] existing (hypothesis << 6 | token) children of the beam's trie nodes
+                         (N <= 64, K <= 1024) */
   uint8_t* tokPos;    /* [N] position of a token in this frame's short-list */
   double* zScore;  /* [CAP2] score pass of the lexicon decoder: candidate score ... */
   uint32_t* zOrd;  /* [CAP2] ... and generation order = (item, sub-candidate), enough to rebuild it */
@@ -289,7 +290,7 @@ struct LaneLds {
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
-                       int dense, int lane, int CAP2 = 0, int itemCap = 0) {
+                       int dense, int lane, int CAP2 = 0, int itemCap = 0, int nWaves = 16) {
   size_t off = 0;
   LaneLds* const LL = (lane && base) ? (LaneLds*)base : nullptr;
   if (lane) {
@@ -324,7 +325,7 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.cOrd, uint32_t, CAP)
   FLTX_CARVE(w.cNext, uint32_t, CAP)
   FLTX_CARVE(w.bLexMask, unsigned long long, itemCap ? K : 0)
-  FLTX_CARVE(w.itemList, uint32_t, itemCap)
+  FLTX_CARVE(w.itemList, uint16_t, itemCap)
   FLTX_CARVE(w.tokPos, uint8_t, itemCap ? N : 0)
   FLTX_CARVE(w.zScore, double, CAP2)
   FLTX_CARVE(w.zOrd, uint32_t, CAP2)
@@ -353,8 +354,8 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.relTab, unsigned long long, lane ? (size_t)K * (N + 1) : 0)
   FLTX_CARVE_L(w.repTab, unsigned long long, lane ? K : 0, repTab)
   FLTX_CARVE_L(w.bRec, uint4, lane ? 2 * K : 0, bRec)
-  FLTX_CARVE(w.wcum, uint32_t, lane ? 16 * 256 : 0)
-  FLTX_CARVE_L(w.tick, uint32_t, lane ? 512 : 0, tick)
+  FLTX_CARVE(w.wcum, uint32_t, nWaves * 256)
+  FLTX_CARVE_L(w.tick, uint32_t, 512, tick)
   FLTX_CARVE(w.pMate, int32_t, (dense && !lane) ? 16 * 64 : 0)
   FLTX_CARVE(w.pPar, int32_t, (dense && !lane) ? 16 * 64 : 0)
   FLTX_CARVE(w.surv, uint32_t, K)
@@ -1129,8 +1130,8 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       int h0, n0;
       if (listed) {
         const uint32_t code = w.itemList[i0];
-        h0 = (int)(code >> 8);
-        n0 = (int)(code & 0xFFu);
+        h0 = (int)(code >> 6);
+        n0 = (int)(code & 63u);
       } else {
         h0 = i0 / f.nTok;
         const int r0 = i0 - h0 * f.nTok;
@@ -1149,8 +1150,8 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
         int h1, n1;
         if (listed) {
           const uint32_t code = w.itemList[i1];
-          h1 = (int)(code >> 8);
-          n1 = (int)(code & 0xFFu);
+          h1 = (int)(code >> 6);
+          n1 = (int)(code & 63u);
         } else {
           h1 = i1 / f.nTok;
           const int r1 = i1 - h1 * f.nTok;
@@ -1175,8 +1176,8 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       int r;
       if (listed) {
         const uint32_t code = w.itemList[i];
-        h = (int)(code >> 8);
-        n = (int)(code & 0xFFu);
+        h = (int)(code >> 6);
+        n = (int)(code & 63u);
         r = (f.nTok == P.N) ? n : (int)w.tokPos[n];
       } else {
         h = i / f.nTok;
@@ -1754,6 +1755,115 @@ FLTX_DEV void selectTopK(const DecodeParams& P, const Ws& w, int nLead, int K) {
  * and the rank IS the slot in the next beam.  Falls back to the iterative
  * selectTopK() when the short-list would not fit (degenerate distributions).
  * Returns the number of survivors; w.surv[r] = candidate index of rank r. */
+/* Histogram select with the workspace in LDS, three barriers (the scheme of
+ * fltx_lane.h): 512 bins over [thr, best] in two monotone segments; every wave
+ * scans the counts itself (8 bins per lane) and keeps its own copy of the
+ * prefixes, so there is no "wave 0 works, the others wait" step and no barrier
+ * between prefix and scatter; counting sort; rank inside the bin four entries
+ * per LDS round trip.  hist[0..512) and tick[] are zero on entry (runFrame)
+ * and left dirty.  Returns false (nothing written but hist) when the score
+ * range is degenerate or the K-th bin overflows the short-list: the caller
+ * then takes the general path. */
+FLTX_DEV bool selectFast(const DecodeParams& P, const Ws& w, int nLead, int K, double best, double thr,
+                         double spread, int& Lout) {
+  constexpr int NB2 = 512;
+  const int W = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int lane = laneId(), wave = waveId();
+  const double range = best - thr;
+  const int NF = (NB2 * 3) / 4;
+  double cut = spread * 1.25 + 1e-3;
+  cut = cut > range * 0.125 ? cut : range * 0.125;
+  cut = cut < range * 0.9 ? cut : range * 0.9;
+  const double sF = (double)NF / cut, sC = (double)(NB2 - NF) / (range - cut);
+  if (!(range > 0.0) || !(range < 1e6) || !(sF > 0.0) || !(sF < 1e300) || !(sC > 0.0) || !(sC < 1e300)) {
+    return false; /* uniform: every thread sees the same best / thr / spread */
+  }
+  for (int i = tid; i < nLead; i += W) {
+    const double d = best - w.cScore[w.lead[i]];
+    const double x = d < cut ? d * sF : (double)NF + (d - cut) * sC;
+    int bin = (x < (double)NB2) ? (int)x : NB2 - 1;
+    bin = bin < 0 ? 0 : bin;
+    w.lbin[i] = (uint16_t)bin;
+    atomAdd32(&w.hist[bin], 1u);
+  }
+  wsBarrier(P); /* 1 */
+  const uint4 cq0 = ((const uint4*)w.hist)[2 * lane], cq1 = ((const uint4*)w.hist)[2 * lane + 1];
+  const int mineCnt = (int)(cq0.x + cq0.y + cq0.z + cq0.w + cq1.x + cq1.y + cq1.z + cq1.w);
+  const int inc = waveInclusiveScan(mineCnt);
+  int pre[9];
+  pre[0] = inc - mineCnt;
+  pre[1] = pre[0] + (int)cq0.x;
+  pre[2] = pre[1] + (int)cq0.y;
+  pre[3] = pre[2] + (int)cq0.z;
+  pre[4] = pre[3] + (int)cq0.w;
+  pre[5] = pre[4] + (int)cq1.x;
+  pre[6] = pre[5] + (int)cq1.y;
+  pre[7] = pre[6] + (int)cq1.z;
+  pre[8] = inc;
+  const int total = (int)waveReadLane32((uint32_t)inc, 63);
+  const unsigned long long cm = waveBallot(pre[0] < K && inc >= K);
+  int bstar = NB2 - 1, L = total;
+  {
+    int q = 7, cumAt = inc;
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {
+      const bool hit = pre[i + 1] >= K;
+      q = hit ? i : q;
+      cumAt = hit ? pre[i + 1] : cumAt;
+    }
+    const int X = cm ? __builtin_ctzll(cm) : 0;
+    const uint32_t both = waveReadLane32((uint32_t)(8 * lane + q) | ((uint32_t)cumAt << 16), X);
+    if (cm) {
+      bstar = (int)(both & 0xFFFFu);
+      L = (int)(both >> 16);
+    }
+  }
+  if (L > P.SCAP || total > 65535) {
+    return false; /* uniform; the general path recomputes from lead[] */
+  }
+  ((uint4*)(w.wcum + wave * (NB2 / 2)))[lane] =
+      make_uint4((uint32_t)pre[0] | ((uint32_t)pre[1] << 16), (uint32_t)pre[2] | ((uint32_t)pre[3] << 16),
+                 (uint32_t)pre[4] | ((uint32_t)pre[5] << 16), (uint32_t)pre[6] | ((uint32_t)pre[7] << 16));
+  waveSync();
+  for (int i = tid; i < nLead; i += W) {
+    const int bin = (int)w.lbin[i];
+    if (bin <= bstar) {
+      const uint32_t lo = ((const uint16_t*)(w.wcum + wave * (NB2 / 2)))[bin];
+      const uint32_t cnt = w.hist[bin];
+      const uint32_t p = lo + atomAdd32(&w.tick[bin], 1u);
+      const uint32_t c = w.lead[i];
+      const unsigned long long key = f64Key(w.cScore[c]);
+      w.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), w.cOrd[c], lo | ((lo + cnt) << 16));
+      w.sIdx[p] = c;
+    }
+  }
+  wsBarrier(P); /* 2 */
+  for (int p = tid; p < L; p += W) {
+    const uint4 me = w.sEnt[p];
+    const unsigned long long k = ((unsigned long long)me.y << 32) | me.x;
+    const int lo = (int)(me.w & 0xFFFFu), hi = (int)(me.w >> 16);
+    int rank = lo;
+    for (int q = lo; q < hi; q += 4) {
+      uint4 e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        e[u] = w.sEnt[q + u < L ? q + u : L - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long k2 = ((unsigned long long)e[u].y << 32) | e[u].x;
+        rank += (q + u < hi && (k2 > k || (k2 == k && e[u].z < me.z))) ? 1 : 0;
+      }
+    }
+    if (rank < K) {
+      w.surv[rank] = w.sIdx[p];
+    }
+  }
+  wsBarrier(P); /* 3 */
+  Lout = L;
+  return true;
+}
+
 FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K, double best, double thr,
                            double spread) {
   const int W = (int)blockDim.x;
@@ -1774,6 +1884,8 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K,
     }
     L = nLead;
     wsBarrier(P);
+  } else if (P.gws == nullptr && selectFast(P, w, nLead, K, best, thr, spread, L)) {
+    return nS;
   } else {
     /* Bins over [best - beamThreshold, best]: the leaders already passed the
      * threshold (foldGroups), so no pass over them is needed to find the range.
@@ -2157,7 +2269,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
           const int n = __builtin_ctzll(m);
           m &= m - 1ull;
           if (pos < P.itemCap) {
-            w.itemList[pos] = ((uint32_t)h << 8) | (uint32_t)n;
+            w.itemList[pos] = (uint16_t)(((uint32_t)h << 6) | (uint32_t)n);
           }
           ++pos;
         }
@@ -2255,6 +2367,12 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
     nCand = nCand > P.CAP ? P.CAP : nCand;
     foldGroups(P, w, thr, nCand);
   }
+  if (P.gws == nullptr) { /* selectFast expects empty counters */
+    for (int i = tid; i < 512; i += W) {
+      w.hist[i] = 0u;
+      w.tick[i] = 0u;
+    }
+  }
   wsBarrier(P);
   FLTX_PROF(2);
   const int nLead = w.sc[SC_NLEAD];
@@ -2283,7 +2401,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
-  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane, P.CAP2, P.itemCap);
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane, P.CAP2, P.itemCap, (W + 63) >> 6);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {

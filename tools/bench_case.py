@@ -45,6 +45,8 @@ def main():
         print("  clocks/frame/utt by phase [prep, generate, fold, select, build, row, -, -]:",
               " ".join("%.0f" % v for v in pr), "total %.0f" % pr.sum())
         d.set("profile", 0)
+    print("  geometry: lds=%d cap=%d cap2=%d cut=%d items=%d lds_bytes=%d" % (
+        d.get("lds"), d.get("cap"), d.get("cap2"), d.get("cut"), d.get("items"), d.stats()["lds_bytes"]))
     print("%s batch=%d T=%d K=%d: engine %d threads %d, decode kernel %.2f ms, backtrace %.2f ms, "
           "wall/batch %.2f ms (incl. H2D), %.2f M frames/s (kernel)" %
           (name, B, c["T"], c["K"], d.get("engine"), d.get("threads"), k, b, min(ms), B * c["T"] / k / 1e3))
