@@ -219,3 +219,23 @@ def test_engine_selection(gpu_session, golden, name, engine):
     d.close()
     assert got == engine
     assert ok, why
+
+
+HBM_WS = ["lf_ctc_t60_k10", "lf_asg_t30_n8", "lx_scores_t50", "C1_ctc_u0"] + \
+    [c["name"] for c in cases.CASES if c["name"].startswith("ng_")][:3]
+
+
+@pytest.mark.parametrize("name", HBM_WS)
+def test_workspace_in_hbm(gpu_session, golden, name):
+    """Big beams carve the per-frame workspace from HBM instead of LDS (agent-scope
+    barriers, L2 atomics).  Forced here on small cases: same n-best."""
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    d = gpu_session.decoder(c, inp)
+    d.set("force_global_ws", 1)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    assert d.get("lds") == 0
+    tol = 1e-5 if c["log_add"] else 0.0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
+    d.close()
+    assert ok, why
