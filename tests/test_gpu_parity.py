@@ -239,3 +239,18 @@ def test_workspace_in_hbm(gpu_session, golden, name):
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
     d.close()
     assert ok, why
+
+
+@pytest.mark.parametrize("N,K,Kt,dist", [(200, 12, 20, "uniform"), (1000, 20, 50, "uniform"), (96, 70, 96, "ctc")])
+def test_large_token_sets_match_oracle(gpu_session, oracle_lib, N, K, Kt, dist):
+    """Word-piece sized token sets (N > 64: no lane / lean step, token short-list
+    by the general path) against the oracle on the fly."""
+    from text_amd import synth
+    c = cases.case("big_n", dist=dist, T=30, N=N, K=K, Kt=Kt, u=11)
+    e = synth.emissions(dist, c["u"], c["T"], N)
+    d = gpu_session.decoder(c, dict(tr=None))
+    d.decode_batch(e, [c["T"]], N)
+    want = helpers.run_checker(oracle_lib, c, dict(e=e, tr=None, lex=None))
+    ok, why = helpers.hyps_equal(want, d.results(0))
+    d.close()
+    assert ok, why
