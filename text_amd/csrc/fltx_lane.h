@@ -9,9 +9,9 @@
  * number of instructions a wave issues between barriers, so:
  *   * every wave keeps the WHOLE beam in registers, hypothesis h in lane h
  *     (score, token, and the scores/tokens of the <= 3 related hypotheses it
- *     can merge with), and evaluates the candidates of "its" tokens
- *     (token n belongs to wave n mod #waves) with no memory access at all:
- *     e[n] is wave-uniform, everything else is lane-local;
+ *     can merge with), and evaluates the candidates of "its" tokens (the
+ *     tokens are dealt to the waves, see laneToken) with no memory access at
+ *     all: e[n] is wave-uniform, everything else is lane-local;
  *   * the merge of LexiconFreeDecoder.cpp:101-103 needs no table: a group has
  *     <= 3 members -- the hypothesis of an LM state and its blank/non-blank
  *     twin ("mate"), plus the repeat of the child state's hypothesis -- and a
@@ -28,8 +28,10 @@
  *   * histogram prefix, K-th-bin search and scatter positions are computed by
  *     every wave redundantly from the shared counts: no "wave 0 works, the
  *     rest waits" section and no barrier between prefix and scatter;
- *   * the epilogue of the build (state masks, history records) is deferred to
- *     the next frame's first phase and done by one otherwise idle wave.
+ *   * the ~K short-listed candidates become the next beam in two waves that
+ *     run concurrently (what the next phase 1 reads / everything else), and
+ *     the epilogue of the build (state masks, history records) is deferred to
+ *     the next frame's first phase and done by the wave with the fewest tokens.
  * Three barriers per frame (the third is the row hand-over of the caller).
  */
 #pragma once
