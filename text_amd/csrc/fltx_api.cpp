@@ -44,7 +44,7 @@ template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gws(DecodeParams P) {
   decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
 }
-__global__ void __launch_bounds__(256) fltx_backtrace_kernel(BacktraceParams P) {
+__global__ void __launch_bounds__(512) fltx_backtrace_kernel(BacktraceParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_bt_smem[];
   backtraceUtterance(P, fltx_bt_smem);
 }
@@ -1391,10 +1391,10 @@ int launchBacktrace(fltx_decoder* d) {
 #ifdef FLTX_EMU
   const int btThreads = 64;
 #else
-  const int btThreads = 256;
+  const int btThreads = 512;
 #endif
   const size_t perFrame = (size_t)Q.K * (8 + (d->kind == FLTX_DECODER_LEXICON ? 4 : 0) + 8);
-  int F = (int)std::min<size_t>((size_t)96 * 1024 / perFrame, 512);
+  int F = (int)std::min<size_t>((size_t)144 * 1024 / perFrame, 512);
   if (F < 8 || Q.K > 4 * btThreads) {
     F = 0;
   }

@@ -2719,10 +2719,28 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
     const int lo = hi - F + 1 > 0 ? hi - F + 1 : 0;
     const int nf = hi - lo + 1;
     const int64_t src = hb + (int64_t)lo * K;
-    for (int i = tid; i < nf * K; i += W) {
-      cPT[i] = P.histPT[src + i];
-      if (lex) {
-        cW[i] = P.histW[src + i];
+    /* eight loads in flight per thread before the first LDS store: the copy is
+     * bandwidth work, not a chain of load -> store round trips */
+    for (int base = tid; base < nf * K; base += 8 * W) {
+      int2 v[8];
+      int32_t wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * W;
+        if (i < nf * K) {
+          v[u] = P.histPT[src + i];
+          wv[u] = lex ? P.histW[src + i] : -1;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * W;
+        if (i < nf * K) {
+          cPT[i] = v[u];
+          if (lex) {
+            cW[i] = wv[u];
+          }
+        }
       }
     }
     __syncthreads();
