@@ -1387,13 +1387,13 @@ int launchBacktrace(fltx_decoder* d) {
   Q.tokens = d->tokens.as<int32_t>();
   Q.words = d->kind == FLTX_DECODER_LEXICON ? d->words.as<int32_t>() : nullptr;
   Q.nbest = 0;
-  /* frames per LDS chunk: records in ({parent, token} 8 B, word 4 B) + token and word tiles out */
+  /* frames per LDS chunk: two record buffers in ({parent, token} 8 B, word 4 B) + token and word tiles out */
 #ifdef FLTX_EMU
   const int btThreads = 64;
 #else
   const int btThreads = 512;
 #endif
-  const size_t perFrame = (size_t)Q.K * (8 + (d->kind == FLTX_DECODER_LEXICON ? 4 : 0) + 8);
+  const size_t perFrame = (size_t)Q.K * (2 * (8 + (d->kind == FLTX_DECODER_LEXICON ? 4 : 0)) + 8);
   int F = (int)std::min<size_t>((size_t)144 * 1024 / perFrame, 512);
   if (F < 8 || Q.K > 4 * btThreads) {
     F = 0;

@@ -2669,7 +2669,8 @@ struct BacktraceParams {
  * is T x ~1 us per hypothesis and the token rows come out as strided 4-byte
  * stores.  Instead the history is taken F frames at a time, newest first: the
  * chunk's {parent, token} (and word) records are copied to LDS with coalesced
- * loads, every hypothesis walks its F steps there (~100 clocks each), drops its
+ * loads (double buffered: the next chunk arrives while this one is walked),
+ * every hypothesis walks its F steps there (~100 clocks each), drops its
  * tokens into an LDS tile, and the tile leaves as row-contiguous stores. */
 FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
   const int b = (int)blockIdx.x;
@@ -2706,36 +2707,43 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
     return;
   }
   const int F = P.F;
-  int2* cPT = (int2*)smem;                                  /* [F][K] */
-  int32_t* cW = (int32_t*)(cPT + (size_t)F * K);            /* [F][K] (lexicon decoder) */
-  int32_t* oT = cW + (lex ? (size_t)F * K : 0);             /* [nh][F] */
-  int32_t* oW = oT + (size_t)F * K;                         /* [nh][F] */
+  /* two record buffers: while the walker waves walk chunk c, the other waves
+   * copy chunk c + 1 (the copy is most of the kernel's time) */
+  int2* cPT0 = (int2*)smem;                                   /* [2][F][K] */
+  int32_t* cW0 = (int32_t*)(cPT0 + (size_t)2 * F * K);        /* [2][F][K] (lexicon decoder) */
+  int32_t* oT = cW0 + (lex ? (size_t)2 * F * K : 0);          /* [nh][F] */
+  int32_t* oW = oT + (size_t)F * K;                           /* [nh][F] */
   int slot[4]; /* hypotheses tid, tid + W, ... (nh <= 4 W is checked by the host) */
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     slot[q] = tid + q * W;
   }
-  for (int hi = ff; hi >= 0; hi -= F) {
+  const int wThreads = nh >= W ? W : ((nh + 63) >> 6) << 6; /* whole waves that walk */
+  const int mThreads = W - wThreads;                         /* threads free to copy meanwhile */
+  /* copy chunk [lo, hi] into buffer `buf` with threads t0, t0 + step, ...: eight
+   * loads in flight per thread before the first LDS store -- the copy is
+   * bandwidth work, not a chain of load -> store round trips */
+  auto copyChunk = [&](int hi, int buf, int t0, int step) {
     const int lo = hi - F + 1 > 0 ? hi - F + 1 : 0;
-    const int nf = hi - lo + 1;
+    const int n = (hi - lo + 1) * K;
     const int64_t src = hb + (int64_t)lo * K;
-    /* eight loads in flight per thread before the first LDS store: the copy is
-     * bandwidth work, not a chain of load -> store round trips */
-    for (int base = tid; base < nf * K; base += 8 * W) {
+    int2* cPT = cPT0 + (size_t)buf * F * K;
+    int32_t* cW = cW0 + (size_t)buf * F * K;
+    for (int base = t0; base < n; base += 8 * step) {
       int2 v[8];
       int32_t wv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = base + u * W;
-        if (i < nf * K) {
+        const int i = base + u * step;
+        if (i < n) {
           v[u] = P.histPT[src + i];
           wv[u] = lex ? P.histW[src + i] : -1;
         }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = base + u * W;
-        if (i < nf * K) {
+        const int i = base + u * step;
+        if (i < n) {
           cPT[i] = v[u];
           if (lex) {
             cW[i] = wv[u];
@@ -2743,27 +2751,43 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
         }
       }
     }
-    __syncthreads();
+  };
+  copyChunk(ff, 0, tid, W);
+  __syncthreads();
+  int c = 0;
+  for (int hi = ff; hi >= 0; hi -= F, ++c) {
+    const int lo = hi - F + 1 > 0 ? hi - F + 1 : 0;
+    const int nf = hi - lo + 1;
+    const int2* cPT = cPT0 + (size_t)(c & 1) * F * K;
+    const int32_t* cW = cW0 + (size_t)(c & 1) * F * K;
+    const bool more = lo > 0;
+    if (tid < wThreads) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = tid + q * W;
-      if (k < nh) {
-        int s = slot[q];
-        for (int j = nf - 1; j >= 0; --j) {
-          int tokv = -1, wv = -1;
-          if (s >= 0) {
-            const int2 pt = cPT[j * K + s];
-            tokv = pt.y;
-            wv = lex ? cW[j * K + s] : -1;
-            s = pt.x;
+      for (int q = 0; q < 4; ++q) {
+        const int k = tid + q * W;
+        if (k < nh) {
+          int s = slot[q];
+          for (int j = nf - 1; j >= 0; --j) {
+            int tokv = -1, wv = -1;
+            if (s >= 0) {
+              const int2 pt = cPT[j * K + s];
+              tokv = pt.y;
+              wv = lex ? cW[j * K + s] : -1;
+              s = pt.x;
+            }
+            oT[k * F + j] = tokv;
+            if (P.words) {
+              oW[k * F + j] = wv;
+            }
           }
-          oT[k * F + j] = tokv;
-          if (P.words) {
-            oW[k * F + j] = wv;
-          }
+          slot[q] = s;
         }
-        slot[q] = s;
       }
+    } else if (more) {
+      copyChunk(lo - 1, (c + 1) & 1, tid - wThreads, mThreads);
+    }
+    if (more && mThreads == 0) { /* every thread walks: copy afterwards */
+      copyChunk(lo - 1, (c + 1) & 1, tid, W);
     }
     __syncthreads();
     for (int k = tid >> 6; k < nh; k += W >> 6) { /* a wave per row: contiguous stores */
