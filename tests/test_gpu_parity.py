@@ -254,3 +254,25 @@ def test_large_token_sets_match_oracle(gpu_session, oracle_lib, N, K, Kt, dist):
     ok, why = helpers.hyps_equal(want, d.results(0))
     d.close()
     assert ok, why
+
+
+@pytest.mark.parametrize("name", ["lf_ctc_t60_k10", "lx_scores_t50", "ng_word_t40_k10", "lf_ctc_n29_k65"])
+def test_decoder_reuse_across_batches(gpu_session, oracle_lib, name):
+    """One decoder object, several batches of different content and shape: the
+    per-utterance tables that persist across launches (LM-state ids, child
+    tables, history) must not leak from one batch into the next."""
+    from text_amd import synth
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    d = gpu_session.decoder(c, inp)
+    lex = inp["lex"] if c["dist"] == "lexspell" else None
+    for rnd, (B, T) in enumerate([(3, c["T"]), (5, c["T"] // 2 + 1), (2, c["T"] + 7), (3, c["T"])]):
+        embs = [synth.emissions(c["dist"], 500 + 10 * rnd + b, T, c["N"], lexicon=lex) for b in range(B)]
+        flat = np.concatenate([e.reshape(-1) for e in embs])
+        d.decode_batch(flat, [T] * B, c["N"])
+        for b in range(B):
+            cb = dict(c, T=T)
+            want = helpers.run_checker(oracle_lib, cb, dict(inp, e=embs[b]))
+            ok, why = helpers.hyps_equal(want, d.results(b))
+            assert ok, "round %d utterance %d: %s" % (rnd, b, why)
+    d.close()
