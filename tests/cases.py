@@ -111,3 +111,28 @@ APPENDIX_B = {
     "C3_uniform_u0": (13, 0xF3B0CBE10F12C3EB, "-0x1.073519b8p+10"),
     "C4z_spell_u0": (69, 0xE65C45F2D737271E, "-0x1.749f9bfc8p+8"),
 }
+
+
+def fuzz_cases(n=36):
+    """Random option combinations for the differential tests (GPU and emulator vs oracle)."""
+    import random
+    rnd = random.Random(20260928)
+    out = []
+    for i in range(n):
+        kind = ["lexfree", "lexfree", "lexicon"][i % 3]
+        N = rnd.choice([5, 12, 29, 29, 40, 64])
+        if kind == "lexicon":
+            N = 29
+        K = rnd.choice([1, 2, 3, 7, 16, 33, 64, 65, 90])
+        Kt = rnd.choice([N, N, max(1, N // 2), min(N, 3)])
+        lm = "zero" if i % 2 == 0 or kind == "lexfree" and N > 29 else ("ngram", rnd.choice([2, 3, 4]), 40 + i)
+        out.append(case(
+            "fuzz%02d" % i, kind=kind, dist=rnd.choice(["ctc", "uniform"]) if kind == "lexfree" else "lexspell",
+            u=300 + i, T=rnd.choice([1, 9, 25, 41]), N=N, K=K, Kt=Kt, thr=rnd.choice([2.0, 8.0, 25.0, 100.0]),
+            lm_weight=rnd.choice([0.0, 0.5, 2.0]) if lm != "zero" else 0.0,
+            word_score=rnd.choice([0.0, -1.0, 1.5]) if kind == "lexicon" else 0.0,
+            unk_score=rnd.choice([float("-inf"), -3.0]) if kind == "lexicon" else float("-inf"),
+            sil_score=rnd.choice([0.0, -0.5, 0.3]), log_add=rnd.random() < 0.2,
+            lexicon=SMALL_LEX if kind == "lexicon" else None, lm=lm,
+            is_lm_token=(kind == "lexfree" and lm != "zero")))
+    return out

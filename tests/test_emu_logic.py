@@ -59,3 +59,15 @@ def test_emulated_score_cut_is_exact_or_retried(emu_session, golden, c):
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
     d.close()
     assert ok, why
+
+
+@pytest.mark.parametrize("c", [c for c in cases.fuzz_cases(18) if c["T"] <= 25 and c["K"] <= 33],
+                         ids=lambda c: c["name"])
+def test_emulated_random_configurations_match_oracle(emu_session, oracle_lib, c):
+    """The randomized differential test of tests/test_gpu_parity.py, on the
+    emulated kernels (small shapes only)."""
+    inp = helpers.case_inputs(c)
+    want = helpers.run_checker(oracle_lib, c, inp)
+    got = emu_session.run(c, inp, threads=128 if c["kind"] == "lexfree" and c["N"] > 16 else 64)
+    ok, why = helpers.hyps_equal(want, got, 1e-9 if c["log_add"] else 0.0)
+    assert ok, "%s: %s" % ({k: c[k] for k in ("kind", "N", "K", "Kt", "thr", "lm", "log_add", "T")}, why)
