@@ -204,6 +204,18 @@ FLTX_API int fltx_result_count(fltx_decoder* dec, int32_t b, int32_t* n_hyp,
 FLTX_API int fltx_result_fetch(fltx_decoder* dec, int32_t b, int32_t max_hyp,
                                double* scores, int32_t* tokens, int32_t* words,
                                int32_t* n_copied);
+/* The whole batch's n-best in one PCIe transfer per array (offline decodes):
+ * counts, scores and token / word rows are copied into pinned host buffers
+ * owned by the decoder and pointers to them are returned; they stay valid
+ * until the next decode on this decoder.  Hypothesis k of utterance b:
+ * scores[(b * beam_size + k) * 3 + {0,1,2}] = score, emitting-model score, LM
+ * score; tokens + offsets[b] + k * length[b] holds its length[b] tokens (words
+ * likewise; *words is NULL for the lexicon-free decoder, whose word sequence
+ * is all -1, LexiconFreeDecoder.h:80-82).  Replaces a loop of
+ * getAllFinalHypothesis() calls (Decoder.h:71-73) over the utterances. */
+FLTX_API int fltx_result_fetch_batch(fltx_decoder* dec, const int32_t** n_hyp, const int32_t** length,
+                                     const double** scores, const int32_t** tokens, const int32_t** words,
+                                     const int64_t** offsets);
 /* getBestHypothesis(lookBack) of stream b (LexiconFreeDecoder.cpp:188-194,
  * decoder/Utils.h:268-310): *length = 0 for an empty result. */
 FLTX_API int fltx_result_best(fltx_decoder* dec, int32_t b, int32_t look_back,

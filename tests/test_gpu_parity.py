@@ -287,3 +287,24 @@ def test_random_configurations_match_oracle(gpu_session, oracle_lib, c):
     got = gpu_session.run(c, inp)
     ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
     assert ok, "%s: %s" % ({k: c[k] for k in ("kind", "N", "K", "Kt", "thr", "lm", "log_add", "T")}, why)
+
+
+@pytest.mark.parametrize("name", ["C1_ctc_u0", "lx_scores_t50"])
+def test_batched_result_fetch_equals_per_utterance_fetch(gpu_session, name):
+    """fltx_result_fetch_batch (one transfer per array through pinned staging)
+    returns exactly what the per-utterance fltx_result_fetch returns."""
+    from text_amd import synth
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    lex = inp["lex"] if c["dist"] == "lexspell" else None
+    Ts = [c["T"], 0, 7, c["T"] // 2]
+    embs = [synth.emissions(c["dist"], 900 + b, T, c["N"], lexicon=lex) for b, T in enumerate(Ts)]
+    flat = np.concatenate([e.reshape(-1) for e in embs])
+    d = gpu_session.decoder(c, inp)
+    d.decode_batch(flat, Ts, c["N"])
+    allh = d.results_batch()
+    assert len(allh) == len(Ts)
+    for b in range(len(Ts)):
+        ok, why = helpers.hyps_equal(d.results(b), allh[b])
+        assert ok, "utterance %d: %s" % (b, why)
+    d.close()

@@ -52,7 +52,7 @@ class Lib:
         "fltx_trie_create", "fltx_trie_destroy", "fltx_decoder_create",
         "fltx_decoder_destroy", "fltx_decode_batch", "fltx_stream_begin",
         "fltx_stream_step", "fltx_stream_end", "fltx_stream_prune",
-        "fltx_stream_frames_in_buffer", "fltx_result_count", "fltx_result_fetch",
+        "fltx_stream_frames_in_buffer", "fltx_result_count", "fltx_result_fetch", "fltx_result_fetch_batch",
         "fltx_result_best", "fltx_result_device", "fltx_decoder_stats",
         "fltx_decoder_set", "fltx_decoder_get", "fltx_decoder_timing", "fltx_decoder_profile", "fltx_htrie_create", "fltx_htrie_destroy", "fltx_htrie_insert",
         "fltx_htrie_search", "fltx_htrie_smear", "fltx_htrie_num_nodes", "fltx_htrie_upload",
@@ -96,6 +96,7 @@ class Lib:
             "fltx_stream_frames_in_buffer": [vp, i32, vp],
             "fltx_result_count": [vp, i32, vp, vp],
             "fltx_result_fetch": [vp, i32, i32, vp, vp, vp, vp],
+            "fltx_result_fetch_batch": [vp, pvp, pvp, pvp, pvp, pvp, pvp],
             "fltx_result_best": [vp, i32, i32, vp, vp, vp, i32, vp],
             "fltx_result_device": [vp, pvp, pvp, pvp, pvp, pvp],
             "fltx_decoder_stats": [vp, vp, vp, vp, vp],
@@ -429,6 +430,41 @@ class BatchDecoder:
         assert got.value == n
         return [Hyp(scores[3 * i], scores[3 * i + 1], scores[3 * i + 2], tokens[i].copy(), words[i].copy())
                 for i in range(n)]
+
+    def fetch_batch_raw(self):
+        """The six pointers of fltx_result_fetch_batch (n_hyp, length, scores, tokens, words, offsets)."""
+        ptrs = [C.c_void_p() for _ in range(6)]
+        self.L.check(self.L.lib.fltx_result_fetch_batch(self.h, *[C.byref(p) for p in ptrs]))
+        return [p.value for p in ptrs]
+
+    def results_batch(self, max_hyp=None):
+        """n-best of every utterance of the last decode_batch: one transfer per
+        array into pinned host memory, then NumPy views (no per-hypothesis copies;
+        the views stay valid until the next decode)."""
+        pn, pl, ps, pt, pw, po = (C.c_void_p() for _ in range(6))
+        self.L.check(self.L.lib.fltx_result_fetch_batch(self.h, C.byref(pn), C.byref(pl), C.byref(ps), C.byref(pt),
+                                                        C.byref(pw), C.byref(po)))
+        B = self.B
+
+        def view(ptr, ctype, n):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
+        nh = view(pn, C.c_int32, B)
+        ln = view(pl, C.c_int32, B)
+        off = view(po, C.c_int64, B + 1)
+        total = int(off[B])
+        K = int(self.options.beam_size)
+        sc = view(ps, C.c_double, B * K * 3).reshape(B, K, 3)
+        tok = view(pt, C.c_int32, max(total, 1))
+        wrd = view(pw, C.c_int32, max(total, 1)) if pw.value else None
+        out = []
+        for b in range(B):
+            n = int(nh[b]) if max_hyp is None else min(int(nh[b]), max_hyp)
+            L = int(ln[b])
+            tb = tok[off[b]:off[b] + n * L].reshape(n, L)
+            wb = wrd[off[b]:off[b] + n * L].reshape(n, L) if wrd is not None else None
+            out.append([Hyp(sc[b, i, 0], sc[b, i, 1], sc[b, i, 2], tb[i],
+                            wb[i] if wb is not None else np.full(L, -1, dtype=np.int32)) for i in range(n)])
+        return out
 
     def best(self, b, look_back=0, capacity=1 << 16):
         scores = np.zeros(3, dtype=np.float64)

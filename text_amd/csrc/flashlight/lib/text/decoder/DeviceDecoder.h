@@ -44,6 +44,7 @@ class DeviceDecoder {
     sil_ = sil;
     blank_ = blank;
     nTrans_ = (int)transitions.size();
+    beamSize_ = opt.beam_size;
   }
 
   fltx_ctx* ctx() const { return ctx_->h; }
@@ -81,9 +82,29 @@ class DeviceDecoder {
                             t32.data(), (int32_t)t32.size(), N));
     open_ = true;
     pendingBegin_ = false;
+    /* the whole n-best crosses PCIe once (pinned staging inside the library) */
+    const int32_t *nHyp = nullptr, *len = nullptr, *tok = nullptr, *wrd = nullptr;
+    const double* sc = nullptr;
+    const int64_t* off = nullptr;
+    check(fltx_result_fetch_batch(h_, &nHyp, &len, &sc, &tok, &wrd, &off));
     std::vector<std::vector<DecodeResult>> out(T.size());
     for (size_t b = 0; b < T.size(); ++b) {
-      out[b] = results((int)b);
+      const int n = nHyp[b], L = len[b];
+      out[b].reserve((size_t)n);
+      for (int i = 0; i < n; ++i) {
+        DecodeResult r(L);
+        const double* s3 = sc + ((size_t)b * beamSize_ + (size_t)i) * 3;
+        r.score = s3[0];
+        r.emittingModelScore = s3[1];
+        r.lmScore = s3[2];
+        const int32_t* tp = tok + off[b] + (int64_t)i * L;
+        std::copy(tp, tp + L, r.tokens.begin());
+        if (wrd) {
+          const int32_t* wp = wrd + off[b] + (int64_t)i * L;
+          std::copy(wp, wp + L, r.words.begin());
+        } /* else: DecodeResult(L) leaves words at -1 (LexiconFreeDecoder.h:80-82) */
+        out[b].push_back(std::move(r));
+      }
     }
     return out;
   }
@@ -164,6 +185,7 @@ class DeviceDecoder {
   void setMaxStreamFrames(int n) { maxFrames_ = n; }
 
  private:
+  int beamSize_ = 0;
   int guessN() const {
     if (nTrans_ > 0) {
       int n = 1;

@@ -120,6 +120,43 @@ constexpr size_t kMaxLds = 160 * 1024; /* gfx950: 160 KiB LDS per CU */
 
 #endif
 
+/* growable PINNED host buffer: results cross PCIe in one transfer per array */
+struct HBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) {
+      return 0;
+    }
+    release();
+#ifdef FLTX_EMU
+    p = malloc(n ? n : 1);
+    if (!p) {
+      return 1;
+    }
+#else
+    if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) {
+      p = nullptr;
+      return 1;
+    }
+#endif
+    cap = n;
+    return 0;
+  }
+  void release() {
+    if (p) {
+#ifdef FLTX_EMU
+      free(p);
+#else
+      (void)hipHostFree(p);
+#endif
+    }
+    p = nullptr;
+    cap = 0;
+  }
+  ~HBuf() { release(); }
+};
+
 /* growable device buffer */
 struct DBuf {
   void* p = nullptr;
@@ -241,6 +278,9 @@ struct fltx_decoder {
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
+  HBuf hTokens, hWords, hScores; /* fltx_result_fetch_batch */
+  std::vector<int32_t> hLen, hNHyp;
+  bool hostFetched = false;
   int keepScores = 0;
   int profile = 0, profWave = 0;
   /* host caches of the last results */
@@ -1448,6 +1488,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   d->haveResults = false;
   d->resultsSynced = false;
   d->backtraced = false;
+  d->hostFetched = false;
   for (int attempt = 0; attempt < 2; ++attempt) {
     int rc = prepare(d, B, N, T, attempt == 1);
     if (rc) {
@@ -1528,6 +1569,7 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   d->haveResults = false;
   d->resultsSynced = false;
   d->backtraced = false;
+  d->hostFetched = false;
   d->frames.assign(B, 0);
   DecodeParams P;
   fillParams(d, P);
@@ -1574,6 +1616,7 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
   }
   d->resultsSynced = false;
   d->backtraced = false;
+  d->hostFetched = false;
   return FLTX_OK;
 }
 
@@ -1599,6 +1642,7 @@ int fltx_stream_end(fltx_decoder* d) {
   d->ended = true;
   d->resultsSynced = false;
   d->backtraced = false;
+  d->hostFetched = false;
   return FLTX_OK;
 }
 
@@ -1644,6 +1688,7 @@ int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
   }
   d->resultsSynced = false;
   d->backtraced = false;
+  d->hostFetched = false;
   if ((rc = syncResults(d))) {
     return rc;
   }
@@ -1763,6 +1808,69 @@ int fltx_result_fetch(fltx_decoder* d, int32_t b, int32_t maxHyp, double* scores
         std::fill(words, words + (size_t)n * len, -1); /* LexiconFreeDecoder.h:80-82 */
       }
     }
+  }
+  return FLTX_OK;
+}
+
+int fltx_result_fetch_batch(fltx_decoder* d, const int32_t** nHyp, const int32_t** length, const double** scores,
+                            const int32_t** tokens, const int32_t** words, const int64_t** offsets) {
+  if (!d) {
+    return fail(FLTX_ERR_INVALID, "fltx_result_fetch_batch: null decoder");
+  }
+  if (!d->haveResults || !d->ended) {
+    return fail(FLTX_ERR_STATE, "fltx_result_fetch_batch: no finished decode (use fltx_result_fetch on a stream)");
+  }
+  int rc = syncResults(d);
+  if (rc) {
+    return rc;
+  }
+  const int B = d->B, K = d->opt.beam_size;
+  for (int b = 0; b < B; ++b) {
+    if ((rc = checkStatus(d, b))) {
+      return rc;
+    }
+  }
+  if (!d->hostFetched) {
+    if (!d->backtraced && (rc = launchBacktrace(d))) {
+      return rc;
+    }
+    Stream st = d->ctx->stream;
+    const size_t nRec = (size_t)std::max<int64_t>(d->histRecords, 1);
+    if (d->hTokens.ensure(4 * nRec) || d->hScores.ensure(8 * 3 * (size_t)B * K) ||
+        (d->kind == FLTX_DECODER_LEXICON && d->hWords.ensure(4 * nRec))) {
+      return fail(FLTX_ERR_OOM, "pinned result buffers: allocation failed");
+    }
+    if (devCopyD2H(d->hScores.p, d->outScores.p, 8 * 3 * (size_t)B * K, st) ||
+        devCopyD2H(d->hTokens.p, d->tokens.p, 4 * nRec, st) ||
+        (d->kind == FLTX_DECODER_LEXICON && devCopyD2H(d->hWords.p, d->words.p, 4 * nRec, st))) {
+      return fail(FLTX_ERR_HIP, "result copy failed: %s", devErr());
+    }
+    d->hLen.resize(B);
+    d->hNHyp.resize(B);
+    for (int b = 0; b < B; ++b) {
+      d->hLen[b] = d->hFrame[b] + 1;
+      /* LexiconDecoder.cpp:276-280: nothing before the first frame */
+      d->hNHyp[b] = (d->kind == FLTX_DECODER_LEXICON && d->hFrame[b] < 1) ? 0 : d->hN[b];
+    }
+    d->hostFetched = true;
+  }
+  if (nHyp) {
+    *nHyp = d->hNHyp.data();
+  }
+  if (length) {
+    *length = d->hLen.data();
+  }
+  if (scores) {
+    *scores = (const double*)d->hScores.p;
+  }
+  if (tokens) {
+    *tokens = (const int32_t*)d->hTokens.p;
+  }
+  if (words) {
+    *words = d->kind == FLTX_DECODER_LEXICON ? (const int32_t*)d->hWords.p : nullptr;
+  }
+  if (offsets) {
+    *offsets = d->histOff.data();
   }
   return FLTX_OK;
 }

@@ -50,6 +50,21 @@ def main():
     print("%s batch=%d T=%d K=%d: engine %d threads %d, decode kernel %.2f ms, backtrace %.2f ms, "
           "wall/batch %.2f ms (incl. H2D), %.2f M frames/s (kernel)" %
           (name, B, c["T"], c["K"], d.get("engine"), d.get("threads"), k, b, min(ms), B * c["T"] / k / 1e3))
+    for rep in range(2 if os.environ.get("FLTX_E2E") else 0):  # host emissions in, every hypothesis out on the host
+        # (second repetition = steady state: the pinned staging buffers exist)
+        t0 = time.perf_counter()
+        d.decode_batch(e, Ts, c["N"])
+        t1 = time.perf_counter()
+        allh = d.results_batch()
+        nh = sum(len(h) for h in allh)
+        t2 = time.perf_counter()
+        t3 = time.perf_counter()
+        raw = d.fetch_batch_raw()
+        t4 = time.perf_counter()
+        print("  end to end #%d: H2D + kernels %.2f ms, + n-best of all utterances on the host (%d hypotheses as NumPy "
+              "views) %.2f ms => %.2f M frames/s; C-ABI fetch alone (already staged) %.3f ms" %
+              (rep, (t1 - t0) * 1e3, nh, (t2 - t0) * 1e3, B * c["T"] / (t2 - t0) / 1e6, (t4 - t3) * 1e3))
+        del raw
     ncpu = int(os.environ.get("FLTX_CPU", "0"))
     if ncpu > 0:  # reference (oracle/_ref) on the host, one thread, same utterances; n-best compared
         from oracle import orclib
