@@ -129,9 +129,12 @@ def fuzz_cases(n=36):
         out.append(case(
             "fuzz%02d" % i, kind=kind, dist=rnd.choice(["ctc", "uniform"]) if kind == "lexfree" else "lexspell",
             u=300 + i, T=rnd.choice([1, 9, 25, 41]), N=N, K=K, Kt=Kt, thr=rnd.choice([2.0, 8.0, 25.0, 100.0]),
-            lm_weight=rnd.choice([0.0, 0.5, 2.0]) if lm != "zero" else 0.0,
+            # (an LM that does not enter the score, or <unk> paths without an LM to tell them
+            # apart, produce equal-score hypotheses: the reference itself is then not a
+            # function of its inputs)
+            lm_weight=rnd.choice([0.5, 2.0]) if lm != "zero" else 0.0,
             word_score=rnd.choice([0.0, -1.0, 1.5]) if kind == "lexicon" else 0.0,
-            unk_score=rnd.choice([float("-inf"), -3.0]) if kind == "lexicon" else float("-inf"),
+            unk_score=rnd.choice([float("-inf"), -3.0]) if kind == "lexicon" and lm != "zero" else float("-inf"),
             sil_score=rnd.choice([0.0, -0.5, 0.3]), log_add=rnd.random() < 0.2,
             lexicon=SMALL_LEX if kind == "lexicon" else None, lm=lm,
             is_lm_token=(kind == "lexfree" and lm != "zero")))

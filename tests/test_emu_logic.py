@@ -68,6 +68,8 @@ def test_emulated_random_configurations_match_oracle(emu_session, oracle_lib, c)
     emulated kernels (small shapes only)."""
     inp = helpers.case_inputs(c)
     want = helpers.run_checker(oracle_lib, c, inp)
+    if len({h.score for h in want}) != len(want):
+        pytest.skip("equal scores in the n-best: the reference's own result is order dependent")
     got = emu_session.run(c, inp, threads=128 if c["kind"] == "lexfree" and c["N"] > 16 else 64)
     ok, why = helpers.hyps_equal(want, got, 1e-9 if c["log_add"] else 0.0)
     assert ok, "%s: %s" % ({k: c[k] for k in ("kind", "N", "K", "Kt", "thr", "lm", "log_add", "T")}, why)
