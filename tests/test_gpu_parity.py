@@ -310,3 +310,25 @@ def test_batched_result_fetch_equals_per_utterance_fetch(gpu_session, name):
         ok, why = helpers.hyps_equal(d.results(b), allh[b])
         assert ok, "utterance %d: %s" % (b, why)
     d.close()
+
+
+def test_partial_rerun_of_flagged_utterances(gpu_session, oracle_lib):
+    """With the score cut forced tight some utterances of a batch flag a frame
+    (fewer than K groups survived the cut) and only those are decoded again on
+    the general path; every utterance must still equal the oracle."""
+    from text_amd import synth
+    c = cases.BY_NAME["lx_scores_t50"]
+    inp = helpers.case_inputs(c)
+    lex = inp["lex"]
+    B = 8
+    embs = [synth.emissions(c["dist"], 800 + b, c["T"], c["N"], lexicon=lex) for b in range(B)]
+    flat = np.concatenate([e.reshape(-1) for e in embs])
+    d = gpu_session.decoder(c, inp)
+    d.set("cut_m", c["K"] + 1)
+    for _ in range(2):  # the second batch starts from the fast path again (or the sticky fallback): same results
+        d.decode_batch(flat, [c["T"]] * B, c["N"])
+        for b in range(B):
+            want = helpers.run_checker(oracle_lib, c, dict(inp, e=embs[b]))
+            ok, why = helpers.hyps_equal(want, d.results(b))
+            assert ok, "utterance %d: %s" % (b, why)
+    d.close()

@@ -279,6 +279,8 @@ struct fltx_decoder {
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   HBuf hTokens, hWords, hScores; /* fltx_result_fetch_batch */
+  DBuf uttMap;                   /* utterances of a partial re-run */
+  int nLaunch = 0;               /* workgroups of the next decode launch (0: all B) */
   std::vector<int32_t> hLen, hNHyp;
   bool hostFetched = false;
   int keepScores = 0;
@@ -1265,7 +1267,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   const DecodeParams* pp = &P;
   const int gmax = d->lean;
   const int gt = d->lane;
-  emuLaunch(d->B, W, d->wsInLds ? d->wsBytes : 16, [pp, gmax, gt](char* smem) {
+  emuLaunch(d->nLaunch > 0 ? d->nLaunch : d->B, W, d->wsInLds ? d->wsBytes : 16, [pp, gmax, gt](char* smem) {
     char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
     if (gt == 4) {
       decodeUtterance<1, 4>(*pp, base);
@@ -1287,24 +1289,25 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     }
   }
   HIPCHK(hipEventRecord(d->ev[0], d->ctx->stream));
+  const int nGrid = d->nLaunch > 0 ? d->nLaunch : d->B;
 #define FLTX_LAUNCH_LDS(WW, GG)                                                                  \
   do {                                                                                           \
     HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lds<WW, GG>,                      \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
-    hipLaunchKernelGGL((fltx_decode_kernel_lds<WW, GG>), dim3(d->B), dim3(WW), d->wsBytes,       \
+    hipLaunchKernelGGL((fltx_decode_kernel_lds<WW, GG>), dim3(nGrid), dim3(WW), d->wsBytes,      \
                        d->ctx->stream, P);                                                       \
   } while (0)
 #define FLTX_LAUNCH_LANE(WW, GG)                                                                 \
   do {                                                                                           \
     HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lane<WW, GG>,                     \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
-    hipLaunchKernelGGL((fltx_decode_kernel_lane<WW, GG>), dim3(d->B), dim3(WW), d->wsBytes,      \
+    hipLaunchKernelGGL((fltx_decode_kernel_lane<WW, GG>), dim3(nGrid), dim3(WW), d->wsBytes,     \
                        d->ctx->stream, P);                                                       \
   } while (0)
 #define FLTX_LAUNCH(WW)                                                                          \
   do {                                                                                           \
     if (!d->wsInLds) {                                                                           \
-      hipLaunchKernelGGL(fltx_decode_kernel_gws<WW>, dim3(d->B), dim3(WW), 0, d->ctx->stream, P); \
+      hipLaunchKernelGGL(fltx_decode_kernel_gws<WW>, dim3(nGrid), dim3(WW), 0, d->ctx->stream, P); \
     } else if (d->lane == 4) {                                                                   \
       FLTX_LAUNCH_LANE(WW, 4);                                                                   \
     } else if (d->lane == 8) {                                                                   \
@@ -1489,6 +1492,14 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   d->resultsSynced = false;
   d->backtraced = false;
   d->hostFetched = false;
+  /* The optimistic fast paths (LDS-sized candidate lists of the lexicon
+   * decoder, the score cut, the one-pass histogram select of the lean / lane
+   * steps) flag the rare utterance they cannot serve.  Only those utterances
+   * are decoded again, on the general path (HBM workspace / no cut / generic
+   * engine); the others keep their results.  The fallback sticks to the decoder
+   * only when a large part of the batch needed it. */
+  std::vector<int32_t> redoList;
+  const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean;
   for (int attempt = 0; attempt < 2; ++attempt) {
     int rc = prepare(d, B, N, T, attempt == 1);
     if (rc) {
@@ -1504,41 +1515,54 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     }
     P.doBegin = 1;
     P.doEnd = 1;
-    if ((rc = launchDecode(d, P))) {
+    d->nLaunch = 0;
+    if (attempt == 1) {
+      if (d->uttMap.ensure(4 * redoList.size(), d->ctx->stream, false) ||
+          devCopyH2D(d->uttMap.p, redoList.data(), 4 * redoList.size(), d->ctx->stream)) {
+        return fail(FLTX_ERR_OOM, "re-run list upload failed");
+      }
+      P.uttMap = d->uttMap.as<int32_t>();
+      d->nLaunch = (int)redoList.size();
+    }
+    rc = launchDecode(d, P);
+    d->nLaunch = 0;
+    if (rc) {
       return rc;
     }
     if (attempt == 0 && ((d->kind == FLTX_DECODER_LEXICON && d->wsInLds) || d->lean)) {
-      /* optimistic fast paths: the LDS sizing of the lexicon decoder assumes a
-       * sparse trie fan-out, and the lean lexicon-free step assumes the K-th
-       * best score can be isolated by one histogram pass.  Both flag the rare
-       * miss; redo the batch on the general path (HBM workspace / generic
-       * engine), which has no such assumption. */
       d->resultsSynced = false;
       if ((rc = syncResults(d))) {
         return rc;
       }
-      bool redo = false;
+      bool ws = false, cut = false, lean = false;
       for (int b = 0; b < B; ++b) {
-        if ((d->hStatus[b] & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON) {
-          d->forceGlobalWs = 1;
-          redo = true;
-        }
-        if ((d->hStatus[b] & ST_CUT_RETRY) && d->CAP2) { /* the score cut left fewer than K groups */
-          d->noCut = 1;
-          redo = true;
-        }
-        if ((d->hStatus[b] & ST_SELECT_FALLBACK) && d->lean) {
-          d->noLean = 1;
-          redo = true;
+        const int st = d->hStatus[b];
+        const bool o = (st & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON;
+        const bool c = (st & ST_CUT_RETRY) && d->CAP2;
+        const bool l = (st & ST_SELECT_FALLBACK) && d->lean;
+        if (o || c || l) {
+          redoList.push_back(b);
+          ws |= o;
+          cut |= c;
+          lean |= l;
         }
       }
-      if (redo) {
+      if (!redoList.empty()) {
+        d->forceGlobalWs = ws ? 1 : d->forceGlobalWs;
+        d->noCut = cut ? 1 : d->noCut;
+        d->noLean = lean ? 1 : d->noLean;
         d->resultsSynced = false;
         continue;
       }
     }
     break;
   }
+  if (!redoList.empty() && (int)redoList.size() * 4 <= B) { /* a few outliers: next batch tries the fast path again */
+    d->forceGlobalWs = savedGlobalWs;
+    d->noCut = savedNoCut;
+    d->noLean = savedNoLean;
+  }
+  d->resultsSynced = false;
   int rc = launchBacktrace(d);
   if (rc) {
     return rc;

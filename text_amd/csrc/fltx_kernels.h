@@ -118,6 +118,7 @@ struct DecodeParams {
   const float* emissions;
   const int64_t* emOff;
   const int32_t* stepT;
+  const int32_t* uttMap; /* utterance handled by workgroup i (a partial re-run), or null: workgroup i = utterance i */
   int32_t doBegin, doEnd;
   /* persistent per-utterance state (HBM) */
   int32_t* uttNBeam;
@@ -2397,7 +2398,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 /* ------------------------------------------------------------------------ */
 template <int GMAX, int GT = 0>
 FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
-  const int b = (int)blockIdx.x;
+  const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
