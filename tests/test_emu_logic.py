@@ -73,3 +73,23 @@ def test_emulated_random_configurations_match_oracle(emu_session, oracle_lib, c)
     got = emu_session.run(c, inp, threads=128 if c["kind"] == "lexfree" and c["N"] > 16 else 64)
     ok, why = helpers.hyps_equal(want, got, 1e-9 if c["log_add"] else 0.0)
     assert ok, "%s: %s" % ({k: c[k] for k in ("kind", "N", "K", "Kt", "thr", "lm", "log_add", "T")}, why)
+
+
+@pytest.mark.parametrize("name", ["lf_ctc_n29_k65", "lf_ctc_n29_k64", "lf_ctc_t60_k10_logadd"])
+def test_emulated_streaming_lean_step(emu_session, golden, name):
+    """Big beams: more groups per thread than the register-resident lean step
+    holds (one wave, beam 64 / 65 x 29 tokens => 30 groups per thread): groups
+    are evaluated twice instead (fltx_lean.h, GMAX == 255)."""
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    d = emu_session.decoder(c, inp, 64)
+    d.set("lane", 0)
+    if c["K"] < 30:
+        d.set("threads", 64)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    lean = d.get("lean")
+    tol = 1e-9 if c["log_add"] else 0.0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
+    d.close()
+    assert lean == (255 if c["K"] >= 30 else 6)
+    assert ok, why

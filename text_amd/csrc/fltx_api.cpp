@@ -888,6 +888,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0));
   } else if (!strcmp(key, "lane")) {
     *value = d->lane;
+  } else if (!strcmp(key, "lean")) {
+    *value = d->lean; /* groups per thread kept in registers: 6 / 12, or 255 = streaming */
   } else if (!strcmp(key, "threads")) {
     *value = d->threads;
   } else if (!strcmp(key, "lds")) {
@@ -1028,7 +1030,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (d->dense && !d->noLean && !d->forceGlobalWs && d->lm->kind == 0 && K < 32000 && N <= 64) {
     const int64_t groups = (int64_t)K * (nTok + 1);
     const int64_t per = (groups + d->threads - 1) / d->threads;
-    d->lean = per <= 6 ? 6 : (per <= 12 ? 12 : 0);
+    d->lean = per <= 6 ? 6 : (per <= 12 ? 12 : 255); /* 255: streaming lean step (groups evaluated twice) */
   }
   /* lane-per-slot frame step (fltx_lane.h): beam and token set fit one wave's lanes */
   d->lane = 0;
@@ -1037,17 +1039,30 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const int per = (N + nW - 1) / nW;
     d->lane = per <= 4 ? 4 : (per <= 8 ? 8 : 0);
   }
+  if (d->lean && !d->lane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
+    Ws t2;
+    const size_t need = carveWs(t2, nullptr, K, 1, 64, 1024, N, K + 256, 2, 0, 0, 0, d->threads / 64);
+    if (need > kMaxLds) {
+      d->lean = 0;
+    }
+  }
+  if (d->lean) {
+    d->dense = 2; /* lean-only workspace layout (carveWs) */
+  }
   int64_t worst = d->kind == FLTX_DECODER_LEXFREE ? (int64_t)K * (nTok + (d->dense ? 1 : 0))
                                                   : (int64_t)K * ((int64_t)nTok * 8 + 2);
-  if (d->lean) {
-    worst = K; /* no candidate records at all */
-  }
   worst = std::max<int64_t>(worst, K);
+  if (d->lean) {
+    worst = 1; /* no candidate records at all */
+  }
   int64_t capC = worst;
   d->NB = 1024;
   d->SCAP = K + 256;
   Ws tmp;
   auto hsFor = [&](int64_t c) {
+    if (d->lean) {
+      return 64; /* the merge hash is not used */
+    }
     int64_t keys = d->dense ? K : c;
     return std::max((int)nextPow2((uint64_t)keys * 2), 64);
   };
@@ -1277,6 +1292,8 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       decodeUtterance<6>(*pp, base);
     } else if (gmax == 12) {
       decodeUtterance<12>(*pp, base);
+    } else if (gmax == 255) {
+      decodeUtterance<255>(*pp, base);
     } else {
       decodeUtterance<0>(*pp, base);
     }
@@ -1316,6 +1333,8 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       FLTX_LAUNCH_LDS(WW, 6);                                                                    \
     } else if (d->lean == 12) {                                                                  \
       FLTX_LAUNCH_LDS(WW, 12);                                                                   \
+    } else if (d->lean == 255) {                                                                 \
+      FLTX_LAUNCH_LDS(WW, 255);                                                                  \
     } else {                                                                                     \
       FLTX_LAUNCH_LDS(WW, 0);                                                                    \
     }                                                                                            \

@@ -293,6 +293,9 @@ struct LaneLds {
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
                        int dense, int lane, int CAP2 = 0, int itemCap = 0, int nWaves = 16) {
   size_t off = 0;
+  /* dense == 2: the lean / lane steps only -- no candidate records, no LM / lexicon
+   * fields of the beam, none of the generic select's tables */
+  const bool leanOnly = dense == 2; /* (the host then passes CAP = 1, HS = 64) */
   LaneLds* const LL = (lane && base) ? (LaneLds*)base : nullptr;
   if (lane) {
     off = alignUp(sizeof(LaneLds), 16);
@@ -310,13 +313,13 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   }
   FLTX_CARVE_L(w.bScore, double, 2 * K, bScore)
   FLTX_CARVE_L(w.bAm, double, 2 * K, bAm)
-  FLTX_CARVE(w.bLm, double, 2 * K)
+  FLTX_CARVE(w.bLm, double, leanOnly ? 0 : 2 * K)
   FLTX_CARVE_L(w.bState, uint32_t, 2 * K, bState)
   FLTX_CARVE_L(w.bSPar, uint32_t, 2 * K, bSPar)
   FLTX_CARVE_L(w.bSEdge, int32_t, 2 * K, bSEdge)
-  FLTX_CARVE(w.bLex, uint32_t, 2 * K)
+  FLTX_CARVE(w.bLex, uint32_t, leanOnly ? 0 : 2 * K)
   FLTX_CARVE_L(w.bTokPb, uint32_t, 2 * K, bTokPb)
-  FLTX_CARVE(w.bLexMax, float, 2 * K)
+  FLTX_CARVE(w.bLexMax, float, leanOnly ? 0 : 2 * K)
   FLTX_CARVE(w.erow, float, 2 * N)
   FLTX_CARVE(w.cScore, double, CAP)
   FLTX_CARVE(w.cKey, uint4, CAP)
@@ -342,9 +345,9 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE_L(w.sIdx, uint32_t, SCAP, sIdx)
   FLTX_CARVE_L(w.sSrc, uint32_t, SCAP, sSrc)
   FLTX_CARVE_L(w.sEnt, uint4, SCAP, sEnt)
-  FLTX_CARVE(w.sBin, uint32_t, (dense && !lane) ? SCAP : 0)
-  FLTX_CARVE(w.sNext, uint32_t, (dense && !lane) ? SCAP : 0)
-  FLTX_CARVE(w.bhead, uint32_t, (dense && !lane) ? NB + NB / 16 + 1 : 0)
+  FLTX_CARVE(w.sBin, uint32_t, 0)
+  FLTX_CARVE(w.sNext, uint32_t, 0)
+  FLTX_CARVE(w.bhead, uint32_t, 0)
   FLTX_CARVE(w.hcum, uint32_t, lane ? 0 : NB + NB / 16 + 1)
   FLTX_CARVE(w.dKid, int16_t, dense ? (size_t)K * N : 0)
   FLTX_CARVE_L(w.bMask, unsigned long long, dense ? 2 * K : 0, bMask)
@@ -355,8 +358,8 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.relTab, unsigned long long, lane ? (size_t)K * (N + 1) : 0)
   FLTX_CARVE_L(w.repTab, unsigned long long, lane ? K : 0, repTab)
   FLTX_CARVE_L(w.bRec, uint4, lane ? 2 * K : 0, bRec)
-  FLTX_CARVE(w.wcum, uint32_t, nWaves * 256)
-  FLTX_CARVE_L(w.tick, uint32_t, 512, tick)
+  FLTX_CARVE(w.wcum, uint32_t, (leanOnly && !lane) ? 0 : nWaves * 256)
+  FLTX_CARVE_L(w.tick, uint32_t, (leanOnly && !lane) ? 0 : 512, tick)
   FLTX_CARVE(w.pMate, int32_t, (dense && !lane) ? 16 * 64 : 0)
   FLTX_CARVE(w.pPar, int32_t, (dense && !lane) ? 16 * 64 : 0)
   FLTX_CARVE(w.surv, uint32_t, K)
@@ -2421,12 +2424,18 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
     if (tid == 0) {
       w.bScore[(0) * P.K + 0] = 0.0;
       w.bAm[(0) * P.K + 0] = 0.0;
-      w.bLm[(0) * P.K + 0] = 0.0;
+      if constexpr (GMAX == 0) {
+        w.bLm[(0) * P.K + 0] = 0.0;
+      }
       w.bState[(0) * P.K + 0] = 0u;
       w.bSPar[(0) * P.K + 0] = kNoParent;
       w.bSEdge[(0) * P.K + 0] = 0;
-      w.bLex[(0) * P.K + 0] = 0u;
-      w.bLexMax[0] = 0.0f;
+      if constexpr (GMAX == 0) {
+        w.bLex[(0) * P.K + 0] = 0u;
+      }
+      if constexpr (GMAX == 0) {
+        w.bLexMax[0] = 0.0f;
+      }
       w.bTokPb[(0) * P.K + 0] = (uint32_t)P.sil;
       if constexpr (GMAX > 0) {
         w.bMask[0] = 0ull;
@@ -2465,12 +2474,18 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
       const size_t g = (size_t)b * P.K + i;
       w.bScore[(0) * P.K + i] = P.gScore[g];
       w.bAm[(0) * P.K + i] = P.gAm[g];
-      w.bLm[(0) * P.K + i] = P.gLm[g];
+      if constexpr (GMAX == 0) {
+        w.bLm[(0) * P.K + i] = P.gLm[g];
+      }
       w.bState[(0) * P.K + i] = P.gState[g];
       w.bSPar[(0) * P.K + i] = P.gSPar[g];
       w.bSEdge[(0) * P.K + i] = P.gSEdge[g];
-      w.bLex[(0) * P.K + i] = P.gLex[g];
-      w.bLexMax[i] = P.gLexMax[g];
+      if constexpr (GMAX == 0) {
+        w.bLex[(0) * P.K + i] = P.gLex[g];
+      }
+      if constexpr (GMAX == 0) {
+        w.bLexMax[i] = P.gLexMax[g];
+      }
       w.bTokPb[(0) * P.K + i] = P.gTokPb[g];
       if constexpr (GMAX > 0) {
         w.bMask[i] = P.gMask[g];
@@ -2530,8 +2545,8 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
   for (int q = 0; q < 8; ++q) {
     f.acc[q] = 0ull;
   }
-  LeanMap<(GMAX > 0 ? GMAX : 1)> lmap;
-  if constexpr (GMAX > 0 && GT == 0) {
+  LeanMap<(GMAX > 0 && GMAX < 255 ? GMAX : 1)> lmap; /* GMAX == 255: streaming lean step, no per-thread map */
+  if constexpr (GMAX > 0 && GMAX < 255 && GT == 0) {
     leanMapInit(P, nTok, lmap);
   }
   for (int t = 0; t < T; ++t) {

@@ -197,7 +197,8 @@ FLTX_DEV void leanEval(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
 }
 
 template <int GMAX>
-FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const LeanMap<GMAX>& map,
+FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
+                          const LeanMap<(GMAX < 255 ? GMAX : 1)>& map,
                           int frameOut) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
@@ -334,24 +335,43 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
   }
   const double best = f64FromKey(w.red[0]);
   const double thr = best - P.beamThreshold;
-  /* ---- phase B: evaluate my groups into registers, bin them ------------------ */
-  LeanGroup grp[GMAX];
-  int bins[GMAX];
+  /* ---- phase B: evaluate my groups, bin them ---------------------------------- */
+  /* GMAX < 255: the <= GMAX groups of a thread stay in registers through the
+   * prune.  GMAX == 255 ("streaming", big beams): any number of groups per
+   * thread; a group is evaluated here for the histogram and evaluated AGAIN in
+   * phase D if its bin made the short-list -- twice the arithmetic, no
+   * registers, no candidate records (K = 500 x 29 tokens would otherwise need
+   * the 800 KB record workspace in HBM). */
+  constexpr bool STREAM = GMAX == 255;
+  constexpr int GR = STREAM ? 1 : GMAX;
+  LeanGroup grp[GR];
+  int bins[GR];
   double lo = thr;
   const bool wide = !(best - thr < 1e6); /* threshold too wide for useful bins */
-#pragma unroll
-  for (int j = 0; j < GMAX; ++j) {
-    leanEval(P, w, f, map.kind[j], map.rep[j], map.r[j], thr, grp[j]);
-  }
-  if (wide) {
-    double mn = __builtin_huge_val();
+  const int nGall = K * f.nTok + K; /* (state, token) groups, then one orphan-repeat slot per hypothesis */
+  const int dRep_ = W / f.nTok, dR_ = W - dRep_ * f.nTok; /* streaming: (rep, r) advance per W groups */
+  if constexpr (!STREAM) {
 #pragma unroll
     for (int j = 0; j < GMAX; ++j) {
-      if (grp[j].valid && grp[j].s > -__builtin_huge_val()) {
-        mn = grp[j].s < mn ? grp[j].s : mn;
-      }
+      leanEval(P, w, f, map.kind[j], map.rep[j], map.r[j], thr, grp[j]);
     }
-    lo = blockMinF64(P, mn, &w.red[1]);
+  }
+  if (wide) {
+    if constexpr (STREAM) {
+      if (tid == 0) { /* the general path handles unbounded thresholds */
+        atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_SELECT_FALLBACK);
+      }
+      return 0;
+    } else {
+      double mn = __builtin_huge_val();
+#pragma unroll
+      for (int j = 0; j < GMAX; ++j) {
+        if (grp[j].valid && grp[j].s > -__builtin_huge_val()) {
+          mn = grp[j].s < mn ? grp[j].s : mn;
+        }
+      }
+      lo = blockMinF64(P, mn, &w.red[1]);
+    }
   }
   /* Two-segment monotone binning of d = best - score over [0, range]: the
    * K-th best score is what the histogram has to isolate, so the part of the
@@ -374,16 +394,36 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
     sF = 0.0;
     sC = 0.0;
   }
+  auto binOf = [&](double sc) {
+    const double d = best - sc;
+    const double x = d < cut ? d * sF : (double)NF + (d - cut) * sC;
+    int bin = (x < (double)P.NB) ? (int)x : P.NB - 1; /* also catches inf / NaN */
+    return bin < 0 ? 0 : bin;
+  };
+  if constexpr (STREAM) {
+    int rep = tid / f.nTok, r = tid - rep * f.nTok;
+    for (int g = tid; g < nGall; g += W) {
+      const int nG0 = K * f.nTok;
+      LeanGroup x;
+      leanEval(P, w, f, g < nG0 ? 1 : 2, g < nG0 ? rep : g - nG0, r, thr, x);
+      if (x.valid) {
+        atomAdd32(&w.hist[FLTX_HB(binOf(x.s))], 1u);
+      }
+      rep += dRep_;
+      r += dR_;
+      if (r >= f.nTok) {
+        r -= f.nTok;
+        rep += 1;
+      }
+    }
+  } else {
 #pragma unroll
-  for (int j = 0; j < GMAX; ++j) {
-    bins[j] = 0;
-    if (grp[j].valid) {
-      const double d = best - grp[j].s;
-      const double x = d < cut ? d * sF : (double)NF + (d - cut) * sC;
-      int bin = (x < (double)P.NB) ? (int)x : P.NB - 1; /* also catches inf / NaN */
-      bin = bin < 0 ? 0 : bin;
-      bins[j] = bin;
-      atomAdd32(&w.hist[FLTX_HB(bin)], 1u);
+    for (int j = 0; j < GMAX; ++j) {
+      bins[j] = 0;
+      if (grp[j].valid) {
+        bins[j] = binOf(grp[j].s);
+        atomAdd32(&w.hist[FLTX_HB(bins[j])], 1u);
+      }
     }
   }
   FLTX_PROF(1);
@@ -434,15 +474,39 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f, const
   /* ---- phase D: counting sort of the short-list by bin ---------------------------- */
   /* position = (candidates in better bins) + a ticket inside the bin; the bin's
    * count in hist[] doubles as the ticket counter (counted down) */
+  auto scatter = [&](const LeanGroup& x, int bin, int g) {
+    const int hb = FLTX_HB(bin);
+    const uint32_t p = w.hcum[hb] + (atomAdd32(&w.hist[hb], 0xFFFFFFFFu) - 1u);
+    const unsigned long long key = f64Key(x.s);
+    w.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), x.ord, (uint32_t)bin);
+    w.sIdx[p] = (uint32_t)g;
+    w.sSrc[p] = x.src;
+  };
+  if constexpr (STREAM) {
+    int rep = tid / f.nTok, r = tid - rep * f.nTok;
+    for (int g = tid; g < nGall; g += W) {
+      const int nG0 = K * f.nTok;
+      LeanGroup x;
+      leanEval(P, w, f, g < nG0 ? 1 : 2, g < nG0 ? rep : g - nG0, r, thr, x);
+      if (x.valid) {
+        const int bin = binOf(x.s);
+        if (bin <= bstar) {
+          scatter(x, bin, g);
+        }
+      }
+      rep += dRep_;
+      r += dR_;
+      if (r >= f.nTok) {
+        r -= f.nTok;
+        rep += 1;
+      }
+    }
+  } else {
 #pragma unroll
-  for (int j = 0; j < GMAX; ++j) {
-    if (grp[j].valid && bins[j] <= bstar) {
-      const int hb = FLTX_HB(bins[j]);
-      const uint32_t p = w.hcum[hb] + (atomAdd32(&w.hist[hb], 0xFFFFFFFFu) - 1u);
-      const unsigned long long key = f64Key(grp[j].s);
-      w.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), grp[j].ord, (uint32_t)bins[j]);
-      w.sIdx[p] = (uint32_t)(j * W + tid);
-      w.sSrc[p] = grp[j].src;
+    for (int j = 0; j < GMAX; ++j) {
+      if (grp[j].valid && bins[j] <= bstar) {
+        scatter(grp[j], bins[j], j * W + tid);
+      }
     }
   }
   ldsBarrier(); /* 5 */
