@@ -93,3 +93,20 @@ def test_emulated_streaming_lean_step(emu_session, golden, name):
     d.close()
     assert lean == (255 if c["K"] >= 30 else 6)
     assert ok, why
+
+
+def test_emulated_streaming_lean_step_over_hbm_workspace(emu_session, oracle_lib):
+    """A lexicon-free beam too large for a CU's LDS (700 x 29 tokens): the
+    streaming lean step runs over the HBM workspace with agent-scope barriers."""
+    from text_amd import synth
+    c = cases.case("bigbeam", T=12, N=29, K=700, u=21)
+    e = synth.emissions("ctc", c["u"], c["T"], c["N"])
+    d = emu_session.decoder(c, dict(tr=None), 64)
+    d.decode_batch(e, [c["T"]], c["N"])
+    assert d.get("lean") == 255 and d.get("lds") == 0
+    want = helpers.run_checker(oracle_lib, c, dict(e=e, tr=None, lex=None))
+    got = d.results(0)
+    d.close()
+    if len({h.score for h in want}) == len(want):
+        ok, why = helpers.hyps_equal(want, got)
+        assert ok, why

@@ -332,3 +332,21 @@ def test_partial_rerun_of_flagged_utterances(gpu_session, oracle_lib):
             ok, why = helpers.hyps_equal(want, d.results(b))
             assert ok, "utterance %d: %s" % (b, why)
     d.close()
+
+
+@pytest.mark.parametrize("K,T,dist", [(700, 40, "ctc"), (1500, 25, "ctc"), (600, 30, "uniform")])
+def test_big_lexicon_free_beams(gpu_session, oracle_lib, K, T, dist):
+    """Beams beyond what fits a CU's LDS: streaming lean step over the HBM workspace."""
+    from text_amd import synth
+    c = cases.case("bigbeam", dist=dist, T=T, N=29, K=K, u=23)
+    e = synth.emissions(dist, c["u"], T, c["N"])
+    d = gpu_session.decoder(c, dict(tr=None))
+    d.decode_batch(e, [T], c["N"])
+    assert d.get("lean") == 255 and d.get("lds") == 0
+    want = helpers.run_checker(oracle_lib, c, dict(e=e, tr=None, lex=None))
+    got = d.results(0)
+    d.close()
+    if len({h.score for h in want}) != len(want):
+        pytest.skip("equal scores in the n-best")
+    ok, why = helpers.hyps_equal(want, got)
+    assert ok, why

@@ -41,6 +41,11 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
   decodeUtterance<1, GT>(P, fltx_smem);
 }
 template <int W>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) { /* streaming lean step, HBM workspace */
+  extern __shared__ __attribute__((aligned(16))) char fltx_hot[]; /* histogram & block scalars stay in LDS */
+  decodeUtterance<255>(P, P.gws + (size_t)blockIdx.x * P.gwsStride, fltx_hot);
+}
+template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gws(DecodeParams P) {
   decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
 }
@@ -267,6 +272,7 @@ struct fltx_decoder {
   int CAP = 0, HS = 0, NB = 0, SCAP = 0, dense = 0, noDense = 0;
   int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
+  size_t hotBytes = 0; /* LDS part of a split (HBM + LDS) lean workspace */
   int itemCap = 0, noItems = 0; /* lexicon decoder: list of existing (hypothesis, token) children */
   int CAP2 = 0, cutM = 0, noCut = 0, userCutM = 0; /* lexicon decoder: slim score-pass list + cut-off (runFrame) */
   size_t wsBytes = 0;
@@ -1027,6 +1033,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   /* lean frame step (fltx_lean.h): lexicon-free + ZeroLM, groups held in registers */
   d->lean = 0;
+  bool leanInHbm = false;
   if (d->dense && !d->noLean && !d->forceGlobalWs && d->lm->kind == 0 && K < 32000 && N <= 64) {
     const int64_t groups = (int64_t)K * (nTok + 1);
     const int64_t per = (groups + d->threads - 1) / d->threads;
@@ -1043,7 +1050,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     Ws t2;
     const size_t need = carveWs(t2, nullptr, K, 1, 64, 1024, N, K + 256, 2, 0, 0, 0, d->threads / 64);
     if (need > kMaxLds) {
-      d->lean = 0;
+      d->lean = 255; /* too big for LDS: the streaming step over an HBM workspace (leanBarrier) */
+      leanInHbm = true;
     }
   }
   if (d->lean) {
@@ -1077,7 +1085,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->lane, 0, d->itemCap,
                    d->threads / 64);
   };
-  bool lds = !d->forceGlobalWs;
+  bool lds = !d->forceGlobalWs && !leanInHbm;
   d->CAP2 = 0;
   d->cutM = 0;
   const bool forceCut = d->userCutM > 0 && d->kind == FLTX_DECODER_LEXICON && !forceWorstCaseCap; /* tests */
@@ -1135,8 +1143,14 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (!lds) {
     d->itemCap = 0;
   }
-  d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap,
-                       d->threads / 64);
+  d->hotBytes = 0;
+  if (leanInHbm) {
+    d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap,
+                         d->threads / 64, true, nullptr, &d->hotBytes);
+  } else {
+    d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap,
+                         d->threads / 64);
+  }
   d->wsInLds = lds;
   /* buffers */
   bool grewTab = false;
@@ -1282,8 +1296,14 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   const DecodeParams* pp = &P;
   const int gmax = d->lean;
   const int gt = d->lane;
-  emuLaunch(d->nLaunch > 0 ? d->nLaunch : d->B, W, d->wsInLds ? d->wsBytes : 16, [pp, gmax, gt](char* smem) {
+  const bool hot = !d->wsInLds && d->hotBytes > 0;
+  emuLaunch(d->nLaunch > 0 ? d->nLaunch : d->B, W, d->wsInLds ? d->wsBytes : (hot ? d->hotBytes : 16),
+            [pp, gmax, gt, hot](char* smem) {
     char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
+    if (hot) {
+      decodeUtterance<255>(*pp, base, smem);
+      return;
+    }
     if (gt == 4) {
       decodeUtterance<1, 4>(*pp, base);
     } else if (gt == 8) {
@@ -1323,7 +1343,9 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   } while (0)
 #define FLTX_LAUNCH(WW)                                                                          \
   do {                                                                                           \
-    if (!d->wsInLds) {                                                                           \
+    if (!d->wsInLds && d->lean) {                                                                \
+      hipLaunchKernelGGL(fltx_decode_kernel_gwslean<WW>, dim3(nGrid), dim3(WW), d->hotBytes, d->ctx->stream, P); \
+    } else if (!d->wsInLds) {                                                                    \
       hipLaunchKernelGGL(fltx_decode_kernel_gws<WW>, dim3(nGrid), dim3(WW), 0, d->ctx->stream, P); \
     } else if (d->lane == 4) {                                                                   \
       FLTX_LAUNCH_LANE(WW, 4);                                                                   \

@@ -291,8 +291,14 @@ struct LaneLds {
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
-                       int dense, int lane, int CAP2 = 0, int itemCap = 0, int nWaves = 16) {
+                       int dense, int lane, int CAP2 = 0, int itemCap = 0, int nWaves = 16,
+                       bool splitHot = false, char* hotBase = nullptr, size_t* hotBytes = nullptr) {
   size_t off = 0;
+  /* splitHot: the workspace proper lives in HBM, but the small arrays every
+   * thread hammers with atomics or re-reads all the time (histogram, its
+   * prefixes, block scalars, the emission row) are carved from `hotBase` (LDS):
+   * a hot L2 atomic costs hundreds of clocks, an LDS one tens */
+  size_t offHot = 0;
   /* dense == 2: the lean / lane steps only -- no candidate records, no LM / lexicon
    * fields of the beam, none of the generic select's tables */
   const bool leanOnly = dense == 2; /* (the host then passes CAP = 1, HS = 64) */
@@ -304,6 +310,14 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   off = alignUp(off, 16);                                    \
   field = (type*)(base ? base + off : nullptr);              \
   off += sizeof(type) * (size_t)(count);
+#define FLTX_CARVE_H(field, type, count)                     \
+  if (splitHot) {                                            \
+    offHot = alignUp(offHot, 16);                            \
+    field = (type*)(hotBase ? hotBase + offHot : nullptr);   \
+    offHot += sizeof(type) * (size_t)(count);                \
+  } else {                                                   \
+    FLTX_CARVE(field, type, count)                           \
+  }
   /* a field of the fixed lane block in lane mode, carved like the rest otherwise */
 #define FLTX_CARVE_L(field, type, count, member)             \
   if (lane) {                                                \
@@ -320,7 +334,7 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.bLex, uint32_t, leanOnly ? 0 : 2 * K)
   FLTX_CARVE_L(w.bTokPb, uint32_t, 2 * K, bTokPb)
   FLTX_CARVE(w.bLexMax, float, leanOnly ? 0 : 2 * K)
-  FLTX_CARVE(w.erow, float, 2 * N)
+  FLTX_CARVE_H(w.erow, float, 2 * N)
   FLTX_CARVE(w.cScore, double, CAP)
   FLTX_CARVE(w.cKey, uint4, CAP)
   FLTX_CARVE(w.cSrc, uint32_t, CAP)
@@ -348,7 +362,7 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.sBin, uint32_t, 0)
   FLTX_CARVE(w.sNext, uint32_t, 0)
   FLTX_CARVE(w.bhead, uint32_t, 0)
-  FLTX_CARVE(w.hcum, uint32_t, lane ? 0 : NB + NB / 16 + 1)
+  FLTX_CARVE_H(w.hcum, uint32_t, lane ? 0 : NB + NB / 16 + 1)
   FLTX_CARVE(w.dKid, int16_t, dense ? (size_t)K * N : 0)
   FLTX_CARVE_L(w.bMask, unsigned long long, dense ? 2 * K : 0, bMask)
   FLTX_CARVE_L(w.addMask, unsigned long long, dense ? K : 0, addMask)
@@ -366,14 +380,26 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE_L(w.dMate, int32_t, dense ? K : 0, dMate)
   FLTX_CARVE_L(w.dPar, int32_t, dense ? K : 0, dPar)
   FLTX_CARVE(w.dRep, int16_t, (dense && !lane) ? (size_t)K * N : 0)
-  FLTX_CARVE(w.dIn, uint8_t, N)
-  FLTX_CARVE_L(w.hist, uint32_t, NB + NB / 16 + 1, hist)
-  FLTX_CARVE(w.tokIdx, int32_t, N)
-  FLTX_CARVE(w.wtmp, uint32_t, 32)
-  FLTX_CARVE(w.red, unsigned long long, 4)
-  FLTX_CARVE_L(w.sc, int32_t, 16, sc)
+  FLTX_CARVE_H(w.dIn, uint8_t, N)
+  if (splitHot) {
+    FLTX_CARVE_H(w.hist, uint32_t, NB + NB / 16 + 1)
+  } else {
+    FLTX_CARVE_L(w.hist, uint32_t, NB + NB / 16 + 1, hist)
+  }
+  FLTX_CARVE_H(w.tokIdx, int32_t, N)
+  FLTX_CARVE_H(w.wtmp, uint32_t, 32)
+  FLTX_CARVE_H(w.red, unsigned long long, 4)
+  if (splitHot) {
+    FLTX_CARVE_H(w.sc, int32_t, 16)
+  } else {
+    FLTX_CARVE_L(w.sc, int32_t, 16, sc)
+  }
 #undef FLTX_CARVE_L
+#undef FLTX_CARVE_H
 #undef FLTX_CARVE
+  if (hotBytes) {
+    *hotBytes = alignUp(offHot, 16);
+  }
   return alignUp(off, 16);
 }
 
@@ -395,15 +421,19 @@ FLTX_HD uint32_t hashKey(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
 /* Workgroup barrier for code whose workspace may live in HBM (big beams).
  * There the counters and hash heads are updated with L2 atomics, which do not
  * refresh this CU's vector L1, so a plain load after the barrier could hit a
- * stale line: make the barrier an agent-scope release/acquire (buffer_wbl2 +
- * buffer_inv, ~3.5 us -- only the slow big-beam path pays it).  With the
+ * stale line: after the barrier the L1 is invalidated (agent-scope acquire,
+ * buffer_inv).  The release side only has to get this wave's stores to the L2
+ * (workgroup scope: vmcnt wait; the L1 is write-through) -- every wave of a
+ * workgroup sits on the same CU and therefore behind the same L2, so the
+ * agent-scope release (buffer_wbl2: write the whole L2's dirty lines back to
+ * HBM, tens of microseconds with 32 workgroups dirtying it) is not needed.  With the
  * workspace in LDS it waits for this wave's LDS operations only (ldsBarrier):
  * __syncthreads() would also drain the global loads of the emission-row
  * prefetch (~2k clocks) and the history stores at every barrier. */
 FLTX_DEV void wsBarrier(const DecodeParams& P) {
 #ifndef FLTX_EMU
   if (P.gws != nullptr) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* my stores are in L2 */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* my stores are in L2 */
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return;
@@ -418,7 +448,7 @@ FLTX_DEV void wsBarrier(const DecodeParams& P) {
 FLTX_DEV void wsBarrierMem(const DecodeParams& P) {
 #ifndef FLTX_EMU
   if (P.gws != nullptr) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* my stores are in L2 */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* my stores are in L2 */
     __syncthreads();
     /* invalidate AFTER the barrier: the L1 is shared by the waves of the CU, so
      * a wave that is still loading before its barrier can re-populate lines
@@ -2400,12 +2430,13 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 /* with up to GMAX candidate groups per thread (fltx_lean.h).                 */
 /* ------------------------------------------------------------------------ */
 template <int GMAX, int GT = 0>
-FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
+FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase = nullptr) {
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   Ws w;
-  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane, P.CAP2, P.itemCap, (W + 63) >> 6);
+  carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane, P.CAP2, P.itemCap, (W + 63) >> 6,
+          hotBase != nullptr, hotBase);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {
@@ -2589,8 +2620,10 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase) {
         }
       }
     }
-    if constexpr (GMAX > 0) {
+    if constexpr (GT > 0) {
       ldsBarrier(); /* the row hand-over is LDS only; back-pointer stores stay in flight */
+    } else if constexpr (GMAX > 0) {
+      leanBarrier(P);
     } else if (P.lmKind != 0) {
       wsBarrierMem(P); /* n-gram contexts of the new LM states, read by next frame's scoring */
     } else {

@@ -30,6 +30,17 @@
  */
 #pragma once
 
+/* the lean steps normally run with their workspace in LDS; beams too large for a
+ * CU's LDS run the same code over an HBM workspace, where a barrier must also
+ * publish / re-read memory at agent scope (wsBarrier) */
+FLTX_DEV void leanBarrier(const DecodeParams& P) {
+  if (P.gws != nullptr) {
+    wsBarrier(P);
+  } else {
+    ldsBarrier();
+  }
+}
+
 struct LeanGroup {
   double s;
   uint32_t src; /* parent slot | kNewState */
@@ -280,7 +291,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
       atomMax64(&w.red[0], bk);
     }
   }
-  ldsBarrier(); /* 1 */
+  leanBarrier(P); /* 1 */
   FLTX_PROF(6);
   /* ---- combine relations, repeat table, short-list membership ---------------- */
   for (int h = tid; h < f.nBeam; h += W) {
@@ -328,7 +339,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
       }
     }
   }
-  ldsBarrier(); /* 2 */
+  leanBarrier(P); /* 2 */
   FLTX_PROF(0);
   if (w.red[0] == 0ull) {
     return 0;
@@ -427,7 +438,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
     }
   }
   FLTX_PROF(1);
-  ldsBarrier(); /* 3 */
+  leanBarrier(P); /* 3 */
   /* ---- phase C: wave 0 turns counts into prefixes up to the K-th best's bin --- */
   if (wave == 0) {
     constexpr int PER = 16; /* NB / 64; the skewed index makes lane*16+q conflict-free */
@@ -461,7 +472,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
       w.sc[SC_CUM] = inc;
     }
   }
-  ldsBarrier(); /* 4 */
+  leanBarrier(P); /* 4 */
   const int bstar = w.sc[SC_BSTAR];
   const int L = w.sc[SC_CUM];
   FLTX_PROF(2);
@@ -509,7 +520,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
       }
     }
   }
-  ldsBarrier(); /* 5 */
+  leanBarrier(P); /* 5 */
   FLTX_PROF(3);
   const int nS = L < K ? L : K;
   const int64_t hbase = f.histBase + (int64_t)frameOut * P.K;
@@ -608,7 +619,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
     w.eRep[rank] = repSlot;
     w.bPar[rank] = h;
   }
-  ldsBarrier(); /* 6 */
+  leanBarrier(P); /* 6 */
   /* ---- phase E2: masks incl. this frame's additions; coalesced history write --- */
   for (int r = tid; r < nS; r += W) {
     const int rs = w.eRep[r];
@@ -628,7 +639,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
       P.maskTab[(size_t)f.b * P.idCap + w.bState[co + r]] = w.bMask[co + r] | add;
     }
   }
-  ldsBarrier(); /* 7 */
+  leanBarrier(P); /* 7 */
   FLTX_PROF(4);
   return nS;
 }
@@ -652,7 +663,7 @@ FLTX_DEV int runEndLean(const DecodeParams& P, const Ws& w, FrameCtx& f, int fra
     }
     w.dMate[h] = mate;
   }
-  __syncthreads();
+  leanBarrier(P);
   const double best = f.nBeam > 0 ? w.bScore[co] : 0.0;
   const double thr = best - P.beamThreshold;
   const int rounds = (f.nBeam + W - 1) / W;
@@ -689,7 +700,7 @@ FLTX_DEV int runEndLean(const DecodeParams& P, const Ws& w, FrameCtx& f, int fra
       }
     }
   }
-  __syncthreads();
+  leanBarrier(P);
   const int L = w.sc[SC_NSMALL];
   const int64_t hbase = f.histBase + (int64_t)frameOut * P.K;
   for (int j = tid; j < L; j += W) {
@@ -717,6 +728,6 @@ FLTX_DEV int runEndLean(const DecodeParams& P, const Ws& w, FrameCtx& f, int fra
       hs[2] = 0.0;
     }
   }
-  __syncthreads();
+  leanBarrier(P);
   return L;
 }
