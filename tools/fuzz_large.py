@@ -26,6 +26,10 @@ for i in range(14):
         cs.append(cases.case("L%02d" % i, dist=rnd.choice(["ctc", "uniform"]), u=700 + i, T=rnd.choice([400, 800]), N=29,
                              K=K, Kt=rnd.choice([29, 29, 12]), thr=rnd.choice([10.0, 25.0]),
                              sil_score=rnd.choice([0.0, -0.4])))
+for i, (K, T, Kt, dist, la) in enumerate([(300, 120, 29, "ctc", False), (450, 80, 29, "uniform", False), (300, 60, 12, "ctc", False),
+                                          (640, 50, 29, "ctc", False), (900, 30, 29, "ctc", False), (260, 60, 29, "ctc", True),
+                                          (700, 30, 29, "ctc", True)]):
+    cs.append(cases.case("B%02d" % i, dist=dist, u=900 + i, T=T, N=29, K=K, Kt=Kt, log_add=la))
 orc = orclib.load("oracle")
 s = helpers.FltxSession(None)
 bad = 0
@@ -36,9 +40,10 @@ for c in cs:
     d = s.decoder(c, inp)
     d.decode_batch(inp["e"], [c["T"]], c["N"])
     got = d.results(0)
-    info = "engine %d lds %d cut %d items %d" % (d.get("engine"), d.get("lds"), d.get("cut"), d.get("items"))
+    info = "engine %d lean %d lds %d cut %d items %d" % (d.get("engine"), d.get("lean"), d.get("lds"), d.get("cut"),
+                                                        d.get("items"))
     d.close()
-    ok, why = helpers.hyps_equal(want, got)
+    ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
     print(c["name"], c["kind"], "K=%d Kt=%d T=%d lm=%s" % (c["K"], c["Kt"], c["T"], c["lm"]), info,
           "OK" if ok else ("TIE-" if tie else "") + "MISMATCH " + why, flush=True)
     bad += 0 if ok or tie else 1
