@@ -25,7 +25,7 @@ def test_emulated_two_waves(emu_session, golden):
     assert ok, why
 
 
-LANE = ["lf_ctc_t20_k4", "lf_ctc_t60_k10", "lf_uni_t40_k10", "lf_ctc_t1", "lf_ctc_k1",
+LANE = ["lf_ctc_t20_k4", "lf_ctc_t60_k10", "lf_uni_t40_k10", "lf_ctc_t60_k10_logadd", "lf_ctc_t1", "lf_ctc_k1",
         "lf_ctc_thr3", "lf_ctc_sil", "lf_asg_t30_n8", "lf_ctc_n4"]
 
 

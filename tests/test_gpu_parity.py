@@ -203,7 +203,7 @@ def test_lexicon_score_cut(gpu_session, golden, c, mode):
 
 
 @pytest.mark.parametrize("name,engine", [("lf_ctc_t60_k10", 3), ("lf_uni_n64_k64", 3), ("lf_ctc_n29_k64", 3),
-                                         ("lf_ctc_n29_k65", 2), ("lf_ctc_t60_k10_logadd", 2),
+                                         ("lf_ctc_n29_k65", 2), ("lf_ctc_t60_k10_logadd", 3),
                                          ("lf_ctc_t60_k10_kt5", 2)])
 def test_engine_selection(gpu_session, golden, name, engine):
     """Which frame step serves which configuration: lane-per-slot (3) for

@@ -35,10 +35,10 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_lds(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   decodeUtterance<GMAX>(P, fltx_smem);
 }
-template <int W, int GT>
+template <int W, int GT, bool LOGADD>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  decodeUtterance<1, GT>(P, fltx_smem);
+  decodeUtterance<1, GT, LOGADD>(P, fltx_smem);
 }
 template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) { /* streaming lean step, HBM workspace */
@@ -1041,7 +1041,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   /* lane-per-slot frame step (fltx_lane.h): beam and token set fit one wave's lanes */
   d->lane = 0;
-  if (d->lean && !d->noLane && K <= 64 && N <= 64 && nTok == N && d->opt.beam_threshold < 1e6 && !d->opt.log_add) {
+  if (d->lean && !d->noLane && K <= 64 && N <= 64 && nTok == N) {
     const int nW = d->threads / 64;
     const int per = (N + nW - 1) / nW;
     d->lane = per <= 4 ? 4 : (per <= 8 ? 8 : 0);
@@ -1305,9 +1305,17 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       return;
     }
     if (gt == 4) {
-      decodeUtterance<1, 4>(*pp, base);
+      if (pp->logAdd) {
+        decodeUtterance<1, 4, true>(*pp, base);
+      } else {
+        decodeUtterance<1, 4, false>(*pp, base);
+      }
     } else if (gt == 8) {
-      decodeUtterance<1, 8>(*pp, base);
+      if (pp->logAdd) {
+        decodeUtterance<1, 8, true>(*pp, base);
+      } else {
+        decodeUtterance<1, 8, false>(*pp, base);
+      }
     } else if (gmax == 6) {
       decodeUtterance<6>(*pp, base);
     } else if (gmax == 12) {
@@ -1334,12 +1342,20 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     hipLaunchKernelGGL((fltx_decode_kernel_lds<WW, GG>), dim3(nGrid), dim3(WW), d->wsBytes,      \
                        d->ctx->stream, P);                                                       \
   } while (0)
+#define FLTX_LAUNCH_LANE1(WW, GG, LA)                                                            \
+  do {                                                                                           \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lane<WW, GG, LA>,                 \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
+    hipLaunchKernelGGL((fltx_decode_kernel_lane<WW, GG, LA>), dim3(nGrid), dim3(WW), d->wsBytes, \
+                       d->ctx->stream, P);                                                       \
+  } while (0)
 #define FLTX_LAUNCH_LANE(WW, GG)                                                                 \
   do {                                                                                           \
-    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lane<WW, GG>,                     \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
-    hipLaunchKernelGGL((fltx_decode_kernel_lane<WW, GG>), dim3(nGrid), dim3(WW), d->wsBytes,     \
-                       d->ctx->stream, P);                                                       \
+    if (d->opt.log_add) {                                                                        \
+      FLTX_LAUNCH_LANE1(WW, GG, true);                                                           \
+    } else {                                                                                     \
+      FLTX_LAUNCH_LANE1(WW, GG, false);                                                          \
+    }                                                                                            \
   } while (0)
 #define FLTX_LAUNCH(WW)                                                                          \
   do {                                                                                           \
@@ -1372,6 +1388,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
 #undef FLTX_LAUNCH
 #undef FLTX_LAUNCH_LDS
 #undef FLTX_LAUNCH_LANE
+#undef FLTX_LAUNCH_LANE1
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(d->ev[1], d->ctx->stream));
   d->timed = false;

@@ -2429,7 +2429,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 /* GMAX == 0: generic engine; GMAX > 0: lean lexicon-free + ZeroLM frame step */
 /* with up to GMAX candidate groups per thread (fltx_lean.h).                 */
 /* ------------------------------------------------------------------------ */
-template <int GMAX, int GT = 0>
+template <int GMAX, int GT = 0, bool LOGADD = false>
 FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase = nullptr) {
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x;
@@ -2597,7 +2597,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     f.e = w.erow + rb * P.N;
     f.useTrans = (P.criterion == 0) && (total + t > 0) && P.transitions != nullptr;
     if constexpr (GT > 0) {
-      nBeam = runFrameLane<GT>(P, w, *(LaneLds*)wsBase, f, lcarry, frame + t + 1);
+      nBeam = runFrameLane<GT, LOGADD>(P, w, *(LaneLds*)wsBase, f, lcarry, frame + t + 1);
     } else if constexpr (GMAX > 0) {
       nBeam = runFrameLean<GMAX>(P, w, f, lmap, frame + t + 1);
     } else {

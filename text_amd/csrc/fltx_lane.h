@@ -1,7 +1,7 @@
 /*
  * fltx_lane.h -- "lane = beam slot" frame step for the headline configuration:
- * LexiconFreeDecoder + ZeroLM, max-merge (logAdd = false), beam <= 64 and <= 64
- * tokens (C2: beam 50, 29 tokens), included by fltx_kernels.h.
+ * LexiconFreeDecoder + ZeroLM, beam <= 64 and <= 64 tokens (C2: beam 50, 29
+ * tokens), max-merge or logAdd (template parameter), included by fltx_kernels.h.
  *
  * Same candidates, same merge groups and the same selection as fltx_lean.h
  * (LexiconFreeDecoder.cpp:30-125), bit-identical results; what changes is the
@@ -125,7 +125,7 @@ FLTX_DEV uint32_t laneBit(unsigned long long m, int n) { /* n is wave-uniform at
   return (uint32_t)(m >> n) & 1u;
 }
 
-template <int GT>
+template <int GT, bool LOGADD>
 FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameCtx& f, LaneCarry& c, int frameOut) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
@@ -251,16 +251,16 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
     return 0;
   }
   const double thr = best - P.beamThreshold;
-  if (!(best - thr < 1e6)) { /* threshold too wide for the fixed bins: general path */
-    if (tid == 0) {
-      atomOr32((uint32_t*)&S.sc[SC_STATUS], ST_SELECT_FALLBACK);
-    }
-    return 0;
-  }
   /* Two-segment monotone binning of d = best - score over [0, range] (see
    * fltx_lean.h), in float: any function that is monotone in the score and the
-   * same in every wave gives exact ranks. */
-  const float rangeF = (float)(best - thr);
+   * same in every wave gives exact ranks.  A threshold far wider than the beam
+   * (beamThreshold = 1e9, inf) would waste the bins on empty range: the binned
+   * range is capped at 8 x the beam's spread + 64 and whatever lies beyond
+   * shares the last bin (still monotone; the K-th best is never out there
+   * unless fewer than K candidates are closer, and then they all survive). */
+  float rangeF = (float)(best - thr);
+  const float wideCap = (float)(a0 - aLast) * 8.0f + 64.0f;
+  rangeF = rangeF < wideCap ? rangeF : wideCap;
   const float NFf = (float)((kLaneNB * 3) / 4);
   /* fine segment = a little more than the current beam's own spread (best to
    * worst score): the next beam's scores land there unless the frame is
@@ -306,6 +306,12 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
       const bool okB = laneBit(maskB, n) != 0u && (sB >= thr);
       const bool pickB = okB && (!okA || sB > sA); /* a tie goes to the lower slot: me */
       cs[j] = pickB ? sB : sA;
+      if constexpr (LOGADD) { /* Utils.h:186-193: members folded in score-descending order; the
+                                 survivor's back-pointer is the best member's either way */
+        LeanGroup g;
+        leanFold(true, okA, sA, (uint32_t)lane, 0u, okB, sB, (uint32_t)mi, 0u, false, 0.0, 0u, 0u, g);
+        cs[j] = g.valid ? g.s : cs[j];
+      }
       validBits |= ((okA || okB) ? 1u : 0u) << j;
       pickBits |= (pickB ? 1u : 0u) << j;
     }
@@ -326,7 +332,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
     const bool okR = here && (sR >= thr);
     const bool okA = here && par >= 0 && newA && (sA >= thr);
     const bool okB = here && pm >= 0 && newB && (sB >= thr);
-    /* max-merge (Utils.h:194-196; logAdd decodes use fltx_lean.h): best member,
+    /* max-merge (Utils.h:194-196): best member,
      * a tie goes to the earlier generated one = the lower slot */
     const bool tB = okB && (!okA || sB > sA); /* par < pm: a tie goes to the parent */
     double s = tB ? sB : sA;
@@ -335,6 +341,11 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
     const bool tR = okR && (!v || sR > s || (sR == s && lane < slot));
     s = tR ? sR : s;
     who = tR ? 2u : (tB ? 1u : 0u);
+    if constexpr (LOGADD) {
+      LeanGroup g;
+      leanFold(true, okA, sA, (uint32_t)pi, 0u, okB, sB, (uint32_t)qi, 0u, okR, sR, (uint32_t)lane, 0u, g);
+      s = g.valid ? g.s : s;
+    }
     cs[GT] = s;
     cbin[GT] = 0;
     validBits |= ((okA || okB || okR) ? 1u : 0u) << GT;
