@@ -204,11 +204,11 @@ def test_lexicon_score_cut(gpu_session, golden, c, mode):
 
 @pytest.mark.parametrize("name,engine", [("lf_ctc_t60_k10", 3), ("lf_uni_n64_k64", 3), ("lf_ctc_n29_k64", 3),
                                          ("lf_ctc_n29_k65", 2), ("lf_ctc_t60_k10_logadd", 3),
-                                         ("lf_ctc_t60_k10_kt5", 2)])
+                                         ("lf_ctc_t60_k10_kt5", 3), ("lf_ctc_t300_k100", 2)])
 def test_engine_selection(gpu_session, golden, name, engine):
     """Which frame step serves which configuration: lane-per-slot (3) for
     lexicon-free + ZeroLM max-merge with beam <= 64 over the full token set,
-    the lean step (2) beyond that, for logAdd and for a token short-list."""
+    (also logAdd, also a token beam), the lean step (2) for bigger beams."""
     c = cases.BY_NAME[name]
     inp = helpers.case_inputs(c)
     d = gpu_session.decoder(c, inp)

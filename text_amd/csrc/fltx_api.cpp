@@ -35,10 +35,10 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_lds(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   decodeUtterance<GMAX>(P, fltx_smem);
 }
-template <int W, int GT, bool LOGADD>
+template <int W, int GT, bool LOGADD, bool FULLTOK>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  decodeUtterance<1, GT, LOGADD>(P, fltx_smem);
+  decodeUtterance<1, GT, LOGADD, FULLTOK>(P, fltx_smem);
 }
 template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) { /* streaming lean step, HBM workspace */
@@ -1041,9 +1041,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   /* lane-per-slot frame step (fltx_lane.h): beam and token set fit one wave's lanes */
   d->lane = 0;
-  if (d->lean && !d->noLane && K <= 64 && N <= 64 && nTok == N) {
+  if (d->lean && !d->noLane && K <= 64 && N <= 64) {
     const int nW = d->threads / 64;
-    const int per = (N + nW - 1) / nW;
+    const int per = (nTok + nW - 1) / nW;
     d->lane = per <= 4 ? 4 : (per <= 8 ? 8 : 0);
   }
   if (d->lean && !d->lane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
@@ -1304,17 +1304,18 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       decodeUtterance<255>(*pp, base, smem);
       return;
     }
+    const bool ft = pp->Kt >= pp->N;
     if (gt == 4) {
       if (pp->logAdd) {
-        decodeUtterance<1, 4, true>(*pp, base);
+        ft ? decodeUtterance<1, 4, true, true>(*pp, base) : decodeUtterance<1, 4, true, false>(*pp, base);
       } else {
-        decodeUtterance<1, 4, false>(*pp, base);
+        ft ? decodeUtterance<1, 4, false, true>(*pp, base) : decodeUtterance<1, 4, false, false>(*pp, base);
       }
     } else if (gt == 8) {
       if (pp->logAdd) {
-        decodeUtterance<1, 8, true>(*pp, base);
+        ft ? decodeUtterance<1, 8, true, true>(*pp, base) : decodeUtterance<1, 8, true, false>(*pp, base);
       } else {
-        decodeUtterance<1, 8, false>(*pp, base);
+        ft ? decodeUtterance<1, 8, false, true>(*pp, base) : decodeUtterance<1, 8, false, false>(*pp, base);
       }
     } else if (gmax == 6) {
       decodeUtterance<6>(*pp, base);
@@ -1342,19 +1343,24 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     hipLaunchKernelGGL((fltx_decode_kernel_lds<WW, GG>), dim3(nGrid), dim3(WW), d->wsBytes,      \
                        d->ctx->stream, P);                                                       \
   } while (0)
-#define FLTX_LAUNCH_LANE1(WW, GG, LA)                                                            \
+#define FLTX_LAUNCH_LANE1(WW, GG, LA, FT)                                                        \
   do {                                                                                           \
-    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lane<WW, GG, LA>,                 \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lane<WW, GG, LA, FT>,             \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
-    hipLaunchKernelGGL((fltx_decode_kernel_lane<WW, GG, LA>), dim3(nGrid), dim3(WW), d->wsBytes, \
-                       d->ctx->stream, P);                                                       \
+    hipLaunchKernelGGL((fltx_decode_kernel_lane<WW, GG, LA, FT>), dim3(nGrid), dim3(WW),         \
+                       d->wsBytes, d->ctx->stream, P);                                           \
   } while (0)
 #define FLTX_LAUNCH_LANE(WW, GG)                                                                 \
   do {                                                                                           \
-    if (d->opt.log_add) {                                                                        \
-      FLTX_LAUNCH_LANE1(WW, GG, true);                                                           \
+    const bool ft_ = d->opt.beam_size_token >= d->N;                                             \
+    if (d->opt.log_add && ft_) {                                                                 \
+      FLTX_LAUNCH_LANE1(WW, GG, true, true);                                                     \
+    } else if (d->opt.log_add) {                                                                 \
+      FLTX_LAUNCH_LANE1(WW, GG, true, false);                                                    \
+    } else if (ft_) {                                                                            \
+      FLTX_LAUNCH_LANE1(WW, GG, false, true);                                                    \
     } else {                                                                                     \
-      FLTX_LAUNCH_LANE1(WW, GG, false);                                                          \
+      FLTX_LAUNCH_LANE1(WW, GG, false, false);                                                   \
     }                                                                                            \
   } while (0)
 #define FLTX_LAUNCH(WW)                                                                          \

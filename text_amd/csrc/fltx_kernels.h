@@ -286,6 +286,11 @@ struct LaneLds {
   uint32_t sIdx[kLaneSCAP];
   uint32_t sSrc[kLaneSCAP];
   int32_t sc[16];
+  /* token short-list (beamSizeToken < N) of the frame whose emission row sits in
+   * erow buffer p: the list for the NEXT frame is made during the build phase */
+  unsigned long long tokMask[2];
+  uint8_t tokIdx[2][64]; /* position -> token */
+  uint8_t tokPos[2][64]; /* token -> position */
 };
 
 /* Carve the workspace out of `base` (LDS or HBM); returns bytes used.  With
@@ -2429,7 +2434,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 /* GMAX == 0: generic engine; GMAX > 0: lean lexicon-free + ZeroLM frame step */
 /* with up to GMAX candidate groups per thread (fltx_lean.h).                 */
 /* ------------------------------------------------------------------------ */
-template <int GMAX, int GT = 0, bool LOGADD = false>
+template <int GMAX, int GT = 0, bool LOGADD = false, bool FULLTOK = true>
 FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase = nullptr) {
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x;
@@ -2553,6 +2558,8 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     }
     if (tid == 0) {
       w.sc[SC_RELSLOW] = 1;
+      ((LaneLds*)wsBase)->tokMask[0] = 0ull;
+      ((LaneLds*)wsBase)->tokMask[1] = 0ull;
     }
   }
   const int nTok = P.Kt < N ? P.Kt : N;
@@ -2567,6 +2574,12 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     }
   }
   wsBarrierMem(P); /* also publishes the root LM state's n-gram context */
+  if constexpr (GT > 0) {
+    if (!FULLTOK && T > 0) { /* token list of the first frame (later ones are made a frame ahead) */
+      laneShortlist(P, w, *(LaneLds*)wsBase, 0, nTok, 0);
+      ldsBarrier();
+    }
+  }
   FrameCtx f;
   f.b = b;
   f.nTok = nTok;
@@ -2597,14 +2610,15 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     f.e = w.erow + rb * P.N;
     f.useTrans = (P.criterion == 0) && (total + t > 0) && P.transitions != nullptr;
     if constexpr (GT > 0) {
-      nBeam = runFrameLane<GT, LOGADD>(P, w, *(LaneLds*)wsBase, f, lcarry, frame + t + 1);
+      nBeam = runFrameLane<GT, LOGADD, FULLTOK>(P, w, *(LaneLds*)wsBase, f, lcarry, frame + t + 1, rb, pre[0],
+                                                t + 1 < T);
     } else if constexpr (GMAX > 0) {
       nBeam = runFrameLean<GMAX>(P, w, f, lmap, frame + t + 1);
     } else {
       nBeam = runFrame(P, w, f, frame + t + 1, false);
     }
     cur ^= 1; /* with nBeam == 0 either buffer is equally empty */
-    if (t + 1 < T) {
+    if (GT == 0 && t + 1 < T) { /* (the lane step parks the next row itself, before its build phase) */
       if (regPrefetch) {
 #pragma unroll
         for (int q = 0; q < PF; ++q) {

@@ -121,12 +121,36 @@ FLTX_DEV bool laneTokenValid(int wave, int nW, int n, int N) {
   return n < N && (nW == 1 || wave == nW - 1 || n < (nW - 1) * GT);
 }
 
+/* Top-nTok tokens of the emission row in erow buffer `par` (LexiconFreeDecoder.cpp:42-51:
+ * by emission descending, ties to the lower index), by the waves first, first + 1, ...:
+ * lane m holds e[m]; the number of lanes that beat token n is its position. */
+FLTX_DEV void laneShortlist(const DecodeParams& P, const Ws& w, LaneLds& S, int par, int nTok, int first) {
+  const int nW = (int)blockDim.x >> 6;
+  const int wave = waveId(), m = laneId();
+  if (wave < first) {
+    return;
+  }
+  const float* e = w.erow + par * P.N;
+  const float o = m < P.N ? e[m] : 0.0f;
+  for (int n = wave - first; n < P.N; n += nW - first) {
+    const float v = e[n];
+    const unsigned long long beat = waveBallot(m < P.N && (o > v || (o == v && m < n)));
+    const int rank = popc64(beat);
+    if (m == 0 && rank < nTok) {
+      S.tokIdx[par][rank] = (uint8_t)n;
+      S.tokPos[par][n] = (uint8_t)rank;
+      atomOr64(&S.tokMask[par], 1ull << n);
+    }
+  }
+}
+
 FLTX_DEV uint32_t laneBit(unsigned long long m, int n) { /* n is wave-uniform at the call sites */
   return (uint32_t)(m >> n) & 1u;
 }
 
-template <int GT, bool LOGADD>
-FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameCtx& f, LaneCarry& c, int frameOut) {
+template <int GT, bool LOGADD, bool FULLTOK>
+FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameCtx& f, LaneCarry& c, int frameOut,
+                          int rb, float nextVal, bool haveNext) {
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   const int lane = laneId(), wave = waveId();
@@ -136,10 +160,31 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
   const bool ctc = P.criterion == 1;
   const int nBeam = f.nBeam;
   const int kWave = nW - 1;
+  const int nTok = f.nTok;
+  constexpr bool fullTok = FULLTOK; /* beamSizeToken >= N: position == token (compile time: the
+                                       headline configuration pays nothing for token beams) */
+  if (tid == 0 && !fullTok) {
+    S.tokMask[rb ^ 1] = 0ull; /* the other parity's token list is rebuilt during this frame */
+  }
+  /* every way out of the frame parks the next emission row in the other erow
+   * buffer and, with a token beam, lists its top tokens */
+  auto parkRow = [&]() {
+    if (haveNext && tid < N) {
+      w.erow[(rb ^ 1) * N + tid] = nextVal;
+    }
+  };
+  auto bail = [&]() {
+    parkRow();
+    if (haveNext && !fullTok) {
+      ldsBarrier();
+      laneShortlist(P, w, S, rb ^ 1, nTok, 0);
+    }
+    return 0;
+  };
   /* ---- phase 1: beam into lanes, relations, evaluation, histogram ---------------- */
   laneFlush(P, S, f, c);
   if (nBeam == 0) {
-    return 0;
+    return bail();
   }
   const bool live = lane < nBeam;
   const int hc = live ? lane : 0;
@@ -203,14 +248,19 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
   }
   const int mi = mate >= 0 ? mate : hc, pi = par >= 0 ? par : hc, qi = pm >= 0 ? pm : hc;
   const uint4 mRec = S.bRec[co + mi], pRec = S.bRec[co + pi], qRec = S.bRec[co + qi];
+  const unsigned long long tokMaskV = fullTok ? (N >= 64 ? ~0ull : ((1ull << N) - 1ull)) : S.tokMask[rb];
   const float eTok = f.e[tok < N ? tok : 0];
-  const float eLane = f.e[lane < N ? lane : 0];
+  const int rTok = fullTok ? tok : (int)S.tokPos[rb][tok < N ? tok : 0]; /* position of my token (if listed) */
+  const int nLane = fullTok ? lane : (int)S.tokIdx[rb][lane < nTok ? lane : 0];
+  const float eLane = f.e[lane < nTok ? nLane : 0];
   const float eSil = f.e[P.sil];
   float eJ[GT]; /* emissions of this wave's tokens (wave-uniform), all in flight with the loads above */
+  int nJ[GT];   /* the tokens themselves */
 #pragma unroll
   for (int j = 0; j < GT; ++j) {
-    const int n = laneToken<GT>(wave, nW, j);
-    eJ[j] = f.e[n < N ? n : 0];
+    const int r = laneToken<GT>(wave, nW, j);
+    nJ[j] = fullTok ? r : (int)S.tokIdx[rb][r < nTok ? r : 0];
+    eJ[j] = f.e[r < nTok ? nJ[j] : 0];
   }
   const double a0 = S.bScore[co];
   const double aLast = S.bScore[co + nBeam - 1];
@@ -222,7 +272,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
   bool any = false;
   if (a0 - a0 == 0.0) {
     uint32_t ek = 0u;
-    if (lane < N && lane != P.sil && eLane == eLane) {
+    if (lane < nTok && nLane != P.sil && eLane == eLane) {
       ek = f32Key(eLane);
     }
     ek = waveMax32(ek);
@@ -231,14 +281,14 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
       any = true;
     }
     const double sS = (a0 + (double)eSil) + P.silScore;
-    if (sS == sS && (!any || sS > best)) {
+    if (laneBit(tokMaskV, P.sil) != 0u && sS == sS && (!any || sS > best)) {
       best = sS;
       any = true;
     }
   } else {
     unsigned long long bk = 0ull;
-    if (lane < N) {
-      const double s = leanScore(P, a0, lane, (double)eLane);
+    if (lane < nTok) {
+      const double s = leanScore(P, a0, nLane, (double)eLane);
       if (s == s) {
         bk = f64Key(s);
       }
@@ -248,7 +298,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
     best = f64FromKey(bk);
   }
   if (!any) {
-    return 0;
+    return bail();
   }
   const double thr = best - P.beamThreshold;
   /* Two-segment monotone binning of d = best - score over [0, range] (see
@@ -283,7 +333,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
    * evaluate: not the own repeat (it keeps the LM state and belongs to another
    * group) and not a token repeated by a child state's hypothesis (that group
    * is evaluated by the child's lane below) */
-  const unsigned long long allTok = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
+  const unsigned long long allTok = tokMaskV;
   const bool rpM = mate >= 0 && !mpb && !(ctc && mtok == P.blank);
   const unsigned long long maskA = owner ? (allTok & ~repMask & ~(rp ? 1ull << tok : 0ull)) : 0ull;
   const unsigned long long maskB = (owner && mate >= 0) ? (allTok & ~repMask & ~(rpM ? 1ull << mtok : 0ull)) : 0ull;
@@ -292,10 +342,11 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
   uint32_t validBits = 0u, pickBits = 0u;
 #pragma unroll
   for (int j = 0; j < GT; ++j) {
-    const int n = laneToken<GT>(wave, nW, j); /* wave-uniform */
+    const int r = laneToken<GT>(wave, nW, j); /* position in the token list, wave-uniform */
+    const int n = nJ[j];
     cs[j] = 0.0;
     cbin[j] = 0;
-    if (laneTokenValid<GT>(wave, nW, n, N)) {
+    if (laneTokenValid<GT>(wave, nW, r, nTok)) {
       const double en = (double)eJ[j];
       double sA = score + en, sB = mScore + en;
       if (n == P.sil) {
@@ -320,7 +371,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
   { /* the group of my repeat: parent's new-token candidates + my repeat; or the orphan repeat */
     const int n = tok;
     const double en = (double)eTok;
-    const bool here = rp && c.repHere;
+    const bool here = rp && c.repHere && laneBit(tokMaskV, tok < N ? tok : 0) != 0u; /* (token lane-varying here) */
     double sR = score + en, sA = pScore + en, sB = qScore + en;
     if (n == P.sil) {
       sR = sR + P.silScore;
@@ -364,6 +415,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
   FLTX_PROF(1);
   ldsBarrier(); /* 1 */
   /* ---- phase 2: every wave: prefix of the counts, K-th best's bin, scatter -------- */
+  parkRow(); /* frame t + 1's emissions: visible after barrier 2 */
   if (wave == (nW > 1 ? 1 : 0)) { /* the relation tables have been read by everyone */
     if (D >= 0) {
       w.relTab[D] = 0ull;
@@ -417,7 +469,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
     if (tid == 0) {
       atomOr32((uint32_t*)&S.sc[SC_STATUS], ST_SELECT_FALLBACK);
     }
-    return 0;
+    return bail(); /* (parks the row a second time: harmless) */
   }
   /* short-listed candidates of this lane, one per loop trip: about K of the
    * (GT + 1) * W candidate slots are, so the trip count is 1-2, not GT + 1 */
@@ -442,12 +494,15 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
       const uint32_t p = lo + atomAdd32(&S.tick[bin], 1u);
       int n, slot, rep;
       uint32_t flag, orphan = 0u;
+      int r;
       if (j < GT) {
-        n = laneToken<GT>(wave, nW, j);
+        r = laneToken<GT>(wave, nW, j);
+        n = fullTok ? r : (int)S.tokIdx[rb][r < nTok ? r : 0];
         slot = ((pickBits >> j) & 1u) ? mi : lane;
         flag = (ctc && n == P.blank) ? 0u : kNewState;
         rep = lane;
       } else {
+        r = rTok;
         n = tok;
         slot = who == 0u ? pi : (who == 1u ? qi : lane);
         flag = who < 2u ? kNewState : 0u;
@@ -455,7 +510,7 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
         orphan = par >= 0 ? 0u : 1u;
       }
       const unsigned long long key = f64Key(sj);
-      S.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(slot * N + n), lo | ((lo + cnt) << 16));
+      S.sEnt[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(slot * nTok + r), lo | ((lo + cnt) << 16));
       /* group: representative slot, token, orphan flag; source slot | kNewState */
       S.sIdx[p] = (uint32_t)rep | ((uint32_t)n << 8) | (orphan << 16);
       S.sSrc[p] = (uint32_t)slot | flag;
@@ -479,6 +534,9 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
       S.hist[i] = 0u;
       S.tick[i] = 0u;
     }
+  }
+  if (haveNext && !fullTok) { /* the next frame's token list, by the waves that do not build */
+    laneShortlist(P, w, S, rb ^ 1, nTok, nW > 2 ? 2 : 0);
   }
   if (wave == 0 || wave == bWave) {
     for (int p = lane; p < L; p += 64) {
