@@ -35,6 +35,26 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_lds(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   decodeUtterance<GMAX>(P, fltx_smem);
 }
+/* generic engine specialised by assumption: LEX = lexicon decoder with a word LM
+ * (no lexicon-free generation, no token-LM paths), ZLM = ZeroLM (no n-gram
+ * scoring: a third of the kernel and a good part of its register pressure).
+ * The facts are stated to the compiler, which then drops the dead paths. */
+template <int W, bool LEX, bool ZLM>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_lds_spec(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  if (LEX) {
+    __builtin_assume(P.kind == 1);
+    __builtin_assume(P.isLmToken == 0);
+    __builtin_assume(P.dense == 0);
+  }
+  if (ZLM) {
+    __builtin_assume(P.lmKind == 0);
+    __builtin_assume(P.isLmToken == 0);
+  } else {
+    __builtin_assume(P.lmKind == 1);
+  }
+  decodeUtterance<0>(P, fltx_smem);
+}
 template <int W, int GT, bool LOGADD, bool FULLTOK>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
@@ -1343,6 +1363,13 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     hipLaunchKernelGGL((fltx_decode_kernel_lds<WW, GG>), dim3(nGrid), dim3(WW), d->wsBytes,      \
                        d->ctx->stream, P);                                                       \
   } while (0)
+#define FLTX_LAUNCH_SPEC(WW, LX, ZL)                                                             \
+  do {                                                                                           \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lds_spec<WW, LX, ZL>,             \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
+    hipLaunchKernelGGL((fltx_decode_kernel_lds_spec<WW, LX, ZL>), dim3(nGrid), dim3(WW),         \
+                       d->wsBytes, d->ctx->stream, P);                                           \
+  } while (0)
 #define FLTX_LAUNCH_LANE1(WW, GG, LA, FT)                                                        \
   do {                                                                                           \
     HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_lane<WW, GG, LA, FT>,             \
@@ -1379,6 +1406,12 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       FLTX_LAUNCH_LDS(WW, 12);                                                                   \
     } else if (d->lean == 255) {                                                                 \
       FLTX_LAUNCH_LDS(WW, 255);                                                                  \
+    } else if (d->kind == FLTX_DECODER_LEXICON && !d->isLmToken && d->lm->kind == 0) {           \
+      FLTX_LAUNCH_SPEC(WW, true, true);                                                          \
+    } else if (d->kind == FLTX_DECODER_LEXICON && !d->isLmToken) {                               \
+      FLTX_LAUNCH_SPEC(WW, true, false);                                                         \
+    } else if (d->lm->kind == 0 && !d->isLmToken) {                                              \
+      FLTX_LAUNCH_SPEC(WW, false, true);                                                         \
     } else {                                                                                     \
       FLTX_LAUNCH_LDS(WW, 0);                                                                    \
     }                                                                                            \
@@ -1395,6 +1428,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
 #undef FLTX_LAUNCH_LDS
 #undef FLTX_LAUNCH_LANE
 #undef FLTX_LAUNCH_LANE1
+#undef FLTX_LAUNCH_SPEC
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(d->ev[1], d->ctx->stream));
   d->timed = false;
