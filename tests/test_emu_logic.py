@@ -46,8 +46,9 @@ LEX_SMALL = [c for c in cases.CASES if c["kind"] == "lexicon" and c["size"] == "
              and not c["log_add"]]
 
 
+@pytest.mark.parametrize("slim", [1, 0])
 @pytest.mark.parametrize("c", LEX_SMALL, ids=lambda c: c["name"])
-def test_emulated_score_cut_is_exact_or_retried(emu_session, golden, c):
+def test_emulated_score_cut_is_exact_or_retried(emu_session, golden, c, slim):
     """Lexicon decoder, cut-off generation (runFrame): with the cut forced down to
     K + 1 candidates either the kept ones still form K groups (exact by
     construction) or the kernel flags the frame and the batch is redone without
@@ -55,6 +56,7 @@ def test_emulated_score_cut_is_exact_or_retried(emu_session, golden, c):
     inp = helpers.case_inputs(c)
     d = emu_session.decoder(c, inp, 64)
     d.set("cut_m", c["K"] + 1)
+    d.set("slim", slim)  # 0: the recompute form (count per bin, generate again) instead of slim records
     d.decode_batch(inp["e"], [c["T"]], c["N"])
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
     d.close()

@@ -184,7 +184,7 @@ LEX_CUT = [c for c in cases.CASES if c["kind"] == "lexicon" and not c["log_add"]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["tight", "off"])
+@pytest.mark.parametrize("mode", ["tight", "off", "recompute", "recompute_tight"])
 @pytest.mark.parametrize("c", LEX_CUT, ids=lambda c: c["name"])
 def test_lexicon_score_cut(gpu_session, golden, c, mode):
     """The lexicon decoder scores every candidate first and materialises only the
@@ -194,6 +194,12 @@ def test_lexicon_score_cut(gpu_session, golden, c, mode):
     d = gpu_session.decoder(c, inp)
     if mode == "tight":
         d.set("cut_m", c["K"] + 1)
+    elif mode == "recompute":  # no slim records: count per score bin, then generate again
+        d.set("cut_m", 2 * c["K"] + 64)
+        d.set("slim", 0)
+    elif mode == "recompute_tight":
+        d.set("cut_m", c["K"] + 1)
+        d.set("slim", 0)
     else:
         d.set("cut", 0)
     d.decode_batch(inp["e"], [c["T"]], c["N"])

@@ -294,7 +294,8 @@ struct fltx_decoder {
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
   size_t hotBytes = 0; /* LDS part of a split (HBM + LDS) lean workspace */
   int itemCap = 0, noItems = 0; /* lexicon decoder: list of existing (hypothesis, token) children */
-  int CAP2 = 0, cutM = 0, noCut = 0, userCutM = 0; /* lexicon decoder: slim score-pass list + cut-off (runFrame) */
+  int CAP2 = 0, cutM = 0, noCut = 0, userCutM = 0;
+  int cutRecompute = 0, noSlim = 0; /* cut-off generation without the slim list (beams it does not fit) */ /* lexicon decoder: slim score-pass list + cut-off (runFrame) */
   size_t wsBytes = 0;
   bool wsInLds = true;
   /* device buffers */
@@ -922,6 +923,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->wsInLds ? 1 : 0;
   } else if (!strcmp(key, "cut")) {
     *value = d->cutM;
+  } else if (!strcmp(key, "recompute")) {
+    *value = d->cutRecompute;
   } else if (!strcmp(key, "cap")) {
     *value = d->CAP;
   } else if (!strcmp(key, "cap2")) {
@@ -964,6 +967,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "items")) { /* 0: the lexicon decoder walks the full hypothesis x token grid */
     d->noItems = value ? 0 : 1;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "slim")) { /* 0: the cut-off generation recomputes instead of keeping slim records */
+    d->noSlim = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "cut_m")) { /* testing: number of best candidates kept by the cut (default 2K + 64) */
@@ -1108,6 +1115,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   bool lds = !d->forceGlobalWs && !leanInHbm;
   d->CAP2 = 0;
   d->cutM = 0;
+  d->cutRecompute = 0;
   const bool forceCut = d->userCutM > 0 && d->kind == FLTX_DECODER_LEXICON && !forceWorstCaseCap; /* tests */
   if (lds && (bytesFor(capC) > kMaxLds || forceCut)) {
     if (d->kind == FLTX_DECODER_LEXICON && !forceWorstCaseCap) {
@@ -1137,11 +1145,22 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         while (c2 > 4 * M && bytesCut(c2) > kMaxLds) {
           c2 = c2 * 7 / 8;
         }
-        if (bytesCut(c2) <= kMaxLds && c2 >= std::min<int64_t>(4 * M, worst)) {
+        /* the slim list should hold what a frame produces (about K * (nTok + 2));
+         * otherwise generate twice instead of remembering (runFrame) */
+        if (!d->noSlim && bytesCut(c2) <= kMaxLds && c2 >= std::min<int64_t>(std::max<int64_t>(4 * M, expect * 2 / 3), worst)) {
           d->CAP2 = (int)c2;
           d->cutM = (int)M;
           capC = capRec;
           cut = true;
+        } else {
+          const int64_t capRec2 = std::max<int64_t>(M * 5 / 4 + 64, 256);
+          if (carveWs(tmp, nullptr, K, (int)capRec2, hsFor(capRec2), d->NB, N, d->SCAP, d->dense, d->lane, 0,
+                      d->itemCap, d->threads / 64) <= kMaxLds) {
+            d->cutRecompute = 1;
+            d->cutM = (int)M;
+            capC = capRec2;
+            cut = true;
+          }
         }
       }
       if (!cut) {
@@ -1292,6 +1311,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.lane = d->lane;
   P.CAP2 = d->CAP2;
   P.cutM = d->cutM;
+  P.cutRecompute = d->cutRecompute;
   P.gLexMax = d->gLexMax.as<float>();
   P.gws = d->wsInLds ? nullptr : d->gws.as<char>();
   P.gwsStride = (int64_t)d->wsBytes;
@@ -1597,9 +1617,10 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
    * engine); the others keep their results.  The fallback sticks to the decoder
    * only when a large part of the batch needed it. */
   std::vector<int32_t> redoList;
-  const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean;
+  bool recomputeRetry = false; /* the second attempt is the recompute form of the cut-off generation */
+  const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    int rc = prepare(d, B, N, T, attempt == 1);
+    int rc = prepare(d, B, N, T, attempt == 1 && !recomputeRetry);
     if (rc) {
       return rc;
     }
@@ -1633,10 +1654,11 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         return rc;
       }
       bool ws = false, cut = false, lean = false;
+      const bool slimMode = d->CAP2 > 0;
       for (int b = 0; b < B; ++b) {
         const int st = d->hStatus[b];
         const bool o = (st & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON;
-        const bool c = (st & ST_CUT_RETRY) && d->CAP2;
+        const bool c = (st & ST_CUT_RETRY) && (d->CAP2 || d->cutRecompute);
         const bool l = (st & ST_SELECT_FALLBACK) && d->lean;
         if (o || c || l) {
           redoList.push_back(b);
@@ -1646,6 +1668,11 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         }
       }
       if (!redoList.empty()) {
+        if (ws && slimMode && !cut) { /* the slim list overflowed: generate twice instead (still in LDS) */
+          d->noSlim = 1;
+          ws = false;
+          recomputeRetry = true;
+        }
         d->forceGlobalWs = ws ? 1 : d->forceGlobalWs;
         d->noCut = cut ? 1 : d->noCut;
         d->noLean = lean ? 1 : d->noLean;
@@ -1659,6 +1686,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     d->forceGlobalWs = savedGlobalWs;
     d->noCut = savedNoCut;
     d->noLean = savedNoLean;
+    d->noSlim = savedNoSlim;
   }
   d->resultsSynced = false;
   int rc = launchBacktrace(d);

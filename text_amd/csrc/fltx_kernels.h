@@ -149,6 +149,7 @@ struct DecodeParams {
   int32_t CAP2;  /* >0: lexicon decoder scores all candidates into slim {score, order} records first and
                     materialises only the best cutM of them (see runFrame); capacity of that list */
   int32_t cutM;
+  int32_t cutRecompute; /* 1: cut-off generation without the slim list (count per bin, then generate again) */
   int32_t dense; /* 1: lexicon-free frames use the hash-free dense merge */
   int32_t lane;  /* >0: lane-per-slot frame step (fltx_lane.h), value = tokens per wave */
   char* gws;          /* global workspace (big configurations), or null */
@@ -1144,9 +1145,38 @@ FLTX_DEV void denseLeaders(const DecodeParams& P, const Ws& w, const FrameCtx& f
 /* LexiconDecoder::decodeStep inner loops (LexiconDecoder.cpp:55-215).  Work
  * item = (hypothesis, r): r < nTok tries the r-th short-listed token as a trie
  * child, r == nTok is "same node" (2), r == nTok+1 is CTC blank (3). */
-template <bool SLIM, bool LISTED>
+/* linear bins over [preThr, hi] for the recompute form of the cut-off generation */
+struct CutBins {
+  double hi, scale;
+  int bM;
+};
+FLTX_DEV int cutBinOf(const DecodeParams& P, const CutBins& cb, double sc) {
+  const double x = (cb.hi - sc) * cb.scale;
+  int bin = (x < (double)P.NB) ? (int)x : P.NB - 1;
+  return bin < 0 ? 0 : bin;
+}
+
+/* MODE 0: every candidate becomes a record.  MODE 1: score pass into slim
+ * records (cut-off generation).  MODE 2 / 3: the recompute form of the cut-off
+ * generation for beams whose slim list would not fit: pass 2 only counts the
+ * candidates per score bin, pass 3 generates everything again and builds
+ * records for the candidates at or above the cut bin. */
+template <int MODE, bool LISTED>
 FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
-                         unsigned long long& bestKey, double preThr, int nItems) {
+                         unsigned long long& bestKey, double preThr, int nItems, const CutBins& cb) {
+  constexpr bool SLIM = MODE == 1;
+  auto countOnly = [&](bool on, double sc) {
+    if (on && sc >= preThr) {
+      atomAdd32(&w.hist[FLTX_HB(cutBinOf(P, cb, sc))], 1u);
+    }
+  };
+  auto aboveCut = [&](bool on, double sc) {
+    if (on && sc >= preThr && cutBinOf(P, cb, sc) > cb.bM) {
+      w.sc[SC_CUT] = 1; /* left out: noted for the exactness check */
+      return false;
+    }
+    return on;
+  };
   const int per = f.nTok + 2;
   /* (hypothesis, token) items: the nItems existing children listed in itemList
    * (nItems >= 0), or the full nBeam x nTok grid; the 2 stay / blank items per
@@ -1311,9 +1341,11 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u) | kExtend;
       if constexpr (SLIM) {
         pushSlim(P, w, cExt, sc, ordBase, P.isLmToken ? l : childMax, (int32_t)childId, bestKey, preThr);
+      } else if constexpr (MODE == 2) {
+        countOnly(cExt, sc);
       } else {
-        pushCandidate(P, w, cExt, sc, kp, ke, childId, (uint32_t)n, src, (int32_t)__float_as_uint(childMax), l,
-                      ordBase, bestKey, preThr);
+        pushCandidate(P, w, MODE == 3 ? aboveCut(cExt, sc) : cExt, sc, kp, ke, childId, (uint32_t)n, src,
+                      (int32_t)__float_as_uint(childMax), l, ordBase, bestKey, preThr);
       }
     }
     /* (1b) word ends: one candidate per label of the child */
@@ -1341,9 +1373,11 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       }
       if constexpr (SLIM) {
         pushSlim(P, w, on, sc, ordBase + 1 + (uint32_t)j, l, label, bestKey, preThr);
+      } else if constexpr (MODE == 2) {
+        countOnly(on, sc);
       } else {
-        pushCandidate(P, w, on, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, label, l,
-                      ordBase + 1 + (uint32_t)j, bestKey, preThr);
+        pushCandidate(P, w, MODE == 3 ? aboveCut(on, sc) : on, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState,
+                      label, l, ordBase + 1 + (uint32_t)j, bestKey, preThr);
       }
     }
     /* (1c) unknown word */
@@ -1361,16 +1395,20 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       double sc = base + P.lmWeight * (double)l + P.unkScore;
       if constexpr (SLIM) {
         pushSlim(P, w, cUnk, sc, ordBase + 7, l, P.unk, bestKey, preThr);
+      } else if constexpr (MODE == 2) {
+        countOnly(cUnk, sc);
       } else {
-        pushCandidate(P, w, cUnk, sc, kp, ke, 0u, (uint32_t)n, (uint32_t)h | kNewState, P.unk, l,
-                      ordBase + 7, bestKey, preThr);
+        pushCandidate(P, w, MODE == 3 ? aboveCut(cUnk, sc) : cUnk, sc, kp, ke, 0u, (uint32_t)n,
+                      (uint32_t)h | kNewState, P.unk, l, ordBase + 7, bestKey, preThr);
       }
     }
     /* (2)/(3) stay / blank keep state and node */
     if constexpr (SLIM) {
       pushSlim(P, w, cStay, baseS, ordS << 3, 0.0f, -1, bestKey, preThr);
+    } else if constexpr (MODE == 2) {
+      countOnly(cStay, baseS);
     } else {
-      pushCandidate(P, w, cStay, baseS, sparS, (uint32_t)sedgeS, lexS,
+      pushCandidate(P, w, MODE == 3 ? aboveCut(cStay, baseS) : cStay, baseS, sparS, (uint32_t)sedgeS, lexS,
                     (uint32_t)nS | (stayBlank ? kPrevBlank : 0u), (uint32_t)hS, -1, 0.0f, ordS << 3,
                     bestKey, preThr);
     }
@@ -2241,7 +2279,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
     w.sc[SC_BM] = P.NB - 1;
     w.red[2] = 0ull;
   }
-  if (!isEnd && P.kind == 1 && P.CAP2 > 0) {
+  if (!isEnd && P.kind == 1 && (P.CAP2 > 0 || P.cutRecompute)) {
     for (int i = tid; i < P.NB; i += W) {
       w.hist[FLTX_HB(i)] = 0;
     }
@@ -2320,16 +2358,65 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
         w.red[3] = 0ull; /* next frame's short-list mask starts empty */
       }
     }
-    if (P.CAP2 > 0) {
+    CutBins cb;
+    cb.hi = lb + 64.0; /* a candidate that much above the lower bound of the best lands in bin 0 */
+    cb.scale = (double)P.NB / (cb.hi - preThr);
+    cb.bM = P.NB - 1;
+    if (!(cb.scale > 0.0) || !(cb.scale < 1e300)) {
+      cb.scale = 0.0; /* unbounded threshold: one bin, nothing is cut */
+    }
+    if (P.cutRecompute) {
+      /* recompute form of the cut-off generation: count per score bin, find the
+       * bin of the cutM-th best, generate again and keep what reaches it */
       if (listItems) {
-        genLexicon<true, true>(P, w, f, bestKey, preThr, nItems);
+        genLexicon<2, true>(P, w, f, bestKey, preThr, nItems, cb);
       } else {
-        genLexicon<true, false>(P, w, f, bestKey, preThr, nItems);
+        genLexicon<2, false>(P, w, f, bestKey, preThr, nItems, cb);
+      }
+      wsBarrier(P);
+      if (waveId() == 0) {
+        constexpr int PER = 16;
+        const int lane = laneId();
+        int c[PER];
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          c[q] = (int)w.hist[FLTX_HB(lane * PER + q)];
+          mine += c[q];
+        }
+        const int inc = waveInclusiveScan(mine);
+        int cum = inc - mine;
+        if (cum < P.cutM && inc >= P.cutM) {
+          int bq = PER - 1;
+          bool done = false;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            cum += c[q];
+            if (!done && cum >= P.cutM) {
+              bq = q;
+              done = true;
+            }
+          }
+          w.sc[SC_BM] = lane * PER + bq;
+        }
+      }
+      wsBarrier(P);
+      cb.bM = w.sc[SC_BM];
+      if (listItems) {
+        genLexicon<3, true>(P, w, f, bestKey, preThr, nItems, cb);
+      } else {
+        genLexicon<3, false>(P, w, f, bestKey, preThr, nItems, cb);
+      }
+    } else if (P.CAP2 > 0) {
+      if (listItems) {
+        genLexicon<1, true>(P, w, f, bestKey, preThr, nItems, cb);
+      } else {
+        genLexicon<1, false>(P, w, f, bestKey, preThr, nItems, cb);
       }
     } else if (listItems) {
-      genLexicon<false, true>(P, w, f, bestKey, preThr, nItems);
+      genLexicon<0, true>(P, w, f, bestKey, preThr, nItems, cb);
     } else {
-      genLexicon<false, false>(P, w, f, bestKey, preThr, nItems);
+      genLexicon<0, false>(P, w, f, bestKey, preThr, nItems, cb);
     }
   }
   bestKey = waveMax64(bestKey);
@@ -2415,7 +2502,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
   wsBarrier(P);
   FLTX_PROF(2);
   const int nLead = w.sc[SC_NLEAD];
-  if (!isEnd && P.kind == 1 && P.CAP2 > 0 && w.sc[SC_CUT] != 0 && nLead < P.K && tid == 0) {
+  if (!isEnd && P.kind == 1 && (P.CAP2 > 0 || P.cutRecompute) && w.sc[SC_CUT] != 0 && nLead < P.K && tid == 0) {
     atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_CUT_RETRY); /* the cut left fewer than K groups */
   }
   const double spread = f.nBeam > 0 ? w.bScore[f.cur * P.K] - w.bScore[f.cur * P.K + f.nBeam - 1] : 0.0;
