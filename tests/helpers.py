@@ -57,7 +57,7 @@ def case_inputs(c):
 
 
 # ---- n-gram LM plumbing -----------------------------------------------------
-NGRAM_DIR = os.path.join(ROOT, "gpurun_out", "ngram_cache")
+NGRAM_DIR = os.environ.get("FLTX_NGRAM_CACHE", "/tmp/fltx_ngram_cache")  # synthetic ARPA files, regenerated on demand
 
 
 def lm_vocab(c, inp):

@@ -188,14 +188,14 @@ LEX_CUT = [c for c in cases.CASES if c["kind"] == "lexicon" and not c["log_add"]
 @pytest.mark.parametrize("c", LEX_CUT, ids=lambda c: c["name"])
 def test_lexicon_score_cut(gpu_session, golden, c, mode):
     """The lexicon decoder scores every candidate first and materialises only the
-    best 2K + 64 (runFrame, cut-off generation).  Same n-best with the cut
+    best 3K + 64 (runFrame, cut-off generation).  Same n-best with the cut
     forced down to K + 1 (exact, or flagged and redone) and with the cut off."""
     inp = helpers.case_inputs(c)
     d = gpu_session.decoder(c, inp)
     if mode == "tight":
         d.set("cut_m", c["K"] + 1)
     elif mode == "recompute":  # no slim records: count per score bin, then generate again
-        d.set("cut_m", 2 * c["K"] + 64)
+        d.set("cut_m", 3 * c["K"] + 64)
         d.set("slim", 0)
     elif mode == "recompute_tight":
         d.set("cut_m", c["K"] + 1)

@@ -973,7 +973,7 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noSlim = value ? 0 : 1;
     return FLTX_OK;
   }
-  if (!strcmp(key, "cut_m")) { /* testing: number of best candidates kept by the cut (default 2K + 64) */
+  if (!strcmp(key, "cut_m")) { /* testing: number of best candidates kept by the cut (default 3K + 64) */
     d->userCutM = (int)value;
     return FLTX_OK;
   }
@@ -1130,12 +1130,13 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
        * of 3100).  With room for 1.5x that, build every candidate's record in
        * one pass.  Otherwise (max-merge only) score every candidate into a slim
        * {score, order} list first and build records only for the best
-       * cutM = 2K + 64 of them (runFrame): the record area then holds a few
+       * cutM = 3K + 64 of them (runFrame): the record area then holds a few
        * hundred entries and the slim list takes what is left of the LDS. */
       const int64_t expect = (int64_t)K * (nTok + 2) * 3 / 2;
       bool cut = false;
       if ((!fits || c < expect || forceCut) && !d->noCut && !d->opt.log_add) {
-        const int64_t M = d->userCutM > 0 ? std::max<int64_t>(d->userCutM, K) : 2 * (int64_t)K + 64;
+        /* a merge group has up to three members: 3K + 64 of the best candidates hold K groups */
+        const int64_t M = d->userCutM > 0 ? std::max<int64_t>(d->userCutM, K) : 3 * (int64_t)K + 64;
         const int64_t capRec = std::max<int64_t>(2 * M, 512);
         auto bytesCut = [&](int64_t c2) {
           return carveWs(tmp, nullptr, K, (int)capRec, hsFor(capRec), d->NB, N, d->SCAP, d->dense, d->lane, (int)c2,

@@ -1168,6 +1168,8 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
   auto countOnly = [&](bool on, double sc) {
     if (on && sc >= preThr) {
       atomAdd32(&w.hist[FLTX_HB(cutBinOf(P, cb, sc))], 1u);
+      const unsigned long long sk = f64Key(sc);
+      bestKey = sk > bestKey ? sk : bestKey; /* the frame's best is known after this pass */
     }
   };
   auto aboveCut = [&](bool on, double sc) {
@@ -2368,10 +2370,15 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
     if (P.cutRecompute) {
       /* recompute form of the cut-off generation: count per score bin, find the
        * bin of the cutM-th best, generate again and keep what reaches it */
+      unsigned long long bk2 = 0ull;
       if (listItems) {
-        genLexicon<2, true>(P, w, f, bestKey, preThr, nItems, cb);
+        genLexicon<2, true>(P, w, f, bk2, preThr, nItems, cb);
       } else {
-        genLexicon<2, false>(P, w, f, bestKey, preThr, nItems, cb);
+        genLexicon<2, false>(P, w, f, bk2, preThr, nItems, cb);
+      }
+      bk2 = waveMax64(bk2);
+      if (laneId() == 0 && bk2 != 0ull) {
+        atomMax64(&w.red[2], bk2);
       }
       wsBarrier(P);
       if (waveId() == 0) {
@@ -2402,10 +2409,17 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
       }
       wsBarrier(P);
       cb.bM = w.sc[SC_BM];
+      /* the exact threshold is known now: the second generation drops what is
+       * below it, and "left out by the cut" means left out although above it */
+      double thr2 = preThr;
+      if (w.red[2] != 0ull) {
+        const double t = f64FromKey(w.red[2]) - P.beamThreshold;
+        thr2 = t > thr2 ? t : thr2;
+      }
       if (listItems) {
-        genLexicon<3, true>(P, w, f, bestKey, preThr, nItems, cb);
+        genLexicon<3, true>(P, w, f, bestKey, thr2, nItems, cb);
       } else {
-        genLexicon<3, false>(P, w, f, bestKey, preThr, nItems, cb);
+        genLexicon<3, false>(P, w, f, bestKey, thr2, nItems, cb);
       }
     } else if (P.CAP2 > 0) {
       if (listItems) {
