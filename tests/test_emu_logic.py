@@ -63,6 +63,26 @@ def test_emulated_score_cut_is_exact_or_retried(emu_session, golden, c, slim):
     assert ok, why
 
 
+@pytest.mark.parametrize("hot,cut_m", [(2, 0), (1, 0), (2, -1)])
+@pytest.mark.parametrize("c", LEX_SMALL[:4], ids=lambda c: c["name"])
+def test_emulated_hbm_workspace_with_cut(emu_session, golden, c, hot, cut_m):
+    """Lexicon beams that do not fit the LDS (forced here with a tiny LDS budget):
+    beam in an HBM workspace, recompute form of the cut-off generation, candidate
+    records in LDS (level 2) or in HBM (level 1); tight cut -> flagged and redone."""
+    inp = helpers.case_inputs(c)
+    d = emu_session.decoder(c, inp, 64)
+    d.set("lds_budget", 2048)
+    d.set("hot_level", hot)
+    if cut_m:
+        d.set("cut_m", c["K"] + 1)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    if not cut_m:
+        assert d.get("lds") == 0 and d.get("recompute") == 1 and d.get("hot_level") == hot
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
+    d.close()
+    assert ok, why
+
+
 @pytest.mark.parametrize("c", [c for c in cases.fuzz_cases(18) if c["T"] <= 25 and c["K"] <= 33],
                          ids=lambda c: c["name"])
 def test_emulated_random_configurations_match_oracle(emu_session, oracle_lib, c):

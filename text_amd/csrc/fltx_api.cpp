@@ -67,7 +67,10 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) 
 }
 template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gws(DecodeParams P) {
-  decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride);
+  /* HBM workspace; the histogram and block scalars -- and, when they fit, the
+   * candidate records and the merge hash -- stay in LDS (carveWs splitHot) */
+  extern __shared__ __attribute__((aligned(16))) char fltx_hot2[];
+  decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride, fltx_hot2);
 }
 __global__ void __launch_bounds__(512) fltx_backtrace_kernel(BacktraceParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_bt_smem[];
@@ -292,7 +295,10 @@ struct fltx_decoder {
   int CAP = 0, HS = 0, NB = 0, SCAP = 0, dense = 0, noDense = 0;
   int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
-  size_t hotBytes = 0; /* LDS part of a split (HBM + LDS) lean workspace */
+  size_t hotBytes = 0; /* LDS part of a split (HBM + LDS) workspace */
+  int hotLevel = 0;    /* what the LDS part holds (carveWs) */
+  size_t ldsBudget = 0; /* tests: smaller LDS than the hardware's */
+  int maxHotLevel = 2;
   int itemCap = 0, noItems = 0; /* lexicon decoder: list of existing (hypothesis, token) children */
   int CAP2 = 0, cutM = 0, noCut = 0, userCutM = 0;
   int cutRecompute = 0, noSlim = 0; /* cut-off generation without the slim list (beams it does not fit) */ /* lexicon decoder: slim score-pass list + cut-off (runFrame) */
@@ -923,6 +929,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->wsInLds ? 1 : 0;
   } else if (!strcmp(key, "cut")) {
     *value = d->cutM;
+  } else if (!strcmp(key, "hot_level")) {
+    *value = d->wsInLds ? 0 : d->hotLevel;
   } else if (!strcmp(key, "recompute")) {
     *value = d->cutRecompute;
   } else if (!strcmp(key, "cap")) {
@@ -973,6 +981,14 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noSlim = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "hot_level")) { /* testing: 1 keeps the candidate records of an HBM workspace in HBM */
+    d->maxHotLevel = (int)value;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "lds_budget")) { /* testing: pretend the CU has this many bytes of LDS (<= 160 KiB) */
+    d->ldsBudget = value > 0 && (size_t)value < kMaxLds ? (size_t)value : 0;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "cut_m")) { /* testing: number of best candidates kept by the cut (default 3K + 64) */
     d->userCutM = (int)value;
     return FLTX_OK;
@@ -1003,6 +1019,8 @@ namespace {
 /* geometry + buffers for B streams of up to maxFrames frames (plus seed and
  * decodeEnd slots) */
 int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstCaseCap) {
+  const size_t kMaxLdsHw = kMaxLds;
+  const size_t kMaxLds = d->ldsBudget ? d->ldsBudget : kMaxLdsHw;
   Stream st = d->ctx->stream;
   const int K = d->opt.beam_size;
   if (d->kind == FLTX_DECODER_LEXICON && d->trie->nTokens != N) {
@@ -1108,6 +1126,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       d->trie->mask.p && (int64_t)K * nTok > d->threads && K <= 1024) {
     d->itemCap = K * nTok;
   }
+  const int itemCap0 = d->itemCap;
   auto bytesFor = [&](int64_t c) {
     return carveWs(tmp, nullptr, K, (int)c, hsFor(c), d->NB, N, d->SCAP, d->dense, d->lane, 0, d->itemCap,
                    d->threads / 64);
@@ -1155,8 +1174,14 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
           cut = true;
         } else {
           const int64_t capRec2 = std::max<int64_t>(M * 5 / 4 + 64, 256);
-          if (carveWs(tmp, nullptr, K, (int)capRec2, hsFor(capRec2), d->NB, N, d->SCAP, d->dense, d->lane, 0,
-                      d->itemCap, d->threads / 64) <= kMaxLds) {
+          auto bytesRe = [&]() {
+            return carveWs(tmp, nullptr, K, (int)capRec2, hsFor(capRec2), d->NB, N, d->SCAP, d->dense, d->lane, 0,
+                           d->itemCap, d->threads / 64);
+          };
+          if (bytesRe() > kMaxLds && d->itemCap) {
+            d->itemCap = 0; /* the grid form of the generation needs no list */
+          }
+          if (bytesRe() <= kMaxLds) {
             d->cutRecompute = 1;
             d->cutM = (int)M;
             capC = capRec2;
@@ -1175,18 +1200,39 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       lds = false;
     }
   }
-  d->CAP = (int)capC;
-  d->HS = hsFor(capC);
   if (!lds) {
     d->lane = 0;
-  }
-  if (!lds) {
     d->itemCap = 0;
+    /* Lexicon beams too big for the LDS: the recompute form of the cut-off
+     * generation still keeps the candidate records few (3K + 64), so those and
+     * the merge hash usually fit the LDS while the beam itself, its select
+     * lists and the item list live in HBM (carveWs level 2). */
+    if (d->kind == FLTX_DECODER_LEXICON && !forceWorstCaseCap && !d->forceGlobalWs && !leanInHbm && !d->noCut &&
+        !d->opt.log_add && N <= 64) {
+      const int64_t M = d->userCutM > 0 ? std::max<int64_t>(d->userCutM, K) : 3 * (int64_t)K + 64;
+      d->cutRecompute = 1;
+      d->cutM = (int)M;
+      d->CAP2 = 0;
+      capC = std::max<int64_t>(M * 5 / 4 + 64, 256);
+      d->itemCap = itemCap0;
+    }
   }
+  d->CAP = (int)capC;
+  d->HS = hsFor(capC);
   d->hotBytes = 0;
-  if (leanInHbm) {
+  d->hotLevel = 0;
+  if (!lds) {
+    d->hotLevel = 1;
+    if (!leanInHbm) {
+      size_t hb = 0;
+      carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap,
+              d->threads / 64, 2, nullptr, &hb);
+      if (hb <= kMaxLdsHw && d->maxHotLevel >= 2) {
+        d->hotLevel = 2;
+      }
+    }
     d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap,
-                         d->threads / 64, true, nullptr, &d->hotBytes);
+                         d->threads / 64, d->hotLevel, nullptr, &d->hotBytes);
   } else {
     d->wsBytes = carveWs(tmp, nullptr, K, d->CAP, d->HS, d->NB, N, d->SCAP, d->dense, d->lane, d->CAP2, d->itemCap,
                          d->threads / 64);
@@ -1313,6 +1359,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.CAP2 = d->CAP2;
   P.cutM = d->cutM;
   P.cutRecompute = d->cutRecompute;
+  P.hotLevel = d->hotLevel;
   P.gLexMax = d->gLexMax.as<float>();
   P.gws = d->wsInLds ? nullptr : d->gws.as<char>();
   P.gwsStride = (int64_t)d->wsBytes;
@@ -1342,7 +1389,11 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
             [pp, gmax, gt, hot](char* smem) {
     char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
     if (hot) {
-      decodeUtterance<255>(*pp, base, smem);
+      if (gmax == 255) {
+        decodeUtterance<255>(*pp, base, smem);
+      } else {
+        decodeUtterance<0>(*pp, base, smem);
+      }
       return;
     }
     const bool ft = pp->Kt >= pp->N;
@@ -1416,7 +1467,9 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     if (!d->wsInLds && d->lean) {                                                                \
       hipLaunchKernelGGL(fltx_decode_kernel_gwslean<WW>, dim3(nGrid), dim3(WW), d->hotBytes, d->ctx->stream, P); \
     } else if (!d->wsInLds) {                                                                    \
-      hipLaunchKernelGGL(fltx_decode_kernel_gws<WW>, dim3(nGrid), dim3(WW), 0, d->ctx->stream, P); \
+      HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_gws<WW>,                        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->hotBytes)); \
+      hipLaunchKernelGGL(fltx_decode_kernel_gws<WW>, dim3(nGrid), dim3(WW), d->hotBytes, d->ctx->stream, P); \
     } else if (d->lane == 4) {                                                                   \
       FLTX_LAUNCH_LANE(WW, 4);                                                                   \
     } else if (d->lane == 8) {                                                                   \
@@ -1649,7 +1702,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     if (rc) {
       return rc;
     }
-    if (attempt == 0 && ((d->kind == FLTX_DECODER_LEXICON && d->wsInLds) || d->lean)) {
+    if (attempt == 0 && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || d->cutRecompute)) || d->lean)) {
       d->resultsSynced = false;
       if ((rc = syncResults(d))) {
         return rc;
@@ -1669,6 +1722,10 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         }
       }
       if (!redoList.empty()) {
+        if (!d->wsInLds && d->cutRecompute) { /* HBM workspace with the cut: the plain HBM path is what is left */
+          ws = true;
+          cut = true;
+        }
         if (ws && slimMode && !cut) { /* the slim list overflowed: generate twice instead (still in LDS) */
           d->noSlim = 1;
           ws = false;

@@ -149,6 +149,7 @@ struct DecodeParams {
   int32_t CAP2;  /* >0: lexicon decoder scores all candidates into slim {score, order} records first and
                     materialises only the best cutM of them (see runFrame); capacity of that list */
   int32_t cutM;
+  int32_t hotLevel;     /* HBM workspace: 1 = histogram / scalars in LDS, 2 = candidate records and merge hash too */
   int32_t cutRecompute; /* 1: cut-off generation without the slim list (count per bin, then generate again) */
   int32_t dense; /* 1: lexicon-free frames use the hash-free dense merge */
   int32_t lane;  /* >0: lane-per-slot frame step (fltx_lane.h), value = tokens per wave */
@@ -298,7 +299,7 @@ struct LaneLds {
  * base == nullptr it only computes the size (host side). */
 FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N, int SCAP,
                        int dense, int lane, int CAP2 = 0, int itemCap = 0, int nWaves = 16,
-                       bool splitHot = false, char* hotBase = nullptr, size_t* hotBytes = nullptr) {
+                       int splitHot = 0, char* hotBase = nullptr, size_t* hotBytes = nullptr) {
   size_t off = 0;
   /* splitHot: the workspace proper lives in HBM, but the small arrays every
    * thread hammers with atomics or re-reads all the time (histogram, its
@@ -324,6 +325,14 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   } else {                                                   \
     FLTX_CARVE(field, type, count)                           \
   }
+  /* level 2: the candidate records and the merge hash go to LDS as well (the
+   * beam, its select lists and the item list stay in HBM) */
+#define FLTX_CARVE_R(field, type, count)                     \
+  if (splitHot >= 2) {                                       \
+    FLTX_CARVE_H(field, type, count)                         \
+  } else {                                                   \
+    FLTX_CARVE(field, type, count)                           \
+  }
   /* a field of the fixed lane block in lane mode, carved like the rest otherwise */
 #define FLTX_CARVE_L(field, type, count, member)             \
   if (lane) {                                                \
@@ -341,13 +350,13 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE_L(w.bTokPb, uint32_t, 2 * K, bTokPb)
   FLTX_CARVE(w.bLexMax, float, leanOnly ? 0 : 2 * K)
   FLTX_CARVE_H(w.erow, float, 2 * N)
-  FLTX_CARVE(w.cScore, double, CAP)
-  FLTX_CARVE(w.cKey, uint4, CAP)
-  FLTX_CARVE(w.cSrc, uint32_t, CAP)
-  FLTX_CARVE(w.cAux, int32_t, CAP)
-  FLTX_CARVE(w.cLm, float, CAP)
-  FLTX_CARVE(w.cOrd, uint32_t, CAP)
-  FLTX_CARVE(w.cNext, uint32_t, CAP)
+  FLTX_CARVE_R(w.cScore, double, CAP)
+  FLTX_CARVE_R(w.cKey, uint4, CAP)
+  FLTX_CARVE_R(w.cSrc, uint32_t, CAP)
+  FLTX_CARVE_R(w.cAux, int32_t, CAP)
+  FLTX_CARVE_R(w.cLm, float, CAP)
+  FLTX_CARVE_R(w.cOrd, uint32_t, CAP)
+  FLTX_CARVE_R(w.cNext, uint32_t, CAP)
   FLTX_CARVE(w.bLexMask, unsigned long long, itemCap ? K : 0)
   FLTX_CARVE(w.itemList, uint16_t, itemCap)
   FLTX_CARVE(w.tokPos, uint8_t, itemCap ? N : 0)
@@ -355,11 +364,11 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.zOrd, uint32_t, CAP2)
   FLTX_CARVE(w.zLm, float, CAP2)
   FLTX_CARVE(w.zAux, int32_t, CAP2)
-  FLTX_CARVE(w.head, uint32_t, HS)
-  FLTX_CARVE(w.lead, uint32_t, CAP)
-  FLTX_CARVE(w.lstat, uint8_t, CAP)
-  FLTX_CARVE(w.lbin, uint16_t, CAP)
-  FLTX_CARVE(w.small, uint32_t, CAP)
+  FLTX_CARVE_R(w.head, uint32_t, HS)
+  FLTX_CARVE_R(w.lead, uint32_t, CAP)
+  FLTX_CARVE_R(w.lstat, uint8_t, CAP)
+  FLTX_CARVE_R(w.lbin, uint16_t, CAP)
+  FLTX_CARVE_R(w.small, uint32_t, CAP)
   FLTX_CARVE(w.sKey, unsigned long long, SCAP)
   FLTX_CARVE(w.sOrd, uint32_t, SCAP)
   FLTX_CARVE_L(w.sIdx, uint32_t, SCAP, sIdx)
@@ -378,8 +387,12 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
   FLTX_CARVE(w.relTab, unsigned long long, lane ? (size_t)K * (N + 1) : 0)
   FLTX_CARVE_L(w.repTab, unsigned long long, lane ? K : 0, repTab)
   FLTX_CARVE_L(w.bRec, uint4, lane ? 2 * K : 0, bRec)
-  FLTX_CARVE(w.wcum, uint32_t, (leanOnly && !lane) ? 0 : nWaves * 256)
-  FLTX_CARVE_L(w.tick, uint32_t, (leanOnly && !lane) ? 0 : 512, tick)
+  FLTX_CARVE_H(w.wcum, uint32_t, (leanOnly && !lane) ? 0 : nWaves * 256)
+  if (splitHot) {
+    FLTX_CARVE_H(w.tick, uint32_t, (leanOnly && !lane) ? 0 : 512)
+  } else {
+    FLTX_CARVE_L(w.tick, uint32_t, (leanOnly && !lane) ? 0 : 512, tick)
+  }
   FLTX_CARVE(w.pMate, int32_t, (dense && !lane) ? 16 * 64 : 0)
   FLTX_CARVE(w.pPar, int32_t, (dense && !lane) ? 16 * 64 : 0)
   FLTX_CARVE(w.surv, uint32_t, K)
@@ -401,6 +414,7 @@ FLTX_HD size_t carveWs(Ws& w, char* base, int K, int CAP, int HS, int NB, int N,
     FLTX_CARVE_L(w.sc, int32_t, 16, sc)
   }
 #undef FLTX_CARVE_L
+#undef FLTX_CARVE_R
 #undef FLTX_CARVE_H
 #undef FLTX_CARVE
   if (hotBytes) {
@@ -2542,7 +2556,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
   const int tid = (int)threadIdx.x;
   Ws w;
   carveWs(w, wsBase, P.K, P.CAP, P.HS, P.NB, P.N, P.SCAP, P.dense, P.lane, P.CAP2, P.itemCap, (W + 63) >> 6,
-          hotBase != nullptr, hotBase);
+          hotBase != nullptr ? (P.hotLevel > 1 ? P.hotLevel : 1) : 0, hotBase);
   int cur = 0;
   int nBeam, frame, total;
   if (tid == 0) {

@@ -5,7 +5,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, cases, helpers
 from text_amd import synth
 s = helpers.FltxSession(None)
-for K, Kt, lm in [(200, 29, "zero"), (500, 29, "zero"), (500, 10, "zero"), (500, 29, ("ngram", 4, 8))]:
+for K, Kt, lm in [(200, 29, "zero"), (300, 29, "zero"), (300, 29, ("ngram", 4, 8)), (500, 29, "zero"), (500, 10, "zero"), (500, 29, ("ngram", 4, 8))]:
     c = cases.case("x", kind="lexicon", dist="lexspell", T=300, N=29, K=K, Kt=Kt, lexicon=cases.FULL_LEX, lm=lm,
                    lm_weight=2.0 if lm != "zero" else 0.0, word_score=2.0 if lm != "zero" else 0.0)
     inp = helpers.case_inputs(c); d = s.decoder(c, inp)

@@ -30,6 +30,12 @@ for i, (K, T, Kt, dist, la) in enumerate([(300, 120, 29, "ctc", False), (450, 80
                                           (640, 50, 29, "ctc", False), (900, 30, 29, "ctc", False), (260, 60, 29, "ctc", True),
                                           (700, 30, 29, "ctc", True)]):
     cs.append(cases.case("B%02d" % i, dist=dist, u=900 + i, T=T, N=29, K=K, Kt=Kt, log_add=la))
+for i, (K, Kt, lm) in enumerate([(200, 29, "zero"), (300, 29, "zero"), (280, 29, ("ngram", 4, 8)), (240, 10, "zero"),
+                                 (500, 29, "zero"), (500, 29, ("ngram", 4, 8)), (800, 29, "zero"), (1200, 10, "zero")]):
+    # lexicon beams in the hundreds: recompute form of the cut-off generation, with / without the item list
+    cs.append(cases.case("R%02d" % i, kind="lexicon", dist="lexspell", u=950 + i, T=120, N=29, K=K, Kt=Kt, thr=25.0,
+                         lexicon=cases.FULL_LEX, lm=lm, lm_weight=2.0 if lm != "zero" else 0.0,
+                         word_score=2.0 if lm != "zero" else 0.0, sil_score=-1.0 if lm != "zero" else 0.0))
 orc = orclib.load("oracle")
 s = helpers.FltxSession(None)
 bad = 0
@@ -40,8 +46,8 @@ for c in cs:
     d = s.decoder(c, inp)
     d.decode_batch(inp["e"], [c["T"]], c["N"])
     got = d.results(0)
-    info = "engine %d lean %d lds %d cut %d items %d" % (d.get("engine"), d.get("lean"), d.get("lds"), d.get("cut"),
-                                                        d.get("items"))
+    info = "engine %d lean %d lds %d hot %d cut %d re %d items %d" % (d.get("engine"), d.get("lean"), d.get("lds"), d.get("hot_level"),
+                                                                     d.get("cut"), d.get("recompute"), d.get("items"))
     d.close()
     ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
     print(c["name"], c["kind"], "K=%d Kt=%d T=%d lm=%s" % (c["K"], c["Kt"], c["T"], c["lm"]), info,
