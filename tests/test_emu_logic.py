@@ -63,9 +63,9 @@ def test_emulated_score_cut_is_exact_or_retried(emu_session, golden, c, slim):
     assert ok, why
 
 
-@pytest.mark.parametrize("hot,cut_m", [(2, 0), (1, 0), (2, -1)])
+@pytest.mark.parametrize("hot,slim,cut_m", [(2, 1, 0), (1, 1, 0), (2, 0, 0), (1, 0, 0), (2, 1, -1), (2, 0, -1)])
 @pytest.mark.parametrize("c", LEX_SMALL[:4], ids=lambda c: c["name"])
-def test_emulated_hbm_workspace_with_cut(emu_session, golden, c, hot, cut_m):
+def test_emulated_hbm_workspace_with_cut(emu_session, golden, c, hot, slim, cut_m):
     """Lexicon beams that do not fit the LDS (forced here with a tiny LDS budget):
     beam in an HBM workspace, recompute form of the cut-off generation, candidate
     records in LDS (level 2) or in HBM (level 1); tight cut -> flagged and redone."""
@@ -73,11 +73,13 @@ def test_emulated_hbm_workspace_with_cut(emu_session, golden, c, hot, cut_m):
     d = emu_session.decoder(c, inp, 64)
     d.set("lds_budget", 2048)
     d.set("hot_level", hot)
+    d.set("slim", slim)
     if cut_m:
         d.set("cut_m", c["K"] + 1)
     d.decode_batch(inp["e"], [c["T"]], c["N"])
     if not cut_m:
-        assert d.get("lds") == 0 and d.get("recompute") == 1 and d.get("hot_level") == hot
+        assert d.get("lds") == 0 and d.get("recompute") == 1 - slim and d.get("hot_level") == hot
+        assert d.get("cut") > 0 and (d.get("cap2") > 0) == bool(slim)
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
     d.close()
     assert ok, why

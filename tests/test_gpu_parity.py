@@ -209,20 +209,22 @@ def test_lexicon_score_cut(gpu_session, golden, c, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hot,tight", [(2, False), (1, False), (2, True)])
+@pytest.mark.parametrize("hot,slim,tight", [(2, 1, False), (1, 1, False), (2, 0, False), (1, 0, False), (2, 1, True), (2, 0, True)])
 @pytest.mark.parametrize("c", LEX_CUT, ids=lambda c: c["name"])
-def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, tight):
+def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight):
     """Lexicon beams beyond the LDS (forced with a tiny LDS budget): beam in HBM,
     recompute form of the cut-off generation, records in LDS (level 2) or HBM (1)."""
     inp = helpers.case_inputs(c)
     d = gpu_session.decoder(c, inp)
     d.set("lds_budget", 2048)
     d.set("hot_level", hot)
+    d.set("slim", slim)
     if tight:
         d.set("cut_m", c["K"] + 1)
     d.decode_batch(inp["e"], [c["T"]], c["N"])
     if not tight:
-        assert d.get("lds") == 0 and d.get("recompute") == 1 and d.get("hot_level") == hot
+        assert d.get("lds") == 0 and d.get("recompute") == 1 - slim and d.get("hot_level") == hot
+        assert d.get("cut") > 0 and (d.get("cap2") > 0) == bool(slim)
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], 0.0)
     d.close()
     assert ok, why

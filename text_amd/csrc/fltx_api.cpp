@@ -1210,11 +1210,15 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     if (d->kind == FLTX_DECODER_LEXICON && !forceWorstCaseCap && !d->forceGlobalWs && !leanInHbm && !d->noCut &&
         !d->opt.log_add && N <= 64) {
       const int64_t M = d->userCutM > 0 ? std::max<int64_t>(d->userCutM, K) : 3 * (int64_t)K + 64;
-      d->cutRecompute = 1;
       d->cutM = (int)M;
-      d->CAP2 = 0;
       capC = std::max<int64_t>(M * 5 / 4 + 64, 256);
       d->itemCap = itemCap0;
+      if (!d->noSlim) { /* HBM has room for the slim list of everything a frame can produce */
+        d->CAP2 = (int)std::min<int64_t>(worst, std::max<int64_t>(4 * M, (int64_t)K * (nTok + 2) * 3));
+      } else {
+        d->CAP2 = 0;
+        d->cutRecompute = 1;
+      }
     }
   }
   d->CAP = (int)capC;
@@ -1671,10 +1675,13 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
    * engine); the others keep their results.  The fallback sticks to the decoder
    * only when a large part of the batch needed it. */
   std::vector<int32_t> redoList;
-  bool recomputeRetry = false; /* the second attempt is the recompute form of the cut-off generation */
+  size_t firstRedo = 0;
+  bool recomputeRetry = false; /* this attempt is the recompute form of the cut-off generation */
+  bool recomputeTried = false;
   const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    int rc = prepare(d, B, N, T, attempt == 1 && !recomputeRetry);
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    const bool finalForm = attempt > 0 && !recomputeRetry; /* the general path: nothing left to fall back to */
+    int rc = prepare(d, B, N, T, finalForm);
     if (rc) {
       return rc;
     }
@@ -1689,7 +1696,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     P.doBegin = 1;
     P.doEnd = 1;
     d->nLaunch = 0;
-    if (attempt == 1) {
+    if (attempt > 0) {
       if (d->uttMap.ensure(4 * redoList.size(), d->ctx->stream, false) ||
           devCopyH2D(d->uttMap.p, redoList.data(), 4 * redoList.size(), d->ctx->stream)) {
         return fail(FLTX_ERR_OOM, "re-run list upload failed");
@@ -1702,34 +1709,43 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     if (rc) {
       return rc;
     }
-    if (attempt == 0 && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || d->cutRecompute)) || d->lean)) {
+    const bool cutMode = d->CAP2 > 0 || d->cutRecompute;
+    if (!finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean)) {
       d->resultsSynced = false;
       if ((rc = syncResults(d))) {
         return rc;
       }
       bool ws = false, cut = false, lean = false;
       const bool slimMode = d->CAP2 > 0;
-      for (int b = 0; b < B; ++b) {
+      std::vector<int32_t> again;
+      const int nScan = attempt == 0 ? B : (int)redoList.size();
+      for (int i = 0; i < nScan; ++i) {
+        const int b = attempt == 0 ? i : redoList[i];
         const int st = d->hStatus[b];
         const bool o = (st & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON;
-        const bool c = (st & ST_CUT_RETRY) && (d->CAP2 || d->cutRecompute);
+        const bool c = (st & ST_CUT_RETRY) && cutMode;
         const bool l = (st & ST_SELECT_FALLBACK) && d->lean;
         if (o || c || l) {
-          redoList.push_back(b);
+          again.push_back(b);
           ws |= o;
           cut |= c;
           lean |= l;
         }
       }
+      redoList.swap(again);
+      if (attempt == 0) {
+        firstRedo = redoList.size();
+      }
       if (!redoList.empty()) {
-        if (!d->wsInLds && d->cutRecompute) { /* HBM workspace with the cut: the plain HBM path is what is left */
-          ws = true;
-          cut = true;
-        }
-        if (ws && slimMode && !cut) { /* the slim list overflowed: generate twice instead (still in LDS) */
+        recomputeRetry = false;
+        if (ws && slimMode && !cut && !recomputeTried) { /* the slim list overflowed: generate twice instead */
           d->noSlim = 1;
           ws = false;
           recomputeRetry = true;
+          recomputeTried = true;
+        } else if (!d->wsInLds && cutMode) { /* HBM workspace with the cut: the plain HBM path is what is left */
+          ws = true;
+          cut = true;
         }
         d->forceGlobalWs = ws ? 1 : d->forceGlobalWs;
         d->noCut = cut ? 1 : d->noCut;
@@ -1740,7 +1756,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     }
     break;
   }
-  if (!redoList.empty() && (int)redoList.size() * 4 <= B) { /* a few outliers: next batch tries the fast path again */
+  if (firstRedo > 0 && firstRedo * 4 <= (size_t)B) { /* a few outliers: next batch tries the fast path again */
     d->forceGlobalWs = savedGlobalWs;
     d->noCut = savedNoCut;
     d->noLean = savedNoLean;

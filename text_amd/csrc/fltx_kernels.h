@@ -1977,7 +1977,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K,
     }
     L = nLead;
     wsBarrier(P);
-  } else if (P.gws == nullptr && selectFast(P, w, nLead, K, best, thr, spread, L)) {
+  } else if ((P.gws == nullptr || P.hotLevel > 0) && selectFast(P, w, nLead, K, best, thr, spread, L)) {
     return nS;
   } else {
     /* Bins over [best - beamThreshold, best]: the leaders already passed the
@@ -2521,7 +2521,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
     nCand = nCand > P.CAP ? P.CAP : nCand;
     foldGroups(P, w, thr, nCand);
   }
-  if (P.gws == nullptr) { /* selectFast expects empty counters */
+  if (P.gws == nullptr || P.hotLevel > 0) { /* selectFast expects empty counters (they are in LDS either way) */
     for (int i = tid; i < 512; i += W) {
       w.hist[i] = 0u;
       w.tick[i] = 0u;
