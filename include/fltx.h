@@ -243,11 +243,17 @@ FLTX_API int fltx_decoder_profile(fltx_decoder* dec, uint64_t* out);
 /* Tunables: "threads" (threads per utterance: 64..1024), "force_global_ws",
  * "dense" (0 = use the generic hash merge for lexicon-free frames too), "lean" /
  * "lane" (0 = do not use that specialised lexicon-free + ZeroLM frame step),
- * "keep_scores", "profile", "profile_wave". */
+ * "keep_scores", "profile", "profile_wave"; lexicon decoder: "cut" (0 = build
+ * every candidate's record), "slim" (0 = recompute form of the cut-off
+ * generation), "items" (0 = no child-mask item list); test hooks: "cut_m",
+ * "lds_budget" (pretend the CU has fewer bytes of LDS), "hot_level". */
 FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
 /* Geometry chosen for the last batch: "engine" (0 generic hash merge, 1 generic
  * dense merge, 2 lean register-resident step, 3 lane-per-slot step), "lane"
- * (tokens per wave of engine 3, else 0), "threads", "lds" (1 = workspace in LDS). */
+ * (tokens per wave of engine 3, else 0), "threads", "lds" (1 = workspace in LDS),
+ * "hot_level" (HBM workspace: 1 = counters in LDS, 2 = candidate records too),
+ * "cut" (candidates kept by the cut-off generation, 0 = off), "recompute",
+ * "cap", "cap2", "items". */
 FLTX_API int fltx_decoder_get(fltx_decoder* dec, const char* key, int64_t* value);
 
 #ifdef __cplusplus
