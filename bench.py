@@ -8,6 +8,10 @@ Appendix A).  A "step" = one fltx_decode_batch over that batch: decodeBegin +
 T frames + decodeEnd + back-trace of every hypothesis, inputs resident in HBM
 before the timed region, results left in HBM.
 
+--workload C3 / C4 select BASELINE.json configs[2] (90k-word trie, beam 50,
+beamSizeToken 10) and configs[3] (trie + synthetic 4-gram word LM, T = 1500,
+beam 100); the default and the judged line is C2.
+
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -49,7 +53,7 @@ def parse():
     ap.add_argument("--beam", type=int, default=50)
     ap.add_argument("--beam-token", type=int, default=29)
     ap.add_argument("--threads", type=int, default=0, help="threads per utterance (0 = library default)")
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3"])
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4"])
     ap.add_argument("--cpu-sample", type=int, default=160, help="utterances timed on the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
@@ -82,10 +86,13 @@ def main():
 
     from text_amd import _capi, synth
     B, T, N, K, Kt = a.batch, a.frames, a.tokens, a.beam, a.beam_token
+    lex_wl = a.workload in ("C3", "C4")
     if a.workload == "C3":
         Kt = 10
-    lexicon = synth.lexicon() if a.workload == "C3" else None
-    dist_name = "lexspell" if a.workload == "C3" else "ctc"
+    if a.workload == "C4":  # BASELINE.json configs[3]: trie + 4-gram word LM, T=1500, beam=100
+        T, K = (1500 if a.frames == 1000 else a.frames), (100 if a.beam == 50 else a.beam)
+    lexicon = synth.lexicon() if lex_wl else None
+    dist_name = "lexspell" if lex_wl else "ctc"
     u0 = rank * B  # each rank decodes its own shard of the node-wide batch
     e_host = synth.batch(dist_name, B, T, N, lexicon=lexicon, u0=u0)
     e_dev = torch.from_numpy(e_host).cuda()  # resident in HBM before timing
@@ -94,11 +101,20 @@ def main():
     ctx = _capi.Context(device=local)
     lm = _capi.ZeroLM(ctx)
     opt = _capi.make_options(K, Kt, 25.0)
+    arpa = None
+    if a.workload == "C4":
+        # same options as the parity case C4_spell_u0 (tests/cases.py)
+        opt = _capi.make_options(K, Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, False, "ctc")
+        arpa = synthetic_arpa(len(lexicon[1]) - 1)
+        lm = _capi.ArpaLM(arpa[0], arpa[1])
     trie = None
-    if a.workload == "C3":
+    if lex_wl:
         W = len(lexicon[1]) - 1
         ht = _capi.HostTrie(N, 0)
-        ht.insert_many(lexicon[0], lexicon[1], np.arange(W), np.zeros(W))
+        wscore = np.zeros(W, dtype=np.float32)
+        if arpa:  # trie label scores = lm.score(start, word) (DecoderTest.cpp:137-146)
+            wscore = np.array([lm.score_sequence([w], False)[0][0] for w in range(W)], dtype=np.float32)
+        ht.insert_many(lexicon[0], lexicon[1], np.arange(W), wscore)
         ht.smear(1)
         trie = ht.upload(ctx)
         dec = _capi.BatchDecoder(ctx, _capi.LEXICON, opt, lm, 0, N - 1, unk=W, trie=trie)
@@ -164,9 +180,10 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %s + ZeroLM CTC, batch=%d utterances/GPU, T=%d, N=%d, beam=%d, "
+        "config": {"workload": "%s: %s + %s CTC, batch=%d utterances/GPU, T=%d, N=%d, beam=%d, "
                                "beamToken=%d, beamThreshold=25, logAdd=false, `%s` emissions" %
                                (a.workload, "LexiconDecoder + 90k-word trie" if trie else "LexiconFreeDecoder",
+                                "synthetic 4-gram word LM (lmWeight 2, wordScore 2, silScore -1)" if arpa else "ZeroLM",
                                 B, T, N, K, Kt, dist_name),
                    "parallelism": "utterance-sharded x%d, no collective" % world,
                    "threads_per_utterance": st["threads_per_utt"], "lds_bytes_per_workgroup": st["lds_bytes"]},
@@ -191,7 +208,7 @@ def main():
 
     # ---- CPU baseline + parity spot check (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt)
+        out["cpu_baseline"] = cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt, arpa, wscore if lex_wl else None)
     if rank == 0:
         print(json.dumps(out))
     dec.close()
@@ -216,33 +233,57 @@ def pmc_traffic(workload, threads, B, T, N, K):
     return None
 
 
-def cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt):
+def synthetic_arpa(W):
+    """Deterministic synthetic 4-gram ARPA file over the lexicon's words (SURVEY.md
+    section 8d), cached under /tmp -> (path, vocabulary in LM-index order)."""
+    from text_amd import ngram_synth
+    vocab = ngram_synth.words(W) + ["<unk>"]
+    d = os.environ.get("FLTX_NGRAM_CACHE", "/tmp/fltx_ngram_cache")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "lm_o4_s4242_v%d.arpa" % len(vocab))
+    if not os.path.exists(path):
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        ngram_synth.write_arpa(tmp, vocab[:-1], 4, (0, 200000, 100000, 50000), 4242)
+        os.replace(tmp, path)
+    return path, vocab
+
+
+def cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt, arpa=None, wscore=None):
     """Time the reference's CPU path on a bounded sample of the same batch and
     compare its n-best with what the GPU produced for those utterances."""
     from oracle import orclib
     kind = "reference" if orclib.have_ref() else "port"
     lib = orclib.load("ref" if kind == "reference" else "oracle")
     opt = orclib.make_options(K, Kt, 25.0)
+    if arpa:
+        opt = orclib.make_options(K, Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, False, "ctc")
     n = min(a.cpu_sample, B)
+    if arpa:
+        n = min(n, 32)  # ~50 ms of CPU per frame-thousand at beam 100 with the 4-gram
     trie = None
     if lexicon is not None:
         W = len(lexicon[1]) - 1
-        trie = lib.build_trie(N, 0, lexicon[0], lexicon[1], np.arange(W), np.zeros(W), 1)
+        trie = lib.build_trie(N, 0, lexicon[0], lexicon[1], np.arange(W),
+                              wscore if wscore is not None else np.zeros(W), 1)
     t_total = 0.0
     mism = 0
+    lm_shared = lib.lm_arpa_create(arpa[0].encode(), "\n".join(arpa[1]).encode()) if arpa else None
     for b in range(n):
-        lm = lib.lm_zero_create()
+        lm = lm_shared if arpa else lib.lm_zero_create()
         d = lib.lexicon(opt, trie, lm, 0, N - 1, W) if trie else lib.lexfree(opt, lm, 0, N - 1)
         t0 = time.perf_counter()
         hyps = lib.decode(d, e_host[b], T, N)  # fresh decoder per utterance, decode() only
         t_total += time.perf_counter() - t0
         lib.decoder_destroy(d)
-        lib.lm_destroy(lm)
+        if not arpa:
+            lib.lm_destroy(lm)
         got = dec.results(b)
         same = len(got) == len(hyps) and all(
             g.score == h.score and np.array_equal(g.tokens, h.tokens) and np.array_equal(g.words, h.words)
             for g, h in zip(got, hyps))
         mism += 0 if same else 1
+    if lm_shared:
+        lib.lm_destroy(lm_shared)
     return {"value": n * T / t_total, "unit": "frames/s", "cores": 1, "kind": kind,
             "sample": "first %d utterances of the batch, one thread, fresh decoder per utterance, "
                       "decode() wall time only" % n,

@@ -62,7 +62,7 @@ NGRAM_DIR = os.environ.get("FLTX_NGRAM_CACHE", "/tmp/fltx_ngram_cache")  # synth
 
 def lm_vocab(c, inp):
     """user-index -> word list the LM is built over (KenLM.cpp:44-49)."""
-    import ngram_synth
+    from text_amd import ngram_synth
     if c["kind"] == "lexicon" and not c["is_lm_token"]:
         return ngram_synth.words(inp["W"]) + ["<unk>"]  # word ids 0..W-1, unk = W
     return ngram_synth.words(c["N"], "t")
@@ -70,7 +70,7 @@ def lm_vocab(c, inp):
 
 def arpa_path(c, inp):
     """Deterministic synthetic ARPA file for a case (cached on disk)."""
-    import ngram_synth
+    from text_amd import ngram_synth
     _, order, seed = c["lm"]
     vocab = lm_vocab(c, inp)
     big = len(vocab) > 10000

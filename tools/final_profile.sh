@@ -10,6 +10,7 @@ cd "$R"
 python -m pytest tests -m gpu -q > "$O/pytest_gpu.log" 2>&1
 python bench.py > "$O/bench_C2.json" 2> "$O/bench_C2.err"
 python bench.py --workload C3 > "$O/bench_C3.json" 2> "$O/bench_C3.err"
+python bench.py --workload C4 --steps 5 > "$O/bench_C4.json" 2> "$O/bench_C4.err"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_C2" -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu > "$O/prof_C2.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_C3" -- python "$R/bench.py" --workload C3 --steps 3 --warmup 2 --no-cpu > "$O/prof_C3.log" 2>&1
