@@ -1072,9 +1072,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     /* one workgroup per CU: give it two waves per SIMD; more utterances than
      * CUs: 256 threads, so that several utterances share a CU (C2 at B=512:
      * 512 threads cannot co-reside (VGPRs), 256 can) */
-    d->threads = B <= d->ctx->numCUs * (d->kind == FLTX_DECODER_LEXICON ? 2 : 1) ? 512 : 256;
-    /* (the lexicon decoder's workspace fills a CU's LDS either way: C3 at B=512, 256 threads
-     * 13.2 M frames/s, 512 threads 15.5 M) */
+    d->threads = (d->kind == FLTX_DECODER_LEXICON || B <= d->ctx->numCUs) ? 512 : 256;
+    /* (the lexicon decoder's workspace fills a CU's LDS, so one utterance per CU either way:
+     * 1024 utterances, 256 -> 512 threads: C3 19.7 -> 27.9 M frames/s, C4 9.8 -> 12.7 M) */
   }
   /* lean frame step (fltx_lean.h): lexicon-free + ZeroLM, groups held in registers */
   d->lean = 0;
