@@ -573,11 +573,14 @@ FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
   w.cOrd[ci] = ord;
   compilerFence();
 #ifndef FLTX_EMU
-  if (P.gws != nullptr) {
-    /* workspace in HBM: the record must have reached L2 before the atomic
-     * below publishes its index to the other waves (in LDS the pipeline order
-     * of one wave's ds_write / ds_cmpst already guarantees this) */
-    __threadfence();
+  if (P.gws != nullptr && P.hotLevel < 2) {
+    /* records in HBM: the record must have reached L2 before the atomic below
+     * publishes its index to the other waves (in LDS the pipeline order of one
+     * wave's ds_write / ds_cmpst already guarantees this).  The readers sit on
+     * the same CU and read at L2 (below), the L1 is write-through: waiting for
+     * this wave's stores (workgroup-scope release) is enough -- an agent-scope
+     * fence would write the L2 back as well. */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   }
 #endif
   uint32_t s = hashKey(kp, ke, klex, ktp) & (uint32_t)(P.HS - 1);
@@ -593,7 +596,7 @@ FLTX_DEV void pushCandidate(const DecodeParams& P, const Ws& w, bool valid,
     }
     uint4 k;
 #ifndef FLTX_EMU
-    if (P.gws != nullptr) { /* another wave's record: read it at L2, not from a stale L1 line */
+    if (P.gws != nullptr && P.hotLevel < 2) { /* another wave's record: read it at L2, not from a stale L1 line */
       const uint32_t* kq = (const uint32_t*)&w.cKey[cur];
       k.x = __hip_atomic_load(kq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       k.y = __hip_atomic_load(kq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
