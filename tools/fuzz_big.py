@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Larger randomized differential run (GPU vs oracle) than the 36 cases of the test-suite."""
+"""Larger randomized differential run (GPU vs oracle) than the 36 cases of the test-suite.
+FLTX_FUZZ_SET="key=value,key=value" applies decoder tunables to every case (e.g.
+lds_budget=2048 pushes every lexicon case onto the HBM-workspace paths)."""
+import os
 import sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import cases, helpers
@@ -14,7 +17,13 @@ for i, c in enumerate(cs):
     if len({h.score for h in want}) != len(want):
         continue  # equal scores: the reference's own result is order dependent
     try:
-        got = s.run(c, inp)
+        d = s.decoder(c, inp)
+        for kv in filter(None, os.environ.get("FLTX_FUZZ_SET", "").split(",")):
+            d.set(kv.split("=")[0], int(kv.split("=")[1]))
+        d.decode_batch(inp["e"], [c["T"]], c["N"])
+        got = d.results(0)
+        s.last_engine = d.get("engine")
+        d.close()
         ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
     except Exception as e:
         ok, why = False, "EXC %r" % (e,)
