@@ -1173,17 +1173,31 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
           capC = capRec;
           cut = true;
         } else {
-          const int64_t capRec2 = std::max<int64_t>(M * 5 / 4 + 64, 256);
+          int64_t Mr = M;
+          int64_t capRec2 = std::max<int64_t>(Mr * 5 / 4 + 64, 256);
           auto bytesRe = [&]() {
             return carveWs(tmp, nullptr, K, (int)capRec2, hsFor(capRec2), d->NB, N, d->SCAP, d->dense, d->lane, 0,
                            d->itemCap, d->threads / 64);
           };
+          if (bytesRe() > kMaxLds && d->itemCap && d->userCutM <= 0) {
+            /* The item list is worth more than the third member of every group
+             * (groups average ~1.3 members): keep 2K + 64 if that makes it fit.
+             * A frame whose merge then yields fewer than K groups although a
+             * candidate above the threshold was left out is flagged as always
+             * (beam 300 x 29 tokens: 15.6 -> 9.5 ms, none flagged). */
+            const int64_t M2 = 2 * (int64_t)K + 64, cap2 = std::max<int64_t>(M2 * 5 / 4 + 64, 256);
+            if (carveWs(tmp, nullptr, K, (int)cap2, hsFor(cap2), d->NB, N, d->SCAP, d->dense, d->lane, 0, d->itemCap,
+                        d->threads / 64) <= kMaxLds) {
+              Mr = M2;
+              capRec2 = cap2;
+            }
+          }
           if (bytesRe() > kMaxLds && d->itemCap) {
             d->itemCap = 0; /* the grid form of the generation needs no list */
           }
           if (bytesRe() <= kMaxLds) {
             d->cutRecompute = 1;
-            d->cutM = (int)M;
+            d->cutM = (int)Mr;
             capC = capRec2;
             cut = true;
           }
