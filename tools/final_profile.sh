@@ -28,3 +28,6 @@ cd "$R"
 # keep the merge-back small: only the csv summaries
 find "$O" -name "*.db" -delete 2>/dev/null
 du -sh "$O"
+# afterwards, in the container (bench.py looks the traffic up by this exact workload string):
+#   python tools/pmc_traffic.py <fetch>_counter_collection.csv <write>_counter_collection.csv \
+#       "C2 threads=512 batch=256 T=1000 N=29 beam=50" profiles/rNN/hbm_traffic_C2.json
