@@ -63,3 +63,12 @@ def test_no_device_fails_loudly(lib):
     with pytest.raises(_capi.FltxError) as ei:
         _capi.Context(lib=lib)
     assert "no CPU path" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_bench_finds_the_committed_hbm_traffic_of_its_default_workload():
+    """bench.py quotes roofline.traffic from the rocprofv3 --pmc summary committed
+    under profiles/ -- keyed by the exact geometry it was measured on."""
+    import bench
+    tr = bench.pmc_traffic("C2", 512, 256, 1000, 29, 50)
+    assert tr is not None and tr[0] > 1e8 and tr[1].startswith("profiles/")
+    assert bench.pmc_traffic("C2", 256, 256, 1000, 29, 50) is None  # other geometry: not quoted
