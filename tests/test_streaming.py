@@ -33,12 +33,14 @@ def _same(a, b):
             and np.array_equal(a.words, b.words))
 
 
-def run_stream_scenario(session, oracle_lib, name, chunks, look_backs, threads=None):
+def run_stream_scenario(session, oracle_lib, name, chunks, look_backs, threads=None, tunables=()):
     c = cases.BY_NAME[name]
     inp = helpers.case_inputs(c)
     N, T = c["N"], c["T"]
     od, olm, otrie = _oracle_decoder(oracle_lib, c, inp)
     d = session.decoder(c, inp, threads)
+    for k, v in tunables:
+        d.set(k, v)
     oracle_lib.decoder_begin(od)
     d.stream_begin(1, N, T + 4)
     t = 0
@@ -95,3 +97,19 @@ def test_streaming_emulated(emu_session, oracle_lib, name, chunks, lbs):
 ], ids=lambda x: x if isinstance(x, str) else None)
 def test_streaming_on_device(gpu_session, oracle_lib, name, chunks, lbs):
     run_stream_scenario(gpu_session, oracle_lib, name, chunks, lbs)
+
+
+@pytest.mark.parametrize("name,chunks,lbs", SCENARIOS[:2], ids=[s[0] for s in SCENARIOS[:2]])
+def test_streaming_emulated_over_hbm_workspace(emu_session, oracle_lib, name, chunks, lbs):
+    """The same with the beam in an HBM workspace and only the counters (and
+    candidate records) in LDS: nothing kept in LDS may be needed by the next chunk's launch."""
+    run_stream_scenario(emu_session, oracle_lib, name, chunks, lbs, threads=64, tunables=[("lds_budget", 2048)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hot", [1, 2])
+@pytest.mark.parametrize("name,chunks,lbs", SCENARIOS + [("ng_word_t60_k16_4g", [10, 10, 10, 10, 10, 10], [0, 2])],
+                         ids=lambda x: x if isinstance(x, str) else None)
+def test_streaming_on_device_over_hbm_workspace(gpu_session, oracle_lib, name, chunks, lbs, hot):
+    run_stream_scenario(gpu_session, oracle_lib, name, chunks, lbs,
+                        tunables=[("lds_budget", 2048), ("hot_level", hot)])
