@@ -1,0 +1,55 @@
+/*
+ * fltx_instances.h -- every decode-kernel instantiation the host can launch
+ * (launchDecode in fltx_api.cpp), as FLTX_INST(name<args>) lines grouped so
+ * that one group of one workgroup size is one translation unit.
+ *
+ *   fltx_api.cpp    : no FLTX_INST_W  -> all groups x all sizes (extern template)
+ *   fltx_kinst.cpp  : -DFLTX_INST_W=512 -DFLTX_INST_G=1 -> that group only
+ *
+ * (No include guard: it is included with different FLTX_INST definitions.)
+ */
+#define FLTX_G1(W) /* lane-per-slot step, 4 tokens per wave */ \
+  FLTX_INST(fltx_decode_kernel_lane<W, 4, false, false>)      \
+  FLTX_INST(fltx_decode_kernel_lane<W, 4, false, true>)       \
+  FLTX_INST(fltx_decode_kernel_lane<W, 4, true, false>)       \
+  FLTX_INST(fltx_decode_kernel_lane<W, 4, true, true>)
+#define FLTX_G2(W) /* lane-per-slot step, 8 tokens per wave */ \
+  FLTX_INST(fltx_decode_kernel_lane<W, 8, false, false>)      \
+  FLTX_INST(fltx_decode_kernel_lane<W, 8, false, true>)       \
+  FLTX_INST(fltx_decode_kernel_lane<W, 8, true, false>)       \
+  FLTX_INST(fltx_decode_kernel_lane<W, 8, true, true>)
+#define FLTX_G3(W) /* lean step, groups in registers / streaming */ \
+  FLTX_INST(fltx_decode_kernel_lds<W, 6>)                          \
+  FLTX_INST(fltx_decode_kernel_lds<W, 12>)                         \
+  FLTX_INST(fltx_decode_kernel_lds<W, 255>)
+#define FLTX_G4(W) FLTX_INST(fltx_decode_kernel_lds<W, 0>) /* generic engine */
+#define FLTX_G5(W) FLTX_INST(fltx_decode_kernel_lds_spec<W, true, true>)
+#define FLTX_G6(W) FLTX_INST(fltx_decode_kernel_lds_spec<W, true, false>)
+#define FLTX_G7(W) FLTX_INST(fltx_decode_kernel_lds_spec<W, false, true>)
+#define FLTX_G8(W) FLTX_INST(fltx_decode_kernel_gws<W>)
+#define FLTX_G9(W) FLTX_INST(fltx_decode_kernel_gwslean<W>)
+
+#ifdef FLTX_INST_W
+#define FLTX_CAT2_(a, b) a##b
+#define FLTX_CAT_(a, b) FLTX_CAT2_(a, b)
+FLTX_CAT_(FLTX_G, FLTX_INST_G)(FLTX_INST_W)
+#undef FLTX_CAT_
+#undef FLTX_CAT2_
+#else
+#define FLTX_ALLG(W) FLTX_G1(W) FLTX_G2(W) FLTX_G3(W) FLTX_G4(W) FLTX_G5(W) FLTX_G6(W) FLTX_G7(W) FLTX_G8(W) FLTX_G9(W)
+FLTX_ALLG(64)
+FLTX_ALLG(128)
+FLTX_ALLG(256)
+FLTX_ALLG(512)
+FLTX_ALLG(1024)
+#undef FLTX_ALLG
+#endif
+#undef FLTX_G1
+#undef FLTX_G2
+#undef FLTX_G3
+#undef FLTX_G4
+#undef FLTX_G5
+#undef FLTX_G6
+#undef FLTX_G7
+#undef FLTX_G8
+#undef FLTX_G9

@@ -1,0 +1,60 @@
+/*
+ * fltx_kernel_entry.h -- the __global__ entry points of the decode kernels
+ * (templates over workgroup size and engine variant).  Every instantiation
+ * the host launches is listed once in fltx_instances.h; fltx_api.cpp declares
+ * them `extern template` and the instance translation units (fltx_kinst.cpp,
+ * one object per group, compiled in parallel by __graft_entry__.build) define
+ * them, so the 85 kernels do not have to be compiled by one hipcc process.
+ */
+#pragma once
+#include "fltx_kernels.h"
+
+#ifndef FLTX_EMU
+using namespace fltx;
+/* kernels: global scope, external linkage (the runtime resolves them by name) */
+/* One instantiation per workgroup size so that __launch_bounds__ gives the
+ * register allocator the real budget (256 threads = 1 wave per SIMD = up to
+ * 512 VGPRs; the 1024-thread default would cap it at 128 and spill). */
+template <int W, int GMAX>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_lds(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  decodeUtterance<GMAX>(P, fltx_smem);
+}
+/* generic engine specialised by assumption: LEX = lexicon decoder with a word LM
+ * (no lexicon-free generation, no token-LM paths), ZLM = ZeroLM (no n-gram
+ * scoring: a third of the kernel and a good part of its register pressure).
+ * The facts are stated to the compiler, which then drops the dead paths. */
+template <int W, bool LEX, bool ZLM>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_lds_spec(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  if (LEX) {
+    __builtin_assume(P.kind == 1);
+    __builtin_assume(P.isLmToken == 0);
+    __builtin_assume(P.dense == 0);
+  }
+  if (ZLM) {
+    __builtin_assume(P.lmKind == 0);
+    __builtin_assume(P.isLmToken == 0);
+  } else {
+    __builtin_assume(P.lmKind == 1);
+  }
+  decodeUtterance<0>(P, fltx_smem);
+}
+template <int W, int GT, bool LOGADD, bool FULLTOK>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  decodeUtterance<1, GT, LOGADD, FULLTOK>(P, fltx_smem);
+}
+template <int W>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) { /* streaming lean step, HBM workspace */
+  extern __shared__ __attribute__((aligned(16))) char fltx_hot[]; /* histogram & block scalars stay in LDS */
+  decodeUtterance<255>(P, P.gws + (size_t)blockIdx.x * P.gwsStride, fltx_hot);
+}
+template <int W>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_gws(DecodeParams P) {
+  /* HBM workspace; the histogram and block scalars -- and, when they fit, the
+   * candidate records and the merge hash -- stay in LDS (carveWs splitHot) */
+  extern __shared__ __attribute__((aligned(16))) char fltx_hot2[];
+  decodeUtterance<0>(P, P.gws + (size_t)blockIdx.x * P.gwsStride, fltx_hot2);
+}
+#endif /* !FLTX_EMU */
