@@ -83,6 +83,12 @@ FLTX_DEV uint32_t atomCas32(uint32_t* p, uint32_t cmp, uint32_t val) {
 FLTX_DEV uint32_t atomExch32(uint32_t* p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 FLTX_DEV uint32_t atomAdd32(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 FLTX_DEV uint32_t atomOr32(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+FLTX_DEV uint32_t atomMin32(uint32_t* p, uint32_t v) {
+  uint32_t cur = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (cur > v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+  }
+  return cur;
+}
 FLTX_DEV unsigned long long atomMax64(unsigned long long* p, unsigned long long v) {
   unsigned long long cur = __atomic_load_n(p, __ATOMIC_SEQ_CST);
   while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
@@ -132,6 +138,11 @@ FLTX_DEV unsigned long long waveBallot(bool p) {
   });
 }
 FLTX_DEV int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+FLTX_DEV int waveUniform(int v) { return v; }
+FLTX_DEV int wavePrefixCount(unsigned long long m) {
+  const int lane = (int)(threadIdx.x & 63);
+  return __builtin_popcountll(lane ? (m & (~0ull >> (64 - lane))) : 0ull);
+}
 FLTX_DEV uint32_t waveShfl32(uint32_t v, int src) {
   return emuExchange(v, [src](const unsigned long long* s) { return (uint32_t)s[src & 63]; });
 }

@@ -252,6 +252,9 @@ struct fltx_decoder {
   int CAP = 0, HS = 0, NB = 0, SCAP = 0, dense = 0, noDense = 0;
   int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
+  int slane = 0, noSlane = 0; /* slane: list positions per wave of the lane = LM state kernel (fltx_slane.h), 0 = off */
+  bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
+  const float* lastEmis = nullptr; /* device emissions of the last offline batch (the back-trace re-reads them) */
   size_t hotBytes = 0; /* LDS part of a split (HBM + LDS) workspace */
   int hotLevel = 0;    /* what the LDS part holds (carveWs) */
   size_t ldsBudget = 0; /* tests: smaller LDS than the hardware's */
@@ -875,7 +878,9 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     return fail(FLTX_ERR_INVALID, "fltx_decoder_get: null argument");
   }
   if (!strcmp(key, "engine")) {
-    *value = d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0));
+    *value = d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0)));
+  } else if (!strcmp(key, "slane")) {
+    *value = d->slane;
   } else if (!strcmp(key, "lane")) {
     *value = d->lane;
   } else if (!strcmp(key, "lean")) {
@@ -952,6 +957,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "cut")) { /* 0: the lexicon decoder materialises every candidate (no score-pass cut) */
     d->noCut = value ? 0 : 1;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "slane")) { /* 0: do not use the lane = LM state kernel (fltx_slane.h) */
+    d->noSlane = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "lane")) { /* 0: beams <= 64 use the lean kernel instead of the lane-per-slot kernel */
@@ -1047,6 +1056,25 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const int nW = d->threads / 64;
     const int per = (nTok + nW - 1) / nW;
     d->lane = per <= 4 ? 4 : (per <= 8 ? 8 : 0);
+  }
+  /* lane = LM state decode (fltx_slane.h): offline lexicon-free + ZeroLM max-merge, beam and
+   * tokens within one wave's lanes; the history rows are its LM-state memo (23-bit ids) */
+  d->slane = 0;
+  if (d->lane && !d->noSlane && d->offlineCall && !d->keepScores && !d->opt.log_add && !forceWorstCaseCap &&
+      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
+      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
+      (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
+    const int thr = d->userThreads ? d->threads : 512;
+    const int nNorm = thr / 64 - 1;
+    const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
+    if (nNorm >= 1 && nList <= 4 * nNorm) {
+      d->slane = 4;
+    } else if (nNorm >= 1 && nList <= 9 * nNorm) {
+      d->slane = 9;
+    }
+    if (d->slane) {
+      d->threads = thr;
+    }
   }
   if (d->lean && !d->lane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
     Ws t2;
@@ -1213,6 +1241,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
                          d->threads / 64);
   }
   d->wsInLds = lds;
+  if (d->slane) {
+    d->wsBytes = sizeof(SlaneLds);
+    d->wsInLds = true;
+    lds = true;
+  }
   /* buffers */
   bool grewTab = false;
   int rc = 0;
@@ -1253,7 +1286,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (!lds) {
     rc |= d->gws.ensure(d->wsBytes * (size_t)B, st, false);
   }
-  if (d->lean) {
+  if (d->lean && !d->slane) {
     d->idCap = (int64_t)K * (maxT + 2) + 2;
     rc |= d->childTab.ensure(4 * (size_t)B * d->idCap * N, st, false);
     rc |= d->maskTab.ensure(8 * (size_t)B * d->idCap, st, false);
@@ -1359,9 +1392,10 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   const DecodeParams* pp = &P;
   const int gmax = d->lean;
   const int gt = d->lane;
+  const int sl = d->slane;
   const bool hot = !d->wsInLds && d->hotBytes > 0;
   emuLaunch(d->nLaunch > 0 ? d->nLaunch : d->B, W, d->wsInLds ? d->wsBytes : (hot ? d->hotBytes : 16),
-            [pp, gmax, gt, hot](char* smem) {
+            [pp, gmax, gt, sl, hot](char* smem) {
     char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
     if (hot) {
       if (gmax == 255) {
@@ -1372,7 +1406,11 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       return;
     }
     const bool ft = pp->Kt >= pp->N;
-    if (gt == 4) {
+    if (sl == 4) {
+      slaneUtterance<4, false>(*pp, smem);
+    } else if (sl == 9) {
+      slaneUtterance<9, false>(*pp, smem);
+    } else if (gt == 4) {
       if (pp->logAdd) {
         ft ? decodeUtterance<1, 4, true, true>(*pp, base) : decodeUtterance<1, 4, true, false>(*pp, base);
       } else {
@@ -1437,9 +1475,23 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       FLTX_LAUNCH_LANE1(WW, GG, false, false);                                                   \
     }                                                                                            \
   } while (0)
+#define FLTX_LAUNCH_SLANE(WW, GG)                                                                \
+  do {                                                                                           \
+    if (d->profile) {                                                                            \
+      hipLaunchKernelGGL((fltx_decode_kernel_slane<WW, GG, true>), dim3(nGrid), dim3(WW),        \
+                         d->wsBytes, d->ctx->stream, P);                                         \
+    } else {                                                                                     \
+      hipLaunchKernelGGL((fltx_decode_kernel_slane<WW, GG, false>), dim3(nGrid), dim3(WW),       \
+                         d->wsBytes, d->ctx->stream, P);                                         \
+    }                                                                                            \
+  } while (0)
 #define FLTX_LAUNCH(WW)                                                                          \
   do {                                                                                           \
-    if (!d->wsInLds && d->lean) {                                                                \
+    if (d->slane == 4) {                                                                         \
+      FLTX_LAUNCH_SLANE(WW, 4);                                                                  \
+    } else if (d->slane == 9) {                                                                  \
+      FLTX_LAUNCH_SLANE(WW, 9);                                                                  \
+    } else if (!d->wsInLds && d->lean) {                                                                \
       hipLaunchKernelGGL(fltx_decode_kernel_gwslean<WW>, dim3(nGrid), dim3(WW), d->hotBytes, d->ctx->stream, P); \
     } else if (!d->wsInLds) {                                                                    \
       HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_gws<WW>,                        \
@@ -1478,6 +1530,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
 #undef FLTX_LAUNCH_LANE
 #undef FLTX_LAUNCH_LANE1
 #undef FLTX_LAUNCH_SPEC
+#undef FLTX_LAUNCH_SLANE
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(d->ev[1], d->ctx->stream));
   d->timed = false;
@@ -1523,6 +1576,7 @@ int uploadStep(fltx_decoder* d, const float* emissions, int onDevice, const int6
     }
     P.emissions = d->emis.as<float>();
   }
+  d->lastEmis = P.emissions;
   if (devCopyH2D(d->emOff.p, offs.data(), sizeof(int64_t) * B, st) ||
       devCopyH2D(d->stepT.p, T, sizeof(int32_t) * B, st)) {
     return fail(FLTX_ERR_HIP, "batch descriptor upload failed");
@@ -1589,7 +1643,17 @@ int launchBacktrace(fltx_decoder* d) {
     F = 0;
   }
   Q.F = F;
-  const size_t btLds = F > 0 ? (size_t)F * perFrame + 16 : 16;
+  size_t btLds = F > 0 ? (size_t)F * perFrame + 16 : 16;
+  if (d->slane && F > 0) { /* packed records; emitting-model scores re-accumulated along the paths */
+    Q.packed = 1;
+    Q.amOut = d->outScores.as<double>();
+    Q.emissions = d->lastEmis;
+    Q.emOff = d->emOff.as<int64_t>();
+    Q.N = d->N;
+    Q.transitions = (d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? d->transitions.as<float>() : nullptr;
+    const size_t amLds = 4 * ((size_t)F * d->N + (Q.transitions ? (size_t)d->N * d->N : 0) + (size_t)Q.K * F) + 16;
+    btLds = std::max(btLds, amLds);
+  }
 #ifdef FLTX_EMU
   const BacktraceParams* qq = &Q;
   emuLaunch(d->B, btThreads, btLds, [qq](char* smem) { backtraceUtterance(*qq, smem); });
@@ -1650,6 +1714,8 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   bool recomputeRetry = false; /* this attempt is the recompute form of the cut-off generation */
   bool recomputeTried = false;
   const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
+  const int savedNoSlane = d->noSlane;
+  d->offlineCall = true;
   for (int attempt = 0; attempt < 3; ++attempt) {
     const bool finalForm = attempt > 0 && !recomputeRetry; /* the general path: nothing left to fall back to */
     int rc = prepare(d, B, N, T, finalForm);
@@ -1686,7 +1752,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
       if ((rc = syncResults(d))) {
         return rc;
       }
-      bool ws = false, cut = false, lean = false;
+      bool ws = false, cut = false, lean = false, slaneMiss = false;
       const bool slimMode = d->CAP2 > 0;
       std::vector<int32_t> again;
       const int nScan = attempt == 0 ? B : (int)redoList.size();
@@ -1701,6 +1767,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
           ws |= o;
           cut |= c;
           lean |= l;
+          slaneMiss |= l && d->slane;
         }
       }
       redoList.swap(again);
@@ -1721,6 +1788,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         d->forceGlobalWs = ws ? 1 : d->forceGlobalWs;
         d->noCut = cut ? 1 : d->noCut;
         d->noLean = lean ? 1 : d->noLean;
+        d->noSlane = slaneMiss ? 1 : d->noSlane; /* (re-run on the generic engine) */
         d->resultsSynced = false;
         continue;
       }
@@ -1732,6 +1800,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     d->noCut = savedNoCut;
     d->noLean = savedNoLean;
     d->noSlim = savedNoSlim;
+    d->noSlane = savedNoSlane;
   }
   d->resultsSynced = false;
   int rc = launchBacktrace(d);
@@ -1750,6 +1819,7 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
     return fail(FLTX_ERR_INVALID, "fltx_stream_begin: bad argument");
   }
   std::vector<int32_t> Tm(B, maxFrames);
+  d->offlineCall = false;
   d->keepScores = 1; /* streams serve getBestHypothesis(lookBack) of ancestors */
   int rc = prepare(d, B, N, Tm.data(), true);
   if (rc) {

@@ -28,6 +28,11 @@
 #define FLTX_G7(W) FLTX_INST(fltx_decode_kernel_lds_spec<W, false, true>)
 #define FLTX_G8(W) FLTX_INST(fltx_decode_kernel_gws<W>)
 #define FLTX_G9(W) FLTX_INST(fltx_decode_kernel_gwslean<W>)
+#define FLTX_G10(W) /* lane = LM state decode (fltx_slane.h) */ \
+  FLTX_INST(fltx_decode_kernel_slane<W, 4, false>)             \
+  FLTX_INST(fltx_decode_kernel_slane<W, 9, false>)             \
+  FLTX_INST(fltx_decode_kernel_slane<W, 4, true>)              \
+  FLTX_INST(fltx_decode_kernel_slane<W, 9, true>)
 
 #ifdef FLTX_INST_W
 #define FLTX_CAT2_(a, b) a##b
@@ -36,7 +41,7 @@ FLTX_CAT_(FLTX_G, FLTX_INST_G)(FLTX_INST_W)
 #undef FLTX_CAT_
 #undef FLTX_CAT2_
 #else
-#define FLTX_ALLG(W) FLTX_G1(W) FLTX_G2(W) FLTX_G3(W) FLTX_G4(W) FLTX_G5(W) FLTX_G6(W) FLTX_G7(W) FLTX_G8(W) FLTX_G9(W)
+#define FLTX_ALLG(W) FLTX_G1(W) FLTX_G2(W) FLTX_G3(W) FLTX_G4(W) FLTX_G5(W) FLTX_G6(W) FLTX_G7(W) FLTX_G8(W) FLTX_G9(W) FLTX_G10(W)
 FLTX_ALLG(64)
 FLTX_ALLG(128)
 FLTX_ALLG(256)
@@ -53,3 +58,4 @@ FLTX_ALLG(1024)
 #undef FLTX_G7
 #undef FLTX_G8
 #undef FLTX_G9
+#undef FLTX_G10

@@ -45,6 +45,12 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   decodeUtterance<1, GT, LOGADD, FULLTOK>(P, fltx_smem);
 }
+/* lane = LM state decode of a whole utterance (fltx_slane.h): the headline configuration */
+template <int W, int GT, bool PROF>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_slane(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  slaneUtterance<GT, PROF>(P, fltx_smem);
+}
 template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) { /* streaming lean step, HBM workspace */
   extern __shared__ __attribute__((aligned(16))) char fltx_hot[]; /* histogram & block scalars stay in LDS */

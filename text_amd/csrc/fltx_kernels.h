@@ -2546,6 +2546,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 
 #include "fltx_lean.h"
 #include "fltx_lane.h"
+#include "fltx_slane.h"
 
 /* ------------------------------------------------------------------------ */
 /* the decode kernel: grid = utterances, block = W threads.                  */
@@ -2844,6 +2845,16 @@ struct BacktraceParams {
   int32_t* words;
   int32_t nbest;           /* <= 0: all */
   int32_t F;               /* frames per LDS chunk (0: walk straight through HBM) */
+  /* records of the lane = LM state engine (fltx_slane.h): parent slot in the low byte of x (0xFF = none) */
+  int32_t packed;
+  /* that engine does not carry the emitting-model score through the frames; it is
+   * re-accumulated here along each returned path, in the reference's order
+   * (LexiconFreeDecoder.cpp:58-63,82,95,108: am = prev.am + (e[t][n] (+ transition))) */
+  double* amOut;           /* outScores, or null */
+  const float* emissions;
+  const int64_t* emOff;
+  const float* transitions; /* ASG, else null */
+  int32_t N;
 };
 
 /* A parent-pointer walk is a chain of T dependent loads; straight from HBM that
@@ -2877,7 +2888,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
           const int2 pt = P.histPT[idx];
           tokv = pt.y;
           wv = lex ? P.histW[idx] : -1;
-          slot = pt.x;
+          slot = P.packed ? (((pt.x & 0xFF) == 0xFF) ? -1 : (pt.x & 0xFF)) : pt.x;
         }
         tk[fr] = tokv; /* pruned history: -1 below the cut */
         if (wd) {
@@ -2954,7 +2965,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
               const int2 pt = cPT[j * K + s];
               tokv = pt.y;
               wv = lex ? cW[j * K + s] : -1;
-              s = pt.x;
+              s = P.packed ? (((pt.x & 0xFF) == 0xFF) ? -1 : (pt.x & 0xFF)) : pt.x;
             }
             oT[k * F + j] = tokv;
             if (P.words) {
@@ -2980,6 +2991,54 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
       }
     }
     __syncthreads();
+  }
+  if (P.amOut) {
+    /* emitting-model scores, oldest frame first: the token rows just written and the
+     * emission rows are staged F frames at a time, then hypothesis k (thread k) adds up
+     * its path with LDS reads only (the chain is the additions, not the loads) */
+    float* eT = (float*)smem;                       /* [F][N] */
+    float* trT = eT + (size_t)F * P.N;              /* [N][N] (ASG) */
+    int32_t* tT = (int32_t*)(trT + (P.transitions ? (size_t)P.N * P.N : 0)); /* [nh][F] */
+    const int N = P.N;
+    const float* em = P.emissions + P.emOff[b];
+    if (P.transitions) {
+      for (int i = tid; i < N * N; i += W) {
+        trT[i] = P.transitions[i];
+      }
+    }
+    const int Tb = ff - 1; /* frames decoded: history rows 1 .. Tb */
+    double am = 0.0;
+    int prevTok = (tid < nh && len > 0) ? P.tokens[ob + (int64_t)tid * len] : 0;
+    for (int lo = 1; lo <= Tb; lo += F) {
+      const int hi = lo + F - 1 < Tb ? lo + F - 1 : Tb;
+      const int nf = hi - lo + 1;
+      __syncthreads();
+      for (int k = tid >> 6; k < nh; k += W >> 6) {
+        for (int j = tid & 63; j < nf; j += 64) {
+          tT[k * F + j] = P.tokens[ob + (int64_t)k * len + lo + j];
+        }
+      }
+      for (int i = tid; i < nf * N; i += W) {
+        eT[i] = em[(size_t)(lo - 1) * N + i];
+      }
+      __syncthreads();
+      if (tid < nh) {
+        for (int j = 0; j < nf; ++j) {
+          const int n = tT[tid * F + j];
+          if (n >= 0) {
+            double x = (double)eT[j * N + n];
+            if (P.transitions && lo - 1 + j > 0) {
+              x += (double)trT[n * N + prevTok];
+            }
+            am += x;
+            prevTok = n;
+          }
+        }
+      }
+    }
+    if (tid < nh) {
+      P.amOut[((size_t)b * K + tid) * 3 + 1] = am;
+    }
   }
 }
 /* ------------------------------------------------------------------------ */

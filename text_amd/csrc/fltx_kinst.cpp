@@ -5,7 +5,7 @@
  * links them all into text_amd/lib/libfltx.so.
  */
 #if !defined(FLTX_INST_W) || !defined(FLTX_INST_G)
-#error "compile with -DFLTX_INST_W=<64|128|256|512|1024> -DFLTX_INST_G=<1..9>"
+#error "compile with -DFLTX_INST_W=<64|128|256|512|1024> -DFLTX_INST_G=<1..10>"
 #endif
 #include "fltx_kernel_entry.h"
 

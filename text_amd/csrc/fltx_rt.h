@@ -36,6 +36,7 @@ FLTX_DEV uint32_t atomCas32(uint32_t* p, uint32_t cmp, uint32_t val) {
 FLTX_DEV uint32_t atomExch32(uint32_t* p, uint32_t val) { return atomicExch(p, val); }
 FLTX_DEV uint32_t atomAdd32(uint32_t* p, uint32_t val) { return atomicAdd(p, val); }
 FLTX_DEV uint32_t atomOr32(uint32_t* p, uint32_t val) { return atomicOr(p, val); }
+FLTX_DEV uint32_t atomMin32(uint32_t* p, uint32_t val) { return atomicMin(p, val); }
 FLTX_DEV unsigned long long atomMax64(unsigned long long* p, unsigned long long v) {
   return atomicMax(p, v);
 }
@@ -95,6 +96,12 @@ FLTX_DEV unsigned long long waveShflXor64(unsigned long long v, int m) {
   return ((unsigned long long)hi << 32) | lo;
 }
 FLTX_DEV int waveFirstLaneI(int v) { return __builtin_amdgcn_readfirstlane(v); }
+/* a value the caller knows to be the same in every lane, moved to a scalar register */
+FLTX_DEV int waveUniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+/* number of set bits of `m` below this lane (v_mbcnt_lo/hi) */
+FLTX_DEV int wavePrefixCount(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 #endif /* !FLTX_EMU */
 
 /* ---- portable helpers ------------------------------------------------------ */

@@ -1,0 +1,807 @@
+/*
+ * fltx_slane.h -- "lane = LM state" decode of a whole utterance for the headline
+ * configuration: LexiconFreeDecoder + ZeroLM, max-merge, beam <= 64, <= 64
+ * tokens, offline (decodeBegin + all frames + decodeEnd in one launch).
+ * Included by fltx_kernels.h.  Same candidates, same merge groups, same
+ * selection as LexiconFreeDecoder::decodeStep (LexiconFreeDecoder.cpp:30-125)
+ * with candidatesStore (Utils.h:146-225): bit-identical n-best.
+ *
+ * What is different from fltx_lane.h is what a frame has to do at all:
+ *
+ *   * A lane holds an LM STATE, not a hypothesis: the two hypotheses a state
+ *     can have in the beam -- (S, last token, prevBlank = false) and
+ *     (S, blank, prevBlank = true), LexiconFreeDecoder.h:68-78 -- are the two
+ *     scores `nb` / `b` of one 32-byte record.  The merge of Utils.h:167-198
+ *     then has a fixed shape: every extension of S by a new token n reaches
+ *     state S.n from max(nb, b) (one candidate per (lane, token), no partner
+ *     look-up); S's blank extension and S's repeat are the lane's own; the
+ *     only cross-lane member of any group is the parent state's extension by
+ *     last(S), which joins S's repeat -- one parent link per lane, kept up to
+ *     date by the build step.
+ *   * With ZeroLM the frame's best candidate is best hypothesis + best token,
+ *     and the best hypothesis of frame t + 1 IS the best candidate of frame t:
+ *     best(t) = fl(best(t-1) + emax(t)) is a scalar recurrence every wave
+ *     carries in registers.  The beam therefore need not be sorted, and no
+ *     frame ranks its survivors: a candidate survives iff its histogram bin is
+ *     better than the bin of the K-th best; only the members of that one bin
+ *     are compared with each other (and only when not all of them survive).
+ *   * No short-list, no scatter: after the histogram scan every lane knows
+ *     which of its own candidates survived; new lanes are handed out by a
+ *     per-wave count (one LDS add per wave) and every survivor's record,
+ *     history entry and parent-mask update is written by the lane that
+ *     evaluated it.
+ *   * The emitting-model score is not carried through the frames at all (it
+ *     takes part in no decision): the back-trace kernel re-accumulates it
+ *     along each returned path in the reference's order.
+ *   * An LM state's identity is the index of the history record of the
+ *     hypothesis that first entered it; that record also stores the parent
+ *     state's id and the token, so the history rows double as the memo of
+ *     LMState::child (lm/LM.h:24-34): nothing else is written per frame.  The
+ *     rare re-entry of a state that had dropped out of the beam (about one
+ *     frame in a hundred on the benchmark inputs) scans the rows.
+ *
+ * Three barriers per frame; between them a wave issues ~60 instructions.
+ */
+#pragma once
+
+constexpr int kSlNB = 512;          /* histogram bins: 8 per lane of the scan */
+constexpr int kSlBCap = 128;        /* boundary-bin members compared pairwise */
+constexpr int kSlFineShift = 15;    /* 256 bins per octave of (best - score) */
+constexpr int kSlCoarseShift = 18;  /* 32 bins per octave: 16 octaves in 512 bins */
+constexpr int kSlCoarseBase = 120 << 5; /* float bits of 2^-7, >> kSlCoarseShift */
+constexpr uint32_t kSlNoHyp = 0xFFu;
+constexpr uint32_t kSlNewFlag = 0x100u; /* history record: the hypothesis entered a new LM state */
+
+struct SlRec { /* one LM state of the beam, 32 B */
+  double nb;     /* score of (S, last, prevBlank = false), -inf if absent */
+  double b;      /* score of (S, blank, prevBlank = true), -inf if absent */
+  uint32_t info; /* last token | (parent lane + 1) << 8 | history slot of nb << 16 | of b << 24 */
+  uint32_t sid;  /* state id = history index (row * K + slot) of the hypothesis that entered it */
+  uint32_t spar; /* id of the parent state */
+  uint32_t pad;
+};
+
+struct SlRow { /* what a frame needs to know about its emission row, 32 B */
+  float emaxNS;  /* largest allowed emission of a token other than sil (-inf: none) */
+  float eSil;
+  uint32_t silAllowed;
+  int32_t nList; /* tokens the normal waves evaluate (allowed, not blank) */
+  unsigned long long allow; /* token beam (LexiconFreeDecoder.cpp:42-51): bit n = token n is evaluated */
+  uint32_t nev;  /* re-entry events recorded by the build of the previous frame */
+  int32_t silPos; /* list position of sil, or a value no wave matches */
+};
+
+template <int V>
+struct SlParity {
+  static constexpr int value = V;
+};
+
+struct SlaneLds {
+  SlRec rec[2][64];
+  unsigned long long cmask[2][64]; /* tokens whose child state is in the beam and linked to this lane */
+  unsigned long long mask[2][64];  /* tokens whose child state was ever materialised */
+  uint32_t hist[2][kSlNB];
+  double eAll[2][64];              /* emission row, widened */
+  double eTok[2][64];              /* ... of the listed tokens, by list position */
+  SlRow row[2];
+  uint8_t tokId[2][64];            /* list position -> token */
+  uint32_t off[16];                /* new states of the waves before wave i; [nW] = all */
+  int32_t newLane[64];             /* old lane -> lane in the next beam, -1 = dropped */
+  uint32_t scal[16];
+  unsigned long long bKey[kSlBCap];
+  uint32_t bOrd[kSlBCap];
+  uint32_t evLane[64], evSpar[64], evTok[64];
+  unsigned long long scanMask;
+  uint32_t scanMin, pad0;
+};
+enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2, SL_STATUS = 3 };
+
+FLTX_DEV double slNegInf() { return -__builtin_huge_val(); }
+
+/* bin of a candidate `d` below the frame's best: a window of 512 bins over the
+ * float bit pattern of d (monotone in d, hence in the score: any such binning
+ * gives exact selection); everything nearer than the window shares bin 0,
+ * everything farther bin 511 */
+FLTX_DEV int slBin(double best, double c, int shift, int base) {
+  const float d = (float)(best - c);
+  int q = (int)(__float_as_uint(d) >> shift) - base;
+  q = q < 0 ? 0 : q;
+  return q > kSlNB - 1 ? kSlNB - 1 : q;
+}
+
+struct SlScan {
+  int bstar; /* bin holding the K-th best candidate */
+  int cum;   /* candidates in better bins */
+  int cnt;   /* candidates in bin bstar */
+  int total;
+};
+/* every wave scans the 512 counts itself (8 bins per lane, DPP prefix) */
+FLTX_DEV SlScan slScan(const uint32_t* hist, int K) {
+  const int lane = laneId();
+  const uint4 c0 = ((const uint4*)hist)[2 * lane], c1 = ((const uint4*)hist)[2 * lane + 1];
+  const int mine = (int)(c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w);
+  const int inc = waveInclusiveScan(mine);
+  int pre[9];
+  pre[0] = inc - mine;
+  pre[1] = pre[0] + (int)c0.x;
+  pre[2] = pre[1] + (int)c0.y;
+  pre[3] = pre[2] + (int)c0.z;
+  pre[4] = pre[3] + (int)c0.w;
+  pre[5] = pre[4] + (int)c1.x;
+  pre[6] = pre[5] + (int)c1.y;
+  pre[7] = pre[6] + (int)c1.z;
+  pre[8] = inc;
+  SlScan r;
+  r.total = (int)waveReadLane32((uint32_t)inc, 63);
+  const unsigned long long cm = waveBallot(pre[0] < K && inc >= K);
+  int q = 7, before = pre[7], cq = pre[8] - pre[7];
+#pragma unroll
+  for (int i = 6; i >= 0; --i) {
+    const bool hit = pre[i + 1] >= K;
+    q = hit ? i : q;
+    before = hit ? pre[i] : before;
+    cq = hit ? pre[i + 1] - pre[i] : cq;
+  }
+  const int X = cm ? __builtin_ctzll(cm) : 0;
+  const uint32_t a = waveReadLane32((uint32_t)(8 * lane + q) | ((uint32_t)cq << 16), X);
+  r.cum = (int)waveReadLane32((uint32_t)before, X);
+  r.bstar = (int)(a & 0xFFFFu);
+  r.cnt = (int)(a >> 16);
+  if (!cm) { /* fewer than K candidates: they all survive */
+    r.bstar = kSlNB - 1;
+    r.cum = 0;
+    r.cnt = r.total;
+  }
+  return r;
+}
+
+/* Emission row -> what the frame step reads (buffer q): the widened row, the
+ * token beam, the list of tokens the normal waves evaluate and the row's
+ * largest emission.  One wave; lane n holds e[n]. */
+FLTX_DEV void slPrepRow(const DecodeParams& P, SlaneLds& S, int q, float v, bool ctc) {
+  const int lane = laneId();
+  const int N = P.N;
+  const bool inRow = lane < N;
+  unsigned long long allow = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
+  if (P.Kt < N) { /* LexiconFreeDecoder.cpp:42-51: top beamSizeToken by emission, ties to the lower index */
+    int rank = 0;
+    for (int m = 0; m < N; ++m) {
+      const float o = __uint_as_float(waveReadLane32(__float_as_uint(v), m));
+      rank += (o > v || (o == v && m < lane)) ? 1 : 0;
+    }
+    allow = waveBallot(inRow && rank < P.Kt);
+  }
+  const bool mine = inRow && ((allow >> lane) & 1ull) != 0ull;
+  const uint32_t ek = waveMax32((mine && lane != P.sil && v == v) ? f32Key(v) : 0u);
+  unsigned long long listMask = allow;
+  if (ctc && P.blank >= 0 && P.blank < N) {
+    listMask &= ~(1ull << P.blank);
+  }
+  const int pos = wavePrefixCount(listMask);
+  if (inRow) {
+    S.eAll[q][lane] = (double)v;
+    if ((listMask >> lane) & 1ull) {
+      S.tokId[q][pos] = (uint8_t)lane;
+      S.eTok[q][pos] = (double)v;
+    }
+  }
+  const float eSil = __uint_as_float(waveReadLane32(__float_as_uint(v), P.sil));
+  if (lane == 0) {
+    S.row[q].emaxNS = ek ? f32FromKey(ek) : -__builtin_huge_valf();
+    S.row[q].eSil = eSil;
+    S.row[q].silAllowed = (uint32_t)((allow >> P.sil) & 1ull);
+    S.row[q].nList = popc64(listMask);
+    S.row[q].allow = allow;
+    S.row[q].silPos = ((listMask >> P.sil) & 1ull) ? popc64(listMask & ((1ull << P.sil) - 1ull)) : -4096;
+  }
+}
+
+/* Re-entry of LM states that had dropped out of the beam (recorded by the
+ * build step: a new state whose (parent, token) edge had been materialised
+ * before).  The history rows are the memo of LMState::child (lm/LM.h:24-34):
+ * the earliest record {new state, parent id, token} names the state; records
+ * whose parent id is that state give back its child mask; lanes whose parent id
+ * it is get their link back.  All waves; rare. */
+FLTX_DEV __attribute__((noinline)) void slReenter(SlaneLds& S, const int2* histPT, int q, int nState, int64_t hbase,
+                                                   int64_t nRec) {
+  /* (takes no DecodeParams: passing its address to a call would move the kernel's copy into
+   * scratch memory, and the frame loop would read every option from there) */
+  const int tid = (int)threadIdx.x, W = (int)blockDim.x;
+  const int nev = (int)S.row[q].nev;
+#ifndef FLTX_EMU
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's history stores have reached the L2 */
+#endif
+  ldsBarrier();
+  for (int e = 0; e < nev; ++e) {
+    const int X = (int)S.evLane[e];
+    const uint32_t ps = S.evSpar[e], n = S.evTok[e];
+    if (tid == 0) {
+      S.scanMin = 0xFFFFFFFFu;
+      S.scanMask = 0ull;
+    }
+    ldsBarrier();
+    const unsigned long long* h = (const unsigned long long*)(histPT + hbase);
+    uint32_t found = 0xFFFFFFFFu;
+    for (int64_t i = tid; i < nRec; i += W) {
+      const unsigned long long r = loadCoherent64(h + i);
+      const uint32_t x = (uint32_t)r, y = (uint32_t)(r >> 32);
+      if ((x & kSlNewFlag) && y == n && (x >> 9) == ps) {
+        found = found < (uint32_t)i ? found : (uint32_t)i;
+      }
+    }
+    if (found != 0xFFFFFFFFu) {
+      atomMin32(&S.scanMin, found);
+    }
+    ldsBarrier();
+    const uint32_t sid = S.scanMin;
+    if (sid != 0xFFFFFFFFu) {
+      unsigned long long kids = 0ull;
+      for (int64_t i = tid; i < nRec; i += W) {
+        const unsigned long long r = loadCoherent64(h + i);
+        const uint32_t x = (uint32_t)r, y = (uint32_t)(r >> 32);
+        if ((x & kSlNewFlag) && (x >> 9) == sid) {
+          kids |= 1ull << (y & 63u);
+        }
+      }
+      if (kids) {
+        atomOr64(&S.scanMask, kids);
+      }
+      ldsBarrier();
+      if (tid == 0) {
+        S.rec[q][X].sid = sid;
+        S.mask[q][X] |= S.scanMask;
+      }
+      if (tid < nState && tid != X && S.rec[q][tid].spar == sid) { /* orphans get their parent back */
+        const uint32_t info = S.rec[q][tid].info;
+        S.rec[q][tid].info = (info & ~0xFF00u) | ((uint32_t)(X + 1) << 8);
+        atomOr64(&S.cmask[q][X], 1ull << (info & 0xFFu));
+      }
+    }
+    ldsBarrier();
+  }
+  if (tid == 0) {
+    S.row[q].nev = 0u;
+  }
+  ldsBarrier();
+}
+
+#define FLTX_SLPROF(i)                                        \
+  do {                                                        \
+    if (PROF && P.prof && (int)threadIdx.x == P.profThread) { \
+      const unsigned long long t_ = devClock();               \
+      acc[(i)] += t_ - tPrev;                                 \
+      tPrev = t_;                                             \
+    }                                                         \
+  } while (0)
+
+/* GT = list positions per normal wave (nList <= GT * (waves - 1)) */
+template <int GT, bool PROF>
+FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
+  SlaneLds& S = *(SlaneLds*)smem;
+  const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
+  const int W = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int lane = laneId(), wave = waveUniform(waveId());
+  const int nW = W >> 6;
+  const int selfWave = nW - 1; /* blank / repeat / blank-then-last groups of every lane */
+  const int prepWave = 0;      /* stages the next emission row */
+  const bool isSelf = wave == selfWave;
+  const int K = P.K, N = P.N;
+  const bool ctc = P.criterion == 1;
+  const int T = P.stepT ? P.stepT[b] : 0;
+  const float* em = P.emissions ? P.emissions + P.emOff[b] : nullptr;
+  const int64_t hbase = P.histOff[b];
+  const double NEG = slNegInf();
+  unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long tPrev = devClock();
+
+  /* ---- decodeBegin (LexiconFreeDecoder.cpp:20-28): the root state ------------------ */
+  for (int i = tid; i < 2 * 64; i += W) {
+    ((unsigned long long*)S.cmask)[i] = 0ull;
+    ((unsigned long long*)S.mask)[i] = 0ull;
+  }
+  for (int i = tid; i < 2 * kSlNB; i += W) {
+    ((uint32_t*)S.hist)[i] = 0u;
+  }
+  if (tid < 16) {
+    S.off[tid] = 0u;
+    S.scal[tid] = 0u;
+  }
+  if (tid == 0) {
+    SlRec r;
+    r.nb = 0.0;
+    r.b = NEG;
+    r.info = (uint32_t)P.sil | (0u << 8) | (0u << 16) | (kSlNoHyp << 24);
+    r.sid = 0u;
+    r.spar = 0x7FFFFFu;
+    r.pad = 0u;
+    S.rec[0][0] = r;
+    S.row[0].nev = 0u;
+    S.row[1].nev = 0u;
+    P.histPT[hbase] = make_int2((int)kSlNoHyp, P.sil);
+  }
+  if (tid > 0 && tid < K) { /* unused slots of a row never look like the record of a new state (slReenter) */
+    P.histPT[hbase + tid] = make_int2((int)kSlNoHyp, -1);
+  }
+  /* emission rows: lane n of the prep wave holds e[t + 1][n] (used by the build of frame t) in one of
+   * two registers, alternating with the frame parity; the register is refilled with row t + 3 right
+   * after its use, so a load has two frames to arrive and is never moved between registers */
+  float rowA = 0.0f, rowB = 0.0f;
+  if (wave == prepWave) {
+    const float v0 = (T > 0 && lane < N) ? em[lane] : 0.0f;
+    rowA = (T > 1 && lane < N) ? em[(size_t)1 * N + lane] : 0.0f;
+    rowB = (T > 2 && lane < N) ? em[(size_t)2 * N + lane] : 0.0f;
+    if (T > 0) {
+      slPrepRow(P, S, 0, v0, ctc);
+    }
+  }
+  ldsBarrier();
+
+  int nState = 1, nHyp = 1;
+  double mmax = 0.0; /* best hypothesis of the current beam = best candidate of the previous frame */
+  int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
+  bool dead = false; /* this utterance goes to the general engines */
+  const int sil = P.sil, blank = P.blank;
+  const double silScore = P.silScore, beamThreshold = P.beamThreshold;
+  int2* const histPT = P.histPT;
+
+  /* one frame; PT = parity of the frame (compile time: every LDS address is an immediate) */
+  auto frameStep = [&](auto PT, float& rowReg, const int t) {
+    constexpr int p = decltype(PT)::value, q = p ^ 1;
+    const int frameOut = t + 1;
+    const int64_t hrow = hbase + (int64_t)frameOut * K;
+    /* ---- phase 1: own state, the frame's best, candidates, histogram ------------------- */
+    /* every LDS read of the phase is issued here, before anything waits for one */
+    SlRow row = S.row[p];
+    SlRec me = S.rec[p][lane];
+    unsigned long long cm = S.cmask[p][lane];
+    unsigned long long mk = S.mask[p][lane];
+    double ev[GT];
+    uint32_t tk[GT];
+    double eBlank = 0.0;
+    if (!isSelf) {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        ev[j] = S.eTok[p][wave * GT + j];
+        tk[j] = (uint32_t)S.tokId[p][wave * GT + j] & 63u;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        ev[j] = 0.0;
+        tk[j] = 0u;
+      }
+      eBlank = S.eAll[p][ctc ? blank : 0];
+    }
+    if (row.nev != 0u) { /* rare: states re-entered the beam in the previous build */
+      slReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K);
+      row = S.row[p];
+      me = S.rec[p][lane];
+      cm = S.cmask[p][lane];
+      mk = S.mask[p][lane];
+    }
+    if (tid < kSlNB) {
+      S.hist[q][tid] = 0u;
+    }
+    const bool live = lane < nState;
+    const double nb = live ? me.nb : NEG, bb = live ? me.b : NEG;
+    const int last = (int)(me.info & 0xFFu) & 63;
+    const int pl = live ? (int)((me.info >> 8) & 0xFFu) - 1 : -1;
+    const uint32_t hypNB = (me.info >> 16) & 0xFFu, hypB = me.info >> 24;
+    const bool whichB = bb > nb;
+    const double m = whichB ? bb : nb;
+    const uint32_t hypM = whichB ? hypB : hypNB;
+    /* self wave: what its groups need beyond the lane's own record (second LDS round trip) */
+    SlRec par;
+    double eLast = 0.0;
+    if (isSelf) {
+      par = S.rec[p][pl >= 0 ? pl : 0];
+      eLast = S.eAll[p][last];
+    }
+    /* best candidate of the frame (Utils.h:131-137): best hypothesis + best token */
+    double best = 0.0;
+    bool any = false;
+    if (row.emaxNS > -__builtin_huge_valf()) {
+      best = mmax + (double)row.emaxNS;
+      any = true;
+    }
+    if (row.silAllowed) {
+      const double sS = (mmax + (double)row.eSil) + silScore;
+      if (sS == sS && (!any || sS > best)) {
+        best = sS;
+        any = true;
+      }
+    }
+    if (!any || !(best - best == 0.0)) { /* nothing to extend with, or not finite: general path */
+      dead = true;
+      return;
+    }
+    const double thr = best - beamThreshold;
+    FLTX_SLPROF(0);
+    double cs[GT];
+    int cbin[GT];
+    uint32_t okBits = 0u;
+    uint32_t parR = kSlNoHyp;
+    if (!isSelf) {
+      const unsigned long long skip = cm | (1ull << last);
+      const int silJ = (int)row.silPos - wave * GT; /* list position of sil relative to this wave's first */
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        double c = m + ev[j];
+        if (j == silJ) {
+          c = c + silScore;
+        }
+        const bool ok = live && wave * GT + j < row.nList && ((skip >> tk[j]) & 1ull) == 0ull && c >= thr;
+        cs[j] = c;
+        cbin[j] = slBin(best, c, winShift, winBase);
+        okBits |= ok ? (1u << j) : 0u;
+      }
+    } else {
+      const bool lastOk = live && ((row.allow >> last) & 1ull) != 0ull && !(ctc && last == blank);
+      const bool lastSil = last == sil;
+      /* (S, blank, true): LexiconFreeDecoder.cpp:86-97 */
+      double cB = m + eBlank;
+      if (blank == sil) {
+        cB = cB + silScore;
+      }
+      const bool okB = ctc && live && ((row.allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB >= thr;
+      /* (S, last, false): the repeat (:98-110) and the parent state's extension by last (:69-85) */
+      const int lastP = (int)(par.info & 0xFFu);
+      double r0 = nb + eLast;
+      double r1 = (pl >= 0 && last != lastP) ? par.nb + eLast : NEG;
+      double r2 = (pl >= 0 && ctc) ? par.b + eLast : NEG;
+      /* (S.last, last, false) from (S, blank, true) when no lane holds S.last */
+      double cL = bb + eLast;
+      if (silScore != 0.0) {
+        r0 = lastSil ? r0 + silScore : r0;
+        r1 = lastSil ? r1 + silScore : r1;
+        r2 = lastSil ? r2 + silScore : r2;
+        cL = lastSil ? cL + silScore : cL;
+      }
+      const uint32_t h1 = (par.info >> 16) & 0xFFu, h2 = par.info >> 24;
+      /* max-merge (Utils.h:194-196); a tie goes to the lower history slot */
+      double cR = r0;
+      parR = hypNB;
+      if (r1 > cR || (r1 == cR && h1 < parR)) {
+        cR = r1;
+        parR = h1;
+      }
+      if (r2 > cR || (r2 == cR && h2 < parR)) {
+        cR = r2;
+        parR = h2;
+      }
+      const bool okR = lastOk && cR >= thr;
+      const bool okL = ctc && lastOk && ((cm >> last) & 1ull) == 0ull && cL >= thr;
+      cs[0] = cB;
+      cs[1] = cR;
+      cs[2] = cL;
+#pragma unroll
+      for (int j = 3; j < GT; ++j) {
+        cs[j] = NEG;
+        cbin[j] = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        cbin[j] = slBin(best, cs[j], winShift, winBase);
+      }
+      okBits = (okB ? 1u : 0u) | (okR ? 2u : 0u) | (okL ? 4u : 0u);
+      /* this frame's build ORs into the other parity's masks and counts into off[] */
+      S.cmask[q][lane] = 0ull;
+      S.mask[q][lane] = 0ull;
+      if (lane < 16) {
+        S.off[lane] = 0u;
+      }
+      if (lane == 0) {
+        S.scal[SL_BCNT] = 0u;
+      }
+    }
+    { /* one LDS atomic per candidate inside the window; everything nearer than the window shares
+       * bin 0 and everything farther bin 511 (hundreds of candidates per frame, all on one address):
+       * those are counted per wave with a ballot and added once */
+      int nNear = 0, nFar = 0;
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        const bool ok = ((okBits >> j) & 1u) != 0u;
+        const bool near = ok && cbin[j] == 0, far = ok && cbin[j] == kSlNB - 1;
+        if (ok && !near && !far) {
+          atomAdd32(&S.hist[p][cbin[j]], 1u);
+        }
+        nNear += popc64(waveBallot(near));
+        nFar += popc64(waveBallot(far));
+      }
+      if (lane == 0 && nNear > 0) {
+        atomAdd32(&S.hist[p][0], (uint32_t)nNear);
+      }
+      if (lane == 1 && nFar > 0) {
+        atomAdd32(&S.hist[p][kSlNB - 1], (uint32_t)nFar);
+      }
+    }
+    constexpr int NS = GT; /* candidate slots of a lane (the self wave uses three) */
+    static_assert(GT >= 3, "the self wave keeps its three groups in the slot arrays");
+    FLTX_SLPROF(1);
+    ldsBarrier(); /* 1 */
+    /* ---- phase 2: which candidates survive (Utils.h:200-220) ---------------------------- */
+    uint32_t sel = 0u;
+    SlScan sc;
+    int shift = winShift, base = winBase;
+    unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+    for (;;) {
+      sc = slScan(S.hist[p], K);
+      if (sc.total <= K) {
+        sel = okBits;
+        break;
+      }
+      const int need = K - sc.cum;
+      uint32_t inBin = 0u;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        sel |= (((okBits >> j) & 1u) && cbin[j] < sc.bstar) ? (1u << j) : 0u;
+        inBin |= (((okBits >> j) & 1u) && cbin[j] == sc.bstar) ? (1u << j) : 0u;
+      }
+      if (sc.cnt == need) {
+        sel |= inBin;
+        break;
+      }
+      if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          if ((inBin >> j) & 1u) {
+            const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
+            S.bKey[i] = f64Key(cs[j]);
+            S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+          }
+        }
+        ldsBarrier();
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          if ((inBin >> j) & 1u) {
+            const unsigned long long k = f64Key(cs[j]);
+            const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+            int rank = 0;
+            for (int i = 0; i < sc.cnt; ++i) {
+              const unsigned long long k2 = S.bKey[i];
+              rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
+            }
+            sel |= rank < need ? (1u << j) : 0u;
+          }
+        }
+        break;
+      }
+      /* too many in one bin: the K-th best's float bits lie in [lo, hi]; look again
+       * through the finest window that spans that bracket (<= 4 rounds: 32 bits, 9 per round) */
+      sel = 0u;
+      {
+        const unsigned long long v = (unsigned long long)(sc.bstar + base);
+        if (sc.bstar > 0 || base == 0) {
+          const unsigned long long l2 = v << shift;
+          bLo = l2 > bLo ? l2 : bLo;
+        }
+        if (sc.bstar < kSlNB - 1) {
+          const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
+          bHi = h2 < bHi ? h2 : bHi;
+        }
+        if (bLo >= bHi) { /* equal to the last bit and more of them than the pairwise list holds */
+          dead = true;
+          break;
+        }
+        int ns = 0;
+        while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
+          ++ns;
+        }
+        shift = ns;
+        base = (int)(bLo >> ns);
+      }
+      ldsBarrier();
+      if (tid < kSlNB) {
+        S.hist[p][tid] = 0u;
+      }
+      ldsBarrier();
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        if ((okBits >> j) & 1u) {
+          cbin[j] = slBin(best, cs[j], shift, base);
+          atomAdd32(&S.hist[p][cbin[j]], 1u);
+        }
+      }
+      ldsBarrier();
+    }
+    if (dead) {
+      return;
+    }
+    /* next frame's window: the K-th best in the middle, 256 bins per octave */
+    if (sc.total > K) {
+      const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
+                                            : (sc.bstar + base) >> (kSlFineShift - shift);
+      winShift = kSlFineShift;
+      winBase = q15 > 256 ? q15 - 256 : 0;
+    }
+    FLTX_SLPROF(2);
+    /* new lanes: survivors first (self wave), then the new states wave by wave */
+    int nNewWave = 0;
+    int myNew[NS];
+    int surv = -1;
+    uint32_t hNB = kSlNoHyp, hB = kSlNoHyp;
+    if (!isSelf) {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        const unsigned long long bal = waveBallot(((sel >> j) & 1u) != 0u);
+        myNew[j] = nNewWave + wavePrefixCount(bal);
+        nNewWave += popc64(bal);
+      }
+      if (lane > wave && lane <= nW && nNewWave > 0) {
+        atomAdd32(&S.off[lane], (uint32_t)nNewWave);
+      }
+    } else {
+      const bool sB = (sel & 1u) != 0u, sR = (sel & 2u) != 0u;
+      const unsigned long long balS = waveBallot(sB || sR);
+      const unsigned long long balR = waveBallot(sR), balB = waveBallot(sB), balL = waveBallot((sel & 4u) != 0u);
+      surv = (sB || sR) ? wavePrefixCount(balS) : -1;
+      hNB = (uint32_t)(wavePrefixCount(balR) + wavePrefixCount(balB));
+      hB = hNB + (sR ? 1u : 0u);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        myNew[j] = 0;
+      }
+      myNew[2] = wavePrefixCount(balL);
+      nNewWave = popc64(balL);
+      S.newLane[lane] = surv;
+      if (lane == 0) {
+        S.scal[SL_NSURV] = (uint32_t)popc64(balS);
+        S.scal[SL_NHSURV] = (uint32_t)(popc64(balR) + popc64(balB));
+      }
+      if (lane == nW && nNewWave > 0) {
+        atomAdd32(&S.off[lane], (uint32_t)nNewWave);
+      }
+    }
+    FLTX_SLPROF(3);
+    ldsBarrier(); /* 2 */
+    /* ---- phase 3: every survivor is written by the lane that evaluated it ---------------- */
+    const int nSurv = (int)S.scal[SL_NSURV], nHSurv = (int)S.scal[SL_NHSURV];
+    const int offW = (int)S.off[wave], nNew = (int)S.off[nW];
+    const int myNewLane = S.newLane[lane];
+    const int plNew = S.newLane[pl >= 0 ? pl : 0];
+    auto newState = [&](int idx, double c, int n, uint32_t hp) {
+      const int nl = nSurv + idx;
+      const uint32_t hyp = (uint32_t)(nHSurv + idx);
+      SlRec r;
+      r.nb = c;
+      r.b = NEG;
+      r.info = (uint32_t)n | ((uint32_t)(myNewLane + 1) << 8) | (hyp << 16) | (kSlNoHyp << 24);
+      r.sid = (uint32_t)frameOut * (uint32_t)K + hyp;
+      r.spar = me.sid;
+      r.pad = 0u;
+      S.rec[q][nl] = r;
+      if (myNewLane >= 0) {
+        atomOr64(&S.cmask[q][myNewLane], 1ull << n);
+        atomOr64(&S.mask[q][myNewLane], 1ull << n);
+      }
+      histPT[hrow + hyp] = make_int2((int)(hp | kSlNewFlag | (me.sid << 9)), n);
+      if ((mk >> n) & 1ull) { /* this edge had a child before: it may have descendants in the beam */
+        const uint32_t e = atomAdd32(&S.row[q].nev, 1u);
+        S.evLane[e] = (uint32_t)nl;
+        S.evSpar[e] = me.sid;
+        S.evTok[e] = (uint32_t)n;
+      }
+    };
+    if (!isSelf) {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        if ((sel >> j) & 1u) {
+          newState(offW + myNew[j], cs[j], (int)tk[j], hypM);
+        }
+      }
+    } else {
+      if (surv >= 0) {
+        const bool sB = (sel & 1u) != 0u, sR = (sel & 2u) != 0u;
+        const int pln = pl >= 0 ? plNew : -1;
+        SlRec r;
+        r.nb = sR ? cs[1] : NEG;
+        r.b = sB ? cs[0] : NEG;
+        r.info = (uint32_t)last | ((uint32_t)(pln + 1) << 8) | ((sR ? hNB : kSlNoHyp) << 16) |
+                 ((sB ? hB : kSlNoHyp) << 24);
+        r.sid = me.sid;
+        r.spar = me.spar;
+        r.pad = 0u;
+        S.rec[q][surv] = r;
+        if (mk) {
+          atomOr64(&S.mask[q][surv], mk);
+        }
+        if (pln >= 0) {
+          atomOr64(&S.cmask[q][pln], 1ull << last);
+        }
+        if (sR) {
+          histPT[hrow + hNB] = make_int2((int)parR, last);
+        }
+        if (sB) {
+          histPT[hrow + hB] = make_int2((int)hypM, blank);
+        }
+      }
+      if (sel & 4u) {
+        newState(offW + myNew[2], cs[2], last, hypB);
+      }
+    }
+    if (wave == prepWave) { /* the next frame's emission row */
+      if (lane >= nHSurv + nNew && lane < K) { /* unused slots of the row: see slReenter */
+        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
+      }
+      if (t + 1 < T) {
+        slPrepRow(P, S, q, rowReg, ctc);
+      }
+      rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
+    }
+    nState = nSurv + nNew;
+    nHyp = nHSurv + nNew;
+    mmax = best;
+    FLTX_SLPROF(4);
+    ldsBarrier(); /* 3 */
+    FLTX_SLPROF(5);
+  };
+  {
+    int t = 0;
+    for (; t + 1 < T && !dead; t += 2) {
+      frameStep(SlParity<0>(), rowA, t);
+      if (dead) {
+        break;
+      }
+      frameStep(SlParity<1>(), rowB, t + 1);
+    }
+    if (!dead && t < T) {
+      frameStep(SlParity<0>(), rowA, t);
+    }
+  }
+
+  /* ---- decodeEnd (LexiconFreeDecoder.cpp:127-158): finish() keeps the state, token = sil; the two
+   * hypotheses of a state merge; sorted n-best (candidatesStore returnSorted) ------------------ */
+  const int pe = T & 1;
+  if (!dead && S.row[pe].nev != 0u && T > 0) { /* keeps the records consistent; no effect on the result */
+    slReenter(S, P.histPT, pe, nState, hbase, (int64_t)T * K);
+  }
+  const int ff = T + 1;
+  if (wave == 0 && !dead) {
+    const bool live = lane < nState;
+    const SlRec me = S.rec[pe][live ? lane : 0];
+    const double nb = live ? me.nb : NEG, bb = live ? me.b : NEG;
+    const bool whichB = bb > nb;
+    const double m = whichB ? bb : nb;
+    const uint32_t hp = whichB ? (me.info >> 24) : ((me.info >> 16) & 0xFFu);
+    const double thr = mmax - P.beamThreshold;
+    const bool ok = live && m >= thr;
+    const unsigned long long key = ok ? f64Key(m) : 0ull;
+    int rank = 0;
+    for (int i = 0; i < nState; ++i) {
+      const uint32_t lo = waveReadLane32((uint32_t)key, i), hi = waveReadLane32((uint32_t)(key >> 32), i);
+      const unsigned long long k2 = ((unsigned long long)hi << 32) | lo;
+      const uint32_t h2 = waveReadLane32(hp, i);
+      rank += (k2 > key || (k2 == key && h2 < hp)) ? 1 : 0;
+    }
+    const unsigned long long okMask = waveBallot(ok);
+    if (ok) { /* at most K states hold a hypothesis, so every candidate above the threshold stays */
+      const size_t g = ((size_t)b * K + rank) * 3;
+      P.outScores[g + 0] = m;
+      P.outScores[g + 1] = 0.0; /* emitting-model score: the back-trace kernel fills it in */
+      P.outScores[g + 2] = 0.0; /* ZeroLM */
+      P.histPT[hbase + (int64_t)ff * K + rank] = make_int2((int)hp, P.sil);
+    }
+    if (lane == 0) {
+      P.outN[b] = popc64(okMask);
+      P.uttNBeam[b] = popc64(okMask);
+      P.uttFrame[b] = ff;
+      P.uttTotal[b] = ff;
+      P.uttStatus[b] = 0;
+    }
+  }
+  if (dead && tid == 0) {
+    P.outN[b] = 0;
+    P.uttNBeam[b] = 0;
+    P.uttFrame[b] = ff;
+    P.uttTotal[b] = ff;
+    P.uttStatus[b] = ST_SELECT_FALLBACK;
+  }
+  if (PROF && P.prof && tid == P.profThread) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      P.prof[(size_t)b * 8 + i] = acc[i];
+    }
+  }
+  (void)nHyp;
+}
+#undef FLTX_SLPROF
