@@ -230,22 +230,49 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     assert ok, why
 
 
-@pytest.mark.parametrize("name,engine", [("lf_ctc_t60_k10", 3), ("lf_uni_n64_k64", 3), ("lf_ctc_n29_k64", 3),
-                                         ("lf_ctc_n29_k65", 2), ("lf_ctc_t60_k10_logadd", 3),
-                                         ("lf_ctc_t60_k10_kt5", 3), ("lf_ctc_t300_k100", 2)])
-def test_engine_selection(gpu_session, golden, name, engine):
-    """Which frame step serves which configuration: lane-per-slot (3) for
-    lexicon-free + ZeroLM max-merge with beam <= 64 over the full token set,
-    (also logAdd, also a token beam), the lean step (2) for bigger beams."""
+@pytest.mark.parametrize("name,engine,sets", [
+    ("lf_ctc_t60_k10", 4, {}), ("lf_uni_n64_k64", 4, {}), ("lf_ctc_n29_k64", 4, {}), ("lf_ctc_t60_k10_kt5", 4, {}),
+    ("lf_asg_t40_n29_kt7", 4, {}), ("lf_ctc_sil", 4, {}), ("C2_ctc_u0", 4, {}), ("C2_uniform_u0", 4, {}),
+    ("lf_ctc_t60_k10", 3, {"slane": 0}), ("lf_uni_n64_k64", 3, {"slane": 0}), ("lf_ctc_n29_k64", 3, {"slane": 0}),
+    ("lf_ctc_t60_k10_kt5", 3, {"slane": 0}), ("C2_ctc_u0", 3, {"slane": 0}),
+    ("lf_ctc_n29_k65", 2, {}), ("lf_ctc_t60_k10_logadd", 3, {}), ("lf_ctc_t300_k100", 2, {})])
+def test_engine_selection(gpu_session, golden, name, engine, sets):
+    """Which engine serves which configuration: the lane = LM state decode (4,
+    fltx_slane.h) for offline lexicon-free + ZeroLM max-merge with beam <= 64 and
+    <= 64 tokens (also with a token beam, ASG, silScore); the lane-per-slot step
+    (3) for logAdd and when the former is switched off; the lean step (2) for
+    bigger beams.  Same n-best either way."""
     c = cases.BY_NAME[name]
     inp = helpers.case_inputs(c)
     d = gpu_session.decoder(c, inp)
+    for k, v in sets.items():
+        d.set(k, v)
     d.decode_batch(inp["e"], [c["T"]], c["N"])
     got = d.get("engine")
     tol = 1e-5 if c["log_add"] else 0.0
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
     d.close()
     assert got == engine
+    assert ok, why
+
+
+LANE_OK = [c for c in cases.CASES if c["kind"] == "lexfree" and c["lm"] == "zero" and c["K"] <= 64 and c["N"] <= 64]
+
+
+@pytest.mark.parametrize("c", LANE_OK, ids=lambda c: c["name"])
+def test_lane_per_slot_step_matches_golden(gpu_session, golden, c):
+    """The lane = LM state decode (fltx_slane.h) takes the offline lexicon-free +
+    ZeroLM configurations by default; the lane-per-slot step (fltx_lane.h) still
+    serves streams and logAdd, and must give the same n-best everywhere."""
+    inp = helpers.case_inputs(c)
+    d = gpu_session.decoder(c, inp)
+    d.set("slane", 0)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    eng = d.get("engine")
+    tol = 1e-5 if c["log_add"] else 0.0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
+    d.close()
+    assert eng == 3
     assert ok, why
 
 

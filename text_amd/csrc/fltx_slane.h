@@ -6,7 +6,10 @@
  * selection as LexiconFreeDecoder::decodeStep (LexiconFreeDecoder.cpp:30-125)
  * with candidatesStore (Utils.h:146-225): bit-identical n-best.
  *
- * What is different from fltx_lane.h is what a frame has to do at all:
+ * A wave of this chip issues one vector instruction every ~7 clocks (10 with a
+ * second wave on its SIMD; tools/microbench2.hip), a barrier of eight waves
+ * costs ~140: the frame step is priced in instructions per wave, and this file
+ * is organised around issuing few of them.
  *
  *   * A lane holds an LM STATE, not a hypothesis: the two hypotheses a state
  *     can have in the beam -- (S, last token, prevBlank = false) and
@@ -20,11 +23,16 @@
  *     date by the build step.
  *   * With ZeroLM the frame's best candidate is best hypothesis + best token,
  *     and the best hypothesis of frame t + 1 IS the best candidate of frame t:
- *     best(t) = fl(best(t-1) + emax(t)) is a scalar recurrence every wave
- *     carries in registers.  The beam therefore need not be sorted, and no
- *     frame ranks its survivors: a candidate survives iff its histogram bin is
- *     better than the bin of the K-th best; only the members of that one bin
- *     are compared with each other (and only when not all of them survive).
+ *     best(t) = fl(best(t-1) + emax(t)) is a scalar recurrence, computed by the
+ *     wave that stages the emission rows a frame ahead.  The beam therefore
+ *     need not be sorted, and no frame ranks its survivors: a candidate
+ *     survives iff its histogram bin is better than the bin of the K-th best;
+ *     only the members of that one bin are compared with each other (and only
+ *     when not all of them survive).
+ *   * The histogram is a window of 512 bins over the float bits of
+ *     (best - score), 256 bins per octave, centred on where the K-th best was
+ *     a frame ago.  Candidates beyond the window are not even counted unless
+ *     the window turns out to hold fewer than K.
  *   * No short-list, no scatter: after the histogram scan every lane knows
  *     which of its own candidates survived; new lanes are handed out by a
  *     per-wave count (one LDS add per wave) and every survivor's record,
@@ -40,11 +48,13 @@
  *     rare re-entry of a state that had dropped out of the beam (about one
  *     frame in a hundred on the benchmark inputs) scans the rows.
  *
- * Three barriers per frame; between them a wave issues ~60 instructions.
+ * Three barriers per frame.
  */
 #pragma once
 
 constexpr int kSlNB = 512;          /* histogram bins: 8 per lane of the scan */
+constexpr int kSlFar = kSlNB - 1;   /* beyond the window: counted only on demand */
+constexpr int kSlInvalid = 1023;    /* not a candidate */
 constexpr int kSlBCap = 128;        /* boundary-bin members compared pairwise */
 constexpr int kSlFineShift = 15;    /* 256 bins per octave of (best - score) */
 constexpr int kSlCoarseShift = 18;  /* 32 bins per octave: 16 octaves in 512 bins */
@@ -61,14 +71,15 @@ struct SlRec { /* one LM state of the beam, 32 B */
   uint32_t pad;
 };
 
-struct SlRow { /* what a frame needs to know about its emission row, 32 B */
-  float emaxNS;  /* largest allowed emission of a token other than sil (-inf: none) */
-  float eSil;
-  uint32_t silAllowed;
-  int32_t nList; /* tokens the normal waves evaluate (allowed, not blank) */
-  unsigned long long allow; /* token beam (LexiconFreeDecoder.cpp:42-51): bit n = token n is evaluated */
-  uint32_t nev;  /* re-entry events recorded by the build of the previous frame */
+struct SlRow { /* what a frame needs to know about its emission row, 48 B */
+  double best;    /* the frame's best candidate (Utils.h:131-137) */
+  double thr;     /* best - beamThreshold */
+  int32_t nList;  /* tokens the normal waves evaluate (allowed, not blank) */
   int32_t silPos; /* list position of sil, or a value no wave matches */
+  uint32_t dead;  /* no candidate at all / not finite: the utterance goes to the general engines */
+  uint32_t nev;   /* re-entry events recorded by the build of the previous frame */
+  unsigned long long allow; /* token beam (LexiconFreeDecoder.cpp:42-51): bit n = token n is evaluated */
+  unsigned long long pad;
 };
 
 template <int V>
@@ -82,10 +93,11 @@ struct SlaneLds {
   unsigned long long mask[2][64];  /* tokens whose child state was ever materialised */
   uint32_t hist[2][kSlNB];
   double eAll[2][64];              /* emission row, widened */
-  double eTok[2][64];              /* ... of the listed tokens, by list position */
+  double eTok[2][64];              /* ... of the listed tokens, by list position; NaN past the list */
+  unsigned long long tokBit[2][64]; /* 1 << token of the list position, 0 past the list */
   SlRow row[2];
   uint8_t tokId[2][64];            /* list position -> token */
-  uint32_t off[16];                /* new states of the waves before wave i; [nW] = all */
+  uint32_t off[32];                /* new states of the waves before wave i; [nW] = all (nW <= 16) */
   int32_t newLane[64];             /* old lane -> lane in the next beam, -1 = dropped */
   uint32_t scal[16];
   unsigned long long bKey[kSlBCap];
@@ -94,12 +106,12 @@ struct SlaneLds {
   unsigned long long scanMask;
   uint32_t scanMin, pad0;
 };
-enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2, SL_STATUS = 3 };
+enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2 };
 
 FLTX_DEV double slNegInf() { return -__builtin_huge_val(); }
 
-/* bin of a candidate `d` below the frame's best: a window of 512 bins over the
- * float bit pattern of d (monotone in d, hence in the score: any such binning
+/* bin of a candidate `c` below the frame's best: a window of 512 bins over the
+ * float bit pattern of best - c (monotone in the score, and any monotone binning
  * gives exact selection); everything nearer than the window shares bin 0,
  * everything farther bin 511 */
 FLTX_DEV int slBin(double best, double c, int shift, int base) {
@@ -114,6 +126,7 @@ struct SlScan {
   int cum;   /* candidates in better bins */
   int cnt;   /* candidates in bin bstar */
   int total;
+  bool crossed; /* the counted bins hold at least K */
 };
 /* every wave scans the 512 counts itself (8 bins per lane, DPP prefix) */
 FLTX_DEV SlScan slScan(const uint32_t* hist, int K) {
@@ -147,7 +160,8 @@ FLTX_DEV SlScan slScan(const uint32_t* hist, int K) {
   r.cum = (int)waveReadLane32((uint32_t)before, X);
   r.bstar = (int)(a & 0xFFFFu);
   r.cnt = (int)(a >> 16);
-  if (!cm) { /* fewer than K candidates: they all survive */
+  r.crossed = cm != 0ull;
+  if (!r.crossed) { /* fewer than K counted */
     r.bstar = kSlNB - 1;
     r.cum = 0;
     r.cnt = r.total;
@@ -156,9 +170,10 @@ FLTX_DEV SlScan slScan(const uint32_t* hist, int K) {
 }
 
 /* Emission row -> what the frame step reads (buffer q): the widened row, the
- * token beam, the list of tokens the normal waves evaluate and the row's
- * largest emission.  One wave; lane n holds e[n]. */
-FLTX_DEV void slPrepRow(const DecodeParams& P, SlaneLds& S, int q, float v, bool ctc) {
+ * token beam, the list of tokens the normal waves evaluate, and the frame's best
+ * candidate: best hypothesis (= `mmax`, the previous frame's best candidate) +
+ * best token.  One wave; lane n holds e[n].  Returns the frame's best. */
+FLTX_DEV double slPrepRow(const DecodeParams& P, SlaneLds& S, int q, float v, bool ctc, double mmax) {
   const int lane = laneId();
   const int N = P.N;
   const bool inRow = lane < N;
@@ -174,26 +189,51 @@ FLTX_DEV void slPrepRow(const DecodeParams& P, SlaneLds& S, int q, float v, bool
   const bool mine = inRow && ((allow >> lane) & 1ull) != 0ull;
   const uint32_t ek = waveMax32((mine && lane != P.sil && v == v) ? f32Key(v) : 0u);
   unsigned long long listMask = allow;
-  if (ctc && P.blank >= 0 && P.blank < N) {
+  if (ctc) {
     listMask &= ~(1ull << P.blank);
   }
   const int pos = wavePrefixCount(listMask);
+  const int nList = popc64(listMask);
+  const bool listed = inRow && ((listMask >> lane) & 1ull) != 0ull;
   if (inRow) {
     S.eAll[q][lane] = (double)v;
-    if ((listMask >> lane) & 1ull) {
-      S.tokId[q][pos] = (uint8_t)lane;
-      S.eTok[q][pos] = (double)v;
-    }
+  }
+  if (lane >= nList) { /* past the list: a NaN emission makes every candidate of the position invalid */
+    S.eTok[q][lane] = __builtin_nan("");
+    S.tokBit[q][lane] = 0ull;
+    S.tokId[q][lane] = (uint8_t)0;
+  }
+  waveSync();
+  if (listed) {
+    S.tokId[q][pos] = (uint8_t)lane;
+    S.eTok[q][pos] = (double)v;
+    S.tokBit[q][pos] = 1ull << lane;
   }
   const float eSil = __uint_as_float(waveReadLane32(__float_as_uint(v), P.sil));
-  if (lane == 0) {
-    S.row[q].emaxNS = ek ? f32FromKey(ek) : -__builtin_huge_valf();
-    S.row[q].eSil = eSil;
-    S.row[q].silAllowed = (uint32_t)((allow >> P.sil) & 1ull);
-    S.row[q].nList = popc64(listMask);
-    S.row[q].allow = allow;
-    S.row[q].silPos = ((listMask >> P.sil) & 1ull) ? popc64(listMask & ((1ull << P.sil) - 1ull)) : -4096;
+  /* best candidate of the frame: fl(a + e) is monotone in e, so the best hypothesis with the
+   * largest emission -- sil is scored separately because of silScore */
+  double best = 0.0;
+  bool any = false;
+  if (ek != 0u) {
+    best = mmax + (double)f32FromKey(ek);
+    any = true;
   }
+  if ((allow >> P.sil) & 1ull) {
+    const double sS = (mmax + (double)eSil) + P.silScore;
+    if (sS == sS && (!any || sS > best)) {
+      best = sS;
+      any = true;
+    }
+  }
+  if (lane == 0) {
+    S.row[q].best = best;
+    S.row[q].thr = best - P.beamThreshold;
+    S.row[q].nList = nList;
+    S.row[q].silPos = ((listMask >> P.sil) & 1ull) ? popc64(listMask & ((1ull << P.sil) - 1ull)) : -4096;
+    S.row[q].dead = (!any || !(best - best == 0.0)) ? 1u : 0u;
+    S.row[q].allow = allow;
+  }
+  return best;
 }
 
 /* Re-entry of LM states that had dropped out of the beam (recorded by the
@@ -293,6 +333,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   const double NEG = slNegInf();
   unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
   unsigned long long tPrev = devClock();
+  static_assert(GT >= 3, "the self wave keeps its three groups in the slot arrays");
 
   /* ---- decodeBegin (LexiconFreeDecoder.cpp:20-28): the root state ------------------ */
   for (int i = tid; i < 2 * 64; i += W) {
@@ -302,8 +343,10 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   for (int i = tid; i < 2 * kSlNB; i += W) {
     ((uint32_t*)S.hist)[i] = 0u;
   }
-  if (tid < 16) {
+  if (tid < 32) {
     S.off[tid] = 0u;
+  }
+  if (tid < 16) {
     S.scal[tid] = 0u;
   }
   if (tid == 0) {
@@ -317,6 +360,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     S.rec[0][0] = r;
     S.row[0].nev = 0u;
     S.row[1].nev = 0u;
+    S.row[0].dead = 0u;
+    S.row[1].dead = 0u;
     P.histPT[hbase] = make_int2((int)kSlNoHyp, P.sil);
   }
   if (tid > 0 && tid < K) { /* unused slots of a row never look like the record of a new state (slReenter) */
@@ -326,22 +371,23 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
    * two registers, alternating with the frame parity; the register is refilled with row t + 3 right
    * after its use, so a load has two frames to arrive and is never moved between registers */
   float rowA = 0.0f, rowB = 0.0f;
+  double bestChain = 0.0; /* prep wave: best candidate of the newest prepared frame (decodeBegin: score 0) */
   if (wave == prepWave) {
     const float v0 = (T > 0 && lane < N) ? em[lane] : 0.0f;
     rowA = (T > 1 && lane < N) ? em[(size_t)1 * N + lane] : 0.0f;
     rowB = (T > 2 && lane < N) ? em[(size_t)2 * N + lane] : 0.0f;
     if (T > 0) {
-      slPrepRow(P, S, 0, v0, ctc);
+      bestChain = slPrepRow(P, S, 0, v0, ctc, 0.0);
     }
   }
   ldsBarrier();
 
-  int nState = 1, nHyp = 1;
-  double mmax = 0.0; /* best hypothesis of the current beam = best candidate of the previous frame */
+  int nState = 1;
+  double endBest = 0.0; /* best hypothesis of the final beam (decodeEnd's threshold) */
   int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
   bool dead = false; /* this utterance goes to the general engines */
   const int sil = P.sil, blank = P.blank;
-  const double silScore = P.silScore, beamThreshold = P.beamThreshold;
+  const double silScore = P.silScore;
   int2* const histPT = P.histPT;
 
   /* one frame; PT = parity of the frame (compile time: every LDS address is an immediate) */
@@ -349,38 +395,46 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     constexpr int p = decltype(PT)::value, q = p ^ 1;
     const int frameOut = t + 1;
     const int64_t hrow = hbase + (int64_t)frameOut * K;
-    /* ---- phase 1: own state, the frame's best, candidates, histogram ------------------- */
+    /* ---- phase 1: own state, candidates, histogram ------------------------------------- */
     /* every LDS read of the phase is issued here, before anything waits for one */
-    SlRow row = S.row[p];
+    const double best = S.row[p].best, thr = S.row[p].thr;
+    const int nList = S.row[p].nList, silPos = S.row[p].silPos;
+    const uint32_t rowDead = S.row[p].dead, nev = S.row[p].nev;
     SlRec me = S.rec[p][lane];
     unsigned long long cm = S.cmask[p][lane];
     unsigned long long mk = S.mask[p][lane];
     double ev[GT];
-    uint32_t tk[GT];
+    unsigned long long tb[GT];
     double eBlank = 0.0;
+    unsigned long long allow = 0ull;
     if (!isSelf) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         ev[j] = S.eTok[p][wave * GT + j];
-        tk[j] = (uint32_t)S.tokId[p][wave * GT + j] & 63u;
+        tb[j] = S.tokBit[p][wave * GT + j];
       }
     } else {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         ev[j] = 0.0;
-        tk[j] = 0u;
+        tb[j] = 0ull;
       }
       eBlank = S.eAll[p][ctc ? blank : 0];
+      allow = S.row[p].allow;
     }
-    if (row.nev != 0u) { /* rare: states re-entered the beam in the previous build */
+    (void)nList;
+    if (nev != 0u) { /* rare: states re-entered the beam in the previous build */
       slReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K);
-      row = S.row[p];
       me = S.rec[p][lane];
       cm = S.cmask[p][lane];
       mk = S.mask[p][lane];
     }
-    if (tid < kSlNB) {
-      S.hist[q][tid] = 0u;
+    if (rowDead) { /* nothing to extend with, or not finite: general path */
+      dead = true;
+      return;
+    }
+    for (int i = tid; i < kSlNB; i += W) {
+      S.hist[q][i] = 0u;
     }
     const bool live = lane < nState;
     const double nb = live ? me.nb : NEG, bb = live ? me.b : NEG;
@@ -397,53 +451,38 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       par = S.rec[p][pl >= 0 ? pl : 0];
       eLast = S.eAll[p][last];
     }
-    /* best candidate of the frame (Utils.h:131-137): best hypothesis + best token */
-    double best = 0.0;
-    bool any = false;
-    if (row.emaxNS > -__builtin_huge_valf()) {
-      best = mmax + (double)row.emaxNS;
-      any = true;
-    }
-    if (row.silAllowed) {
-      const double sS = (mmax + (double)row.eSil) + silScore;
-      if (sS == sS && (!any || sS > best)) {
-        best = sS;
-        any = true;
-      }
-    }
-    if (!any || !(best - best == 0.0)) { /* nothing to extend with, or not finite: general path */
-      dead = true;
-      return;
-    }
-    const double thr = best - beamThreshold;
     FLTX_SLPROF(0);
     double cs[GT];
     int cbin[GT];
-    uint32_t okBits = 0u;
     uint32_t parR = kSlNoHyp;
     if (!isSelf) {
-      const unsigned long long skip = cm | (1ull << last);
-      const int silJ = (int)row.silPos - wave * GT; /* list position of sil relative to this wave's first */
+      /* tokens this lane does not extend with here: its own last token (the repeat and the
+       * blank-then-last case belong to the self wave) and those whose child state holds a lane
+       * (that lane merges the extension into its repeat).  A lane without a state skips all. */
+      const uint32_t lastLo = last < 32 ? 1u << last : 0u, lastHi = last < 32 ? 0u : 1u << (last - 32);
+      const uint32_t skLo = live ? ((uint32_t)cm | lastLo) : 0xFFFFFFFFu;
+      const uint32_t skHi = live ? ((uint32_t)(cm >> 32) | lastHi) : 0xFFFFFFFFu;
+      const int silJ = silPos - wave * GT; /* list position of sil relative to this wave's first */
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
-        double c = m + ev[j];
+        double c = m + ev[j]; /* NaN past the end of the list */
         if (j == silJ) {
           c = c + silScore;
         }
-        const bool ok = live && wave * GT + j < row.nList && ((skip >> tk[j]) & 1ull) == 0ull && c >= thr;
+        const uint32_t hit = (skLo & (uint32_t)tb[j]) | (skHi & (uint32_t)(tb[j] >> 32));
+        const bool ok = hit == 0u && c >= thr;
         cs[j] = c;
-        cbin[j] = slBin(best, c, winShift, winBase);
-        okBits |= ok ? (1u << j) : 0u;
+        cbin[j] = ok ? slBin(best, c, winShift, winBase) : kSlInvalid;
       }
     } else {
-      const bool lastOk = live && ((row.allow >> last) & 1ull) != 0ull && !(ctc && last == blank);
+      const bool lastOk = live && ((allow >> last) & 1ull) != 0ull && !(ctc && last == blank);
       const bool lastSil = last == sil;
       /* (S, blank, true): LexiconFreeDecoder.cpp:86-97 */
       double cB = m + eBlank;
       if (blank == sil) {
         cB = cB + silScore;
       }
-      const bool okB = ctc && live && ((row.allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB >= thr;
+      const bool okB = ctc && live && ((allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB >= thr;
       /* (S, last, false): the repeat (:98-110) and the parent state's extension by last (:69-85) */
       const int lastP = (int)(par.info & 0xFFu);
       double r0 = nb + eLast;
@@ -474,77 +513,78 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       cs[0] = cB;
       cs[1] = cR;
       cs[2] = cL;
+      cbin[0] = okB ? slBin(best, cB, winShift, winBase) : kSlInvalid;
+      cbin[1] = okR ? slBin(best, cR, winShift, winBase) : kSlInvalid;
+      cbin[2] = okL ? slBin(best, cL, winShift, winBase) : kSlInvalid;
 #pragma unroll
       for (int j = 3; j < GT; ++j) {
         cs[j] = NEG;
-        cbin[j] = 0;
+        cbin[j] = kSlInvalid;
       }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        cbin[j] = slBin(best, cs[j], winShift, winBase);
-      }
-      okBits = (okB ? 1u : 0u) | (okR ? 2u : 0u) | (okL ? 4u : 0u);
       /* this frame's build ORs into the other parity's masks and counts into off[] */
       S.cmask[q][lane] = 0ull;
       S.mask[q][lane] = 0ull;
-      if (lane < 16) {
+      if (lane < 32) {
         S.off[lane] = 0u;
       }
       if (lane == 0) {
         S.scal[SL_BCNT] = 0u;
       }
     }
-    { /* one LDS atomic per candidate inside the window; everything nearer than the window shares
-       * bin 0 and everything farther bin 511 (hundreds of candidates per frame, all on one address):
-       * those are counted per wave with a ballot and added once */
-      int nNear = 0, nFar = 0;
+    /* one LDS atomic per candidate inside the window (bin 0 = nearer than the window included);
+     * what lies beyond the window (hundreds per frame, they would all hit one address) is not
+     * counted unless the window turns out to hold fewer than K */
 #pragma unroll
-      for (int j = 0; j < GT; ++j) {
-        const bool ok = ((okBits >> j) & 1u) != 0u;
-        const bool near = ok && cbin[j] == 0, far = ok && cbin[j] == kSlNB - 1;
-        if (ok && !near && !far) {
-          atomAdd32(&S.hist[p][cbin[j]], 1u);
-        }
-        nNear += popc64(waveBallot(near));
-        nFar += popc64(waveBallot(far));
-      }
-      if (lane == 0 && nNear > 0) {
-        atomAdd32(&S.hist[p][0], (uint32_t)nNear);
-      }
-      if (lane == 1 && nFar > 0) {
-        atomAdd32(&S.hist[p][kSlNB - 1], (uint32_t)nFar);
+    for (int j = 0; j < GT; ++j) {
+      if (cbin[j] < kSlFar) {
+        atomAdd32(&S.hist[p][cbin[j]], 1u);
       }
     }
-    constexpr int NS = GT; /* candidate slots of a lane (the self wave uses three) */
-    static_assert(GT >= 3, "the self wave keeps its three groups in the slot arrays");
     FLTX_SLPROF(1);
     ldsBarrier(); /* 1 */
     /* ---- phase 2: which candidates survive (Utils.h:200-220) ---------------------------- */
-    uint32_t sel = 0u;
+    unsigned long long selMask[GT]; /* per slot: the lanes whose candidate survives */
     SlScan sc;
     int shift = winShift, base = winBase;
     unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+    bool full = false; /* the counts include what lies beyond the window */
     for (;;) {
       sc = slScan(S.hist[p], K);
-      if (sc.total <= K) {
-        sel = okBits;
+      if (!full && !sc.crossed) {
+        /* fewer than K inside the window: count the far ones too (one add per wave) */
+        int nFar = 0;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          nFar += popc64(waveBallot(cbin[j] == kSlFar));
+        }
+        if (lane == 0 && nFar > 0) {
+          atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
+        }
+        full = true;
+        ldsBarrier();
+        continue;
+      }
+      if (sc.total <= K) { /* everything counted survives (with the far ones: all above the threshold) */
+        const int lim = full ? kSlFar : kSlFar - 1;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          selMask[j] = waveBallot(cbin[j] <= lim);
+        }
         break;
       }
       const int need = K - sc.cum;
-      uint32_t inBin = 0u;
-#pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        sel |= (((okBits >> j) & 1u) && cbin[j] < sc.bstar) ? (1u << j) : 0u;
-        inBin |= (((okBits >> j) & 1u) && cbin[j] == sc.bstar) ? (1u << j) : 0u;
-      }
       if (sc.cnt == need) {
-        sel |= inBin;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          selMask[j] = waveBallot(cbin[j] <= sc.bstar);
+        }
         break;
       }
       if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
+        uint32_t take = 0u;
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if ((inBin >> j) & 1u) {
+        for (int j = 0; j < GT; ++j) {
+          if (cbin[j] == sc.bstar) {
             const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
             S.bKey[i] = f64Key(cs[j]);
             S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
@@ -552,8 +592,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         }
         ldsBarrier();
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if ((inBin >> j) & 1u) {
+        for (int j = 0; j < GT; ++j) {
+          if (cbin[j] == sc.bstar) {
             const unsigned long long k = f64Key(cs[j]);
             const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
             int rank = 0;
@@ -561,14 +601,17 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
               const unsigned long long k2 = S.bKey[i];
               rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
             }
-            sel |= rank < need ? (1u << j) : 0u;
+            take |= rank < need ? (1u << j) : 0u;
           }
+        }
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          selMask[j] = waveBallot(cbin[j] < sc.bstar || ((take >> j) & 1u) != 0u);
         }
         break;
       }
       /* too many in one bin: the K-th best's float bits lie in [lo, hi]; look again
        * through the finest window that spans that bracket (<= 4 rounds: 32 bits, 9 per round) */
-      sel = 0u;
       {
         const unsigned long long v = (unsigned long long)(sc.bstar + base);
         if (sc.bstar > 0 || base == 0) {
@@ -591,13 +634,14 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         base = (int)(bLo >> ns);
       }
       ldsBarrier();
-      if (tid < kSlNB) {
-        S.hist[p][tid] = 0u;
+      for (int i = tid; i < kSlNB; i += W) {
+        S.hist[p][i] = 0u;
       }
       ldsBarrier();
+      full = true;
 #pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        if ((okBits >> j) & 1u) {
+      for (int j = 0; j < GT; ++j) {
+        if (cbin[j] != kSlInvalid) {
           cbin[j] = slBin(best, cs[j], shift, base);
           atomAdd32(&S.hist[p][cbin[j]], 1u);
         }
@@ -617,28 +661,30 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     FLTX_SLPROF(2);
     /* new lanes: survivors first (self wave), then the new states wave by wave */
     int nNewWave = 0;
-    int myNew[NS];
+    int myNew[GT];
     int surv = -1;
     uint32_t hNB = kSlNoHyp, hB = kSlNoHyp;
     if (!isSelf) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
-        const unsigned long long bal = waveBallot(((sel >> j) & 1u) != 0u);
-        myNew[j] = nNewWave + wavePrefixCount(bal);
-        nNewWave += popc64(bal);
+        myNew[j] = 0;
+        if (selMask[j] != 0ull) {
+          myNew[j] = nNewWave + wavePrefixCount(selMask[j]);
+          nNewWave += popc64(selMask[j]);
+        }
       }
       if (lane > wave && lane <= nW && nNewWave > 0) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
       }
     } else {
-      const bool sB = (sel & 1u) != 0u, sR = (sel & 2u) != 0u;
-      const unsigned long long balS = waveBallot(sB || sR);
-      const unsigned long long balR = waveBallot(sR), balB = waveBallot(sB), balL = waveBallot((sel & 4u) != 0u);
-      surv = (sB || sR) ? wavePrefixCount(balS) : -1;
+      const unsigned long long balB = selMask[0], balR = selMask[1], balL = selMask[2];
+      const unsigned long long balS = balB | balR;
+      const bool sR = ((balR >> lane) & 1ull) != 0ull;
+      surv = ((balS >> lane) & 1ull) ? wavePrefixCount(balS) : -1;
       hNB = (uint32_t)(wavePrefixCount(balR) + wavePrefixCount(balB));
       hB = hNB + (sR ? 1u : 0u);
 #pragma unroll
-      for (int j = 0; j < NS; ++j) {
+      for (int j = 0; j < GT; ++j) {
         myNew[j] = 0;
       }
       myNew[2] = wavePrefixCount(balL);
@@ -685,13 +731,15 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     if (!isSelf) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
-        if ((sel >> j) & 1u) {
-          newState(offW + myNew[j], cs[j], (int)tk[j], hypM);
+        if (selMask[j] != 0ull) { /* (most positions of most frames have no survivor at all) */
+          if ((selMask[j] >> lane) & 1ull) {
+            newState(offW + myNew[j], cs[j], (int)S.tokId[p][wave * GT + j], hypM);
+          }
         }
       }
     } else {
       if (surv >= 0) {
-        const bool sB = (sel & 1u) != 0u, sR = (sel & 2u) != 0u;
+        const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
         const int pln = pl >= 0 ? plNew : -1;
         SlRec r;
         r.nb = sR ? cs[1] : NEG;
@@ -715,7 +763,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
           histPT[hrow + hB] = make_int2((int)hypM, blank);
         }
       }
-      if (sel & 4u) {
+      if ((selMask[2] >> lane) & 1ull) {
         newState(offW + myNew[2], cs[2], last, hypB);
       }
     }
@@ -724,13 +772,12 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
       }
       if (t + 1 < T) {
-        slPrepRow(P, S, q, rowReg, ctc);
+        bestChain = slPrepRow(P, S, q, rowReg, ctc, bestChain);
       }
       rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
     }
     nState = nSurv + nNew;
-    nHyp = nHSurv + nNew;
-    mmax = best;
+    endBest = best;
     FLTX_SLPROF(4);
     ldsBarrier(); /* 3 */
     FLTX_SLPROF(5);
@@ -752,9 +799,6 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   /* ---- decodeEnd (LexiconFreeDecoder.cpp:127-158): finish() keeps the state, token = sil; the two
    * hypotheses of a state merge; sorted n-best (candidatesStore returnSorted) ------------------ */
   const int pe = T & 1;
-  if (!dead && S.row[pe].nev != 0u && T > 0) { /* keeps the records consistent; no effect on the result */
-    slReenter(S, P.histPT, pe, nState, hbase, (int64_t)T * K);
-  }
   const int ff = T + 1;
   if (wave == 0 && !dead) {
     const bool live = lane < nState;
@@ -763,7 +807,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const bool whichB = bb > nb;
     const double m = whichB ? bb : nb;
     const uint32_t hp = whichB ? (me.info >> 24) : ((me.info >> 16) & 0xFFu);
-    const double thr = mmax - P.beamThreshold;
+    const double thr = endBest - P.beamThreshold;
     const bool ok = live && m >= thr;
     const unsigned long long key = ok ? f64Key(m) : 0ull;
     int rank = 0;
@@ -802,6 +846,5 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       P.prof[(size_t)b * 8 + i] = acc[i];
     }
   }
-  (void)nHyp;
 }
 #undef FLTX_SLPROF
