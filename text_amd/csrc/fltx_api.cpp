@@ -252,6 +252,7 @@ struct fltx_decoder {
   int CAP = 0, HS = 0, NB = 0, SCAP = 0, dense = 0, noDense = 0;
   int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
+  int slaneThreads = 0; /* tuning: workgroup size of the lane = LM state kernel (0 = first that fits) */
   int slane = 0, noSlane = 0; /* slane: list positions per wave of the lane = LM state kernel (fltx_slane.h), 0 = off */
   bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
   const float* lastEmis = nullptr; /* device emissions of the last offline batch (the back-trace re-reads them) */
@@ -959,6 +960,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noCut = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "slane_threads")) {
+    d->slaneThreads = (int)value;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "slane")) { /* 0: do not use the lane = LM state kernel (fltx_slane.h) */
     d->noSlane = value ? 0 : 1;
     return FLTX_OK;
@@ -1064,16 +1069,19 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
       (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
       (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
-    const int thr = d->userThreads ? d->threads : 512;
-    const int nNorm = thr / 64 - 1;
+    /* (threads, list positions per token wave) pairs that are compiled (fltx_instances.h); two of the
+     * waves do not evaluate tokens (own groups of the lanes / row staging and housekeeping) */
+    static const int geo[][2] = {{512, 5}, {576, 4}, {448, 6}, {384, 7}, {320, 10}, {640, 4}, {512, 12}, {576, 10}}; /* fastest first (C2) */
     const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
-    if (nNorm >= 1 && nList <= 4 * nNorm) {
-      d->slane = 4;
-    } else if (nNorm >= 1 && nList <= 9 * nNorm) {
-      d->slane = 9;
-    }
-    if (d->slane) {
-      d->threads = thr;
+    for (const auto& g : geo) {
+      if ((d->userThreads && d->threads != g[0]) || (d->slaneThreads && d->slaneThreads != g[0])) {
+        continue;
+      }
+      if (nList <= g[1] * (g[0] / 64 - 2)) {
+        d->slane = g[1];
+        d->threads = g[0];
+        break;
+      }
     }
   }
   if (d->lean && !d->lane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
@@ -1408,8 +1416,16 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     const bool ft = pp->Kt >= pp->N;
     if (sl == 4) {
       slaneUtterance<4, false>(*pp, smem);
-    } else if (sl == 9) {
-      slaneUtterance<9, false>(*pp, smem);
+    } else if (sl == 5) {
+      slaneUtterance<5, false>(*pp, smem);
+    } else if (sl == 6) {
+      slaneUtterance<6, false>(*pp, smem);
+    } else if (sl == 7) {
+      slaneUtterance<7, false>(*pp, smem);
+    } else if (sl == 10) {
+      slaneUtterance<10, false>(*pp, smem);
+    } else if (sl == 12) {
+      slaneUtterance<12, false>(*pp, smem);
     } else if (gt == 4) {
       if (pp->logAdd) {
         ft ? decodeUtterance<1, 4, true, true>(*pp, base) : decodeUtterance<1, 4, true, false>(*pp, base);
@@ -1487,11 +1503,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   } while (0)
 #define FLTX_LAUNCH(WW)                                                                          \
   do {                                                                                           \
-    if (d->slane == 4) {                                                                         \
-      FLTX_LAUNCH_SLANE(WW, 4);                                                                  \
-    } else if (d->slane == 9) {                                                                  \
-      FLTX_LAUNCH_SLANE(WW, 9);                                                                  \
-    } else if (!d->wsInLds && d->lean) {                                                                \
+    if (!d->wsInLds && d->lean) {                                                                \
       hipLaunchKernelGGL(fltx_decode_kernel_gwslean<WW>, dim3(nGrid), dim3(WW), d->hotBytes, d->ctx->stream, P); \
     } else if (!d->wsInLds) {                                                                    \
       HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_gws<WW>,                        \
@@ -1517,6 +1529,20 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       FLTX_LAUNCH_LDS(WW, 0);                                                                    \
     }                                                                                            \
   } while (0)
+  if (d->slane) {
+    const int key = W * 100 + d->slane;
+    switch (key) {
+      case 32010: FLTX_LAUNCH_SLANE(320, 10); break;
+      case 38407: FLTX_LAUNCH_SLANE(384, 7); break;
+      case 44806: FLTX_LAUNCH_SLANE(448, 6); break;
+      case 51205: FLTX_LAUNCH_SLANE(512, 5); break;
+      case 57604: FLTX_LAUNCH_SLANE(576, 4); break;
+      case 64004: FLTX_LAUNCH_SLANE(640, 4); break;
+      case 51212: FLTX_LAUNCH_SLANE(512, 12); break;
+      case 57610: FLTX_LAUNCH_SLANE(576, 10); break;
+      default: return fail(FLTX_ERR_INVALID, "no lane = LM state kernel for %d threads x %d positions", W, d->slane);
+    }
+  } else
   switch (W) {
     case 64: FLTX_LAUNCH(64); break;
     case 128: FLTX_LAUNCH(128); break;

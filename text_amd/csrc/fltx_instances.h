@@ -28,11 +28,18 @@
 #define FLTX_G7(W) FLTX_INST(fltx_decode_kernel_lds_spec<W, false, true>)
 #define FLTX_G8(W) FLTX_INST(fltx_decode_kernel_gws<W>)
 #define FLTX_G9(W) FLTX_INST(fltx_decode_kernel_gwslean<W>)
-#define FLTX_G10(W) /* lane = LM state decode (fltx_slane.h) */ \
-  FLTX_INST(fltx_decode_kernel_slane<W, 4, false>)             \
-  FLTX_INST(fltx_decode_kernel_slane<W, 9, false>)             \
-  FLTX_INST(fltx_decode_kernel_slane<W, 4, true>)              \
-  FLTX_INST(fltx_decode_kernel_slane<W, 9, true>)
+/* lane = LM state decode (fltx_slane.h): (threads, list positions per wave) pairs; W is ignored */
+#define FLTX_SLANE_SET(PROF)                               \
+  FLTX_INST(fltx_decode_kernel_slane<320, 10, PROF>)       \
+  FLTX_INST(fltx_decode_kernel_slane<384, 7, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<448, 6, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<512, 5, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<576, 4, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<640, 4, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<512, 12, PROF>)       \
+  FLTX_INST(fltx_decode_kernel_slane<576, 10, PROF>)
+#define FLTX_G10(W) FLTX_SLANE_SET(false)
+#define FLTX_G11(W) FLTX_SLANE_SET(true)
 
 #ifdef FLTX_INST_W
 #define FLTX_CAT2_(a, b) a##b
@@ -41,12 +48,14 @@ FLTX_CAT_(FLTX_G, FLTX_INST_G)(FLTX_INST_W)
 #undef FLTX_CAT_
 #undef FLTX_CAT2_
 #else
-#define FLTX_ALLG(W) FLTX_G1(W) FLTX_G2(W) FLTX_G3(W) FLTX_G4(W) FLTX_G5(W) FLTX_G6(W) FLTX_G7(W) FLTX_G8(W) FLTX_G9(W) FLTX_G10(W)
+#define FLTX_ALLG(W) FLTX_G1(W) FLTX_G2(W) FLTX_G3(W) FLTX_G4(W) FLTX_G5(W) FLTX_G6(W) FLTX_G7(W) FLTX_G8(W) FLTX_G9(W)
 FLTX_ALLG(64)
 FLTX_ALLG(128)
 FLTX_ALLG(256)
 FLTX_ALLG(512)
 FLTX_ALLG(1024)
+FLTX_G10(0)
+FLTX_G11(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -59,3 +68,5 @@ FLTX_ALLG(1024)
 #undef FLTX_G8
 #undef FLTX_G9
 #undef FLTX_G10
+#undef FLTX_G11
+#undef FLTX_SLANE_SET

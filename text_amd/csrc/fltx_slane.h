@@ -55,6 +55,7 @@
 constexpr int kSlNB = 512;          /* histogram bins: 8 per lane of the scan */
 constexpr int kSlFar = kSlNB - 1;   /* beyond the window: counted only on demand */
 constexpr int kSlInvalid = 1023;    /* not a candidate */
+constexpr int kSlList = 96;         /* list positions addressable by the token waves (GT x waves) */
 constexpr int kSlBCap = 128;        /* boundary-bin members compared pairwise */
 constexpr int kSlFineShift = 15;    /* 256 bins per octave of (best - score) */
 constexpr int kSlCoarseShift = 18;  /* 32 bins per octave: 16 octaves in 512 bins */
@@ -93,11 +94,11 @@ struct SlaneLds {
   unsigned long long mask[2][64];  /* tokens whose child state was ever materialised */
   uint32_t hist[2][kSlNB];
   double eAll[2][64];              /* emission row, widened */
-  double eTok[2][64];              /* ... of the listed tokens, by list position; NaN past the list */
-  unsigned long long tokBit[2][64]; /* 1 << token of the list position, 0 past the list */
+  double eTok[2][kSlList];         /* ... of the listed tokens, by list position; NaN past the list */
+  unsigned long long tokBit[2][kSlList]; /* 1 << token of the list position, 0 past the list */
   SlRow row[2];
-  uint8_t tokId[2][64];            /* list position -> token */
-  uint32_t off[32];                /* new states of the waves before wave i; [nW] = all (nW <= 16) */
+  uint8_t tokId[2][kSlList];       /* list position -> token */
+  uint32_t off[32];                /* new states of the waves before wave i; [self wave + 1] = all */
   int32_t newLane[64];             /* old lane -> lane in the next beam, -1 = dropped */
   uint32_t scal[16];
   unsigned long long bKey[kSlBCap];
@@ -169,46 +170,40 @@ FLTX_DEV SlScan slScan(const uint32_t* hist, int K) {
   return r;
 }
 
-/* Emission row -> what the frame step reads (buffer q): the widened row, the
- * token beam, the list of tokens the normal waves evaluate, and the frame's best
- * candidate: best hypothesis (= `mmax`, the previous frame's best candidate) +
- * best token.  One wave; lane n holds e[n].  Returns the frame's best. */
-FLTX_DEV double slPrepRow(const DecodeParams& P, SlaneLds& S, int q, float v, bool ctc, double mmax) {
+/* Emission row -> what the frame step reads: the widened row, the token beam, the
+ * list of tokens the token waves evaluate, and the frame's best candidate: best
+ * hypothesis (= `mmax`, the previous frame's best candidate) + best token.  One
+ * wave; lane n holds e[n].  In two halves so that the staging wave can spread the
+ * work over a frame: slRowScan (registers only) and slRowStore (LDS writes). */
+struct SlRowRegs {
+  unsigned long long allow, listMask;
+  double best;
+  float v;
+  int nList;
+  bool dead;
+};
+FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mmax) {
   const int lane = laneId();
   const int N = P.N;
   const bool inRow = lane < N;
-  unsigned long long allow = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
+  SlRowRegs r;
+  r.v = v;
+  r.allow = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
   if (P.Kt < N) { /* LexiconFreeDecoder.cpp:42-51: top beamSizeToken by emission, ties to the lower index */
     int rank = 0;
     for (int m = 0; m < N; ++m) {
       const float o = __uint_as_float(waveReadLane32(__float_as_uint(v), m));
       rank += (o > v || (o == v && m < lane)) ? 1 : 0;
     }
-    allow = waveBallot(inRow && rank < P.Kt);
+    r.allow = waveBallot(inRow && rank < P.Kt);
   }
-  const bool mine = inRow && ((allow >> lane) & 1ull) != 0ull;
+  const bool mine = inRow && ((r.allow >> lane) & 1ull) != 0ull;
   const uint32_t ek = waveMax32((mine && lane != P.sil && v == v) ? f32Key(v) : 0u);
-  unsigned long long listMask = allow;
+  r.listMask = r.allow;
   if (ctc) {
-    listMask &= ~(1ull << P.blank);
+    r.listMask &= ~(1ull << P.blank);
   }
-  const int pos = wavePrefixCount(listMask);
-  const int nList = popc64(listMask);
-  const bool listed = inRow && ((listMask >> lane) & 1ull) != 0ull;
-  if (inRow) {
-    S.eAll[q][lane] = (double)v;
-  }
-  if (lane >= nList) { /* past the list: a NaN emission makes every candidate of the position invalid */
-    S.eTok[q][lane] = __builtin_nan("");
-    S.tokBit[q][lane] = 0ull;
-    S.tokId[q][lane] = (uint8_t)0;
-  }
-  waveSync();
-  if (listed) {
-    S.tokId[q][pos] = (uint8_t)lane;
-    S.eTok[q][pos] = (double)v;
-    S.tokBit[q][pos] = 1ull << lane;
-  }
+  r.nList = popc64(r.listMask);
   const float eSil = __uint_as_float(waveReadLane32(__float_as_uint(v), P.sil));
   /* best candidate of the frame: fl(a + e) is monotone in e, so the best hypothesis with the
    * largest emission -- sil is scored separately because of silScore */
@@ -218,22 +213,49 @@ FLTX_DEV double slPrepRow(const DecodeParams& P, SlaneLds& S, int q, float v, bo
     best = mmax + (double)f32FromKey(ek);
     any = true;
   }
-  if ((allow >> P.sil) & 1ull) {
+  if ((r.allow >> P.sil) & 1ull) {
     const double sS = (mmax + (double)eSil) + P.silScore;
     if (sS == sS && (!any || sS > best)) {
       best = sS;
       any = true;
     }
   }
-  if (lane == 0) {
-    S.row[q].best = best;
-    S.row[q].thr = best - P.beamThreshold;
-    S.row[q].nList = nList;
-    S.row[q].silPos = ((listMask >> P.sil) & 1ull) ? popc64(listMask & ((1ull << P.sil) - 1ull)) : -4096;
-    S.row[q].dead = (!any || !(best - best == 0.0)) ? 1u : 0u;
-    S.row[q].allow = allow;
+  r.best = best;
+  r.dead = !any || !(best - best == 0.0);
+  return r;
+}
+/* padPast: also (re)write the positions past the end of the list (NaN emission = no candidate);
+ * with the whole token set listed their content never changes and the prologue writes them once */
+FLTX_DEV void slRowStore(const DecodeParams& P, SlaneLds& S, int q, const SlRowRegs& r, bool padPast) {
+  const int lane = laneId();
+  const bool inRow = lane < P.N;
+  const int pos = wavePrefixCount(r.listMask);
+  const bool listed = inRow && ((r.listMask >> lane) & 1ull) != 0ull;
+  if (inRow) {
+    S.eAll[q][lane] = (double)r.v;
   }
-  return best;
+  if (padPast) {
+    for (int i = lane; i < kSlList; i += 64) {
+      if (i >= r.nList) {
+        S.eTok[q][i] = __builtin_nan("");
+        S.tokBit[q][i] = 0ull;
+        S.tokId[q][i] = (uint8_t)0;
+      }
+    }
+  }
+  if (listed) {
+    S.tokId[q][pos] = (uint8_t)lane;
+    S.eTok[q][pos] = (double)r.v;
+    S.tokBit[q][pos] = 1ull << lane;
+  }
+  if (lane == 0) {
+    S.row[q].best = r.best;
+    S.row[q].thr = r.best - P.beamThreshold;
+    S.row[q].nList = r.nList;
+    S.row[q].silPos = ((r.listMask >> P.sil) & 1ull) ? popc64(r.listMask & ((1ull << P.sil) - 1ull)) : -4096;
+    S.row[q].dead = r.dead ? 1u : 0u;
+    S.row[q].allow = r.allow;
+  }
 }
 
 /* Re-entry of LM states that had dropped out of the beam (recorded by the
@@ -314,7 +336,7 @@ FLTX_DEV __attribute__((noinline)) void slReenter(SlaneLds& S, const int2* histP
     }                                                         \
   } while (0)
 
-/* GT = list positions per normal wave (nList <= GT * (waves - 1)) */
+/* GT = list positions per normal wave (nList <= GT * (waves - 2)) */
 template <int GT, bool PROF>
 FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   SlaneLds& S = *(SlaneLds*)smem;
@@ -322,9 +344,12 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   const int W = (int)blockDim.x, tid = (int)threadIdx.x;
   const int lane = laneId(), wave = waveUniform(waveId());
   const int nW = W >> 6;
-  const int selfWave = nW - 1; /* blank / repeat / blank-then-last groups of every lane */
-  const int prepWave = 0;      /* stages the next emission row */
-  const bool isSelf = wave == selfWave;
+  /* waves 0 .. nW - 3 evaluate the listed tokens (GT list positions each); the next one owns the
+   * blank / repeat / blank-then-last groups of every lane; the last one stages the next emission
+   * row and does the per-frame housekeeping, off everybody else's path */
+  const int selfWave = nW - 2;
+  const int prepWave = nW - 1;
+  const bool isSelf = wave == selfWave, isSvc = wave == prepWave;
   const int K = P.K, N = P.N;
   const bool ctc = P.criterion == 1;
   const int T = P.stepT ? P.stepT[b] : 0;
@@ -376,9 +401,10 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const float v0 = (T > 0 && lane < N) ? em[lane] : 0.0f;
     rowA = (T > 1 && lane < N) ? em[(size_t)1 * N + lane] : 0.0f;
     rowB = (T > 2 && lane < N) ? em[(size_t)2 * N + lane] : 0.0f;
-    if (T > 0) {
-      bestChain = slPrepRow(P, S, 0, v0, ctc, 0.0);
-    }
+    SlRowRegs r0 = slRowScan(P, v0, ctc, 0.0);
+    bestChain = r0.best;
+    slRowStore(P, S, 0, r0, true);
+    slRowStore(P, S, 1, r0, true); /* (the positions past the list; the rest is rewritten by frame 0) */
   }
   ldsBarrier();
 
@@ -407,20 +433,20 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     unsigned long long tb[GT];
     double eBlank = 0.0;
     unsigned long long allow = 0ull;
-    if (!isSelf) {
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      ev[j] = 0.0;
+      tb[j] = 0ull;
+    }
+    if (isSelf) {
+      eBlank = S.eAll[p][ctc ? blank : 0];
+      allow = S.row[p].allow;
+    } else if (!isSvc) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         ev[j] = S.eTok[p][wave * GT + j];
         tb[j] = S.tokBit[p][wave * GT + j];
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < GT; ++j) {
-        ev[j] = 0.0;
-        tb[j] = 0ull;
-      }
-      eBlank = S.eAll[p][ctc ? blank : 0];
-      allow = S.row[p].allow;
     }
     (void)nList;
     if (nev != 0u) { /* rare: states re-entered the beam in the previous build */
@@ -433,10 +459,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       dead = true;
       return;
     }
-    for (int i = tid; i < kSlNB; i += W) {
-      S.hist[q][i] = 0u;
-    }
-    const bool live = lane < nState;
+    const bool live = lane < nState && !isSvc;
     const double nb = live ? me.nb : NEG, bb = live ? me.b : NEG;
     const int last = (int)(me.info & 0xFFu) & 63;
     const int pl = live ? (int)((me.info >> 8) & 0xFFu) - 1 : -1;
@@ -455,7 +478,29 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     double cs[GT];
     int cbin[GT];
     uint32_t parR = kSlNoHyp;
-    if (!isSelf) {
+    SlRowRegs nextRow = {};
+    if (isSvc) {
+      /* housekeeping for everybody: the other parity's histogram (used by the next frame), the
+       * masks and counters this frame's build adds to; then the next frame's emission row */
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        cs[j] = NEG;
+        cbin[j] = kSlInvalid;
+      }
+      S.cmask[q][lane] = 0ull;
+      S.mask[q][lane] = 0ull;
+      if (lane < 32) {
+        S.off[lane] = 0u;
+      }
+      if (lane == 0) {
+        S.scal[SL_BCNT] = 0u;
+      }
+      if (t + 1 < T) {
+        nextRow = slRowScan(P, rowReg, ctc, bestChain);
+        bestChain = nextRow.best;
+      }
+      rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
+    } else if (!isSelf) {
       /* tokens this lane does not extend with here: its own last token (the repeat and the
        * blank-then-last case belong to the self wave) and those whose child state holds a lane
        * (that lane merges the extension into its repeat).  A lane without a state skips all. */
@@ -520,15 +565,6 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       for (int j = 3; j < GT; ++j) {
         cs[j] = NEG;
         cbin[j] = kSlInvalid;
-      }
-      /* this frame's build ORs into the other parity's masks and counts into off[] */
-      S.cmask[q][lane] = 0ull;
-      S.mask[q][lane] = 0ull;
-      if (lane < 32) {
-        S.off[lane] = 0u;
-      }
-      if (lane == 0) {
-        S.scal[SL_BCNT] = 0u;
       }
     }
     /* one LDS atomic per candidate inside the window (bin 0 = nearer than the window included);
@@ -664,7 +700,12 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     int myNew[GT];
     int surv = -1;
     uint32_t hNB = kSlNoHyp, hB = kSlNoHyp;
-    if (!isSelf) {
+    if (isSvc) {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        myNew[j] = 0;
+      }
+    } else if (!isSelf) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         myNew[j] = 0;
@@ -673,7 +714,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
           nNewWave += popc64(selMask[j]);
         }
       }
-      if (lane > wave && lane <= nW && nNewWave > 0) {
+      if (lane > wave && lane <= selfWave + 1 && nNewWave > 0) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
       }
     } else {
@@ -694,7 +735,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         S.scal[SL_NSURV] = (uint32_t)popc64(balS);
         S.scal[SL_NHSURV] = (uint32_t)(popc64(balR) + popc64(balB));
       }
-      if (lane == nW && nNewWave > 0) {
+      if (lane == selfWave + 1 && nNewWave > 0) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
       }
     }
@@ -702,7 +743,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     ldsBarrier(); /* 2 */
     /* ---- phase 3: every survivor is written by the lane that evaluated it ---------------- */
     const int nSurv = (int)S.scal[SL_NSURV], nHSurv = (int)S.scal[SL_NHSURV];
-    const int offW = (int)S.off[wave], nNew = (int)S.off[nW];
+    const int offW = (int)S.off[wave], nNew = (int)S.off[selfWave + 1];
     const int myNewLane = S.newLane[lane];
     const int plNew = S.newLane[pl >= 0 ? pl : 0];
     auto newState = [&](int idx, double c, int n, uint32_t hp) {
@@ -728,7 +769,16 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         S.evTok[e] = (uint32_t)n;
       }
     };
-    if (!isSelf) {
+    if (isSvc) {
+      if (lane >= nHSurv + nNew && lane < K) { /* unused slots of the history row: see slReenter */
+        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
+      }
+      if (t + 1 < T) {
+        slRowStore(P, S, q, nextRow, P.Kt < N);
+      }
+      ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+      ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+    } else if (!isSelf) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         if (selMask[j] != 0ull) { /* (most positions of most frames have no survivor at all) */
@@ -766,15 +816,6 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       if ((selMask[2] >> lane) & 1ull) {
         newState(offW + myNew[2], cs[2], last, hypB);
       }
-    }
-    if (wave == prepWave) { /* the next frame's emission row */
-      if (lane >= nHSurv + nNew && lane < K) { /* unused slots of the row: see slReenter */
-        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
-      }
-      if (t + 1 < T) {
-        bestChain = slPrepRow(P, S, q, rowReg, ctc, bestChain);
-      }
-      rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
     }
     nState = nSurv + nNew;
     endBest = best;
