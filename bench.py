@@ -8,28 +8,42 @@ Appendix A).  A "step" = one fltx_decode_batch over that batch: decodeBegin +
 T frames + decodeEnd + back-trace of every hypothesis, inputs resident in HBM
 before the timed region, results left in HBM.
 
---workload C3 / C4 select BASELINE.json configs[2] (90k-word trie, beam 50,
-beamSizeToken 10) and configs[3] (trie + synthetic 4-gram word LM, T = 1500,
-beam 100); the default and the judged line is C2.
+--workload C3 / C4 / C5 select BASELINE.json configs[2] (90k-word trie, beam 50,
+beamSizeToken 10), configs[3] (trie + synthetic 4-gram word LM, T = 1500, beam
+100) and configs[4] (configs[3] with 8192 utterances over 8 GPUs = 1024 per GPU;
+the line also carries the strong-scaling figure: 8192 utterances over the N GPUs
+of the run).  The default and the judged line is C2.
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One process per GPU; utterances shard across ranks with no data-path
-collective (weak scaling: 256 utterances per GPU); torch.distributed is used
-only for the barrier and the max-over-ranks of the timed region.
+One process per GPU; utterances shard across ranks with no data-path collective
+(weak scaling: the same batch per GPU); torch.distributed is used only for the
+barrier and the max-over-ranks of the timed region.  `--gpus N` WITHOUT the
+launcher (WORLD_SIZE unset) starts the N ranks itself, so the line always
+reports the N it was asked for.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : dominant kernel (fltx_decode_kernel) vs the HBM roofline,
-                 algorithmic bytes per SURVEY.md section 8(d) / HIP-event duration
-  cpu_baseline : the unmodified reference (oracle/_ref, kind "reference") or,
-                 if that prebuilt .so is absent, the oracle restatement (kind
-                 "port"), one thread, on a bounded sample of the same batch.
+  roofline     : dominant kernel (the decode kernel) vs the HBM roofline: its own
+                 algorithmic bytes (n-gram queries and
+                 returned hypotheses as the kernels counted them) / its HIP-event
+                 duration; the back-trace epilogue and the whole job likewise
+  cpu_baseline : the unmodified reference (oracle/_ref, kind "reference") or, if
+                 that prebuilt .so is absent, the oracle restatement (kind
+                 "port"), one thread, on a bounded sample of the same batch;
+                 N = 1 only, like the three blocks below
+  cpu_baseline_steady / cpu_baseline_all_cores : the same decoder object reused
+                 across utterances; one decoder per host thread on every core
+  end_to_end   : host emissions in (H2D), kernels, the whole n-best back in host
+                 memory, DecodeResult-like views materialised
+  streaming    : the same batch as B parallel streams fed in chunks of 50 frames
+                 with prune() after every chunk
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -41,31 +55,111 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 HBM_MEASURED_GBS = 6290.0    # same guide: 6.29 TB/s float4 copy
 
+WORKLOADS = {
+    # name: (decoder, batch/GPU, T, beam, beamToken, LM)
+    "C2": dict(lex=False, batch=256, T=1000, K=50, Kt=29, lm=False),
+    "C3": dict(lex=True, batch=256, T=1000, K=50, Kt=10, lm=False),
+    "C4": dict(lex=True, batch=256, T=1500, K=100, Kt=29, lm=True),
+    "C5": dict(lex=True, batch=1024, T=1500, K=100, Kt=29, lm=True, total=8192),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
-    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (0 = the workload's)")
+    ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--tokens", type=int, default=29)
-    ap.add_argument("--beam", type=int, default=50)
-    ap.add_argument("--beam-token", type=int, default=29)
+    ap.add_argument("--beam", type=int, default=0)
+    ap.add_argument("--beam-token", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0, help="threads per utterance (0 = library default)")
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4"])
-    ap.add_argument("--cpu-sample", type=int, default=160, help="utterances timed on the CPU baseline")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=160, help="utterances timed on the one-thread CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true", help="skip every CPU / host-side leg (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip all-cores / steady / end-to-end / streaming")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
     ap.add_argument("--profile-waves", default="0", help="comma-separated wave indices to sample with --profile")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
-    ap.add_argument("--device", type=int, default=-1, help="override the CUDA device (default: LOCAL_RANK)")
+    ap.add_argument("--device", type=int, default=-1, help="override the device (default: LOCAL_RANK)")
     ap.add_argument("--set", action="append", default=[], help="decoder tunable key=value (repeatable)")
     return ap.parse_args()
 
 
+def self_launch(a):
+    """`--gpus N` without a launcher: start the N ranks (one per GPU) ourselves through
+    torch.distributed.run and pass rank 0's line through, so n_gpus is what was asked for."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    if r.returncode != 0 or not line:
+        sys.stdout.write(r.stdout)
+        raise SystemExit("bench.py: the %d-rank run failed (exit %d)" % (a.gpus, r.returncode))
+    print(line[-1])
+
+
+class Job:
+    """Everything one rank needs to decode its shard: synthetic inputs, LM, trie, decoder."""
+
+    def __init__(self, a, rank, local, B, cfg):
+        from text_amd import _capi, synth
+        self.capi = _capi
+        self.a, self.B = a, B
+        self.T, self.N, self.K, self.Kt = cfg["T"], a.tokens, cfg["K"], min(cfg["Kt"], a.tokens)
+        self.lex, self.haslm = cfg["lex"], cfg["lm"]
+        N = self.N
+        self.lexicon = synth.lexicon() if self.lex else None
+        self.dist = "lexspell" if self.lex else "ctc"
+        self.u0 = rank * B
+        self.e_host = synth.batch(self.dist, B, self.T, N, lexicon=self.lexicon, u0=self.u0)
+        self.ctx = _capi.Context(device=local)
+        self.lm = _capi.ZeroLM(self.ctx)
+        self.opt = _capi.make_options(self.K, self.Kt, 25.0)
+        self.arpa = None
+        if self.haslm:
+            # same options as the parity case C4_spell_u0 (tests/cases.py)
+            self.opt = _capi.make_options(self.K, self.Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, False, "ctc")
+            self.arpa = synthetic_arpa(len(self.lexicon[1]) - 1)
+            self.lm = _capi.ArpaLM(self.arpa[0], self.arpa[1])
+        self.trie = self.host_trie = self.wscore = None
+        self.W = 0
+        if self.lex:
+            W = self.W = len(self.lexicon[1]) - 1
+            ht = self.host_trie = _capi.HostTrie(N, 0)
+            self.wscore = np.zeros(W, dtype=np.float32)
+            if self.arpa:  # trie label scores = lm.score(start, word) (DecoderTest.cpp:137-146)
+                self.wscore = np.array([self.lm.score_sequence([w], False)[0][0] for w in range(W)],
+                                       dtype=np.float32)
+            ht.insert_many(self.lexicon[0], self.lexicon[1], np.arange(W), self.wscore)
+            ht.smear(1)
+            self.trie = ht.upload(self.ctx)
+        self.Ts = np.full(B, self.T, dtype=np.int32)
+
+    def decoder(self):
+        c = self.capi
+        if self.lex:
+            d = c.BatchDecoder(self.ctx, c.LEXICON, self.opt, self.lm, 0, self.N - 1, unk=self.W, trie=self.trie)
+        else:
+            d = c.BatchDecoder(self.ctx, c.LEXFREE, self.opt, self.lm, 0, self.N - 1)
+        if self.a.threads:
+            d.set("threads", self.a.threads)
+        for kv in self.a.set:
+            k, v = kv.split("=")
+            d.set(k, int(v))
+        return d
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -74,6 +168,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the decoder has no CPU path")
     if a.device >= 0:
         local = a.device
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants device %d but the node has %d (use --device 0 --backend gloo "
+                         "only for plumbing checks: ranks sharing a GPU measure nothing)" %
+                         (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -84,96 +182,57 @@ def main():
         else:
             dist.init_process_group(a.backend)
 
-    from text_amd import _capi, synth
-    B, T, N, K, Kt = a.batch, a.frames, a.tokens, a.beam, a.beam_token
-    lex_wl = a.workload in ("C3", "C4")
-    if a.workload == "C3":
-        Kt = 10
-    if a.workload == "C4":  # BASELINE.json configs[3]: trie + 4-gram word LM, T=1500, beam=100
-        T, K = (1500 if a.frames == 1000 else a.frames), (100 if a.beam == 50 else a.beam)
-    lexicon = synth.lexicon() if lex_wl else None
-    dist_name = "lexspell" if lex_wl else "ctc"
-    u0 = rank * B  # each rank decodes its own shard of the node-wide batch
-    e_host = synth.batch(dist_name, B, T, N, lexicon=lexicon, u0=u0)
-    e_dev = torch.from_numpy(e_host).cuda()  # resident in HBM before timing
+    cfg = dict(WORKLOADS[a.workload])
+    for key, val in (("T", a.frames), ("K", a.beam), ("Kt", a.beam_token)):
+        if val:
+            cfg[key] = val
+    B = a.batch or cfg["batch"]
+    job = Job(a, rank, local, B, cfg)
+    T, N, K, Kt = job.T, job.N, job.K, job.Kt
+    e_dev = torch.from_numpy(job.e_host).cuda()  # resident in HBM before timing
     torch.cuda.synchronize()
-
-    ctx = _capi.Context(device=local)
-    lm = _capi.ZeroLM(ctx)
-    opt = _capi.make_options(K, Kt, 25.0)
-    arpa = None
-    if a.workload == "C4":
-        # same options as the parity case C4_spell_u0 (tests/cases.py)
-        opt = _capi.make_options(K, Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, False, "ctc")
-        arpa = synthetic_arpa(len(lexicon[1]) - 1)
-        lm = _capi.ArpaLM(arpa[0], arpa[1])
-    trie = None
-    if lex_wl:
-        W = len(lexicon[1]) - 1
-        ht = _capi.HostTrie(N, 0)
-        wscore = np.zeros(W, dtype=np.float32)
-        if arpa:  # trie label scores = lm.score(start, word) (DecoderTest.cpp:137-146)
-            wscore = np.array([lm.score_sequence([w], False)[0][0] for w in range(W)], dtype=np.float32)
-        ht.insert_many(lexicon[0], lexicon[1], np.arange(W), wscore)
-        ht.smear(1)
-        trie = ht.upload(ctx)
-        dec = _capi.BatchDecoder(ctx, _capi.LEXICON, opt, lm, 0, N - 1, unk=W, trie=trie)
-    else:
-        dec = _capi.BatchDecoder(ctx, _capi.LEXFREE, opt, lm, 0, N - 1)
-    if a.threads:
-        dec.set("threads", a.threads)
-    for kv in a.set:
-        k, v = kv.split("=")
-        dec.set(k, int(v))
-    Ts = np.full(B, T, dtype=np.int32)
-
-    def step():
-        dec.decode_batch(None, Ts, N, device_ptr=e_dev.data_ptr())
+    dec = job.decoder()
 
     def fence():
-        ctx.synchronize()
+        job.ctx.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
+    def timed(step, steps, warmup, after=None):
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            if after:
+                after()
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     kern_ms, bt_ms = [], []
-    for _ in range(a.steps):
-        step()
-        # HIP events recorded by the library on its own launch stream
+
+    def step():
+        dec.decode_batch(None, job.Ts, N, device_ptr=e_dev.data_ptr())
+
+    def after():  # HIP events recorded by the library on its own launch stream
         d_ms, b_ms = dec.timing()
         kern_ms.append(d_ms)
         bt_ms.append(b_ms)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    for pw in ([int(x) for x in a.profile_waves.split(",")] if (a.profile and rank == 0) else []):
-        dec.set("profile", 1)
-        dec.set("profile_wave", pw)
-        step()
-        ctx.synchronize()
-        pr = dec.profile().astype(np.float64)
-        names = ["A2(combine)", "B(eval+bin)", "C(prefix)", "D(shortlist)", "E(build)", "row", "A1(relations)", "E-rank"]
-        order = list(range(8))
-        if dec.get("engine") == 3:  # fltx_lane.h marks, in program order
-            names = ["best+bins", "eval+hist", "bar1+prefix", "scatter", "build", "row+bar3", "load+relations", "bar2+rank"]
-            order = [6, 0, 1, 2, 3, 7, 4, 5]
-        names = [names[i] for i in order]
-        pr = pr[order]
-        tot = pr[:8].sum()
-        sys.stderr.write("wave %d phase split (shader clocks, %% of %.3g): " % (pw, tot) + ", ".join(
-            "%s %.0f" % (n, v / (B * T)) for n, v in zip(names, pr[:8])) +
-            " | clocks/frame/utt %.0f\n" % (tot / (B * T)))
-        dec.set("profile", 0)
+
+    dt = timed(step, a.steps, a.warmup, after)
+    if a.profile and rank == 0:
+        phase_profile(a, dec, job, step, B, T)
     st = dec.stats()
-    frames_total = B * T * a.steps * world
-    value = frames_total / dt
+    by = dec.bytes()
+    engine = dec.get("engine")
+    value = B * T * a.steps * world / dt
 
     out = {
         "metric": "decoded frames/sec (whole node), T=%d N=%d beam=%d; hyp bit-exact vs CPU" % (T, N, K),
@@ -182,33 +241,59 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %s + %s CTC, batch=%d utterances/GPU, T=%d, N=%d, beam=%d, "
                                "beamToken=%d, beamThreshold=25, logAdd=false, `%s` emissions" %
-                               (a.workload, "LexiconDecoder + 90k-word trie" if trie else "LexiconFreeDecoder",
-                                "synthetic 4-gram word LM (lmWeight 2, wordScore 2, silScore -1)" if arpa else "ZeroLM",
-                                B, T, N, K, Kt, dist_name),
+                               (a.workload, "LexiconDecoder + 90k-word trie" if job.lex else "LexiconFreeDecoder",
+                                "synthetic 4-gram word LM (lmWeight 2, wordScore 2, silScore -1)" if job.haslm
+                                else "ZeroLM", B, T, N, K, Kt, job.dist),
                    "parallelism": "utterance-sharded x%d, no collective" % world,
-                   "threads_per_utterance": st["threads_per_utt"], "lds_bytes_per_workgroup": st["lds_bytes"]},
+                   "threads_per_utterance": st["threads_per_utt"], "lds_bytes_per_workgroup": st["lds_bytes"],
+                   "engine": engine},
     }
-    # ---- roofline of the dominant kernel (rank-local) -----------------------
-    k_ms = float(np.mean(kern_ms))
-    alg_bytes = st["algorithmic_bytes"]
-    ach = alg_bytes / (k_ms * 1e-3) / 1e9
-    out["roofline"] = {"bound": "hbm", "kernel": "fltx_decode_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                       "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
-                       "backtrace_kernel_ms": float(np.mean(bt_ms)),
-                       "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBS,
-                       "us_per_frame_step": k_ms * 1e3 / T}
-
+    # ---- roofline (rank-local): each kernel's own algorithmic bytes over its own duration ----
+    k_ms, b_ms = float(np.mean(kern_ms)), float(np.mean(bt_ms))
+    ach = by["decode"] / (k_ms * 1e-3) / 1e9
+    rl = {"bound": "hbm", "kernel": "fltx_decode_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+          "algorithmic_bytes_per_launch": by["decode"], "kernel_ms": k_ms,
+          "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBS, "us_per_frame_step": k_ms * 1e3 / T,
+          "ngram_query_bytes": by["lm"]}
+    e_ach = by["epilogue"] / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0
+    rl["epilogue"] = {"kernel": "fltx_backtrace_kernel", "algorithmic_bytes_per_launch": by["epilogue"],
+                      "kernel_ms": b_ms, "achieved": e_ach, "frac": e_ach / HBM_PEAK_GBS}
+    w_ach = (by["decode"] + by["epilogue"]) / ((k_ms + b_ms) * 1e-3) / 1e9
+    rl["whole_job"] = {"algorithmic_bytes_per_launch": by["decode"] + by["epilogue"], "kernels_ms": k_ms + b_ms,
+                       "achieved": w_ach, "frac": w_ach / HBM_PEAK_GBS}
     # HBM traffic per launch comes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    # over this same command (tools/pmc_traffic.py); it is quoted only for the geometry it was
-    # measured on.
-    tr = pmc_traffic(a.workload, st["threads_per_utt"], B, T, N, K)
+    # over this same command (tools/pmc_traffic.py); it is quoted only for the geometry and
+    # engine it was measured on.
+    tr = pmc_traffic(a.workload, st["threads_per_utt"], B, T, N, K, engine)
     if tr is not None:
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
+        rl["traffic"], rl["traffic_source"] = tr
+    out["roofline"] = rl
 
-    # ---- CPU baseline + parity spot check (rank 0, N=1 only) ----------------
+    # ---- configs[4]: the same 8192 utterances over however many GPUs run (strong scaling) ----
+    total = cfg.get("total")
+    if total and not a.batch:
+        Bs = total // world
+        job_s = job if Bs == B else Job(a, rank, local, Bs, cfg)
+        es_dev = e_dev if Bs == B else torch.from_numpy(job_s.e_host).cuda()
+        torch.cuda.synchronize()
+        dec_s = dec if Bs == B else job_s.decoder()
+        steps_s = max(1, a.steps // 4)
+        dts = timed(lambda: dec_s.decode_batch(None, job_s.Ts, N, device_ptr=es_dev.data_ptr()), steps_s, 1)
+        out["strong_scaling"] = {"total_utterances": Bs * world, "utterances_per_gpu": Bs, "steps": steps_s,
+                                 "ms_per_step": dts / steps_s * 1e3, "value": Bs * world * T * steps_s / dts,
+                                 "unit": "frames/s"}
+        if dec_s is not dec:
+            dec_s.close()
+
+    # ---- CPU baselines + parity spot check, end to end, streaming (rank 0, N=1 only) --------
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt, arpa, wscore if lex_wl else None)
+        step()  # the n-best compared below
+        out["cpu_baseline"] = cpu_baseline(a, dec, job)
+        if not a.no_extras:
+            out["cpu_baseline_steady"], out["cpu_baseline_all_cores"] = cpu_more(a, job)
+            out["end_to_end"] = end_to_end(job, dec, B, T, N)
+            out["streaming"] = streaming(job, B, T, N)
     if rank == 0:
         print(json.dumps(out))
     dec.close()
@@ -216,9 +301,35 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(workload, threads, B, T, N, K):
+def phase_profile(a, dec, job, step, B, T):
+    for pw in [int(x) for x in a.profile_waves.split(",")]:
+        dec.set("profile", 1)
+        dec.set("profile_wave", pw)
+        step()
+        job.ctx.synchronize()
+        pr = dec.profile().astype(np.float64)
+        names = ["A2(combine)", "B(eval+bin)", "C(prefix)", "D(shortlist)", "E(build)", "row", "A1(relations)", "E-rank"]
+        order = list(range(8))
+        eng = dec.get("engine")
+        if eng == 3:  # fltx_lane.h marks, in program order
+            names = ["best+bins", "eval+hist", "bar1+prefix", "scatter", "build", "row+bar3", "load+relations", "bar2+rank"]
+            order = [6, 0, 1, 2, 3, 7, 4, 5]
+        if eng == 4:  # fltx_slane.h
+            names = ["loads", "candidates+hist", "bar1+scan+select", "new-lane counts", "bar2+build", "bar3", "-", "-"]
+        names = [names[i] for i in order]
+        pr = pr[order]
+        tot = pr[:8].sum()
+        sys.stderr.write("wave %d phase split (shader clocks, %% of %.3g): " % (pw, tot) + ", ".join(
+            "%s %.0f" % (n, v / (B * T)) for n, v in zip(names, pr[:8])) +
+            " | clocks/frame/utt %.0f\n" % (tot / (B * T)))
+        dec.set("profile", 0)
+
+
+def pmc_traffic(workload, threads, B, T, N, K, engine=None):
     import glob
     want = "%s threads=%d batch=%d T=%d N=%d beam=%d" % (workload, threads, B, T, N, K)
+    if engine is not None:
+        want += " engine=%d" % engine
     here = os.path.dirname(os.path.abspath(__file__))
     for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", "hbm_traffic_*.json")), reverse=True):
         try:
@@ -248,47 +359,169 @@ def synthetic_arpa(W):
     return path, vocab
 
 
-def cpu_baseline(a, dec, e_host, lexicon, B, T, N, K, Kt, arpa=None, wscore=None):
+class CpuSide:
+    """The CPU checker set up for the job's configuration (test infrastructure: only this
+    baseline leg touches oracle/)."""
+
+    def __init__(self, job):
+        from oracle import orclib
+        self.kind = "reference" if orclib.have_ref() else "port"
+        self.lib = lib = orclib.load("ref" if self.kind == "reference" else "oracle")
+        self.job = job
+        self.opt = orclib.make_options(job.K, job.Kt, 25.0)
+        if job.arpa:
+            self.opt = orclib.make_options(job.K, job.Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, False, "ctc")
+        self.trie = None
+        if job.lexicon is not None:
+            self.trie = lib.build_trie(job.N, 0, job.lexicon[0], job.lexicon[1], np.arange(job.W), job.wscore, 1)
+        self.lm_shared = lib.lm_arpa_create(job.arpa[0].encode(), "\n".join(job.arpa[1]).encode()) \
+            if job.arpa else None
+
+    def new_decoder(self):
+        lib, job = self.lib, self.job
+        lm = self.lm_shared if self.lm_shared else lib.lm_zero_create()
+        d = lib.lexicon(self.opt, self.trie, lm, 0, job.N - 1, job.W) if self.trie \
+            else lib.lexfree(self.opt, lm, 0, job.N - 1)
+        return d, lm
+
+    def free(self, d, lm):
+        self.lib.decoder_destroy(d)
+        if not self.lm_shared:
+            self.lib.lm_destroy(lm)
+
+
+def cpu_baseline(a, dec, job):
     """Time the reference's CPU path on a bounded sample of the same batch and
     compare its n-best with what the GPU produced for those utterances."""
-    from oracle import orclib
-    kind = "reference" if orclib.have_ref() else "port"
-    lib = orclib.load("ref" if kind == "reference" else "oracle")
-    opt = orclib.make_options(K, Kt, 25.0)
-    if arpa:
-        opt = orclib.make_options(K, Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, False, "ctc")
-    n = min(a.cpu_sample, B)
-    if arpa:
+    cpu = CpuSide(job)
+    n = min(a.cpu_sample, job.B)
+    if job.arpa:
         n = min(n, 32)  # ~50 ms of CPU per frame-thousand at beam 100 with the 4-gram
-    trie = None
-    if lexicon is not None:
-        W = len(lexicon[1]) - 1
-        trie = lib.build_trie(N, 0, lexicon[0], lexicon[1], np.arange(W),
-                              wscore if wscore is not None else np.zeros(W), 1)
     t_total = 0.0
     mism = 0
-    lm_shared = lib.lm_arpa_create(arpa[0].encode(), "\n".join(arpa[1]).encode()) if arpa else None
     for b in range(n):
-        lm = lm_shared if arpa else lib.lm_zero_create()
-        d = lib.lexicon(opt, trie, lm, 0, N - 1, W) if trie else lib.lexfree(opt, lm, 0, N - 1)
+        d, lm = cpu.new_decoder()
         t0 = time.perf_counter()
-        hyps = lib.decode(d, e_host[b], T, N)  # fresh decoder per utterance, decode() only
+        hyps = cpu.lib.decode(d, job.e_host[b], job.T, job.N)  # fresh decoder per utterance, decode() only
         t_total += time.perf_counter() - t0
-        lib.decoder_destroy(d)
-        if not arpa:
-            lib.lm_destroy(lm)
+        cpu.free(d, lm)
         got = dec.results(b)
         same = len(got) == len(hyps) and all(
-            g.score == h.score and np.array_equal(g.tokens, h.tokens) and np.array_equal(g.words, h.words)
-            for g, h in zip(got, hyps))
+            g.score == h.score and g.am == h.am and np.array_equal(g.tokens, h.tokens) and
+            np.array_equal(g.words, h.words) for g, h in zip(got, hyps))
         mism += 0 if same else 1
-    if lm_shared:
-        lib.lm_destroy(lm_shared)
-    return {"value": n * T / t_total, "unit": "frames/s", "cores": 1, "kind": kind,
+    return {"value": n * job.T / t_total, "unit": "frames/s", "cores": 1, "kind": cpu.kind,
             "sample": "first %d utterances of the batch, one thread, fresh decoder per utterance, "
                       "decode() wall time only" % n,
             "seconds": t_total, "gpu_nbest_mismatches_on_sample": mism,
             "host_cpus": os.cpu_count()}
+
+
+def cpu_more(a, job):
+    """(steady state: one decoder object reused, as a server would; all cores: one decoder per
+    host thread, trie / LM shared read-only, utterances dealt round-robin)."""
+    from concurrent.futures import ThreadPoolExecutor
+    cpu = CpuSide(job)
+    lib = cpu.lib
+    per_utt = 0.9 if job.arpa else (0.25 if job.lex else 0.09)  # rough seconds, to bound the legs
+    # -- steady state, one thread
+    n = max(4, min(job.B, int(8.0 / per_utt)))
+    d, lm = cpu.new_decoder()
+    lib.decode(d, job.e_host[0], job.T, job.N)
+    t0 = time.perf_counter()
+    for b in range(n):
+        lib.decode(d, job.e_host[b % job.B], job.T, job.N)
+    ts = time.perf_counter() - t0
+    cpu.free(d, lm)
+    steady = {"value": n * job.T / ts, "unit": "frames/s", "cores": 1, "kind": cpu.kind, "seconds": ts,
+              "sample": "%d utterances through ONE decoder object (decodeBegin frees the previous "
+                        "utterance's LM-state trie inside the timed region)" % n}
+    # -- all cores (ctypes releases the GIL inside the call)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:  # a container may own fewer cores than it sees (cgroup v2 cpu.max = "quota period")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    budget = 8.0  # seconds of wall time; every thread decodes whole utterances until it is spent
+    done = [0] * cores
+    t0 = time.perf_counter()
+
+    def work(k):
+        dd, ll = cpu.new_decoder()
+        i = 0
+        while time.perf_counter() - t0 < budget:
+            lib.decode(dd, job.e_host[(k + i * cores) % job.B], job.T, job.N)
+            i += 1
+        done[k] = i
+        cpu.free(dd, ll)
+
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(work, range(cores)))
+    ta = time.perf_counter() - t0
+    allc = {"value": sum(done) * job.T / ta, "unit": "frames/s", "cores": cores, "kind": cpu.kind,
+            "seconds": ta, "utterances": sum(done), "cgroup_cpu_quota_cores": quota,
+            "sample": "%d host threads, one decoder per thread (reused), trie / LM shared read-only, every "
+                      "thread decodes utterances of the batch until %.0f s of wall time are spent" % (cores, budget)}
+    return steady, allc
+
+
+def end_to_end(job, dec, B, T, N):
+    """Host buffers on both sides: pageable emissions in (H2D inside the call), kernels, the whole
+    n-best back in host memory through pinned staging, NumPy views over it (what a Python caller
+    gets), and -- separately -- one Python object per hypothesis."""
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        dec.decode_batch(job.e_host, job.Ts, N)
+        t1 = time.perf_counter()
+        arrays = dec.results_arrays()
+        t2 = time.perf_counter()
+        objs = dec.results_batch()
+        t3 = time.perf_counter()
+        cur = (t2 - t0, t1 - t0, t2 - t1, t3 - t2, len(objs), int(arrays["n_hyp"].sum()))
+        best = cur if best is None or cur[0] < best[0] else best
+    return {"ms_per_batch": best[0] * 1e3, "value": B * T / best[0], "unit": "frames/s",
+            "h2d_plus_kernels_ms": best[1] * 1e3, "results_to_host_arrays_ms": best[2] * 1e3,
+            "python_object_per_hypothesis_ms": best[3] * 1e3, "hypotheses": best[5],
+            "note": "value = emissions in host memory -> n-best in host memory as NumPy arrays "
+                    "(scores [B,K,3], tokens rows); per-hypothesis Python objects are extra and optional"}
+
+
+def streaming(job, B, T, N, chunk=50):
+    """Decoder::decodeStep in chunks with prune() after each (SURVEY.md section 8 f3): B parallel
+    streams, emissions from host memory chunk by chunk, getBestHypothesis at the end."""
+    c = job.capi
+    d = job.decoder()
+    Tc = np.full(B, chunk, dtype=np.int32)
+    nchunk = T // chunk
+    lat = []
+    best = None
+    for rep in range(2):
+        d.stream_begin(B, N, 4 * chunk + 8)
+        job.ctx.synchronize()
+        t0 = time.perf_counter()
+        for k in range(nchunk):
+            tc = time.perf_counter()
+            d.stream_step(np.ascontiguousarray(job.e_host[:, k * chunk:(k + 1) * chunk, :]), Tc)
+            d.stream_prune(0)
+            job.ctx.synchronize()
+            lat.append(time.perf_counter() - tc)
+        d.stream_end()
+        job.ctx.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    d.close()
+    lat = np.sort(np.array(lat[len(lat) // 2:]))
+    return {"value": B * nchunk * chunk / best, "unit": "frames/s", "streams": B, "chunk_frames": chunk,
+            "chunk_latency_ms_median": float(np.median(lat) * 1e3),
+            "chunk_latency_ms_p95": float(lat[int(0.95 * (len(lat) - 1))] * 1e3),
+            "note": "stream_step(50 frames, host emissions) + prune(0) + synchronize per chunk"}
 
 
 if __name__ == "__main__":

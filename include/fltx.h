@@ -148,6 +148,13 @@ FLTX_API int fltx_htrie_search(fltx_htrie* t, const int32_t* indices, int32_t n,
 FLTX_API int fltx_htrie_smear(fltx_htrie* t, int32_t mode);
 FLTX_API int fltx_htrie_num_nodes(fltx_htrie* t, int64_t* n);
 FLTX_API int fltx_htrie_upload(fltx_htrie* t, fltx_ctx* ctx, fltx_trie** out);
+/* One node of the host trie by id (0 = root): TrieNode::idx / maxScore / labels / scores and
+ * the (token, node id) pairs of TrieNode::children (decoder/Trie.h:30-55), for bindings that
+ * expose the node tree (bindings/python/.../_decoder.cpp:173-186).  Any output may be NULL;
+ * labels / scores hold up to 6 entries, the child arrays child_capacity. */
+FLTX_API int fltx_htrie_node(fltx_htrie* t, int64_t node, int32_t* token, float* max_score,
+                             int32_t* n_labels, int32_t* labels, float* scores, int32_t* n_children,
+                             int32_t* child_tokens, int64_t* child_nodes, int32_t child_capacity);
 
 /* ---- decoder ------------------------------------------------------------- */
 /* LexiconFreeDecoder(opt, lm, sil, blank, transitions)
@@ -228,12 +235,48 @@ FLTX_API int fltx_result_device(fltx_decoder* dec, const int32_t** n_hyp,
                                 const double** scores, const int32_t** tokens,
                                 const int32_t** words, const int64_t** tok_off);
 
+/* ---- one batch over several devices -------------------------------------- */
+/* Utterances are independent: a group holds one context
+ * and one decoder per entry of `devices` (an index may repeat: two contexts on
+ * one device), the trie of `htrie` and the tables of `lm` replicated on each.
+ * fltx_group_decode_batch cuts the batch into contiguous shards of about equal
+ * frame count and runs fltx_decode_batch on every shard from its own host
+ * thread; there is no inter-device traffic.  Replaces the loop over
+ * Decoder::decode (decoder/Decoder.h:51-57) a multi-GPU caller would write.
+ * emissions[i] is the buffer device i reads its shard from (the same host
+ * pointer for all, or per-device HBM pointers with on_device[i] != 0); offsets
+ * (NULL: utterances packed back to back) index into it with the caller's
+ * utterance numbering.  Results are addressed by that numbering too. */
+typedef struct fltx_group fltx_group;
+FLTX_API int fltx_group_create(const int32_t* devices, int32_t n_devices, int32_t kind,
+                               const fltx_options* opt, fltx_htrie* htrie, const fltx_lm* lm,
+                               int32_t sil, int32_t blank, int32_t unk, const float* transitions,
+                               int32_t n_transitions, int32_t is_lm_token, fltx_group** out);
+FLTX_API int fltx_group_destroy(fltx_group* group);
+FLTX_API int fltx_group_size(fltx_group* group, int32_t* n_devices);
+/* decoder of part i and the utterances [first, first + count) it holds of the last batch */
+FLTX_API int fltx_group_decoder(fltx_group* group, int32_t i, fltx_decoder** dec, int32_t* first,
+                                int32_t* count);
+FLTX_API int fltx_group_decode_batch(fltx_group* group, const float* const* emissions,
+                                     const int32_t* on_device, const int64_t* offsets,
+                                     const int32_t* T, int32_t B, int32_t N);
+FLTX_API int fltx_group_result_count(fltx_group* group, int32_t b, int32_t* n_hyp, int32_t* length);
+FLTX_API int fltx_group_result_fetch(fltx_group* group, int32_t b, int32_t max_hyp, double* scores,
+                                     int32_t* tokens, int32_t* words, int32_t* n_copied);
+FLTX_API int fltx_group_synchronize(fltx_group* group);
+
 /* ---- introspection for bench.py ------------------------------------------ */
 /* Frames decoded and kernel launches issued by the last decode call, plus the
  * algorithmic HBM bytes of SURVEY.md section 8(d) for it. */
 FLTX_API int fltx_decoder_stats(fltx_decoder* dec, int64_t* frames,
                                 int64_t* algorithmic_bytes, int32_t* threads_per_utt,
                                 int32_t* lds_bytes);
+/* The same algorithmic bytes split by kernel: the decode kernel's share (emission rows in,
+ * one back-pointer record per surviving slot out, trie gathers, plus 16 * order bytes per
+ * n-gram LM query the kernel counted: *lm_bytes, included in *decode_bytes) and the
+ * back-trace epilogue's (16 bytes per step of each hypothesis actually returned). */
+FLTX_API int fltx_decoder_bytes(fltx_decoder* dec, int64_t* decode_bytes, int64_t* epilogue_bytes,
+                                int64_t* lm_bytes);
 /* Durations (ms) of the decode kernel and of the back-trace kernel of the last
  * fltx_decode_batch, from HIP events recorded on the context stream. */
 FLTX_API int fltx_decoder_timing(fltx_decoder* dec, float* decode_ms, float* backtrace_ms);

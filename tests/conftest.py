@@ -31,8 +31,8 @@ def emu_session():
     import subprocess
     import helpers
     src = [os.path.join(ROOT, "text_amd", "csrc", f) for f in
-           ("fltx_api.cpp", "fltx_kernels.h", "fltx_lean.h", "fltx_lane.h", "fltx_rt.h", "fltx_host_trie.cpp",
-            "fltx_arpa.cpp")] + \
+           ("fltx_api.cpp", "fltx_kernels.h", "fltx_lean.h", "fltx_lane.h", "fltx_slane.h", "fltx_rt.h",
+            "fltx_host_trie.cpp", "fltx_arpa.cpp", "fltx_group.cpp", "fltx_kernel_entry.h")] + \
           [os.path.join(ROOT, "tests", "emu", f) for f in ("hip_emu.h", "hip_emu.cpp")]
     if (not os.path.exists(helpers.EMU_LIB) or
             os.path.getmtime(helpers.EMU_LIB) < max(os.path.getmtime(s) for s in src)):

@@ -131,3 +131,88 @@ def test_decode_batch_binding(gpu_session):
         one = dec.decode(e.ctypes.data, T, N)
         assert [r.score for r in one] == [r.score for r in got]
         assert [r.tokens for r in one] == [r.tokens for r in got]
+
+
+def test_trie_node_tree_is_walkable():
+    """TrieNode.children through get_root() / search(), as Python code over the reference's
+    binding can do (_decoder.cpp:173-186): the tree is materialised from the host trie."""
+    from flashlight.lib.text.decoder import SmearingMode, Trie
+    trie = Trie(6, 0)
+    words = {7: [1, 2], 8: [1, 3], 9: [1, 3, 4], 10: [5]}
+    for label, spelling in words.items():
+        trie.insert(spelling, label, -float(label))
+    trie.smear(SmearingMode.MAX)
+    root = trie.get_root()
+    assert sorted(root.children.keys()) == [1, 5]
+    n1 = root.children[1]
+    assert sorted(n1.children.keys()) == [2, 3] and n1.labels == []
+    assert n1.children[3].labels == [8] and n1.children[3].children[4].labels == [9]
+    assert n1.max_score == -7.0  # smeared maximum of the subtree
+
+    def walk(node, prefix, out):
+        for lab in node.labels:
+            out[lab] = prefix
+        for tok, child in node.children.items():
+            assert child.idx == tok
+            walk(child, prefix + [tok], out)
+        return out
+    assert walk(root, [], {}) == words
+    assert trie.search([1, 3]).children[4].idx == 4
+    trie.insert([5, 5], 11, -0.5)  # a later insert shows up in the next walk
+    assert 5 in trie.get_root().children[5].children
+
+
+@pytest.mark.gpu
+def test_decode_batch_arrays_and_devices(gpu_session):
+    """decode_batch_arrays: NumPy views over the library's pinned buffers + lazily built
+    DecodeResult objects; decode_batch(devices=[0, 0]): two contexts, same results."""
+    from flashlight.lib.text.decoder import CriterionType, LexiconFreeDecoder, LexiconFreeDecoderOptions, ZeroLM
+    from text_amd import synth
+    N, Ts = 29, [40, 7, 25, 0, 33]
+    opts = LexiconFreeDecoderOptions(10, N, 25.0, 0.0, 0.0, False, CriterionType.CTC)
+    dec = LexiconFreeDecoder(opts, ZeroLM(), 0, N - 1, [])
+    embs = [synth.emissions("ctc", 3 + i, T, N) for i, T in enumerate(Ts)]
+    flat = np.concatenate([e.reshape(-1) for e in embs])
+    ref = dec.decode_batch(flat.ctypes.data, Ts, N)
+    two = dec.decode_batch(flat.ctypes.data, Ts, N, devices=[0, 0])
+    for a, b in zip(ref, two):
+        assert [r.score for r in a] == [r.score for r in b] and [r.tokens for r in a] == [r.tokens for r in b]
+        assert [r.emittingModelScore for r in a] == [r.emittingModelScore for r in b]
+    res = dec.decode_batch_arrays(flat.ctypes.data, Ts, N)
+    assert len(res) == len(Ts) and res.words is None
+    assert list(res.n_hyp) == [len(x) for x in ref] and list(res.length) == [T + 2 for T in Ts]
+    for b, want in enumerate(ref):
+        got = res[b]
+        assert [r.score for r in got] == [r.score for r in want]
+        for i, r in enumerate(want):
+            assert res.scores[b, i, 0] == r.score and res.scores[b, i, 1] == r.emittingModelScore
+            assert list(res.tokens_of(b, i)) == r.tokens
+            L = res.length[b]
+            assert list(res.tokens[res.offsets[b] + i * L: res.offsets[b] + (i + 1) * L]) == r.tokens
+
+
+@pytest.mark.gpu
+def test_streaming_through_the_facade_at_a_big_beam(gpu_session):
+    """decode_begin / decode_step / decode_end with beam 500 (the stream's frame budget follows
+    the beam: 2^15 frames would not be indexable) equals decode() of the same utterance."""
+    from flashlight.lib.text.decoder import CriterionType, LexiconFreeDecoder, LexiconFreeDecoderOptions, ZeroLM
+    from text_amd import synth
+    N, T = 29, 90
+    opts = LexiconFreeDecoderOptions(500, N, 25.0, 0.0, 0.0, False, CriterionType.CTC)
+    dec = LexiconFreeDecoder(opts, ZeroLM(), 0, N - 1, [])
+    e = synth.emissions("ctc", 11, T, N)
+    one = dec.decode(e.ctypes.data, T, N)
+    dec.decode_begin()
+    for k in range(0, T, 30):
+        chunk = np.ascontiguousarray(e[k:k + 30])
+        dec.decode_step(chunk.ctypes.data, 30, N)
+    dec.decode_end()
+    got = dec.get_all_final_hypothesis()
+    assert [r.score for r in got] == [r.score for r in one]
+    assert [r.tokens for r in got] == [r.tokens for r in one]
+    dec.set_max_stream_frames(64)
+    dec.decode_begin()
+    with pytest.raises(IndexError):
+        for k in range(0, T, 30):
+            chunk = np.ascontiguousarray(e[k:k + 30])
+            dec.decode_step(chunk.ctypes.data, 30, N)

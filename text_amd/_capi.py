@@ -56,6 +56,8 @@ class Lib:
         "fltx_result_best", "fltx_result_device", "fltx_decoder_stats",
         "fltx_decoder_set", "fltx_decoder_get", "fltx_decoder_timing", "fltx_decoder_profile", "fltx_htrie_create", "fltx_htrie_destroy", "fltx_htrie_insert",
         "fltx_htrie_search", "fltx_htrie_smear", "fltx_htrie_num_nodes", "fltx_htrie_upload",
+        "fltx_decoder_bytes", "fltx_htrie_node", "fltx_group_create", "fltx_group_destroy", "fltx_group_size", "fltx_group_decoder",
+        "fltx_group_decode_batch", "fltx_group_result_count", "fltx_group_result_fetch", "fltx_group_synchronize",
     ]
 
     def __init__(self, path=None):
@@ -111,6 +113,16 @@ class Lib:
             "fltx_htrie_smear": [vp, i32],
             "fltx_htrie_num_nodes": [vp, vp],
             "fltx_htrie_upload": [vp, vp, pvp],
+            "fltx_decoder_bytes": [vp, vp, vp, vp],
+            "fltx_htrie_node": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32],
+            "fltx_group_create": [vp, i32, i32, C.POINTER(Options), vp, vp, i32, i32, i32, vp, i32, i32, pvp],
+            "fltx_group_destroy": [vp],
+            "fltx_group_size": [vp, vp],
+            "fltx_group_decoder": [vp, i32, pvp, vp, vp],
+            "fltx_group_decode_batch": [vp, vp, vp, vp, vp, i32, i32],
+            "fltx_group_result_count": [vp, i32, vp, vp],
+            "fltx_group_result_fetch": [vp, i32, i32, vp, vp, vp, vp],
+            "fltx_group_synchronize": [vp],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -437,10 +449,12 @@ class BatchDecoder:
         self.L.check(self.L.lib.fltx_result_fetch_batch(self.h, *[C.byref(p) for p in ptrs]))
         return [p.value for p in ptrs]
 
-    def results_batch(self, max_hyp=None):
-        """n-best of every utterance of the last decode_batch: one transfer per
-        array into pinned host memory, then NumPy views (no per-hypothesis copies;
-        the views stay valid until the next decode)."""
+    def results_arrays(self):
+        """n-best of every utterance of the last decode_batch as NumPy arrays over the
+        decoder's pinned host buffers (one transfer per array; valid until the next decode):
+        n_hyp [B], length [B], scores [B, K, 3] (score, emitting-model score, LM score),
+        tokens / words: flat int32 with offsets [B + 1] -- hypothesis i of utterance b is
+        tokens[offsets[b] + i * length[b] : offsets[b] + (i + 1) * length[b]]."""
         pn, pl, ps, pt, pw, po = (C.c_void_p() for _ in range(6))
         self.L.check(self.L.lib.fltx_result_fetch_batch(self.h, C.byref(pn), C.byref(pl), C.byref(ps), C.byref(pt),
                                                         C.byref(pw), C.byref(po)))
@@ -448,16 +462,21 @@ class BatchDecoder:
 
         def view(ptr, ctype, n):
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
-        nh = view(pn, C.c_int32, B)
-        ln = view(pl, C.c_int32, B)
         off = view(po, C.c_int64, B + 1)
         total = int(off[B])
         K = int(self.options.beam_size)
-        sc = view(ps, C.c_double, B * K * 3).reshape(B, K, 3)
-        tok = view(pt, C.c_int32, max(total, 1))
-        wrd = view(pw, C.c_int32, max(total, 1)) if pw.value else None
+        return {"n_hyp": view(pn, C.c_int32, B), "length": view(pl, C.c_int32, B), "offsets": off,
+                "scores": view(ps, C.c_double, B * K * 3).reshape(B, K, 3),
+                "tokens": view(pt, C.c_int32, max(total, 1)),
+                "words": view(pw, C.c_int32, max(total, 1)) if pw.value else None}
+
+    def results_batch(self, max_hyp=None):
+        """[[Hyp]] for every utterance: Python objects over the arrays of results_arrays()
+        (token rows are views, not copies)."""
+        r = self.results_arrays()
+        nh, ln, off, sc, tok, wrd = r["n_hyp"], r["length"], r["offsets"], r["scores"], r["tokens"], r["words"]
         out = []
-        for b in range(B):
+        for b in range(self.B):
             n = int(nh[b]) if max_hyp is None else min(int(nh[b]), max_hyp)
             L = int(ln[b])
             tb = tok[off[b]:off[b] + n * L].reshape(n, L)
@@ -489,6 +508,12 @@ class BatchDecoder:
         return {"frames": fr.value, "algorithmic_bytes": by.value, "threads_per_utt": th.value,
                 "lds_bytes": lds.value}
 
+    def bytes(self):
+        """Algorithmic bytes of the last offline decode, split by kernel."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self.L.check(self.L.lib.fltx_decoder_bytes(self.h, C.addressof(a), C.addressof(b), C.addressof(c)))
+        return {"decode": a.value, "epilogue": b.value, "lm": c.value}
+
     def profile(self):
         out = np.zeros(8, dtype=np.uint64)
         self.L.check(self.L.lib.fltx_decoder_profile(self.h, _ptr(out)))
@@ -502,6 +527,86 @@ class BatchDecoder:
     def close(self):
         if self.h:
             self.L.lib.fltx_decoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DecoderGroup:
+    """fltx_group: one batch sharded over several devices (one context, decoder
+    and host thread per entry of `devices`; no inter-device traffic)."""
+
+    def __init__(self, devices, kind, options, lm, sil, blank, unk=-1, host_trie=None, transitions=None,
+                 is_lm_token=False, lib=None):
+        self.L = lib or lm.L
+        self.options = options
+        self._keep = (lm, host_trie)
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        tr = None if transitions is None or len(transitions) == 0 else \
+            np.ascontiguousarray(transitions, dtype=np.float32)
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_group_create(
+            _ptr(dv), len(dv), kind, C.byref(options), host_trie.h if host_trie is not None else None, lm.h,
+            sil, blank, unk, _ptr(tr), 0 if tr is None else tr.size, int(is_lm_token), C.byref(h)))
+        self.h = h
+        self.n = len(dv)
+        self.B = 0
+
+    def decode_batch(self, emissions, T, N, offsets=None, device_ptrs=None):
+        """emissions: one host float32 array for the whole batch, or device_ptrs =
+        one HBM address per device (the part's shard, addressed by `offsets`)."""
+        T = np.ascontiguousarray(T, dtype=np.int32)
+        B = len(T)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.int64)
+        ptrs = (C.c_void_p * self.n)()
+        ond = np.zeros(self.n, dtype=np.int32)
+        if device_ptrs is not None:
+            for i, p in enumerate(device_ptrs):
+                ptrs[i] = p
+            ond[:] = 1
+        else:
+            self._e = np.ascontiguousarray(emissions, dtype=np.float32)
+            for i in range(self.n):
+                ptrs[i] = self._e.ctypes.data
+        self.L.check(self.L.lib.fltx_group_decode_batch(self.h, ptrs, _ptr(ond), _ptr(off), _ptr(T), B, N))
+        self.B = B
+
+    def parts(self):
+        """[(BatchDecoder-like handle, first, count)] of the last batch."""
+        out = []
+        for i in range(self.n):
+            d, f, c = C.c_void_p(), C.c_int32(0), C.c_int32(0)
+            self.L.check(self.L.lib.fltx_group_decoder(self.h, i, C.byref(d), C.addressof(f), C.addressof(c)))
+            out.append((d, f.value, c.value))
+        return out
+
+    def results(self, b, max_hyp=None):
+        n, ln = C.c_int32(0), C.c_int32(0)
+        self.L.check(self.L.lib.fltx_group_result_count(self.h, b, C.addressof(n), C.addressof(ln)))
+        n, ln = n.value, ln.value
+        if max_hyp is not None:
+            n = min(n, max_hyp)
+        if n == 0:
+            return []
+        scores = np.zeros(3 * n, dtype=np.float64)
+        tokens = np.zeros((n, ln), dtype=np.int32)
+        words = np.zeros((n, ln), dtype=np.int32)
+        got = C.c_int32(0)
+        self.L.check(self.L.lib.fltx_group_result_fetch(self.h, b, n, _ptr(scores), _ptr(tokens), _ptr(words),
+                                                        C.addressof(got)))
+        return [Hyp(scores[3 * i], scores[3 * i + 1], scores[3 * i + 2], tokens[i].copy(), words[i].copy())
+                for i in range(n)]
+
+    def synchronize(self):
+        self.L.check(self.L.lib.fltx_group_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.lib.fltx_group_destroy(self.h)
             self.h = None
 
     def __del__(self):

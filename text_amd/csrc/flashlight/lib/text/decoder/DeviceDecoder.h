@@ -16,13 +16,35 @@ namespace lib {
 namespace text {
 namespace detail {
 
+/* the n-best of a whole batch where the library put it (pinned host memory, valid until the next
+ * decode on the decoder): hypothesis i of utterance b has scores[(b * K + i) * 3 + {0,1,2}] and the
+ * length[b] tokens at tokens + offsets[b] + i * length[b] (words likewise, null for lexicon-free) */
+struct BatchView {
+  int B = 0, K = 0;
+  const int32_t* nHyp = nullptr;
+  const int32_t* length = nullptr;
+  const double* scores = nullptr;
+  const int32_t* tokens = nullptr;
+  const int32_t* words = nullptr;
+  const int64_t* offsets = nullptr;
+};
+
 class DeviceDecoder {
  public:
-  /* frames a single stream may hold between prune() calls */
+  /* frames a single stream may hold between prune() calls: 2^15, or fewer for big beams -- the
+   * history is sized up front (beam x frames records) and the engines index at most 2^22 / beam
+   * frames; setMaxStreamFrames() overrides */
   static constexpr int kDefaultMaxStreamFrames = 1 << 15;
+  static int defaultMaxStreamFrames(int beamSize) {
+    const long long byBeam = (1ll << 22) / (beamSize > 0 ? beamSize : 1) - 4;
+    return (int)std::max<long long>(64, std::min<long long>(kDefaultMaxStreamFrames, byBeam));
+  }
 
   DeviceDecoder() = default;
   ~DeviceDecoder() {
+    if (group_) {
+      fltx_group_destroy(group_);
+    }
     if (h_) {
       fltx_decoder_destroy(h_);
     }
@@ -31,7 +53,14 @@ class DeviceDecoder {
   DeviceDecoder& operator=(const DeviceDecoder&) = delete;
 
   void create(int kind, const fltx_options& opt, const fltx_trie* trie, const LMPtr& lm, int sil, int blank,
-              int unk, const std::vector<float>& transitions, bool isLmToken) {
+              int unk, const std::vector<float>& transitions, bool isLmToken, fltx_htrie* hostTrie = nullptr) {
+    kind_ = kind;
+    opt_ = opt;
+    lmKeep_ = lm;
+    unk_ = unk;
+    transitions_ = transitions;
+    isLmToken_ = isLmToken;
+    hostTrie_ = hostTrie;
     if (!lm || !lm->deviceHandle()) {
       throw std::runtime_error(
           "[decoder] this LM has no device tables (ZeroLM and KenLM/ARPA are supported); "
@@ -40,11 +69,11 @@ class DeviceDecoder {
     check(fltx_decoder_create(ctx_->h, kind, &opt, trie, lm->deviceHandle(), sil, blank, unk,
                               transitions.empty() ? nullptr : transitions.data(), (int32_t)transitions.size(),
                               isLmToken ? 1 : 0, &h_));
-    check(fltx_decoder_set(h_, "keep_scores", 1));
     sil_ = sil;
     blank_ = blank;
     nTrans_ = (int)transitions.size();
     beamSize_ = opt.beam_size;
+    maxFrames_ = defaultMaxStreamFrames(opt.beam_size);
   }
 
   fltx_ctx* ctx() const { return ctx_->h; }
@@ -69,41 +98,88 @@ class DeviceDecoder {
   std::vector<DecodeResult> decodeOne(const float* emissions, int T, int N) {
     const int64_t off = 0;
     const int32_t t32 = T;
+    /* getBestHypothesis(lookBack) after decode() reports an ancestor's scores (Utils.h:236-238):
+     * the single-utterance call keeps the per-frame score history, the batched one does not */
+    check(fltx_decoder_set(h_, "keep_scores", 1));
     check(fltx_decode_batch(h_, emissions, 0, &off, &t32, 1, N));
     open_ = true;
     pendingBegin_ = false;
     return results(0);
   }
 
-  std::vector<std::vector<DecodeResult>> decodeBatch(const float* emissions, const std::vector<int64_t>& offsets,
-                                                     const std::vector<int>& T, int N, bool onDevice) {
+  /* decode the batch and leave the n-best as arrays (no per-hypothesis objects) */
+  BatchView decodeBatchView(const float* emissions, const std::vector<int64_t>& offsets, const std::vector<int>& T,
+                            int N, bool onDevice) {
     std::vector<int32_t> t32(T.begin(), T.end());
+    check(fltx_decoder_set(h_, "keep_scores", 0));
     check(fltx_decode_batch(h_, emissions, onDevice ? 1 : 0, offsets.empty() ? nullptr : offsets.data(),
                             t32.data(), (int32_t)t32.size(), N));
     open_ = true;
     pendingBegin_ = false;
     /* the whole n-best crosses PCIe once (pinned staging inside the library) */
-    const int32_t *nHyp = nullptr, *len = nullptr, *tok = nullptr, *wrd = nullptr;
-    const double* sc = nullptr;
-    const int64_t* off = nullptr;
-    check(fltx_result_fetch_batch(h_, &nHyp, &len, &sc, &tok, &wrd, &off));
+    BatchView v;
+    v.B = (int)T.size();
+    v.K = beamSize_;
+    check(fltx_result_fetch_batch(h_, &v.nHyp, &v.length, &v.scores, &v.tokens, &v.words, &v.offsets));
+    return v;
+  }
+
+  /* DecodeResult objects of utterance b of a view */
+  std::vector<DecodeResult> materialise(const BatchView& v, int b) const {
+    std::vector<DecodeResult> out;
+    fill(out, b, v.nHyp, v.length, v.scores, v.tokens, v.words, v.offsets);
+    return out;
+  }
+
+  std::vector<std::vector<DecodeResult>> decodeBatch(const float* emissions, const std::vector<int64_t>& offsets,
+                                                     const std::vector<int>& T, int N, bool onDevice) {
+    const BatchView v = decodeBatchView(emissions, offsets, T, N, onDevice);
     std::vector<std::vector<DecodeResult>> out(T.size());
     for (size_t b = 0; b < T.size(); ++b) {
-      const int n = nHyp[b], L = len[b];
-      out[b].reserve((size_t)n);
-      for (int i = 0; i < n; ++i) {
-        DecodeResult r(L);
-        const double* s3 = sc + ((size_t)b * beamSize_ + (size_t)i) * 3;
-        r.score = s3[0];
-        r.emittingModelScore = s3[1];
-        r.lmScore = s3[2];
-        const int32_t* tp = tok + off[b] + (int64_t)i * L;
-        std::copy(tp, tp + L, r.tokens.begin());
-        if (wrd) {
-          const int32_t* wp = wrd + off[b] + (int64_t)i * L;
-          std::copy(wp, wp + L, r.words.begin());
-        } /* else: DecodeResult(L) leaves words at -1 (LexiconFreeDecoder.h:80-82) */
-        out[b].push_back(std::move(r));
+      fill(out[b], (int)b, v.nHyp, v.length, v.scores, v.tokens, v.words, v.offsets);
+    }
+    return out;
+  }
+
+  /* The same batch over several devices: one context, decoder and host
+   * thread per entry of `devices` (an index may repeat), trie and LM tables replicated, the
+   * utterances cut into contiguous shards of about equal frame count, results in input order.
+   * `emissions` is host memory. */
+  std::vector<std::vector<DecodeResult>> decodeBatchOn(const std::vector<int>& devices, const float* emissions,
+                                                       const std::vector<int64_t>& offsets,
+                                                       const std::vector<int>& T, int N) {
+    if (devices.empty()) {
+      throw std::invalid_argument("[decoder] decodeBatch: empty device list");
+    }
+    if (!group_ || devices != groupDevices_) {
+      if (group_) {
+        fltx_group_destroy(group_);
+        group_ = nullptr;
+      }
+      std::vector<int32_t> dv(devices.begin(), devices.end());
+      check(fltx_group_create(dv.data(), (int32_t)dv.size(), kind_, &opt_, hostTrie_, lmKeep_->deviceHandle(), sil_,
+                              blank_, unk_, transitions_.empty() ? nullptr : transitions_.data(),
+                              (int32_t)transitions_.size(), isLmToken_ ? 1 : 0, &group_));
+      groupDevices_ = devices;
+    }
+    std::vector<int32_t> t32(T.begin(), T.end());
+    std::vector<const float*> ptrs(devices.size(), emissions);
+    check(fltx_group_decode_batch(group_, ptrs.data(), nullptr, offsets.empty() ? nullptr : offsets.data(),
+                                  t32.data(), (int32_t)t32.size(), N));
+    std::vector<std::vector<DecodeResult>> out(T.size());
+    for (size_t i = 0; i < devices.size(); ++i) {
+      fltx_decoder* part = nullptr;
+      int32_t first = 0, count = 0;
+      check(fltx_group_decoder(group_, (int32_t)i, &part, &first, &count));
+      if (count == 0) {
+        continue;
+      }
+      const int32_t *nHyp = nullptr, *len = nullptr, *tok = nullptr, *wrd = nullptr;
+      const double* sc = nullptr;
+      const int64_t* off = nullptr;
+      check(fltx_result_fetch_batch(part, &nHyp, &len, &sc, &tok, &wrd, &off));
+      for (int k = 0; k < count; ++k) {
+        fill(out[(size_t)(first + k)], k, nHyp, len, sc, tok, wrd, off);
       }
     }
     return out;
@@ -185,7 +261,35 @@ class DeviceDecoder {
   void setMaxStreamFrames(int n) { maxFrames_ = n; }
 
  private:
+  /* n-best of utterance b of a fetched batch -> DecodeResult objects */
+  void fill(std::vector<DecodeResult>& dst, int b, const int32_t* nHyp, const int32_t* len, const double* sc,
+            const int32_t* tok, const int32_t* wrd, const int64_t* off) const {
+    const int n = nHyp[b], L = len[b];
+    dst.reserve((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      DecodeResult r(L);
+      const double* s3 = sc + ((size_t)b * beamSize_ + (size_t)i) * 3;
+      r.score = s3[0];
+      r.emittingModelScore = s3[1];
+      r.lmScore = s3[2];
+      const int32_t* tp = tok + off[b] + (int64_t)i * L;
+      std::copy(tp, tp + L, r.tokens.begin());
+      if (wrd) {
+        const int32_t* wp = wrd + off[b] + (int64_t)i * L;
+        std::copy(wp, wp + L, r.words.begin());
+      } /* else: DecodeResult(L) leaves words at -1 (LexiconFreeDecoder.h:80-82) */
+      dst.push_back(std::move(r));
+    }
+  }
   int beamSize_ = 0;
+  int kind_ = 0, unk_ = -1;
+  fltx_options opt_{};
+  LMPtr lmKeep_;
+  std::vector<float> transitions_;
+  bool isLmToken_ = false;
+  fltx_htrie* hostTrie_ = nullptr;
+  fltx_group* group_ = nullptr;
+  std::vector<int> groupDevices_;
   int guessN() const {
     if (nTrans_ > 0) {
       int n = 1;

@@ -39,8 +39,9 @@ class FL_TEXT_API LexiconDecoder : public Decoder {
     }
     fltx_options o{opt_.beamSize, opt_.beamSizeToken, opt_.beamThreshold, opt_.lmWeight, opt_.wordScore,
                    opt_.unkScore, opt_.silScore, opt_.logAdd ? 1 : 0, (int32_t)opt_.criterionType};
-    dev_.create(FLTX_DECODER_LEXICON, o, lexicon_->deviceHandle(dev_.ctx()), lm_, sil_, blank_, unk_,
-                transitions_, isLmToken_);
+    devTrie_ = lexicon_->deviceHandle(dev_.ctx()); /* this decoder's reference keeps the upload alive */
+    dev_.create(FLTX_DECODER_LEXICON, o, devTrie_.get(), lm_, sil_, blank_, unk_, transitions_, isLmToken_,
+                lexicon_->hostHandle());
   }
 
   void decodeBegin() override { dev_.begin(); }
@@ -67,8 +68,34 @@ class FL_TEXT_API LexiconDecoder : public Decoder {
     }
     return dev_.decodeBatch(emissions, o, T, N, onDevice);
   }
+  /* additive: the same, leaving the n-best as arrays in pinned host memory (valid until the next
+   * decode); materialise(view, b) builds the DecodeResult objects of one utterance on demand */
+  detail::BatchView decodeBatchView(const float* emissions, const std::vector<int>& T, int N,
+                                    const std::vector<int64_t>& offsets = {}, bool onDevice = false) {
+    return dev_.decodeBatchView(emissions, packedOffsets(offsets, T, N), T, N, onDevice);
+  }
+  std::vector<DecodeResult> materialise(const detail::BatchView& v, int b) const { return dev_.materialise(v, b); }
+  /* additive: frames one stream may buffer between prune() calls (decodeStep path) */
+  void setMaxStreamFrames(int n) { dev_.setMaxStreamFrames(n); }
+  /* additive: the batch sharded over `devices` (one host thread + stream per device, results in
+   * input order) */
+  std::vector<std::vector<DecodeResult>> decodeBatch(const float* emissions, const std::vector<int>& T, int N,
+                                                     const std::vector<int>& devices,
+                                                     const std::vector<int64_t>& offsets = {}) {
+    return dev_.decodeBatchOn(devices, emissions, offsets, T, N);
+  }
 
  protected:
+  static std::vector<int64_t> packedOffsets(const std::vector<int64_t>& offsets, const std::vector<int>& T, int N) {
+    if (!offsets.empty()) {
+      return offsets;
+    }
+    std::vector<int64_t> o(T.size(), 0);
+    for (size_t b = 1; b < T.size(); ++b) {
+      o[b] = o[b - 1] + (int64_t)T[b - 1] * N;
+    }
+    return o;
+  }
   LexiconDecoderOptions opt_;
   TriePtr lexicon_;
   LMPtr lm_;
@@ -77,6 +104,7 @@ class FL_TEXT_API LexiconDecoder : public Decoder {
   int unk_;
   std::vector<float> transitions_;
   bool isLmToken_;
+  std::shared_ptr<const fltx_trie> devTrie_;
   detail::DeviceDecoder dev_;
 };
 

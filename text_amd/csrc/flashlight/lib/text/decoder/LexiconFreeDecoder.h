@@ -60,6 +60,22 @@ class FL_TEXT_API LexiconFreeDecoder : public Decoder {
                                                      bool onDevice = false) {
     return dev_.decodeBatch(emissions, packed(offsets, T, N), T, N, onDevice);
   }
+  /* additive: the same, leaving the n-best as arrays in pinned host memory (valid until the next
+   * decode); materialise(view, b) builds the DecodeResult objects of one utterance on demand */
+  detail::BatchView decodeBatchView(const float* emissions, const std::vector<int>& T, int N,
+                                    const std::vector<int64_t>& offsets = {}, bool onDevice = false) {
+    return dev_.decodeBatchView(emissions, packed(offsets, T, N), T, N, onDevice);
+  }
+  std::vector<DecodeResult> materialise(const detail::BatchView& v, int b) const { return dev_.materialise(v, b); }
+  /* additive: frames one stream may buffer between prune() calls (decodeStep path) */
+  void setMaxStreamFrames(int n) { dev_.setMaxStreamFrames(n); }
+  /* additive: the batch sharded over `devices` (one host thread + stream per device, results in
+   * input order) */
+  std::vector<std::vector<DecodeResult>> decodeBatch(const float* emissions, const std::vector<int>& T, int N,
+                                                     const std::vector<int>& devices,
+                                                     const std::vector<int64_t>& offsets = {}) {
+    return dev_.decodeBatchOn(devices, emissions, offsets, T, N);
+  }
 
  protected:
   static std::vector<int64_t> packed(const std::vector<int64_t>& offsets, const std::vector<int>& T, int N) {

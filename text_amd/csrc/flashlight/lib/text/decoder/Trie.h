@@ -2,8 +2,8 @@
  * decoder/Trie.h -- Trie / TrieNode with the reference's interface
  * (flashlight/lib/text/decoder/Trie.h:19-94), backed by the host trie of the C
  * ABI (fltx_htrie_*), which restates Trie.cpp:26-101 and flattens into HBM.
- * insert()/search() return snapshots of the node (idx, labels, scores,
- * maxScore); `children` is not materialised on the host side of the facade.
+ * getRoot()/search() expose the node tree (children, labels, scores, maxScore)
+ * as the reference does; it is materialised from the host trie on first use.
  */
 #pragma once
 #include <memory>
@@ -33,35 +33,30 @@ using TrieNodePtr = std::shared_ptr<TrieNode>;
 
 class FL_TEXT_API Trie {
  public:
-  Trie(int maxChildren, int rootIdx) : root_(std::make_shared<TrieNode>(rootIdx)) {
+  Trie(int maxChildren, int rootIdx) : maxChildren_(maxChildren), root_(std::make_shared<TrieNode>(rootIdx)) {
     detail::check(fltx_htrie_create(maxChildren, rootIdx, &h_));
   }
-  ~Trie() {
-    if (dev_) {
-      fltx_trie_destroy(dev_);
-    }
-    fltx_htrie_destroy(h_);
-  }
+  ~Trie() { fltx_htrie_destroy(h_); }
   Trie(const Trie&) = delete;
   Trie& operator=(const Trie&) = delete;
 
-  const TrieNode* getRoot() const { return root_.get(); }
+  /* the node tree (children, labels, scores, maxScore) as the host trie holds it now; built on
+   * first use after a modification (O(nodes)) and shared with search() */
+  const TrieNode* getRoot() const {
+    materialise();
+    return root_.get();
+  }
 
+  /* returns a snapshot of the node the word ends in (idx, labels, scores, maxScore; children left
+   * empty: building a lexicon must not pay for the node tree -- use search() for that) */
   TrieNodePtr insert(const std::vector<int>& indices, int label, float score) {
     std::vector<int32_t> idx(indices.begin(), indices.end());
     detail::check(fltx_htrie_insert(h_, idx.data(), (int32_t)idx.size(), label, score)); /* out_of_range */
     dirty_ = true;
-    return search(indices);
-  }
-
-  TrieNodePtr search(const std::vector<int>& indices) {
-    std::vector<int32_t> idx(indices.begin(), indices.end());
+    treeStale_ = true;
     int32_t found = 0, n = 0, labels[kTrieMaxLabel];
     float ms = 0, scores[kTrieMaxLabel];
     detail::check(fltx_htrie_search(h_, idx.data(), (int32_t)idx.size(), &found, &ms, &n, labels, scores));
-    if (!found) {
-      return nullptr;
-    }
     auto node = std::make_shared<TrieNode>(indices.empty() ? root_->idx : indices.back());
     node->labels.assign(labels, labels + n);
     node->scores.assign(scores, scores + n);
@@ -69,30 +64,80 @@ class FL_TEXT_API Trie {
     return node;
   }
 
+  TrieNodePtr search(const std::vector<int>& indices) {
+    materialise();
+    TrieNodePtr node = root_;
+    for (int idx : indices) {
+      auto it = node->children.find(idx);
+      if (it == node->children.end()) {
+        return nullptr;
+      }
+      node = it->second;
+    }
+    return node;
+  }
+
   void smear(const SmearingMode smearMode) {
     detail::check(fltx_htrie_smear(h_, (int32_t)smearMode));
     dirty_ = true;
+    treeStale_ = true;
   }
 
-  /* additive: the flattened trie in HBM (uploaded on first use, re-uploaded
-   * after later insert()/smear() calls) */
-  const fltx_trie* deviceHandle(fltx_ctx* ctx) const {
-    if (dirty_ || !dev_) {
-      if (dev_) {
-        fltx_trie_destroy(dev_);
-        dev_ = nullptr;
-      }
-      detail::check(fltx_htrie_upload(h_, ctx, &dev_));
+  /* additive: the host trie behind this object (fltx_group_create replicates it per device) */
+  fltx_htrie* hostHandle() const { return h_; }
+
+  /* additive: the flattened trie in HBM.  Uploaded on first use; insert()/smear() afterwards make
+   * the next call upload a NEW copy -- decoders created earlier keep the one they were built with
+   * (each holds a reference), so a shared Trie stays valid for every decoder. */
+  std::shared_ptr<const fltx_trie> deviceHandle(fltx_ctx* ctx) const {
+    if (dirty_ || !dev_ || devCtx_ != ctx) {
+      fltx_trie* t = nullptr;
+      detail::check(fltx_htrie_upload(h_, ctx, &t));
+      dev_ = std::shared_ptr<const fltx_trie>(t, [](const fltx_trie* p) { fltx_trie_destroy(const_cast<fltx_trie*>(p)); });
+      devCtx_ = ctx;
       dirty_ = false;
     }
     return dev_;
   }
 
  private:
+  void materialise() const {
+    if (!treeStale_) {
+      return;
+    }
+    std::vector<int32_t> toks((size_t)maxChildren_);
+    std::vector<int64_t> ids((size_t)maxChildren_);
+    /* (node id in the host trie, TrieNode to fill) -- iterative: words can be long */
+    std::vector<std::pair<int64_t, TrieNode*>> stack;
+    root_->children.clear();
+    stack.emplace_back(0, root_.get());
+    while (!stack.empty()) {
+      const auto cur = stack.back();
+      stack.pop_back();
+      int32_t tok = 0, nl = 0, nc = 0, labels[kTrieMaxLabel];
+      float ms = 0, scores[kTrieMaxLabel];
+      detail::check(fltx_htrie_node(h_, cur.first, &tok, &ms, &nl, labels, scores, &nc, toks.data(), ids.data(),
+                                    maxChildren_));
+      TrieNode* nd = cur.second;
+      nd->labels.assign(labels, labels + nl);
+      nd->scores.assign(scores, scores + nl);
+      nd->maxScore = ms;
+      for (int i = 0; i < nc; ++i) {
+        auto child = std::make_shared<TrieNode>(toks[(size_t)i]);
+        nd->children[toks[(size_t)i]] = child;
+        stack.emplace_back(ids[(size_t)i], child.get());
+      }
+    }
+    treeStale_ = false;
+  }
+
+  int maxChildren_;
   TrieNodePtr root_;
   fltx_htrie* h_ = nullptr;
-  mutable fltx_trie* dev_ = nullptr;
+  mutable std::shared_ptr<const fltx_trie> dev_;
+  mutable fltx_ctx* devCtx_ = nullptr;
   mutable bool dirty_ = true;
+  mutable bool treeStale_ = true;
 };
 
 using TriePtr = std::shared_ptr<Trie>;

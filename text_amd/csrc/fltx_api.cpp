@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -205,14 +207,29 @@ struct fltx_ctx {
   bool ownStream = false;
 };
 
+/* every entry point that allocates, copies or launches selects its context's device first:
+ * decoders of several devices are driven from several host threads (fltx_group_*) */
+static int useDevice(const fltx_ctx* ctx) {
+#ifndef FLTX_EMU
+  return (ctx && hipSetDevice(ctx->device) != hipSuccess) ? 1 : 0;
+#else
+  (void)ctx;
+  return 0;
+#endif
+}
+
 struct fltx_lm {
   fltx_ctx* ctx = nullptr;
   int kind = 0; /* 0 zero, 1 ngram */
   int order = 0;
   int32_t bos = 0, eos = 0, unk = 0, nUsr = 0;
   uint32_t mask = 0;
-  DBuf tab, backoff, usrToLm;
-  bool uploaded = false;
+  /* device copies of the tables, one set per context (= per device) that has a decoder using this LM */
+  struct Dev {
+    DBuf tab, backoff, usrToLm;
+  };
+  std::mutex devMu;
+  std::unordered_map<fltx_ctx*, std::unique_ptr<Dev>> dev;
   /* host copies for fltx_lm_score_sequence */
   std::vector<NgramSlot> hTab;
   std::vector<float> hBackoff;
@@ -228,6 +245,7 @@ struct fltx_trie {
 
 struct fltx_decoder {
   fltx_ctx* ctx = nullptr;
+  fltx_lm::Dev* lmDev = nullptr; /* this context's copy of the LM tables (null for ZeroLM) */
   int kind = 0;
   fltx_options opt{};
   const fltx_trie* trie = nullptr;
@@ -270,6 +288,7 @@ struct fltx_decoder {
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
+  DBuf scored; /* n-gram LM queries per utterance (accounting) */
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   HBuf hTokens, hWords, hScores; /* fltx_result_fetch_batch */
@@ -277,13 +296,14 @@ struct fltx_decoder {
   int nLaunch = 0;               /* workgroups of the next decode launch (0: all B) */
   std::vector<int32_t> hLen, hNHyp;
   bool hostFetched = false;
-  int keepScores = 0;
+  int keepScores = 0, userKeepScores = 0; /* (streams force the score history on; offline decodes use the caller's choice) */
   int profile = 0, profWave = 0;
   /* host caches of the last results */
   std::vector<int32_t> hN, hFrame, hStatus;
   bool resultsSynced = false;
   bool backtraced = false;
-  int64_t statFrames = 0, statBytes = 0;
+  int64_t statFrames = 0, statBytes = 0, statDecodeBytes = 0, statEpilogueBytes = 0, statLmBytes = 0;
+  bool statsDone = false;
 #ifndef FLTX_EMU
   /* HIP events on the launch stream bracketing the two kernels of the last
    * fltx_decode_batch (bench.py's roofline leg reads them) */
@@ -402,6 +422,14 @@ int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t nNgrams, const in
   if (order < 1 || order > kMaxNgramOrder) {
     return fail(FLTX_ERR_UNSUPPORTED, "n-gram order %d outside 1..%d (FL_TEXT_KENLM_MAX_ORDER)", order,
                 kMaxNgramOrder);
+  }
+  if (nUsr < 0 || (nUsr > 0 && !usrToLm)) {
+    return fail(FLTX_ERR_INVALID, "fltx_lm_ngram_create: usr_to_lm is null for n_usr = %d", nUsr);
+  }
+  for (int32_t u = 0; u < nUsr; ++u) {
+    if (usrToLm[u] < 0) {
+      return fail(FLTX_ERR_INVALID, "fltx_lm_ngram_create: usr_to_lm[%d] = %d is negative", u, usrToLm[u]);
+    }
   }
   /* forward trie of n-grams: node id per n-gram, (context node, word) -> node */
   struct HostNode {
@@ -709,6 +737,9 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
   if (nNodes >= (1ll << 31)) {
     return fail(FLTX_ERR_UNSUPPORTED, "trie too large");
   }
+  if (useDevice(ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (nNodes >= (1ll << 28) || (int64_t)labelOff[nNodes] >= (1ll << 28)) {
     return fail(FLTX_ERR_UNSUPPORTED, "trie too large for the packed edge records");
   }
@@ -786,24 +817,32 @@ int fltx_trie_destroy(fltx_trie* t) {
 }
 
 /* upload the flat n-gram tables to the context's device (once) */
-static int lmEnsureUploaded(fltx_lm* lm, fltx_ctx* ctx) {
-  if (lm->kind == 0 || lm->uploaded) {
+static int lmEnsureUploaded(fltx_lm* lm, fltx_ctx* ctx, fltx_lm::Dev** out) {
+  *out = nullptr;
+  if (lm->kind == 0) {
     return FLTX_OK;
   }
+  std::lock_guard<std::mutex> lock(lm->devMu);
+  auto it = lm->dev.find(ctx);
+  if (it != lm->dev.end()) {
+    *out = it->second.get();
+    return FLTX_OK;
+  }
+  std::unique_ptr<fltx_lm::Dev> dv(new fltx_lm::Dev());
   Stream st = ctx->stream;
   const size_t cap = lm->hTab.size(), nn = lm->hBackoff.size();
-  if (lm->tab.ensure(sizeof(NgramSlot) * cap, st, false) || lm->backoff.ensure(sizeof(float) * nn, st, false) ||
-      lm->usrToLm.ensure(sizeof(int32_t) * std::max<size_t>(1, lm->hUsr.size()), st, false)) {
+  if (dv->tab.ensure(sizeof(NgramSlot) * cap, st, false) || dv->backoff.ensure(sizeof(float) * nn, st, false) ||
+      dv->usrToLm.ensure(sizeof(int32_t) * std::max<size_t>(1, lm->hUsr.size()), st, false)) {
     return fail(FLTX_ERR_OOM, "n-gram tables: device allocation failed");
   }
-  if (devCopyH2D(lm->tab.p, lm->hTab.data(), sizeof(NgramSlot) * cap, st) ||
-      devCopyH2D(lm->backoff.p, lm->hBackoff.data(), sizeof(float) * nn, st) ||
-      (!lm->hUsr.empty() && devCopyH2D(lm->usrToLm.p, lm->hUsr.data(), sizeof(int32_t) * lm->hUsr.size(), st)) ||
+  if (devCopyH2D(dv->tab.p, lm->hTab.data(), sizeof(NgramSlot) * cap, st) ||
+      devCopyH2D(dv->backoff.p, lm->hBackoff.data(), sizeof(float) * nn, st) ||
+      (!lm->hUsr.empty() && devCopyH2D(dv->usrToLm.p, lm->hUsr.data(), sizeof(int32_t) * lm->hUsr.size(), st)) ||
       devSync(st)) {
     return fail(FLTX_ERR_HIP, "n-gram tables: upload failed");
   }
-  lm->ctx = ctx;
-  lm->uploaded = true;
+  *out = dv.get();
+  lm->dev[ctx] = std::move(dv);
   return FLTX_OK;
 }
 
@@ -830,13 +869,21 @@ int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, co
   if (opt->criterion != FLTX_CRITERION_ASG && opt->criterion != FLTX_CRITERION_CTC) {
     return fail(FLTX_ERR_UNSUPPORTED, "criterion %d not supported (ASG, CTC only)", opt->criterion);
   }
+  if (trie && trie->ctx != ctx) {
+    return fail(FLTX_ERR_INVALID, "fltx_decoder_create: the trie was uploaded to another context (device)");
+  }
+  if (useDevice(ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
+  fltx_lm::Dev* lmDev = nullptr;
   {
-    int rcu = lmEnsureUploaded(const_cast<fltx_lm*>(lm), ctx);
+    int rcu = lmEnsureUploaded(const_cast<fltx_lm*>(lm), ctx, &lmDev);
     if (rcu) {
       return rcu;
     }
   }
   auto* d = new fltx_decoder();
+  d->lmDev = lmDev;
   d->ctx = ctx;
   d->kind = kind;
   d->opt = *opt;
@@ -860,6 +907,9 @@ int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, co
 }
 
 int fltx_decoder_destroy(fltx_decoder* d) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (d) {
     devSync(d->ctx->stream);
 #ifndef FLTX_EMU
@@ -921,7 +971,7 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     return FLTX_OK;
   }
   if (!strcmp(key, "keep_scores")) { /* record {score, am, lm} per history slot (getBestHypothesis) */
-    d->keepScores = value != 0;
+    d->keepScores = d->userKeepScores = value != 0;
     return FLTX_OK;
   }
   if (!strcmp(key, "profile_wave")) {
@@ -1301,6 +1351,12 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     rc |= d->uttNextId.ensure(4 * (size_t)B, st, true);
     rc |= d->gMask.ensure(8 * bk, st, false);
   }
+  if (d->lm->kind == 1) {
+    rc |= d->scored.ensure(4 * (size_t)B, st, false);
+    if (!rc) {
+      devMemset(d->scored.p, 0, 4 * (size_t)B, st);
+    }
+  }
   if (rc) {
     return fail(FLTX_ERR_OOM, "device allocation failed (B=%d K=%d T<=%d)", B, K, maxT);
   }
@@ -1336,10 +1392,10 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   }
   P.lmKind = d->lm->kind;
   P.lmOrder = d->lm->order;
-  P.ngTab = d->lm->tab.as<NgramSlot>();
+  P.ngTab = d->lmDev ? d->lmDev->tab.as<NgramSlot>() : nullptr;
   P.ngMask = d->lm->mask;
-  P.ngBackoff = d->lm->backoff.as<float>();
-  P.usrToLm = d->lm->usrToLm.as<int32_t>();
+  P.ngBackoff = d->lmDev ? d->lmDev->backoff.as<float>() : nullptr;
+  P.usrToLm = d->lmDev ? d->lmDev->usrToLm.as<int32_t>() : nullptr;
   P.nUsr = d->lm->nUsr;
   P.lmBos = d->lm->bos;
   P.lmEos = d->lm->eos;
@@ -1387,6 +1443,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.uttNextId = d->uttNextId.as<int32_t>();
   P.gMask = d->gMask.as<unsigned long long>();
   P.prof = nullptr;
+  P.scored = (d->lm->kind == 1 && d->scored.p) ? d->scored.as<uint32_t>() : nullptr;
   P.profThread = 64 * d->profWave;
   if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {
     devMemset(d->prof.p, 0, 8 * 8 * (size_t)d->B, d->ctx->stream);
@@ -1697,22 +1754,43 @@ int launchBacktrace(fltx_decoder* d) {
   return FLTX_OK;
 }
 
-void accountBytes(fltx_decoder* d, const int32_t* T) {
-  /* B_frame = 4N + 8K (+ 4*K*Kt + 8K + 4K for the
-   * lexicon decoder), epilogue 16 * H * (T + 2) with H = K as the bound */
+/* SURVEY.md section 8(d), per utterance: decode phase = T x (4N + 8K (+ 4*K*Kt + 8K + 4K for the
+ * lexicon decoder)) + 16 * order per n-gram LM query the kernel issued; epilogue = 16 * H * (T + 2)
+ * for the H hypotheses actually returned.  Needs the result counts: evaluated when asked for. */
+int accountBytes(fltx_decoder* d) {
+  if (d->statsDone) {
+    return FLTX_OK;
+  }
   const int64_t K = d->opt.beam_size, N = d->N;
   const int64_t Kt = std::min<int64_t>(d->opt.beam_size_token, N);
-  int64_t frames = 0, bytes = 0;
+  int rc = syncResults(d);
+  if (rc) {
+    return rc;
+  }
+  std::vector<uint32_t> scored(d->B, 0u);
+  if (d->lm->kind == 1 && d->scored.p &&
+      devCopyD2H(scored.data(), d->scored.p, 4 * (size_t)d->B, d->ctx->stream)) {
+    return fail(FLTX_ERR_HIP, "counter copy failed");
+  }
+  int64_t frames = 0, dec = 0, epi = 0, lm = 0;
   for (int b = 0; b < d->B; ++b) {
-    frames += T[b];
+    const int64_t T = d->T[b];
+    frames += T;
     int64_t per = 4 * N + 8 * K;
     if (d->kind == FLTX_DECODER_LEXICON) {
       per += 4 * K * Kt + 8 * K + 4 * K;
     }
-    bytes += per * T[b] + 16 * K * (T[b] + 2);
+    dec += per * T;
+    lm += 16 * (int64_t)d->lm->order * (int64_t)scored[b];
+    epi += 16 * (int64_t)d->hN[b] * (T + 2);
   }
   d->statFrames = frames;
-  d->statBytes = bytes;
+  d->statDecodeBytes = dec + lm;
+  d->statLmBytes = lm;
+  d->statEpilogueBytes = epi;
+  d->statBytes = dec + lm + epi;
+  d->statsDone = true;
+  return FLTX_OK;
 }
 
 } // namespace
@@ -1721,6 +1799,9 @@ extern "C" {
 
 int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice, const int64_t* offsets,
                       const int32_t* T, int32_t B, int32_t N) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || !T || B <= 0 || N <= 0) {
     return fail(FLTX_ERR_INVALID, "fltx_decode_batch: bad argument");
   }
@@ -1742,6 +1823,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
   const int savedNoSlane = d->noSlane;
   d->offlineCall = true;
+  d->keepScores = d->userKeepScores; /* a stream on this decoder had switched the score history on */
   for (int attempt = 0; attempt < 3; ++attempt) {
     const bool finalForm = attempt > 0 && !recomputeRetry; /* the general path: nothing left to fall back to */
     int rc = prepare(d, B, N, T, finalForm);
@@ -1834,13 +1916,16 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     return rc;
   }
   d->T.assign(T, T + B);
-  accountBytes(d, T);
+  d->statsDone = false;
   d->haveResults = true;
   d->ended = true;
   return FLTX_OK;
 }
 
 int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || B <= 0 || N <= 0 || maxFrames < 0) {
     return fail(FLTX_ERR_INVALID, "fltx_stream_begin: bad argument");
   }
@@ -1879,6 +1964,9 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
 
 int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, const int64_t* offsets,
                      const int32_t* T) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || !T) {
     return fail(FLTX_ERR_INVALID, "fltx_stream_step: bad argument");
   }
@@ -1912,6 +2000,9 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
 }
 
 int fltx_stream_end(fltx_decoder* d) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d) {
     return fail(FLTX_ERR_INVALID, "null decoder");
   }
@@ -1967,6 +2058,9 @@ static int launchStreamOp(fltx_decoder* d, int op, int lookBack, int cap) {
 }
 
 int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || lookBack < 0) {
     return fail(FLTX_ERR_INVALID, "fltx_stream_prune: bad argument");
   }
@@ -2018,6 +2112,9 @@ static int checkStatus(fltx_decoder* d, int b) {
 }
 
 int fltx_result_count(fltx_decoder* d, int32_t b, int32_t* nHyp, int32_t* length) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || b < 0 || b >= d->B) {
     return fail(FLTX_ERR_INVALID, "fltx_result_count: bad argument");
   }
@@ -2105,6 +2202,9 @@ int fltx_result_fetch(fltx_decoder* d, int32_t b, int32_t maxHyp, double* scores
 
 int fltx_result_fetch_batch(fltx_decoder* d, const int32_t** nHyp, const int32_t** length, const double** scores,
                             const int32_t** tokens, const int32_t** words, const int64_t** offsets) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d) {
     return fail(FLTX_ERR_INVALID, "fltx_result_fetch_batch: null decoder");
   }
@@ -2168,6 +2268,9 @@ int fltx_result_fetch_batch(fltx_decoder* d, const int32_t** nHyp, const int32_t
 
 int fltx_result_best(fltx_decoder* d, int32_t b, int32_t lookBack, double* scores, int32_t* tokens,
                      int32_t* words, int32_t capacity, int32_t* length) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || b < 0 || b >= d->B || lookBack < 0 || !length) {
     return fail(FLTX_ERR_INVALID, "fltx_result_best: bad argument");
   }
@@ -2230,6 +2333,9 @@ int fltx_result_best(fltx_decoder* d, int32_t b, int32_t lookBack, double* score
 
 int fltx_result_device(fltx_decoder* d, const int32_t** nHyp, const double** scores,
                        const int32_t** tokens, const int32_t** words, const int64_t** tokOff) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || !d->haveResults) {
     return fail(FLTX_ERR_STATE, "no decode has been run");
   }
@@ -2261,6 +2367,9 @@ int fltx_result_device(fltx_decoder* d, const int32_t** nHyp, const double** sco
  * utterances of the batch (0 prep, 1 generate, 2 fold, 3 select, 4 build,
  * 5 row hand-over) */
 int fltx_decoder_profile(fltx_decoder* d, uint64_t* out) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || !out) {
     return fail(FLTX_ERR_INVALID, "null argument");
   }
@@ -2281,6 +2390,9 @@ int fltx_decoder_profile(fltx_decoder* d, uint64_t* out) {
 }
 
 int fltx_decoder_timing(fltx_decoder* d, float* decodeMs, float* backtraceMs) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d) {
     return fail(FLTX_ERR_INVALID, "null decoder");
   }
@@ -2312,8 +2424,17 @@ int fltx_decoder_timing(fltx_decoder* d, float* decodeMs, float* backtraceMs) {
 
 int fltx_decoder_stats(fltx_decoder* d, int64_t* frames, int64_t* bytes, int32_t* threads,
                        int32_t* ldsBytes) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d) {
     return fail(FLTX_ERR_INVALID, "null decoder");
+  }
+  if (d->haveResults && d->ended && !d->streaming) {
+    int rc = accountBytes(d);
+    if (rc) {
+      return rc;
+    }
   }
   if (frames) {
     *frames = d->statFrames;
@@ -2326,6 +2447,32 @@ int fltx_decoder_stats(fltx_decoder* d, int64_t* frames, int64_t* bytes, int32_t
   }
   if (ldsBytes) {
     *ldsBytes = d->wsInLds ? (int32_t)d->wsBytes : 0;
+  }
+  return FLTX_OK;
+}
+
+int fltx_decoder_bytes(fltx_decoder* d, int64_t* decodeBytes, int64_t* epilogueBytes, int64_t* lmBytes) {
+  if (d && useDevice(d->ctx)) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
+  if (!d) {
+    return fail(FLTX_ERR_INVALID, "null decoder");
+  }
+  if (!d->haveResults || !d->ended || d->streaming) {
+    return fail(FLTX_ERR_STATE, "fltx_decoder_bytes: no finished offline decode");
+  }
+  int rc = accountBytes(d);
+  if (rc) {
+    return rc;
+  }
+  if (decodeBytes) {
+    *decodeBytes = d->statDecodeBytes;
+  }
+  if (epilogueBytes) {
+    *epilogueBytes = d->statEpilogueBytes;
+  }
+  if (lmBytes) {
+    *lmBytes = d->statLmBytes;
   }
   return FLTX_OK;
 }

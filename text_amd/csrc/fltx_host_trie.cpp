@@ -166,6 +166,54 @@ int fltx_htrie_num_nodes(fltx_htrie* t, int64_t* n) {
   return FLTX_OK;
 }
 
+int fltx_htrie_node(fltx_htrie* t, int64_t node, int32_t* token, float* maxScore, int32_t* nLabels,
+                    int32_t* labels, float* scores, int32_t* nChildren, int32_t* childTokens,
+                    int64_t* childNodes, int32_t childCapacity) {
+  if (!t) {
+    return fltx_set_error_(FLTX_ERR_INVALID, "fltx_htrie_node: null trie");
+  }
+  if (node < 0 || node >= (int64_t)t->nodes.size()) {
+    return fltx_set_error_(FLTX_ERR_RANGE, "fltx_htrie_node: node out of range");
+  }
+  const HNode& nd = t->nodes[(size_t)node];
+  if (token) {
+    *token = nd.token;
+  }
+  if (maxScore) {
+    *maxScore = nd.maxScore;
+  }
+  if (nLabels) {
+    *nLabels = (int32_t)nd.labels.size();
+  }
+  for (size_t i = 0; i < nd.labels.size(); ++i) {
+    if (labels) {
+      labels[i] = nd.labels[i];
+    }
+    if (scores) {
+      scores[i] = nd.scores[i];
+    }
+  }
+  if (nChildren) {
+    *nChildren = (int32_t)nd.kids.size();
+  }
+  if (childTokens || childNodes) {
+    if ((int32_t)nd.kids.size() > childCapacity) {
+      return fltx_set_error_(FLTX_ERR_RANGE, "fltx_htrie_node: child_capacity too small");
+    }
+    int32_t i = 0;
+    for (const auto& kv : nd.kids) {
+      if (childTokens) {
+        childTokens[i] = kv.first;
+      }
+      if (childNodes) {
+        childNodes[i] = kv.second;
+      }
+      ++i;
+    }
+  }
+  return FLTX_OK;
+}
+
 int fltx_htrie_upload(fltx_htrie* t, fltx_ctx* ctx, fltx_trie** out) {
   if (!t || !ctx || !out) {
     return fltx_set_error_(FLTX_ERR_INVALID, "fltx_htrie_upload: null argument");

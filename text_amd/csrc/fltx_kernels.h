@@ -169,6 +169,7 @@ struct DecodeParams {
   int64_t idCap;
   int32_t* uttNextId;
   unsigned long long* gMask;    /* [B*K] parked masks of the beam slots */
+  uint32_t* scored;             /* [B] n-gram LM queries issued for utterance b (accounting), or null */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
   int32_t profThread; /* the thread whose clock is sampled (lane 0 of the wave under study) */
@@ -852,6 +853,7 @@ struct FrameCtx {
   int nTok;      /* min(beamSizeToken, N) */
   bool useTrans; /* ASG and global frame > 0 */
   const float* e; /* emission row in LDS */
+  mutable uint32_t nScored = 0; /* n-gram LM queries of this thread (roofline accounting) */
 };
 
 /* LexiconFreeDecoder::decodeStep inner loops (LexiconFreeDecoder.cpp:54-112) */
@@ -881,6 +883,7 @@ FLTX_DEV void genLexFree(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       const bool newTok = ctc ? (n != P.blank && (n != prevTok || prevBlank)) : (n != prevTok);
       if (newTok) { /* :69-85 */
         lm = lmScoreDev(P, f.b, w.bState[(f.cur) * P.K + h], n);
+        f.nScored += P.lmKind != 0 ? 1u : 0u;
         score = score + P.lmWeight * (double)lm;
         kp = w.bState[(f.cur) * P.K + h];
         ke = (uint32_t)n;
@@ -1007,6 +1010,7 @@ FLTX_DEV bool denseEval(const DecodeParams& P, const Ws& w, const FrameCtx& f, i
       }
       if (!haveLm) {
         lm = lmScoreDev(P, f.b, sid, n);
+        f.nScored += P.lmKind != 0 ? 1u : 0u;
         haveLm = true;
       }
       double s = w.bScore[(cur) * P.K + h] + en;
@@ -1301,6 +1305,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
         }
         if (P.isLmToken) {
           lmTok = lmScoreDev(P, f.b, sid, n); /* :82-86 */
+          f.nScored += (P.lmKind != 0 && MODE != 3) ? 1u : 0u;
         }
         const int nl = (int)(ed.meta & 7u);
         cExt = (!ctc || prevBlank || n != prevTok) && (ed.meta & 8u) != 0; /* :89-91 */
@@ -1381,6 +1386,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
         label = j == 0 ? lab0 : P.trieLabels[labOff + j];
         if (!P.isLmToken) {
           l = lmScoreDev(P, f.b, sid, label) - lexMax; /* float subtraction, :127 */
+          f.nScored += (P.lmKind != 0 && MODE != 3) ? 1u : 0u;
           kp = sid;
           ke = (uint32_t)label;
         } else {
@@ -1406,6 +1412,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       if (cUnk) {
         if (!P.isLmToken) {
           l = lmScoreDev(P, f.b, sid, P.unk) - lexMax;
+          f.nScored += (P.lmKind != 0 && MODE != 3) ? 1u : 0u;
           ke = (uint32_t)P.unk;
         } else {
           l = lmTok;
@@ -2800,6 +2807,9 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     for (int q = 0; q < 8; ++q) {
       P.prof[(size_t)b * 8 + q] = f.acc[q];
     }
+  }
+  if (P.scored && f.nScored != 0u) {
+    atomAdd32(&P.scored[b], f.nScored);
   }
   /* park the beam in HBM for the next decodeStep / prune / best */
   for (int i = tid; i < nBeam; i += W) {

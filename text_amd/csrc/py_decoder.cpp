@@ -7,9 +7,11 @@
  * method names, raw-address emissions (`ndarray.ctypes.data`) and pickle
  * support; seq2seq classes are out of scope.  Additive: decode_batch().
  */
+#include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <functional>
 #include <limits>
 
 #include "flashlight/lib/text/decoder/LexiconDecoder.h"
@@ -43,6 +45,39 @@ class PyLM : public LM {
 
 const float* asPtr(uintptr_t p) { return reinterpret_cast<const float*>(p); }
 
+/* additive: the n-best of a whole batch as NumPy arrays over the library's pinned host buffers
+ * (zero copy; valid until the next decode on the decoder, which the arrays keep alive).  Indexing
+ * builds the DecodeResult objects of ONE utterance: Python code that wants the best hypothesis of
+ * every utterance, or arrays, does not pay for 12 800 objects per batch. */
+struct BatchResults {
+  py::object owner; /* the decoder */
+  detail::BatchView v;
+  std::function<std::vector<DecodeResult>(int)> make;
+  py::array nHyp, length, offsets, scores, tokens;
+  py::object words;
+};
+
+template <class Dec>
+BatchResults makeBatchResults(py::object self, Dec& d, const detail::BatchView& v) {
+  BatchResults r;
+  r.owner = self;
+  r.v = v;
+  Dec* dp = &d;
+  r.make = [dp, v](int b) { return dp->materialise(v, b); };
+  const py::ssize_t B = v.B;
+  const py::ssize_t total = v.offsets[v.B];
+  r.nHyp = py::array_t<int32_t>({B}, {sizeof(int32_t)}, v.nHyp, self);
+  r.length = py::array_t<int32_t>({B}, {sizeof(int32_t)}, v.length, self);
+  r.offsets = py::array_t<int64_t>({B + 1}, {sizeof(int64_t)}, v.offsets, self);
+  r.scores = py::array_t<double>({B, (py::ssize_t)v.K, (py::ssize_t)3},
+                                 {(py::ssize_t)(sizeof(double) * 3 * v.K), (py::ssize_t)(sizeof(double) * 3),
+                                  (py::ssize_t)sizeof(double)},
+                                 v.scores, self);
+  r.tokens = py::array_t<int32_t>({total}, {sizeof(int32_t)}, v.tokens, self);
+  r.words = v.words ? py::object(py::array_t<int32_t>({total}, {sizeof(int32_t)}, v.words, self)) : py::none();
+  return r;
+}
+
 template <class Dec>
 void bindDecoderMethods(py::class_<Dec>& c) {
   c.def("decode_begin", &Dec::decodeBegin)
@@ -56,12 +91,29 @@ void bindDecoderMethods(py::class_<Dec>& c) {
       .def("get_all_final_hypothesis", &Dec::getAllFinalHypothesis)
       .def("n_hypothesis", &Dec::nHypothesis)
       .def("n_decoded_frames_in_buffer", &Dec::nDecodedFramesInBuffer)
-      /* additive: B utterances packed back to back at `emissions` */
+      /* additive: B utterances packed back to back at `emissions`; devices = [0, 1, ...] shards the
+       * batch over several GPUs (one host thread + stream per device, results in input order) */
       .def("decode_batch",
-           [](Dec& d, uintptr_t e, const std::vector<int>& T, int N, bool onDevice) {
-             return d.decodeBatch(asPtr(e), T, N, {}, onDevice);
+           [](Dec& d, uintptr_t e, const std::vector<int>& T, int N, bool onDevice, const std::vector<int>& devices) {
+             py::gil_scoped_release nogil;
+             if (!devices.empty()) {
+               return d.decodeBatch(asPtr(e), T, N, devices);
+             }
+             return d.decodeBatch(asPtr(e), T, N, std::vector<int64_t>{}, onDevice);
            },
-           "emissions"_a, "T"_a, "N"_a, "on_device"_a = false);
+           "emissions"_a, "T"_a, "N"_a, "on_device"_a = false, "devices"_a = std::vector<int>{})
+      .def("decode_batch_arrays",
+           [](py::object self, uintptr_t e, const std::vector<int>& T, int N, bool onDevice) {
+             Dec& d = self.cast<Dec&>();
+             detail::BatchView v;
+             {
+               py::gil_scoped_release nogil;
+               v = d.decodeBatchView(asPtr(e), T, N, {}, onDevice);
+             }
+             return makeBatchResults(self, d, v);
+           },
+           "emissions"_a, "T"_a, "N"_a, "on_device"_a = false)
+      .def("set_max_stream_frames", &Dec::setMaxStreamFrames, "frames"_a);
 }
 
 } // namespace
@@ -173,6 +225,36 @@ PYBIND11_MODULE(flashlight_lib_text_decoder, m) {
       .def_readwrite("lmScore", &DecodeResult::lmScore)
       .def_readwrite("words", &DecodeResult::words)
       .def_readwrite("tokens", &DecodeResult::tokens);
+
+  py::class_<BatchResults>(m, "BatchResults")
+      .def_readonly("n_hyp", &BatchResults::nHyp)
+      .def_readonly("length", &BatchResults::length)
+      .def_readonly("offsets", &BatchResults::offsets)
+      .def_readonly("scores", &BatchResults::scores)
+      .def_readonly("tokens", &BatchResults::tokens)
+      .def_readonly("words", &BatchResults::words)
+      .def("__len__", [](const BatchResults& r) { return r.v.B; })
+      .def("__getitem__",
+           [](const BatchResults& r, int b) {
+             if (b < 0) {
+               b += r.v.B;
+             }
+             if (b < 0 || b >= r.v.B) {
+               throw py::index_error();
+             }
+             return r.make(b);
+           },
+           "b"_a)
+      .def("tokens_of",
+           [](const BatchResults& r, int b, int i) {
+             if (b < 0 || b >= r.v.B || i < 0 || i >= r.v.nHyp[b]) {
+               throw py::index_error();
+             }
+             const py::ssize_t L = r.v.length[b];
+             return py::array_t<int32_t>({L}, {sizeof(int32_t)}, r.v.tokens + r.v.offsets[b] + (int64_t)i * L,
+                                         r.owner);
+           },
+           "b"_a, "i"_a = 0);
 
   py::class_<LexiconDecoder> lex(m, "LexiconDecoder");
   lex.def(py::init<LexiconDecoderOptions, const TriePtr, const LMPtr, const int, const int, const int,
