@@ -1,0 +1,113 @@
+"""GPU (-m gpu): the BASELINE.json batch shapes of the lexicon decoder as they are
+benchmarked -- C3 (90k-word trie, ZeroLM, B=256), C4 (trie + synthetic 4-gram,
+B=256) and C5's per-GPU share (C4 at B=1024: four launch rounds of 256
+workgroups) -- through the C ABI.  Utterances with a committed golden equal it;
+sampled utterances equal the oracle; every 17th utterance passes size-independent
+checks: sorted n-best, emitting-model score = sum of the emissions along the
+token path, and the collapsed token path between two word ends spells the word
+that was emitted."""
+import numpy as np
+import pytest
+
+import cases
+import helpers
+from text_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _spelling(lex, w):
+    sf, so = lex
+    return [int(x) for x in sf[so[w]:so[w + 1]]]
+
+
+def _check_structure(h, e, lex, T, N, zero_lm, opt):
+    """size-independent properties of one hypothesis of the lexicon decoder (CTC)."""
+    blank = N - 1
+    assert len(h.tokens) == T + 2 and h.tokens[0] == 0 and h.tokens[-1] == 0
+    path = e[np.arange(T), h.tokens[1:-1]].astype(np.float64)
+    acc = 0.0
+    for v in path:
+        acc += v
+    assert acc == h.am  # LexiconDecoder.cpp:69,105: am = prev.am + emission, in frame order
+    letters, prev, n_words, n_sil = [], None, 0, 0
+    for f in range(1, T + 1):
+        t, w = int(h.tokens[f]), int(h.words[f])
+        n_sil += 1 if t == 0 else 0
+        if t != blank and t != prev:
+            letters.append(t)
+        prev = t
+        if w >= 0:
+            n_words += 1
+            while letters and letters[0] == 0:
+                letters.pop(0)  # sil emitted while waiting at the root
+            assert letters == _spelling(lex, w), (f, w, letters, _spelling(lex, w))
+            letters = []
+    if zero_lm:
+        assert h.lm == 0.0 and h.score == h.am
+    else:
+        want = h.am + opt["lm_weight"] * h.lm + opt["word_score"] * n_words + opt["sil_score"] * n_sil
+        assert abs(want - h.score) < 1e-6 * max(1.0, abs(h.score))
+    return n_words
+
+
+def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample):
+    c = cases.BY_NAME[name0]
+    inp = helpers.case_inputs(c)
+    T, N = c["T"], c["N"]
+    e = synth.batch("lexspell", B, T, N, lexicon=inp["lex"])
+    d = gpu_session.decoder(c, inp)
+    d.decode_batch(e, [T] * B, N)
+    assert d.get("lds") == 1
+    for b, name in ((0, name0), (255, name255)):
+        if name and b < B:
+            ok, why = helpers.check_against_golden(d.results(b), golden[name])
+            assert ok, "%s: %s" % (name, why)
+    opt = dict(lm_weight=c["lm_weight"], word_score=c["word_score"], sil_score=c["sil_score"])
+    words = 0
+    for b in range(0, B, 17):
+        hyps = d.results(b)
+        assert 0 < len(hyps) <= c["K"]
+        sc = [h.score for h in hyps]
+        assert all(x > y for x, y in zip(sc, sc[1:]))
+        for h in hyps[:3]:
+            words += _check_structure(h, e[b], inp["lex"], T, N, c["lm"] == "zero", opt)
+    assert words > 0
+    for b in sample:
+        cb = dict(c, u=b)
+        want = helpers.run_checker(oracle_lib, cb, dict(inp, e=e[b]))
+        ok, why = helpers.hyps_equal(want, d.results(b))
+        assert ok, "utterance %d vs oracle: %s" % (b, why)
+    d.close()
+
+
+def test_c3_batch_of_256(gpu_session, golden, oracle_lib):
+    _run_batch(gpu_session, golden, oracle_lib, "C3_spell_u0", "C3_spell_u255", 256, sample=[97, 201])
+
+
+def test_c4_batch_of_256(gpu_session, golden, oracle_lib):
+    _run_batch(gpu_session, golden, oracle_lib, "C4_spell_u0", "C4_spell_u255", 256, sample=[131])
+
+
+def test_c5_share_of_one_gpu_1024_utterances(gpu_session, golden, oracle_lib):
+    """BASELINE.json configs[4]: 8192 utterances over 8 GPUs = 1024 per GPU, i.e. four launch
+    rounds of the 256 workgroups a device runs at a time."""
+    _run_batch(gpu_session, golden, oracle_lib, "C4_spell_u0", "C4_spell_u255", 1024, sample=[700, 1023])
+
+
+def test_random_configurations_slice(gpu_session, oracle_lib):
+    """A bounded slice of tools/fuzz_big.py: random option / size / LM / lexicon combinations
+    against the oracle (ties in the reference's n-best are skipped: its own result is order
+    dependent there)."""
+    bad, ran = [], 0
+    for c in cases.fuzz_cases(160)[40:]:
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue
+        got = gpu_session.run(c, inp)
+        ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
+        ran += 1
+        if not ok:
+            bad.append((c["name"], why))
+    assert ran > 60 and not bad, bad[:3]
