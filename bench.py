@@ -448,6 +448,9 @@ def cpu_more(a, job):
         quota = None if q == "max" else float(q) / float(per)
     except (OSError, ValueError):
         pass
+    visible = cores
+    if quota:  # more threads than the quota only adds allocator contention
+        cores = max(1, min(cores, int(quota + 0.999)))
     budget = 8.0  # seconds of wall time; every thread decodes whole utterances until it is spent
     done = [0] * cores
     t0 = time.perf_counter()
@@ -465,7 +468,7 @@ def cpu_more(a, job):
         list(ex.map(work, range(cores)))
     ta = time.perf_counter() - t0
     allc = {"value": sum(done) * job.T / ta, "unit": "frames/s", "cores": cores, "kind": cpu.kind,
-            "seconds": ta, "utterances": sum(done), "cgroup_cpu_quota_cores": quota,
+            "seconds": ta, "utterances": sum(done), "cgroup_cpu_quota_cores": quota, "visible_cpus": visible,
             "sample": "%d host threads, one decoder per thread (reused), trie / LM shared read-only, every "
                       "thread decodes utterances of the batch until %.0f s of wall time are spent" % (cores, budget)}
     return steady, allc
