@@ -3023,26 +3023,87 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
       const int hi = lo + F - 1 < Tb ? lo + F - 1 : Tb;
       const int nf = hi - lo + 1;
       __syncthreads();
-      for (int k = tid >> 6; k < nh; k += W >> 6) {
-        for (int j = tid & 63; j < nf; j += 64) {
-          tT[k * F + j] = P.tokens[ob + (int64_t)k * len + lo + j];
+      { /* eight loads in flight per thread before the first LDS store (a load -> store loop would
+           pay one memory latency per element), and no integer division in the index arithmetic */
+        const int nWv = W >> 6, wv = tid >> 6, ln = tid & 63;
+        for (int jb = 0; jb < nf; jb += 64) { /* token rows: wave wv takes rows wv, wv + nWv, ... */
+          for (int k0 = wv; k0 < nh; k0 += 8 * nWv) {
+            int32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int k = k0 + u * nWv;
+              v[u] = (k < nh && jb + ln < nf) ? P.tokens[ob + (int64_t)k * len + lo + jb + ln] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int k = k0 + u * nWv;
+              if (k < nh && jb + ln < nf) {
+                tT[k * F + jb + ln] = v[u];
+              }
+            }
+          }
         }
-      }
-      for (int i = tid; i < nf * N; i += W) {
-        eT[i] = em[(size_t)(lo - 1) * N + i];
+        const int nEm = nf * N; /* emission rows of the chunk: contiguous */
+        for (int base = tid; base < nEm; base += 8 * W) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = base + u * W;
+            v[u] = i < nEm ? em[(size_t)(lo - 1) * N + i] : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = base + u * W;
+            if (i < nEm) {
+              eT[i] = v[u];
+            }
+          }
+        }
       }
       __syncthreads();
       if (tid < nh) {
-        for (int j = 0; j < nf; ++j) {
-          const int n = tT[tid * F + j];
-          if (n >= 0) {
-            double x = (double)eT[j * N + n];
-            if (P.transitions && lo - 1 + j > 0) {
-              x += (double)trT[n * N + prevTok];
+        /* the chain is the additions: tokens and emissions of eight steps are read ahead of them
+         * (two dependent LDS round trips per step otherwise) */
+        constexpr int U = 8;
+        const int row = tid * F;
+        auto walk = [&](auto withTrans) {
+          constexpr bool TR = decltype(withTrans)::value;
+          for (int j0 = 0; j0 < nf; j0 += U) {
+            int tk[U];
+            float ev[U], tr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              tk[u] = tT[row + (j0 + u < nf ? j0 + u : nf - 1)];
             }
-            am += x;
-            prevTok = n;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              ev[u] = eT[(j0 + u < nf ? j0 + u : nf - 1) * N + (tk[u] >= 0 ? tk[u] : 0)];
+              tr[u] = 0.0f;
+            }
+            if (TR) {
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int pv = u == 0 ? prevTok : tk[u - 1];
+                tr[u] = (tk[u] >= 0 && pv >= 0 && lo - 1 + j0 + u > 0) ? trT[tk[u] * N + pv] : 0.0f;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (j0 + u < nf && tk[u] >= 0) {
+                double x = (double)ev[u];
+                if (TR && lo - 1 + j0 + u > 0) {
+                  x += (double)tr[u];
+                }
+                am += x;
+                prevTok = tk[u];
+              }
+            }
           }
+        };
+        if (P.transitions) {
+          walk(SlParity<1>());
+        } else {
+          walk(SlParity<0>());
         }
       }
     }
