@@ -1623,7 +1623,9 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
 
 int bumpEpoch(fltx_decoder* d) {
   if (d->epoch >= 65535u) {
-    if (devMemset(d->stateTab.p, 0, sizeof(unsigned long long) * (size_t)d->B * d->stateCap, d->ctx->stream)) {
+    /* the whole allocation, not just this batch's part: a larger earlier batch left keys tagged
+     * with epochs that are about to be reused */
+    if (devMemset(d->stateTab.p, 0, d->stateTab.cap, d->ctx->stream)) {
       return fail(FLTX_ERR_HIP, "state table reset failed");
     }
     d->epoch = 0;
