@@ -111,3 +111,29 @@ def test_random_configurations_slice(gpu_session, oracle_lib):
         if not ok:
             bad.append((c["name"], why))
     assert ran > 60 and not bad, bad[:3]
+
+
+def test_edge_configurations_of_the_lexicon_free_decoders(gpu_session, oracle_lib):
+    """tools/edge_cases.py inside the suite: tiny token sets, beam 1 and beam = a wave's lanes,
+    thresholds 0 / inf (with an unbounded threshold a score of -inf passes every comparison:
+    what exists must be told by the bookkeeping, not by the scores), token beams of 1 and 3,
+    silScore of both signs, ASG with transitions, one-frame utterances."""
+    import itertools
+    bad, ran = [], 0
+    grid = itertools.product([2, 3, 29, 64], [1, 2, 50, 64], [0.0, 1.5, 25.0, float("inf")], [None, 1, 3],
+                             [0.0, -0.7, 0.4], ["ctc", "asg"], [1, 2, 17, 120])
+    for i, (N, K, thr, Kt, sil, crit, T) in enumerate(grid):
+        if i % 7 not in (0, 3) or (crit == "asg" and N == 2):
+            continue
+        c = cases.case("edge%d" % i, dist=["ctc", "uniform"][i % 2], u=500 + i, T=T, N=N, K=K,
+                       Kt=min(N, Kt) if Kt else None, thr=thr, sil_score=sil, crit=crit,
+                       trans_seed=(90 + i) if crit == "asg" else None)
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue
+        ok, why = helpers.hyps_equal(want, gpu_session.run(c, inp))
+        ran += 1
+        if not ok:
+            bad.append(({k: c[k] for k in ("N", "K", "Kt", "thr", "sil_score", "crit", "T", "dist")}, why))
+    assert ran > 1000 and not bad, bad[:3]

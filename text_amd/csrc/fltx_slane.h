@@ -530,9 +530,16 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       const bool okB = ctc && live && ((allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB >= thr;
       /* (S, last, false): the repeat (:98-110) and the parent state's extension by last (:69-85) */
       const int lastP = (int)(par.info & 0xFFu);
+      const uint32_t h1 = (par.info >> 16) & 0xFFu, h2 = par.info >> 24;
+      /* which members exist is told by the history slots, not by the scores: with an unbounded
+       * threshold a score of -inf passes every comparison */
+      const bool has0 = hypNB != kSlNoHyp;
+      const bool has1 = pl >= 0 && last != lastP && h1 != kSlNoHyp;
+      const bool has2 = pl >= 0 && ctc && h2 != kSlNoHyp;
+      const bool hasB = hypB != kSlNoHyp;
       double r0 = nb + eLast;
-      double r1 = (pl >= 0 && last != lastP) ? par.nb + eLast : NEG;
-      double r2 = (pl >= 0 && ctc) ? par.b + eLast : NEG;
+      double r1 = has1 ? par.nb + eLast : NEG;
+      double r2 = has2 ? par.b + eLast : NEG;
       /* (S.last, last, false) from (S, blank, true) when no lane holds S.last */
       double cL = bb + eLast;
       if (silScore != 0.0) {
@@ -541,20 +548,20 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         r2 = lastSil ? r2 + silScore : r2;
         cL = lastSil ? cL + silScore : cL;
       }
-      const uint32_t h1 = (par.info >> 16) & 0xFFu, h2 = par.info >> 24;
-      /* max-merge (Utils.h:194-196); a tie goes to the lower history slot */
+      /* max-merge (Utils.h:194-196); a tie goes to the lower history slot (a member that does not
+       * exist has slot 255 and score -inf: it never wins against one that does) */
       double cR = r0;
       parR = hypNB;
-      if (r1 > cR || (r1 == cR && h1 < parR)) {
+      if (has1 && (r1 > cR || (r1 == cR && h1 < parR))) {
         cR = r1;
         parR = h1;
       }
-      if (r2 > cR || (r2 == cR && h2 < parR)) {
+      if (has2 && (r2 > cR || (r2 == cR && h2 < parR))) {
         cR = r2;
         parR = h2;
       }
-      const bool okR = lastOk && cR >= thr;
-      const bool okL = ctc && lastOk && ((cm >> last) & 1ull) == 0ull && cL >= thr;
+      const bool okR = lastOk && (has0 || has1 || has2) && cR >= thr;
+      const bool okL = ctc && lastOk && hasB && ((cm >> last) & 1ull) == 0ull && cL >= thr;
       cs[0] = cB;
       cs[1] = cR;
       cs[2] = cL;
