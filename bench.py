@@ -316,6 +316,9 @@ def phase_profile(a, dec, job, step, B, T):
             order = [6, 0, 1, 2, 3, 7, 4, 5]
         if eng == 4:  # fltx_slane.h
             names = ["loads", "candidates+hist", "bar1+scan+select", "new-lane counts", "bar2+build", "bar3", "-", "-"]
+        if eng == 5:  # fltx_xlane.h (the last column counts lanes that came back, not clocks)
+            names = ["loads+reentry", "candidates+best", "barA+verdicts+hist", "bar1+scan+select", "new-lane counts",
+                     "bar2+build", "bar3", "re-entries"]
         names = [names[i] for i in order]
         pr = pr[order]
         tot = pr[:8].sum()

@@ -69,6 +69,9 @@ def test_bench_finds_the_committed_hbm_traffic_of_its_default_workload():
     """bench.py quotes roofline.traffic from the rocprofv3 --pmc summary committed
     under profiles/ -- keyed by the exact geometry it was measured on."""
     import bench
-    tr = bench.pmc_traffic("C2", 512, 256, 1000, 29, 50)
-    assert tr is not None and tr[0] > 1e8 and tr[1].startswith("profiles/")
-    assert bench.pmc_traffic("C2", 256, 256, 1000, 29, 50) is None  # other geometry: not quoted
+    tr = bench.pmc_traffic("C2", 512, 256, 1000, 29, 50, engine=4)
+    assert tr is not None and tr[0] > 1e8 and tr[1].startswith("profiles/r02/")
+    assert bench.pmc_traffic("C2", 256, 256, 1000, 29, 50, engine=4) is None  # other geometry: not quoted
+    assert bench.pmc_traffic("C2", 512, 256, 1000, 29, 50, engine=3) is None  # other engine: not quoted
+    for w, K, T in (("C3", 50, 1000), ("C4", 100, 1500)):
+        assert bench.pmc_traffic(w, 512, 256, T, 29, K, engine=0) is not None

@@ -241,6 +241,13 @@ struct fltx_trie {
   int64_t nNodes = 0;
   int32_t nTokens = 0;
   DBuf edge, labels, mask;
+  /* breadth-first re-layout for the lane = (LM state, trie node) engine (fltx_xlane.h): a node's
+   * children are contiguous and in token order, so a child's id is the first child's id plus the
+   * number of children with a smaller token; one 32-byte XNode per node, root = 0 */
+  DBuf xnode;
+  bool xOk = false;     /* the layout exists and the trie has the shape that engine assumes: */
+  int32_t xEndTok = -1; /* every node that carries labels is entered by this one token (the word separator) */
+  bool xZeroSmear = true; /* every maxScore is 0 (a lexicon without LM scores) */
 };
 
 struct fltx_decoder {
@@ -272,6 +279,9 @@ struct fltx_decoder {
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
   int slaneThreads = 0; /* tuning: workgroup size of the lane = LM state kernel (0 = first that fits) */
   int slane = 0, noSlane = 0; /* slane: list positions per wave of the lane = LM state kernel (fltx_slane.h), 0 = off */
+  int lastRedo = 0;           /* utterances of the last offline call that had to be decoded again on a general path */
+  bool batchPacked = false;   /* some utterance of the current results has packed history records (ST_PACKED) */
+  int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
   bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
   const float* lastEmis = nullptr; /* device emissions of the last offline batch (the back-trace re-reads them) */
   size_t hotBytes = 0; /* LDS part of a split (HBM + LDS) workspace */
@@ -790,6 +800,67 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
   t->nTokens = nTokens;
   Stream st = ctx->stream;
   size_t nLab = (size_t)labelOff[nNodes];
+  /* breadth-first layout (see fltx_trie::xnode) */
+  std::vector<XNode> xn;
+  if (nTokens <= 64 && !cmask.empty()) {
+    std::vector<int64_t> order; /* new id -> old id */
+    std::vector<int32_t> tokOf((size_t)nNodes, -1);
+    std::vector<uint32_t> parentOf((size_t)nNodes + 1, 0u); /* by new id */
+    order.reserve((size_t)nNodes);
+    order.push_back(0);
+    xn.resize((size_t)nNodes);
+    bool ok = true;
+    int endTok = -1;
+    bool zero = true;
+    for (size_t q = 0; q < order.size(); ++q) {
+      const int64_t o = order[q];
+      XNode x;
+      memset(&x, 0, sizeof(x));
+      x.childMask = cmask[(size_t)o];
+      x.firstChild = (uint32_t)order.size();
+      x.maxScore = maxScore[o];
+      x.endLabel0 = -1;
+      x.parent = parentOf[q];
+      zero = zero && maxScore[o] == 0.0f;
+      for (int tk = 0; tk < nTokens; ++tk) {
+        const int32_t c = child[o * nTokens + tk];
+        if (c < 0) {
+          continue;
+        }
+        if (order.size() <= (size_t)nNodes) {
+          parentOf[order.size()] = (uint32_t)q;
+        }
+        order.push_back(c);
+        tokOf[(size_t)c] = tk;
+        if (nKids[(size_t)c] > 0) {
+          x.kidsMask |= 1ull << tk;
+        }
+        const int nl = labelOff[c + 1] - labelOff[c];
+        if (nl > 0) {
+          if (endTok < 0) {
+            endTok = tk;
+          }
+          ok = ok && tk == endTok && nl == 1; /* one word-ending token, one word per spelling */
+          x.endLabel0 = labels[labelOff[c]];
+        }
+      }
+      xn[q] = x;
+    }
+    ok = ok && order.size() == (size_t)nNodes && (labelOff[1] - labelOff[0]) == 0; /* a tree; no label on the root */
+    t->xOk = ok;
+    t->xEndTok = endTok;
+    t->xZeroSmear = zero;
+    if (!ok) {
+      xn.clear();
+    }
+  }
+  if (!xn.empty()) {
+    if (t->xnode.ensure(sizeof(XNode) * xn.size(), st, false) ||
+        devCopyH2D(t->xnode.p, xn.data(), sizeof(XNode) * xn.size(), st)) {
+      delete t;
+      return fail(FLTX_ERR_OOM, "trie: breadth-first layout upload failed");
+    }
+  }
   if (!cmask.empty()) {
     if (t->mask.ensure(8 * cmask.size(), st, false) ||
         devCopyH2D(t->mask.p, cmask.data(), 8 * cmask.size(), st)) {
@@ -929,7 +1000,11 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     return fail(FLTX_ERR_INVALID, "fltx_decoder_get: null argument");
   }
   if (!strcmp(key, "engine")) {
-    *value = d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0)));
+    *value = d->xlane ? 5 : (d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0))));
+  } else if (!strcmp(key, "xlane")) {
+    *value = d->xlane;
+  } else if (!strcmp(key, "redone")) {
+    *value = d->lastRedo;
   } else if (!strcmp(key, "slane")) {
     *value = d->slane;
   } else if (!strcmp(key, "lane")) {
@@ -1008,6 +1083,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "cut")) { /* 0: the lexicon decoder materialises every candidate (no score-pass cut) */
     d->noCut = value ? 0 : 1;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "xlane")) { /* 0: do not use the lane = (LM state, trie node) kernel (fltx_xlane.h) */
+    d->noXlane = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "slane_threads")) {
@@ -1129,6 +1208,27 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       }
       if (nList <= g[1] * (g[0] / 64 - 2)) {
         d->slane = g[1];
+        d->threads = g[0];
+        break;
+      }
+    }
+  }
+  /* lane = (LM state, trie node) decode (fltx_xlane.h): offline LexiconDecoder + ZeroLM over a lexicon
+   * without LM scores, CTC max-merge, one word per spelling, every word ending in sil, no <unk> */
+  d->xlane = 0;
+  if (d->kind == FLTX_DECODER_LEXICON && !d->noXlane && d->offlineCall && !d->keepScores && !d->opt.log_add &&
+      !forceWorstCaseCap && !d->forceGlobalWs && d->lm->kind == 0 && !d->isLmToken && d->trie && d->trie->xOk &&
+      d->trie->xZeroSmear && d->trie->xEndTok == d->sil && d->sil != d->blank &&
+      d->opt.criterion == FLTX_CRITERION_CTC && !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) &&
+      K <= 64 && N <= 64 && d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N && d->blank >= 0 &&
+      d->blank < N && (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
+    static const int geo[][2] = {{512, 3}, {576, 5}, {640, 10}};
+    for (const auto& g : geo) {
+      if ((d->userThreads && d->threads != g[0]) || (d->slaneThreads && d->slaneThreads != g[0])) {
+        continue;
+      }
+      if (nTok <= g[1] * (g[0] / 64 - 3)) {
+        d->xlane = g[1];
         d->threads = g[0];
         break;
       }
@@ -1304,6 +1404,15 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     d->wsInLds = true;
     lds = true;
   }
+  if (d->xlane) {
+    d->wsBytes = sizeof(XlaneLds);
+    d->wsInLds = true;
+    lds = true;
+    d->itemCap = 0;
+    d->CAP2 = 0;
+    d->cutM = 0;
+    d->cutRecompute = 0;
+  }
   /* buffers */
   bool grewTab = false;
   int rc = 0;
@@ -1443,6 +1552,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.uttNextId = d->uttNextId.as<int32_t>();
   P.gMask = d->gMask.as<unsigned long long>();
   P.prof = nullptr;
+  P.xnode = (d->trie && d->trie->xnode.p) ? d->trie->xnode.as<XNode>() : nullptr;
+  P.xEndTok = d->trie ? d->trie->xEndTok : -1;
   P.scored = (d->lm->kind == 1 && d->scored.p) ? d->scored.as<uint32_t>() : nullptr;
   P.profThread = 64 * d->profWave;
   if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {
@@ -1458,9 +1569,10 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   const int gmax = d->lean;
   const int gt = d->lane;
   const int sl = d->slane;
+  const int xl = d->xlane;
   const bool hot = !d->wsInLds && d->hotBytes > 0;
   emuLaunch(d->nLaunch > 0 ? d->nLaunch : d->B, W, d->wsInLds ? d->wsBytes : (hot ? d->hotBytes : 16),
-            [pp, gmax, gt, sl, hot](char* smem) {
+            [pp, gmax, gt, sl, xl, hot](char* smem) {
     char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
     if (hot) {
       if (gmax == 255) {
@@ -1471,7 +1583,13 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       return;
     }
     const bool ft = pp->Kt >= pp->N;
-    if (sl == 4) {
+    if (xl == 3) {
+      xlaneUtterance<3, false>(*pp, smem);
+    } else if (xl == 5) {
+      xlaneUtterance<5, false>(*pp, smem);
+    } else if (xl == 10) {
+      xlaneUtterance<10, false>(*pp, smem);
+    } else if (sl == 4) {
       slaneUtterance<4, false>(*pp, smem);
     } else if (sl == 5) {
       slaneUtterance<5, false>(*pp, smem);
@@ -1586,7 +1704,29 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       FLTX_LAUNCH_LDS(WW, 0);                                                                    \
     }                                                                                            \
   } while (0)
-  if (d->slane) {
+  if (d->xlane) {
+#define FLTX_LAUNCH_XLANE(WW, GG)                                                                \
+  do {                                                                                           \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, false>,             \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, true>,              \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
+    if (d->profile) {                                                                            \
+      hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, true>), dim3(nGrid), dim3(WW),        \
+                         d->wsBytes, d->ctx->stream, P);                                         \
+    } else {                                                                                     \
+      hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, false>), dim3(nGrid), dim3(WW),       \
+                         d->wsBytes, d->ctx->stream, P);                                         \
+    }                                                                                            \
+  } while (0)
+    switch (W * 100 + d->xlane) {
+      case 51203: FLTX_LAUNCH_XLANE(512, 3); break;
+      case 57605: FLTX_LAUNCH_XLANE(576, 5); break;
+      case 64010: FLTX_LAUNCH_XLANE(640, 10); break;
+      default: return fail(FLTX_ERR_INVALID, "no lane = (LM state, node) kernel for %d threads x %d positions", W, d->xlane);
+    }
+#undef FLTX_LAUNCH_XLANE
+  } else if (d->slane) {
     const int key = W * 100 + d->slane;
     switch (key) {
       case 32010: FLTX_LAUNCH_SLANE(320, 10); break;
@@ -1729,8 +1869,9 @@ int launchBacktrace(fltx_decoder* d) {
   }
   Q.F = F;
   size_t btLds = F > 0 ? (size_t)F * perFrame + 16 : 16;
-  if (d->slane && F > 0) { /* packed records; emitting-model scores re-accumulated along the paths */
+  if (d->batchPacked && F > 0) { /* packed records; emitting-model scores re-accumulated along the paths */
     Q.packed = 1;
+    Q.uttStatus = d->uttStatus.as<int32_t>();
     Q.amOut = d->outScores.as<double>();
     Q.emissions = d->lastEmis;
     Q.emOff = d->emOff.as<int64_t>();
@@ -1823,8 +1964,9 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   bool recomputeRetry = false; /* this attempt is the recompute form of the cut-off generation */
   bool recomputeTried = false;
   const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
-  const int savedNoSlane = d->noSlane;
+  const int savedNoSlane = d->noSlane, savedNoXlane = d->noXlane;
   d->offlineCall = true;
+  d->batchPacked = false;
   d->keepScores = d->userKeepScores; /* a stream on this decoder had switched the score history on */
   for (int attempt = 0; attempt < 3; ++attempt) {
     const bool finalForm = attempt > 0 && !recomputeRetry; /* the general path: nothing left to fall back to */
@@ -1832,6 +1974,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     if (rc) {
       return rc;
     }
+    d->batchPacked = d->batchPacked || d->slane || d->xlane;
     if ((rc = bumpEpoch(d))) {
       return rc;
     }
@@ -1857,12 +2000,12 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
       return rc;
     }
     const bool cutMode = d->CAP2 > 0 || d->cutRecompute;
-    if (!finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean)) {
+    if (!finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->xlane)) {
       d->resultsSynced = false;
       if ((rc = syncResults(d))) {
         return rc;
       }
-      bool ws = false, cut = false, lean = false, slaneMiss = false;
+      bool ws = false, cut = false, lean = false, slaneMiss = false, xlaneMiss = false;
       const bool slimMode = d->CAP2 > 0;
       std::vector<int32_t> again;
       const int nScan = attempt == 0 ? B : (int)redoList.size();
@@ -1872,12 +2015,14 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         const bool o = (st & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON;
         const bool c = (st & ST_CUT_RETRY) && cutMode;
         const bool l = (st & ST_SELECT_FALLBACK) && d->lean;
-        if (o || c || l) {
+        const bool x = (st & ST_SELECT_FALLBACK) && d->xlane;
+        if (o || c || l || x) {
           again.push_back(b);
           ws |= o;
           cut |= c;
           lean |= l;
           slaneMiss |= l && d->slane;
+          xlaneMiss |= x;
         }
       }
       redoList.swap(again);
@@ -1899,18 +2044,21 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         d->noCut = cut ? 1 : d->noCut;
         d->noLean = lean ? 1 : d->noLean;
         d->noSlane = slaneMiss ? 1 : d->noSlane; /* (re-run on the generic engine) */
+        d->noXlane = xlaneMiss ? 1 : d->noXlane;
         d->resultsSynced = false;
         continue;
       }
     }
     break;
   }
+  d->lastRedo = (int)firstRedo;
   if (firstRedo > 0 && firstRedo * 4 <= (size_t)B) { /* a few outliers: next batch tries the fast path again */
     d->forceGlobalWs = savedGlobalWs;
     d->noCut = savedNoCut;
     d->noLean = savedNoLean;
     d->noSlim = savedNoSlim;
     d->noSlane = savedNoSlane;
+    d->noXlane = savedNoXlane;
   }
   d->resultsSynced = false;
   int rc = launchBacktrace(d);
@@ -1933,6 +2081,7 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   }
   std::vector<int32_t> Tm(B, maxFrames);
   d->offlineCall = false;
+  d->batchPacked = false;
   d->keepScores = 1; /* streams serve getBestHypothesis(lookBack) of ancestors */
   int rc = prepare(d, B, N, Tm.data(), true);
   if (rc) {

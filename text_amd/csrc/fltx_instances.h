@@ -40,6 +40,12 @@
   FLTX_INST(fltx_decode_kernel_slane<576, 10, PROF>)
 #define FLTX_G10(W) FLTX_SLANE_SET(false)
 #define FLTX_G11(W) FLTX_SLANE_SET(true)
+/* lane = (LM state, trie node) decode (fltx_xlane.h): three waves do not evaluate listed tokens */
+#define FLTX_XLANE_SET(PROF)                               \
+  FLTX_INST(fltx_decode_kernel_xlane<512, 3, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<576, 5, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<640, 10, PROF>)
+#define FLTX_G12(W) FLTX_XLANE_SET(false) FLTX_XLANE_SET(true)
 
 #ifdef FLTX_INST_W
 #define FLTX_CAT2_(a, b) a##b
@@ -56,6 +62,7 @@ FLTX_ALLG(512)
 FLTX_ALLG(1024)
 FLTX_G10(0)
 FLTX_G11(0)
+FLTX_G12(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -69,4 +76,6 @@ FLTX_G11(0)
 #undef FLTX_G9
 #undef FLTX_G10
 #undef FLTX_G11
+#undef FLTX_G12
+#undef FLTX_XLANE_SET
 #undef FLTX_SLANE_SET

@@ -51,6 +51,12 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_slane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   slaneUtterance<GT, PROF>(P, fltx_smem);
 }
+/* lane = (LM state, trie node) decode of a whole utterance (fltx_xlane.h): lexicon + ZeroLM */
+template <int W, int GT, bool PROF>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_xlane(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  xlaneUtterance<GT, PROF>(P, fltx_smem);
+}
 template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) { /* streaming lean step, HBM workspace */
   extern __shared__ __attribute__((aligned(16))) char fltx_hot[]; /* histogram & block scalars stay in LDS */

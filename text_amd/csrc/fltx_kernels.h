@@ -69,6 +69,17 @@ struct TrieEdge {
   uint32_t meta;   /* nLabels:3 | hasChildren:1 | labOff:28 */
 };
 
+/* Breadth-first layout of the trie for fltx_xlane.h: the children of a node are contiguous and in
+ * token order: child(n) = firstChild + popcount(childMask & ((1 << n) - 1)).  32 bytes. */
+struct XNode {
+  unsigned long long childMask; /* tokens that have a child */
+  unsigned long long kidsMask;  /* ... whose child has children itself (LexiconDecoder.cpp:89-91) */
+  uint32_t firstChild;
+  int32_t endLabel0;            /* label of the child entered by the word-ending token, -1 = none */
+  float maxScore;               /* TrieNode::maxScore (Trie.h:54) */
+  uint32_t parent;              /* breadth-first id of the parent node (root: 0) */
+};
+
 struct NgramSlot { /* 16 B open-addressing slot: (context node, word) -> n-gram */
   uint32_t ctx;    /* node id of the context n-gram (0 = empty context) */
   uint32_t word;   /* LM word id; 0xFFFFFFFF = empty slot */
@@ -90,7 +101,8 @@ constexpr int kFinishEdge = -1;              /* KenLM::finish child key (KenLM.c
 constexpr uint32_t kPhantomNode = 0x80000000u; /* NgramSlot.node: navigation-only prefix */
 constexpr int kMaxNgramOrder = 6;            /* FL_TEXT_KENLM_MAX_ORDER (lm/CMakeLists.txt:3) */
 
-enum { ST_OK = 0, ST_CAND_OVERFLOW = 1, ST_TABLE_FULL = 2, ST_SELECT_FALLBACK = 4, ST_CUT_RETRY = 8 };
+enum { ST_OK = 0, ST_CAND_OVERFLOW = 1, ST_TABLE_FULL = 2, ST_SELECT_FALLBACK = 4, ST_CUT_RETRY = 8,
+       ST_PACKED = 16 /* not an error: the history holds the packed records of fltx_slane.h / fltx_xlane.h */ };
 
 struct DecodeParams {
   /* options (LexiconDecoderOptions, LexiconDecoder.h:21-31) */
@@ -170,6 +182,8 @@ struct DecodeParams {
   int32_t* uttNextId;
   unsigned long long* gMask;    /* [B*K] parked masks of the beam slots */
   uint32_t* scored;             /* [B] n-gram LM queries issued for utterance b (accounting), or null */
+  const XNode* xnode;           /* breadth-first trie layout (fltx_xlane.h), or null */
+  int32_t xEndTok;              /* the token every word ends with in that layout */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
   int32_t profThread; /* the thread whose clock is sampled (lane 0 of the wave under study) */
@@ -2554,6 +2568,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 #include "fltx_lean.h"
 #include "fltx_lane.h"
 #include "fltx_slane.h"
+#include "fltx_xlane.h"
 
 /* ------------------------------------------------------------------------ */
 /* the decode kernel: grid = utterances, block = W threads.                  */
@@ -2857,6 +2872,7 @@ struct BacktraceParams {
   int32_t F;               /* frames per LDS chunk (0: walk straight through HBM) */
   /* records of the lane = LM state engine (fltx_slane.h): parent slot in the low byte of x (0xFF = none) */
   int32_t packed;
+  const int32_t* uttStatus; /* ST_PACKED per utterance (a re-run on the generic engine leaves plain records) */
   /* that engine does not carry the emitting-model score through the frames; it is
    * re-accumulated here along each returned path, in the reference's order
    * (LexiconFreeDecoder.cpp:58-63,82,95,108: am = prev.am + (e[t][n] (+ transition))) */
@@ -2885,6 +2901,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
   const int len = ff + 1;
   const int K = P.K;
   const bool lex = P.kind == 1;
+  const bool packed = P.packed && (P.uttStatus[b] & ST_PACKED) != 0;
   const int64_t hb = P.histOff[b], ob = P.tokOff[b];
   if (P.F <= 0) { /* beam too large for a useful chunk: one thread per hypothesis through HBM */
     for (int k = tid; k < nh; k += W) {
@@ -2896,9 +2913,9 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
         if (slot >= 0) {
           const int64_t idx = hb + (int64_t)fr * K + slot;
           const int2 pt = P.histPT[idx];
-          tokv = pt.y;
+          tokv = packed ? (pt.y < 0 ? pt.y : (pt.y & 0xFF)) : pt.y;
           wv = lex ? P.histW[idx] : -1;
-          slot = P.packed ? (((pt.x & 0xFF) == 0xFF) ? -1 : (pt.x & 0xFF)) : pt.x;
+          slot = packed ? (((pt.x & 0xFF) == 0xFF) ? -1 : (pt.x & 0xFF)) : pt.x;
         }
         tk[fr] = tokv; /* pruned history: -1 below the cut */
         if (wd) {
@@ -2973,9 +2990,9 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
             int tokv = -1, wv = -1;
             if (s >= 0) {
               const int2 pt = cPT[j * K + s];
-              tokv = pt.y;
+              tokv = packed ? (pt.y < 0 ? pt.y : (pt.y & 0xFF)) : pt.y;
               wv = lex ? cW[j * K + s] : -1;
-              s = P.packed ? (((pt.x & 0xFF) == 0xFF) ? -1 : (pt.x & 0xFF)) : pt.x;
+              s = packed ? (((pt.x & 0xFF) == 0xFF) ? -1 : (pt.x & 0xFF)) : pt.x;
             }
             oT[k * F + j] = tokv;
             if (P.words) {
@@ -3002,7 +3019,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
     }
     __syncthreads();
   }
-  if (P.amOut) {
+  if (P.amOut && packed) {
     /* emitting-model scores, oldest frame first: the token rows just written and the
      * emission rows are staged F frames at a time, then hypothesis k (thread k) adds up
      * its path with LDS reads only (the chain is the additions, not the loads) */

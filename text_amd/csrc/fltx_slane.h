@@ -226,7 +226,8 @@ FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mm
 }
 /* padPast: also (re)write the positions past the end of the list (NaN emission = no candidate);
  * with the whole token set listed their content never changes and the prologue writes them once */
-FLTX_DEV void slRowStore(const DecodeParams& P, SlaneLds& S, int q, const SlRowRegs& r, bool padPast) {
+template <typename LDS>
+FLTX_DEV void slRowStore(const DecodeParams& P, LDS& S, int q, const SlRowRegs& r, bool padPast) {
   const int lane = laneId();
   const bool inRow = lane < P.N;
   const int pos = wavePrefixCount(r.listMask);
@@ -878,7 +879,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       P.uttNBeam[b] = popc64(okMask);
       P.uttFrame[b] = ff;
       P.uttTotal[b] = ff;
-      P.uttStatus[b] = 0;
+      P.uttStatus[b] = ST_PACKED;
     }
   }
   if (dead && tid == 0) {

@@ -1,0 +1,903 @@
+/*
+ * fltx_xlane.h -- "lane = (LM state, trie node)" decode of a whole utterance for the
+ * lexicon decoder: LexiconDecoder + ZeroLM over a lexicon without LM scores (every
+ * TrieNode::maxScore zero), CTC, max-merge, beam <= 64, <= 64 tokens, one word per
+ * spelling, every word ending in one separator token, no <unk>, offline.  Included by
+ * fltx_kernels.h after fltx_slane.h, whose organisation, histogram window, scan and
+ * emission-row staging it shares.  Same candidates, same merge groups, same selection as
+ * LexiconDecoder::decodeStep (LexiconDecoder.cpp:32-229) with candidatesStore
+ * (Utils.h:146-225): bit-identical n-best.
+ *
+ * A lane holds the two hypotheses of one (lmState, lex) pair: `nb` = (.., token of the
+ * node, prevBlank = false) and `b` = (.., blank, true), LexiconDecoder.h:79-91.  What the
+ * reference does per hypothesis then has the same fixed shape as in fltx_slane.h:
+ *   * "eat a new token" (:89-110) from a lane to the child node reached by token n comes
+ *     from max(nb, b) -- from b alone when n is the node's own token (:89) -- and is a new
+ *     lane, unless a lane holds that child already: then it joins the child lane's "stay"
+ *     candidate (:168-194) through the child's link to its parent lane;
+ *   * the child's id needs no gather: the trie is laid out breadth first
+ *     (fltx_trie::xnode), child(n) = firstChild + popcount(childMask below n); the child's
+ *     own 32-byte record is fetched once, when its lane is created;
+ *   * blank (:197-213) and stay are the lane's own, and not subject to the token beam;
+ *   * a word ends (:113-142) when the child reached by the separator token carries a
+ *     label: the candidate lands on the root with a new LM state.  This is the one
+ *     many-to-one merge of the lexicon decoder -- several lanes can emit the same word
+ *     from the same LM state, and a lane may already stand on that root -- and it goes
+ *     through a small LDS hash keyed by (LM state, word): one atomic max per candidate,
+ *     resolved after the barrier that also publishes the frame's best candidate (which,
+ *     unlike in the lexicon-free decoder, is not a recurrence: the trie decides what a
+ *     lane can take);
+ *   * an LM state is a number handed out when a word first ends from a given LM state; an
+ *     LDS memo (LM state, word) -> number keeps it stable when the root lane that stood
+ *     for it drops out of the beam and the word is emitted again (lm/LM.h:24-34);
+ *   * a lane is the pair (LM state number, node id), so a lane that comes back after it
+ *     dropped out is recognised by value.  What has to be restored is the link of the
+ *     lanes in the beam that are its trie children: every lane without a parent lane
+ *     enters (LM state, parent node) in a per-frame LDS table, and whoever creates a lane
+ *     looks its pair up there and adopts them.
+ * Waves: token waves (GT list positions each), one for the lanes' own groups (blank,
+ * stay + parent's extension, blank-then-own-token), one for the word ends, one that
+ * stages the emission rows.  Four barriers per frame.
+ */
+#pragma once
+
+constexpr int kXlRoot = 128;  /* slots of the per-frame (LM state, word) merge table */
+constexpr int kXlOrph = 128;  /* slots of the per-frame table of lanes without a parent lane */
+constexpr int kXlMemo = 4096; /* slots of the LM-state memo */
+
+/* the lanes of one frame, one array per field (conflict-free LDS access, and a wave reads only
+ * the fields its role needs) */
+struct XlLanes {
+  double nb[64], b[64];
+  unsigned long long childMask[64], kidsMask[64]; /* XNode of the lane's node */
+  unsigned long long cmask[64];                   /* tokens whose child node holds a lane that links here */
+  uint32_t info[64];       /* own token | history slot of nb << 16 | of b << 24 */
+  uint32_t link[64];       /* lane + 1 of the trie parent's lane, 0 = not in the beam (or root) */
+  uint32_t lmSid[64];      /* LM state */
+  uint32_t node[64];       /* trie node, breadth-first id, 0 = root */
+  uint32_t parent[64];     /* its parent node */
+  uint32_t firstChild[64];
+  int32_t endLabel[64];    /* word that ends when the separator follows, -1 = none */
+  uint32_t dPar[64];       /* root lanes: the LM state the word was emitted from ... */
+  int32_t dWord[64];       /* ... and the word (-1: the start state) */
+};
+
+struct XlRootSlot { /* (LM state, word) -> best candidate landing there this frame, 32 B */
+  unsigned long long key;  /* 0 = free */
+  unsigned long long best; /* order-preserving score key */
+  uint32_t lane;           /* lane + 1 of the root lane that already stands there, 0 = none */
+  uint32_t minLane;        /* lowest arriving lane among those that reach `best` */
+  uint32_t winHyp;         /* its history slot ... */
+  int32_t winWord;         /* ... and word (for the root lane's back-pointer) */
+};
+
+struct XlOrphSlot { /* (LM state, node) -> the lanes whose parent that pair is and has no lane */
+  unsigned long long key; /* 0 = free */
+  unsigned long long lanes;
+};
+
+struct XlMemoSlot {
+  unsigned long long key; /* 0 = free */
+  uint32_t sid, pad;
+};
+
+struct XlaneLds {
+  XlLanes L[2];
+  uint32_t hist[2][kSlNB];
+  double eAll[2][64];
+  double eTok[2][kSlList];
+  unsigned long long tokBit[2][kSlList];
+  SlRow row[2];
+  uint8_t tokId[2][kSlList];
+  XlRootSlot root[kXlRoot];
+  XlOrphSlot orph[2][kXlOrph];
+  XlMemoSlot memo[kXlMemo];
+  unsigned long long bestKey[2]; /* the frame's best candidate (all waves add their own) */
+  XNode rootNode;
+  uint32_t off[32];
+  int32_t newLane[64];
+  uint32_t scal[16];
+  unsigned long long bKey[kSlBCap];
+  uint32_t bOrd[kSlBCap];
+  uint32_t memoUsed, lmNext;
+};
+
+enum { XL_FLAG = 15 }; /* scal[]: a table ran full -> general path */
+
+FLTX_DEV unsigned long long xlKey(uint32_t a, int32_t b) {
+  return ((unsigned long long)(a + 1u) << 32) | (uint32_t)(b + 2);
+}
+FLTX_DEV uint32_t xlHash(unsigned long long k) {
+  return hashKey((uint32_t)k, (uint32_t)(k >> 32), 0x9E3779B9u, 0x7F4A7C15u);
+}
+/* slot of `key` in the per-frame merge table (claimed if new); -1 when the table is full */
+FLTX_DEV int xlRootFind(XlaneLds& S, unsigned long long key) {
+  uint32_t h = xlHash(key) & (kXlRoot - 1);
+  for (int probe = 0; probe < kXlRoot; ++probe) {
+    const unsigned long long old = atomCas64(&S.root[h].key, 0ull, key);
+    if (old == 0ull || old == key) {
+      return (int)h;
+    }
+    h = (h + 1u) & (kXlRoot - 1);
+  }
+  return -1;
+}
+/* a lane without a parent lane announces itself under its parent's pair (<= 64 lanes, 128 slots) */
+FLTX_DEV void xlOrphAdd(XlOrphSlot* tab, unsigned long long key, int lane) {
+  uint32_t h = xlHash(key) & (kXlOrph - 1);
+  for (;;) {
+    const unsigned long long old = atomCas64(&tab[h].key, 0ull, key);
+    if (old == 0ull || old == key) {
+      atomOr64(&tab[h].lanes, 1ull << lane);
+      return;
+    }
+    h = (h + 1u) & (kXlOrph - 1);
+  }
+}
+FLTX_DEV unsigned long long xlOrphGet(const XlOrphSlot* tab, unsigned long long key) {
+  uint32_t h = xlHash(key) & (kXlOrph - 1);
+  for (;;) {
+    const unsigned long long k = tab[h].key;
+    if (k == key) {
+      return tab[h].lanes;
+    }
+    if (k == 0ull) {
+      return 0ull;
+    }
+    h = (h + 1u) & (kXlOrph - 1);
+  }
+}
+
+#define FLTX_XLPROF(i)                                        \
+  do {                                                        \
+    if (PROF && P.prof && (int)threadIdx.x == P.profThread) { \
+      const unsigned long long t_ = devClock();               \
+      acc[(i)] += t_ - tPrev;                                 \
+      tPrev = t_;                                             \
+    }                                                         \
+  } while (0)
+
+/* GT = list positions per token wave (allowed tokens <= GT * (waves - 3)) */
+template <int GT, bool PROF>
+FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
+  XlaneLds& S = *(XlaneLds*)smem;
+  const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
+  const int W = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int lane = laneId(), wave = waveUniform(waveId());
+  const int nW = W >> 6;
+  const int selfWave = nW - 3, wordWave = nW - 2, prepWave = nW - 1;
+  const bool isSelf = wave == selfWave, isWord = wave == wordWave, isSvc = wave == prepWave;
+  const bool isTok = wave < selfWave;
+  const int K = P.K, N = P.N;
+  const int T = P.stepT ? P.stepT[b] : 0;
+  const float* em = P.emissions ? P.emissions + P.emOff[b] : nullptr;
+  const int64_t hbase = P.histOff[b];
+  const double NEG = slNegInf();
+  const int sil = P.sil, blank = P.blank;
+  const int endTok = P.xEndTok; /* the word separator (== sil where this engine is selected) */
+  const double silScore = P.silScore, wordScore = P.wordScore, beamThreshold = P.beamThreshold;
+  int2* const histPT = P.histPT;
+  int32_t* const histW = P.histW;
+  const XNode* const xnode = P.xnode;
+  unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long tPrev = devClock();
+  static_assert(GT >= 3, "the self wave keeps its three groups in the slot arrays");
+
+  /* ---- decodeBegin (LexiconDecoder.cpp:21-30): the start state at the root ------------- */
+  for (int i = tid; i < 2 * 64; i += W) {
+    ((unsigned long long*)S.L[0].cmask)[i & 63] = 0ull;
+    ((unsigned long long*)S.L[1].cmask)[i & 63] = 0ull;
+  }
+  for (int i = tid; i < 2 * kSlNB; i += W) {
+    ((uint32_t*)S.hist)[i] = 0u;
+  }
+  for (int i = tid; i < kXlRoot; i += W) {
+    S.root[i].key = 0ull;
+    S.root[i].best = 0ull;
+    S.root[i].lane = 0u;
+    S.root[i].minLane = 0xFFFFFFFFu;
+  }
+  for (int i = tid; i < 2 * kXlOrph; i += W) {
+    S.orph[0][i].key = 0ull; /* (orph[0..1] are contiguous) */
+    S.orph[0][i].lanes = 0ull;
+  }
+  for (int i = tid; i < kXlMemo; i += W) {
+    S.memo[i].key = 0ull;
+  }
+  if (tid < 32) {
+    S.off[tid] = 0u;
+  }
+  if (tid < 16) {
+    S.scal[tid] = 0u;
+  }
+  if (tid == 0) {
+    const XNode r0 = xnode[0];
+    S.rootNode = r0;
+    XlLanes& L0 = S.L[0];
+    L0.nb[0] = 0.0;
+    L0.b[0] = NEG;
+    L0.childMask[0] = r0.childMask;
+    L0.kidsMask[0] = r0.kidsMask;
+    L0.info[0] = (uint32_t)sil | (0u << 16) | (kSlNoHyp << 24);
+    L0.link[0] = 0u;
+    L0.lmSid[0] = 0u;
+    L0.node[0] = 0u;
+    L0.parent[0] = 0u;
+    L0.firstChild[0] = r0.firstChild;
+    L0.endLabel[0] = r0.endLabel0;
+    L0.dPar[0] = 0x7FFFFFFFu;
+    L0.dWord[0] = -1;
+    S.row[0].nev = 0u;
+    S.row[1].nev = 0u;
+    S.row[0].dead = 0u;
+    S.row[1].dead = 0u;
+    S.bestKey[0] = 0ull;
+    S.bestKey[1] = 0ull;
+    S.memoUsed = 0u;
+    S.lmNext = 1u;
+    histPT[hbase] = make_int2((int)kSlNoHyp, sil);
+    histW[hbase] = -1;
+  }
+  if (tid > 0 && tid < K) {
+    histPT[hbase + tid] = make_int2((int)kSlNoHyp, -1);
+  }
+  float rowA = 0.0f, rowB = 0.0f;
+  if (isSvc) {
+    const float v0 = (T > 0 && lane < N) ? em[lane] : 0.0f;
+    rowA = (T > 1 && lane < N) ? em[(size_t)1 * N + lane] : 0.0f;
+    rowB = (T > 2 && lane < N) ? em[(size_t)2 * N + lane] : 0.0f;
+    /* (the row's `best` is not used by this engine: ctc = false keeps blank in the token list,
+     * which is harmless -- no trie node has a child for it) */
+    SlRowRegs r0 = slRowScan(P, v0, false, 0.0);
+    slRowStore(P, S, 0, r0, true);
+    slRowStore(P, S, 1, r0, true);
+  }
+  ldsBarrier();
+
+  int nState = 1;
+  int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
+  bool dead = false;
+
+  auto frameStep = [&](auto PT, float& rowReg, const int t) {
+    constexpr int p = decltype(PT)::value, q = p ^ 1;
+    const int frameOut = t + 1;
+    const int64_t hrow = hbase + (int64_t)frameOut * K;
+    XlLanes& Lp = S.L[p];
+    XlLanes& Lq = S.L[q];
+    /* ---- phase 1a: own lane, candidates, the merge and orphan tables, the frame's best ------ */
+    const int silPos = S.row[p].silPos;
+    const unsigned long long allow = S.row[p].allow;
+    const bool live = lane < nState && !isSvc;
+    const double nb = live ? Lp.nb[lane] : NEG, bb = live ? Lp.b[lane] : NEG;
+    const uint32_t info = Lp.info[lane];
+    const unsigned long long cm = Lp.cmask[lane];
+    const unsigned long long childMask = Lp.childMask[lane], kidsMask = Lp.kidsMask[lane];
+    const uint32_t lmSid = Lp.lmSid[lane], node = Lp.node[lane];
+    const int32_t endLabel = Lp.endLabel[lane];
+    double ev[GT];
+    unsigned long long tb[GT];
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      ev[j] = 0.0;
+      tb[j] = 0ull;
+    }
+    if (isTok) {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        ev[j] = S.eTok[p][wave * GT + j];
+        tb[j] = S.tokBit[p][wave * GT + j];
+      }
+    }
+    const int last = (int)(info & 0xFFu) & 63;
+    const uint32_t hypNB = (info >> 16) & 0xFFu, hypB = info >> 24;
+    const bool hasNB = hypNB != kSlNoHyp, hasB = hypB != kSlNoHyp;
+    const bool whichB = bb > nb;
+    const double m = whichB ? bb : nb;
+    const uint32_t hypM = whichB ? hypB : hypNB;
+    const bool atRoot = node == 0u;
+    const bool useB = atRoot && last == endTok; /* word end: the nb hypothesis on the root would repeat its token (:114-122) */
+    const double eBlank = S.eAll[p][blank], eLast = S.eAll[p][last], eEnd = S.eAll[p][endTok], eSil = S.eAll[p][sil];
+    int pl = -1;
+    double parNB = NEG, parB = NEG;
+    uint32_t parInfo = 0u;
+    if (isSelf) {
+      pl = live ? (int)Lp.link[lane] - 1 : -1;
+      const int pi = pl >= 0 ? pl : 0;
+      parNB = Lp.nb[pi];
+      parB = Lp.b[pi];
+      parInfo = Lp.info[pi];
+    }
+    FLTX_XLPROF(0);
+    double cs[GT];
+    int cbin[GT];
+    bool cok[GT];
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      cs[j] = NEG;
+      cbin[j] = kSlInvalid;
+      cok[j] = false;
+    }
+    uint32_t parR = kSlNoHyp;
+    int rootSlot = -1;    /* self wave: the root lane's slot in the merge table; word wave: the arrival's */
+    SlRowRegs nextRow = {};
+    if (isSvc) {
+      Lq.cmask[lane] = 0ull;
+      if (lane < 32) {
+        S.off[lane] = 0u;
+      }
+      if (lane == 0) {
+        S.scal[SL_BCNT] = 0u;
+        S.bestKey[q] = 0ull;
+      }
+      if (t + 1 < T) {
+        nextRow = slRowScan(P, rowReg, false, 0.0);
+      }
+      rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
+    } else if (isTok) {
+      /* "eat a new token" into a child that has children (LexiconDecoder.cpp:89-110): every listed
+       * token but the node's own (that one needs the blank in between: the self wave) and those
+       * whose child node holds a lane already (the child lane merges it into its stay) */
+      const unsigned long long ext = childMask & kidsMask;
+      const uint32_t lastLo = last < 32 ? 1u << last : 0u, lastHi = last < 32 ? 0u : 1u << (last - 32);
+      const uint32_t skLo = live ? ((uint32_t)cm | lastLo | ~(uint32_t)ext) : 0xFFFFFFFFu;
+      const uint32_t skHi = live ? ((uint32_t)(cm >> 32) | lastHi | ~(uint32_t)(ext >> 32)) : 0xFFFFFFFFu;
+      const int silJ = silPos - wave * GT;
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        double c = m + ev[j];
+        if (j == silJ) {
+          c = c + silScore;
+        }
+        const uint32_t hit = (skLo & (uint32_t)tb[j]) | (skHi & (uint32_t)(tb[j] >> 32));
+        cs[j] = c;
+        cok[j] = hit == 0u && tb[j] != 0ull && c == c;
+      }
+    } else if (isSelf) {
+      /* blank (:197-213): always tried */
+      double cB = m + eBlank;
+      cs[0] = cB;
+      cok[0] = live;
+      /* stay (:168-194): the node's own token again from the nb hypothesis -- at the root: sil from
+       * either hypothesis -- plus the trie parent's extension by that token.  The extension is a
+       * "(1) try children" candidate and needs the token in the token beam; stay and blank do not
+       * (LexiconDecoder.cpp:61,168,197) */
+      const int lastP = (int)(parInfo & 0xFFu);
+      const uint32_t h1 = (parInfo >> 16) & 0xFFu, h2 = parInfo >> 24;
+      const bool allowLast = ((allow >> last) & 1ull) != 0ull;
+      const bool has0 = atRoot ? true : hasNB;
+      const bool has1 = pl >= 0 && allowLast && last != lastP && h1 != kSlNoHyp;
+      const bool has2 = pl >= 0 && allowLast && h2 != kSlNoHyp;
+      double r0 = (atRoot ? m : nb) + (atRoot ? eSil : eLast);
+      double r1 = has1 ? parNB + eLast : NEG;
+      double r2 = has2 ? parB + eLast : NEG;
+      if (silScore != 0.0) {
+        const bool ls = atRoot || last == sil;
+        r0 = ls ? r0 + silScore : r0;
+        r1 = ls ? r1 + silScore : r1;
+        r2 = ls ? r2 + silScore : r2;
+      }
+      double cR = r0;
+      parR = atRoot ? hypM : hypNB;
+      if (has1 && (r1 > cR || (r1 == cR && h1 < parR))) {
+        cR = r1;
+        parR = h1;
+      }
+      if (has2 && (r2 > cR || (r2 == cR && h2 < parR))) {
+        cR = r2;
+        parR = h2;
+      }
+      cs[1] = cR;
+      cok[1] = live && (has0 || has1 || has2);
+      if (live && atRoot) { /* words ending here this frame join through the merge table */
+        rootSlot = xlRootFind(S, xlKey(Lp.dPar[lane], Lp.dWord[lane]));
+        if (rootSlot >= 0) {
+          S.root[rootSlot].lane = (uint32_t)lane + 1u;
+          atomMax64(&S.root[rootSlot].best, f64Key(cR));
+        }
+      }
+      if (live && !atRoot && pl < 0) { /* no parent lane: whoever creates it this frame finds this lane here */
+        xlOrphAdd(S.orph[p], xlKey(lmSid, (int32_t)Lp.parent[lane]), lane);
+      }
+      /* blank, then the node's own token again (:89 with prevBlank): into the child, if it has children
+       * and no lane */
+      const bool extLast = ((childMask & kidsMask) >> last) & 1ull;
+      double cL = bb + eLast;
+      if (last == sil) {
+        cL = cL + silScore;
+      }
+      cs[2] = cL;
+      cok[2] = live && hasB && extLast && allowLast && ((cm >> last) & 1ull) == 0ull;
+    } else if (isWord) {
+      /* a word ends (:113-142): the child reached by the separator carries a label */
+      const bool can = live && endLabel >= 0 && ((allow >> endTok) & 1ull) != 0ull;
+      const double src = useB ? bb : m;
+      const bool hasSrc = useB ? hasB : true;
+      double c = src + eEnd;
+      if (endTok == sil) {
+        c = c + silScore;
+      }
+      c = (c + P.lmWeight * 0.0) + wordScore; /* ZeroLM, unsmeared lexicon: lmScore - lexMaxScore = 0 */
+      cs[0] = c;
+      cok[0] = can && hasSrc && c == c;
+      if (cok[0]) {
+        rootSlot = xlRootFind(S, xlKey(lmSid, endLabel));
+        if (rootSlot >= 0) {
+          atomMax64(&S.root[rootSlot].best, f64Key(c));
+        }
+      }
+    }
+    if (waveBallot(rootSlot < 0 && ((isSelf && live && atRoot) || (isWord && cok[0]))) != 0ull) {
+      dead = true; /* merge table full: general path (uniform after the barrier below via bestKey = ~0) */
+      if (lane == 0) {
+        S.bestKey[p] = ~0ull;
+      }
+    }
+    { /* the frame's best candidate (Utils.h:131-137) */
+      unsigned long long mx = 0ull;
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        const unsigned long long k = cok[j] ? f64Key(cs[j]) : 0ull;
+        mx = k > mx ? k : mx;
+      }
+      if (waveBallot(mx != 0ull) != 0ull) {
+        mx = waveMax64(mx);
+        if (lane == 0) {
+          atomMax64(&S.bestKey[p], mx);
+        }
+      }
+    }
+    FLTX_XLPROF(1);
+    ldsBarrier(); /* A */
+    /* ---- phase 1b: threshold, merge-table verdicts, histogram ---------------------------- */
+    const unsigned long long bk = S.bestKey[p];
+    if (bk == 0ull || bk == ~0ull) {
+      dead = true;
+      return;
+    }
+    const double best = f64FromKey(bk);
+    if (!(best - best == 0.0)) {
+      dead = true;
+      return;
+    }
+    const double thr = best - beamThreshold;
+    if (isSelf && rootSlot >= 0) { /* the root lane's stay group takes the best word ending on it */
+      const unsigned long long rb = S.root[rootSlot].best;
+      if (rb > f64Key(cs[1])) {
+        cs[1] = f64FromKey(rb);
+        parR = kSlNoHyp; /* back-pointer: read from the slot in the build */
+      }
+    }
+    if (isWord) {
+      /* of the arrivals that reach the slot's best the lowest lane represents them: it is the
+       * back-pointer a root lane takes when a word ending on it beats its own stay, and it is the
+       * candidate for a new root lane when nobody stands there */
+      const bool top = cok[0] && S.root[rootSlot].best == f64Key(cs[0]);
+      if (top) {
+        atomMin32(&S.root[rootSlot].minLane, (uint32_t)lane);
+      }
+      waveSync();
+      const bool rep = top && S.root[rootSlot].minLane == (uint32_t)lane;
+      if (rep) {
+        S.root[rootSlot].winHyp = useB ? hypB : hypM;
+        S.root[rootSlot].winWord = endLabel;
+      }
+      cok[0] = rep && S.root[rootSlot].lane == 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      if (cok[j] && cs[j] >= thr) {
+        cbin[j] = slBin(best, cs[j], winShift, winBase);
+        if (cbin[j] < kSlFar) {
+          atomAdd32(&S.hist[p][cbin[j]], 1u);
+        }
+      }
+    }
+    FLTX_XLPROF(2);
+    ldsBarrier(); /* 1 */
+    /* ---- phase 2: which candidates survive (as fltx_slane.h) ------------------------------ */
+    unsigned long long selMask[GT];
+    SlScan sc;
+    int shift = winShift, base = winBase;
+    unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+    bool full = false;
+    for (;;) {
+      sc = slScan(S.hist[p], K);
+      if (!full && !sc.crossed) {
+        int nFar = 0;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          nFar += popc64(waveBallot(cbin[j] == kSlFar));
+        }
+        if (lane == 0 && nFar > 0) {
+          atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
+        }
+        full = true;
+        ldsBarrier();
+        continue;
+      }
+      if (sc.total <= K) {
+        const int lim = full ? kSlFar : kSlFar - 1;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          selMask[j] = waveBallot(cbin[j] <= lim);
+        }
+        break;
+      }
+      const int need = K - sc.cum;
+      if (sc.cnt == need) {
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          selMask[j] = waveBallot(cbin[j] <= sc.bstar);
+        }
+        break;
+      }
+      if (sc.cnt <= kSlBCap) {
+        uint32_t take = 0u;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          if (cbin[j] == sc.bstar) {
+            const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
+            S.bKey[i] = f64Key(cs[j]);
+            S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+          }
+        }
+        ldsBarrier();
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          if (cbin[j] == sc.bstar) {
+            const unsigned long long k = f64Key(cs[j]);
+            const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+            int rank = 0;
+            for (int i = 0; i < sc.cnt; ++i) {
+              const unsigned long long k2 = S.bKey[i];
+              rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
+            }
+            take |= rank < need ? (1u << j) : 0u;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          selMask[j] = waveBallot(cbin[j] < sc.bstar || ((take >> j) & 1u) != 0u);
+        }
+        break;
+      }
+      {
+        const unsigned long long v = (unsigned long long)(sc.bstar + base);
+        if (sc.bstar > 0 || base == 0) {
+          const unsigned long long l2 = v << shift;
+          bLo = l2 > bLo ? l2 : bLo;
+        }
+        if (sc.bstar < kSlNB - 1) {
+          const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
+          bHi = h2 < bHi ? h2 : bHi;
+        }
+        if (bLo >= bHi) {
+          dead = true;
+          break;
+        }
+        int ns = 0;
+        while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
+          ++ns;
+        }
+        shift = ns;
+        base = (int)(bLo >> ns);
+      }
+      ldsBarrier();
+      for (int i = tid; i < kSlNB; i += W) {
+        S.hist[p][i] = 0u;
+      }
+      ldsBarrier();
+      full = true;
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        if (cbin[j] != kSlInvalid) {
+          cbin[j] = slBin(best, cs[j], shift, base);
+          atomAdd32(&S.hist[p][cbin[j]], 1u);
+        }
+      }
+      ldsBarrier();
+    }
+    if (dead) {
+      return;
+    }
+    if (sc.total > K) {
+      const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
+                                            : (sc.bstar + base) >> (kSlFineShift - shift);
+      winShift = kSlFineShift;
+      winBase = q15 > 256 ? q15 - 256 : 0;
+    }
+    FLTX_XLPROF(3);
+    /* new lanes: survivors first (self wave), then new trie lanes wave by wave, then new roots */
+    int nNewWave = 0;
+    int myNew[GT];
+    int surv = -1;
+    uint32_t hNB = kSlNoHyp, hB = kSlNoHyp;
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      myNew[j] = 0;
+    }
+    if (isTok || isWord) {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        if (selMask[j] != 0ull) {
+          myNew[j] = nNewWave + wavePrefixCount(selMask[j]);
+          nNewWave += popc64(selMask[j]);
+        }
+      }
+      /* order of the new lanes: token waves, self wave (its blank-then-own-token lanes), word wave */
+      const int slot = isTok ? wave : selfWave + 1;
+      if (lane > slot && lane <= selfWave + 2 && nNewWave > 0) {
+        atomAdd32(&S.off[lane], (uint32_t)nNewWave);
+      }
+    } else if (isSelf) {
+      const unsigned long long balB = selMask[0], balR = selMask[1], balL = selMask[2];
+      const unsigned long long balS = balB | balR;
+      const bool sR = ((balR >> lane) & 1ull) != 0ull;
+      surv = ((balS >> lane) & 1ull) ? wavePrefixCount(balS) : -1;
+      hNB = (uint32_t)(wavePrefixCount(balR) + wavePrefixCount(balB));
+      hB = hNB + (sR ? 1u : 0u);
+      myNew[2] = wavePrefixCount(balL);
+      nNewWave = popc64(balL);
+      S.newLane[lane] = surv;
+      if (lane == 0) {
+        S.scal[SL_NSURV] = (uint32_t)popc64(balS);
+        S.scal[SL_NHSURV] = (uint32_t)(popc64(balR) + popc64(balB));
+      }
+      if (lane > selfWave && lane <= selfWave + 2 && nNewWave > 0) {
+        atomAdd32(&S.off[lane], (uint32_t)nNewWave);
+      }
+      /* the survivors' links, here and not in the build: the builders overwrite the link of the
+       * lanes they adopt */
+      waveSync();
+      const int pln = pl >= 0 ? S.newLane[pl] : -1;
+      if (surv >= 0) {
+        Lq.link[surv] = (uint32_t)(pln + 1);
+      }
+      pl = pln; /* from here on: the parent's lane in the next frame */
+    }
+    FLTX_XLPROF(4);
+    ldsBarrier(); /* 2 */
+    /* ---- phase 3: every survivor is written by the lane that evaluated it ------------------ */
+    const int nSurv = (int)S.scal[SL_NSURV], nHSurv = (int)S.scal[SL_NHSURV];
+    const int offW = (int)S.off[isTok ? wave : (isSelf ? selfWave : selfWave + 1)], nNew = (int)S.off[selfWave + 2];
+    const int myNewLane = S.newLane[lane];
+    /* the lanes in the beam whose parent pair (lm, nd) is: they link to the new lane nl */
+    auto adopt = [&](uint32_t lm, uint32_t nd, int nl) {
+      unsigned long long o = xlOrphGet(S.orph[p], xlKey(lm, (int32_t)nd));
+      unsigned long long toks = 0ull;
+      while (o) {
+        const int x = __builtin_ctzll(o);
+        o &= o - 1ull;
+        const int nx = S.newLane[x];
+        if (nx >= 0) {
+          Lq.link[nx] = (uint32_t)nl + 1u;
+          toks |= 1ull << (Lp.info[x] & 63u);
+        }
+      }
+      if (toks) {
+        atomOr64(&Lq.cmask[nl], toks);
+      }
+    };
+    /* a new lane on the child reached by token n (the child's record comes from HBM: the one
+     * gather of a frame) */
+    auto newChild = [&](int idx, double c, int n, uint32_t hp) {
+      const int nl = nSurv + idx;
+      const uint32_t hyp = (uint32_t)(nHSurv + idx);
+      const uint32_t child = Lp.firstChild[lane] + (uint32_t)popc64(childMask & ((1ull << n) - 1ull));
+      const XNode cx = xnode[child];
+      Lq.nb[nl] = c;
+      Lq.b[nl] = NEG;
+      Lq.childMask[nl] = cx.childMask;
+      Lq.kidsMask[nl] = cx.kidsMask;
+      Lq.info[nl] = (uint32_t)n | (hyp << 16) | (kSlNoHyp << 24);
+      Lq.link[nl] = (uint32_t)(myNewLane + 1);
+      Lq.lmSid[nl] = lmSid;
+      Lq.node[nl] = child;
+      Lq.parent[nl] = node;
+      Lq.firstChild[nl] = cx.firstChild;
+      Lq.endLabel[nl] = cx.endLabel0;
+      Lq.dPar[nl] = 0u;
+      Lq.dWord[nl] = -1;
+      if (myNewLane >= 0) {
+        atomOr64(&Lq.cmask[myNewLane], 1ull << n);
+      }
+      histPT[hrow + hyp] = make_int2((int)hp, n);
+      histW[hrow + hyp] = -1;
+      adopt(lmSid, child, nl);
+    };
+    if (isSvc) {
+      if (lane >= nHSurv + nNew && lane < K) {
+        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
+      }
+      if (t + 1 < T) {
+        slRowStore(P, S, q, nextRow, P.Kt < N);
+      }
+      ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+      ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = lane; i < kXlRoot; i += 64) { /* the merge table of the next frame starts empty (winHyp /
+                                                    winWord, which the self wave reads now, stay) */
+        S.root[i].key = 0ull;
+        S.root[i].best = 0ull;
+        S.root[i].lane = 0u;
+        S.root[i].minLane = 0xFFFFFFFFu;
+      }
+      for (int i = lane; i < kXlOrph; i += 64) {
+        S.orph[q][i].key = 0ull;
+        S.orph[q][i].lanes = 0ull;
+      }
+    } else if (isTok) {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        if (selMask[j] != 0ull) {
+          if ((selMask[j] >> lane) & 1ull) {
+            newChild(offW + myNew[j], cs[j], (int)S.tokId[p][wave * GT + j], hypM);
+          }
+        }
+      }
+    } else if (isSelf) {
+      if (surv >= 0) {
+        const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
+        Lq.nb[surv] = sR ? cs[1] : NEG;
+        Lq.b[surv] = sB ? cs[0] : NEG;
+        Lq.childMask[surv] = childMask;
+        Lq.kidsMask[surv] = kidsMask;
+        Lq.info[surv] = (uint32_t)last | ((sR ? hNB : kSlNoHyp) << 16) | ((sB ? hB : kSlNoHyp) << 24);
+        Lq.lmSid[surv] = lmSid;
+        Lq.node[surv] = node;
+        Lq.parent[surv] = Lp.parent[lane];
+        Lq.firstChild[surv] = Lp.firstChild[lane];
+        Lq.endLabel[surv] = endLabel;
+        Lq.dPar[surv] = Lp.dPar[lane];
+        Lq.dWord[surv] = Lp.dWord[lane];
+        if (pl >= 0) {
+          atomOr64(&Lq.cmask[pl], 1ull << last);
+        }
+        if (sR) {
+          uint32_t hp = parR;
+          int32_t wd = -1;
+          if (hp == kSlNoHyp) { /* a word ending on this root beat its own stay */
+            hp = S.root[rootSlot].winHyp;
+            wd = S.root[rootSlot].winWord;
+          }
+          histPT[hrow + hNB] = make_int2((int)hp, atRoot ? sil : last);
+          histW[hrow + hNB] = wd;
+        }
+        if (sB) {
+          histPT[hrow + hB] = make_int2((int)hypM, blank);
+          histW[hrow + hB] = -1;
+        }
+      }
+      if ((selMask[2] >> lane) & 1ull) {
+        newChild(offW + myNew[2], cs[2], last, hypB);
+      }
+    } else if (isWord) {
+      if ((selMask[0] >> lane) & 1ull) { /* a word ended and nobody stood on that root: a new root lane */
+        const int nl = nSurv + offW + myNew[0];
+        const uint32_t hyp = (uint32_t)(nHSurv + offW + myNew[0]);
+        const uint32_t hp = useB ? hypB : hypM;
+        /* the LM state's number (memo: the same (LM state, word) gives the same state back) */
+        const unsigned long long mkey = xlKey(lmSid, endLabel);
+        uint32_t h = xlHash(mkey) & (kXlMemo - 1);
+        uint32_t sid = 0u;
+        for (int probe = 0;; ++probe) {
+          const unsigned long long old = atomCas64(&S.memo[h].key, 0ull, mkey);
+          if (old == 0ull) {
+            sid = atomAdd32(&S.lmNext, 1u);
+            S.memo[h].sid = sid;
+            if (atomAdd32(&S.memoUsed, 1u) > (uint32_t)(kXlMemo * 3 / 4)) {
+              atomOr32(&S.scal[XL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
+            }
+            break;
+          }
+          if (old == mkey) {
+            sid = S.memo[h].sid;
+            break;
+          }
+          h = (h + 1u) & (kXlMemo - 1);
+          if (probe > kXlMemo) {
+            atomOr32(&S.scal[XL_FLAG], 1u);
+            break;
+          }
+        }
+        const XNode r0 = S.rootNode;
+        Lq.nb[nl] = cs[0];
+        Lq.b[nl] = NEG;
+        Lq.childMask[nl] = r0.childMask;
+        Lq.kidsMask[nl] = r0.kidsMask;
+        Lq.info[nl] = (uint32_t)endTok | (hyp << 16) | (kSlNoHyp << 24);
+        Lq.link[nl] = 0u;
+        Lq.lmSid[nl] = sid;
+        Lq.node[nl] = 0u;
+        Lq.parent[nl] = 0u;
+        Lq.firstChild[nl] = r0.firstChild;
+        Lq.endLabel[nl] = r0.endLabel0;
+        Lq.dPar[nl] = lmSid;
+        Lq.dWord[nl] = endLabel;
+        histPT[hrow + hyp] = make_int2((int)hp, endTok);
+        histW[hrow + hyp] = endLabel;
+        adopt(sid, 0u, nl);
+      }
+    }
+    nState = nSurv + nNew;
+    FLTX_XLPROF(5);
+    ldsBarrier(); /* 3 */
+    if (S.scal[XL_FLAG] != 0u) {
+      dead = true;
+    }
+    FLTX_XLPROF(6);
+  };
+  {
+    int t = 0;
+    for (; t + 1 < T && !dead; t += 2) {
+      frameStep(SlParity<0>(), rowA, t);
+      if (dead) {
+        break;
+      }
+      frameStep(SlParity<1>(), rowB, t + 1);
+    }
+    if (!dead && t < T) {
+      frameStep(SlParity<0>(), rowA, t);
+    }
+  }
+
+  /* ---- decodeEnd (LexiconDecoder.cpp:231-274): if any hypothesis stands on the root only those
+   * finish; finish() keeps the LM state (ZeroLM), token = sil; the two hypotheses of a lane merge;
+   * sorted n-best ---------------------------------------------------------------------------- */
+  const int pe = T & 1;
+  const int ff = T + 1;
+  if (wave == 0 && !dead) {
+    const bool live = lane < nState;
+    const XlLanes& Le = S.L[pe];
+    const int li = live ? lane : 0;
+    const double nb = live ? Le.nb[li] : NEG, bb = live ? Le.b[li] : NEG;
+    const uint32_t info = Le.info[li];
+    const bool onRoot = Le.node[li] == 0u;
+    const bool whichB = bb > nb;
+    const double m = whichB ? bb : nb;
+    const uint32_t hp = whichB ? (info >> 24) : ((info >> 16) & 0xFFu);
+    const bool nice = waveBallot(live && onRoot) != 0ull;
+    const bool cand = live && (!nice || onRoot);
+    /* candidatesBestScore_ is the best of the candidates that finish */
+    const unsigned long long bk = waveMax64(cand ? f64Key(m) : 0ull);
+    const double thr = f64FromKey(bk) - P.beamThreshold;
+    const bool ok = cand && bk != 0ull && m >= thr;
+    const unsigned long long key = ok ? f64Key(m) : 0ull;
+    int rank = 0;
+    for (int i = 0; i < nState; ++i) {
+      const uint32_t lo = waveReadLane32((uint32_t)key, i), hi = waveReadLane32((uint32_t)(key >> 32), i);
+      const unsigned long long k2 = ((unsigned long long)hi << 32) | lo;
+      const uint32_t h2 = waveReadLane32(hp, i);
+      rank += (k2 > key || (k2 == key && h2 < hp)) ? 1 : 0;
+    }
+    const unsigned long long okMask = waveBallot(ok);
+    if (ok) {
+      const size_t g = ((size_t)b * K + rank) * 3;
+      P.outScores[g + 0] = m;
+      P.outScores[g + 1] = 0.0; /* emitting-model score: the back-trace kernel fills it in */
+      P.outScores[g + 2] = 0.0; /* ZeroLM over an unsmeared lexicon: every lmScore term is 0 */
+      histPT[hbase + (int64_t)ff * K + rank] = make_int2((int)hp, sil);
+      histW[hbase + (int64_t)ff * K + rank] = -1;
+    }
+    if (lane == 0) {
+      P.outN[b] = popc64(okMask);
+      P.uttNBeam[b] = popc64(okMask);
+      P.uttFrame[b] = ff;
+      P.uttTotal[b] = ff;
+      P.uttStatus[b] = ST_PACKED;
+    }
+  }
+  if (dead && tid == 0) {
+    P.outN[b] = 0;
+    P.uttNBeam[b] = 0;
+    P.uttFrame[b] = ff;
+    P.uttTotal[b] = ff;
+    P.uttStatus[b] = ST_SELECT_FALLBACK;
+  }
+  if (PROF && P.prof && tid == P.profThread) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      P.prof[(size_t)b * 8 + i] = acc[i];
+    }
+  }
+}
+#undef FLTX_XLPROF
