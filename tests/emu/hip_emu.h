@@ -147,6 +147,16 @@ FLTX_DEV uint32_t waveShfl32(uint32_t v, int src) {
   return emuExchange(v, [src](const unsigned long long* s) { return (uint32_t)s[src & 63]; });
 }
 FLTX_DEV uint32_t waveReadLane32(uint32_t v, int src) { return waveShfl32(v, src); }
+FLTX_DEV uint32_t waveGather32(uint32_t v, int src) { return waveShfl32(v, src); }
+FLTX_DEV unsigned long long waveShfl64(unsigned long long v, int src) {
+  return emuExchange(v, [src](const unsigned long long* s) { return s[src & 63]; });
+}
+/* lane i of a row of 16 takes the value of lane (i - R) mod 16 of its row (DPP row_ror) */
+template <int R>
+FLTX_DEV unsigned long long waveRowRor64(unsigned long long v) {
+  const int lane = (int)(threadIdx.x & 63);
+  return waveShfl64(v, (lane & ~15) | ((lane - R) & 15));
+}
 FLTX_DEV unsigned long long waveMax64(unsigned long long v) {
   return emuExchange(v, [](const unsigned long long* s) {
     unsigned long long m = 0;

@@ -1222,7 +1222,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       d->opt.criterion == FLTX_CRITERION_CTC && !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) &&
       K <= 64 && N <= 64 && d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N && d->blank >= 0 &&
       d->blank < N && (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
-    static const int geo[][2] = {{512, 3}, {576, 5}, {640, 10}};
+    static const int geo[][2] = {{512, 2}, {512, 3}, {640, 2}, {576, 5}, {640, 10}};
     for (const auto& g : geo) {
       if ((d->userThreads && d->threads != g[0]) || (d->slaneThreads && d->slaneThreads != g[0])) {
         continue;
@@ -1589,6 +1589,8 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       xlaneUtterance<5, false>(*pp, smem);
     } else if (xl == 10) {
       xlaneUtterance<10, false>(*pp, smem);
+    } else if (xl == 2) {
+      xlaneUtterance<2, false>(*pp, smem);
     } else if (sl == 4) {
       slaneUtterance<4, false>(*pp, smem);
     } else if (sl == 5) {
@@ -1720,6 +1722,8 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     }                                                                                            \
   } while (0)
     switch (W * 100 + d->xlane) {
+      case 51202: FLTX_LAUNCH_XLANE(512, 2); break;
+      case 64002: FLTX_LAUNCH_XLANE(640, 2); break;
       case 51203: FLTX_LAUNCH_XLANE(512, 3); break;
       case 57605: FLTX_LAUNCH_XLANE(576, 5); break;
       case 64010: FLTX_LAUNCH_XLANE(640, 10); break;

@@ -42,6 +42,8 @@
 #define FLTX_G11(W) FLTX_SLANE_SET(true)
 /* lane = (LM state, trie node) decode (fltx_xlane.h): three waves do not evaluate listed tokens */
 #define FLTX_XLANE_SET(PROF)                               \
+  FLTX_INST(fltx_decode_kernel_xlane<512, 2, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<640, 2, PROF>)        \
   FLTX_INST(fltx_decode_kernel_xlane<512, 3, PROF>)        \
   FLTX_INST(fltx_decode_kernel_xlane<576, 5, PROF>)        \
   FLTX_INST(fltx_decode_kernel_xlane<640, 10, PROF>)

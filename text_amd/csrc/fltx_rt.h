@@ -89,6 +89,13 @@ FLTX_DEV uint32_t waveReadLane32(uint32_t v, int src) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
 }
 FLTX_DEV int waveShflUpI(int v, int d) { return __shfl_up(v, d, 64); }
+/* per-lane source (ds_bpermute) */
+FLTX_DEV uint32_t waveGather32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+FLTX_DEV unsigned long long waveShfl64(unsigned long long v, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+  const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
 FLTX_DEV unsigned long long waveShflXor64(unsigned long long v, int m) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   lo = (uint32_t)__shfl_xor((int)lo, m, 64);
@@ -147,6 +154,15 @@ FLTX_DEV unsigned long long dppTake64(unsigned long long v) {
   v = OP(v, TAKE<0x118, 0xf>(v)); /* row_shr:8 */  \
   v = OP(v, TAKE<0x142, 0xa>(v)); /* row_bcast:15 -> rows 1,3 */ \
   v = OP(v, TAKE<0x143, 0xc>(v)); /* row_bcast:31 -> rows 2,3 */
+/* lane i of a row of 16 takes the value of lane (i - R) mod 16 of its row */
+template <int R>
+FLTX_DEV unsigned long long waveRowRor64(unsigned long long v) {
+  if constexpr (R == 0) {
+    return v;
+  } else {
+    return dppTake64<0x120 + R, 0xf>(v);
+  }
+}
 FLTX_DEV unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
 FLTX_DEV uint32_t uadd32(uint32_t a, uint32_t b) { return a + b; }
 FLTX_DEV unsigned long long waveBcastLast64(unsigned long long v) {

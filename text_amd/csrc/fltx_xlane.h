@@ -36,7 +36,7 @@
  *     enters (LM state, parent node) in a per-frame LDS table, and whoever creates a lane
  *     looks its pair up there and adopts them.
  * Waves: token waves (GT list positions each), one for the lanes' own groups (blank,
- * stay + parent's extension, blank-then-own-token), one for the word ends, one that
+ * stay + parent's extension), one for the word ends and blank-then-own-token, one that
  * stages the emission rows.  Four barriers per frame.
  */
 #pragma once
@@ -44,6 +44,7 @@
 constexpr int kXlRoot = 128;  /* slots of the per-frame (LM state, word) merge table */
 constexpr int kXlOrph = 128;  /* slots of the per-frame table of lanes without a parent lane */
 constexpr int kXlMemo = 4096; /* slots of the LM-state memo */
+constexpr int kXlWarmBin = 320; /* candidates below this bin of the window (the last K-th sits at 256) get their child node prefetched */
 
 /* the lanes of one frame, one array per field (conflict-free LDS access, and a wave reads only
  * the fields its role needs) */
@@ -148,6 +149,38 @@ FLTX_DEV unsigned long long xlOrphGet(const XlOrphSlot* tab, unsigned long long 
   }
 }
 
+/* The token beam of a row of N <= 32 emissions (LexiconDecoder.cpp:42-51: the beamSizeToken largest,
+ * ties to the lower index), all pairs compared with 16 in-row rotations: the four rows of 16
+ * lanes take (tokens 0-15 among themselves), (16-31 among themselves), (0-15 against 16-31) and
+ * (16-31 against 0-15).  Keys are made unique by the index, so one 64-bit compare orders a pair. */
+struct XlRank {
+  unsigned long long mine, src;
+  int part;
+};
+FLTX_DEV XlRank xlRankBegin(float v, int N) {
+  const int lane = laneId();
+  const int tok = lane & 31;
+  const float vt = __uint_as_float(waveGather32(__float_as_uint(v + 0.0f), tok)); /* (-0 -> +0: equal as floats) */
+  XlRank r;
+  r.mine = tok < N ? (((unsigned long long)f32Key(vt) << 6) | (unsigned long long)(63 - tok)) : 0ull;
+  const unsigned long long other = waveShfl64(r.mine, lane ^ 16);
+  r.src = lane < 32 ? r.mine : other;
+  r.part = 0;
+  return r;
+}
+template <int R0, int R1>
+FLTX_DEV void xlRankRange(XlRank& r) {
+  if constexpr (R0 < R1) {
+    r.part += waveRowRor64<R0>(r.src) > r.mine ? 1 : 0;
+    xlRankRange<R0 + 1, R1>(r);
+  }
+}
+FLTX_DEV unsigned long long xlRankEnd(const XlRank& r, int N, int Kt) {
+  const int lane = laneId();
+  const int tot = r.part + (int)waveGather32((uint32_t)r.part, lane ^ 32);
+  return waveBallot(lane < N && lane < 32 && tot < Kt);
+}
+
 #define FLTX_XLPROF(i)                                        \
   do {                                                        \
     if (PROF && P.prof && (int)threadIdx.x == P.profThread) { \
@@ -181,7 +214,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
   const XNode* const xnode = P.xnode;
   unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
   unsigned long long tPrev = devClock();
-  static_assert(GT >= 3, "the self wave keeps its three groups in the slot arrays");
+  static_assert(GT >= 2, "the self and word waves keep their two groups in the slot arrays");
 
   /* ---- decodeBegin (LexiconDecoder.cpp:21-30): the start state at the root ------------- */
   for (int i = tid; i < 2 * 64; i += W) {
@@ -319,7 +352,22 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     }
     uint32_t parR = kSlNoHyp;
     int rootSlot = -1;    /* self wave: the root lane's slot in the merge table; word wave: the arrival's */
+    /* staging wave: the token beam of the next frame's row (LexiconDecoder.cpp:42-51: top beamSizeToken
+     * by emission, ties to the lower index) is ranked in three pieces, in the gaps this wave has */
     SlRowRegs nextRow = {};
+    const float rv = rowReg;
+    int rk = 0;
+    auto rankPart = [&](int m0, int m1) {
+      for (int mm = m0; mm < m1; ++mm) {
+        const float o = __uint_as_float(waveReadLane32(__float_as_uint(rv), mm));
+        rk += (o > rv || (o == rv && mm < lane)) ? 1 : 0;
+      }
+    };
+    const bool needRank = P.Kt < N && t + 1 < T;
+    const int rk1 = N / 3, rk2 = 2 * N / 3;
+    /* (rows of <= 32 finite emissions: all pairs by row rotations; else one source token at a time) */
+    const bool fastRank = needRank && N <= 32 && isSvc && waveBallot(lane < N && !(rv == rv)) == 0ull;
+    XlRank rs = {};
     if (isSvc) {
       Lq.cmask[lane] = 0ull;
       if (lane < 32) {
@@ -329,8 +377,11 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
         S.scal[SL_BCNT] = 0u;
         S.bestKey[q] = 0ull;
       }
-      if (t + 1 < T) {
-        nextRow = slRowScan(P, rowReg, false, 0.0);
+      if (fastRank) {
+        rs = xlRankBegin(rv, N);
+        xlRankRange<0, 4>(rs);
+      } else if (needRank) {
+        rankPart(0, rk1);
       }
       rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
     } else if (isTok) {
@@ -395,18 +446,6 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
           atomMax64(&S.root[rootSlot].best, f64Key(cR));
         }
       }
-      if (live && !atRoot && pl < 0) { /* no parent lane: whoever creates it this frame finds this lane here */
-        xlOrphAdd(S.orph[p], xlKey(lmSid, (int32_t)Lp.parent[lane]), lane);
-      }
-      /* blank, then the node's own token again (:89 with prevBlank): into the child, if it has children
-       * and no lane */
-      const bool extLast = ((childMask & kidsMask) >> last) & 1ull;
-      double cL = bb + eLast;
-      if (last == sil) {
-        cL = cL + silScore;
-      }
-      cs[2] = cL;
-      cok[2] = live && hasB && extLast && allowLast && ((cm >> last) & 1ull) == 0ull;
     } else if (isWord) {
       /* a word ends (:113-142): the child reached by the separator carries a label */
       const bool can = live && endLabel >= 0 && ((allow >> endTok) & 1ull) != 0ull;
@@ -425,6 +464,16 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
           atomMax64(&S.root[rootSlot].best, f64Key(c));
         }
       }
+      /* blank, then the node's own token again (:89 with prevBlank): into the child, if it has children
+       * and no lane */
+      const bool extLast = ((childMask & kidsMask) >> last) & 1ull;
+      const bool allowLast = ((allow >> last) & 1ull) != 0ull;
+      double cL = bb + eLast;
+      if (last == sil) {
+        cL = cL + silScore;
+      }
+      cs[1] = cL;
+      cok[1] = live && hasB && extLast && allowLast && ((cm >> last) & 1ull) == 0ull && cL == cL;
     }
     if (waveBallot(rootSlot < 0 && ((isSelf && live && atRoot) || (isWord && cok[0]))) != 0ull) {
       dead = true; /* merge table full: general path (uniform after the barrier below via bestKey = ~0) */
@@ -483,12 +532,35 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       }
       cok[0] = rep && S.root[rootSlot].lane == 0u;
     }
+    if (isSvc && fastRank) {
+      xlRankRange<4, 10>(rs);
+    } else if (isSvc && needRank) {
+      rankPart(rk1, rk2);
+    }
+    if (isSelf && live && !atRoot && pl < 0) { /* no parent lane: whoever creates it this frame finds this lane here */
+      xlOrphAdd(S.orph[p], xlKey(lmSid, (int32_t)Lp.parent[lane]), lane);
+    }
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
       if (cok[j] && cs[j] >= thr) {
         cbin[j] = slBin(best, cs[j], winShift, winBase);
         if (cbin[j] < kSlFar) {
           atomAdd32(&S.hist[p][cbin[j]], 1u);
+        }
+      }
+    }
+    /* the record of a child node is read when its lane is created (phase 3); touching it now, for
+     * the candidates that land in the part of the window where survivors are found, brings its
+     * cache line into this CU's L1 while the selection runs */
+    uint32_t warm = 0u;
+    if (isTok || isWord) {
+      const uint32_t fc = Lp.firstChild[lane];
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        if (cbin[j] < kXlWarmBin && (isTok || j == 1)) {
+          const int n = isTok ? __builtin_ctzll(tb[j] | (1ull << 63)) : last;
+          const uint32_t child = fc + (uint32_t)popc64(childMask & ((1ull << n) - 1ull));
+          warm += ((const volatile uint32_t*)(xnode + child))[2];
         }
       }
     }
@@ -512,6 +584,9 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
           atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
         }
         full = true;
+        if (PROF) {
+          acc[7] += 1000000ull; /* frames that had to count the far candidates */
+        }
         ldsBarrier();
         continue;
       }
@@ -532,6 +607,9 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
         break;
       }
       if (sc.cnt <= kSlBCap) {
+        if (PROF) {
+          acc[7] += 1ull; /* frames that rank the members of the K-th best's bin */
+        }
         uint32_t take = 0u;
 #pragma unroll
         for (int j = 0; j < GT; ++j) {
@@ -575,6 +653,9 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
           dead = true;
           break;
         }
+        if (PROF) {
+          acc[7] += 1000ull; /* histogram passes over a narrowed bracket */
+        }
         int ns = 0;
         while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
           ++ns;
@@ -608,6 +689,19 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     }
     FLTX_XLPROF(3);
     /* new lanes: survivors first (self wave), then new trie lanes wave by wave, then new roots */
+    uint32_t pend = 0u;         /* list positions of this lane that become new lanes */
+    int planN = 0;
+    uint32_t planNode = 0u;     /* the child the next new lane of this lane stands on, its record ... */
+    XNode planX = {};
+    unsigned long long planOrph = 0ull; /* ... and the lanes in the beam whose parent pair it is */
+    uint32_t rootSid = 0u;
+    unsigned long long rootOrph = 0ull;
+    auto planChild = [&](int n) {
+      planN = n;
+      planNode = Lp.firstChild[lane] + (uint32_t)popc64(childMask & ((1ull << n) - 1ull));
+      planX = xnode[planNode];
+      planOrph = xlOrphGet(S.orph[p], xlKey(lmSid, (int32_t)planNode));
+    };
     int nNewWave = 0;
     int myNew[GT];
     int surv = -1;
@@ -624,27 +718,63 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
           nNewWave += popc64(selMask[j]);
         }
       }
-      /* order of the new lanes: token waves, self wave (its blank-then-own-token lanes), word wave */
+      /* order of the new lanes: token waves, then the word wave (new roots, blank-then-own-token lanes) */
       const int slot = isTok ? wave : selfWave + 1;
       if (lane > slot && lane <= selfWave + 2 && nNewWave > 0) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
       }
+      /* what a new lane needs and is known already: the child's record (one 32-byte gather from HBM,
+       * in flight across the barrier), the lanes it adopts, the LM state of a new root */
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        pend |= (isTok || j == 1) ? (uint32_t)((selMask[j] >> lane) & 1ull) << j : 0u;
+      }
+      if (pend) {
+        const int j0 = __builtin_ctz(pend);
+        unsigned long long tbj = tb[0];
+#pragma unroll
+        for (int j = 1; j < GT; ++j) {
+          tbj = j == j0 ? tb[j] : tbj;
+        }
+        planChild(isTok ? __builtin_ctzll(tbj | (1ull << 63)) : last);
+      }
+      if (isWord && ((selMask[0] >> lane) & 1ull)) {
+        /* the LM state's number (memo: the same (LM state, word) gives the same state back) */
+        const unsigned long long mkey = xlKey(lmSid, endLabel);
+        uint32_t h = xlHash(mkey) & (kXlMemo - 1);
+        for (int probe = 0;; ++probe) {
+          const unsigned long long old = atomCas64(&S.memo[h].key, 0ull, mkey);
+          if (old == 0ull) {
+            rootSid = atomAdd32(&S.lmNext, 1u);
+            S.memo[h].sid = rootSid;
+            if (atomAdd32(&S.memoUsed, 1u) > (uint32_t)(kXlMemo * 3 / 4)) {
+              atomOr32(&S.scal[XL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
+            }
+            break;
+          }
+          if (old == mkey) {
+            rootSid = S.memo[h].sid;
+            break;
+          }
+          h = (h + 1u) & (kXlMemo - 1);
+          if (probe > kXlMemo) {
+            atomOr32(&S.scal[XL_FLAG], 1u);
+            break;
+          }
+        }
+        rootOrph = xlOrphGet(S.orph[p], xlKey(rootSid, 0));
+      }
     } else if (isSelf) {
-      const unsigned long long balB = selMask[0], balR = selMask[1], balL = selMask[2];
+      const unsigned long long balB = selMask[0], balR = selMask[1];
       const unsigned long long balS = balB | balR;
       const bool sR = ((balR >> lane) & 1ull) != 0ull;
       surv = ((balS >> lane) & 1ull) ? wavePrefixCount(balS) : -1;
       hNB = (uint32_t)(wavePrefixCount(balR) + wavePrefixCount(balB));
       hB = hNB + (sR ? 1u : 0u);
-      myNew[2] = wavePrefixCount(balL);
-      nNewWave = popc64(balL);
       S.newLane[lane] = surv;
       if (lane == 0) {
         S.scal[SL_NSURV] = (uint32_t)popc64(balS);
         S.scal[SL_NHSURV] = (uint32_t)(popc64(balR) + popc64(balB));
-      }
-      if (lane > selfWave && lane <= selfWave + 2 && nNewWave > 0) {
-        atomAdd32(&S.off[lane], (uint32_t)nNewWave);
       }
       /* the survivors' links, here and not in the build: the builders overwrite the link of the
        * lanes they adopt */
@@ -654,6 +784,20 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
         Lq.link[surv] = (uint32_t)(pln + 1);
       }
       pl = pln; /* from here on: the parent's lane in the next frame */
+    } else if (isSvc && t + 1 < T) {
+      nextRow.v = rv;
+      nextRow.allow = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
+      if (fastRank) {
+        xlRankRange<10, 16>(rs);
+        nextRow.allow = xlRankEnd(rs, N, P.Kt);
+      } else if (needRank) {
+        rankPart(rk2, N);
+        nextRow.allow = waveBallot(lane < N && rk < P.Kt);
+      }
+      nextRow.listMask = nextRow.allow;
+      nextRow.nList = popc64(nextRow.allow);
+      nextRow.best = 0.0; /* (this engine takes the frame's best from the candidates) */
+      nextRow.dead = false;
     }
     FLTX_XLPROF(4);
     ldsBarrier(); /* 2 */
@@ -662,8 +806,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     const int offW = (int)S.off[isTok ? wave : (isSelf ? selfWave : selfWave + 1)], nNew = (int)S.off[selfWave + 2];
     const int myNewLane = S.newLane[lane];
     /* the lanes in the beam whose parent pair (lm, nd) is: they link to the new lane nl */
-    auto adopt = [&](uint32_t lm, uint32_t nd, int nl) {
-      unsigned long long o = xlOrphGet(S.orph[p], xlKey(lm, (int32_t)nd));
+    auto adopt = [&](unsigned long long o, int nl) {
       unsigned long long toks = 0ull;
       while (o) {
         const int x = __builtin_ctzll(o);
@@ -678,13 +821,13 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
         atomOr64(&Lq.cmask[nl], toks);
       }
     };
-    /* a new lane on the child reached by token n (the child's record comes from HBM: the one
-     * gather of a frame) */
-    auto newChild = [&](int idx, double c, int n, uint32_t hp) {
+    /* a new lane on the planned child */
+    auto newChild = [&](int idx, double c, uint32_t hp) {
       const int nl = nSurv + idx;
       const uint32_t hyp = (uint32_t)(nHSurv + idx);
-      const uint32_t child = Lp.firstChild[lane] + (uint32_t)popc64(childMask & ((1ull << n) - 1ull));
-      const XNode cx = xnode[child];
+      const int n = planN;
+      const uint32_t child = planNode;
+      const XNode cx = planX;
       Lq.nb[nl] = c;
       Lq.b[nl] = NEG;
       Lq.childMask[nl] = cx.childMask;
@@ -703,7 +846,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       }
       histPT[hrow + hyp] = make_int2((int)hp, n);
       histW[hrow + hyp] = -1;
-      adopt(lmSid, child, nl);
+      adopt(planOrph, nl);
     };
     if (isSvc) {
       if (lane >= nHSurv + nNew && lane < K) {
@@ -726,13 +869,27 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
         S.orph[q][i].lanes = 0ull;
       }
     } else if (isTok) {
+      /* most lanes create at most one: every round takes each lane's lowest pending position */
+      bool first = true;
+      while (waveBallot(pend != 0u) != 0ull) {
+        if (pend) {
+          const int j0 = __builtin_ctz(pend);
+          pend &= pend - 1u;
+          double c = cs[0];
+          int mn = myNew[0];
+          unsigned long long tbj = tb[0];
 #pragma unroll
-      for (int j = 0; j < GT; ++j) {
-        if (selMask[j] != 0ull) {
-          if ((selMask[j] >> lane) & 1ull) {
-            newChild(offW + myNew[j], cs[j], (int)S.tokId[p][wave * GT + j], hypM);
+          for (int j = 1; j < GT; ++j) {
+            c = j == j0 ? cs[j] : c;
+            mn = j == j0 ? myNew[j] : mn;
+            tbj = j == j0 ? tb[j] : tbj;
           }
+          if (!first) {
+            planChild(__builtin_ctzll(tbj | (1ull << 63)));
+          }
+          newChild(offW + mn, c, hypM);
         }
+        first = false;
       }
     } else if (isSelf) {
       if (surv >= 0) {
@@ -767,38 +924,15 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
           histW[hrow + hB] = -1;
         }
       }
-      if ((selMask[2] >> lane) & 1ull) {
-        newChild(offW + myNew[2], cs[2], last, hypB);
-      }
     } else if (isWord) {
+      if ((selMask[1] >> lane) & 1ull) {
+        newChild(offW + myNew[1], cs[1], hypB);
+      }
       if ((selMask[0] >> lane) & 1ull) { /* a word ended and nobody stood on that root: a new root lane */
         const int nl = nSurv + offW + myNew[0];
         const uint32_t hyp = (uint32_t)(nHSurv + offW + myNew[0]);
         const uint32_t hp = useB ? hypB : hypM;
-        /* the LM state's number (memo: the same (LM state, word) gives the same state back) */
-        const unsigned long long mkey = xlKey(lmSid, endLabel);
-        uint32_t h = xlHash(mkey) & (kXlMemo - 1);
-        uint32_t sid = 0u;
-        for (int probe = 0;; ++probe) {
-          const unsigned long long old = atomCas64(&S.memo[h].key, 0ull, mkey);
-          if (old == 0ull) {
-            sid = atomAdd32(&S.lmNext, 1u);
-            S.memo[h].sid = sid;
-            if (atomAdd32(&S.memoUsed, 1u) > (uint32_t)(kXlMemo * 3 / 4)) {
-              atomOr32(&S.scal[XL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
-            }
-            break;
-          }
-          if (old == mkey) {
-            sid = S.memo[h].sid;
-            break;
-          }
-          h = (h + 1u) & (kXlMemo - 1);
-          if (probe > kXlMemo) {
-            atomOr32(&S.scal[XL_FLAG], 1u);
-            break;
-          }
-        }
+        const uint32_t sid = rootSid;
         const XNode r0 = S.rootNode;
         Lq.nb[nl] = cs[0];
         Lq.b[nl] = NEG;
@@ -815,10 +949,15 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
         Lq.dWord[nl] = endLabel;
         histPT[hrow + hyp] = make_int2((int)hp, endTok);
         histW[hrow + hyp] = endLabel;
-        adopt(sid, 0u, nl);
+        adopt(rootOrph, nl);
       }
     }
     nState = nSurv + nNew;
+#ifndef FLTX_EMU
+    __asm__ volatile("" ::"v"(warm));
+#else
+    (void)warm;
+#endif
     FLTX_XLPROF(5);
     ldsBarrier(); /* 3 */
     if (S.scal[XL_FLAG] != 0u) {
