@@ -42,6 +42,25 @@ def test_emulated_lane_per_slot_kernel(emu_session, golden, name):
     assert ok, why
 
 
+XLANE = [("lx_t0", 0), ("lx_spell_t40_k8", 0), ("lx_spell_t40_k8", 640), ("lx_spell_t60_k12_full", 0),
+         ("lx_uni_t40_k10", 0), ("lx_uni_t40_k10", 640)]
+
+
+@pytest.mark.parametrize("name,threads", XLANE)
+def test_emulated_lexicon_lane_engine(emu_session, golden, name, threads):
+    """fltx_xlane.h (LexiconDecoder + ZeroLM, beam <= 64): lane = (LM state, trie node)."""
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    d = emu_session.decoder(c, inp)
+    if threads:
+        d.set("slane_threads", threads)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    assert d.get("engine") == 5 and d.get("redone") == 0 and (not threads or d.get("threads") == threads)
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
+    d.close()
+    assert ok, why
+
+
 LEX_SMALL = [c for c in cases.CASES if c["kind"] == "lexicon" and c["size"] == "small" and c["T"] <= 40
              and not c["log_add"]]
 

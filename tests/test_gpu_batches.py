@@ -51,14 +51,18 @@ def _check_structure(h, e, lex, T, N, zero_lm, opt):
     return n_words
 
 
-def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample):
+def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample, sets=None, engine=None):
     c = cases.BY_NAME[name0]
     inp = helpers.case_inputs(c)
     T, N = c["T"], c["N"]
     e = synth.batch("lexspell", B, T, N, lexicon=inp["lex"])
     d = gpu_session.decoder(c, inp)
+    for k, v in (sets or {}).items():
+        d.set(k, v)
     d.decode_batch(e, [T] * B, N)
     assert d.get("lds") == 1
+    if engine is not None:
+        assert d.get("engine") == engine and d.get("redone") == 0
     for b, name in ((0, name0), (255, name255)):
         if name and b < B:
             ok, why = helpers.check_against_golden(d.results(b), golden[name])
@@ -81,8 +85,12 @@ def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample):
     d.close()
 
 
-def test_c3_batch_of_256(gpu_session, golden, oracle_lib):
-    _run_batch(gpu_session, golden, oracle_lib, "C3_spell_u0", "C3_spell_u255", 256, sample=[97, 201])
+@pytest.mark.parametrize("sets,engine", [({}, 5), ({"xlane": 0}, 0)], ids=["lane-engine", "generic-engine"])
+def test_c3_batch_of_256(gpu_session, golden, oracle_lib, sets, engine):
+    """C3 as benchmarked: served by the lane = (LM state, trie node) engine (fltx_xlane.h); the
+    generic engine, which takes over whenever that one does not apply, on the same batch."""
+    _run_batch(gpu_session, golden, oracle_lib, "C3_spell_u0", "C3_spell_u255", 256, sample=[97, 201], sets=sets,
+               engine=engine)
 
 
 def test_c4_batch_of_256(gpu_session, golden, oracle_lib):
@@ -137,3 +145,57 @@ def test_edge_configurations_of_the_lexicon_free_decoders(gpu_session, oracle_li
         if not ok:
             bad.append(({k: c[k] for k in ("N", "K", "Kt", "thr", "sil_score", "crit", "T", "dist")}, why))
     assert ran > 1000 and not bad, bad[:3]
+
+
+def test_edge_configurations_of_the_lexicon_lane_engine(gpu_session, oracle_lib):
+    """LexiconDecoder + ZeroLM through fltx_xlane.h against the oracle: beam 1 .. 64, thresholds
+    0 / inf, token beams of 1 / 3 / 10 (stay and blank are not subject to it, the trie parent's
+    extension is), silScore and wordScore of both signs, one-frame utterances, `uniform` rows
+    (every token plausible: lanes drop out and come back all the time) and `lexspell` rows."""
+    import itertools
+    bad, ran, served = [], 0, 0
+    grid = itertools.product([1, 2, 7, 50, 64], [0.0, 1.5, 25.0, float("inf")], [None, 1, 3, 10], [0.0, -0.7, 0.4],
+                             [0.0, 1.5, -2.0], [1, 2, 17, 120], ["lexspell", "uniform"])
+    for i, (K, thr, Kt, sil, ws, T, dist) in enumerate(grid):
+        if i % 11 not in (0, 4):
+            continue
+        c = cases.case("xedge%d" % i, kind="lexicon", dist=dist, u=700 + i, T=T, K=K, Kt=Kt, thr=thr, sil_score=sil,
+                       word_score=ws, lexicon=cases.SMALL_LEX)
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue
+        got = gpu_session.run(c, inp)
+        served += gpu_session.last_engine == 5
+        ok, why = helpers.hyps_equal(want, got)
+        ran += 1
+        if not ok:
+            bad.append(({k: c[k] for k in ("K", "Kt", "thr", "sil_score", "word_score", "T", "dist")}, why))
+    assert ran > 300 and served == ran and not bad, (ran, served, bad[:3])
+
+
+@pytest.mark.parametrize("kind", ["lexfree", "lexicon"])
+def test_utterances_handed_to_the_generic_engine_inside_a_lane_engine_batch(gpu_session, kind):
+    """The lane engines write packed history records and flag each utterance they finished
+    (ST_PACKED); one whose frame has no finite candidate (a row of -inf) is decoded again on the
+    generic engine, which writes plain records, and the back-trace has to read each kind as what
+    it is.  Every utterance must equal what the generic engine alone returns for it."""
+    c = cases.BY_NAME["lf_ctc_t60_k10" if kind == "lexfree" else "lx_spell_t60_k12_full"]
+    inp = helpers.case_inputs(c)
+    T, N, B = c["T"], c["N"], 6
+    e = synth.batch("ctc" if kind == "lexfree" else "lexspell", B, T, N, lexicon=inp["lex"])
+    e[2, 17, :] = -np.inf
+    e[4, 0, :] = -np.inf
+    off = "slane" if kind == "lexfree" else "xlane"
+    res = {}
+    for name, sets in (("lane", {}), ("generic", {off: 0, "lane": 0, "lean": 0})):
+        d = gpu_session.decoder(c, inp)
+        for k, v in sets.items():
+            d.set(k, v)
+        d.decode_batch(e, [T] * B, N)
+        res[name] = ([d.results(b) for b in range(B)], d.get("engine"), d.get("redone"))
+        d.close()
+    assert res["lane"][1] in (4, 5) and res["lane"][2] == 2 and res["generic"][1] in (0, 1)
+    for b in range(B):
+        ok, why = helpers.hyps_equal(res["generic"][0][b], res["lane"][0][b])
+        assert ok, "utterance %d: %s" % (b, why)

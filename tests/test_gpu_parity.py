@@ -235,13 +235,22 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     ("lf_asg_t40_n29_kt7", 4, {}), ("lf_ctc_sil", 4, {}), ("C2_ctc_u0", 4, {}), ("C2_uniform_u0", 4, {}),
     ("lf_ctc_t60_k10", 3, {"slane": 0}), ("lf_uni_n64_k64", 3, {"slane": 0}), ("lf_ctc_n29_k64", 3, {"slane": 0}),
     ("lf_ctc_t60_k10_kt5", 3, {"slane": 0}), ("C2_ctc_u0", 3, {"slane": 0}),
-    ("lf_ctc_n29_k65", 2, {}), ("lf_ctc_t60_k10_logadd", 3, {}), ("lf_ctc_t300_k100", 2, {})])
+    ("lf_ctc_n29_k65", 2, {}), ("lf_ctc_t60_k10_logadd", 3, {}), ("lf_ctc_t300_k100", 2, {}),
+    ("lx_spell_t40_k8", 5, {}), ("lx_spell_t60_k12_full", 5, {}), ("lx_uni_t40_k10", 5, {}), ("lx_t0", 5, {}),
+    ("C3_spell_u0", 5, {}), ("C3_spell_u255", 5, {}), ("C3_uniform_u0", 5, {}), ("C3_spell_u0", 5, {"slane_threads": 640}),
+    ("lx_spell_t60_k12_full", 5, {"slane_threads": 576}), ("lx_spell_t40_k8", 5, {"slane_threads": 640}),
+    ("lx_spell_t40_k8", 0, {"xlane": 0}), ("C3_spell_u0", 0, {"xlane": 0}), ("C3_uniform_u0", 0, {"cut": 0}),
+    ("lx_spell_unk", 0, {}), ("lx_asg_t40", 0, {}), ("lx_scores_t50", 0, {}), ("lx_spell_t60_k12_logadd", 0, {}),
+    ("ng_word_t40_k10", 0, {})])
 def test_engine_selection(gpu_session, golden, name, engine, sets):
     """Which engine serves which configuration: the lane = LM state decode (4,
     fltx_slane.h) for offline lexicon-free + ZeroLM max-merge with beam <= 64 and
     <= 64 tokens (also with a token beam, ASG, silScore); the lane-per-slot step
     (3) for logAdd and when the former is switched off; the lean step (2) for
-    bigger beams.  Same n-best either way."""
+    bigger beams; the lane = (LM state, trie node) decode (5, fltx_xlane.h) for
+    the offline lexicon decoder + ZeroLM over a lexicon without scores (CTC,
+    max-merge, no <unk>, beam <= 64); the generic engine (0) for everything else
+    and whenever one of its own tunables is touched.  Same n-best either way."""
     c = cases.BY_NAME[name]
     inp = helpers.case_inputs(c)
     d = gpu_session.decoder(c, inp)

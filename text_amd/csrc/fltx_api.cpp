@@ -279,6 +279,8 @@ struct fltx_decoder {
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
   int slaneThreads = 0; /* tuning: workgroup size of the lane = LM state kernel (0 = first that fits) */
   int slane = 0, noSlane = 0; /* slane: list positions per wave of the lane = LM state kernel (fltx_slane.h), 0 = off */
+  bool genericAsked = false;  /* fltx_decoder_set touched a tunable of the generic engine */
+  int engineFirst = 0;
   int lastRedo = 0;           /* utterances of the last offline call that had to be decoded again on a general path */
   bool batchPacked = false;   /* some utterance of the current results has packed history records (ST_PACKED) */
   int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
@@ -999,8 +1001,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
   if (!d || !key || !value) {
     return fail(FLTX_ERR_INVALID, "fltx_decoder_get: null argument");
   }
-  if (!strcmp(key, "engine")) {
-    *value = d->xlane ? 5 : (d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0))));
+  if (!strcmp(key, "engine")) { /* the engine the last call started on ("redone" counts what it handed on) */
+    *value = d->engineFirst;
   } else if (!strcmp(key, "xlane")) {
     *value = d->xlane;
   } else if (!strcmp(key, "redone")) {
@@ -1062,26 +1064,32 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     return FLTX_OK;
   }
   if (!strcmp(key, "items")) { /* 0: the lexicon decoder walks the full hypothesis x token grid */
+    d->genericAsked = true; /* a knob of the generic lexicon engine: that engine is what the caller wants */
     d->noItems = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "slim")) { /* 0: the cut-off generation recomputes instead of keeping slim records */
+    d->genericAsked = true; /* a knob of the generic lexicon engine: that engine is what the caller wants */
     d->noSlim = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "hot_level")) { /* testing: 1 keeps the candidate records of an HBM workspace in HBM */
+    d->genericAsked = true; /* a knob of the generic lexicon engine: that engine is what the caller wants */
     d->maxHotLevel = (int)value;
     return FLTX_OK;
   }
   if (!strcmp(key, "lds_budget")) { /* testing: pretend the CU has this many bytes of LDS (<= 160 KiB) */
+    d->genericAsked = true; /* a knob of the generic lexicon engine: that engine is what the caller wants */
     d->ldsBudget = value > 0 && (size_t)value < kMaxLds ? (size_t)value : 0;
     return FLTX_OK;
   }
   if (!strcmp(key, "cut_m")) { /* testing: number of best candidates kept by the cut (default 3K + 64) */
+    d->genericAsked = true; /* a knob of the generic lexicon engine: that engine is what the caller wants */
     d->userCutM = (int)value;
     return FLTX_OK;
   }
   if (!strcmp(key, "cut")) { /* 0: the lexicon decoder materialises every candidate (no score-pass cut) */
+    d->genericAsked = true; /* a knob of the generic lexicon engine: that engine is what the caller wants */
     d->noCut = value ? 0 : 1;
     return FLTX_OK;
   }
@@ -1106,6 +1114,7 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     return FLTX_OK;
   }
   if (!strcmp(key, "force_global_ws")) {
+    d->genericAsked = true; /* a knob of the generic lexicon engine: that engine is what the caller wants */
     d->forceGlobalWs = value != 0;
     return FLTX_OK;
   }
@@ -1118,6 +1127,10 @@ namespace {
 
 /* geometry + buffers for B streams of up to maxFrames frames (plus seed and
  * decodeEnd slots) */
+int engineOf(const fltx_decoder* d) {
+  return d->xlane ? 5 : (d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0))));
+}
+
 int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstCaseCap) {
   const size_t kMaxLdsHw = kMaxLds;
   const size_t kMaxLds = d->ldsBudget ? d->ldsBudget : kMaxLdsHw;
@@ -1216,7 +1229,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   /* lane = (LM state, trie node) decode (fltx_xlane.h): offline LexiconDecoder + ZeroLM over a lexicon
    * without LM scores, CTC max-merge, one word per spelling, every word ending in sil, no <unk> */
   d->xlane = 0;
-  if (d->kind == FLTX_DECODER_LEXICON && !d->noXlane && d->offlineCall && !d->keepScores && !d->opt.log_add &&
+  if (d->kind == FLTX_DECODER_LEXICON && !d->noXlane && !d->genericAsked && d->offlineCall && !d->keepScores && !d->opt.log_add &&
       !forceWorstCaseCap && !d->forceGlobalWs && d->lm->kind == 0 && !d->isLmToken && d->trie && d->trie->xOk &&
       d->trie->xZeroSmear && d->trie->xEndTok == d->sil && d->sil != d->blank &&
       d->opt.criterion == FLTX_CRITERION_CTC && !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) &&
@@ -1979,6 +1992,9 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
       return rc;
     }
     d->batchPacked = d->batchPacked || d->slane || d->xlane;
+    if (attempt == 0) {
+      d->engineFirst = engineOf(d);
+    }
     if ((rc = bumpEpoch(d))) {
       return rc;
     }
@@ -2091,6 +2107,7 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   if (rc) {
     return rc;
   }
+  d->engineFirst = engineOf(d);
   if ((rc = bumpEpoch(d))) {
     return rc;
   }

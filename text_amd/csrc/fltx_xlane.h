@@ -63,18 +63,20 @@ struct XlLanes {
   int32_t dWord[64];       /* ... and the word (-1: the start state) */
 };
 
-struct XlRootSlot { /* (LM state, word) -> best candidate landing there this frame, 32 B */
-  unsigned long long key;  /* 0 = free */
-  unsigned long long best; /* order-preserving score key */
-  uint32_t lane;           /* lane + 1 of the root lane that already stands there, 0 = none */
-  uint32_t minLane;        /* lowest arriving lane among those that reach `best` */
-  uint32_t winHyp;         /* its history slot ... */
-  int32_t winWord;         /* ... and word (for the root lane's back-pointer) */
+/* (LM state, word) -> best candidate landing there this frame; one array per field: the table is
+ * wiped every frame with a few wide stores */
+struct alignas(16) XlRootTab {
+  unsigned long long key[kXlRoot];  /* 0 = free */
+  unsigned long long best[kXlRoot]; /* order-preserving score key */
+  uint32_t lane[kXlRoot];           /* lane + 1 of the root lane that already stands there, 0 = none */
+  uint32_t minLane[kXlRoot];        /* lowest arriving lane among those that reach `best` */
+  uint32_t winHyp[kXlRoot];         /* its history slot ... */
+  int32_t winWord[kXlRoot];         /* ... and word (for the root lane's back-pointer) */
 };
-
-struct XlOrphSlot { /* (LM state, node) -> the lanes whose parent that pair is and has no lane */
-  unsigned long long key; /* 0 = free */
-  unsigned long long lanes;
+/* (LM state, node) -> the lanes whose parent that pair is and has no lane */
+struct alignas(16) XlOrphTab {
+  unsigned long long key[kXlOrph]; /* 0 = free */
+  unsigned long long lanes[kXlOrph];
 };
 
 struct XlMemoSlot {
@@ -90,8 +92,8 @@ struct XlaneLds {
   unsigned long long tokBit[2][kSlList];
   SlRow row[2];
   uint8_t tokId[2][kSlList];
-  XlRootSlot root[kXlRoot];
-  XlOrphSlot orph[2][kXlOrph];
+  XlRootTab root;
+  XlOrphTab orph[2];
   XlMemoSlot memo[kXlMemo];
   unsigned long long bestKey[2]; /* the frame's best candidate (all waves add their own) */
   XNode rootNode;
@@ -115,7 +117,7 @@ FLTX_DEV uint32_t xlHash(unsigned long long k) {
 FLTX_DEV int xlRootFind(XlaneLds& S, unsigned long long key) {
   uint32_t h = xlHash(key) & (kXlRoot - 1);
   for (int probe = 0; probe < kXlRoot; ++probe) {
-    const unsigned long long old = atomCas64(&S.root[h].key, 0ull, key);
+    const unsigned long long old = atomCas64(&S.root.key[h], 0ull, key);
     if (old == 0ull || old == key) {
       return (int)h;
     }
@@ -124,23 +126,23 @@ FLTX_DEV int xlRootFind(XlaneLds& S, unsigned long long key) {
   return -1;
 }
 /* a lane without a parent lane announces itself under its parent's pair (<= 64 lanes, 128 slots) */
-FLTX_DEV void xlOrphAdd(XlOrphSlot* tab, unsigned long long key, int lane) {
+FLTX_DEV void xlOrphAdd(XlOrphTab& tab, unsigned long long key, int lane) {
   uint32_t h = xlHash(key) & (kXlOrph - 1);
   for (;;) {
-    const unsigned long long old = atomCas64(&tab[h].key, 0ull, key);
+    const unsigned long long old = atomCas64(&tab.key[h], 0ull, key);
     if (old == 0ull || old == key) {
-      atomOr64(&tab[h].lanes, 1ull << lane);
+      atomOr64(&tab.lanes[h], 1ull << lane);
       return;
     }
     h = (h + 1u) & (kXlOrph - 1);
   }
 }
-FLTX_DEV unsigned long long xlOrphGet(const XlOrphSlot* tab, unsigned long long key) {
+FLTX_DEV unsigned long long xlOrphGet(const XlOrphTab& tab, unsigned long long key) {
   uint32_t h = xlHash(key) & (kXlOrph - 1);
   for (;;) {
-    const unsigned long long k = tab[h].key;
+    const unsigned long long k = tab.key[h];
     if (k == key) {
-      return tab[h].lanes;
+      return tab.lanes[h];
     }
     if (k == 0ull) {
       return 0ull;
@@ -225,14 +227,16 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     ((uint32_t*)S.hist)[i] = 0u;
   }
   for (int i = tid; i < kXlRoot; i += W) {
-    S.root[i].key = 0ull;
-    S.root[i].best = 0ull;
-    S.root[i].lane = 0u;
-    S.root[i].minLane = 0xFFFFFFFFu;
+    S.root.key[i] = 0ull;
+    S.root.best[i] = 0ull;
+    S.root.lane[i] = 0u;
+    S.root.minLane[i] = 0xFFFFFFFFu;
   }
-  for (int i = tid; i < 2 * kXlOrph; i += W) {
-    S.orph[0][i].key = 0ull; /* (orph[0..1] are contiguous) */
-    S.orph[0][i].lanes = 0ull;
+  for (int i = tid; i < kXlOrph; i += W) {
+    S.orph[0].key[i] = 0ull;
+    S.orph[0].lanes[i] = 0ull;
+    S.orph[1].key[i] = 0ull;
+    S.orph[1].lanes[i] = 0ull;
   }
   for (int i = tid; i < kXlMemo; i += W) {
     S.memo[i].key = 0ull;
@@ -442,8 +446,8 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       if (live && atRoot) { /* words ending here this frame join through the merge table */
         rootSlot = xlRootFind(S, xlKey(Lp.dPar[lane], Lp.dWord[lane]));
         if (rootSlot >= 0) {
-          S.root[rootSlot].lane = (uint32_t)lane + 1u;
-          atomMax64(&S.root[rootSlot].best, f64Key(cR));
+          S.root.lane[rootSlot] = (uint32_t)lane + 1u;
+          atomMax64(&S.root.best[rootSlot], f64Key(cR));
         }
       }
     } else if (isWord) {
@@ -461,7 +465,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       if (cok[0]) {
         rootSlot = xlRootFind(S, xlKey(lmSid, endLabel));
         if (rootSlot >= 0) {
-          atomMax64(&S.root[rootSlot].best, f64Key(c));
+          atomMax64(&S.root.best[rootSlot], f64Key(c));
         }
       }
       /* blank, then the node's own token again (:89 with prevBlank): into the child, if it has children
@@ -510,7 +514,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     }
     const double thr = best - beamThreshold;
     if (isSelf && rootSlot >= 0) { /* the root lane's stay group takes the best word ending on it */
-      const unsigned long long rb = S.root[rootSlot].best;
+      const unsigned long long rb = S.root.best[rootSlot];
       if (rb > f64Key(cs[1])) {
         cs[1] = f64FromKey(rb);
         parR = kSlNoHyp; /* back-pointer: read from the slot in the build */
@@ -520,17 +524,17 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       /* of the arrivals that reach the slot's best the lowest lane represents them: it is the
        * back-pointer a root lane takes when a word ending on it beats its own stay, and it is the
        * candidate for a new root lane when nobody stands there */
-      const bool top = cok[0] && S.root[rootSlot].best == f64Key(cs[0]);
+      const bool top = cok[0] && S.root.best[rootSlot] == f64Key(cs[0]);
       if (top) {
-        atomMin32(&S.root[rootSlot].minLane, (uint32_t)lane);
+        atomMin32(&S.root.minLane[rootSlot], (uint32_t)lane);
       }
       waveSync();
-      const bool rep = top && S.root[rootSlot].minLane == (uint32_t)lane;
+      const bool rep = top && S.root.minLane[rootSlot] == (uint32_t)lane;
       if (rep) {
-        S.root[rootSlot].winHyp = useB ? hypB : hypM;
-        S.root[rootSlot].winWord = endLabel;
+        S.root.winHyp[rootSlot] = useB ? hypB : hypM;
+        S.root.winWord[rootSlot] = endLabel;
       }
-      cok[0] = rep && S.root[rootSlot].lane == 0u;
+      cok[0] = rep && S.root.lane[rootSlot] == 0u;
     }
     if (isSvc && fastRank) {
       xlRankRange<4, 10>(rs);
@@ -857,17 +861,19 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       }
       ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
       ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
-      for (int i = lane; i < kXlRoot; i += 64) { /* the merge table of the next frame starts empty (winHyp /
-                                                    winWord, which the self wave reads now, stay) */
-        S.root[i].key = 0ull;
-        S.root[i].best = 0ull;
-        S.root[i].lane = 0u;
-        S.root[i].minLane = 0xFFFFFFFFu;
+      /* the merge table of the next frame starts empty (winHyp / winWord, which the self wave reads
+       * now, stay), and so does its orphan table: 16 bytes per lane and store */
+      static_assert(kXlRoot == 128 && kXlOrph == 128, "the wipes below cover 128 slots");
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u), f4 = make_uint4(~0u, ~0u, ~0u, ~0u);
+      ((uint4*)S.root.key)[lane] = z4;
+      ((uint4*)S.root.best)[lane] = z4;
+      if (lane < 32) {
+        ((uint4*)S.root.lane)[lane] = z4;
+      } else {
+        ((uint4*)S.root.minLane)[lane - 32] = f4;
       }
-      for (int i = lane; i < kXlOrph; i += 64) {
-        S.orph[q][i].key = 0ull;
-        S.orph[q][i].lanes = 0ull;
-      }
+      ((uint4*)S.orph[q].key)[lane] = z4;
+      ((uint4*)S.orph[q].lanes)[lane] = z4;
     } else if (isTok) {
       /* most lanes create at most one: every round takes each lane's lowest pending position */
       bool first = true;
@@ -913,8 +919,8 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
           uint32_t hp = parR;
           int32_t wd = -1;
           if (hp == kSlNoHyp) { /* a word ending on this root beat its own stay */
-            hp = S.root[rootSlot].winHyp;
-            wd = S.root[rootSlot].winWord;
+            hp = S.root.winHyp[rootSlot];
+            wd = S.root.winWord[rootSlot];
           }
           histPT[hrow + hNB] = make_int2((int)hp, atRoot ? sil : last);
           histW[hrow + hNB] = wd;
