@@ -244,7 +244,7 @@ struct fltx_trie {
   /* breadth-first re-layout for the lane = (LM state, trie node) engine (fltx_xlane.h): a node's
    * children are contiguous and in token order, so a child's id is the first child's id plus the
    * number of children with a smaller token; one 32-byte XNode per node, root = 0 */
-  DBuf xnode;
+  DBuf xnode, xdelta;
   bool xOk = false;     /* the layout exists and the trie has the shape that engine assumes: */
   int32_t xEndTok = -1; /* every node that carries labels is entered by this one token (the word separator) */
   bool xZeroSmear = true; /* every maxScore is 0 (a lexicon without LM scores) */
@@ -279,10 +279,12 @@ struct fltx_decoder {
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
   int slaneThreads = 0; /* tuning: workgroup size of the lane = LM state kernel (0 = first that fits) */
   int slane = 0, noSlane = 0; /* slane: list positions per wave of the lane = LM state kernel (fltx_slane.h), 0 = off */
+  bool preferYlane = false;
   bool genericAsked = false;  /* fltx_decoder_set touched a tunable of the generic engine */
   int engineFirst = 0;
   int lastRedo = 0;           /* utterances of the last offline call that had to be decoded again on a general path */
   bool batchPacked = false;   /* some utterance of the current results has packed history records (ST_PACKED) */
+  int ylane = 0, noYlane = 0, ylaneLm = 0, ylaneRounds = 0, ylaneTpw = 0; /* ylane: lane groups of fltx_ylane.h (0 = not used) */
   int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
   bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
   const float* lastEmis = nullptr; /* device emissions of the last offline batch (the back-trace re-reads them) */
@@ -804,6 +806,7 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
   size_t nLab = (size_t)labelOff[nNodes];
   /* breadth-first layout (see fltx_trie::xnode) */
   std::vector<XNode> xn;
+  std::vector<float> xdHost;
   if (nTokens <= 64 && !cmask.empty()) {
     std::vector<int64_t> order; /* new id -> old id */
     std::vector<int32_t> tokOf((size_t)nNodes, -1);
@@ -848,17 +851,29 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
       }
       xn[q] = x;
     }
+    std::vector<float> xd(xn.size(), 0.0f);
+    for (size_t q = 1; q < order.size() && q < xd.size(); ++q) { /* lex->maxScore - lexMaxScore, LexiconDecoder.cpp:47,96 */
+      const uint32_t pq = xn[q].parent;
+      xd[q] = xn[q].maxScore - (pq == 0u ? 0.0f : xn[pq].maxScore);
+    }
     ok = ok && order.size() == (size_t)nNodes && (labelOff[1] - labelOff[0]) == 0; /* a tree; no label on the root */
     t->xOk = ok;
     t->xEndTok = endTok;
     t->xZeroSmear = zero;
     if (!ok) {
       xn.clear();
+      xd.clear();
     }
+    xdHost.swap(xd);
   }
   if (!xn.empty()) {
     if (t->xnode.ensure(sizeof(XNode) * xn.size(), st, false) ||
         devCopyH2D(t->xnode.p, xn.data(), sizeof(XNode) * xn.size(), st)) {
+      delete t;
+      return fail(FLTX_ERR_OOM, "trie: breadth-first layout upload failed");
+    }
+    if (t->xdelta.ensure(sizeof(float) * xdHost.size(), st, false) ||
+        devCopyH2D(t->xdelta.p, xdHost.data(), sizeof(float) * xdHost.size(), st)) {
       delete t;
       return fail(FLTX_ERR_OOM, "trie: breadth-first layout upload failed");
     }
@@ -1005,6 +1020,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->engineFirst;
   } else if (!strcmp(key, "xlane")) {
     *value = d->xlane;
+  } else if (!strcmp(key, "ylane")) {
+    *value = d->ylane;
   } else if (!strcmp(key, "redone")) {
     *value = d->lastRedo;
   } else if (!strcmp(key, "slane")) {
@@ -1097,6 +1114,11 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noXlane = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "ylane")) { /* 0: do not use fltx_ylane.h; 2: prefer it where fltx_xlane.h applies too */
+    d->noYlane = value ? 0 : 1;
+    d->preferYlane = value == 2;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "slane_threads")) {
     d->slaneThreads = (int)value;
     return FLTX_OK;
@@ -1128,7 +1150,7 @@ namespace {
 /* geometry + buffers for B streams of up to maxFrames frames (plus seed and
  * decodeEnd slots) */
 int engineOf(const fltx_decoder* d) {
-  return d->xlane ? 5 : (d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0))));
+  return d->ylane ? 6 : d->xlane ? 5 : (d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0))));
 }
 
 int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstCaseCap) {
@@ -1245,6 +1267,28 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         d->threads = g[0];
         break;
       }
+    }
+  }
+  /* ... with the LM terms and two lane groups (fltx_ylane.h): n-gram word LM and / or smeared trie,
+   * beams up to 128 */
+  d->ylane = 0;
+  if (d->kind == FLTX_DECODER_LEXICON && !d->noYlane && !d->genericAsked && (!d->xlane || d->preferYlane) &&
+      d->offlineCall && !d->keepScores && !d->opt.log_add && !forceWorstCaseCap && !d->forceGlobalWs &&
+      (d->lm->kind == 0 || d->lm->kind == 1) && !d->isLmToken && d->trie && d->trie->xOk &&
+      d->trie->xEndTok == d->sil && d->sil != d->blank && d->opt.criterion == FLTX_CRITERION_CTC &&
+      !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) && K <= 128 && N <= 64 &&
+      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N && d->blank >= 0 && d->blank < N) {
+    const int ng = K <= 64 ? 1 : 2;
+    const int threads = ng == 1 ? 512 : 768;
+    const int nTokWaves = threads / 64 - ng - 2;
+    const int tpw = (nTok + nTokWaves - 1) / nTokWaves;
+    if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96) {
+      d->ylane = ng;
+      d->ylaneRounds = ng == 1 ? 2 : 4;
+      d->ylaneTpw = tpw;
+      d->ylaneLm = (d->lm->kind != 0 || !d->trie->xZeroSmear) ? 1 : 0;
+      d->threads = threads;
+      d->xlane = 0;
     }
   }
   if (d->lean && !d->lane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
@@ -1417,6 +1461,15 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     d->wsInLds = true;
     lds = true;
   }
+  if (d->ylane) {
+    d->wsBytes = sizeof(YlaneLds);
+    d->wsInLds = true;
+    lds = true;
+    d->itemCap = 0;
+    d->CAP2 = 0;
+    d->cutM = 0;
+    d->cutRecompute = 0;
+  }
   if (d->xlane) {
     d->wsBytes = sizeof(XlaneLds);
     d->wsInLds = true;
@@ -1567,6 +1620,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.prof = nullptr;
   P.xnode = (d->trie && d->trie->xnode.p) ? d->trie->xnode.as<XNode>() : nullptr;
   P.xEndTok = d->trie ? d->trie->xEndTok : -1;
+  P.xdelta = (d->trie && d->trie->xdelta.p) ? d->trie->xdelta.as<float>() : nullptr;
+  P.yTpw = d->ylaneTpw;
   P.scored = (d->lm->kind == 1 && d->scored.p) ? d->scored.as<uint32_t>() : nullptr;
   P.profThread = 64 * d->profWave;
   if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {
@@ -1583,9 +1638,10 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   const int gt = d->lane;
   const int sl = d->slane;
   const int xl = d->xlane;
+  const int yl = d->ylane ? d->ylane * 10 + d->ylaneLm : 0;
   const bool hot = !d->wsInLds && d->hotBytes > 0;
   emuLaunch(d->nLaunch > 0 ? d->nLaunch : d->B, W, d->wsInLds ? d->wsBytes : (hot ? d->hotBytes : 16),
-            [pp, gmax, gt, sl, xl, hot](char* smem) {
+            [pp, gmax, gt, sl, xl, yl, hot](char* smem) {
     char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
     if (hot) {
       if (gmax == 255) {
@@ -1596,7 +1652,15 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       return;
     }
     const bool ft = pp->Kt >= pp->N;
-    if (xl == 3) {
+    if (yl == 10) {
+      ylaneUtterance<1, 2, 0, false>(*pp, smem);
+    } else if (yl == 11) {
+      ylaneUtterance<1, 2, 1, false>(*pp, smem);
+    } else if (yl == 20) {
+      ylaneUtterance<2, 4, 0, false>(*pp, smem);
+    } else if (yl == 21) {
+      ylaneUtterance<2, 4, 1, false>(*pp, smem);
+    } else if (xl == 3) {
       xlaneUtterance<3, false>(*pp, smem);
     } else if (xl == 5) {
       xlaneUtterance<5, false>(*pp, smem);
@@ -1719,7 +1783,30 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       FLTX_LAUNCH_LDS(WW, 0);                                                                    \
     }                                                                                            \
   } while (0)
-  if (d->xlane) {
+  if (d->ylane) {
+#define FLTX_LAUNCH_YLANE(WW, NG, RR, LMK)                                                            \
+  do {                                                                                                \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<WW, NG, RR, LMK, false>,         \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));         \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<WW, NG, RR, LMK, true>,          \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));         \
+    if (d->profile) {                                                                                 \
+      hipLaunchKernelGGL((fltx_decode_kernel_ylane<WW, NG, RR, LMK, true>), dim3(nGrid), dim3(WW),    \
+                         d->wsBytes, d->ctx->stream, P);                                              \
+    } else {                                                                                          \
+      hipLaunchKernelGGL((fltx_decode_kernel_ylane<WW, NG, RR, LMK, false>), dim3(nGrid), dim3(WW),   \
+                         d->wsBytes, d->ctx->stream, P);                                              \
+    }                                                                                                 \
+  } while (0)
+    switch (d->ylane * 10 + d->ylaneLm) {
+      case 10: FLTX_LAUNCH_YLANE(512, 1, 2, 0); break;
+      case 11: FLTX_LAUNCH_YLANE(512, 1, 2, 1); break;
+      case 20: FLTX_LAUNCH_YLANE(768, 2, 4, 0); break;
+      case 21: FLTX_LAUNCH_YLANE(768, 2, 4, 1); break;
+      default: return fail(FLTX_ERR_INVALID, "no fltx_ylane.h kernel for %d lane groups", d->ylane);
+    }
+#undef FLTX_LAUNCH_YLANE
+  } else if (d->xlane) {
 #define FLTX_LAUNCH_XLANE(WW, GG)                                                                \
   do {                                                                                           \
     HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, false>,             \
@@ -1981,7 +2068,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   bool recomputeRetry = false; /* this attempt is the recompute form of the cut-off generation */
   bool recomputeTried = false;
   const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
-  const int savedNoSlane = d->noSlane, savedNoXlane = d->noXlane;
+  const int savedNoSlane = d->noSlane, savedNoXlane = d->noXlane, savedNoYlane = d->noYlane;
   d->offlineCall = true;
   d->batchPacked = false;
   d->keepScores = d->userKeepScores; /* a stream on this decoder had switched the score history on */
@@ -1991,7 +2078,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     if (rc) {
       return rc;
     }
-    d->batchPacked = d->batchPacked || d->slane || d->xlane;
+    d->batchPacked = d->batchPacked || d->slane || d->xlane || d->ylane;
     if (attempt == 0) {
       d->engineFirst = engineOf(d);
     }
@@ -2020,7 +2107,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
       return rc;
     }
     const bool cutMode = d->CAP2 > 0 || d->cutRecompute;
-    if (!finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->xlane)) {
+    if (!finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->xlane || d->ylane)) {
       d->resultsSynced = false;
       if ((rc = syncResults(d))) {
         return rc;
@@ -2035,7 +2122,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         const bool o = (st & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON;
         const bool c = (st & ST_CUT_RETRY) && cutMode;
         const bool l = (st & ST_SELECT_FALLBACK) && d->lean;
-        const bool x = (st & ST_SELECT_FALLBACK) && d->xlane;
+        const bool x = (st & ST_SELECT_FALLBACK) && (d->xlane || d->ylane);
         if (o || c || l || x) {
           again.push_back(b);
           ws |= o;
@@ -2065,6 +2152,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         d->noLean = lean ? 1 : d->noLean;
         d->noSlane = slaneMiss ? 1 : d->noSlane; /* (re-run on the generic engine) */
         d->noXlane = xlaneMiss ? 1 : d->noXlane;
+        d->noYlane = xlaneMiss ? 1 : d->noYlane;
         d->resultsSynced = false;
         continue;
       }
@@ -2079,6 +2167,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     d->noSlim = savedNoSlim;
     d->noSlane = savedNoSlane;
     d->noXlane = savedNoXlane;
+    d->noYlane = savedNoYlane;
   }
   d->resultsSynced = false;
   int rc = launchBacktrace(d);

@@ -48,6 +48,14 @@
   FLTX_INST(fltx_decode_kernel_xlane<576, 5, PROF>)        \
   FLTX_INST(fltx_decode_kernel_xlane<640, 10, PROF>)
 #define FLTX_G12(W) FLTX_XLANE_SET(false) FLTX_XLANE_SET(true)
+/* ... with LM terms, two lane groups (fltx_ylane.h): (threads, groups, rounds, LM terms) */
+#define FLTX_YLANE_SET(PROF)                               \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 0, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 1, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 0, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 1, PROF>)
+#define FLTX_G13(W) FLTX_YLANE_SET(false)
+#define FLTX_G14(W) FLTX_YLANE_SET(true)
 
 #ifdef FLTX_INST_W
 #define FLTX_CAT2_(a, b) a##b
@@ -65,6 +73,8 @@ FLTX_ALLG(1024)
 FLTX_G10(0)
 FLTX_G11(0)
 FLTX_G12(0)
+FLTX_G13(0)
+FLTX_G14(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -79,5 +89,8 @@ FLTX_G12(0)
 #undef FLTX_G10
 #undef FLTX_G11
 #undef FLTX_G12
+#undef FLTX_G13
+#undef FLTX_G14
+#undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET
 #undef FLTX_SLANE_SET

@@ -57,6 +57,12 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_xlane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   xlaneUtterance<GT, PROF>(P, fltx_smem);
 }
+/* ... with a word LM and / or a smeared trie, beams up to 128 (fltx_ylane.h) */
+template <int W, int NG, int R, int LMK, bool PROF>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_ylane(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  ylaneUtterance<NG, R, LMK, PROF>(P, fltx_smem);
+}
 template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) { /* streaming lean step, HBM workspace */
   extern __shared__ __attribute__((aligned(16))) char fltx_hot[]; /* histogram & block scalars stay in LDS */

@@ -184,6 +184,8 @@ struct DecodeParams {
   uint32_t* scored;             /* [B] n-gram LM queries issued for utterance b (accounting), or null */
   const XNode* xnode;           /* breadth-first trie layout (fltx_xlane.h), or null */
   int32_t xEndTok;              /* the token every word ends with in that layout */
+  const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
+  int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
   int32_t profThread; /* the thread whose clock is sampled (lane 0 of the wave under study) */
@@ -2569,6 +2571,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 #include "fltx_lane.h"
 #include "fltx_slane.h"
 #include "fltx_xlane.h"
+#include "fltx_ylane.h"
 
 /* ------------------------------------------------------------------------ */
 /* the decode kernel: grid = utterances, block = W threads.                  */

@@ -1,0 +1,1293 @@
+/*
+ * fltx_ylane.h -- "lane = (LM state, trie node)" decode of a whole utterance for the
+ * lexicon decoder with a word LM: LexiconDecoder + ZeroLM or n-gram LM, smeared trie
+ * (TrieNode::maxScore), CTC, max-merge, beam <= 128, <= 64 tokens, one word per
+ * spelling, every word ending in the separator token, no <unk>, offline.  Included by
+ * fltx_kernels.h after fltx_xlane.h, whose lane formulation it keeps (read the head of
+ * that file first) and whose row staging, token-beam ranking, histogram window and scan
+ * it shares.  Same candidates, same merge groups, same selection as
+ * LexiconDecoder::decodeStep (LexiconDecoder.cpp:32-229) with candidatesStore
+ * (Utils.h:146-225): bit-identical n-best, emitting-model and LM scores.
+ *
+ * What differs from fltx_xlane.h:
+ *   * lanes keep their slot for as long as they live (two groups of 64): nothing is
+ *     compacted, the fields that describe a lane's trie node are written once, links
+ *     between a lane and its trie parent's lane stay valid until one of them drops out;
+ *     a new lane takes a slot from the free list the lanes' own waves publish;
+ *   * the token waves do not walk a lane x token grid -- deep in the trie a lane has one
+ *     or two children -- but compact the (lane, token) pairs that have a child into a
+ *     list first (a ballot and a prefix count per token and group) and then evaluate one
+ *     pair per thread and round;
+ *   * scores carry the LM terms of the reference: the smearing difference
+ *     child.maxScore - parent.maxScore when a token is eaten (:96), lm.score - maxScore
+ *     when a word ends (:125), lm.finish at the end (:246); a lane also carries the LM
+ *     score of its two hypotheses (the emitting-model score is re-accumulated by the
+ *     back-trace);
+ *   * LM states are numbered as in fltx_xlane.h (LMState::child is a trie over words, also
+ *     for KenLM, lm/KenLM.cpp:66-75); the n-gram context of a state lives in
+ *     DecodeParams::stateCtx as for the generic engine, and the n-gram score of the word a
+ *     lane can end is looked up once per lane and kept with it.
+ * Waves: token waves, one per lane group for the lanes' own groups (blank, stay + parent's
+ * extension), one for the word ends and blank-then-own-token, one that stages the rows.
+ */
+#pragma once
+
+constexpr int kYlLanes = 128;
+constexpr int kYlRoot = 256;  /* slots of the per-frame (LM state, word) merge table */
+constexpr int kYlOrph = 256;  /* slots of the per-frame table of lanes without a parent lane */
+constexpr int kYlMemo = 4096; /* slots of the LM-state memo */
+constexpr int kYlTokWaves = 12;
+constexpr uint32_t kYlNoLm = 0x7FC00001u; /* endLm: not looked up yet (a NaN no arithmetic produces) */
+
+struct YlLanes { /* in place: slot = lane for as long as the lane lives */
+  double nb[kYlLanes], b[kYlLanes];
+  double lmNB[kYlLanes], lmB[kYlLanes];                 /* LM score of the two hypotheses */
+  unsigned long long childMask[kYlLanes], kidsMask[kYlLanes]; /* XNode of the lane's node */
+  uint32_t info[kYlLanes];       /* own token | history slot of nb << 16 | of b << 24 */
+  uint32_t link[kYlLanes];       /* lane + 1 of the trie parent's lane, 0 = not in the beam (or root) */
+  uint32_t lmSid[kYlLanes];      /* LM state */
+  uint32_t node[kYlLanes];       /* trie node, breadth-first id, 0 = root */
+  uint32_t parent[kYlLanes];     /* its parent node */
+  uint32_t firstChild[kYlLanes];
+  int32_t endLabel[kYlLanes];    /* word that ends when the separator follows, -1 = none */
+  uint32_t dPar[kYlLanes];       /* root lanes: the LM state the word was emitted from ... */
+  int32_t dWord[kYlLanes];       /* ... and the word (-1: the start state) */
+  float maxScore[kYlLanes];      /* TrieNode::maxScore of the node */
+  float delta[kYlLanes];         /* maxScore - (parent is the root ? 0 : parent's maxScore), LexiconDecoder.cpp:47,96 */
+  uint32_t endLm[kYlLanes];      /* float bits: lm.score(LM state, endLabel), kYlNoLm = not looked up */
+};
+
+struct alignas(16) YlRootTab {
+  unsigned long long key[kYlRoot];  /* 0 = free */
+  unsigned long long best[kYlRoot]; /* order-preserving score key */
+  double winLm[kYlRoot];            /* LM score of the arrival that represents the slot */
+  uint32_t lane[kYlRoot];           /* lane + 1 of the root lane that already stands there, 0 = none */
+  uint32_t minLane[kYlRoot];        /* lowest arriving lane among those that reach `best` */
+  uint32_t winHyp[kYlRoot];         /* its history slot ... */
+  int32_t winWord[kYlRoot];         /* ... and word (for the root lane's back-pointer) */
+};
+struct alignas(16) YlOrphTab {
+  unsigned long long key[kYlOrph]; /* 0 = free */
+  unsigned long long lanes[2][kYlOrph];
+};
+
+struct YlaneLds {
+  YlLanes L;
+  unsigned long long cmask[2][kYlLanes]; /* tokens whose child node holds a lane that links here */
+  uint32_t hist[2][kSlNB];
+  double eAll[2][64];
+  double eTok[2][kSlList];
+  unsigned long long tokBit[2][kSlList];
+  SlRow row[2];
+  uint8_t tokId[2][kSlList];
+  YlRootTab root;
+  YlOrphTab orph[2];
+  XlMemoSlot memo[kYlMemo];
+  unsigned long long bestKey[2];
+  unsigned long long alive[2][2];    /* lanes of the frame, per group */
+  unsigned long long surv[2];        /* ... that stay for the next frame (alive[next] = these + the new lanes) */
+  XNode rootNode;
+  uint32_t off[32];                  /* new lanes of the waves before wave i (token waves, then the word wave); [last + 1] = all */
+  uint32_t offH[4];                  /* surviving hypotheses of the lane groups before group g; [NG] = all */
+  uint32_t nFree[2];
+  uint8_t freeList[2][64];           /* free slots of a group, in slot order */
+  uint16_t cand[kYlTokWaves][256];   /* (lane | list position << 8) pairs of a token wave */
+  uint32_t scal[16];
+  unsigned long long bKey[kSlBCap];
+  uint32_t bOrd[kSlBCap];
+  uint32_t memoUsed, lmNext;
+  /* decodeEnd */
+  unsigned long long endKey[kYlLanes];
+  double endScore[kYlLanes], endLmS[kYlLanes];
+  uint32_t endHyp[kYlLanes];
+};
+
+enum { YL_FLAG = 15, YL_NICE = 14 };
+
+FLTX_DEV int ylRootFind(YlaneLds& S, unsigned long long key) {
+  uint32_t h = xlHash(key) & (kYlRoot - 1);
+  for (int probe = 0; probe < kYlRoot; ++probe) {
+    const unsigned long long old = atomCas64(&S.root.key[h], 0ull, key);
+    if (old == 0ull || old == key) {
+      return (int)h;
+    }
+    h = (h + 1u) & (kYlRoot - 1);
+  }
+  return -1;
+}
+FLTX_DEV void ylOrphAdd(YlOrphTab& tab, unsigned long long key, int li) {
+  uint32_t h = xlHash(key) & (kYlOrph - 1);
+  for (;;) {
+    const unsigned long long old = atomCas64(&tab.key[h], 0ull, key);
+    if (old == 0ull || old == key) {
+      atomOr64(&tab.lanes[li >> 6][h], 1ull << (li & 63));
+      return;
+    }
+    h = (h + 1u) & (kYlOrph - 1);
+  }
+}
+FLTX_DEV int ylOrphFind(const YlOrphTab& tab, unsigned long long key) {
+  uint32_t h = xlHash(key) & (kYlOrph - 1);
+  for (;;) {
+    const unsigned long long k = tab.key[h];
+    if (k == key) {
+      return (int)h;
+    }
+    if (k == 0ull) {
+      return -1;
+    }
+    h = (h + 1u) & (kYlOrph - 1);
+  }
+}
+
+/* n-gram score of LM word `word` after LM state `sid` (KenLM::score, lm/KenLM.cpp:66-86).  The
+ * contexts of the states live in HBM (DecodeParams::stateCtx) and are written by other waves of
+ * this workgroup in earlier frames: read past the L1.  wantCtx: the context of the resulting
+ * state goes to state `outSid`. */
+FLTX_DEV float ylNgram(const DecodeParams& P, int b, uint32_t sid, uint32_t word, uint32_t outSid, bool wantCtx) {
+  const int Lc = P.lmOrder - 1;
+  const uint32_t* ctx = (const uint32_t*)(P.stateCtx + ((size_t)b * P.stateCap + sid) * Lc);
+  int32_t c[kMaxNgramOrder];
+#pragma unroll
+  for (int q = 0; q < kMaxNgramOrder; ++q) {
+    c[q] = q < Lc ? (int32_t)loadCoherent32(ctx + q) : 0;
+  }
+  int32_t* out = wantCtx ? P.stateCtx + ((size_t)b * P.stateCap + outSid) * Lc : nullptr;
+  const float r = ngScore(P, c, word, out);
+#ifndef FLTX_EMU
+  if (wantCtx) {
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the new context has left this wave */
+  }
+#endif
+  return r;
+}
+FLTX_DEV float ylLmScore(const DecodeParams& P, int b, uint32_t sid, int usr, uint32_t outSid, bool wantCtx) {
+  const uint32_t word = (usr >= 0 && usr < P.nUsr) ? (uint32_t)P.usrToLm[usr] : (uint32_t)P.lmUnk;
+  return ylNgram(P, b, sid, word, outSid, wantCtx);
+}
+
+#define FLTX_YLPROF(i)                                        \
+  do {                                                        \
+    if (PROF && P.prof && (int)threadIdx.x == P.profThread) { \
+      const unsigned long long t_ = devClock();               \
+      acc[(i)] += t_ - tPrev;                                 \
+      tPrev = t_;                                             \
+    }                                                         \
+  } while (0)
+
+/* NG lane groups of 64; R candidate pairs per token-wave thread; LMK = 0: ZeroLM over an
+ * unsmeared lexicon (every LM term is zero and left out), 1: smeared trie and / or n-gram LM */
+template <int NG, int R, int LMK, bool PROF>
+FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
+  YlaneLds& S = *(YlaneLds*)smem;
+  constexpr int NS = R > 2 * NG ? R : 2 * NG; /* candidate slots of a thread */
+  static_assert(NG == 1 || NG == 2, "one or two lane groups");
+  static_assert(R * 64 <= 256, "cand[] holds 256 pairs per token wave");
+  const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
+  const int W = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int lane = laneId(), wave = waveUniform(waveId());
+  const int nW = W >> 6;
+  const int nTok = nW - NG - 2;
+  const int wordWave = nW - 2, prepWave = nW - 1;
+  const bool isTok = wave < nTok, isSelf = wave >= nTok && wave < nTok + NG, isWord = wave == wordWave;
+  const bool isSvc = wave == prepWave;
+  const int grp = isSelf ? wave - nTok : 0;
+  const int li = grp * 64 + lane; /* self waves: the lane this thread owns */
+  const int K = P.K, N = P.N, TPW = P.yTpw;
+  const int T = P.stepT ? P.stepT[b] : 0;
+  const float* em = P.emissions ? P.emissions + P.emOff[b] : nullptr;
+  const int64_t hbase = P.histOff[b];
+  const double NEG = slNegInf();
+  const int sil = P.sil, blank = P.blank;
+  const int endTok = P.xEndTok;
+  const double silScore = P.silScore, wordScore = P.wordScore, beamThreshold = P.beamThreshold;
+  const double lmWeight = P.lmWeight;
+  const bool ngram = LMK != 0 && P.lmKind != 0;
+  int2* const histPT = P.histPT;
+  int32_t* const histW = P.histW;
+  const XNode* const xnode = P.xnode;
+  const float* const xdelta = P.xdelta;
+  YlLanes& L = S.L;
+  unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long tPrev = devClock();
+  uint32_t nScored = 0u;
+
+  /* ---- decodeBegin (LexiconDecoder.cpp:21-30): the start state at the root ------------- */
+  for (int i = tid; i < 2 * kYlLanes; i += W) {
+    ((unsigned long long*)S.cmask)[i] = 0ull;
+  }
+  for (int i = tid; i < 2 * kSlNB; i += W) {
+    ((uint32_t*)S.hist)[i] = 0u;
+  }
+  for (int i = tid; i < kYlRoot; i += W) {
+    S.root.key[i] = 0ull;
+    S.root.best[i] = 0ull;
+    S.root.lane[i] = 0u;
+    S.root.minLane[i] = 0xFFFFFFFFu;
+  }
+  for (int i = tid; i < kYlOrph; i += W) {
+    S.orph[0].key[i] = 0ull;
+    S.orph[0].lanes[0][i] = 0ull;
+    S.orph[0].lanes[1][i] = 0ull;
+    S.orph[1].key[i] = 0ull;
+    S.orph[1].lanes[0][i] = 0ull;
+    S.orph[1].lanes[1][i] = 0ull;
+  }
+  for (int i = tid; i < kYlMemo; i += W) {
+    S.memo[i].key = 0ull;
+  }
+  if (tid < 32) {
+    S.off[tid] = 0u;
+  }
+  if (tid < 16) {
+    S.scal[tid] = 0u;
+  }
+  if (tid < 4) {
+    S.offH[tid] = 0u;
+  }
+  if (tid == 0) {
+    const XNode r0 = xnode[0];
+    S.rootNode = r0;
+    L.nb[0] = 0.0;
+    L.b[0] = NEG;
+    L.lmNB[0] = 0.0;
+    L.lmB[0] = 0.0;
+    L.childMask[0] = r0.childMask;
+    L.kidsMask[0] = r0.kidsMask;
+    L.info[0] = (uint32_t)sil | (0u << 16) | (kSlNoHyp << 24);
+    L.link[0] = 0u;
+    L.lmSid[0] = 0u;
+    L.node[0] = 0u;
+    L.parent[0] = 0u;
+    L.firstChild[0] = r0.firstChild;
+    L.endLabel[0] = r0.endLabel0;
+    L.dPar[0] = 0x7FFFFFFFu;
+    L.dWord[0] = -1;
+    L.maxScore[0] = r0.maxScore;
+    L.delta[0] = 0.0f;
+    L.endLm[0] = kYlNoLm;
+    S.alive[0][0] = 1ull;
+    S.alive[0][1] = 0ull;
+    S.alive[1][0] = 0ull;
+    S.alive[1][1] = 0ull;
+    S.row[0].nev = 0u;
+    S.row[1].nev = 0u;
+    S.row[0].dead = 0u;
+    S.row[1].dead = 0u;
+    S.bestKey[0] = 0ull;
+    S.bestKey[1] = 0ull;
+    S.memoUsed = 0u;
+    S.lmNext = 1u;
+    histPT[hbase] = make_int2((int)kSlNoHyp, sil);
+    histW[hbase] = -1;
+    if (ngram) { /* KenLM::start(false): context = <s> (KenLM.cpp:57) */
+      const int Lc = P.lmOrder - 1;
+      int32_t* c0 = P.stateCtx + (size_t)b * P.stateCap * Lc;
+      uint32_t nd = 0;
+      float pr;
+      const bool ok = ngFind(P, 0u, (uint32_t)P.lmBos, nd, pr);
+      for (int q = 0; q < Lc; ++q) {
+        c0[q] = (q == 0 && ok) ? (int32_t)nd : 0;
+      }
+    }
+  }
+  if (tid > 0 && tid < K) {
+    histPT[hbase + tid] = make_int2((int)kSlNoHyp, -1);
+  }
+  float rowA = 0.0f, rowB = 0.0f;
+  if (isSvc) {
+    const float v0 = (T > 0 && lane < N) ? em[lane] : 0.0f;
+    rowA = (T > 1 && lane < N) ? em[(size_t)1 * N + lane] : 0.0f;
+    rowB = (T > 2 && lane < N) ? em[(size_t)2 * N + lane] : 0.0f;
+    SlRowRegs r0 = slRowScan(P, v0, false, 0.0);
+    slRowStore(P, S, 0, r0, true);
+    slRowStore(P, S, 1, r0, true);
+  }
+#ifndef FLTX_EMU
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the start state's context is read back from HBM */
+#endif
+  ldsBarrier();
+
+  int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
+  bool dead = false;
+
+  auto frameStep = [&](auto PT, float& rowReg, const int t) {
+    constexpr int p = decltype(PT)::value, q = p ^ 1;
+    const int frameOut = t + 1;
+    const int64_t hrow = hbase + (int64_t)frameOut * K;
+    /* ---- phase 1a: candidates, the merge table, the frame's best --------------------------- */
+    const int silPos = S.row[p].silPos;
+    const unsigned long long allow = S.row[p].allow;
+    const unsigned long long alive0 = S.alive[p][0], alive1 = NG > 1 ? S.alive[p][1] : 0ull;
+    double cs[NS], clm[NS];
+    int cbin[NS];
+    bool cok[NS];
+    uint32_t cinf[NS]; /* token waves: lane | token << 8 | history slot of the source << 16;  word wave: history slot << 16 */
+    uint32_t cnode[NS]; /* token waves, word wave (odd slots): the child node */
+    float cdl[NS];      /* ... and its smearing difference */
+    uint32_t cpl[NS];   /* LM state of the lane the candidate comes from */
+    uint32_t cpn[NS];   /* its node (word wave, even slots: the word) */
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      cs[j] = NEG;
+      clm[j] = 0.0;
+      cbin[j] = kSlInvalid;
+      cok[j] = false;
+      cinf[j] = 0u;
+      cnode[j] = 0u;
+      cdl[j] = 0.0f;
+      cpl[j] = 0u;
+      cpn[j] = 0u;
+    }
+    /* own lane (self waves) */
+    bool live = false, atRoot = false;
+    double nb = NEG, bb = NEG, m = NEG, lmM = 0.0, lmOwnNB = 0.0;
+    uint32_t info = 0u, hypNB = kSlNoHyp, hypB = kSlNoHyp, hypM = kSlNoHyp, parR = kSlNoHyp;
+    int last = 0, pl = -1, rootSlot = -1;
+    bool whichB = false;
+    double lmR = 0.0; /* LM score of the winning member of the stay group */
+    /* word wave, per group */
+    int wSlot[NG];
+    bool wUseB[NG];
+    uint32_t wHypB[NG], wHypM[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      wSlot[g] = -1;
+      wUseB[g] = false;
+      wHypB[g] = kSlNoHyp;
+      wHypM[g] = kSlNoHyp;
+    }
+    int nCand = 0; /* token waves: pairs in cand[wave] */
+    /* staging wave: ranks the token beam of the next row in three pieces (see fltx_xlane.h) */
+    SlRowRegs nextRow = {};
+    const float rv = rowReg;
+    int rk = 0;
+    auto rankPart = [&](int m0, int m1) {
+      for (int mm = m0; mm < m1; ++mm) {
+        const float o = __uint_as_float(waveReadLane32(__float_as_uint(rv), mm));
+        rk += (o > rv || (o == rv && mm < lane)) ? 1 : 0;
+      }
+    };
+    const bool needRank = P.Kt < N && t + 1 < T;
+    const int rk1 = N / 3, rk2 = 2 * N / 3;
+    const bool fastRank = needRank && N <= 32 && isSvc && waveBallot(lane < N && !(rv == rv)) == 0ull;
+    XlRank rs = {};
+    FLTX_YLPROF(0);
+    if (isSvc) {
+      S.cmask[q][lane] = 0ull;
+      S.cmask[q][lane + 64] = 0ull;
+      if (lane < 32) {
+        S.off[lane] = 0u;
+      }
+      if (lane < 4) {
+        S.offH[lane] = 0u;
+      }
+      if (lane == 0) {
+        S.scal[SL_BCNT] = 0u;
+        S.bestKey[q] = 0ull;
+      }
+      if (fastRank) {
+        rs = xlRankBegin(rv, N);
+        xlRankRange<0, 4>(rs);
+      } else if (needRank) {
+        rankPart(0, rk1);
+      }
+      rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
+    } else if (isTok) {
+      /* the (lane, token) pairs with a child that has children and no lane of its own yet, the
+       * node's own token excepted (that one needs the blank in between): LexiconDecoder.cpp:89-110 */
+      unsigned long long ext[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int x = g * 64 + lane;
+        const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+        const unsigned long long own = 1ull << (L.info[x] & 63u);
+        ext[g] = lv ? (L.childMask[x] & L.kidsMask[x] & ~S.cmask[p][x] & ~own) : 0ull;
+      }
+      for (int j = 0; j < TPW; ++j) {
+        const unsigned long long tbj = S.tokBit[p][wave * TPW + j];
+        if (tbj == 0ull) {
+          continue;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const bool has = (ext[g] & tbj) != 0ull;
+          const unsigned long long bal = waveBallot(has);
+          if (bal != 0ull) {
+            const int at = nCand + wavePrefixCount(bal);
+            if (has && at < R * 64) {
+              S.cand[wave][at] = (uint16_t)((g * 64 + lane) | (j << 8));
+            }
+            nCand += popc64(bal);
+          }
+        }
+      }
+      if (nCand > R * 64) { /* more pairs than the threads' rounds take: general path */
+        dead = true;
+        nCand = R * 64;
+        if (lane == 0) {
+          S.bestKey[p] = ~0ull;
+        }
+      }
+      waveSync();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int id = r * 64 + lane;
+        if (r * 64 < nCand) {
+          const bool valid = id < nCand;
+          const uint32_t c16 = valid ? (uint32_t)S.cand[wave][id] : 0u;
+          const int x = (int)(c16 & 0xFFu), pos = wave * TPW + (int)(c16 >> 8);
+          const double xnb = L.nb[x], xb = L.b[x];
+          const uint32_t xi = L.info[x];
+          const double ev = S.eTok[p][pos];
+          const int n = (int)S.tokId[p][pos];
+          const bool wb = xb > xnb;
+          double c = (wb ? xb : xnb) + ev;
+          if (pos == silPos) {
+            c = c + silScore;
+          }
+          const uint32_t hp = wb ? (xi >> 24) : ((xi >> 16) & 0xFFu);
+          cinf[r] = (uint32_t)x | ((uint32_t)n << 8) | (hp << 16);
+          const uint32_t child = L.firstChild[x] + (uint32_t)popc64(L.childMask[x] & ((1ull << n) - 1ull));
+          cnode[r] = child;
+          cpl[r] = L.lmSid[x];
+          cpn[r] = L.node[x];
+          if (LMK) {
+            const float dl = valid ? xdelta[child] : 0.0f;
+            cdl[r] = dl;
+            c = c + lmWeight * (double)dl; /* lmScore = lex->maxScore - lexMaxScore, LexiconDecoder.cpp:96,101 */
+            clm[r] = (wb ? L.lmB[x] : L.lmNB[x]) + (double)dl;
+          }
+          cs[r] = c;
+          cok[r] = valid && c == c;
+        }
+      }
+    } else if (isSelf) {
+      live = (((grp == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+      nb = live ? L.nb[li] : NEG;
+      bb = live ? L.b[li] : NEG;
+      info = L.info[li];
+      last = (int)(info & 0xFFu) & 63;
+      hypNB = (info >> 16) & 0xFFu;
+      hypB = info >> 24;
+      whichB = bb > nb;
+      m = whichB ? bb : nb;
+      hypM = whichB ? hypB : hypNB;
+      atRoot = L.node[li] == 0u;
+      pl = live ? (int)L.link[li] - 1 : -1;
+      const int pi = pl >= 0 ? pl : 0;
+      const double parNB = L.nb[pi], parB = L.b[pi];
+      const uint32_t parInfo = L.info[pi];
+      double lmNBv = 0.0, lmBv = 0.0, parLmNB = 0.0, parLmB = 0.0, dl = 0.0;
+      if (LMK) {
+        lmNBv = L.lmNB[li];
+        lmBv = L.lmB[li];
+        parLmNB = L.lmNB[pi];
+        parLmB = L.lmB[pi];
+        dl = (double)L.delta[li];
+      }
+      lmM = whichB ? lmBv : lmNBv;
+      lmOwnNB = lmNBv;
+      const double eBlank = S.eAll[p][blank], eLast = S.eAll[p][last], eSil = S.eAll[p][sil];
+      /* blank (:197-213): always tried */
+      cs[0] = m + eBlank;
+      clm[0] = lmM;
+      cok[0] = live;
+      /* stay (:168-194) + the trie parent's extension by the node's token (a "(1) try children"
+       * candidate: needs the token in the token beam, carries the smearing difference) */
+      const int lastP = (int)(parInfo & 0xFFu);
+      const uint32_t h1 = (parInfo >> 16) & 0xFFu, h2 = parInfo >> 24;
+      const bool allowLast = ((allow >> last) & 1ull) != 0ull;
+      const bool hasNB = hypNB != kSlNoHyp;
+      const bool has0 = atRoot ? true : hasNB;
+      const bool has1 = pl >= 0 && allowLast && last != lastP && h1 != kSlNoHyp;
+      const bool has2 = pl >= 0 && allowLast && h2 != kSlNoHyp;
+      double r0 = (atRoot ? m : nb) + (atRoot ? eSil : eLast);
+      double r1 = has1 ? parNB + eLast : NEG;
+      double r2 = has2 ? parB + eLast : NEG;
+      if (silScore != 0.0) {
+        const bool ls = atRoot || last == sil;
+        r0 = ls ? r0 + silScore : r0;
+        r1 = ls ? r1 + silScore : r1;
+        r2 = ls ? r2 + silScore : r2;
+      }
+      if (LMK) {
+        r1 = r1 + lmWeight * dl;
+        r2 = r2 + lmWeight * dl;
+      }
+      double cR = r0;
+      parR = atRoot ? hypM : hypNB;
+      lmR = atRoot ? lmM : lmNBv;
+      if (has1 && (r1 > cR || (r1 == cR && h1 < parR))) {
+        cR = r1;
+        parR = h1;
+        lmR = parLmNB + dl;
+      }
+      if (has2 && (r2 > cR || (r2 == cR && h2 < parR))) {
+        cR = r2;
+        parR = h2;
+        lmR = parLmB + dl;
+      }
+      cs[1] = cR;
+      clm[1] = lmR;
+      cok[1] = live && (has0 || has1 || has2);
+      if (live && atRoot) { /* words ending here this frame join through the merge table */
+        rootSlot = ylRootFind(S, xlKey(L.dPar[li], L.dWord[li]));
+        if (rootSlot >= 0) {
+          S.root.lane[rootSlot] = (uint32_t)li + 1u;
+          atomMax64(&S.root.best[rootSlot], f64Key(cR));
+        }
+      }
+    } else if (isWord) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int x = g * 64 + lane;
+        const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+        const double xnb = lv ? L.nb[x] : NEG, xb = lv ? L.b[x] : NEG;
+        const uint32_t xi = L.info[x];
+        const int xl = (int)(xi & 0xFFu) & 63;
+        const uint32_t xhNB = (xi >> 16) & 0xFFu, xhB = xi >> 24;
+        const bool wb = xb > xnb;
+        const double xm = wb ? xb : xnb;
+        const bool xRoot = L.node[x] == 0u;
+        const int32_t el = L.endLabel[x];
+        const uint32_t xlm = L.lmSid[x];
+        const double eEnd = S.eAll[p][endTok], eLast = S.eAll[p][xl];
+        /* a word ends (:113-142); on the root the nb hypothesis would repeat its token (:114-122) */
+        const bool useB = xRoot && xl == endTok;
+        const bool can = lv && el >= 0 && ((allow >> endTok) & 1ull) != 0ull && (useB ? xhB != kSlNoHyp : true);
+        double c = (useB ? xb : xm) + eEnd;
+        if (endTok == sil) {
+          c = c + silScore;
+        }
+        float lmS = 0.0f;
+        double srcLm = 0.0;
+        if (LMK) {
+          float sc = 0.0f;
+          if (ngram && can) {
+            uint32_t bits = L.endLm[x];
+            if (bits == kYlNoLm) {
+              bits = __float_as_uint(ylLmScore(P, b, xlm, el, 0u, false));
+              L.endLm[x] = bits;
+              ++nScored;
+            }
+            sc = __uint_as_float(bits);
+          }
+          lmS = sc - (xRoot ? 0.0f : L.maxScore[x]); /* lmScore - lexMaxScore, LexiconDecoder.cpp:47,125 */
+          srcLm = useB ? L.lmB[x] : (wb ? L.lmB[x] : L.lmNB[x]);
+        }
+        c = (c + lmWeight * (double)lmS) + wordScore;
+        cs[2 * g] = c;
+        clm[2 * g] = srcLm + (double)lmS;
+        cok[2 * g] = can && c == c;
+        cinf[2 * g] = (useB ? xhB : (wb ? xhB : xhNB)) << 16;
+        cpl[2 * g] = xlm;
+        cpn[2 * g] = (uint32_t)el;
+        cpl[2 * g + 1] = xlm;
+        cpn[2 * g + 1] = L.node[x];
+        wUseB[g] = useB;
+        wHypB[g] = xhB;
+        wHypM[g] = wb ? xhB : xhNB;
+        if (cok[2 * g]) {
+          wSlot[g] = ylRootFind(S, xlKey(xlm, el));
+          if (wSlot[g] >= 0) {
+            atomMax64(&S.root.best[wSlot[g]], f64Key(c));
+          }
+        }
+        /* blank, then the node's own token again (:89 with prevBlank): into the child, if it has
+         * children and no lane */
+        const unsigned long long cmk = L.childMask[x];
+        const bool extLast = ((cmk & L.kidsMask[x]) >> xl) & 1ull;
+        const bool allowLast = ((allow >> xl) & 1ull) != 0ull;
+        const bool go = lv && xhB != kSlNoHyp && extLast && allowLast && ((S.cmask[p][x] >> xl) & 1ull) == 0ull;
+        double cL = xb + eLast;
+        if (xl == sil) {
+          cL = cL + silScore;
+        }
+        const uint32_t child = L.firstChild[x] + (uint32_t)popc64(cmk & ((1ull << xl) - 1ull));
+        cnode[2 * g + 1] = child;
+        if (LMK) {
+          const float dl = go ? xdelta[child] : 0.0f;
+          cdl[2 * g + 1] = dl;
+          cL = cL + lmWeight * (double)dl;
+          clm[2 * g + 1] = L.lmB[x] + (double)dl;
+        }
+        cs[2 * g + 1] = cL;
+        cok[2 * g + 1] = go && cL == cL;
+        cinf[2 * g + 1] = (uint32_t)x | ((uint32_t)xl << 8) | (xhB << 16);
+      }
+    }
+    {
+      bool full = isSelf && live && atRoot && rootSlot < 0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        full = full || (isWord && cok[2 * g] && wSlot[g] < 0);
+      }
+      if (waveBallot(full) != 0ull) {
+        dead = true; /* merge table full: general path (uniform after the barrier below via bestKey = ~0) */
+        if (lane == 0) {
+          S.bestKey[p] = ~0ull;
+        }
+      }
+    }
+    { /* the frame's best candidate (Utils.h:131-137) */
+      unsigned long long mx = 0ull;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        const unsigned long long k = cok[j] ? f64Key(cs[j]) : 0ull;
+        mx = k > mx ? k : mx;
+      }
+      if (waveBallot(mx != 0ull) != 0ull) {
+        mx = waveMax64(mx);
+        if (lane == 0) {
+          atomMax64(&S.bestKey[p], mx);
+        }
+      }
+    }
+    FLTX_YLPROF(1);
+    ldsBarrier(); /* A */
+    /* ---- phase 1b: threshold, merge-table verdicts, histogram ---------------------------- */
+    const unsigned long long bk = S.bestKey[p];
+    if (bk == 0ull || bk == ~0ull) {
+      dead = true;
+      return;
+    }
+    const double best = f64FromKey(bk);
+    if (!(best - best == 0.0)) {
+      dead = true;
+      return;
+    }
+    const double thr = best - beamThreshold;
+    if (isSelf && rootSlot >= 0) { /* the root lane's stay group takes the best word ending on it */
+      const unsigned long long rb = S.root.best[rootSlot];
+      if (rb > f64Key(cs[1])) {
+        cs[1] = f64FromKey(rb);
+        parR = kSlNoHyp; /* back-pointer and LM score: read from the slot in the build */
+      }
+    }
+    if (isWord) {
+      /* of the arrivals that reach a slot's best the lowest lane represents them: the back-pointer a
+       * root lane takes when a word ending on it beats its own stay, and the candidate for a new
+       * root lane when nobody stands there.  (One wave handles the arrivals of all groups: the two
+       * steps below need no barrier.) */
+      bool top[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        top[g] = cok[2 * g] && S.root.best[wSlot[g] >= 0 ? wSlot[g] : 0] == f64Key(cs[2 * g]);
+        if (top[g]) {
+          atomMin32(&S.root.minLane[wSlot[g]], (uint32_t)(g * 64 + lane));
+        }
+      }
+      waveSync();
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int sl = wSlot[g] >= 0 ? wSlot[g] : 0;
+        const bool rep = top[g] && S.root.minLane[sl] == (uint32_t)(g * 64 + lane);
+        if (rep) {
+          S.root.winHyp[sl] = wUseB[g] ? wHypB[g] : wHypM[g];
+          S.root.winWord[sl] = (int32_t)cpn[2 * g];
+          S.root.winLm[sl] = clm[2 * g];
+        }
+        cok[2 * g] = rep && S.root.lane[sl] == 0u;
+      }
+    }
+    if (isSvc && fastRank) {
+      xlRankRange<4, 10>(rs);
+    } else if (isSvc && needRank) {
+      rankPart(rk1, rk2);
+    }
+    if (isSelf && live && !atRoot && pl < 0) { /* no parent lane: whoever creates it this frame finds this lane here */
+      ylOrphAdd(S.orph[p], xlKey(L.lmSid[li], (int32_t)L.parent[li]), li);
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      if (cok[j] && cs[j] >= thr) {
+        cbin[j] = slBin(best, cs[j], winShift, winBase);
+        if (cbin[j] < kSlFar) {
+          atomAdd32(&S.hist[p][cbin[j]], 1u);
+        }
+      }
+    }
+    FLTX_YLPROF(2);
+    ldsBarrier(); /* 1 */
+    /* ---- phase 2: which candidates survive (as fltx_slane.h) ------------------------------ */
+    unsigned long long selMask[NS];
+    SlScan sc;
+    int shift = winShift, base = winBase;
+    unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+    bool full = false;
+    for (;;) {
+      sc = slScan(S.hist[p], K);
+      if (!full && !sc.crossed) {
+        int nFar = 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          nFar += popc64(waveBallot(cbin[j] == kSlFar));
+        }
+        if (lane == 0 && nFar > 0) {
+          atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
+        }
+        full = true;
+        ldsBarrier();
+        continue;
+      }
+      if (sc.total <= K) {
+        const int lim = full ? kSlFar : kSlFar - 1;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          selMask[j] = waveBallot(cbin[j] <= lim);
+        }
+        break;
+      }
+      const int need = K - sc.cum;
+      if (sc.cnt == need) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          selMask[j] = waveBallot(cbin[j] <= sc.bstar);
+        }
+        break;
+      }
+      if (sc.cnt <= kSlBCap) {
+        uint32_t take = 0u;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          if (cbin[j] == sc.bstar) {
+            const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
+            S.bKey[i] = f64Key(cs[j]);
+            S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+          }
+        }
+        ldsBarrier();
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          if (cbin[j] == sc.bstar) {
+            const unsigned long long k = f64Key(cs[j]);
+            const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+            int rank = 0;
+            for (int i = 0; i < sc.cnt; ++i) {
+              const unsigned long long k2 = S.bKey[i];
+              rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
+            }
+            take |= rank < need ? (1u << j) : 0u;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          selMask[j] = waveBallot(cbin[j] < sc.bstar || ((take >> j) & 1u) != 0u);
+        }
+        break;
+      }
+      {
+        const unsigned long long v = (unsigned long long)(sc.bstar + base);
+        if (sc.bstar > 0 || base == 0) {
+          const unsigned long long l2 = v << shift;
+          bLo = l2 > bLo ? l2 : bLo;
+        }
+        if (sc.bstar < kSlNB - 1) {
+          const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
+          bHi = h2 < bHi ? h2 : bHi;
+        }
+        if (bLo >= bHi) {
+          dead = true;
+          break;
+        }
+        int ns = 0;
+        while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
+          ++ns;
+        }
+        shift = ns;
+        base = (int)(bLo >> ns);
+      }
+      ldsBarrier();
+      for (int i = tid; i < kSlNB; i += W) {
+        S.hist[p][i] = 0u;
+      }
+      ldsBarrier();
+      full = true;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        if (cbin[j] != kSlInvalid) {
+          cbin[j] = slBin(best, cs[j], shift, base);
+          atomAdd32(&S.hist[p][cbin[j]], 1u);
+        }
+      }
+      ldsBarrier();
+    }
+    if (dead) {
+      return;
+    }
+    if (sc.total > K) {
+      const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
+                                            : (sc.bstar + base) >> (kSlFineShift - shift);
+      winShift = kSlFineShift;
+      winBase = q15 > 256 ? q15 - 256 : 0;
+    }
+    FLTX_YLPROF(3);
+    /* ---- what the build needs and is known already ----------------------------------------- */
+    uint32_t pend = 0u;         /* slots of this thread that become new lanes */
+    int nNewWave = 0;
+    int myNew[NS];
+    XNode planX = {};           /* record of the child the first new lane of this thread stands on ... */
+    int planOrph = -1;          /* ... and the slot of the orphan table that lists the lanes it adopts */
+    int planSlot = -1;
+    uint32_t rootSid[NG];
+    int rootOrph[NG];
+    bool surv = false;
+    uint32_t hNB = kSlNoHyp, hB = kSlNoHyp;
+    unsigned long long balS = 0ull;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      myNew[j] = 0;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      rootSid[g] = 0u;
+      rootOrph[g] = -1;
+    }
+    uint32_t planLm = 0u, planPar = 0u;
+    /* (reads nothing of the lanes: a slot whose lane drops out this frame is taken again in the same build) */
+    auto planChild = [&](int j) {
+      uint32_t cn = cnode[0];
+      planLm = cpl[0];
+      planPar = cpn[0];
+#pragma unroll
+      for (int i = 1; i < NS; ++i) {
+        cn = i == j ? cnode[i] : cn;
+        planLm = i == j ? cpl[i] : planLm;
+        planPar = i == j ? cpn[i] : planPar;
+      }
+      planSlot = j;
+      planX = xnode[cn];
+      planOrph = ylOrphFind(S.orph[p], xlKey(planLm, (int32_t)cn));
+      return cn;
+    };
+    uint32_t planNode = 0u;
+    if (isTok || isWord) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        if (selMask[j] != 0ull) {
+          myNew[j] = nNewWave + wavePrefixCount(selMask[j]);
+          nNewWave += popc64(selMask[j]);
+        }
+        pend |= (uint32_t)((selMask[j] >> lane) & 1ull) << j;
+      }
+      /* order of the new lanes: token waves, then the word wave */
+      const int slot = isTok ? wave : nTok;
+      if (lane > slot && lane <= nTok + 1 && nNewWave > 0) {
+        atomAdd32(&S.off[lane], (uint32_t)nNewWave);
+      }
+      const uint32_t childPend = isTok ? pend : (pend & 0xAAAAAAAAu); /* word wave: odd slots are children */
+      if (childPend) {
+        planNode = planChild(__builtin_ctz(childPend));
+      }
+      if (isWord) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if ((pend >> (2 * g)) & 1u) {
+            /* the LM state's number (memo: the same (LM state, word) gives the same state back) */
+            const uint32_t xlm = cpl[2 * g];
+            const int32_t el = (int32_t)cpn[2 * g];
+            const unsigned long long mkey = xlKey(xlm, el);
+            uint32_t h = xlHash(mkey) & (kYlMemo - 1);
+            for (int probe = 0;; ++probe) {
+              const unsigned long long old = atomCas64(&S.memo[h].key, 0ull, mkey);
+              if (old == 0ull) {
+                const uint32_t sid = atomAdd32(&S.lmNext, 1u);
+                rootSid[g] = sid;
+                S.memo[h].sid = sid;
+                if (atomAdd32(&S.memoUsed, 1u) > (uint32_t)(kYlMemo * 3 / 4) || sid + 1u >= P.stateCap) {
+                  atomOr32(&S.scal[YL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
+                } else if (ngram) {
+                  ylLmScore(P, b, xlm, el, sid, true); /* the new state's n-gram context */
+                  ++nScored;
+                }
+                break;
+              }
+              if (old == mkey) {
+                rootSid[g] = S.memo[h].sid;
+                break;
+              }
+              h = (h + 1u) & (kYlMemo - 1);
+              if (probe > kYlMemo) {
+                atomOr32(&S.scal[YL_FLAG], 1u);
+                break;
+              }
+            }
+            rootOrph[g] = ylOrphFind(S.orph[p], xlKey(rootSid[g], 0));
+          }
+        }
+      }
+    } else if (isSelf) {
+      const unsigned long long balB = selMask[0], balR = selMask[1];
+      balS = balB | balR;
+      const bool sR = ((balR >> lane) & 1ull) != 0ull;
+      surv = ((balS >> lane) & 1ull) != 0ull;
+      hNB = (uint32_t)(wavePrefixCount(balR) + wavePrefixCount(balB));
+      hB = hNB + (sR ? 1u : 0u);
+      const unsigned long long fr = ~balS;
+      if ((fr >> lane) & 1ull) {
+        S.freeList[grp][wavePrefixCount(fr)] = (uint8_t)lane;
+      }
+      if (lane == 0) {
+        S.alive[q][grp] = balS;
+        S.surv[grp] = balS;
+        S.nFree[grp] = (uint32_t)popc64(fr);
+      }
+      if (lane > grp && lane <= NG) {
+        atomAdd32(&S.offH[lane], (uint32_t)(popc64(balR) + popc64(balB)));
+      }
+    } else if (isSvc && t + 1 < T) {
+      nextRow.v = rv;
+      nextRow.allow = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
+      if (fastRank) {
+        xlRankRange<10, 16>(rs);
+        nextRow.allow = xlRankEnd(rs, N, P.Kt);
+      } else if (needRank) {
+        rankPart(rk2, N);
+        nextRow.allow = waveBallot(lane < N && rk < P.Kt);
+      }
+      nextRow.listMask = nextRow.allow;
+      nextRow.nList = popc64(nextRow.allow);
+      nextRow.best = 0.0; /* (this engine takes the frame's best from the candidates) */
+      nextRow.dead = false;
+    }
+    FLTX_YLPROF(4);
+    ldsBarrier(); /* 2 */
+    /* ---- phase 3: every survivor is written by the thread that evaluated it ---------------- */
+    const unsigned long long surv0 = S.surv[0], surv1 = NG > 1 ? S.surv[1] : 0ull;
+    const int nHSurv = (int)S.offH[NG];
+    const int nNew = (int)S.off[nTok + 1];
+    const uint32_t nFree0 = S.nFree[0];
+    auto survives = [&](int x) { return (((x < 64 ? surv0 : surv1) >> (x & 63)) & 1ull) != 0ull; };
+    auto freeSlot = [&](int idx) {
+      return (uint32_t)idx < nFree0 ? (int)S.freeList[0][idx] : 64 + (int)S.freeList[1][(idx - (int)nFree0) & 63];
+    };
+    /* the lanes in the beam whose parent pair is the one in orphan slot `os`: they link to lane nl */
+    auto adopt = [&](int os, int nl) {
+      if (os < 0) {
+        return;
+      }
+      unsigned long long toks = 0ull;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        unsigned long long o = S.orph[p].lanes[g][os];
+        while (o) {
+          const int x = g * 64 + __builtin_ctzll(o);
+          o &= o - 1ull;
+          if (survives(x)) {
+            L.link[x] = (uint32_t)nl + 1u;
+            toks |= 1ull << (L.info[x] & 63u);
+          }
+        }
+      }
+      if (toks) {
+        atomOr64(&S.cmask[q][nl], toks);
+      }
+    };
+    /* a new lane on the planned child */
+    auto newChild = [&](int idx, double c, double lmc, uint32_t ci, uint32_t child, float dl) {
+      const int nl = freeSlot(idx);
+      const uint32_t hyp = (uint32_t)(nHSurv + idx);
+      const int x = (int)(ci & 0xFFu), n = (int)((ci >> 8) & 0xFFu);
+      const uint32_t hp = ci >> 16;
+      const XNode cx = planX;
+      const bool ps = survives(x);
+      L.nb[nl] = c;
+      L.b[nl] = NEG;
+      L.lmNB[nl] = lmc;
+      L.lmB[nl] = 0.0;
+      L.childMask[nl] = cx.childMask;
+      L.kidsMask[nl] = cx.kidsMask;
+      L.info[nl] = (uint32_t)n | (hyp << 16) | (kSlNoHyp << 24);
+      L.link[nl] = ps ? (uint32_t)x + 1u : 0u;
+      L.lmSid[nl] = planLm;
+      L.node[nl] = child;
+      L.parent[nl] = planPar;
+      L.firstChild[nl] = cx.firstChild;
+      L.endLabel[nl] = cx.endLabel0;
+      L.dPar[nl] = 0u;
+      L.dWord[nl] = -1;
+      L.maxScore[nl] = cx.maxScore;
+      L.delta[nl] = dl;
+      L.endLm[nl] = kYlNoLm;
+      atomOr64(&S.alive[q][nl >> 6], 1ull << (nl & 63));
+      if (ps) {
+        atomOr64(&S.cmask[q][x], 1ull << n);
+      }
+      histPT[hrow + hyp] = make_int2((int)hp, n);
+      histW[hrow + hyp] = -1;
+      adopt(planOrph, nl);
+    };
+    if (isSvc) {
+      if (lane + 64 * 0 >= nHSurv + nNew && lane < K) {
+        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
+      }
+      if (lane + 64 >= nHSurv + nNew && lane + 64 < K) {
+        histPT[hrow + lane + 64] = make_int2((int)kSlNoHyp, -1);
+      }
+      if (t + 1 < T) {
+        slRowStore(P, S, q, nextRow, P.Kt < N);
+      }
+      ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+      ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+      /* the merge table of the next frame starts empty (winHyp / winWord / winLm, which the self
+       * waves read now, stay), and so does its orphan table: 16 bytes per lane and store */
+      static_assert(kYlRoot == 256 && kYlOrph == 256, "the wipes below cover 256 slots");
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u), f4 = make_uint4(~0u, ~0u, ~0u, ~0u);
+      ((uint4*)S.root.key)[lane] = z4;
+      ((uint4*)S.root.key)[lane + 64] = z4;
+      ((uint4*)S.root.best)[lane] = z4;
+      ((uint4*)S.root.best)[lane + 64] = z4;
+      ((uint4*)S.root.lane)[lane] = z4;
+      ((uint4*)S.root.minLane)[lane] = f4;
+      ((uint4*)S.orph[q].key)[lane] = z4;
+      ((uint4*)S.orph[q].key)[lane + 64] = z4;
+      ((uint4*)S.orph[q].lanes[0])[lane] = z4;
+      ((uint4*)S.orph[q].lanes[0])[lane + 64] = z4;
+      ((uint4*)S.orph[q].lanes[1])[lane] = z4;
+      ((uint4*)S.orph[q].lanes[1])[lane + 64] = z4;
+    } else if (isTok) {
+      /* most threads create at most one: every round takes each thread's lowest pending slot */
+      bool first = true;
+      while (waveBallot(pend != 0u) != 0ull) {
+        if (pend) {
+          const int j0 = __builtin_ctz(pend);
+          pend &= pend - 1u;
+          double c = cs[0], lmc = clm[0];
+          int mn = myNew[0];
+          uint32_t ci = cinf[0];
+          float dl = cdl[0];
+#pragma unroll
+          for (int j = 1; j < NS; ++j) {
+            c = j == j0 ? cs[j] : c;
+            lmc = j == j0 ? clm[j] : lmc;
+            mn = j == j0 ? myNew[j] : mn;
+            ci = j == j0 ? cinf[j] : ci;
+            dl = j == j0 ? cdl[j] : dl;
+          }
+          if (!first) {
+            planNode = planChild(j0);
+          }
+          newChild((int)S.off[wave] + mn, c, lmc, ci, planNode, dl);
+        }
+        first = false;
+      }
+    } else if (isSelf) {
+      if (surv) {
+        const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
+        const uint32_t hb = S.offH[grp];
+        L.nb[li] = sR ? cs[1] : NEG;
+        L.b[li] = sB ? cs[0] : NEG;
+        L.info[li] = (uint32_t)last | ((sR ? hNB + hb : kSlNoHyp) << 16) | ((sB ? hB + hb : kSlNoHyp) << 24);
+        if (pl >= 0) {
+          if (survives(pl)) {
+            atomOr64(&S.cmask[q][pl], 1ull << last);
+          } else {
+            L.link[li] = 0u;
+          }
+        }
+        double lmStay = lmR;
+        if (sR) {
+          uint32_t hp = parR;
+          int32_t wd = -1;
+          if (hp == kSlNoHyp) { /* a word ending on this root beat its own stay */
+            hp = S.root.winHyp[rootSlot];
+            wd = S.root.winWord[rootSlot];
+            lmStay = S.root.winLm[rootSlot];
+          }
+          histPT[hrow + hNB + hb] = make_int2((int)hp, atRoot ? sil : last);
+          histW[hrow + hNB + hb] = wd;
+        }
+        if (sB) {
+          histPT[hrow + hB + hb] = make_int2((int)hypM, blank);
+          histW[hrow + hB + hb] = -1;
+        }
+        if (LMK) {
+          L.lmNB[li] = lmStay;
+          L.lmB[li] = lmM;
+        }
+      }
+    } else if (isWord) {
+      const int offW = (int)S.off[nTok];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int x = g * 64 + lane;
+        if ((pend >> (2 * g)) & 1u) { /* a word ended and nobody stood on that root: a new root lane */
+          const int idx = offW + myNew[2 * g];
+          const int nl = freeSlot(idx);
+          const uint32_t hyp = (uint32_t)(nHSurv + idx);
+          const uint32_t hp = cinf[2 * g] >> 16;
+          const uint32_t sid = rootSid[g];
+          const XNode r0 = S.rootNode;
+          const uint32_t xlm = cpl[2 * g];
+          const int32_t el = (int32_t)cpn[2 * g];
+          L.nb[nl] = cs[2 * g];
+          L.b[nl] = NEG;
+          L.lmNB[nl] = clm[2 * g];
+          L.lmB[nl] = 0.0;
+          L.childMask[nl] = r0.childMask;
+          L.kidsMask[nl] = r0.kidsMask;
+          L.info[nl] = (uint32_t)endTok | (hyp << 16) | (kSlNoHyp << 24);
+          L.link[nl] = 0u;
+          L.lmSid[nl] = sid;
+          L.node[nl] = 0u;
+          L.parent[nl] = 0u;
+          L.firstChild[nl] = r0.firstChild;
+          L.endLabel[nl] = r0.endLabel0;
+          L.dPar[nl] = xlm;
+          L.dWord[nl] = el;
+          L.maxScore[nl] = r0.maxScore;
+          L.delta[nl] = 0.0f;
+          L.endLm[nl] = kYlNoLm;
+          atomOr64(&S.alive[q][nl >> 6], 1ull << (nl & 63));
+          histPT[hrow + hyp] = make_int2((int)hp, endTok);
+          histW[hrow + hyp] = el;
+          adopt(rootOrph[g], nl);
+          (void)x;
+        }
+      }
+      /* blank-then-own-token lanes */
+      uint32_t cp = pend & 0xAAAAAAAAu;
+      bool first = true;
+      while (waveBallot(cp != 0u) != 0ull) {
+        if (cp) {
+          const int j0 = __builtin_ctz(cp);
+          cp &= cp - 1u;
+          double c = cs[0], lmc = clm[0];
+          int mn = myNew[0];
+          uint32_t ci = cinf[0];
+          float dl = cdl[0];
+#pragma unroll
+          for (int j = 1; j < NS; ++j) {
+            c = j == j0 ? cs[j] : c;
+            lmc = j == j0 ? clm[j] : lmc;
+            mn = j == j0 ? myNew[j] : mn;
+            ci = j == j0 ? cinf[j] : ci;
+            dl = j == j0 ? cdl[j] : dl;
+          }
+          if (!first) {
+            planNode = planChild(j0);
+          }
+          newChild(offW + mn, c, lmc, ci, planNode, dl);
+        }
+        first = false;
+      }
+    }
+    FLTX_YLPROF(5);
+    ldsBarrier(); /* 3 */
+    if (S.scal[YL_FLAG] != 0u) {
+      dead = true;
+    }
+    FLTX_YLPROF(6);
+  };
+  {
+    int t = 0;
+    for (; t + 1 < T && !dead; t += 2) {
+      frameStep(SlParity<0>(), rowA, t);
+      if (dead) {
+        break;
+      }
+      frameStep(SlParity<1>(), rowB, t + 1);
+    }
+    if (!dead && t < T) {
+      frameStep(SlParity<0>(), rowA, t);
+    }
+  }
+
+  /* ---- decodeEnd (LexiconDecoder.cpp:231-274): if any hypothesis stands on the root only those
+   * finish; lm.finish (KenLM.cpp:88-104: the score of </s>) is added; the two hypotheses of a lane
+   * merge; sorted n-best ------------------------------------------------------------------------ */
+  const int pe = T & 1;
+  const int ff = T + 1;
+  if (!dead) {
+    bool liveE = false, onRoot = false;
+    double mE = NEG, lmE = 0.0;
+    uint32_t hpE = kSlNoHyp, lmSidE = 0u;
+    if (wave < NG) {
+      const int x = wave * 64 + lane;
+      liveE = ((S.alive[pe][wave] >> lane) & 1ull) != 0ull;
+      const double xnb = liveE ? L.nb[x] : NEG, xb = liveE ? L.b[x] : NEG;
+      const uint32_t xi = L.info[x];
+      const bool wb = xb > xnb;
+      mE = wb ? xb : xnb;
+      hpE = wb ? (xi >> 24) : ((xi >> 16) & 0xFFu);
+      lmE = LMK ? (wb ? L.lmB[x] : L.lmNB[x]) : 0.0;
+      lmSidE = L.lmSid[x];
+      onRoot = L.node[x] == 0u;
+      if (liveE && onRoot) {
+        S.scal[YL_NICE] = 1u;
+      }
+    }
+    ldsBarrier();
+    const bool nice = S.scal[YL_NICE] != 0u;
+    if (wave < NG) {
+      const int x = wave * 64 + lane;
+      const bool cand = liveE && (!nice || onRoot);
+      double sc = mE;
+      if (ngram && cand) {
+        const float fs = ylNgram(P, b, lmSidE, (uint32_t)P.lmEos, 0u, false);
+        ++nScored;
+        sc = mE + lmWeight * (double)fs;
+        lmE = lmE + (double)fs;
+      }
+      S.endKey[x] = (cand && sc == sc) ? f64Key(sc) : 0ull;
+      S.endScore[x] = sc;
+      S.endLmS[x] = lmE;
+      S.endHyp[x] = hpE;
+    }
+    ldsBarrier();
+    if (wave < NG) {
+      const int x = wave * 64 + lane;
+      unsigned long long bk = 0ull;
+      for (int i = 0; i < 64 * NG; ++i) {
+        const unsigned long long k2 = S.endKey[i];
+        bk = k2 > bk ? k2 : bk;
+      }
+      /* candidatesBestScore_ is the best of the candidates that finish */
+      const double thr = f64FromKey(bk) - P.beamThreshold;
+      const unsigned long long key = S.endKey[x];
+      const bool ok = key != 0ull && bk != 0ull && S.endScore[x] >= thr;
+      int rank = 0, nOk = 0;
+      for (int i = 0; i < 64 * NG; ++i) {
+        const unsigned long long k2 = S.endKey[i];
+        const bool ok2 = k2 != 0ull && S.endScore[i] >= thr;
+        const uint32_t h2 = S.endHyp[i];
+        rank += (ok2 && (k2 > key || (k2 == key && h2 < hpE))) ? 1 : 0;
+        nOk += ok2 ? 1 : 0;
+      }
+      if (ok) {
+        const size_t g = ((size_t)b * K + rank) * 3;
+        P.outScores[g + 0] = S.endScore[x];
+        P.outScores[g + 1] = 0.0; /* emitting-model score: the back-trace kernel fills it in */
+        P.outScores[g + 2] = S.endLmS[x];
+        histPT[hbase + (int64_t)ff * K + rank] = make_int2((int)hpE, sil);
+        histW[hbase + (int64_t)ff * K + rank] = -1;
+      }
+      if (tid == 0) {
+        P.outN[b] = nOk;
+        P.uttNBeam[b] = nOk;
+        P.uttFrame[b] = ff;
+        P.uttTotal[b] = ff;
+        P.uttStatus[b] = ST_PACKED;
+      }
+    }
+  }
+  if (dead && tid == 0) {
+    P.outN[b] = 0;
+    P.uttNBeam[b] = 0;
+    P.uttFrame[b] = ff;
+    P.uttTotal[b] = ff;
+    P.uttStatus[b] = ST_SELECT_FALLBACK;
+  }
+  if (P.scored && nScored != 0u) {
+    atomAdd32(&P.scored[b], nScored);
+  }
+  if (PROF && P.prof && tid == P.profThread) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      P.prof[(size_t)b * 8 + i] = acc[i];
+    }
+  }
+  (void)li;
+}
+#undef FLTX_YLPROF
