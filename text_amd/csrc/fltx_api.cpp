@@ -247,6 +247,7 @@ struct fltx_trie {
   DBuf xnode, xdelta;
   bool xOk = false;     /* the layout exists and the trie has the shape that engine assumes: */
   int32_t xEndTok = -1; /* every node that carries labels is entered by this one token (the word separator) */
+  float xDeltaMin = 0.0f, xDeltaMax = 0.0f; /* range of the smearing differences of the layout */
   bool xZeroSmear = true; /* every maxScore is 0 (a lexicon without LM scores) */
 };
 
@@ -864,6 +865,10 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
       xn.clear();
       xd.clear();
     }
+    for (float v : xd) {
+      t->xDeltaMin = std::min(t->xDeltaMin, v);
+      t->xDeltaMax = std::max(t->xDeltaMax, v);
+    }
     xdHost.swap(xd);
   }
   if (!xn.empty()) {
@@ -1282,7 +1287,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const int threads = ng == 1 ? 512 : 768;
     const int nTokWaves = threads / 64 - ng - 2;
     const int tpw = (nTok + nTokWaves - 1) / nTokWaves;
-    if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96) {
+    if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96 && tpw * 64 * ng <= 512 && nTokWaves <= 8) {
       d->ylane = ng;
       d->ylaneRounds = ng == 1 ? 2 : 4;
       d->ylaneTpw = tpw;
@@ -1622,6 +1627,9 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xEndTok = d->trie ? d->trie->xEndTok : -1;
   P.xdelta = (d->trie && d->trie->xdelta.p) ? d->trie->xdelta.as<float>() : nullptr;
   P.yTpw = d->ylaneTpw;
+  P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
+                                              d->opt.lm_weight * (double)d->trie->xDeltaMax))
+                     : 0.0;
   P.scored = (d->lm->kind == 1 && d->scored.p) ? d->scored.as<uint32_t>() : nullptr;
   P.profThread = 64 * d->profWave;
   if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {

@@ -186,6 +186,7 @@ struct DecodeParams {
   int32_t xEndTok;              /* the token every word ends with in that layout */
   const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
+  double yBound;                /* ... and the largest lmWeight x smearing difference of the lexicon (>= 0) */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
   int32_t profThread; /* the thread whose clock is sampled (lane 0 of the wave under study) */

@@ -35,8 +35,9 @@
 constexpr int kYlLanes = 128;
 constexpr int kYlRoot = 256;  /* slots of the per-frame (LM state, word) merge table */
 constexpr int kYlOrph = 256;  /* slots of the per-frame table of lanes without a parent lane */
-constexpr int kYlMemo = 4096; /* slots of the LM-state memo */
-constexpr int kYlTokWaves = 12;
+constexpr int kYlMemo = 8192; /* slots of the LM-state memo: (LM state + 1) << 40 | (word + 1) << 16 | number of the child state */
+constexpr int kYlTokWaves = 8;
+constexpr int kYlPairs = 512; /* (lane, token) pairs a token wave can list: positions per wave x lanes */
 constexpr uint32_t kYlNoLm = 0x7FC00001u; /* endLm: not looked up yet (a NaN no arithmetic produces) */
 
 struct YlLanes { /* in place: slot = lane for as long as the lane lives */
@@ -82,7 +83,7 @@ struct YlaneLds {
   uint8_t tokId[2][kSlList];
   YlRootTab root;
   YlOrphTab orph[2];
-  XlMemoSlot memo[kYlMemo];
+  unsigned long long memo[kYlMemo];
   unsigned long long bestKey[2];
   unsigned long long alive[2][2];    /* lanes of the frame, per group */
   unsigned long long surv[2];        /* ... that stay for the next frame (alive[next] = these + the new lanes) */
@@ -91,11 +92,14 @@ struct YlaneLds {
   uint32_t offH[4];                  /* surviving hypotheses of the lane groups before group g; [NG] = all */
   uint32_t nFree[2];
   uint8_t freeList[2][64];           /* free slots of a group, in slot order */
-  uint16_t cand[kYlTokWaves][256];   /* (lane | list position << 8) pairs of a token wave */
+  uint16_t cand[kYlTokWaves][kYlPairs]; /* (lane | list position << 8) pairs of a token wave */
+  uint16_t pbin[kYlTokWaves][kYlPairs]; /* a wave with more pairs than its rounds take ranks them: bins ... */
+  uint32_t whist[kYlTokWaves][kSlNB];   /* ... and their counts */
+  unsigned long long lb[2];          /* a candidate the frame is known to have (stay / blank of a surviving lane): best >= this */
   uint32_t scal[16];
   unsigned long long bKey[kSlBCap];
   uint32_t bOrd[kSlBCap];
-  uint32_t memoUsed, lmNext;
+  uint32_t lmNext, pad0;
   /* decodeEnd */
   unsigned long long endKey[kYlLanes];
   double endScore[kYlLanes], endLmS[kYlLanes];
@@ -166,6 +170,16 @@ FLTX_DEV float ylLmScore(const DecodeParams& P, int b, uint32_t sid, int usr, ui
   return ylNgram(P, b, sid, word, outSid, wantCtx);
 }
 
+#ifdef FLTX_EMU
+#define YL_WHY(r)                                                                          \
+  do {                                                                                     \
+    if (getenv("FLTX_YL_WHY") && lane == 0) {                                              \
+      fprintf(stderr, "ylane: utterance %d wave %d gives up, reason %d\n", b, wave, (r)); \
+    }                                                                                      \
+  } while (0)
+#else
+#define YL_WHY(r) ((void)0)
+#endif
 #define FLTX_YLPROF(i)                                        \
   do {                                                        \
     if (PROF && P.prof && (int)threadIdx.x == P.profThread) { \
@@ -182,7 +196,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   YlaneLds& S = *(YlaneLds*)smem;
   constexpr int NS = R > 2 * NG ? R : 2 * NG; /* candidate slots of a thread */
   static_assert(NG == 1 || NG == 2, "one or two lane groups");
-  static_assert(R * 64 <= 256, "cand[] holds 256 pairs per token wave");
+  static_assert(R * 64 <= kYlPairs, "cand[] holds kYlPairs pairs per token wave");
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x, tid = (int)threadIdx.x;
   const int lane = laneId(), wave = waveUniform(waveId());
@@ -234,7 +248,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     S.orph[1].lanes[1][i] = 0ull;
   }
   for (int i = tid; i < kYlMemo; i += W) {
-    S.memo[i].key = 0ull;
+    S.memo[i] = 0ull;
   }
   if (tid < 32) {
     S.off[tid] = 0u;
@@ -276,7 +290,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     S.row[1].dead = 0u;
     S.bestKey[0] = 0ull;
     S.bestKey[1] = 0ull;
-    S.memoUsed = 0u;
+    S.lb[0] = 0ull;
+    S.lb[1] = 0ull;
     S.lmNext = 1u;
     histPT[hbase] = make_int2((int)kSlNoHyp, sil);
     histW[hbase] = -1;
@@ -385,6 +400,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       if (lane == 0) {
         S.scal[SL_BCNT] = 0u;
         S.bestKey[q] = 0ull;
+        S.lb[q] = 0ull;
       }
       if (fastRank) {
         rs = xlRankBegin(rv, N);
@@ -397,37 +413,115 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       /* the (lane, token) pairs with a child that has children and no lane of its own yet, the
        * node's own token excepted (that one needs the blank in between): LexiconDecoder.cpp:89-110 */
       unsigned long long ext[NG];
+      double mg[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int x = g * 64 + lane;
         const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
         const unsigned long long own = 1ull << (L.info[x] & 63u);
         ext[g] = lv ? (L.childMask[x] & L.kidsMask[x] & ~S.cmask[p][x] & ~own) : 0ull;
+        const double xnb = L.nb[x], xb = L.b[x];
+        mg[g] = xb > xnb ? xb : xnb;
       }
+      /* Pairs that cannot reach the threshold are left out at once: the frame's best is at least
+       * lb (a stay / blank candidate of a lane that survived the last frame), and a pair scores at
+       * most m + e (+ silScore) + the largest smearing term of the lexicon. */
+      const unsigned long long lbk = S.lb[p];
+      const double lbBest = lbk != 0ull ? f64FromKey(lbk) : NEG;
+      const double thrLB = lbBest - beamThreshold;
+      const double bterm = LMK ? P.yBound : 0.0;
       for (int j = 0; j < TPW; ++j) {
-        const unsigned long long tbj = S.tokBit[p][wave * TPW + j];
+        const int pos = wave * TPW + j;
+        const unsigned long long tbj = S.tokBit[p][pos];
         if (tbj == 0ull) {
           continue;
         }
+        double ej = S.eTok[p][pos];
+        if (pos == silPos) {
+          ej = ej + silScore;
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          const bool has = (ext[g] & tbj) != 0ull;
+          const bool has = (ext[g] & tbj) != 0ull && (mg[g] + ej) + bterm >= thrLB;
           const unsigned long long bal = waveBallot(has);
           if (bal != 0ull) {
             const int at = nCand + wavePrefixCount(bal);
-            if (has && at < R * 64) {
+            if (has && at < kYlPairs) {
               S.cand[wave][at] = (uint16_t)((g * 64 + lane) | (j << 8));
             }
             nCand += popc64(bal);
           }
         }
       }
-      if (nCand > R * 64) { /* more pairs than the threads' rounds take: general path */
-        dead = true;
-        nCand = R * 64;
-        if (lane == 0) {
-          S.bestKey[p] = ~0ull;
+#ifdef FLTX_EMU
+      if (getenv("FLTX_YL_WHY") && lane == 0 && wave == 1) {
+        fprintf(stderr, "ylane: frame %d wave %d pairs %d lanes %d\n", t, wave, nCand, popc64(alive0) + popc64(alive1));
+      }
+#endif
+      if (nCand > kYlPairs) { /* (the host sizes the waves' shares so that this cannot happen) */
+        dead = true; YL_WHY(7);
+        nCand = kYlPairs;
+      }
+      waveSync();
+      if (nCand > R * 64 && !dead) {
+        /* More pairs than the threads' rounds take (the beam fans out at the start of an utterance):
+         * none but the K best of this wave's own pairs can be among the frame's K best, so the wave
+         * ranks its pairs by itself -- bins of the distance to lb, whole bins kept -- and goes on with
+         * those. */
+        uint32_t* wh = S.whist[wave];
+        ((uint4*)wh)[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+        ((uint4*)wh)[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+        waveSync();
+        for (int c0 = 0; c0 < nCand; c0 += 64) {
+          const int id = c0 + lane;
+          const bool valid = id < nCand;
+          const uint32_t c16 = valid ? (uint32_t)S.cand[wave][id] : 0u;
+          const int x = (int)(c16 & 0xFFu), pos = wave * TPW + (int)(c16 >> 8);
+          const double xnb = L.nb[x], xb = L.b[x];
+          const int n = (int)S.tokId[p][pos];
+          double c = (xb > xnb ? xb : xnb) + S.eTok[p][pos];
+          if (pos == silPos) {
+            c = c + silScore;
+          }
+          if (LMK) {
+            const uint32_t child = L.firstChild[x] + (uint32_t)popc64(L.childMask[x] & ((1ull << n) - 1ull));
+            const float dl = valid ? xdelta[child] : 0.0f;
+            c = c + lmWeight * (double)dl;
+          }
+          int bin = kSlInvalid;
+          if (valid && c == c) {
+            bin = c >= lbBest ? 0 : slBin(lbBest, c, kSlCoarseShift, kSlCoarseBase);
+            atomAdd32(&wh[bin], 1u);
+          }
+          if (valid) {
+            S.pbin[wave][id] = (uint16_t)bin;
+          }
         }
+        waveSync();
+        const SlScan ws = slScan(wh, K);
+        const int cut = ws.crossed ? ws.bstar : kSlNB - 1;
+        int kept = 0;
+        for (int c0 = 0; c0 < nCand; c0 += 64) {
+          const int id = c0 + lane;
+          const bool valid = id < nCand;
+          const uint32_t c16 = valid ? (uint32_t)S.cand[wave][id] : 0u;
+          const bool keep = valid && (int)S.pbin[wave][valid ? id : 0] <= cut;
+          const unsigned long long bal = waveBallot(keep);
+          waveSync();
+          if (keep) {
+            S.cand[wave][kept + wavePrefixCount(bal)] = (uint16_t)c16;
+          }
+          kept += popc64(bal);
+          waveSync();
+        }
+        nCand = kept;
+        if (!(lbk != 0ull) || nCand > R * 64) { /* still too many (ties by the hundred): general path */
+          dead = true; YL_WHY(1);
+          nCand = R * 64;
+        }
+      }
+      if (dead && lane == 0) {
+        S.bestKey[p] = ~0ull;
       }
       waveSync();
 #pragma unroll
@@ -624,7 +718,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         full = full || (isWord && cok[2 * g] && wSlot[g] < 0);
       }
       if (waveBallot(full) != 0ull) {
-        dead = true; /* merge table full: general path (uniform after the barrier below via bestKey = ~0) */
+        dead = true; YL_WHY(2); /* merge table full: general path (uniform after the barrier below via bestKey = ~0) */
         if (lane == 0) {
           S.bestKey[p] = ~0ull;
         }
@@ -649,12 +743,12 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     /* ---- phase 1b: threshold, merge-table verdicts, histogram ---------------------------- */
     const unsigned long long bk = S.bestKey[p];
     if (bk == 0ull || bk == ~0ull) {
-      dead = true;
+      dead = true; YL_WHY(3);
       return;
     }
     const double best = f64FromKey(bk);
     if (!(best - best == 0.0)) {
-      dead = true;
+      dead = true; YL_WHY(4);
       return;
     }
     const double thr = best - beamThreshold;
@@ -708,6 +802,18 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
     }
+#ifdef FLTX_EMU
+    if (getenv("FLTX_YL_WHY") && isTok && wave == 1) {
+      int np = 0, nw = 0;
+      for (int j = 0; j < NS; ++j) {
+        np += popc64(waveBallot(cbin[j] != kSlInvalid));
+        nw += popc64(waveBallot(cbin[j] < kSlFar));
+      }
+      if (lane == 0) {
+        fprintf(stderr, "ylane: frame %d passing %d inwindow %d\n", t, np, nw);
+      }
+    }
+#endif
     FLTX_YLPROF(2);
     ldsBarrier(); /* 1 */
     /* ---- phase 2: which candidates survive (as fltx_slane.h) ------------------------------ */
@@ -788,7 +894,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           bHi = h2 < bHi ? h2 : bHi;
         }
         if (bLo >= bHi) {
-          dead = true;
+          dead = true; YL_WHY(5);
           break;
         }
         int ns = 0;
@@ -887,24 +993,31 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             /* the LM state's number (memo: the same (LM state, word) gives the same state back) */
             const uint32_t xlm = cpl[2 * g];
             const int32_t el = (int32_t)cpn[2 * g];
-            const unsigned long long mkey = xlKey(xlm, el);
+            const unsigned long long mkey = ((unsigned long long)(xlm + 1u) << 24) | (unsigned long long)(uint32_t)(el + 1);
             uint32_t h = xlHash(mkey) & (kYlMemo - 1);
+            uint32_t sid = 0u;
+            bool have = false; /* a number was taken from the counter for this state */
             for (int probe = 0;; ++probe) {
-              const unsigned long long old = atomCas64(&S.memo[h].key, 0ull, mkey);
-              if (old == 0ull) {
-                const uint32_t sid = atomAdd32(&S.lmNext, 1u);
-                rootSid[g] = sid;
-                S.memo[h].sid = sid;
-                if (atomAdd32(&S.memoUsed, 1u) > (uint32_t)(kYlMemo * 3 / 4) || sid + 1u >= P.stateCap) {
-                  atomOr32(&S.scal[YL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
-                } else if (ngram) {
-                  ylLmScore(P, b, xlm, el, sid, true); /* the new state's n-gram context */
-                  ++nScored;
+              unsigned long long cur = S.memo[h];
+              if (cur == 0ull) {
+                if (!have) {
+                  sid = atomAdd32(&S.lmNext, 1u);
+                  have = true;
                 }
-                break;
+                cur = atomCas64(&S.memo[h], 0ull, (mkey << 16) | (unsigned long long)(sid & 0xFFFFu));
+                if (cur == 0ull) { /* a new LM state */
+                  if (sid > (uint32_t)(kYlMemo * 3 / 4) || sid + 1u >= P.stateCap || sid >= 0xFFFFu ||
+                      (uint32_t)(el + 1) >= (1u << 24)) {
+                    atomOr32(&S.scal[YL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
+                  } else if (ngram) {
+                    ylLmScore(P, b, xlm, el, sid, true); /* its n-gram context */
+                    ++nScored;
+                  }
+                  break;
+                }
               }
-              if (old == mkey) {
-                rootSid[g] = S.memo[h].sid;
+              if ((cur >> 16) == mkey) { /* (a number taken in vain stays unused) */
+                sid = (uint32_t)(cur & 0xFFFFull);
                 break;
               }
               h = (h + 1u) & (kYlMemo - 1);
@@ -913,6 +1026,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
                 break;
               }
             }
+            rootSid[g] = sid;
             rootOrph[g] = ylOrphFind(S.orph[p], xlKey(rootSid[g], 0));
           }
         }
@@ -950,6 +1064,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       nextRow.nList = popc64(nextRow.allow);
       nextRow.best = 0.0; /* (this engine takes the frame's best from the candidates) */
       nextRow.dead = false;
+      slRowStore(P, S, q, nextRow, P.Kt < N); /* (here: the lanes' own waves price their next stay / blank in the build) */
     }
     FLTX_YLPROF(4);
     ldsBarrier(); /* 2 */
@@ -1024,9 +1139,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       }
       if (lane + 64 >= nHSurv + nNew && lane + 64 < K) {
         histPT[hrow + lane + 64] = make_int2((int)kSlNoHyp, -1);
-      }
-      if (t + 1 < T) {
-        slRowStore(P, S, q, nextRow, P.Kt < N);
       }
       ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
       ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
@@ -1107,6 +1219,30 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           L.lmB[li] = lmM;
         }
       }
+      if (t + 1 < T) { /* what the next frame is sure to have: this lane's blank and stay (see the token waves) */
+        unsigned long long k = 0ull;
+        if (surv) {
+          const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
+          const double nnb = sR ? cs[1] : NEG, nbb = sB ? cs[0] : NEG;
+          const double nm = nbb > nnb ? nbb : nnb;
+          const double c0 = nm + S.eAll[q][blank];
+          k = c0 == c0 ? f64Key(c0) : 0ull;
+          if (atRoot || sR) {
+            double c1 = (atRoot ? nm : nnb) + S.eAll[q][atRoot ? sil : last];
+            if (atRoot || last == sil) {
+              c1 = c1 + silScore;
+            }
+            const unsigned long long k1 = c1 == c1 ? f64Key(c1) : 0ull;
+            k = k1 > k ? k1 : k;
+          }
+        }
+        if (waveBallot(k != 0ull) != 0ull) {
+          k = waveMax64(k);
+          if (lane == 0) {
+            atomMax64(&S.lb[q], k);
+          }
+        }
+      }
     } else if (isWord) {
       const int offW = (int)S.off[nTok];
 #pragma unroll
@@ -1176,7 +1312,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     FLTX_YLPROF(5);
     ldsBarrier(); /* 3 */
     if (S.scal[YL_FLAG] != 0u) {
-      dead = true;
+      dead = true; YL_WHY(6);
     }
     FLTX_YLPROF(6);
   };
@@ -1272,6 +1408,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       }
     }
   }
+#ifdef FLTX_EMU
+  if (getenv("FLTX_YL_WHY") && tid == 0) {
+    fprintf(stderr, "ylane: utterance %d ends dead=%d with %u LM states\n", b, (int)dead, S.lmNext);
+  }
+#endif
   if (dead && tid == 0) {
     P.outN[b] = 0;
     P.uttNBeam[b] = 0;
@@ -1291,3 +1432,4 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   (void)li;
 }
 #undef FLTX_YLPROF
+#undef YL_WHY

@@ -24,6 +24,7 @@ def main():
         d = job.decoder()
         d.decode_batch(job.e_host, job.Ts, job.N)
         job.ctx.synchronize()
+        print("first call: engine", d.get("engine"), "redone", d.get("redone"))
         t0 = time.perf_counter()
         d.decode_batch(job.e_host, job.Ts, job.N)
         job.ctx.synchronize()
