@@ -320,6 +320,9 @@ def phase_profile(a, dec, job, step, B, T):
             # narrowed histogram passes + 1e6 x far-candidate counts)
             names = ["loads", "candidates+best", "barA+verdicts+hist", "bar1+scan+select", "new-lane counts",
                      "bar2+build", "bar3", "select paths"]
+        if eng == 6:  # fltx_ylane.h
+            names = ["loads", "candidates+best", "barA+verdicts+hist", "bar1+scan+select", "plans+counts", "bar2+build",
+                     "bar3", "-"]
         names = [names[i] for i in order]
         pr = pr[order]
         tot = pr[:8].sum()

@@ -61,6 +61,39 @@ def test_emulated_lexicon_lane_engine(emu_session, golden, name, threads):
     assert ok, why
 
 
+YLANE = [("lx_scores_t50", {}), ("ng_word_t40_k10", {}), ("ng_word_t60_k16_4g", {}), ("lx_spell_t40_k8", {"ylane": 2}),
+         ("lx_uni_t40_k10", {"ylane": 2}), ("lx_t0", {"ylane": 2})]
+
+
+@pytest.mark.parametrize("name,sets", YLANE)
+def test_emulated_lexicon_lane_engine_with_lm_terms(emu_session, golden, name, sets):
+    """fltx_ylane.h (n-gram word LM / smeared trie / beams up to 128): stable lane slots, compacted
+    (lane, token) pairs."""
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    d = emu_session.decoder(c, inp)
+    for k, v in sets.items():
+        d.set(k, v)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    assert d.get("engine") == 6 and d.get("redone") == 0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
+    d.close()
+    assert ok, why
+
+
+def test_emulated_two_lane_groups(emu_session, oracle_lib):
+    """beam 90 over an n-gram LM: two groups of 64 lanes, four rounds of pairs per token-wave thread."""
+    c = [x for x in cases.fuzz_cases(120) if x["name"] == "fuzz113"][0]
+    inp = helpers.case_inputs(c)
+    want = helpers.run_checker(oracle_lib, c, inp)
+    d = emu_session.decoder(c, inp)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    assert d.get("engine") == 6 and d.get("ylane") == 2 and d.get("redone") == 0
+    ok, why = helpers.hyps_equal(want, d.results(0))
+    d.close()
+    assert ok, why
+
+
 LEX_SMALL = [c for c in cases.CASES if c["kind"] == "lexicon" and c["size"] == "small" and c["T"] <= 40
              and not c["log_add"]]
 

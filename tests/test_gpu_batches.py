@@ -85,7 +85,8 @@ def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample, sets=
     d.close()
 
 
-@pytest.mark.parametrize("sets,engine", [({}, 5), ({"xlane": 0}, 0)], ids=["lane-engine", "generic-engine"])
+@pytest.mark.parametrize("sets,engine", [({}, 5), ({"xlane": 0}, 6), ({"xlane": 0, "ylane": 0}, 0)],
+                         ids=["lane-engine", "lane-engine-with-lm-terms", "generic-engine"])
 def test_c3_batch_of_256(gpu_session, golden, oracle_lib, sets, engine):
     """C3 as benchmarked: served by the lane = (LM state, trie node) engine (fltx_xlane.h); the
     generic engine, which takes over whenever that one does not apply, on the same batch."""
@@ -93,14 +94,18 @@ def test_c3_batch_of_256(gpu_session, golden, oracle_lib, sets, engine):
                engine=engine)
 
 
-def test_c4_batch_of_256(gpu_session, golden, oracle_lib):
-    _run_batch(gpu_session, golden, oracle_lib, "C4_spell_u0", "C4_spell_u255", 256, sample=[131])
+@pytest.mark.parametrize("sets,engine", [({}, 6), ({"ylane": 0}, 0)], ids=["lane-engine", "generic-engine"])
+def test_c4_batch_of_256(gpu_session, golden, oracle_lib, sets, engine):
+    """C4 as benchmarked: served by fltx_ylane.h (n-gram word LM, smeared trie, beam 100 = two lane
+    groups); the generic engine on the same batch."""
+    _run_batch(gpu_session, golden, oracle_lib, "C4_spell_u0", "C4_spell_u255", 256, sample=[131], sets=sets,
+               engine=engine)
 
 
 def test_c5_share_of_one_gpu_1024_utterances(gpu_session, golden, oracle_lib):
     """BASELINE.json configs[4]: 8192 utterances over 8 GPUs = 1024 per GPU, i.e. four launch
     rounds of the 256 workgroups a device runs at a time."""
-    _run_batch(gpu_session, golden, oracle_lib, "C4_spell_u0", "C4_spell_u255", 1024, sample=[700, 1023])
+    _run_batch(gpu_session, golden, oracle_lib, "C4_spell_u0", "C4_spell_u255", 1024, sample=[700, 1023], engine=6)
 
 
 def test_random_configurations_slice(gpu_session, oracle_lib):
@@ -174,28 +179,57 @@ def test_edge_configurations_of_the_lexicon_lane_engine(gpu_session, oracle_lib)
     assert ran > 300 and served == ran and not bad, (ran, served, bad[:3])
 
 
-@pytest.mark.parametrize("kind", ["lexfree", "lexicon"])
+@pytest.mark.parametrize("kind", ["lexfree", "lexicon", "lexicon-lm"])
 def test_utterances_handed_to_the_generic_engine_inside_a_lane_engine_batch(gpu_session, kind):
     """The lane engines write packed history records and flag each utterance they finished
     (ST_PACKED); one whose frame has no finite candidate (a row of -inf) is decoded again on the
     generic engine, which writes plain records, and the back-trace has to read each kind as what
     it is.  Every utterance must equal what the generic engine alone returns for it."""
-    c = cases.BY_NAME["lf_ctc_t60_k10" if kind == "lexfree" else "lx_spell_t60_k12_full"]
+    c = cases.BY_NAME[{"lexfree": "lf_ctc_t60_k10", "lexicon": "lx_spell_t60_k12_full",
+                       "lexicon-lm": "ng_word_t60_k16_4g"}[kind]]
     inp = helpers.case_inputs(c)
     T, N, B = c["T"], c["N"], 6
     e = synth.batch("ctc" if kind == "lexfree" else "lexspell", B, T, N, lexicon=inp["lex"])
     e[2, 17, :] = -np.inf
     e[4, 0, :] = -np.inf
-    off = "slane" if kind == "lexfree" else "xlane"
     res = {}
-    for name, sets in (("lane", {}), ("generic", {off: 0, "lane": 0, "lean": 0})):
+    for name, sets in (("lane", {}), ("generic", {"slane": 0, "xlane": 0, "ylane": 0, "lane": 0, "lean": 0})):
         d = gpu_session.decoder(c, inp)
         for k, v in sets.items():
             d.set(k, v)
         d.decode_batch(e, [T] * B, N)
         res[name] = ([d.results(b) for b in range(B)], d.get("engine"), d.get("redone"))
         d.close()
-    assert res["lane"][1] in (4, 5) and res["lane"][2] == 2 and res["generic"][1] in (0, 1)
+    assert res["lane"][1] in (4, 5, 6) and res["lane"][2] == 2 and res["generic"][1] in (0, 1)
     for b in range(B):
         ok, why = helpers.hyps_equal(res["generic"][0][b], res["lane"][0][b])
         assert ok, "utterance %d: %s" % (b, why)
+
+
+def test_edge_configurations_of_the_lexicon_lane_engine_with_lm_terms(gpu_session, oracle_lib):
+    """fltx_ylane.h against the oracle: n-gram word LMs of order 2 .. 4 and label scores without an
+    LM (smearing only), beams 1 .. 128 (one and two lane groups), thresholds 0 .. inf, token
+    beams, lmWeight / wordScore / silScore of both signs, one-frame utterances, `uniform` rows."""
+    import itertools
+    bad, ran, served = [], 0, 0
+    grid = itertools.product([1, 2, 7, 64, 65, 100, 128], [0.0, 2.0, 25.0, float("inf")], [None, 3, 10],
+                             [("ngram", 2, 71), ("ngram", 4, 72), "scores"], [0.7, 2.0, -0.5], [0.0, 1.5, -2.0],
+                             [0.0, -0.7], [1, 17, 90], ["lexspell", "uniform"])
+    for i, (K, thr, Kt, lm, lw, ws, sil, T, dist) in enumerate(grid):
+        if i % 53 not in (0, 19):
+            continue
+        c = cases.case("yedge%d" % i, kind="lexicon", dist=dist, u=900 + i, T=T, K=K, Kt=Kt, thr=thr, sil_score=sil,
+                       word_score=ws, lm_weight=lw, lexicon=cases.SMALL_LEX, lm="zero" if lm == "scores" else lm,
+                       label_scores=(50 + i % 7) if lm == "scores" else None)
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue
+        got = gpu_session.run(c, inp)
+        served += gpu_session.last_engine == 6
+        ok, why = helpers.hyps_equal(want, got)
+        ran += 1
+        if not ok:
+            bad.append(({k: c[k] for k in ("K", "Kt", "thr", "lm", "lm_weight", "sil_score", "word_score", "T", "dist",
+                                           "label_scores")}, why))
+    assert ran > 250 and served == ran and not bad, (ran, served, bad[:3])

@@ -239,9 +239,13 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     ("lx_spell_t40_k8", 5, {}), ("lx_spell_t60_k12_full", 5, {}), ("lx_uni_t40_k10", 5, {}), ("lx_t0", 5, {}),
     ("C3_spell_u0", 5, {}), ("C3_spell_u255", 5, {}), ("C3_uniform_u0", 5, {}), ("C3_spell_u0", 5, {"slane_threads": 640}),
     ("lx_spell_t60_k12_full", 5, {"slane_threads": 576}), ("lx_spell_t40_k8", 5, {"slane_threads": 640}),
-    ("lx_spell_t40_k8", 0, {"xlane": 0}), ("C3_spell_u0", 0, {"xlane": 0}), ("C3_uniform_u0", 0, {"cut": 0}),
-    ("lx_spell_unk", 0, {}), ("lx_asg_t40", 0, {}), ("lx_scores_t50", 0, {}), ("lx_spell_t60_k12_logadd", 0, {}),
-    ("ng_word_t40_k10", 0, {})])
+    ("lx_spell_t40_k8", 6, {"xlane": 0}), ("C3_spell_u0", 0, {"xlane": 0, "ylane": 0}), ("C3_uniform_u0", 0, {"cut": 0}),
+    ("lx_spell_unk", 0, {}), ("lx_asg_t40", 0, {}), ("lx_spell_t60_k12_logadd", 0, {}), ("ng_word_unk_t40", 0, {}),
+    ("ng_word_logadd_t40", 0, {}), ("ng_tok_lexicon_t40", 0, {}),
+    ("lx_scores_t50", 6, {}), ("ng_word_t40_k10", 6, {}), ("ng_word_t60_k16_4g", 6, {}), ("C4_spell_u0", 6, {}),
+    ("C4_spell_u255", 6, {}), ("C4z_spell_u0", 6, {}), ("lx_spell_t40_k8", 6, {"ylane": 2}),
+    ("lx_uni_t40_k10", 6, {"ylane": 2}), ("C3_spell_u0", 6, {"ylane": 2}), ("C3_uniform_u0", 6, {"ylane": 2}),
+    ("ng_word_t40_k10", 0, {"ylane": 0}), ("C4_spell_u0", 0, {"ylane": 0}), ("lx_scores_t50", 0, {"slim": 1})])
 def test_engine_selection(gpu_session, golden, name, engine, sets):
     """Which engine serves which configuration: the lane = LM state decode (4,
     fltx_slane.h) for offline lexicon-free + ZeroLM max-merge with beam <= 64 and
@@ -249,7 +253,9 @@ def test_engine_selection(gpu_session, golden, name, engine, sets):
     (3) for logAdd and when the former is switched off; the lean step (2) for
     bigger beams; the lane = (LM state, trie node) decode (5, fltx_xlane.h) for
     the offline lexicon decoder + ZeroLM over a lexicon without scores (CTC,
-    max-merge, no <unk>, beam <= 64); the generic engine (0) for everything else
+    max-merge, no <unk>, beam <= 64); the same with the LM terms (6, fltx_ylane.h)
+    for an n-gram word LM and / or a smeared trie and beams up to 128; the
+    generic engine (0) for everything else
     and whenever one of its own tunables is touched.  Same n-best either way."""
     c = cases.BY_NAME[name]
     inp = helpers.case_inputs(c)
