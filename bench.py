@@ -322,7 +322,7 @@ def phase_profile(a, dec, job, step, B, T):
                      "bar2+build", "bar3", "select paths"]
         if eng == 6:  # fltx_ylane.h
             names = ["loads", "candidates+best", "barA+verdicts+hist", "bar1+scan+select", "plans+counts", "bar2+build",
-                     "bar3", "-"]
+                     "bar3", "(word wave: up to the n-gram look-ups)"]
         names = [names[i] for i in order]
         pr = pr[order]
         tot = pr[:8].sum()

@@ -245,6 +245,7 @@ struct fltx_trie {
    * children are contiguous and in token order, so a child's id is the first child's id plus the
    * number of children with a smaller token; one 32-byte XNode per node, root = 0 */
   DBuf xnode, xdelta;
+  std::vector<int32_t> xEndHost; /* XNode::endLabel0 per node (host copy: decoders map it to LM word ids) */
   bool xOk = false;     /* the layout exists and the trie has the shape that engine assumes: */
   int32_t xEndTok = -1; /* every node that carries labels is entered by this one token (the word separator) */
   float xDeltaMin = 0.0f, xDeltaMax = 0.0f; /* range of the smearing differences of the layout */
@@ -285,6 +286,9 @@ struct fltx_decoder {
   int engineFirst = 0;
   int lastRedo = 0;           /* utterances of the last offline call that had to be decoded again on a general path */
   bool batchPacked = false;   /* some utterance of the current results has packed history records (ST_PACKED) */
+  DBuf xlmword;               /* fltx_ylane.h: LM word id of XNode::endLabel0 per node (this decoder's trie x LM) */
+  const fltx_trie* xlmwordTrie = nullptr;
+  const fltx_lm* xlmwordLm = nullptr;
   int ylane = 0, noYlane = 0, ylaneLm = 0, ylaneRounds = 0, ylaneTpw = 0; /* ylane: lane groups of fltx_ylane.h (0 = not used) */
   int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
   bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
@@ -869,6 +873,10 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
       t->xDeltaMin = std::min(t->xDeltaMin, v);
       t->xDeltaMax = std::max(t->xDeltaMax, v);
     }
+    t->xEndHost.resize(xn.size());
+    for (size_t q = 0; q < xn.size(); ++q) {
+      t->xEndHost[q] = xn[q].endLabel0;
+    }
     xdHost.swap(xd);
   }
   if (!xn.empty()) {
@@ -1294,6 +1302,20 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       d->ylaneLm = (d->lm->kind != 0 || !d->trie->xZeroSmear) ? 1 : 0;
       d->threads = threads;
       d->xlane = 0;
+      if (d->lm->kind == 1 && (d->xlmwordTrie != d->trie || d->xlmwordLm != d->lm)) {
+        const std::vector<int32_t>& el = d->trie->xEndHost;
+        std::vector<int32_t> w(el.size());
+        for (size_t i = 0; i < el.size(); ++i) { /* KenLM::score: usrToLmIdxMap_, unknown words -> <unk> */
+          w[i] = el[i] < 0 ? -1 : ((size_t)el[i] < d->lm->hUsr.size() ? d->lm->hUsr[(size_t)el[i]] : d->lm->unk);
+        }
+        if (d->xlmword.ensure(sizeof(int32_t) * std::max<size_t>(1, w.size()), d->ctx->stream, false) ||
+            devCopyH2D(d->xlmword.p, w.data(), sizeof(int32_t) * w.size(), d->ctx->stream)) {
+          return fail(FLTX_ERR_OOM, "LM word ids of the lexicon: upload failed");
+        }
+        devSync(d->ctx->stream); /* (w is a local) */
+        d->xlmwordTrie = d->trie;
+        d->xlmwordLm = d->lm;
+      }
     }
   }
   if (d->lean && !d->lane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
@@ -1627,6 +1649,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xEndTok = d->trie ? d->trie->xEndTok : -1;
   P.xdelta = (d->trie && d->trie->xdelta.p) ? d->trie->xdelta.as<float>() : nullptr;
   P.yTpw = d->ylaneTpw;
+  P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;

@@ -186,6 +186,7 @@ struct DecodeParams {
   int32_t xEndTok;              /* the token every word ends with in that layout */
   const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
+  const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */
   double yBound;                /* ... and the largest lmWeight x smearing difference of the lexicon (>= 0) */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
@@ -698,20 +699,21 @@ FLTX_DEV bool ngFind(const DecodeParams& P, uint32_t ctx, uint32_t word, uint32_
  * 2 * order dependent ones), and everything is indexed statically so that it
  * stays in registers (a dynamically indexed local array lives in scratch
  * memory). */
-FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t word,
+template <int MO> /* MO: an upper bound of the model's order, to size the unrolled loops */
+FLTX_DEV float ngScoreT(const DecodeParams& P, const int32_t* ctxIn, uint32_t word,
                        int32_t* ctxOut) {
   const int L = P.lmOrder - 1;
-  uint32_t c[kMaxNgramOrder];     /* context node for k context words (k = 0: none) */
-  uint32_t slot[kMaxNgramOrder];
-  NgramSlot e[kMaxNgramOrder];
-  float bo[kMaxNgramOrder];
-  bool act[kMaxNgramOrder];
+  uint32_t c[MO];     /* context node for k context words (k = 0: none) */
+  uint32_t slot[MO];
+  NgramSlot e[MO];
+  float bo[MO];
+  bool act[MO];
 #pragma unroll
-  for (int k = 0; k < kMaxNgramOrder; ++k) {
+  for (int k = 0; k < MO; ++k) {
     c[k] = (k >= 1 && k <= L) ? (uint32_t)ctxIn[k - 1] : 0u;
   }
 #pragma unroll
-  for (int k = 0; k < kMaxNgramOrder; ++k) {
+  for (int k = 0; k < MO; ++k) {
     /* k context words; a suffix of the context that is not an n-gram of the model is skipped */
     act[k] = k <= L && (k == 0 || c[k] != 0u);
     slot[k] = hashKey(c[k], word, 0x5bd1e995u, 0) & P.ngMask;
@@ -727,12 +729,12 @@ FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t wor
       bo[k] = P.ngBackoff[c[k]];
     }
   }
-  uint32_t nodes[kMaxNgramOrder];
-  bool found[kMaxNgramOrder];
+  uint32_t nodes[MO];
+  bool found[MO];
   int longest = -1;
   float prob = 0.0f;
 #pragma unroll
-  for (int k = 0; k < kMaxNgramOrder; ++k) {
+  for (int k = 0; k < MO; ++k) {
     found[k] = false;
     nodes[k] = 0u;
     if (act[k]) {
@@ -767,14 +769,14 @@ FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t wor
     longest = 0;
   }
 #pragma unroll
-  for (int j = 1; j < kMaxNgramOrder; ++j) {
+  for (int j = 1; j < MO; ++j) {
     if (j > longest && j <= L && c[j] != 0u) {
       prob += bo[j];
     }
   }
   if (ctxOut) {
 #pragma unroll
-    for (int j = 0; j < kMaxNgramOrder - 1; ++j) {
+    for (int j = 0; j < MO - 1; ++j) {
       if (j < L) {
         /* suffix of length j+1 of (context, word) = n-gram (last j ctx words, word) */
         ctxOut[j] = (j <= longest && found[j]) ? (int32_t)nodes[j] : 0;
@@ -782,6 +784,10 @@ FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t wor
     }
   }
   return prob;
+}
+
+FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t word, int32_t* ctxOut) {
+  return ngScoreT<kMaxNgramOrder>(P, ctxIn, word, ctxOut);
 }
 
 /* LM::score for the hypothesis in beam slot h (state id sid). */

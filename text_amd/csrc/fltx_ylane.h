@@ -55,7 +55,9 @@ struct YlLanes { /* in place: slot = lane for as long as the lane lives */
   int32_t dWord[kYlLanes];       /* ... and the word (-1: the start state) */
   float maxScore[kYlLanes];      /* TrieNode::maxScore of the node */
   float delta[kYlLanes];         /* maxScore - (parent is the root ? 0 : parent's maxScore), LexiconDecoder.cpp:47,96 */
+  int32_t endWord[kYlLanes];     /* LM word id of endLabel (n-gram LM) */
   uint32_t endLm[kYlLanes];      /* float bits: lm.score(LM state, endLabel), kYlNoLm = not looked up */
+  int32_t endCtx[kMaxNgramOrder - 1][kYlLanes]; /* ... and the n-gram context of the LM state that word leads to */
 };
 
 struct alignas(16) YlRootTab {
@@ -88,10 +90,12 @@ struct YlaneLds {
   unsigned long long alive[2][2];    /* lanes of the frame, per group */
   unsigned long long surv[2];        /* ... that stay for the next frame (alive[next] = these + the new lanes) */
   XNode rootNode;
+  int32_t rootWord, pad1;            /* LM word id of the root's endLabel */
   uint32_t off[32];                  /* new lanes of the waves before wave i (token waves, then the word wave); [last + 1] = all */
   uint32_t offH[4];                  /* surviving hypotheses of the lane groups before group g; [NG] = all */
   uint32_t nFree[2];
   uint8_t freeList[2][64];           /* free slots of a group, in slot order */
+  uint8_t lmReq[kYlLanes];           /* lanes whose word has no n-gram score yet */
   uint16_t cand[kYlTokWaves][kYlPairs]; /* (lane | list position << 8) pairs of a token wave */
   uint16_t pbin[kYlTokWaves][kYlPairs]; /* a wave with more pairs than its rounds take ranks them: bins ... */
   uint32_t whist[kYlTokWaves][kSlNB];   /* ... and their counts */
@@ -148,7 +152,7 @@ FLTX_DEV int ylOrphFind(const YlOrphTab& tab, unsigned long long key) {
  * contexts of the states live in HBM (DecodeParams::stateCtx) and are written by other waves of
  * this workgroup in earlier frames: read past the L1.  wantCtx: the context of the resulting
  * state goes to state `outSid`. */
-FLTX_DEV float ylNgram(const DecodeParams& P, int b, uint32_t sid, uint32_t word, uint32_t outSid, bool wantCtx) {
+FLTX_DEV float ylNgram(const DecodeParams& P, int b, uint32_t sid, uint32_t word, int32_t* out) {
   const int Lc = P.lmOrder - 1;
   const uint32_t* ctx = (const uint32_t*)(P.stateCtx + ((size_t)b * P.stateCap + sid) * Lc);
   int32_t c[kMaxNgramOrder];
@@ -156,18 +160,13 @@ FLTX_DEV float ylNgram(const DecodeParams& P, int b, uint32_t sid, uint32_t word
   for (int q = 0; q < kMaxNgramOrder; ++q) {
     c[q] = q < Lc ? (int32_t)loadCoherent32(ctx + q) : 0;
   }
-  int32_t* out = wantCtx ? P.stateCtx + ((size_t)b * P.stateCap + outSid) * Lc : nullptr;
-  const float r = ngScore(P, c, word, out);
-#ifndef FLTX_EMU
-  if (wantCtx) {
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the new context has left this wave */
+  if (Lc <= 3) { /* (models up to order 4: two thirds of the unrolled look-up) */
+    return ngScoreT<4>(P, c, word, out);
   }
-#endif
-  return r;
+  return ngScore(P, c, word, out);
 }
-FLTX_DEV float ylLmScore(const DecodeParams& P, int b, uint32_t sid, int usr, uint32_t outSid, bool wantCtx) {
-  const uint32_t word = (usr >= 0 && usr < P.nUsr) ? (uint32_t)P.usrToLm[usr] : (uint32_t)P.lmUnk;
-  return ylNgram(P, b, sid, word, outSid, wantCtx);
+FLTX_DEV uint32_t ylLmWord(const DecodeParams& P, int usr) {
+  return (usr >= 0 && usr < P.nUsr) ? (uint32_t)P.usrToLm[usr] : (uint32_t)P.lmUnk;
 }
 
 #ifdef FLTX_EMU
@@ -280,6 +279,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     L.maxScore[0] = r0.maxScore;
     L.delta[0] = 0.0f;
     L.endLm[0] = kYlNoLm;
+    L.endWord[0] = (ngram && r0.endLabel0 >= 0) ? (int32_t)ylLmWord(P, r0.endLabel0) : -1;
+    S.rootWord = L.endWord[0];
     S.alive[0][0] = 1ull;
     S.alive[0][1] = 0ull;
     S.alive[1][0] = 0ull;
@@ -633,6 +634,44 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
     } else if (isWord) {
+      if (ngram) {
+        /* lm.score(LM state, word) of the lanes that can end a word and have not asked yet: once per
+         * lane, all of a frame's look-ups side by side (one trip to the n-gram tables) */
+        int nReq = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int x = g * 64 + lane;
+          const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+          const bool need = lv && L.endLabel[x] >= 0 && L.endLm[x] == kYlNoLm;
+          const unsigned long long bal = waveBallot(need);
+          if (need) {
+            S.lmReq[nReq + wavePrefixCount(bal)] = (uint8_t)x;
+          }
+          nReq += popc64(bal);
+        }
+        if (nReq > 0) {
+          waveSync();
+          for (int i0 = 0; i0 < nReq; i0 += 64) {
+            if (i0 + lane < nReq) {
+              const int x = (int)S.lmReq[i0 + lane];
+              int32_t out[kMaxNgramOrder];
+#pragma unroll
+              for (int k = 0; k < kMaxNgramOrder; ++k) {
+                out[k] = 0;
+              }
+              const float sc = ylNgram(P, b, L.lmSid[x], (uint32_t)L.endWord[x], out);
+              L.endLm[x] = __float_as_uint(sc);
+#pragma unroll
+              for (int k = 0; k < kMaxNgramOrder - 1; ++k) {
+                L.endCtx[k][x] = out[k];
+              }
+              ++nScored;
+            }
+          }
+          waveSync();
+        }
+      }
+      FLTX_YLPROF(7);
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int x = g * 64 + lane;
@@ -659,13 +698,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         if (LMK) {
           float sc = 0.0f;
           if (ngram && can) {
-            uint32_t bits = L.endLm[x];
-            if (bits == kYlNoLm) {
-              bits = __float_as_uint(ylLmScore(P, b, xlm, el, 0u, false));
-              L.endLm[x] = bits;
-              ++nScored;
-            }
-            sc = __uint_as_float(bits);
+            sc = __uint_as_float(L.endLm[x]);
           }
           lmS = sc - (xRoot ? 0.0f : L.maxScore[x]); /* lmScore - lexMaxScore, LexiconDecoder.cpp:47,125 */
           srcLm = useB ? L.lmB[x] : (wb ? L.lmB[x] : L.lmNB[x]);
@@ -937,6 +970,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     int planOrph = -1;          /* ... and the slot of the orphan table that lists the lanes it adopts */
     int planSlot = -1;
     uint32_t rootSid[NG];
+    bool wroteCtx = false; /* a new LM state's context is on its way to HBM */
     int rootOrph[NG];
     bool surv = false;
     uint32_t hNB = kSlNoHyp, hB = kSlNoHyp;
@@ -951,6 +985,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       rootOrph[g] = -1;
     }
     uint32_t planLm = 0u, planPar = 0u;
+    int32_t planWord = -1;
     /* (reads nothing of the lanes: a slot whose lane drops out this frame is taken again in the same build) */
     auto planChild = [&](int j) {
       uint32_t cn = cnode[0];
@@ -964,6 +999,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       }
       planSlot = j;
       planX = xnode[cn];
+      planWord = ngram ? P.xlmword[cn] : -1;
       planOrph = ylOrphFind(S.orph[p], xlKey(planLm, (int32_t)cn));
       return cn;
     };
@@ -1009,9 +1045,16 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
                   if (sid > (uint32_t)(kYlMemo * 3 / 4) || sid + 1u >= P.stateCap || sid >= 0xFFFFu ||
                       (uint32_t)(el + 1) >= (1u << 24)) {
                     atomOr32(&S.scal[YL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
-                  } else if (ngram) {
-                    ylLmScore(P, b, xlm, el, sid, true); /* its n-gram context */
-                    ++nScored;
+                  } else if (ngram) { /* its n-gram context: kept with the lane since the look-up */
+                    const int Lc = P.lmOrder - 1;
+                    int32_t* dst = P.stateCtx + ((size_t)b * P.stateCap + sid) * Lc;
+#pragma unroll
+                    for (int k = 0; k < kMaxNgramOrder - 1; ++k) {
+                      if (k < Lc) {
+                        dst[k] = L.endCtx[k][g * 64 + lane];
+                      }
+                    }
+                    wroteCtx = true;
                   }
                   break;
                 }
@@ -1125,6 +1168,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       L.maxScore[nl] = cx.maxScore;
       L.delta[nl] = dl;
       L.endLm[nl] = kYlNoLm;
+      L.endWord[nl] = planWord;
       atomOr64(&S.alive[q][nl >> 6], 1ull << (nl & 63));
       if (ps) {
         atomOr64(&S.cmask[q][x], 1ull << n);
@@ -1275,6 +1319,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           L.maxScore[nl] = r0.maxScore;
           L.delta[nl] = 0.0f;
           L.endLm[nl] = kYlNoLm;
+          L.endWord[nl] = S.rootWord;
           atomOr64(&S.alive[q][nl >> 6], 1ull << (nl & 63));
           histPT[hrow + hyp] = make_int2((int)hp, endTok);
           histW[hrow + hyp] = el;
@@ -1309,6 +1354,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         first = false;
       }
     }
+#ifndef FLTX_EMU
+    if (wroteCtx) {
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* ... and has arrived before anybody can ask for it */
+    }
+#endif
     FLTX_YLPROF(5);
     ldsBarrier(); /* 3 */
     if (S.scal[YL_FLAG] != 0u) {
@@ -1361,7 +1411,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const bool cand = liveE && (!nice || onRoot);
       double sc = mE;
       if (ngram && cand) {
-        const float fs = ylNgram(P, b, lmSidE, (uint32_t)P.lmEos, 0u, false);
+        const float fs = ylNgram(P, b, lmSidE, (uint32_t)P.lmEos, nullptr);
         ++nScored;
         sc = mE + lmWeight * (double)fs;
         lmE = lmE + (double)fs;

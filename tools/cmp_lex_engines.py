@@ -19,7 +19,7 @@ def main():
     T = int(a[2]) if len(a) > 2 else 1000
     K = int(a[3]) if len(a) > 3 else 50
     Kt = int(a[4]) if len(a) > 4 else 10
-    sets = [x.split("=") for x in a[5:]] or [["xlane", "0"]]
+    sets = [x.split("=") for x in a[5:]] or [["xlane", "0"], ["ylane", "0"]]
     N = 29
     lex = synth.lexicon()
     e = synth.batch(dist, B, T, N, lexicon=lex if dist == "lexspell" else None)
