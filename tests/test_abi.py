@@ -73,5 +73,6 @@ def test_bench_finds_the_committed_hbm_traffic_of_its_default_workload():
     assert tr is not None and tr[0] > 1e8 and tr[1].startswith("profiles/r02/")
     assert bench.pmc_traffic("C2", 256, 256, 1000, 29, 50, engine=4) is None  # other geometry: not quoted
     assert bench.pmc_traffic("C2", 512, 256, 1000, 29, 50, engine=3) is None  # other engine: not quoted
-    for w, K, T in (("C3", 50, 1000), ("C4", 100, 1500)):
-        assert bench.pmc_traffic(w, 512, 256, T, 29, K, engine=0) is not None
+    assert bench.pmc_traffic("C3", 512, 256, 1000, 29, 50, engine=5) is not None  # fltx_xlane.h
+    assert bench.pmc_traffic("C4", 768, 256, 1500, 29, 100, engine=6) is not None  # fltx_ylane.h
+    assert bench.pmc_traffic("C4", 512, 256, 1500, 29, 100, engine=0) is None  # the generic engine was not re-measured
