@@ -96,6 +96,9 @@ struct YlaneLds {
   uint32_t nFree[2];
   uint8_t freeList[2][64];           /* free slots of a group, in slot order */
   uint8_t lmReq[kYlLanes];           /* lanes whose word has no n-gram score yet */
+  uint8_t nrList[kYlLanes];          /* arrivals that become root lanes, and what was found out for them */
+  int16_t nrOrph[kYlLanes];
+  uint32_t nrSid[kYlLanes];
   uint16_t cand[kYlTokWaves][kYlPairs]; /* (lane | list position << 8) pairs of a token wave */
   uint16_t pbin[kYlTokWaves][kYlPairs]; /* a wave with more pairs than its rounds take ranks them: bins ... */
   uint32_t whist[kYlTokWaves][kSlNB];   /* ... and their counts */
@@ -1023,54 +1026,77 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         planNode = planChild(__builtin_ctz(childPend));
       }
       if (isWord) {
+        /* New root lanes: the LM state's number (memo: the same (LM state, word) gives the same state
+         * back), a new state's n-gram context, the lanes the root lane adopts.  The arrivals of both
+         * groups side by side, one per thread. */
+        int nr = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          if ((pend >> (2 * g)) & 1u) {
-            /* the LM state's number (memo: the same (LM state, word) gives the same state back) */
-            const uint32_t xlm = cpl[2 * g];
-            const int32_t el = (int32_t)cpn[2 * g];
-            const unsigned long long mkey = ((unsigned long long)(xlm + 1u) << 24) | (unsigned long long)(uint32_t)(el + 1);
-            uint32_t h = xlHash(mkey) & (kYlMemo - 1);
-            uint32_t sid = 0u;
-            bool have = false; /* a number was taken from the counter for this state */
-            for (int probe = 0;; ++probe) {
-              unsigned long long cur = S.memo[h];
-              if (cur == 0ull) {
-                if (!have) {
-                  sid = atomAdd32(&S.lmNext, 1u);
-                  have = true;
-                }
-                cur = atomCas64(&S.memo[h], 0ull, (mkey << 16) | (unsigned long long)(sid & 0xFFFFu));
-                if (cur == 0ull) { /* a new LM state */
-                  if (sid > (uint32_t)(kYlMemo * 3 / 4) || sid + 1u >= P.stateCap || sid >= 0xFFFFu ||
-                      (uint32_t)(el + 1) >= (1u << 24)) {
-                    atomOr32(&S.scal[YL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
-                  } else if (ngram) { /* its n-gram context: kept with the lane since the look-up */
-                    const int Lc = P.lmOrder - 1;
-                    int32_t* dst = P.stateCtx + ((size_t)b * P.stateCap + sid) * Lc;
-#pragma unroll
-                    for (int k = 0; k < kMaxNgramOrder - 1; ++k) {
-                      if (k < Lc) {
-                        dst[k] = L.endCtx[k][g * 64 + lane];
-                      }
-                    }
-                    wroteCtx = true;
+          const bool want = ((pend >> (2 * g)) & 1u) != 0u;
+          const unsigned long long bal = waveBallot(want);
+          if (want) {
+            S.nrList[nr + wavePrefixCount(bal)] = (uint8_t)(g * 64 + lane);
+          }
+          nr += popc64(bal);
+        }
+        if (nr > 0) {
+          waveSync();
+          for (int i0 = 0; i0 < nr; i0 += 64) {
+            if (i0 + lane < nr) {
+              const int x = (int)S.nrList[i0 + lane];
+              const uint32_t xlm = L.lmSid[x];
+              const int32_t el = L.endLabel[x];
+              const unsigned long long mkey = ((unsigned long long)(xlm + 1u) << 24) | (unsigned long long)(uint32_t)(el + 1);
+              uint32_t h = xlHash(mkey) & (kYlMemo - 1);
+              uint32_t sid = 0u;
+              bool have = false; /* a number was taken from the counter for this state */
+              for (int probe = 0;; ++probe) {
+                unsigned long long cur = S.memo[h];
+                if (cur == 0ull) {
+                  if (!have) {
+                    sid = atomAdd32(&S.lmNext, 1u);
+                    have = true;
                   }
+                  cur = atomCas64(&S.memo[h], 0ull, (mkey << 16) | (unsigned long long)(sid & 0xFFFFu));
+                  if (cur == 0ull) { /* a new LM state */
+                    if (sid > (uint32_t)(kYlMemo * 3 / 4) || sid + 1u >= P.stateCap || sid >= 0xFFFFu ||
+                        (uint32_t)(el + 1) >= (1u << 24)) {
+                      atomOr32(&S.scal[YL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
+                    } else if (ngram) { /* its n-gram context: kept with the lane since the look-up */
+                      const int Lc = P.lmOrder - 1;
+                      int32_t* dst = P.stateCtx + ((size_t)b * P.stateCap + sid) * Lc;
+#pragma unroll
+                      for (int k = 0; k < kMaxNgramOrder - 1; ++k) {
+                        if (k < Lc) {
+                          dst[k] = L.endCtx[k][x];
+                        }
+                      }
+                      wroteCtx = true;
+                    }
+                    break;
+                  }
+                }
+                if ((cur >> 16) == mkey) { /* (a number taken in vain stays unused) */
+                  sid = (uint32_t)(cur & 0xFFFFull);
+                  break;
+                }
+                h = (h + 1u) & (kYlMemo - 1);
+                if (probe > kYlMemo) {
+                  atomOr32(&S.scal[YL_FLAG], 1u);
                   break;
                 }
               }
-              if ((cur >> 16) == mkey) { /* (a number taken in vain stays unused) */
-                sid = (uint32_t)(cur & 0xFFFFull);
-                break;
-              }
-              h = (h + 1u) & (kYlMemo - 1);
-              if (probe > kYlMemo) {
-                atomOr32(&S.scal[YL_FLAG], 1u);
-                break;
-              }
+              S.nrSid[x] = sid;
+              S.nrOrph[x] = (int16_t)ylOrphFind(S.orph[p], xlKey(sid, 0));
             }
-            rootSid[g] = sid;
-            rootOrph[g] = ylOrphFind(S.orph[p], xlKey(rootSid[g], 0));
+          }
+          waveSync();
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            if ((pend >> (2 * g)) & 1u) {
+              rootSid[g] = S.nrSid[g * 64 + lane];
+              rootOrph[g] = (int)S.nrOrph[g * 64 + lane];
+            }
           }
         }
       }
