@@ -196,7 +196,7 @@ FLTX_DEV uint32_t ylLmWord(const DecodeParams& P, int usr) {
 template <int NG, int R, int LMK, bool PROF>
 FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   YlaneLds& S = *(YlaneLds*)smem;
-  constexpr int NS = R > 2 * NG ? R : 2 * NG; /* candidate slots of a thread */
+  constexpr int NS = R > NG ? R : (NG > 2 ? NG : 2); /* candidate slots of a thread */
   static_assert(NG == 1 || NG == 2, "one or two lane groups");
   static_assert(R * 64 <= kYlPairs, "cand[] holds kYlPairs pairs per token wave");
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
@@ -413,6 +413,38 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         rankPart(0, rk1);
       }
       rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
+      /* blank, then the node's own token again (:89 with prevBlank): into the child, if it has children
+       * and no lane -- this wave has the time */
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int x = g * 64 + lane;
+        const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+        const double xb = lv ? L.b[x] : NEG;
+        const uint32_t xi = L.info[x];
+        const int xl = (int)(xi & 0xFFu) & 63;
+        const uint32_t xhB = xi >> 24;
+        const unsigned long long cmk = L.childMask[x];
+        const bool extLast = ((cmk & L.kidsMask[x]) >> xl) & 1ull;
+        const bool allowLast = ((allow >> xl) & 1ull) != 0ull;
+        const bool go = lv && xhB != kSlNoHyp && extLast && allowLast && ((S.cmask[p][x] >> xl) & 1ull) == 0ull;
+        double cL = xb + S.eAll[p][xl];
+        if (xl == sil) {
+          cL = cL + silScore;
+        }
+        const uint32_t child = L.firstChild[x] + (uint32_t)popc64(cmk & ((1ull << xl) - 1ull));
+        cnode[g] = child;
+        cpl[g] = L.lmSid[x];
+        cpn[g] = L.node[x];
+        if (LMK) {
+          const float dl = go ? xdelta[child] : 0.0f;
+          cdl[g] = dl;
+          cL = cL + lmWeight * (double)dl;
+          clm[g] = L.lmB[x] + (double)dl;
+        }
+        cs[g] = cL;
+        cok[g] = go && cL == cL;
+        cinf[g] = (uint32_t)x | ((uint32_t)xl << 8) | (xhB << 16);
+      }
     } else if (isTok) {
       /* the (lane, token) pairs with a child that has children and no lane of its own yet, the
        * node's own token excepted (that one needs the blank in between): LexiconDecoder.cpp:89-110 */
@@ -707,51 +739,28 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           srcLm = useB ? L.lmB[x] : (wb ? L.lmB[x] : L.lmNB[x]);
         }
         c = (c + lmWeight * (double)lmS) + wordScore;
-        cs[2 * g] = c;
-        clm[2 * g] = srcLm + (double)lmS;
-        cok[2 * g] = can && c == c;
-        cinf[2 * g] = (useB ? xhB : (wb ? xhB : xhNB)) << 16;
-        cpl[2 * g] = xlm;
-        cpn[2 * g] = (uint32_t)el;
-        cpl[2 * g + 1] = xlm;
-        cpn[2 * g + 1] = L.node[x];
+        cs[g] = c;
+        clm[g] = srcLm + (double)lmS;
+        cok[g] = can && c == c;
+        cinf[g] = (useB ? xhB : (wb ? xhB : xhNB)) << 16;
+        cpl[g] = xlm;
+        cpn[g] = (uint32_t)el;
         wUseB[g] = useB;
         wHypB[g] = xhB;
         wHypM[g] = wb ? xhB : xhNB;
-        if (cok[2 * g]) {
+        if (cok[g]) {
           wSlot[g] = ylRootFind(S, xlKey(xlm, el));
           if (wSlot[g] >= 0) {
             atomMax64(&S.root.best[wSlot[g]], f64Key(c));
           }
         }
-        /* blank, then the node's own token again (:89 with prevBlank): into the child, if it has
-         * children and no lane */
-        const unsigned long long cmk = L.childMask[x];
-        const bool extLast = ((cmk & L.kidsMask[x]) >> xl) & 1ull;
-        const bool allowLast = ((allow >> xl) & 1ull) != 0ull;
-        const bool go = lv && xhB != kSlNoHyp && extLast && allowLast && ((S.cmask[p][x] >> xl) & 1ull) == 0ull;
-        double cL = xb + eLast;
-        if (xl == sil) {
-          cL = cL + silScore;
-        }
-        const uint32_t child = L.firstChild[x] + (uint32_t)popc64(cmk & ((1ull << xl) - 1ull));
-        cnode[2 * g + 1] = child;
-        if (LMK) {
-          const float dl = go ? xdelta[child] : 0.0f;
-          cdl[2 * g + 1] = dl;
-          cL = cL + lmWeight * (double)dl;
-          clm[2 * g + 1] = L.lmB[x] + (double)dl;
-        }
-        cs[2 * g + 1] = cL;
-        cok[2 * g + 1] = go && cL == cL;
-        cinf[2 * g + 1] = (uint32_t)x | ((uint32_t)xl << 8) | (xhB << 16);
       }
     }
     {
       bool full = isSelf && live && atRoot && rootSlot < 0;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        full = full || (isWord && cok[2 * g] && wSlot[g] < 0);
+        full = full || (isWord && cok[g] && wSlot[g] < 0);
       }
       if (waveBallot(full) != 0ull) {
         dead = true; YL_WHY(2); /* merge table full: general path (uniform after the barrier below via bestKey = ~0) */
@@ -776,6 +785,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     }
     FLTX_YLPROF(1);
     ldsBarrier(); /* A */
+    /* slots this wave uses (uniform per wave): the loops over the slots stop there */
+    const int nUsed = isTok ? (nCand + 63) >> 6 : (isSelf ? 2 : NG);
     /* ---- phase 1b: threshold, merge-table verdicts, histogram ---------------------------- */
     const unsigned long long bk = S.bestKey[p];
     if (bk == 0ull || bk == ~0ull) {
@@ -803,7 +814,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       bool top[NG];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        top[g] = cok[2 * g] && S.root.best[wSlot[g] >= 0 ? wSlot[g] : 0] == f64Key(cs[2 * g]);
+        top[g] = cok[g] && S.root.best[wSlot[g] >= 0 ? wSlot[g] : 0] == f64Key(cs[g]);
         if (top[g]) {
           atomMin32(&S.root.minLane[wSlot[g]], (uint32_t)(g * 64 + lane));
         }
@@ -815,10 +826,10 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         const bool rep = top[g] && S.root.minLane[sl] == (uint32_t)(g * 64 + lane);
         if (rep) {
           S.root.winHyp[sl] = wUseB[g] ? wHypB[g] : wHypM[g];
-          S.root.winWord[sl] = (int32_t)cpn[2 * g];
-          S.root.winLm[sl] = clm[2 * g];
+          S.root.winWord[sl] = (int32_t)cpn[g];
+          S.root.winLm[sl] = clm[g];
         }
-        cok[2 * g] = rep && S.root.lane[sl] == 0u;
+        cok[g] = rep && S.root.lane[sl] == 0u;
       }
     }
     if (isSvc && fastRank) {
@@ -831,6 +842,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     }
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
+      if (j >= nUsed) {
+        continue;
+      }
       if (cok[j] && cs[j] >= thr) {
         cbin[j] = slBin(best, cs[j], winShift, winBase);
         if (cbin[j] < kSlFar) {
@@ -842,6 +856,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     if (getenv("FLTX_YL_WHY") && isTok && wave == 1) {
       int np = 0, nw = 0;
       for (int j = 0; j < NS; ++j) {
+        if (j >= nUsed) {
+          continue;
+        }
         np += popc64(waveBallot(cbin[j] != kSlInvalid));
         nw += popc64(waveBallot(cbin[j] < kSlFar));
       }
@@ -854,6 +871,10 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     ldsBarrier(); /* 1 */
     /* ---- phase 2: which candidates survive (as fltx_slane.h) ------------------------------ */
     unsigned long long selMask[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      selMask[j] = 0ull;
+    }
     SlScan sc;
     int shift = winShift, base = winBase;
     unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
@@ -864,6 +885,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         int nFar = 0;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
+          if (j >= nUsed) {
+            continue;
+          }
           nFar += popc64(waveBallot(cbin[j] == kSlFar));
         }
         if (lane == 0 && nFar > 0) {
@@ -877,6 +901,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         const int lim = full ? kSlFar : kSlFar - 1;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
+          if (j >= nUsed) {
+            continue;
+          }
           selMask[j] = waveBallot(cbin[j] <= lim);
         }
         break;
@@ -885,6 +912,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       if (sc.cnt == need) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
+          if (j >= nUsed) {
+            continue;
+          }
           selMask[j] = waveBallot(cbin[j] <= sc.bstar);
         }
         break;
@@ -893,6 +923,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         uint32_t take = 0u;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
+          if (j >= nUsed) {
+            continue;
+          }
           if (cbin[j] == sc.bstar) {
             const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
             S.bKey[i] = f64Key(cs[j]);
@@ -902,6 +935,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         ldsBarrier();
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
+          if (j >= nUsed) {
+            continue;
+          }
           if (cbin[j] == sc.bstar) {
             const unsigned long long k = f64Key(cs[j]);
             const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
@@ -915,6 +951,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         }
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
+          if (j >= nUsed) {
+            continue;
+          }
           selMask[j] = waveBallot(cbin[j] < sc.bstar || ((take >> j) & 1u) != 0u);
         }
         break;
@@ -948,6 +987,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       full = true;
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
+        if (j >= nUsed) {
+          continue;
+        }
         if (cbin[j] != kSlInvalid) {
           cbin[j] = slBin(best, cs[j], shift, base);
           atomAdd32(&S.hist[p][cbin[j]], 1u);
@@ -980,6 +1022,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     unsigned long long balS = 0ull;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
+      if (j >= nUsed) {
+        continue;
+      }
       myNew[j] = 0;
     }
 #pragma unroll
@@ -1007,21 +1052,24 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       return cn;
     };
     uint32_t planNode = 0u;
-    if (isTok || isWord) {
+    if (isTok || isWord || isSvc) {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
+        if (j >= nUsed) {
+          continue;
+        }
         if (selMask[j] != 0ull) {
           myNew[j] = nNewWave + wavePrefixCount(selMask[j]);
           nNewWave += popc64(selMask[j]);
         }
         pend |= (uint32_t)((selMask[j] >> lane) & 1ull) << j;
       }
-      /* order of the new lanes: token waves, then the word wave */
-      const int slot = isTok ? wave : nTok;
-      if (lane > slot && lane <= nTok + 1 && nNewWave > 0) {
+      /* order of the new lanes: token waves, the word wave, the staging wave */
+      const int slot = isTok ? wave : (isWord ? nTok : nTok + 1);
+      if (lane > slot && lane <= nTok + 2 && nNewWave > 0) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
       }
-      const uint32_t childPend = isTok ? pend : (pend & 0xAAAAAAAAu); /* word wave: odd slots are children */
+      const uint32_t childPend = isWord ? 0u : pend; /* (the word wave's new lanes stand on the root) */
       if (childPend) {
         planNode = planChild(__builtin_ctz(childPend));
       }
@@ -1032,7 +1080,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         int nr = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          const bool want = ((pend >> (2 * g)) & 1u) != 0u;
+          const bool want = ((pend >> g) & 1u) != 0u;
           const unsigned long long bal = waveBallot(want);
           if (want) {
             S.nrList[nr + wavePrefixCount(bal)] = (uint8_t)(g * 64 + lane);
@@ -1093,7 +1141,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           waveSync();
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
-            if ((pend >> (2 * g)) & 1u) {
+            if ((pend >> g) & 1u) {
               rootSid[g] = S.nrSid[g * 64 + lane];
               rootOrph[g] = (int)S.nrOrph[g * 64 + lane];
             }
@@ -1119,7 +1167,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       if (lane > grp && lane <= NG) {
         atomAdd32(&S.offH[lane], (uint32_t)(popc64(balR) + popc64(balB)));
       }
-    } else if (isSvc && t + 1 < T) {
+    }
+    if (isSvc && t + 1 < T) {
       nextRow.v = rv;
       nextRow.allow = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
       if (fastRank) {
@@ -1140,7 +1189,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     /* ---- phase 3: every survivor is written by the thread that evaluated it ---------------- */
     const unsigned long long surv0 = S.surv[0], surv1 = NG > 1 ? S.surv[1] : 0ull;
     const int nHSurv = (int)S.offH[NG];
-    const int nNew = (int)S.off[nTok + 1];
+    const int nNew = (int)S.off[nTok + 2];
     const uint32_t nFree0 = S.nFree[0];
     auto survives = [&](int x) { return (((x < 64 ? surv0 : surv1) >> (x & 63)) & 1ull) != 0ull; };
     auto freeSlot = [&](int idx) {
@@ -1228,6 +1277,33 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       ((uint4*)S.orph[q].lanes[0])[lane + 64] = z4;
       ((uint4*)S.orph[q].lanes[1])[lane] = z4;
       ((uint4*)S.orph[q].lanes[1])[lane + 64] = z4;
+      /* blank-then-own-token lanes */
+      const int offS = (int)S.off[nTok + 1];
+      uint32_t cp = pend;
+      bool first = true;
+      while (waveBallot(cp != 0u) != 0ull) {
+        if (cp) {
+          const int j0 = __builtin_ctz(cp);
+          cp &= cp - 1u;
+          double c = cs[0], lmc = clm[0];
+          int mn = myNew[0];
+          uint32_t ci = cinf[0];
+          float dl = cdl[0];
+#pragma unroll
+          for (int j = 1; j < NS; ++j) {
+            c = j == j0 ? cs[j] : c;
+            lmc = j == j0 ? clm[j] : lmc;
+            mn = j == j0 ? myNew[j] : mn;
+            ci = j == j0 ? cinf[j] : ci;
+            dl = j == j0 ? cdl[j] : dl;
+          }
+          if (!first) {
+            planNode = planChild(j0);
+          }
+          newChild(offS + mn, c, lmc, ci, planNode, dl);
+        }
+        first = false;
+      }
     } else if (isTok) {
       /* most threads create at most one: every round takes each thread's lowest pending slot */
       bool first = true;
@@ -1318,18 +1394,18 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int x = g * 64 + lane;
-        if ((pend >> (2 * g)) & 1u) { /* a word ended and nobody stood on that root: a new root lane */
-          const int idx = offW + myNew[2 * g];
+        if ((pend >> g) & 1u) { /* a word ended and nobody stood on that root: a new root lane */
+          const int idx = offW + myNew[g];
           const int nl = freeSlot(idx);
           const uint32_t hyp = (uint32_t)(nHSurv + idx);
-          const uint32_t hp = cinf[2 * g] >> 16;
+          const uint32_t hp = cinf[g] >> 16;
           const uint32_t sid = rootSid[g];
           const XNode r0 = S.rootNode;
-          const uint32_t xlm = cpl[2 * g];
-          const int32_t el = (int32_t)cpn[2 * g];
-          L.nb[nl] = cs[2 * g];
+          const uint32_t xlm = cpl[g];
+          const int32_t el = (int32_t)cpn[g];
+          L.nb[nl] = cs[g];
           L.b[nl] = NEG;
-          L.lmNB[nl] = clm[2 * g];
+          L.lmNB[nl] = clm[g];
           L.lmB[nl] = 0.0;
           L.childMask[nl] = r0.childMask;
           L.kidsMask[nl] = r0.kidsMask;
@@ -1352,32 +1428,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           adopt(rootOrph[g], nl);
           (void)x;
         }
-      }
-      /* blank-then-own-token lanes */
-      uint32_t cp = pend & 0xAAAAAAAAu;
-      bool first = true;
-      while (waveBallot(cp != 0u) != 0ull) {
-        if (cp) {
-          const int j0 = __builtin_ctz(cp);
-          cp &= cp - 1u;
-          double c = cs[0], lmc = clm[0];
-          int mn = myNew[0];
-          uint32_t ci = cinf[0];
-          float dl = cdl[0];
-#pragma unroll
-          for (int j = 1; j < NS; ++j) {
-            c = j == j0 ? cs[j] : c;
-            lmc = j == j0 ? clm[j] : lmc;
-            mn = j == j0 ? myNew[j] : mn;
-            ci = j == j0 ? cinf[j] : ci;
-            dl = j == j0 ? cdl[j] : dl;
-          }
-          if (!first) {
-            planNode = planChild(j0);
-          }
-          newChild(offW + mn, c, lmc, ci, planNode, dl);
-        }
-        first = false;
       }
     }
 #ifndef FLTX_EMU
