@@ -13,6 +13,9 @@ for w in C2 C3 C4; do
 done
 python bench.py --workload C5 --steps 4 --no-extras > "$O/bench_C5_1gpu.json" 2> "$O/bench_C5_1gpu.err"
 cd /tmp
+# C5's share of one GPU (1 024 utterances): traffic only (--batch keeps the 8 192-utterance pass out of the PMC runs)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_C5" -- python "$R/bench.py" --workload C5 --batch 1024 --steps 2 --warmup 1 --no-cpu > "$O/pmc_fetch_C5.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_C5" -- python "$R/bench.py" --workload C5 --batch 1024 --steps 2 --warmup 1 --no-cpu > "$O/pmc_write_C5.log" 2>&1
 for w in C2 C3 C4; do
   st=5; [ $w = C4 ] && st=3
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$w" -- python "$R/bench.py" --workload $w --steps $st --warmup 2 --no-cpu > "$O/prof_$w.log" 2>&1
