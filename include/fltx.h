@@ -286,16 +286,18 @@ FLTX_API int fltx_decoder_profile(fltx_decoder* dec, uint64_t* out);
 /* Tunables: "threads" (threads per utterance: 64..1024), "force_global_ws",
  * "dense" (0 = use the generic hash merge for lexicon-free frames too), "lean" /
  * "lane" / "slane" (0 = do not use that specialised lexicon-free + ZeroLM frame
- * step), "slane_threads", "xlane" (0 = lexicon + ZeroLM frames use the generic
- * engine), "keep_scores", "profile", "profile_wave"; lexicon decoder: "cut" (0 = build
+ * step), "slane_threads", "xlane" / "ylane" (0 = do not use that lane engine of the
+ * lexicon decoder; "ylane" = 2 prefers fltx_ylane.h where both apply), "keep_scores", "profile", "profile_wave"; lexicon decoder: "cut" (0 = build
  * every candidate's record), "slim" (0 = recompute form of the cut-off
  * generation), "items" (0 = no child-mask item list); test hooks: "cut_m",
  * "lds_budget" (pretend the CU has fewer bytes of LDS), "hot_level". */
 FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
 /* Geometry chosen for the last batch: "engine" (0 generic hash merge, 1 generic
  * dense merge, 2 lean register-resident step, 3 lane-per-slot step, 4 lane = LM
- * state step, 5 lane = (LM state, trie node) step of the lexicon decoder),
+ * state step, 5 lane = (LM state, trie node) step of the lexicon decoder, 6 the
+ * same with the LM terms: n-gram word LM, smeared trie, beams up to 128),
  * "lane" / "slane" / "xlane" (tokens per wave of engine 3 / 4 / 5, else 0),
+ * "ylane" (lane groups of engine 6, else 0),
  * "redone" (utterances of the last offline call that the fast path handed to a
  * general one), "threads", "lds" (1 = workspace in LDS),
  * "hot_level" (HBM workspace: 1 = counters in LDS, 2 = candidate records too),

@@ -75,4 +75,5 @@ def test_bench_finds_the_committed_hbm_traffic_of_its_default_workload():
     assert bench.pmc_traffic("C2", 512, 256, 1000, 29, 50, engine=3) is None  # other engine: not quoted
     assert bench.pmc_traffic("C3", 512, 256, 1000, 29, 50, engine=5) is not None  # fltx_xlane.h
     assert bench.pmc_traffic("C4", 768, 256, 1500, 29, 100, engine=6) is not None  # fltx_ylane.h
+    assert bench.pmc_traffic("C5", 768, 1024, 1500, 29, 100, engine=6) is not None  # C5's share of one GPU
     assert bench.pmc_traffic("C4", 512, 256, 1500, 29, 100, engine=0) is None  # the generic engine was not re-measured
