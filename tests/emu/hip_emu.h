@@ -138,6 +138,12 @@ FLTX_DEV unsigned long long waveBallot(bool p) {
   });
 }
 FLTX_DEV int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+FLTX_DEV void ldsRowLoad(float* ldsRow, const float* src, bool active) {
+  if (active) {
+    ldsRow[threadIdx.x & 63] = *src;
+  }
+}
+FLTX_DEV void ldsRowWait() {}
 FLTX_DEV int waveUniform(int v) { return v; }
 FLTX_DEV int wavePrefixCount(unsigned long long m) {
   const int lane = (int)(threadIdx.x & 63);

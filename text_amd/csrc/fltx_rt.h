@@ -78,6 +78,15 @@ FLTX_DEV void waveSync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+/* One dword per active lane from HBM straight into LDS (global_load_lds_dword: no register in
+ * between, so nothing in the instruction stream waits for it): lane l's word lands at ldsRow[l].
+ * ldsRowWait() before the row is read. */
+FLTX_DEV void ldsRowLoad(float* ldsRow, const float* src, bool active) {
+  if (active) {
+    __builtin_amdgcn_global_load_lds(src, ldsRow, 4, 0, 0);
+  }
+}
+FLTX_DEV void ldsRowWait() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 FLTX_DEV unsigned long long waveBallot(bool p) { return __ballot(p); }
 FLTX_DEV int popc64(unsigned long long m) { return __popcll(m); }
 /* src must be wave-uniform: v_readlane_b32 (VALU) instead of ds_bpermute (LDS crossbar) */

@@ -106,6 +106,7 @@ struct SlaneLds {
   uint32_t evLane[64], evSpar[64], evTok[64];
   unsigned long long scanMask;
   uint32_t scanMin, pad0;
+  float raw[3][64]; /* emission rows on their way in: row r lands in raw[r % 3] two frames before it is staged */
 };
 enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2 };
 
@@ -400,8 +401,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   double bestChain = 0.0; /* prep wave: best candidate of the newest prepared frame (decodeBegin: score 0) */
   if (wave == prepWave) {
     const float v0 = (T > 0 && lane < N) ? em[lane] : 0.0f;
-    rowA = (T > 1 && lane < N) ? em[(size_t)1 * N + lane] : 0.0f;
-    rowB = (T > 2 && lane < N) ? em[(size_t)2 * N + lane] : 0.0f;
+    ldsRowLoad(S.raw[1], em + (size_t)1 * N + lane, T > 1 && lane < N);
+    ldsRowLoad(S.raw[2], em + (size_t)2 * N + lane, T > 2 && lane < N);
     SlRowRegs r0 = slRowScan(P, v0, ctc, 0.0);
     bestChain = r0.best;
     slRowStore(P, S, 0, r0, true);
@@ -427,9 +428,13 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const double best = S.row[p].best, thr = S.row[p].thr;
     const int nList = S.row[p].nList, silPos = S.row[p].silPos;
     const uint32_t rowDead = S.row[p].dead, nev = S.row[p].nev;
-    SlRec me = S.rec[p][lane];
-    unsigned long long cm = S.cmask[p][lane];
-    unsigned long long mk = S.mask[p][lane];
+    SlRec me = {};
+    unsigned long long cm = 0ull, mk = 0ull;
+    if (!isSvc) { /* (the staging wave has the longest way to the first barrier: it skips what it does not use) */
+      me = S.rec[p][lane];
+      cm = S.cmask[p][lane];
+      mk = S.mask[p][lane];
+    }
     double ev[GT];
     unsigned long long tb[GT];
     double eBlank = 0.0;
@@ -481,26 +486,21 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     uint32_t parR = kSlNoHyp;
     SlRowRegs nextRow = {};
     if (isSvc) {
-      /* housekeeping for everybody: the other parity's histogram (used by the next frame), the
-       * masks and counters this frame's build adds to; then the next frame's emission row */
+      /* the next frame's emission row (the masks and counters this frame's build adds to are wiped
+       * by the first token wave, which reaches the barrier earlier) */
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         cs[j] = NEG;
         cbin[j] = kSlInvalid;
       }
-      S.cmask[q][lane] = 0ull;
-      S.mask[q][lane] = 0ull;
-      if (lane < 32) {
-        S.off[lane] = 0u;
-      }
-      if (lane == 0) {
-        S.scal[SL_BCNT] = 0u;
-      }
       if (t + 1 < T) {
-        nextRow = slRowScan(P, rowReg, ctc, bestChain);
+        ldsRowWait(); /* (issued two frames ago) */
+        const float rv = lane < N ? S.raw[(t + 1) % 3][lane] : 0.0f;
+        nextRow = slRowScan(P, rv, ctc, bestChain);
         bestChain = nextRow.best;
       }
-      rowReg = (t + 3 < T && lane < N) ? em[(size_t)(t + 3) * N + lane] : 0.0f;
+      ldsRowLoad(S.raw[t % 3], em + (size_t)(t + 3) * N + lane, t + 3 < T && lane < N); /* (row t's slot: read last frame) */
+      (void)rowReg;
     } else if (!isSelf) {
       /* tokens this lane does not extend with here: its own last token (the repeat and the
        * blank-then-last case belong to the self wave) and those whose child state holds a lane
@@ -573,6 +573,16 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       for (int j = 3; j < GT; ++j) {
         cs[j] = NEG;
         cbin[j] = kSlInvalid;
+      }
+    }
+    if (wave == 0) { /* housekeeping for everybody: what this frame's build adds to */
+      S.cmask[q][lane] = 0ull;
+      S.mask[q][lane] = 0ull;
+      if (lane < 32) {
+        S.off[lane] = 0u;
+      }
+      if (lane == 0) {
+        S.scal[SL_BCNT] = 0u;
       }
     }
     /* one LDS atomic per candidate inside the window (bin 0 = nearer than the window included);
@@ -778,9 +788,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       }
     };
     if (isSvc) {
-      if (lane >= nHSurv + nNew && lane < K) { /* unused slots of the history row: see slReenter */
-        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
-      }
+      /* (this wave issues no stores to HBM: it loads an emission row per frame, and a wait for that
+       * load would wait for every store issued since as well) */
       if (t + 1 < T) {
         slRowStore(P, S, q, nextRow, P.Kt < N);
       }
@@ -796,6 +805,9 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
     } else {
+      if (lane >= nHSurv + nNew && lane < K) { /* unused slots of the history row: see slReenter */
+        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
+      }
       if (surv >= 0) {
         const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
         const int pln = pl >= 0 ? plNew : -1;

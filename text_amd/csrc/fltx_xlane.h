@@ -853,9 +853,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       adopt(planOrph, nl);
     };
     if (isSvc) {
-      if (lane >= nHSurv + nNew && lane < K) {
-        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
-      }
+      /* (no stores to HBM from this wave: a wait for its emission-row load would wait for them too) */
       if (t + 1 < T) {
         slRowStore(P, S, q, nextRow, P.Kt < N);
       }
@@ -898,6 +896,9 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
         first = false;
       }
     } else if (isSelf) {
+      if (lane >= nHSurv + nNew && lane < K) { /* unused slots of the history row */
+        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
+      }
       if (surv >= 0) {
         const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
         Lq.nb[surv] = sR ? cs[1] : NEG;

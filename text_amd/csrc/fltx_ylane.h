@@ -1253,12 +1253,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       adopt(planOrph, nl);
     };
     if (isSvc) {
-      if (lane + 64 * 0 >= nHSurv + nNew && lane < K) {
-        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
-      }
-      if (lane + 64 >= nHSurv + nNew && lane + 64 < K) {
-        histPT[hrow + lane + 64] = make_int2((int)kSlNoHyp, -1);
-      }
       ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
       ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
       /* the merge table of the next frame starts empty (winHyp / winWord / winLm, which the self
@@ -1331,6 +1325,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         first = false;
       }
     } else if (isSelf) {
+      if (li >= nHSurv + nNew && li < K) { /* unused slots of the history row */
+        histPT[hrow + li] = make_int2((int)kSlNoHyp, -1);
+      }
       if (surv) {
         const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
         const uint32_t hb = S.offH[grp];
