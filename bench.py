@@ -315,7 +315,8 @@ def phase_profile(a, dec, job, step, B, T):
             names = ["best+bins", "eval+hist", "bar1+prefix", "scatter", "build", "row+bar3", "load+relations", "bar2+rank"]
             order = [6, 0, 1, 2, 3, 7, 4, 5]
         if eng == 4:  # fltx_slane.h
-            names = ["loads", "candidates+hist", "bar1+scan+select", "new-lane counts", "bar2+build", "bar3", "-", "-"]
+            names = ["loads", "candidates+hist", "bar1+scan+select", "new-lane counts", "bar2+build", "bar3",
+                     "(frames ranking the boundary bin)", "(members of that bin)"]
         if eng == 5:  # fltx_xlane.h (the last column is not clocks: per frame, boundary-bin rankings + 1e3 x
             # narrowed histogram passes + 1e6 x far-candidate counts)
             names = ["loads", "candidates+best", "barA+verdicts+hist", "bar1+scan+select", "new-lane counts",
@@ -327,7 +328,7 @@ def phase_profile(a, dec, job, step, B, T):
         pr = pr[order]
         tot = pr[:8].sum()
         sys.stderr.write("wave %d phase split (shader clocks, %% of %.3g): " % (pw, tot) + ", ".join(
-            ("%s %.3f" if n == "select paths" else "%s %.0f") % (n, v / (B * T)) for n, v in zip(names, pr[:8])) +
+            ("%s %.3f" if n == "select paths" or n.startswith("(") else "%s %.0f") % (n, v / (B * T)) for n, v in zip(names, pr[:8])) +
             " | clocks/frame/utt %.0f\n" % (tot / (B * T)))
         dec.set("profile", 0)
 

@@ -30,7 +30,7 @@
  *     only the members of that one bin are compared with each other (and only
  *     when not all of them survive).
  *   * The histogram is a window of 512 bins over the float bits of
- *     (best - score), 256 bins per octave, centred on where the K-th best was
+ *     (best - score), 128 bins per octave, centred on where the K-th best was
  *     a frame ago.  Candidates beyond the window are not even counted unless
  *     the window turns out to hold fewer than K.
  *   * No short-list, no scatter: after the histogram scan every lane knows
@@ -52,14 +52,15 @@
  */
 #pragma once
 
-constexpr int kSlNB = 512;          /* histogram bins: 8 per lane of the scan */
+constexpr int kSlNB = 256;          /* histogram bins: 4 per lane of the scan */
+constexpr int kSlMid = kSlNB / 2;   /* where the window puts the last frame's K-th best */
 constexpr int kSlFar = kSlNB - 1;   /* beyond the window: counted only on demand */
 constexpr int kSlInvalid = 1023;    /* not a candidate */
 constexpr int kSlList = 96;         /* list positions addressable by the token waves (GT x waves) */
 constexpr int kSlBCap = 128;        /* boundary-bin members compared pairwise */
-constexpr int kSlFineShift = 15;    /* 256 bins per octave of (best - score) */
-constexpr int kSlCoarseShift = 18;  /* 32 bins per octave: 16 octaves in 512 bins */
-constexpr int kSlCoarseBase = 120 << 5; /* float bits of 2^-7, >> kSlCoarseShift */
+constexpr int kSlFineShift = 16;    /* 128 bins per octave of (best - score): the window spans two octaves */
+constexpr int kSlCoarseShift = 19;  /* 16 bins per octave: 16 octaves in 256 bins */
+constexpr int kSlCoarseBase = 120 << 4; /* float bits of 2^-7, >> kSlCoarseShift */
 constexpr uint32_t kSlNoHyp = 0xFFu;
 constexpr uint32_t kSlNewFlag = 0x100u; /* history record: the hypothesis entered a new LM state */
 
@@ -130,35 +131,37 @@ struct SlScan {
   int total;
   bool crossed; /* the counted bins hold at least K */
 };
-/* every wave scans the 512 counts itself (8 bins per lane, DPP prefix) */
-FLTX_DEV SlScan slScan(const uint32_t* hist, int K) {
+/* every wave scans the counts itself (4 bins per lane, DPP prefix) */
+/* noFar: leave the last bin out.  Nobody counts there before the first scan, but a wave that finds
+ * fewer than K inside the window adds its far candidates right after its own scan: a wave that
+ * scans later must not see them, or the two would disagree about which barriers follow. */
+FLTX_DEV SlScan slScan(const uint32_t* hist, int K, bool noFar) {
   const int lane = laneId();
-  const uint4 c0 = ((const uint4*)hist)[2 * lane], c1 = ((const uint4*)hist)[2 * lane + 1];
-  const int mine = (int)(c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w);
+  uint4 c0 = ((const uint4*)hist)[lane];
+  if (noFar && lane == 63) {
+    c0.w = 0u;
+  }
+  const int mine = (int)(c0.x + c0.y + c0.z + c0.w);
   const int inc = waveInclusiveScan(mine);
-  int pre[9];
+  int pre[5];
   pre[0] = inc - mine;
   pre[1] = pre[0] + (int)c0.x;
   pre[2] = pre[1] + (int)c0.y;
   pre[3] = pre[2] + (int)c0.z;
-  pre[4] = pre[3] + (int)c0.w;
-  pre[5] = pre[4] + (int)c1.x;
-  pre[6] = pre[5] + (int)c1.y;
-  pre[7] = pre[6] + (int)c1.z;
-  pre[8] = inc;
+  pre[4] = inc;
   SlScan r;
   r.total = (int)waveReadLane32((uint32_t)inc, 63);
   const unsigned long long cm = waveBallot(pre[0] < K && inc >= K);
-  int q = 7, before = pre[7], cq = pre[8] - pre[7];
+  int q = 3, before = pre[3], cq = pre[4] - pre[3];
 #pragma unroll
-  for (int i = 6; i >= 0; --i) {
+  for (int i = 2; i >= 0; --i) {
     const bool hit = pre[i + 1] >= K;
     q = hit ? i : q;
     before = hit ? pre[i] : before;
     cq = hit ? pre[i + 1] - pre[i] : cq;
   }
   const int X = cm ? __builtin_ctzll(cm) : 0;
-  const uint32_t a = waveReadLane32((uint32_t)(8 * lane + q) | ((uint32_t)cq << 16), X);
+  const uint32_t a = waveReadLane32((uint32_t)(4 * lane + q) | ((uint32_t)cq << 16), X);
   r.cum = (int)waveReadLane32((uint32_t)before, X);
   r.bstar = (int)(a & 0xFFFFu);
   r.cnt = (int)(a >> 16);
@@ -603,7 +606,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
     bool full = false; /* the counts include what lies beyond the window */
     for (;;) {
-      sc = slScan(S.hist[p], K);
+      sc = slScan(S.hist[p], K, !full);
       if (!full && !sc.crossed) {
         /* fewer than K inside the window: count the far ones too (one add per wave) */
         int nFar = 0;
@@ -635,6 +638,10 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         break;
       }
       if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
+        if (PROF) {
+          acc[6] += 1ull;
+          acc[7] += (unsigned long long)sc.cnt;
+        }
         uint32_t take = 0u;
 #pragma unroll
         for (int j = 0; j < GT; ++j) {
@@ -705,12 +712,12 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     if (dead) {
       return;
     }
-    /* next frame's window: the K-th best in the middle, 256 bins per octave */
+    /* next frame's window: the K-th best in the middle, 128 bins per octave */
     if (sc.total > K) {
       const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
                                             : (sc.bstar + base) >> (kSlFineShift - shift);
       winShift = kSlFineShift;
-      winBase = q15 > 256 ? q15 - 256 : 0;
+      winBase = q15 > kSlMid ? q15 - kSlMid : 0;
     }
     FLTX_SLPROF(2);
     /* new lanes: survivors first (self wave), then the new states wave by wave */
@@ -793,8 +800,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       if (t + 1 < T) {
         slRowStore(P, S, q, nextRow, P.Kt < N);
       }
-      ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
-      ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+      ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
     } else if (!isSelf) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {

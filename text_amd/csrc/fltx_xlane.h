@@ -44,7 +44,7 @@
 constexpr int kXlRoot = 128;  /* slots of the per-frame (LM state, word) merge table */
 constexpr int kXlOrph = 128;  /* slots of the per-frame table of lanes without a parent lane */
 constexpr int kXlMemo = 4096; /* slots of the LM-state memo */
-constexpr int kXlWarmBin = 320; /* candidates below this bin of the window (the last K-th sits at 256) get their child node prefetched */
+constexpr int kXlWarmBin = kSlMid + kSlMid / 4; /* candidates below this bin of the window (the last K-th sits at kSlMid) get their child node prefetched */
 
 /* the lanes of one frame, one array per field (conflict-free LDS access, and a wave reads only
  * the fields its role needs) */
@@ -577,7 +577,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
     bool full = false;
     for (;;) {
-      sc = slScan(S.hist[p], K);
+      sc = slScan(S.hist[p], K, !full);
       if (!full && !sc.crossed) {
         int nFar = 0;
 #pragma unroll
@@ -689,7 +689,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
                                             : (sc.bstar + base) >> (kSlFineShift - shift);
       winShift = kSlFineShift;
-      winBase = q15 > 256 ? q15 - 256 : 0;
+      winBase = q15 > kSlMid ? q15 - kSlMid : 0;
     }
     FLTX_XLPROF(3);
     /* new lanes: survivors first (self wave), then new trie lanes wave by wave, then new roots */
@@ -857,8 +857,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       if (t + 1 < T) {
         slRowStore(P, S, q, nextRow, P.Kt < N);
       }
-      ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
-      ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+      ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
       /* the merge table of the next frame starts empty (winHyp / winWord, which the self wave reads
        * now, stay), and so does its orphan table: 16 bytes per lane and store */
       static_assert(kXlRoot == 128 && kXlOrph == 128, "the wipes below cover 128 slots");

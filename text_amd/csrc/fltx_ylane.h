@@ -505,8 +505,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
          * ranks its pairs by itself -- bins of the distance to lb, whole bins kept -- and goes on with
          * those. */
         uint32_t* wh = S.whist[wave];
-        ((uint4*)wh)[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
-        ((uint4*)wh)[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+        ((uint4*)wh)[lane] = make_uint4(0u, 0u, 0u, 0u);
         waveSync();
         for (int c0 = 0; c0 < nCand; c0 += 64) {
           const int id = c0 + lane;
@@ -534,7 +533,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           }
         }
         waveSync();
-        const SlScan ws = slScan(wh, K);
+        const SlScan ws = slScan(wh, K, false);
         const int cut = ws.crossed ? ws.bstar : kSlNB - 1;
         int kept = 0;
         for (int c0 = 0; c0 < nCand; c0 += 64) {
@@ -880,7 +879,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
     bool full = false;
     for (;;) {
-      sc = slScan(S.hist[p], K);
+      sc = slScan(S.hist[p], K, !full);
       if (!full && !sc.crossed) {
         int nFar = 0;
 #pragma unroll
@@ -1004,7 +1003,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
                                             : (sc.bstar + base) >> (kSlFineShift - shift);
       winShift = kSlFineShift;
-      winBase = q15 > 256 ? q15 - 256 : 0;
+      winBase = q15 > kSlMid ? q15 - kSlMid : 0;
     }
     FLTX_YLPROF(3);
     /* ---- what the build needs and is known already ----------------------------------------- */
@@ -1253,8 +1252,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       adopt(planOrph, nl);
     };
     if (isSvc) {
-      ((uint4*)S.hist[q])[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
-      ((uint4*)S.hist[q])[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+      ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
       /* the merge table of the next frame starts empty (winHyp / winWord / winLm, which the self
        * waves read now, stay), and so does its orphan table: 16 bytes per lane and store */
       static_assert(kYlRoot == 256 && kYlOrph == 256, "the wipes below cover 256 slots");
