@@ -489,11 +489,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           }
         }
       }
-#ifdef FLTX_EMU
-      if (getenv("FLTX_YL_WHY") && lane == 0 && wave == 1) {
-        fprintf(stderr, "ylane: frame %d wave %d pairs %d lanes %d\n", t, wave, nCand, popc64(alive0) + popc64(alive1));
-      }
-#endif
       if (nCand > kYlPairs) { /* (the host sizes the waves' shares so that this cannot happen) */
         dead = true; YL_WHY(7);
         nCand = kYlPairs;
@@ -851,21 +846,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
     }
-#ifdef FLTX_EMU
-    if (getenv("FLTX_YL_WHY") && isTok && wave == 1) {
-      int np = 0, nw = 0;
-      for (int j = 0; j < NS; ++j) {
-        if (j >= nUsed) {
-          continue;
-        }
-        np += popc64(waveBallot(cbin[j] != kSlInvalid));
-        nw += popc64(waveBallot(cbin[j] < kSlFar));
-      }
-      if (lane == 0) {
-        fprintf(stderr, "ylane: frame %d passing %d inwindow %d\n", t, np, nw);
-      }
-    }
-#endif
     FLTX_YLPROF(2);
     ldsBarrier(); /* 1 */
     /* ---- phase 2: which candidates survive (as fltx_slane.h) ------------------------------ */
