@@ -232,6 +232,7 @@ def main():
     st = dec.stats()
     by = dec.bytes()
     engine = dec.get("engine")
+    redone = dec.get("redone")  # utterances of the last timed batch the engine handed to a more general one
     value = B * T * a.steps * world / dt
 
     out = {
@@ -246,7 +247,7 @@ def main():
                                 else "ZeroLM", B, T, N, K, Kt, job.dist),
                    "parallelism": "utterance-sharded x%d, no collective" % world,
                    "threads_per_utterance": st["threads_per_utt"], "lds_bytes_per_workgroup": st["lds_bytes"],
-                   "engine": engine},
+                   "engine": engine, "redone": redone},
     }
     # ---- roofline (rank-local): each kernel's own algorithmic bytes over its own duration ----
     k_ms, b_ms = float(np.mean(kern_ms)), float(np.mean(bt_ms))
@@ -299,6 +300,13 @@ def main():
     dec.close()
     if dist is not None:
         dist.destroy_process_group()
+    # a line whose n-best differs from the reference's, or that spent its time in fallbacks,
+    # must not look green
+    mism = out.get("cpu_baseline", {}).get("gpu_nbest_mismatches_on_sample", 0)
+    if mism:
+        raise SystemExit("bench.py: %d of the sampled utterances differ from the CPU reference" % mism)
+    if redone * 4 > B:
+        raise SystemExit("bench.py: %d of %d utterances fell back to a general engine" % (redone, B))
 
 
 def phase_profile(a, dec, job, step, B, T):

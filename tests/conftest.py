@@ -30,10 +30,15 @@ def emu_session():
     """Host-thread emulation of the kernels (logic check without a GPU)."""
     import subprocess
     import helpers
-    src = [os.path.join(ROOT, "text_amd", "csrc", f) for f in
-           ("fltx_api.cpp", "fltx_kernels.h", "fltx_lean.h", "fltx_lane.h", "fltx_slane.h", "fltx_rt.h",
-            "fltx_host_trie.cpp", "fltx_arpa.cpp", "fltx_group.cpp", "fltx_kernel_entry.h")] + \
-          [os.path.join(ROOT, "tests", "emu", f) for f in ("hip_emu.h", "hip_emu.cpp")]
+    import glob
+    # every kernel header and host source the emulator is compiled from (a hand-kept list once
+    # missed the lane engines' headers and the CPU suite kept testing a stale library)
+    src = glob.glob(os.path.join(ROOT, "text_amd", "csrc", "fltx_*.h")) + \
+        glob.glob(os.path.join(ROOT, "text_amd", "csrc", "fltx_*.cpp")) + \
+        [os.path.join(ROOT, "include", "fltx.h")] + \
+        glob.glob(os.path.join(ROOT, "tests", "emu", "*.h")) + \
+        glob.glob(os.path.join(ROOT, "tests", "emu", "*.cpp")) + \
+        [os.path.join(ROOT, "tests", "emu", "build.sh")]
     if (not os.path.exists(helpers.EMU_LIB) or
             os.path.getmtime(helpers.EMU_LIB) < max(os.path.getmtime(s) for s in src)):
         subprocess.run([os.path.join(ROOT, "tests", "emu", "build.sh")], check=True)

@@ -186,3 +186,32 @@ def test_emulated_streaming_lean_step_over_hbm_workspace(emu_session, oracle_lib
     if len({h.score for h in want}) == len(want):
         ok, why = helpers.hyps_equal(want, got)
         assert ok, why
+
+
+def test_trie_that_is_not_a_tree_is_accepted_without_the_breadth_first_layout(emu_session):
+    """fltx_trie_create takes a caller's child table: a shared suffix (DAG), a self loop or a back edge must
+    neither write past the breadth-first arrays nor loop for ever -- such a trie simply has no lane-engine
+    layout and decodes on the generic engine (round-2 advisor finding)."""
+    from text_amd import _capi
+    import numpy as np
+    N = 5
+    for extra in ("dag", "self", "back"):
+        child = -np.ones((4, N), dtype=np.int32)
+        child[0, 1] = 1
+        child[0, 2] = 2
+        child[1, 0] = 3
+        if extra == "dag":
+            child[2, 0] = 3  # node 3 reachable twice
+        elif extra == "self":
+            child[3, 3] = 3
+        else:
+            child[3, 1] = 1
+        label_off = np.array([0, 0, 0, 0, 1], dtype=np.int32)
+        t = _capi.Trie(emu_session.ctx, child, np.zeros(4, np.float32), label_off, np.array([0], np.int32))
+        opt = _capi.make_options(4, N, 25.0)
+        d = _capi.BatchDecoder(emu_session.ctx, _capi.LEXICON, opt, emu_session.zero, 0, N - 1, unk=1, trie=t)
+        e = np.zeros((6, N), dtype=np.float32)
+        d.decode_batch(e, [6], N)
+        assert d.get("engine") == 0  # generic engine: the lane engines need the layout
+        d.close()
+        t.close()

@@ -67,3 +67,40 @@ def test_group_on_the_emulated_kernels_matches_oracle(emu_session, oracle_lib, d
 @pytest.mark.parametrize("devices,kind", [([0, 0], "lexfree"), ([0, 0, 0, 0], "lexfree"), ([0, 0], "lexicon")])
 def test_group_two_contexts_on_one_gpu_matches_oracle(gpu_session, oracle_lib, devices, kind):
     _check_group(gpu_session.lib, oracle_lib, devices, kind)
+
+
+def _recreate_groups_with_ngram(sess, oracle_lib):
+    """Groups come and go over one LM object (DeviceDecoder::decodeBatchOn rebuilds its group when the
+    device list changes): a context's copy of the n-gram tables dies with the context and a later
+    context -- possibly at the same address -- gets its own upload (round-2 advisor finding)."""
+    lib = sess.lib
+    c = dict(cases.BY_NAME["ng_word_t40_k10"])
+    inp = helpers.case_inputs(c)
+    N = c["N"]
+    lm = sess.lm_for(c, inp)
+    host_trie = _capi.HostTrie(N, 0, lib=lib)
+    sf, so = inp["lex"]
+    scores = np.array([lm.score_sequence([w], False)[0][0] for w in range(inp["W"])], dtype=np.float32)
+    host_trie.insert_many(sf, so, inp["labels"], scores)
+    host_trie.smear(1)
+    opt = _capi.make_options(c["K"], c["Kt"], c["thr"], c["lm_weight"], c["word_score"], c["unk_score"],
+                             c["sil_score"], c["log_add"], c["crit"])
+    want = helpers.run_checker(oracle_lib, c, inp)
+    flat = np.concatenate([inp["e"].reshape(-1)] * 3).astype(np.float32)
+    for devices in ([0], [0, 0], [0], [0, 0, 0], [0, 0]):
+        g = _capi.DecoderGroup(devices, _capi.LEXICON, opt, lm, 0, N - 1, unk=inp["W"], host_trie=host_trie,
+                               lib=lib)
+        g.decode_batch(flat, [c["T"]] * 3, N)
+        for b in range(3):
+            ok, why = helpers.hyps_equal(want, g.results(b))
+            assert ok, "devices %r, utterance %d: %s" % (devices, b, why)
+        g.close()
+
+
+def test_groups_recreated_over_one_ngram_lm_emulated(emu_session, oracle_lib):
+    _recreate_groups_with_ngram(emu_session, oracle_lib)
+
+
+@pytest.mark.gpu
+def test_groups_recreated_over_one_ngram_lm(gpu_session, oracle_lib):
+    _recreate_groups_with_ngram(gpu_session, oracle_lib)

@@ -216,3 +216,48 @@ def test_streaming_through_the_facade_at_a_big_beam(gpu_session):
         for k in range(0, T, 30):
             chunk = np.ascontiguousarray(e[k:k + 30])
             dec.decode_step(chunk.ctypes.data, 30, N)
+
+
+def test_replabels_and_contiguity_known_answers():
+    """DictionaryTest.cpp:24-147 known answers (PackReplabels, UnpackReplabels, UnpackReplabelsIgnoresInvalid,
+    the contiguity check of Dictionary.cpp:125-137) through the Python names of _dictionary.cpp:45,58-59."""
+    from flashlight.lib.text.dictionary import Dictionary, pack_replabels, unpack_replabels
+    d = Dictionary()
+    for i in (1, 2, 3):
+        d.add_entry("<%d>" % i, i)
+    labels = [5, 6, 6, 6, 10, 8, 8, 10, 10, 10, 10, 10]
+    packed = [labels,
+              [5, 6, 1, 6, 10, 8, 1, 10, 1, 10, 1, 10],
+              [5, 6, 2, 10, 8, 1, 10, 2, 10, 1],
+              [5, 6, 2, 10, 8, 1, 10, 3, 10]]
+    for reps in range(4):
+        assert pack_replabels(labels, d, reps) == packed[reps]
+        assert unpack_replabels(packed[reps], d, reps) == labels
+    d = Dictionary()
+    for i, e in enumerate(["<1>", "<2>", "<3>", "1", "2", "3"]):
+        d.add_entry(e, i + 1)
+    labels = [6, 3, 7, 2, 8, 0, 1]
+    assert unpack_replabels(labels, d, 1) == [6, 3, 7, 2, 8, 0, 0]
+    assert unpack_replabels(labels, d, 2) == [6, 3, 7, 7, 7, 8, 0, 0]
+    assert unpack_replabels(labels, d, 3) == [6, 6, 6, 6, 7, 7, 7, 8, 0, 0]
+    d = Dictionary()
+    for i, e in enumerate(["<1>", "<2>", "1", "2"]):
+        d.add_entry(e, i + 1)
+    assert unpack_replabels([1, 5, 1, 6], d, 2) == [5, 5, 6]         # leading replabel: nothing to repeat
+    assert unpack_replabels([1, 5, 1, 2, 6], d, 2) == [5, 5, 6]      # replabel after a replabel
+    assert unpack_replabels([1, 5, 1, 2, 6], d, 1) == [5, 5, 2, 6]   # "<2>" is an ordinary token at maxReps 1
+    assert unpack_replabels([5, 1, 2, 1, 2, 6], d, 2) == [5, 5, 6]
+    assert unpack_replabels([], d, 2) == [] and unpack_replabels([4, 1], d, 0) == [4, 1]
+    # contiguity (DictionaryTest.cpp:24-48: entries added one after the other are contiguous; a hole is not)
+    d = Dictionary()
+    d.add_entry("a")
+    d.add_entry("b")
+    assert d.is_contiguous()
+    d.add_entry("c", 5)
+    assert not d.is_contiguous()
+    d2 = Dictionary()
+    d2.add_entry("x", 0)
+    d2.add_entry("y", 0)   # two entries, one index: still contiguous
+    d2.add_entry("z", 1)
+    assert d2.is_contiguous() and d2.entry_size() == 3 and d2.index_size() == 2
+    assert d2.map_entries_to_indices(["z", "x"]) == [1, 0] and d2.map_indices_to_entries([1, 0]) == ["z", "x"]

@@ -1,7 +1,8 @@
 /*
- * dictionary/Dictionary.h -- the subset of fl::lib::text::Dictionary
- * (flashlight/lib/text/dictionary/Dictionary.{h,cpp}) that the KenLM adapter
- * needs: a string <-> index bimap with a default index.
+ * dictionary/Dictionary.h -- fl::lib::text::Dictionary
+ * (flashlight/lib/text/dictionary/Dictionary.{h,cpp}) as the decoder path and its
+ * Python surface use it: a string <-> index bimap with a default index (the file /
+ * stream constructors are loadDictionary in dictionary/Utils.h).
  */
 #pragma once
 #include <stdexcept>
@@ -58,6 +59,37 @@ class Dictionary {
     return it->second;
   }
   bool contains(const std::string& entry) const { return entry2idx_.find(entry) != entry2idx_.end(); }
+  /* no hole in 0 .. indexSize() - 1 and every entry's index is known (Dictionary.cpp:125-137) */
+  bool isContiguous() const {
+    const size_t n = indexSize();
+    for (size_t i = 0; i < n; ++i) {
+      if (idx2entry_.count((int)i) == 0) {
+        return false;
+      }
+    }
+    for (const auto& kv : entry2idx_) {
+      if (idx2entry_.count(kv.second) == 0) {
+        return false;
+      }
+    }
+    return true;
+  }
+  std::vector<int> mapEntriesToIndices(const std::vector<std::string>& entries) const {
+    std::vector<int> out;
+    out.reserve(entries.size());
+    for (const auto& e : entries) {
+      out.push_back(getIndex(e));
+    }
+    return out;
+  }
+  std::vector<std::string> mapIndicesToEntries(const std::vector<int>& indices) const {
+    std::vector<std::string> out;
+    out.reserve(indices.size());
+    for (int i : indices) {
+      out.push_back(getEntry(i));
+    }
+    return out;
+  }
 
  private:
   std::unordered_map<std::string, int> entry2idx_;

@@ -2,7 +2,7 @@
  * dictionary/Utils.h -- lexicon loading for the decoder path: the step right
  * before the hot path.  Same functions and results as
  * flashlight/lib/text/dictionary/Utils.cpp:19-62 (createWordDict, loadWords),
- * :64-88 (splitWrd), :90-124 (packReplabels), :152-162 (tkn2Idx) and the file
+ * :64-88 (splitWrd), :90-124 (packReplabels), :126-150 (unpackReplabels), :152-162 (tkn2Idx) and the file
  * constructor of Dictionary (Dictionary.cpp:24-60); written for this tree.
  *
  * One thing is dictated by the reference: word ids are assigned in the iteration
@@ -17,6 +17,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "flashlight/lib/text/dictionary/Dictionary.h"
@@ -94,6 +95,9 @@ inline Dictionary loadDictionary(const std::string& filename) {
     }
     return true;
   });
+  if (!dict.isContiguous()) { /* (Dictionary.cpp:57-59) */
+    throw std::runtime_error("Invalid dictionary format - not contiguous");
+  }
   return dict;
 }
 
@@ -181,6 +185,47 @@ inline std::vector<int> packReplabels(const std::vector<int>& tokens, const Dict
       left -= piece;
     }
     i += run;
+  }
+  return out;
+}
+
+/* the inverse: "<r>" after a token stands for r more copies of it; a replabel with nothing to repeat
+ * (at the start, or right after another replabel) is dropped; indices beyond maxReps are ordinary tokens
+ * (Utils.cpp:126-150; DictionaryTest.cpp:103-147 are the known answers) */
+inline std::vector<int> unpackReplabels(const std::vector<int>& tokens, const Dictionary& dict, int maxReps) {
+  if (tokens.empty() || maxReps <= 0) {
+    return tokens;
+  }
+  std::vector<std::pair<int, int>> reps; /* (index of "<r>", r); the smallest r wins when two share an index */
+  for (int r = 1; r <= maxReps; ++r) {
+    const int idx = dict.getIndex("<" + std::to_string(r) + ">");
+    bool known = false;
+    for (const auto& p : reps) {
+      known = known || p.first == idx;
+    }
+    if (!known) {
+      reps.emplace_back(idx, r);
+    }
+  }
+  std::vector<int> out;
+  bool canRepeat = false; /* the last thing seen was an ordinary token */
+  for (int tok : tokens) {
+    int r = 0;
+    for (const auto& p : reps) {
+      if (p.first == tok) {
+        r = p.second;
+      }
+    }
+    if (r == 0) {
+      out.push_back(tok);
+      canRepeat = true;
+    } else {
+      /* (a token index of -1 cannot be repeated in the reference either: it is its "nothing pending" mark) */
+      if (canRepeat && out.back() != -1) {
+        out.insert(out.end(), (size_t)r, out.back());
+      }
+      canRepeat = false;
+    }
   }
   return out;
 }

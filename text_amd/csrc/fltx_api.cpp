@@ -19,7 +19,9 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "fltx.h"
@@ -201,6 +203,7 @@ uint32_t nextPow2(uint64_t v) {
 /* objects                                                                   */
 /* ------------------------------------------------------------------------ */
 struct fltx_ctx {
+  uint64_t uid = 0; /* never reused: per-context tables are keyed by it, not by the object's address */
   int device = 0;
   int numCUs = 256; /* MI355X; read from the device at creation */
   Stream stream = nullptr;
@@ -209,14 +212,37 @@ struct fltx_ctx {
 
 /* every entry point that allocates, copies or launches selects its context's device first:
  * decoders of several devices are driven from several host threads (fltx_group_*) */
-static int useDevice(const fltx_ctx* ctx) {
+/* ... and puts the calling thread's device back when the entry point returns: the host framework's
+ * later allocations and launches in that thread must not move to another GPU because of a call here */
+struct DeviceScope {
+  int prev = -1;
+  bool failed = false;
+  explicit DeviceScope(const fltx_ctx* ctx) {
 #ifndef FLTX_EMU
-  return (ctx && hipSetDevice(ctx->device) != hipSuccess) ? 1 : 0;
+    if (ctx) {
+      if (hipGetDevice(&prev) != hipSuccess) {
+        prev = -1;
+      }
+      if (prev == ctx->device) {
+        prev = -1; /* nothing to restore */
+      } else {
+        failed = hipSetDevice(ctx->device) != hipSuccess;
+      }
+    }
 #else
-  (void)ctx;
-  return 0;
+    (void)ctx;
 #endif
-}
+  }
+  ~DeviceScope() {
+#ifndef FLTX_EMU
+    if (prev >= 0) {
+      (void)hipSetDevice(prev);
+    }
+#endif
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
 
 struct fltx_lm {
   fltx_ctx* ctx = nullptr;
@@ -229,12 +255,17 @@ struct fltx_lm {
     DBuf tab, backoff, usrToLm;
   };
   std::mutex devMu;
-  std::unordered_map<fltx_ctx*, std::unique_ptr<Dev>> dev;
+  std::unordered_map<uint64_t, std::unique_ptr<Dev>> dev; /* key = fltx_ctx::uid */
   /* host copies for fltx_lm_score_sequence */
   std::vector<NgramSlot> hTab;
   std::vector<float> hBackoff;
   std::vector<int32_t> hUsr;
 };
+
+/* live LM objects: fltx_ctx_destroy drops the tables they hold for that context */
+static std::mutex g_lmRegMu;
+static std::unordered_set<fltx_lm*> g_lmReg;
+static std::atomic<uint64_t> g_ctxUid{1};
 
 struct fltx_trie {
   fltx_ctx* ctx = nullptr;
@@ -308,6 +339,7 @@ struct fltx_decoder {
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
   DBuf scored; /* n-gram LM queries per utterance (accounting) */
+  bool keepScored = false;
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   HBuf hTokens, hWords, hScores; /* fltx_result_fetch_batch */
@@ -353,6 +385,7 @@ int fltx_ctx_create(int device, void* stream, fltx_ctx** out) {
     return fail(FLTX_ERR_INVALID, "fltx_ctx_create: out is null");
   }
   auto* c = new fltx_ctx();
+  c->uid = g_ctxUid.fetch_add(1);
 #ifndef FLTX_EMU
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
@@ -369,11 +402,12 @@ int fltx_ctx_create(int device, void* stream, fltx_ctx** out) {
     delete c;
     return fail(FLTX_ERR_INVALID, "fltx_ctx_create: device %d out of range (%d devices)", device, n);
   }
-  if (hipSetDevice(device) != hipSuccess) {
+  c->device = device;
+  DeviceScope devScope(c);
+  if (devScope.failed) {
     delete c;
     return fail(FLTX_ERR_HIP, "hipSetDevice(%d) failed", device);
   }
-  c->device = device;
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) {
@@ -401,6 +435,14 @@ int fltx_ctx_destroy(fltx_ctx* ctx) {
   if (!ctx) {
     return FLTX_OK;
   }
+  DeviceScope devScope(ctx);
+  { /* the n-gram tables uploaded for this context die with it (a later context may get this address) */
+    std::lock_guard<std::mutex> reg(g_lmRegMu);
+    for (fltx_lm* lm : g_lmReg) {
+      std::lock_guard<std::mutex> lock(lm->devMu);
+      lm->dev.erase(ctx->uid);
+    }
+  }
 #ifndef FLTX_EMU
   if (ctx->ownStream) {
     (void)hipStreamDestroy(ctx->stream);
@@ -427,6 +469,10 @@ int fltx_lm_zero_create(fltx_ctx* ctx, fltx_lm** out) {
   auto* lm = new fltx_lm();
   lm->ctx = ctx;
   lm->kind = 0;
+  {
+    std::lock_guard<std::mutex> reg(g_lmRegMu);
+    g_lmReg.insert(lm);
+  }
   *out = lm;
   return FLTX_OK;
 }
@@ -522,11 +568,19 @@ int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t nNgrams, const in
   }
   lm->hUsr.assign(usrToLm, usrToLm + (usrToLm ? nUsr : 0));
   /* the tables go to HBM when a decoder is created on a context */
+  {
+    std::lock_guard<std::mutex> reg(g_lmRegMu);
+    g_lmReg.insert(lm);
+  }
   *out = lm;
   return FLTX_OK;
 }
 
 int fltx_lm_destroy(fltx_lm* lm) {
+  if (lm) {
+    std::lock_guard<std::mutex> reg(g_lmRegMu);
+    g_lmReg.erase(lm);
+  }
   delete lm;
   return FLTX_OK;
 }
@@ -756,7 +810,8 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
   if (nNodes >= (1ll << 31)) {
     return fail(FLTX_ERR_UNSUPPORTED, "trie too large");
   }
-  if (useDevice(ctx)) {
+  DeviceScope devScope(ctx);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (nNodes >= (1ll << 28) || (int64_t)labelOff[nNodes] >= (1ll << 28)) {
@@ -822,7 +877,9 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
     bool ok = true;
     int endTok = -1;
     bool zero = true;
-    for (size_t q = 0; q < order.size(); ++q) {
+    std::vector<uint8_t> seen((size_t)nNodes, 0);
+    seen[0] = 1;
+    for (size_t q = 0; q < order.size() && ok; ++q) {
       const int64_t o = order[q];
       XNode x;
       memset(&x, 0, sizeof(x));
@@ -837,9 +894,12 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
         if (c < 0) {
           continue;
         }
-        if (order.size() <= (size_t)nNodes) {
-          parentOf[order.size()] = (uint32_t)q;
+        if (seen[(size_t)c] || order.size() >= (size_t)nNodes) { /* not a tree (shared suffix, back edge): */
+          ok = false;                                            /* no breadth-first layout, generic engine only */
+          break;
         }
+        seen[(size_t)c] = 1;
+        parentOf[order.size()] = (uint32_t)q;
         order.push_back(c);
         tokOf[(size_t)c] = tk;
         if (nKids[(size_t)c] > 0) {
@@ -857,7 +917,7 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
       xn[q] = x;
     }
     std::vector<float> xd(xn.size(), 0.0f);
-    for (size_t q = 1; q < order.size() && q < xd.size(); ++q) { /* lex->maxScore - lexMaxScore, LexiconDecoder.cpp:47,96 */
+    for (size_t q = 1; ok && q < order.size() && q < xd.size(); ++q) { /* lex->maxScore - lexMaxScore, LexiconDecoder.cpp:47,96 */
       const uint32_t pq = xn[q].parent;
       xd[q] = xn[q].maxScore - (pq == 0u ? 0.0f : xn[pq].maxScore);
     }
@@ -924,7 +984,7 @@ static int lmEnsureUploaded(fltx_lm* lm, fltx_ctx* ctx, fltx_lm::Dev** out) {
     return FLTX_OK;
   }
   std::lock_guard<std::mutex> lock(lm->devMu);
-  auto it = lm->dev.find(ctx);
+  auto it = lm->dev.find(ctx->uid);
   if (it != lm->dev.end()) {
     *out = it->second.get();
     return FLTX_OK;
@@ -943,7 +1003,7 @@ static int lmEnsureUploaded(fltx_lm* lm, fltx_ctx* ctx, fltx_lm::Dev** out) {
     return fail(FLTX_ERR_HIP, "n-gram tables: upload failed");
   }
   *out = dv.get();
-  lm->dev[ctx] = std::move(dv);
+  lm->dev[ctx->uid] = std::move(dv);
   return FLTX_OK;
 }
 
@@ -973,7 +1033,8 @@ int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, co
   if (trie && trie->ctx != ctx) {
     return fail(FLTX_ERR_INVALID, "fltx_decoder_create: the trie was uploaded to another context (device)");
   }
-  if (useDevice(ctx)) {
+  DeviceScope devScope(ctx);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   fltx_lm::Dev* lmDev = nullptr;
@@ -1008,7 +1069,8 @@ int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, co
 }
 
 int fltx_decoder_destroy(fltx_decoder* d) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (d) {
@@ -1555,7 +1617,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   if (d->lm->kind == 1) {
     rc |= d->scored.ensure(4 * (size_t)B, st, false);
-    if (!rc) {
+    if (!rc && !d->keepScored) { /* (a partial re-run keeps the counts of the utterances it does not touch) */
       devMemset(d->scored.p, 0, 4 * (size_t)B, st);
     }
   }
@@ -1993,14 +2055,23 @@ int launchBacktrace(fltx_decoder* d) {
   Q.nbest = 0;
   /* frames per LDS chunk: two record buffers in ({parent, token} 8 B, word 4 B) + token and word tiles out */
 #ifdef FLTX_EMU
-  const int btThreads = 64;
+  const int btThreads = d->opt.beam_size > 64 ? 128 : 64; /* (the emitting-model pass is one thread per hypothesis) */
 #else
   const int btThreads = 512;
 #endif
   const size_t perFrame = (size_t)Q.K * (2 * (8 + (d->kind == FLTX_DECODER_LEXICON ? 4 : 0)) + 8);
   int F = (int)std::min<size_t>((size_t)144 * 1024 / perFrame, 512);
+  if (d->batchPacked) { /* the emission rows, transitions and addends of a chunk share the same LDS (amLds below) */
+    const size_t fixed = 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;
+    const size_t perAm = 4 * ((size_t)d->N + (size_t)Q.K);
+    const size_t room = (size_t)144 * 1024 > fixed ? (size_t)144 * 1024 - fixed : 0;
+    F = (int)std::min<size_t>((size_t)F, room / perAm);
+  }
   if (F < 8 || Q.K > 4 * btThreads) {
     F = 0;
+  }
+  if (d->batchPacked && F == 0) {
+    return fail(FLTX_ERR_UNSUPPORTED, "back-trace: packed history records need an LDS chunk (K=%d N=%d)", Q.K, d->N);
   }
   Q.F = F;
   size_t btLds = F > 0 ? (size_t)F * perFrame + 16 : 16;
@@ -2077,7 +2148,8 @@ extern "C" {
 
 int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice, const int64_t* offsets,
                       const int32_t* T, int32_t B, int32_t N) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d || !T || B <= 0 || N <= 0) {
@@ -2105,9 +2177,16 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   d->keepScores = d->userKeepScores; /* a stream on this decoder had switched the score history on */
   for (int attempt = 0; attempt < 3; ++attempt) {
     const bool finalForm = attempt > 0 && !recomputeRetry; /* the general path: nothing left to fall back to */
+    d->keepScored = attempt > 0;
     int rc = prepare(d, B, N, T, finalForm);
+    d->keepScored = false;
     if (rc) {
       return rc;
+    }
+    if (attempt > 0 && d->lm->kind == 1 && d->scored.p) {
+      for (int32_t b : redoList) { /* only the utterances decoded again start their query count over */
+        devMemset(d->scored.as<uint32_t>() + b, 0, 4, d->ctx->stream);
+      }
     }
     d->batchPacked = d->batchPacked || d->slane || d->xlane || d->ylane;
     if (attempt == 0) {
@@ -2213,7 +2292,8 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
 }
 
 int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d || B <= 0 || N <= 0 || maxFrames < 0) {
@@ -2256,7 +2336,8 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
 
 int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, const int64_t* offsets,
                      const int32_t* T) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d || !T) {
@@ -2292,7 +2373,8 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
 }
 
 int fltx_stream_end(fltx_decoder* d) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d) {
@@ -2350,7 +2432,8 @@ static int launchStreamOp(fltx_decoder* d, int op, int lookBack, int cap) {
 }
 
 int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d || lookBack < 0) {
@@ -2404,7 +2487,8 @@ static int checkStatus(fltx_decoder* d, int b) {
 }
 
 int fltx_result_count(fltx_decoder* d, int32_t b, int32_t* nHyp, int32_t* length) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d || b < 0 || b >= d->B) {
@@ -2494,7 +2578,8 @@ int fltx_result_fetch(fltx_decoder* d, int32_t b, int32_t maxHyp, double* scores
 
 int fltx_result_fetch_batch(fltx_decoder* d, const int32_t** nHyp, const int32_t** length, const double** scores,
                             const int32_t** tokens, const int32_t** words, const int64_t** offsets) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d) {
@@ -2560,7 +2645,8 @@ int fltx_result_fetch_batch(fltx_decoder* d, const int32_t** nHyp, const int32_t
 
 int fltx_result_best(fltx_decoder* d, int32_t b, int32_t lookBack, double* scores, int32_t* tokens,
                      int32_t* words, int32_t capacity, int32_t* length) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d || b < 0 || b >= d->B || lookBack < 0 || !length) {
@@ -2625,7 +2711,8 @@ int fltx_result_best(fltx_decoder* d, int32_t b, int32_t lookBack, double* score
 
 int fltx_result_device(fltx_decoder* d, const int32_t** nHyp, const double** scores,
                        const int32_t** tokens, const int32_t** words, const int64_t** tokOff) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d || !d->haveResults) {
@@ -2659,7 +2746,8 @@ int fltx_result_device(fltx_decoder* d, const int32_t** nHyp, const double** sco
  * utterances of the batch (0 prep, 1 generate, 2 fold, 3 select, 4 build,
  * 5 row hand-over) */
 int fltx_decoder_profile(fltx_decoder* d, uint64_t* out) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d || !out) {
@@ -2682,7 +2770,8 @@ int fltx_decoder_profile(fltx_decoder* d, uint64_t* out) {
 }
 
 int fltx_decoder_timing(fltx_decoder* d, float* decodeMs, float* backtraceMs) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d) {
@@ -2716,7 +2805,8 @@ int fltx_decoder_timing(fltx_decoder* d, float* decodeMs, float* backtraceMs) {
 
 int fltx_decoder_stats(fltx_decoder* d, int64_t* frames, int64_t* bytes, int32_t* threads,
                        int32_t* ldsBytes) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d) {
@@ -2744,7 +2834,8 @@ int fltx_decoder_stats(fltx_decoder* d, int64_t* frames, int64_t* bytes, int32_t
 }
 
 int fltx_decoder_bytes(fltx_decoder* d, int64_t* decodeBytes, int64_t* epilogueBytes, int64_t* lmBytes) {
-  if (d && useDevice(d->ctx)) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
     return fail(FLTX_ERR_HIP, "hipSetDevice failed");
   }
   if (!d) {

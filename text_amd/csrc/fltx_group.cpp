@@ -3,14 +3,18 @@
  *
  * Utterances are independent, so a batch of B shards over D devices with no
  * exchange at all: one context + one decoder per device, one host thread per
- * device for the duration of a call, trie and LM tables replicated (tens of MB),
+ * device for the life of the group, trie and LM tables replicated (tens of MB),
  * results read back in the caller's utterance order.  Written against the public
  * C ABI only (include/fltx.h); wraps the per-utterance loop a multi-GPU user of
  * Decoder::decode (decoder/Decoder.h:51-57) would write by hand.
  */
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,6 +24,49 @@
 extern "C" int fltx_set_error_(int code, const char* msg);
 
 struct fltx_group {
+  /* one host thread per device, alive for as long as the group (a thread per call would cost
+   * tens of microseconds of create + join against a 2.7 ms batch) */
+  struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, quit = false;
+    Worker() {
+      th = std::thread([this]() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+          cv.wait(lk, [this]() { return busy || quit; });
+          if (quit) {
+            return;
+          }
+          lk.unlock();
+          job();
+          lk.lock();
+          busy = false;
+          cv.notify_all();
+        }
+      });
+    }
+    void post(std::function<void()> f) {
+      std::lock_guard<std::mutex> lk(mu);
+      job = std::move(f);
+      busy = true;
+      cv.notify_all();
+    }
+    void wait() {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [this]() { return !busy; });
+    }
+    ~Worker() {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        quit = true;
+        cv.notify_all();
+      }
+      th.join();
+    }
+  };
   struct Part {
     fltx_ctx* ctx = nullptr;
     fltx_trie* trie = nullptr;
@@ -27,6 +74,7 @@ struct fltx_group {
     int first = 0, count = 0; /* utterances [first, first + count) of the last batch */
     int rc = 0;
     std::string err;
+    std::unique_ptr<Worker> worker; /* started by the first batch that gives this part work */
   };
   std::vector<Part> parts;
   int B = 0;
@@ -35,24 +83,29 @@ struct fltx_group {
 namespace {
 int gfail(int code, const std::string& msg) { return fltx_set_error_(code, msg.c_str()); }
 
-/* run f(part) on every part that has work, each on its own host thread */
+/* run f(part) on every part that has work, each on its part's host thread */
 template <class F>
 int forEachPart(fltx_group* g, F&& f) {
-  std::vector<std::thread> th;
   for (auto& p : g->parts) {
     p.rc = 0;
     if (p.count == 0) {
       continue;
     }
-    th.emplace_back([&p, &f]() {
-      p.rc = f(p);
-      if (p.rc) {
-        p.err = fltx_last_error(); /* (the message is thread-local) */
+    if (!p.worker) {
+      p.worker.reset(new fltx_group::Worker());
+    }
+    fltx_group::Part* pp = &p;
+    p.worker->post([pp, &f]() {
+      pp->rc = f(*pp);
+      if (pp->rc) {
+        pp->err = fltx_last_error(); /* (the message is thread-local) */
       }
     });
   }
-  for (auto& t : th) {
-    t.join();
+  for (auto& p : g->parts) {
+    if (p.count != 0 && p.worker) {
+      p.worker->wait();
+    }
   }
   for (auto& p : g->parts) {
     if (p.rc) {
@@ -110,6 +163,7 @@ int fltx_group_destroy(fltx_group* g) {
     return FLTX_OK;
   }
   for (auto& p : g->parts) {
+    p.worker.reset();
     if (p.dec) {
       fltx_decoder_destroy(p.dec);
     }

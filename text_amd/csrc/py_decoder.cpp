@@ -301,26 +301,12 @@ PYBIND11_MODULE(flashlight_lib_text_decoder, m) {
       .def("set_default_index", &Dictionary::setDefaultIndex, "idx"_a)
       .def("get_index", &Dictionary::getIndex, "entry"_a)
       .def("contains", &Dictionary::contains, "entry"_a)
-      .def("map_entries_to_indices",
-           [](const Dictionary& d, const std::vector<std::string>& es) {
-             std::vector<int> out;
-             for (const auto& e : es) {
-               out.push_back(d.getIndex(e));
-             }
-             return out;
-           },
-           "entries"_a)
-      .def("map_indices_to_entries",
-           [](const Dictionary& d, const std::vector<int>& is) {
-             std::vector<std::string> out;
-             for (int i : is) {
-               out.push_back(d.getEntry(i));
-             }
-             return out;
-           },
-           "indices"_a);
+      .def("is_contiguous", &Dictionary::isContiguous)
+      .def("map_entries_to_indices", &Dictionary::mapEntriesToIndices, "entries"_a)
+      .def("map_indices_to_entries", &Dictionary::mapIndicesToEntries, "indices"_a);
   m.def("create_word_dict", &createWordDict, "lexicon"_a);
   m.def("load_words", &loadWords, "filename"_a, "max_words"_a = -1);
   m.def("pack_replabels", &packReplabels, "tokens"_a, "dict"_a, "max_reps"_a);
+  m.def("unpack_replabels", &unpackReplabels, "tokens"_a, "dict"_a, "max_reps"_a);
   m.def("tkn_to_idx", &tkn2Idx, "spelling"_a, "token_dict"_a, "maxReps"_a);
 }
