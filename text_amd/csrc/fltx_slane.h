@@ -354,7 +354,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
    * row and does the per-frame housekeeping, off everybody else's path */
   const int selfWave = nW - 2;
   const int prepWave = nW - 1;
-  const bool isSelf = wave == selfWave, isSvc = wave == prepWave;
+  const bool isSelfW = wave == selfWave, isSvcW = wave == prepWave;
   const int K = P.K, N = P.N;
   const bool ctc = P.criterion == 1;
   const int T = P.stepT ? P.stepT[b] : 0;
@@ -422,8 +422,11 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   int2* const histPT = P.histPT;
 
   /* one frame; PT = parity of the frame (compile time: every LDS address is an immediate) */
-  auto frameStep = [&](auto PT, float& rowReg, const int t) {
+  /* RL = role of the wave (compile time as well: the three kinds of waves share the barriers and the
+   * selection, and nothing else -- each gets its own straight-line frame and its own registers) */
+  auto frameStep = [&](auto PT, auto RL, float& rowReg, const int t) {
     constexpr int p = decltype(PT)::value, q = p ^ 1;
+    constexpr bool isSelf = decltype(RL)::value == 1, isSvc = decltype(RL)::value == 2;
     const int frameOut = t + 1;
     const int64_t hrow = hbase + (int64_t)frameOut * K;
     /* ---- phase 1: own state, candidates, histogram ------------------------------------- */
@@ -849,18 +852,25 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     ldsBarrier(); /* 3 */
     FLTX_SLPROF(5);
   };
-  {
+  auto frames = [&](auto RL) {
     int t = 0;
     for (; t + 1 < T && !dead; t += 2) {
-      frameStep(SlParity<0>(), rowA, t);
+      frameStep(SlParity<0>(), RL, rowA, t);
       if (dead) {
         break;
       }
-      frameStep(SlParity<1>(), rowB, t + 1);
+      frameStep(SlParity<1>(), RL, rowB, t + 1);
     }
     if (!dead && t < T) {
-      frameStep(SlParity<0>(), rowA, t);
+      frameStep(SlParity<0>(), RL, rowA, t);
     }
+  };
+  if (isSvcW) {
+    frames(SlParity<2>());
+  } else if (isSelfW) {
+    frames(SlParity<1>());
+  } else {
+    frames(SlParity<0>());
   }
 
   /* ---- decodeEnd (LexiconFreeDecoder.cpp:127-158): finish() keeps the state, token = sil; the two
