@@ -1310,7 +1310,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
     /* (threads, list positions per token wave) pairs that are compiled (fltx_instances.h); two of the
      * waves do not evaluate tokens (own groups of the lanes / row staging and housekeeping) */
-    static const int geo[][2] = {{512, 5}, {576, 4}, {448, 6}, {384, 7}, {320, 10}, {640, 4}, {512, 12}, {576, 10}, {256, 14}}; /* fastest first (C2) */
+    static const int geo[][2] = {{576, 4}, {512, 5}, {448, 6}, {384, 7}, {320, 10}, {640, 4}, {512, 12}, {576, 10}}; /* fastest first (C2: 1.95, 2.11, 2.14 ms ...) */
     const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
     for (const auto& g : geo) {
       if ((d->userThreads && d->threads != g[0]) || (d->slaneThreads && d->slaneThreads != g[0])) {
@@ -1773,8 +1773,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       slaneUtterance<10, false>(*pp, smem);
     } else if (sl == 12) {
       slaneUtterance<12, false>(*pp, smem);
-    } else if (sl == 14) {
-      slaneUtterance<14, false>(*pp, smem);
+
     } else if (gt == 4) {
       if (pp->logAdd) {
         ft ? decodeUtterance<1, 4, true, true>(*pp, base) : decodeUtterance<1, 4, true, false>(*pp, base);
@@ -1928,7 +1927,6 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   } else if (d->slane) {
     const int key = W * 100 + d->slane;
     switch (key) {
-      case 25614: FLTX_LAUNCH_SLANE(256, 14); break;
       case 32010: FLTX_LAUNCH_SLANE(320, 10); break;
       case 38407: FLTX_LAUNCH_SLANE(384, 7); break;
       case 44806: FLTX_LAUNCH_SLANE(448, 6); break;

@@ -30,7 +30,6 @@
 #define FLTX_G9(W) FLTX_INST(fltx_decode_kernel_gwslean<W>)
 /* lane = LM state decode (fltx_slane.h): (threads, list positions per wave) pairs; W is ignored */
 #define FLTX_SLANE_SET(PROF)                               \
-  FLTX_INST(fltx_decode_kernel_slane<256, 14, PROF>)       \
   FLTX_INST(fltx_decode_kernel_slane<320, 10, PROF>)       \
   FLTX_INST(fltx_decode_kernel_slane<384, 7, PROF>)        \
   FLTX_INST(fltx_decode_kernel_slane<448, 6, PROF>)        \

@@ -205,9 +205,10 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   const int nW = W >> 6;
   const int nTok = nW - NG - 2;
   const int wordWave = nW - 2, prepWave = nW - 1;
-  const bool isTok = wave < nTok, isSelf = wave >= nTok && wave < nTok + NG, isWord = wave == wordWave;
-  const bool isSvc = wave == prepWave;
-  const int grp = isSelf ? wave - nTok : 0;
+  const bool isTokW = wave < nTok, isSelfW = wave >= nTok && wave < nTok + NG, isWordW = wave == wordWave;
+  const bool isSvc = wave == prepWave; /* (roles at run time) */
+  (void)isTokW;
+  const int grp = isSelfW ? wave - nTok : 0;
   const int li = grp * 64 + lane; /* self waves: the lane this thread owns */
   const int K = P.K, N = P.N, TPW = P.yTpw;
   const int T = P.stepT ? P.stepT[b] : 0;
@@ -330,8 +331,12 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
   bool dead = false;
 
-  auto frameStep = [&](auto PT, float& rowReg, const int t) {
+  /* RL = role of the wave, compile time as the parity (0 token, 1 own groups, 2 word ends, 3 staging):
+   * see fltx_xlane.h */
+  auto frameStep = [&](auto PT, auto RL, float& rowReg, const int t) {
     constexpr int p = decltype(PT)::value, q = p ^ 1;
+    constexpr int role = decltype(RL)::value;
+    constexpr bool isTok = role == 0, isSelf = role == 1, isWord = role == 2, isSvc = role == 3;
     const int frameOut = t + 1;
     const int64_t hrow = hbase + (int64_t)frameOut * K;
     /* ---- phase 1a: candidates, the merge table, the frame's best --------------------------- */
@@ -1417,18 +1422,27 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     }
     FLTX_YLPROF(6);
   };
-  {
+  auto frames = [&](auto RL) {
     int t = 0;
     for (; t + 1 < T && !dead; t += 2) {
-      frameStep(SlParity<0>(), rowA, t);
+      frameStep(SlParity<0>(), RL, rowA, t);
       if (dead) {
         break;
       }
-      frameStep(SlParity<1>(), rowB, t + 1);
+      frameStep(SlParity<1>(), RL, rowB, t + 1);
     }
     if (!dead && t < T) {
-      frameStep(SlParity<0>(), rowA, t);
+      frameStep(SlParity<0>(), RL, rowA, t);
     }
+  };
+  if (isSvc) {
+    frames(SlParity<3>());
+  } else if (isWordW) {
+    frames(SlParity<2>());
+  } else if (isSelfW) {
+    frames(SlParity<1>());
+  } else {
+    frames(SlParity<0>());
   }
 
   /* ---- decodeEnd (LexiconDecoder.cpp:231-274): if any hypothesis stands on the root only those
