@@ -551,7 +551,7 @@ int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t nNgrams, const in
   lm->eos = eos;
   lm->unk = unk;
   lm->nUsr = nUsr;
-  uint32_t cap = nextPow2((uint64_t)entNode.size() * 2 + 16);
+  uint32_t cap = nextPow2((uint64_t)entNode.size() * 4 + 16); /* at most a quarter full: a look-up is a chain of dependent trips to HBM, one more per occupied slot it meets (C4: 2x -> 4x slots = -4 % on the whole kernel) */
   lm->mask = cap - 1;
   lm->hTab.assign(cap, NgramSlot{0, kEmpty, 0, 0.0f});
   for (size_t e = 0; e < entNode.size(); ++e) {
