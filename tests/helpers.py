@@ -183,9 +183,11 @@ class FltxSession:
             d.set("threads", threads)
         return d
 
-    def run(self, c, inp=None, threads=None):
+    def run(self, c, inp=None, threads=None, sets=None):
         inp = inp or case_inputs(c)
         d = self.decoder(c, inp, threads)
+        for k, v in (sets or {}).items():
+            d.set(k, v)
         d.decode_batch(inp["e"], [c["T"]], c["N"])
         out = d.results(0)
         self.last_engine = d.get("engine")

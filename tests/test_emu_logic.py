@@ -62,7 +62,9 @@ def test_emulated_lexicon_lane_engine(emu_session, golden, name, threads):
 
 
 YLANE = [("lx_scores_t50", {}), ("ng_word_t40_k10", {}), ("ng_word_t60_k16_4g", {}), ("lx_spell_t40_k8", {"ylane": 2}),
-         ("lx_uni_t40_k10", {"ylane": 2}), ("lx_t0", {"ylane": 2})]
+         ("lx_uni_t40_k10", {"ylane": 2}), ("lx_t0", {"ylane": 2}),
+         # the geometry that shares a CU: LM-state memo in HBM (fltx_ylane.h, HM = 1)
+         ("ng_word_t40_k10", {"yshare": 1}), ("lx_scores_t50", {"yshare": 1})]
 
 
 @pytest.mark.parametrize("name,sets", YLANE)
@@ -81,14 +83,18 @@ def test_emulated_lexicon_lane_engine_with_lm_terms(emu_session, golden, name, s
     assert ok, why
 
 
-def test_emulated_two_lane_groups(emu_session, oracle_lib):
-    """beam 90 over an n-gram LM: two groups of 64 lanes, four rounds of pairs per token-wave thread."""
+@pytest.mark.parametrize("yshare", [0, 1])
+def test_emulated_two_lane_groups(emu_session, oracle_lib, yshare):
+    """beam 90 over an n-gram LM: two groups of 64 lanes, four rounds of pairs per token-wave thread;
+    yshare = 1: 512 threads (four token waves with twice the pairs each), LM-state memo in HBM."""
     c = [x for x in cases.fuzz_cases(120) if x["name"] == "fuzz113"][0]
     inp = helpers.case_inputs(c)
     want = helpers.run_checker(oracle_lib, c, inp)
     d = emu_session.decoder(c, inp)
+    d.set("yshare", yshare)
     d.decode_batch(inp["e"], [c["T"]], c["N"])
     assert d.get("engine") == 6 and d.get("ylane") == 2 and d.get("redone") == 0
+    assert d.get("yshare") == yshare and d.get("threads") == (512 if yshare else 768)
     ok, why = helpers.hyps_equal(want, d.results(0))
     d.close()
     assert ok, why

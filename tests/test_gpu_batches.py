@@ -51,7 +51,7 @@ def _check_structure(h, e, lex, T, N, zero_lm, opt):
     return n_words
 
 
-def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample, sets=None, engine=None):
+def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample, sets=None, engine=None, expect=None):
     c = cases.BY_NAME[name0]
     inp = helpers.case_inputs(c)
     T, N = c["T"], c["N"]
@@ -63,6 +63,8 @@ def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample, sets=
     assert d.get("lds") == 1
     if engine is not None:
         assert d.get("engine") == engine and d.get("redone") == 0
+    for k, v in (expect or {}).items():
+        assert d.get(k) == v, (k, d.get(k), v)
     for b, name in ((0, name0), (255, name255)):
         if name and b < B:
             ok, why = helpers.check_against_golden(d.results(b), golden[name])
@@ -94,7 +96,8 @@ def test_c3_batch_of_256(gpu_session, golden, oracle_lib, sets, engine):
                engine=engine)
 
 
-@pytest.mark.parametrize("sets,engine", [({}, 6), ({"ylane": 0}, 0)], ids=["lane-engine", "generic-engine"])
+@pytest.mark.parametrize("sets,engine", [({}, 6), ({"yshare": 1}, 6), ({"ylane": 0}, 0)],
+                         ids=["lane-engine", "lane-engine-sharing-a-cu", "generic-engine"])
 def test_c4_batch_of_256(gpu_session, golden, oracle_lib, sets, engine):
     """C4 as benchmarked: served by fltx_ylane.h (n-gram word LM, smeared trie, beam 100 = two lane
     groups); the generic engine on the same batch."""
@@ -105,7 +108,8 @@ def test_c4_batch_of_256(gpu_session, golden, oracle_lib, sets, engine):
 def test_c5_share_of_one_gpu_1024_utterances(gpu_session, golden, oracle_lib):
     """BASELINE.json configs[4]: 8192 utterances over 8 GPUs = 1024 per GPU, i.e. four launch
     rounds of the 256 workgroups a device runs at a time."""
-    _run_batch(gpu_session, golden, oracle_lib, "C4_spell_u0", "C4_spell_u255", 1024, sample=[700, 1023], engine=6)
+    _run_batch(gpu_session, golden, oracle_lib, "C4_spell_u0", "C4_spell_u255", 1024, sample=[700, 1023], engine=6,
+               expect={"yshare": 1, "threads": 512})  # more utterances than CUs: two workgroups share a CU
 
 
 def test_random_configurations_slice(gpu_session, oracle_lib):
@@ -206,8 +210,10 @@ def test_utterances_handed_to_the_generic_engine_inside_a_lane_engine_batch(gpu_
         assert ok, "utterance %d: %s" % (b, why)
 
 
-def test_edge_configurations_of_the_lexicon_lane_engine_with_lm_terms(gpu_session, oracle_lib):
-    """fltx_ylane.h against the oracle: n-gram word LMs of order 2 .. 4 and label scores without an
+@pytest.mark.parametrize("yshare", [-1, 1], ids=["memo-in-lds", "shares-a-cu"])
+def test_edge_configurations_of_the_lexicon_lane_engine_with_lm_terms(gpu_session, oracle_lib, yshare):
+    """(yshare = 1: the geometry of which two workgroups fit a CU -- 512 threads, LM-state memo in HBM.)
+    fltx_ylane.h against the oracle: n-gram word LMs of order 2 .. 4 and label scores without an
     LM (smearing only), beams 1 .. 128 (one and two lane groups), thresholds 0 .. inf, token
     beams, lmWeight / wordScore / silScore of both signs, one-frame utterances, `uniform` rows."""
     import itertools
@@ -225,7 +231,7 @@ def test_edge_configurations_of_the_lexicon_lane_engine_with_lm_terms(gpu_sessio
         want = helpers.run_checker(oracle_lib, c, inp)
         if len({h.score for h in want}) != len(want):
             continue
-        got = gpu_session.run(c, inp)
+        got = gpu_session.run(c, inp, sets={"yshare": yshare})
         served += gpu_session.last_engine == 6
         ok, why = helpers.hyps_equal(want, got)
         ran += 1

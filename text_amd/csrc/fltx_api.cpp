@@ -321,6 +321,8 @@ struct fltx_decoder {
   const fltx_trie* xlmwordTrie = nullptr;
   const fltx_lm* xlmwordLm = nullptr;
   int ylane = 0, noYlane = 0, ylaneLm = 0, ylaneRounds = 0, ylaneTpw = 0; /* ylane: lane groups of fltx_ylane.h (0 = not used) */
+  int yshare = 0, userYshare = -1; /* the geometry of fltx_ylane.h that shares a CU (memo in HBM); user: -1 = when the batch exceeds the CUs */
+  DBuf ymemo;
   int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
   bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
   const float* lastEmis = nullptr; /* device emissions of the last offline batch (the back-trace re-reads them) */
@@ -1097,6 +1099,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->xlane;
   } else if (!strcmp(key, "ylane")) {
     *value = d->ylane;
+  } else if (!strcmp(key, "yshare")) {
+    *value = d->ylane ? d->yshare : 0;
   } else if (!strcmp(key, "redone")) {
     *value = d->lastRedo;
   } else if (!strcmp(key, "slane")) {
@@ -1187,6 +1191,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "xlane")) { /* 0: do not use the lane = (LM state, trie node) kernel (fltx_xlane.h) */
     d->noXlane = value ? 0 : 1;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "yshare")) { /* fltx_ylane.h geometry that shares a CU: 1 always, 0 never, -1 when the batch exceeds the CUs */
+    d->userYshare = (int)value;
     return FLTX_OK;
   }
   if (!strcmp(key, "ylane")) { /* 0: do not use fltx_ylane.h; 2: prefer it where fltx_xlane.h applies too */
@@ -1354,10 +1362,18 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) && K <= 128 && N <= 64 &&
       d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N && d->blank >= 0 && d->blank < N) {
     const int ng = K <= 64 ? 1 : 2;
-    const int threads = ng == 1 ? 512 : 768;
+    /* More utterances than CUs: the geometry of which two workgroups fit a CU (512 threads, <= 128
+     * VGPRs, 77 KB of LDS: the LM-state memo moves to HBM) -- one utterance's waits are the other's
+     * time to run (C5's 1 024 utterances per GPU: 1.6x).  With no more utterances than CUs the second
+     * workgroup would not exist and the memo in LDS is the faster one. */
+    const bool share = d->userYshare >= 0 ? d->userYshare != 0 : B > d->ctx->numCUs;
+    const int threads = ng == 1 ? 512 : (share ? 512 : 768);
     const int nTokWaves = threads / 64 - ng - 2;
     const int tpw = (nTok + nTokWaves - 1) / nTokWaves;
-    if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96 && tpw * 64 * ng <= 512 && nTokWaves <= 8) {
+    const int pairCap = (ng == 2 && share) ? 1024 : 512;
+    d->yshare = 0;
+    if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96 && tpw * 64 * ng <= pairCap && nTokWaves <= 8) {
+      d->yshare = share ? 1 : 0;
       d->ylane = ng;
       d->ylaneRounds = ng == 1 ? 2 : 4;
       d->ylaneTpw = tpw;
@@ -1551,7 +1567,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     lds = true;
   }
   if (d->ylane) {
-    d->wsBytes = sizeof(YlaneLds);
+    d->wsBytes = d->yshare ? offsetof(YlaneLds, memo) : sizeof(YlaneLds);
     d->wsInLds = true;
     lds = true;
     d->itemCap = 0;
@@ -1614,6 +1630,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     rc |= d->maskTab.ensure(8 * (size_t)B * d->idCap, st, false);
     rc |= d->uttNextId.ensure(4 * (size_t)B, st, true);
     rc |= d->gMask.ensure(8 * bk, st, false);
+  }
+  if (d->ylane && d->yshare) {
+    rc |= d->ymemo.ensure(sizeof(unsigned long long) * (size_t)kYlMemo * (size_t)B, st, false); /* (wiped by the kernel) */
   }
   if (d->lm->kind == 1) {
     rc |= d->scored.ensure(4 * (size_t)B, st, false);
@@ -1712,6 +1731,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xdelta = (d->trie && d->trie->xdelta.p) ? d->trie->xdelta.as<float>() : nullptr;
   P.yTpw = d->ylaneTpw;
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
+  P.ymemo = (d->ylane && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;
@@ -1731,7 +1751,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   const int gt = d->lane;
   const int sl = d->slane;
   const int xl = d->xlane;
-  const int yl = d->ylane ? d->ylane * 10 + d->ylaneLm : 0;
+  const int yl = d->ylane ? d->ylane * 10 + d->ylaneLm + (d->yshare ? 100 : 0) : 0;
   const bool hot = !d->wsInLds && d->hotBytes > 0;
   emuLaunch(d->nLaunch > 0 ? d->nLaunch : d->B, W, d->wsInLds ? d->wsBytes : (hot ? d->hotBytes : 16),
             [pp, gmax, gt, sl, xl, yl, hot](char* smem) {
@@ -1746,13 +1766,21 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     }
     const bool ft = pp->Kt >= pp->N;
     if (yl == 10) {
-      ylaneUtterance<1, 2, 0, false>(*pp, smem);
+      ylaneUtterance<1, 2, 0, 0, false>(*pp, smem);
     } else if (yl == 11) {
-      ylaneUtterance<1, 2, 1, false>(*pp, smem);
+      ylaneUtterance<1, 2, 1, 0, false>(*pp, smem);
     } else if (yl == 20) {
-      ylaneUtterance<2, 4, 0, false>(*pp, smem);
+      ylaneUtterance<2, 4, 0, 0, false>(*pp, smem);
     } else if (yl == 21) {
-      ylaneUtterance<2, 4, 1, false>(*pp, smem);
+      ylaneUtterance<2, 4, 1, 0, false>(*pp, smem);
+    } else if (yl == 110) {
+      ylaneUtterance<1, 2, 0, 1, false>(*pp, smem);
+    } else if (yl == 111) {
+      ylaneUtterance<1, 2, 1, 1, false>(*pp, smem);
+    } else if (yl == 120) {
+      ylaneUtterance<2, 4, 0, 1, false>(*pp, smem);
+    } else if (yl == 121) {
+      ylaneUtterance<2, 4, 1, 1, false>(*pp, smem);
     } else if (xl == 3) {
       xlaneUtterance<3, false>(*pp, smem);
     } else if (xl == 5) {
@@ -1878,25 +1906,29 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     }                                                                                            \
   } while (0)
   if (d->ylane) {
-#define FLTX_LAUNCH_YLANE(WW, NG, RR, LMK)                                                            \
-  do {                                                                                                \
-    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<WW, NG, RR, LMK, false>,         \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));         \
-    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<WW, NG, RR, LMK, true>,          \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));         \
-    if (d->profile) {                                                                                 \
-      hipLaunchKernelGGL((fltx_decode_kernel_ylane<WW, NG, RR, LMK, true>), dim3(nGrid), dim3(WW),    \
-                         d->wsBytes, d->ctx->stream, P);                                              \
-    } else {                                                                                          \
-      hipLaunchKernelGGL((fltx_decode_kernel_ylane<WW, NG, RR, LMK, false>), dim3(nGrid), dim3(WW),   \
-                         d->wsBytes, d->ctx->stream, P);                                              \
-    }                                                                                                 \
+#define FLTX_LAUNCH_YLANE(WW, NG, RR, LMK, HM)                                                          \
+  do {                                                                                                  \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<WW, NG, RR, LMK, HM, false>,       \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));           \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<WW, NG, RR, LMK, HM, true>,        \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));           \
+    if (d->profile) {                                                                                   \
+      hipLaunchKernelGGL((fltx_decode_kernel_ylane<WW, NG, RR, LMK, HM, true>), dim3(nGrid), dim3(WW),  \
+                         d->wsBytes, d->ctx->stream, P);                                                \
+    } else {                                                                                            \
+      hipLaunchKernelGGL((fltx_decode_kernel_ylane<WW, NG, RR, LMK, HM, false>), dim3(nGrid), dim3(WW), \
+                         d->wsBytes, d->ctx->stream, P);                                                \
+    }                                                                                                   \
   } while (0)
-    switch (d->ylane * 10 + d->ylaneLm) {
-      case 10: FLTX_LAUNCH_YLANE(512, 1, 2, 0); break;
-      case 11: FLTX_LAUNCH_YLANE(512, 1, 2, 1); break;
-      case 20: FLTX_LAUNCH_YLANE(768, 2, 4, 0); break;
-      case 21: FLTX_LAUNCH_YLANE(768, 2, 4, 1); break;
+    switch (d->ylane * 10 + d->ylaneLm + (d->yshare ? 100 : 0)) {
+      case 10: FLTX_LAUNCH_YLANE(512, 1, 2, 0, 0); break;
+      case 11: FLTX_LAUNCH_YLANE(512, 1, 2, 1, 0); break;
+      case 20: FLTX_LAUNCH_YLANE(768, 2, 4, 0, 0); break;
+      case 21: FLTX_LAUNCH_YLANE(768, 2, 4, 1, 0); break;
+      case 110: FLTX_LAUNCH_YLANE(512, 1, 2, 0, 1); break;
+      case 111: FLTX_LAUNCH_YLANE(512, 1, 2, 1, 1); break;
+      case 120: FLTX_LAUNCH_YLANE(512, 2, 4, 0, 1); break;
+      case 121: FLTX_LAUNCH_YLANE(512, 2, 4, 1, 1); break;
       default: return fail(FLTX_ERR_INVALID, "no fltx_ylane.h kernel for %d lane groups", d->ylane);
     }
 #undef FLTX_LAUNCH_YLANE

@@ -48,12 +48,16 @@
   FLTX_INST(fltx_decode_kernel_xlane<576, 5, PROF>)        \
   FLTX_INST(fltx_decode_kernel_xlane<640, 10, PROF>)
 #define FLTX_G12(W) FLTX_XLANE_SET(false) FLTX_XLANE_SET(true)
-/* ... with LM terms, two lane groups (fltx_ylane.h): (threads, groups, rounds, LM terms) */
-#define FLTX_YLANE_SET(PROF)                               \
-  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 0, PROF>)  \
-  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 1, PROF>)  \
-  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 0, PROF>)  \
-  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 1, PROF>)
+/* ... with LM terms, two lane groups (fltx_ylane.h): (threads, groups, rounds, LM terms, memo in HBM = shares a CU) */
+#define FLTX_YLANE_SET(PROF)                                  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 0, 0, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 1, 0, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 0, 0, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 1, 0, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 0, 1, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 1, 1, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 0, 1, PROF>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 1, 1, PROF>)
 #define FLTX_G13(W) FLTX_YLANE_SET(false)
 #define FLTX_G14(W) FLTX_YLANE_SET(true)
 

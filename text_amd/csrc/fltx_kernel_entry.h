@@ -58,10 +58,12 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_xlane(DecodeParams P) {
   xlaneUtterance<GT, PROF>(P, fltx_smem);
 }
 /* ... with a word LM and / or a smeared trie, beams up to 128 (fltx_ylane.h) */
-template <int W, int NG, int R, int LMK, bool PROF>
-__global__ void __launch_bounds__(W) fltx_decode_kernel_ylane(DecodeParams P) {
+/* HM = 1: the geometry that shares a CU (LM-state memo in HBM, 77 KB of LDS, at most 128 VGPRs: four
+ * waves per SIMD = two workgroups of 512 threads) */
+template <int W, int NG, int R, int LMK, int HM, bool PROF>
+__global__ void __launch_bounds__(W, HM ? 4 : 1) fltx_decode_kernel_ylane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  ylaneUtterance<NG, R, LMK, PROF>(P, fltx_smem);
+  ylaneUtterance<NG, R, LMK, HM, PROF>(P, fltx_smem);
 }
 template <int W>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_gwslean(DecodeParams P) { /* streaming lean step, HBM workspace */

@@ -186,6 +186,7 @@ struct DecodeParams {
   int32_t xEndTok;              /* the token every word ends with in that layout */
   const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
+  unsigned long long* ymemo;    /* fltx_ylane.h, shared-CU geometry: the LM-state memo of every utterance (kYlMemo slots each) */
   const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */
   double yBound;                /* ... and the largest lmWeight x smearing difference of the lexicon (>= 0) */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */

@@ -85,7 +85,6 @@ struct YlaneLds {
   uint8_t tokId[2][kSlList];
   YlRootTab root;
   YlOrphTab orph[2];
-  unsigned long long memo[kYlMemo];
   unsigned long long bestKey[2];
   unsigned long long alive[2][2];    /* lanes of the frame, per group */
   unsigned long long surv[2];        /* ... that stay for the next frame (alive[next] = these + the new lanes) */
@@ -111,6 +110,10 @@ struct YlaneLds {
   unsigned long long endKey[kYlLanes];
   double endScore[kYlLanes], endLmS[kYlLanes];
   uint32_t endHyp[kYlLanes];
+  /* Last member: the shared-CU geometry (HM = 1) keeps the memo in HBM (DecodeParams::ymemo) and is
+   * launched with offsetof(YlaneLds, memo) bytes of LDS -- 77 KB, so that two workgroups fit a CU and
+   * one utterance's waits (two thirds of its wave cycles) are the other's time to run. */
+  unsigned long long memo[kYlMemo];
 };
 
 enum { YL_FLAG = 15, YL_NICE = 14 };
@@ -192,13 +195,16 @@ FLTX_DEV uint32_t ylLmWord(const DecodeParams& P, int usr) {
   } while (0)
 
 /* NG lane groups of 64; R candidate pairs per token-wave thread; LMK = 0: ZeroLM over an
- * unsmeared lexicon (every LM term is zero and left out), 1: smeared trie and / or n-gram LM */
-template <int NG, int R, int LMK, bool PROF>
+ * unsmeared lexicon (every LM term is zero and left out), 1: smeared trie and / or n-gram LM;
+ * HM = 1: the LM-state memo lives in HBM and, with two lane groups, four token waves list twice the
+ * pairs each (512 threads: two workgroups share a CU) */
+template <int NG, int R, int LMK, int HM, bool PROF>
 FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   YlaneLds& S = *(YlaneLds*)smem;
+  constexpr int PAIRS = (NG == 2 && HM) ? 2 * kYlPairs : kYlPairs; /* pairs a token wave can list */
   constexpr int NS = R > NG ? R : (NG > 2 ? NG : 2); /* candidate slots of a thread */
   static_assert(NG == 1 || NG == 2, "one or two lane groups");
-  static_assert(R * 64 <= kYlPairs, "cand[] holds kYlPairs pairs per token wave");
+  static_assert(R * 64 <= PAIRS, "cand[] holds PAIRS pairs per token wave");
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x, tid = (int)threadIdx.x;
   const int lane = laneId(), wave = waveUniform(waveId());
@@ -250,8 +256,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     S.orph[1].lanes[0][i] = 0ull;
     S.orph[1].lanes[1][i] = 0ull;
   }
+  unsigned long long* const memo = HM ? P.ymemo + (size_t)b * kYlMemo : S.memo;
+  uint16_t* const candW = &S.cand[0][0] + (size_t)wave * PAIRS; /* (token waves: wave < 8, or < 4 with twice the pairs) */
+  uint16_t* const pbinW = &S.pbin[0][0] + (size_t)wave * PAIRS;
   for (int i = tid; i < kYlMemo; i += W) {
-    S.memo[i] = 0ull;
+    memo[i] = 0ull; /* (HBM: at L2 before the barrier below, where the word wave's atomics will find it) */
   }
   if (tid < 32) {
     S.off[tid] = 0u;
@@ -487,16 +496,16 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           const unsigned long long bal = waveBallot(has);
           if (bal != 0ull) {
             const int at = nCand + wavePrefixCount(bal);
-            if (has && at < kYlPairs) {
-              S.cand[wave][at] = (uint16_t)((g * 64 + lane) | (j << 8));
+            if (has && at < PAIRS) {
+              candW[at] = (uint16_t)((g * 64 + lane) | (j << 8));
             }
             nCand += popc64(bal);
           }
         }
       }
-      if (nCand > kYlPairs) { /* (the host sizes the waves' shares so that this cannot happen) */
+      if (nCand > PAIRS) { /* (the host sizes the waves' shares so that this cannot happen) */
         dead = true; YL_WHY(7);
-        nCand = kYlPairs;
+        nCand = PAIRS;
       }
       waveSync();
       if (nCand > R * 64 && !dead) {
@@ -510,7 +519,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         for (int c0 = 0; c0 < nCand; c0 += 64) {
           const int id = c0 + lane;
           const bool valid = id < nCand;
-          const uint32_t c16 = valid ? (uint32_t)S.cand[wave][id] : 0u;
+          const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
           const int x = (int)(c16 & 0xFFu), pos = wave * TPW + (int)(c16 >> 8);
           const double xnb = L.nb[x], xb = L.b[x];
           const int n = (int)S.tokId[p][pos];
@@ -529,7 +538,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             atomAdd32(&wh[bin], 1u);
           }
           if (valid) {
-            S.pbin[wave][id] = (uint16_t)bin;
+            pbinW[id] = (uint16_t)bin;
           }
         }
         waveSync();
@@ -539,12 +548,12 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         for (int c0 = 0; c0 < nCand; c0 += 64) {
           const int id = c0 + lane;
           const bool valid = id < nCand;
-          const uint32_t c16 = valid ? (uint32_t)S.cand[wave][id] : 0u;
-          const bool keep = valid && (int)S.pbin[wave][valid ? id : 0] <= cut;
+          const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
+          const bool keep = valid && (int)pbinW[valid ? id : 0] <= cut;
           const unsigned long long bal = waveBallot(keep);
           waveSync();
           if (keep) {
-            S.cand[wave][kept + wavePrefixCount(bal)] = (uint16_t)c16;
+            candW[kept + wavePrefixCount(bal)] = (uint16_t)c16;
           }
           kept += popc64(bal);
           waveSync();
@@ -564,7 +573,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         const int id = r * 64 + lane;
         if (r * 64 < nCand) {
           const bool valid = id < nCand;
-          const uint32_t c16 = valid ? (uint32_t)S.cand[wave][id] : 0u;
+          const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
           const int x = (int)(c16 & 0xFFu), pos = wave * TPW + (int)(c16 >> 8);
           const double xnb = L.nb[x], xb = L.b[x];
           const uint32_t xi = L.info[x];
@@ -1083,13 +1092,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
               uint32_t sid = 0u;
               bool have = false; /* a number was taken from the counter for this state */
               for (int probe = 0;; ++probe) {
-                unsigned long long cur = S.memo[h];
+                unsigned long long cur = HM ? loadCoherent64(&memo[h]) : S.memo[h];
                 if (cur == 0ull) {
                   if (!have) {
                     sid = atomAdd32(&S.lmNext, 1u);
                     have = true;
                   }
-                  cur = atomCas64(&S.memo[h], 0ull, (mkey << 16) | (unsigned long long)(sid & 0xFFFFu));
+                  cur = atomCas64(&memo[h], 0ull, (mkey << 16) | (unsigned long long)(sid & 0xFFFFu));
                   if (cur == 0ull) { /* a new LM state */
                     if (sid > (uint32_t)(kYlMemo * 3 / 4) || sid + 1u >= P.stateCap || sid >= 0xFFFFu ||
                         (uint32_t)(el + 1) >= (1u << 24)) {
