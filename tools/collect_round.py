@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Copies the summaries tools/profile_r02.sh left under gpurun_out/r02/ into profiles/r02/ and
+"""Copies the summaries tools/profile_round.sh left under gpurun_out/<round>/ into profiles/<round>/ and
 rebuilds hbm_traffic_*.json with the workload keys bench.py looks up (geometry and engine are
 taken from the bench lines of the same pass).  Run from the repo root after the gpurun call;
-start from an empty gpurun_out/r02/ (older passes would be mixed in)."""
+start from an empty gpurun_out/<round>/ (older passes would be mixed in)."""
 import glob, json, os, shutil, subprocess, sys
 
-O, D = "gpurun_out/r02", "profiles/r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+O, D = "gpurun_out/" + R, "profiles/" + R
+os.makedirs(D, exist_ok=True)
 SHAPE = {"C2": (256, 1000, 50), "C3": (256, 1000, 50), "C4": (256, 1500, 100), "C5": (1024, 1500, 100)}
 
 

@@ -1,10 +1,11 @@
 #!/bin/bash
-# Regenerates the measurements kept under profiles/r02/ on an MI355X box (run through gpurun from
-# the repo root; outputs land in gpurun_out/r02/).  PMC passes are separate runs with --pmc only
-# (kernel trace is the only trace domain), one counter set per pass.
+# Regenerates the measurements kept under profiles/<round>/ on an MI355X box: tools/profile_round.sh r03 (through gpurun,
+# from the repo root; outputs land in gpurun_out/<round>/, tools/collect_round.py copies the summaries).  PMC passes are
+# separate runs with --pmc only (kernel trace is the only trace domain), one counter set per pass.
+ROUND="${1:-r03}"
 export TMPDIR=/tmp
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
-O="$R/gpurun_out/r02"
+O="$R/gpurun_out/${ROUND}"
 rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 for w in C2 C3 C4; do
