@@ -69,11 +69,11 @@ def test_bench_finds_the_committed_hbm_traffic_of_its_default_workload():
     """bench.py quotes roofline.traffic from the rocprofv3 --pmc summary committed
     under profiles/ -- keyed by the exact geometry it was measured on."""
     import bench
-    tr = bench.pmc_traffic("C2", 512, 256, 1000, 29, 50, engine=4)
-    assert tr is not None and tr[0] > 1e8 and tr[1].startswith("profiles/r02/")
+    tr = bench.pmc_traffic("C2", 576, 256, 1000, 29, 50, engine=4)
+    assert tr is not None and tr[0] > 1e8 and tr[1].startswith("profiles/r03/")
     assert bench.pmc_traffic("C2", 256, 256, 1000, 29, 50, engine=4) is None  # other geometry: not quoted
-    assert bench.pmc_traffic("C2", 512, 256, 1000, 29, 50, engine=3) is None  # other engine: not quoted
+    assert bench.pmc_traffic("C2", 576, 256, 1000, 29, 50, engine=3) is None  # other engine: not quoted
     assert bench.pmc_traffic("C3", 512, 256, 1000, 29, 50, engine=5) is not None  # fltx_xlane.h
     assert bench.pmc_traffic("C4", 768, 256, 1500, 29, 100, engine=6) is not None  # fltx_ylane.h
-    assert bench.pmc_traffic("C5", 768, 1024, 1500, 29, 100, engine=6) is not None  # C5's share of one GPU
+    assert bench.pmc_traffic("C5", 512, 1024, 1500, 29, 100, engine=6) is not None  # C5's share: two workgroups per CU
     assert bench.pmc_traffic("C4", 512, 256, 1500, 29, 100, engine=0) is None  # the generic engine was not re-measured
