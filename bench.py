@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--beam", type=int, default=0)
     ap.add_argument("--beam-token", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0, help="threads per utterance (0 = library default)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="decoder objects (each on its own HIP stream) the steps alternate between: with 2 the "
+                         "back-trace of one batch runs under the decode kernel of the next")
     ap.add_argument("--cpu-sample", type=int, default=160, help="utterances timed on the one-thread CPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip every CPU / host-side leg (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip all-cores / steady / end-to-end / streaming")
@@ -120,6 +123,7 @@ class Job:
         self.u0 = rank * B
         self.e_host = synth.batch(self.dist, B, self.T, N, lexicon=self.lexicon, u0=self.u0)
         self.ctx = _capi.Context(device=local)
+        self.ctx_device, self.more_ctx, self.more_tries = local, [], []
         self.lm = _capi.ZeroLM(self.ctx)
         self.opt = _capi.make_options(self.K, self.Kt, 25.0)
         self.arpa = None
@@ -142,12 +146,21 @@ class Job:
             self.trie = ht.upload(self.ctx)
         self.Ts = np.full(B, self.T, dtype=np.int32)
 
-    def decoder(self):
+    def decoder(self, second_stream=False):
+        """second_stream: a decoder on a context (= HIP stream) of its own, with its own copy of the
+        trie; the LM object is shared (its tables are uploaded once per context)."""
         c = self.capi
+        ctx, trie = self.ctx, self.trie
+        if second_stream:
+            ctx = c.Context(device=self.ctx_device)
+            self.more_ctx.append(ctx)
+            if self.lex:
+                trie = self.host_trie.upload(ctx)
+                self.more_tries.append(trie)
         if self.lex:
-            d = c.BatchDecoder(self.ctx, c.LEXICON, self.opt, self.lm, 0, self.N - 1, unk=self.W, trie=self.trie)
+            d = c.BatchDecoder(ctx, c.LEXICON, self.opt, self.lm, 0, self.N - 1, unk=self.W, trie=trie)
         else:
-            d = c.BatchDecoder(self.ctx, c.LEXFREE, self.opt, self.lm, 0, self.N - 1)
+            d = c.BatchDecoder(ctx, c.LEXFREE, self.opt, self.lm, 0, self.N - 1)
         if self.a.threads:
             d.set("threads", self.a.threads)
         for kv in self.a.set:
@@ -192,9 +205,12 @@ def main():
     e_dev = torch.from_numpy(job.e_host).cuda()  # resident in HBM before timing
     torch.cuda.synchronize()
     dec = job.decoder()
+    decs = [dec] + [job.decoder(second_stream=True) for _ in range(a.pipeline - 1)]
 
     def fence():
         job.ctx.synchronize()
+        for c in job.more_ctx:
+            c.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -217,16 +233,26 @@ def main():
         return dt
 
     kern_ms, bt_ms = [], []
+    turn = [0]
+    ran = [False] * len(decs)
 
-    def step():
-        dec.decode_batch(None, job.Ts, N, device_ptr=e_dev.data_ptr())
+    def read_events(i):  # HIP events the library recorded on that decoder's launch stream (waits for its batch)
+        if ran[i]:
+            d_ms, b_ms = decs[i].timing()
+            kern_ms.append(d_ms)
+            bt_ms.append(b_ms)
+            ran[i] = False
 
-    def after():  # HIP events recorded by the library on its own launch stream
-        d_ms, b_ms = dec.timing()
-        kern_ms.append(d_ms)
-        bt_ms.append(b_ms)
+    def step():  # one batch through the whole path; consecutive steps take turns on the decoder objects
+        i = turn[0] % len(decs)
+        read_events(i)  # (its previous batch: nothing the next launch would not wait for anyway)
+        decs[i].decode_batch(None, job.Ts, N, device_ptr=e_dev.data_ptr())
+        ran[i] = True
+        turn[0] += 1
 
-    dt = timed(step, a.steps, a.warmup, after)
+    dt = timed(step, a.steps, a.warmup)
+    for i in range(len(decs)):
+        read_events(i)
     if a.profile and rank == 0:
         phase_profile(a, dec, job, step, B, T)
     st = dec.stats()
@@ -247,7 +273,10 @@ def main():
                                 else "ZeroLM", B, T, N, K, Kt, job.dist),
                    "parallelism": "utterance-sharded x%d, no collective" % world,
                    "threads_per_utterance": st["threads_per_utt"], "lds_bytes_per_workgroup": st["lds_bytes"],
-                   "engine": engine, "redone": redone},
+                   "engine": engine, "redone": redone,
+                   "pipeline": "%d decoder object(s), one HIP stream each, taking turns batch by batch%s" % (
+                       len(decs), " (the back-trace of a batch runs under the decode kernel of the next)"
+                       if len(decs) > 1 else "")},
     }
     # ---- roofline (rank-local): each kernel's own algorithmic bytes over its own duration ----
     k_ms, b_ms = float(np.mean(kern_ms)), float(np.mean(bt_ms))
@@ -289,7 +318,7 @@ def main():
 
     # ---- CPU baselines + parity spot check, end to end, streaming (rank 0, N=1 only) --------
     if rank == 0 and world == 1 and not a.no_cpu:
-        step()  # the n-best compared below
+        dec.decode_batch(None, job.Ts, N, device_ptr=e_dev.data_ptr())  # the n-best compared below
         out["cpu_baseline"] = cpu_baseline(a, dec, job)
         if not a.no_extras:
             out["cpu_baseline_steady"], out["cpu_baseline_all_cores"] = cpu_more(a, job)
@@ -297,7 +326,8 @@ def main():
             out["streaming"] = streaming(job, B, T, N)
     if rank == 0:
         print(json.dumps(out))
-    dec.close()
+    for d in decs:
+        d.close()
     if dist is not None:
         dist.destroy_process_group()
     # a line whose n-best differs from the reference's, or that spent its time in fallbacks,

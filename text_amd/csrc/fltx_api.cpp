@@ -321,6 +321,7 @@ struct fltx_decoder {
   const fltx_trie* xlmwordTrie = nullptr;
   const fltx_lm* xlmwordLm = nullptr;
   int ylane = 0, noYlane = 0, ylaneLm = 0, ylaneRounds = 0, ylaneTpw = 0; /* ylane: lane groups of fltx_ylane.h (0 = not used) */
+  int btLdsKb = 0;
   int yshare = 0, userYshare = -1; /* the geometry of fltx_ylane.h that shares a CU (memo in HBM); user: -1 = when the batch exceeds the CUs */
   DBuf ymemo;
   int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
@@ -1193,6 +1194,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noXlane = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "bt_lds_kb")) { /* LDS the back-trace kernel stages history chunks in (0: 144 KB) */
+    d->btLdsKb = (int)value;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "yshare")) { /* fltx_ylane.h geometry that shares a CU: 1 always, 0 never, -1 when the batch exceeds the CUs */
     d->userYshare = (int)value;
     return FLTX_OK;
@@ -1318,7 +1323,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
     /* (threads, list positions per token wave) pairs that are compiled (fltx_instances.h); two of the
      * waves do not evaluate tokens (own groups of the lanes / row staging and housekeeping) */
-    static const int geo[][2] = {{576, 4}, {512, 5}, {448, 6}, {384, 7}, {320, 10}, {640, 4}, {512, 12}, {576, 10}}; /* fastest first (C2: 1.95, 2.11, 2.14 ms ...) */
+    static const int geoOne[][2] = {{576, 4}, {512, 5}, {448, 6}, {384, 7}, {320, 10}, {640, 4}, {512, 12}, {576, 10}}; /* fastest first (C2: 1.95, 2.11, 2.14 ms ...) */
+    /* more utterances than CUs: 512 threads (104 VGPRs: four waves per SIMD) let two utterances share a CU --
+     * C2 at 512 utterances: 162.7 M frames/s against 119.3 M with nine waves each */
+    static const int geoTwo[][2] = {{512, 5}, {448, 6}, {384, 7}, {576, 4}, {320, 10}, {640, 4}, {512, 12}, {576, 10}};
+    const auto& geo = B > d->ctx->numCUs ? geoTwo : geoOne;
     const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
     for (const auto& g : geo) {
       if ((d->userThreads && d->threads != g[0]) || (d->slaneThreads && d->slaneThreads != g[0])) {
@@ -2093,11 +2102,12 @@ int launchBacktrace(fltx_decoder* d) {
   const int btThreads = 512;
 #endif
   const size_t perFrame = (size_t)Q.K * (2 * (8 + (d->kind == FLTX_DECODER_LEXICON ? 4 : 0)) + 8);
-  int F = (int)std::min<size_t>((size_t)144 * 1024 / perFrame, 512);
+  const size_t btBudget = (size_t)(d->btLdsKb > 0 ? std::min(d->btLdsKb, 144) : 144) * 1024;
+  int F = (int)std::min<size_t>(btBudget / perFrame, 512);
   if (d->batchPacked) { /* the emission rows, transitions and addends of a chunk share the same LDS (amLds below) */
     const size_t fixed = 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;
     const size_t perAm = 4 * ((size_t)d->N + (size_t)Q.K);
-    const size_t room = (size_t)144 * 1024 > fixed ? (size_t)144 * 1024 - fixed : 0;
+    const size_t room = btBudget > fixed ? btBudget - fixed : 0;
     F = (int)std::min<size_t>((size_t)F, room / perAm);
   }
   if (F < 8 || Q.K > 4 * btThreads) {
