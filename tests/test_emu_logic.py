@@ -221,3 +221,24 @@ def test_trie_that_is_not_a_tree_is_accepted_without_the_breadth_first_layout(em
         assert d.get("engine") == 0  # generic engine: the lane engines need the layout
         d.close()
         t.close()
+
+
+def test_compact_result_fetch_on_the_emulator(emu_session):
+    """fltx_result_fetch_batch_compact against fltx_result_fetch_batch (host logic; the device packing kernel is
+    exercised by tests/test_gpu_parity.py)."""
+    import numpy as np
+    from text_amd import synth
+    c = cases.BY_NAME["lx_spell_t40_k8"]
+    inp = helpers.case_inputs(c)
+    Ts = [c["T"], 0, 7]
+    embs = [synth.emissions(c["dist"], 900 + b, T, c["N"], lexicon=inp["lex"]) for b, T in enumerate(Ts)]
+    d = emu_session.decoder(c, inp)
+    d.decode_batch(np.concatenate([e.reshape(-1) for e in embs]), Ts, c["N"])
+    allh = d.results_batch()
+    r = d.results_arrays_compact()
+    assert int(r["offsets"][-1]) == int((r["n_hyp"] * r["length"]).sum())
+    for b in range(len(Ts)):
+        assert int(r["n_hyp"][b]) == len(allh[b])
+        for i, h in enumerate(allh[b]):
+            assert np.array_equal(d.tokens_of(r, b, i), h.tokens) and np.array_equal(d.words_of(r, b, i), h.words)
+    d.close()

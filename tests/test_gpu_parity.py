@@ -379,6 +379,14 @@ def test_batched_result_fetch_equals_per_utterance_fetch(gpu_session, name):
     for b in range(len(Ts)):
         ok, why = helpers.hyps_equal(d.results(b), allh[b])
         assert ok, "utterance %d: %s" % (b, why)
+    # ... and so does the compacted form (rows that exist only, tokens as bytes, packed on the device)
+    r = d.results_arrays_compact()
+    assert r["tokens_u8"].dtype == np.uint8 and int(r["offsets"][-1]) == int((r["n_hyp"] * r["length"]).sum())
+    for b in range(len(Ts)):
+        assert int(r["n_hyp"][b]) == len(allh[b])
+        for i, h in enumerate(allh[b]):
+            assert np.array_equal(d.tokens_of(r, b, i), h.tokens) and np.array_equal(d.words_of(r, b, i), h.words)
+            assert tuple(r["scores"][b, i]) == (h.score, h.am, h.lm)
     d.close()
 
 

@@ -52,7 +52,7 @@ class Lib:
         "fltx_trie_create", "fltx_trie_destroy", "fltx_decoder_create",
         "fltx_decoder_destroy", "fltx_decode_batch", "fltx_stream_begin",
         "fltx_stream_step", "fltx_stream_end", "fltx_stream_prune",
-        "fltx_stream_frames_in_buffer", "fltx_result_count", "fltx_result_fetch", "fltx_result_fetch_batch",
+        "fltx_stream_frames_in_buffer", "fltx_result_count", "fltx_result_fetch", "fltx_result_fetch_batch", "fltx_result_fetch_batch_compact",
         "fltx_result_best", "fltx_result_device", "fltx_decoder_stats",
         "fltx_decoder_set", "fltx_decoder_get", "fltx_decoder_timing", "fltx_decoder_profile", "fltx_htrie_create", "fltx_htrie_destroy", "fltx_htrie_insert",
         "fltx_htrie_search", "fltx_htrie_smear", "fltx_htrie_num_nodes", "fltx_htrie_upload",
@@ -99,6 +99,7 @@ class Lib:
             "fltx_result_count": [vp, i32, vp, vp],
             "fltx_result_fetch": [vp, i32, i32, vp, vp, vp, vp],
             "fltx_result_fetch_batch": [vp, pvp, pvp, pvp, pvp, pvp, pvp],
+            "fltx_result_fetch_batch_compact": [vp, pvp, pvp, pvp, pvp, pvp, pvp],
             "fltx_result_best": [vp, i32, i32, vp, vp, vp, i32, vp],
             "fltx_result_device": [vp, pvp, pvp, pvp, pvp, pvp],
             "fltx_decoder_stats": [vp, vp, vp, vp, vp],
@@ -378,6 +379,7 @@ class BatchDecoder:
             _ptr(tr), 0 if tr is None else tr.size, int(is_lm_token), C.byref(h)))
         self.h = h
         self.B = 0
+        self.N = None  # token-set size of the last offline batch
         _live["dec"].add(self)
 
     def set(self, key, value):
@@ -397,10 +399,12 @@ class BatchDecoder:
             e = np.ascontiguousarray(emissions, dtype=np.float32)
             self.L.check(self.L.lib.fltx_decode_batch(self.h, _ptr(e), 0, _ptr(offsets), _ptr(T), B, N))
         self.B = B
+        self.N = N
 
     def stream_begin(self, B, N, max_frames):
         self.L.check(self.L.lib.fltx_stream_begin(self.h, B, N, max_frames))
         self.B = B
+        self.N = None  # (streams: fltx_result_fetch per utterance)
         self._N = N
 
     def stream_step(self, emissions, T, offsets=None):
@@ -470,11 +474,48 @@ class BatchDecoder:
                 "tokens": view(pt, C.c_int32, max(total, 1)),
                 "words": view(pw, C.c_int32, max(total, 1)) if pw.value else None}
 
+    def results_arrays_compact(self):
+        """The same through fltx_result_fetch_batch_compact: only the rows of the hypotheses that exist cross
+        PCIe, tokens as uint8 (0xFF = -1), words as int32 rows; `offsets` [B + 1] index both flat arrays.
+        tokens_of(r, b, i) / words_of(r, b, i) below widen one hypothesis' rows on demand."""
+        pn, pl, ps, pt, pw, po = (C.c_void_p() for _ in range(6))
+        self.L.check(self.L.lib.fltx_result_fetch_batch_compact(self.h, C.byref(pn), C.byref(pl), C.byref(ps),
+                                                                C.byref(pt), C.byref(pw), C.byref(po)))
+        B = self.B
+
+        def view(ptr, ctype, n):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
+        off = view(po, C.c_int64, B + 1)
+        total = int(off[B])
+        K = int(self.options.beam_size)
+        return {"n_hyp": view(pn, C.c_int32, B), "length": view(pl, C.c_int32, B), "offsets": off,
+                "scores": view(ps, C.c_double, B * K * 3).reshape(B, K, 3),
+                "tokens_u8": view(pt, C.c_uint8, max(total, 1)),
+                "words": view(pw, C.c_int32, max(total, 1)) if pw.value else None}
+
+    @staticmethod
+    def tokens_of(r, b, i):
+        L, o = int(r["length"][b]), int(r["offsets"][b])
+        t = r["tokens_u8"][o + i * L:o + (i + 1) * L].astype(np.int32)
+        t[t == 255] = -1
+        return t
+
+    @staticmethod
+    def words_of(r, b, i):
+        L, o = int(r["length"][b]), int(r["offsets"][b])
+        return r["words"][o + i * L:o + (i + 1) * L] if r["words"] is not None else np.full(L, -1, dtype=np.int32)
+
     def results_batch(self, max_hyp=None):
-        """[[Hyp]] for every utterance: Python objects over the arrays of results_arrays()
-        (token rows are views, not copies)."""
-        r = self.results_arrays()
-        nh, ln, off, sc, tok, wrd = r["n_hyp"], r["length"], r["offsets"], r["scores"], r["tokens"], r["words"]
+        """[[Hyp]] for every utterance: Python objects over the arrays of results_arrays_compact()
+        (or results_arrays() for token sets that do not fit a byte)."""
+        if self.N is not None and self.N < 255:
+            r = self.results_arrays_compact()
+            nh, ln, off, sc, wrd = r["n_hyp"], r["length"], r["offsets"], r["scores"], r["words"]
+            tok = r["tokens_u8"].astype(np.int32)  # one widening pass for the batch
+            tok[tok == 255] = -1
+        else:
+            r = self.results_arrays()
+            nh, ln, off, sc, tok, wrd = r["n_hyp"], r["length"], r["offsets"], r["scores"], r["tokens"], r["words"]
         out = []
         for b in range(self.B):
             n = int(nh[b]) if max_hyp is None else min(int(nh[b]), max_hyp)

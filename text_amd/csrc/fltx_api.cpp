@@ -37,6 +37,33 @@ __global__ void __launch_bounds__(512) fltx_backtrace_kernel(BacktraceParams P) 
   extern __shared__ __attribute__((aligned(16))) char fltx_bt_smem[];
   backtraceUtterance(P, fltx_bt_smem);
 }
+/* fltx_result_fetch_batch_compact: the rows that exist, tokens narrowed to bytes, packed back to back */
+struct PackParams {
+  const int32_t* tokens;
+  const int32_t* words; /* null: lexicon-free */
+  const int64_t* srcOff;
+  const int64_t* dstOff;
+  const int32_t* count; /* n_hyp[b] * length[b] */
+  uint8_t* tok8;
+  int32_t* wordsOut;
+};
+__global__ void __launch_bounds__(256) fltx_pack_results_kernel(PackParams Q) {
+  const int b = (int)blockIdx.x;
+  const int n = Q.count[b];
+  const int32_t* src = Q.tokens + Q.srcOff[b];
+  uint8_t* dst = Q.tok8 + Q.dstOff[b];
+  for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+    const int32_t v = src[i];
+    dst[i] = v < 0 ? (uint8_t)0xFF : (uint8_t)v;
+  }
+  if (Q.words) {
+    const int32_t* ws = Q.words + Q.srcOff[b];
+    int32_t* wd = Q.wordsOut + Q.dstOff[b];
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+      wd[i] = ws[i];
+    }
+  }
+}
 __global__ void fltx_streamop_kernel(StreamOpParams Q) {
   __shared__ int32_t sh[4];
   streamOpUtterance(Q, sh);
@@ -346,6 +373,10 @@ struct fltx_decoder {
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   HBuf hTokens, hWords, hScores; /* fltx_result_fetch_batch */
+  HBuf hTok8, hWordsC, hPackMeta;  /* fltx_result_fetch_batch_compact */
+  DBuf dTok8, dWordsC, dPackMeta;
+  std::vector<int64_t> packOff;
+  bool compactFetched = false, scoresFetched = false;
   DBuf uttMap;                   /* utterances of a partial re-run */
   int nLaunch = 0;               /* workgroups of the next decode launch (0: all B) */
   std::vector<int32_t> hLen, hNHyp;
@@ -2203,6 +2234,8 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   d->resultsSynced = false;
   d->backtraced = false;
   d->hostFetched = false;
+  d->compactFetched = false;
+  d->scoresFetched = false;
   /* The optimistic fast paths (LDS-sized candidate lists of the lexicon
    * decoder, the score cut, the one-pass histogram select of the lean / lane
    * steps) flag the rare utterance they cannot serve.  Only those utterances
@@ -2361,6 +2394,8 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   d->resultsSynced = false;
   d->backtraced = false;
   d->hostFetched = false;
+  d->compactFetched = false;
+  d->scoresFetched = false;
   d->frames.assign(B, 0);
   DecodeParams P;
   fillParams(d, P);
@@ -2412,6 +2447,8 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
   d->resultsSynced = false;
   d->backtraced = false;
   d->hostFetched = false;
+  d->compactFetched = false;
+  d->scoresFetched = false;
   return FLTX_OK;
 }
 
@@ -2442,6 +2479,8 @@ int fltx_stream_end(fltx_decoder* d) {
   d->resultsSynced = false;
   d->backtraced = false;
   d->hostFetched = false;
+  d->compactFetched = false;
+  d->scoresFetched = false;
   return FLTX_OK;
 }
 
@@ -2492,6 +2531,8 @@ int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
   d->resultsSynced = false;
   d->backtraced = false;
   d->hostFetched = false;
+  d->compactFetched = false;
+  d->scoresFetched = false;
   if ((rc = syncResults(d))) {
     return rc;
   }
@@ -2682,6 +2723,116 @@ int fltx_result_fetch_batch(fltx_decoder* d, const int32_t** nHyp, const int32_t
   }
   if (offsets) {
     *offsets = d->histOff.data();
+  }
+  return FLTX_OK;
+}
+
+int fltx_result_fetch_batch_compact(fltx_decoder* d, const int32_t** nHyp, const int32_t** length,
+                                    const double** scores, const uint8_t** tokensU8, const int32_t** words,
+                                    const int64_t** offsets) {
+  DeviceScope devScope(d ? d->ctx : nullptr);
+  if (devScope.failed) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
+  if (!d) {
+    return fail(FLTX_ERR_INVALID, "fltx_result_fetch_batch_compact: null decoder");
+  }
+  if (!d->haveResults || !d->ended) {
+    return fail(FLTX_ERR_STATE, "fltx_result_fetch_batch_compact: no finished decode");
+  }
+  if (d->N >= 255) {
+    return fail(FLTX_ERR_UNSUPPORTED, "fltx_result_fetch_batch_compact: %d tokens do not fit a byte", d->N);
+  }
+  int rc = syncResults(d);
+  if (rc) {
+    return rc;
+  }
+  const int B = d->B, K = d->opt.beam_size;
+  for (int b = 0; b < B; ++b) {
+    if ((rc = checkStatus(d, b))) {
+      return rc;
+    }
+  }
+  if (!d->compactFetched) {
+    if (!d->backtraced && (rc = launchBacktrace(d))) {
+      return rc;
+    }
+    Stream st = d->ctx->stream;
+    const bool lex = d->kind == FLTX_DECODER_LEXICON;
+    d->hLen.resize(B);
+    d->hNHyp.resize(B);
+    d->packOff.resize((size_t)B + 1);
+    /* meta (one upload): dstOff[B] int64, count[B] int32 */
+    if (d->hPackMeta.ensure(12 * (size_t)B) || d->dPackMeta.ensure(12 * (size_t)B, st, false)) {
+      return fail(FLTX_ERR_OOM, "compact results: allocation failed");
+    }
+    int64_t* hOff = (int64_t*)d->hPackMeta.p;
+    int32_t* hCnt = (int32_t*)(hOff + B);
+    int64_t total = 0;
+    for (int b = 0; b < B; ++b) {
+      d->hLen[b] = d->hFrame[b] + 1;
+      d->hNHyp[b] = (lex && d->hFrame[b] < 1) ? 0 : d->hN[b]; /* LexiconDecoder.cpp:276-280 */
+      d->packOff[b] = total;
+      hOff[b] = total;
+      hCnt[b] = d->hNHyp[b] * d->hLen[b];
+      total += hCnt[b];
+    }
+    d->packOff[B] = total;
+    const size_t tot = (size_t)std::max<int64_t>(total, 1);
+    if (d->dTok8.ensure(tot, st, false) || d->hTok8.ensure(tot) || d->hScores.ensure(8 * 3 * (size_t)B * K) ||
+        (lex && (d->dWordsC.ensure(4 * tot, st, false) || d->hWordsC.ensure(4 * tot)))) {
+      return fail(FLTX_ERR_OOM, "compact results: allocation failed");
+    }
+    if (devCopyH2D(d->dPackMeta.p, d->hPackMeta.p, 12 * (size_t)B, st)) {
+      return fail(FLTX_ERR_HIP, "compact results: upload failed");
+    }
+#ifdef FLTX_EMU
+    for (int b = 0; b < B; ++b) {
+      const int32_t* src = d->tokens.as<int32_t>() + d->histOff[b];
+      for (int i = 0; i < hCnt[b]; ++i) {
+        d->dTok8.as<uint8_t>()[hOff[b] + i] = src[i] < 0 ? (uint8_t)0xFF : (uint8_t)src[i];
+        if (lex) {
+          d->dWordsC.as<int32_t>()[hOff[b] + i] = d->words.as<int32_t>()[d->histOff[b] + i];
+        }
+      }
+    }
+#else
+    PackParams Q;
+    Q.tokens = d->tokens.as<int32_t>();
+    Q.words = lex ? d->words.as<int32_t>() : nullptr;
+    Q.srcOff = d->histOffD.as<int64_t>();
+    Q.dstOff = d->dPackMeta.as<int64_t>();
+    Q.count = (const int32_t*)(d->dPackMeta.as<int64_t>() + B);
+    Q.tok8 = d->dTok8.as<uint8_t>();
+    Q.wordsOut = lex ? d->dWordsC.as<int32_t>() : nullptr;
+    hipLaunchKernelGGL(fltx_pack_results_kernel, dim3(B), dim3(256), 0, st, Q);
+    HIPCHK(hipGetLastError());
+#endif
+    if ((!d->scoresFetched && devCopyD2H(d->hScores.p, d->outScores.p, 8 * 3 * (size_t)B * K, st)) ||
+        (total > 0 && devCopyD2H(d->hTok8.p, d->dTok8.p, (size_t)total, st)) ||
+        (lex && total > 0 && devCopyD2H(d->hWordsC.p, d->dWordsC.p, 4 * (size_t)total, st))) {
+      return fail(FLTX_ERR_HIP, "result copy failed: %s", devErr());
+    }
+    d->scoresFetched = true;
+    d->compactFetched = true;
+  }
+  if (nHyp) {
+    *nHyp = d->hNHyp.data();
+  }
+  if (length) {
+    *length = d->hLen.data();
+  }
+  if (scores) {
+    *scores = (const double*)d->hScores.p;
+  }
+  if (tokensU8) {
+    *tokensU8 = (const uint8_t*)d->hTok8.p;
+  }
+  if (words) {
+    *words = d->kind == FLTX_DECODER_LEXICON ? (const int32_t*)d->hWordsC.p : nullptr;
+  }
+  if (offsets) {
+    *offsets = d->packOff.data();
   }
   return FLTX_OK;
 }
