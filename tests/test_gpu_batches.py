@@ -239,3 +239,28 @@ def test_edge_configurations_of_the_lexicon_lane_engine_with_lm_terms(gpu_sessio
             bad.append(({k: c[k] for k in ("K", "Kt", "thr", "lm", "lm_weight", "sil_score", "word_score", "T", "dist",
                                            "label_scores")}, why))
     assert ran > 250 and served == ran and not bad, (ran, served, bad[:3])
+
+
+def test_logadd_on_the_lane_state_engine(gpu_session, oracle_lib):
+    """logAdd merges on fltx_slane.h (engine 4) against the oracle @1e-5 (device libm): beams 1 .. 64,
+    thresholds 2 .. inf, token beams, silScore, CTC and ASG, `ctc` and `uniform` rows."""
+    import itertools
+    bad, ran = [], 0
+    grid = itertools.product([1, 3, 10, 50, 64], [2.0, 25.0, float("inf")], [None, 5], [12, 29], [1, 30, 120],
+                             ["ctc", "uniform"], [0.0, -0.6], ["ctc", "asg"])
+    for i, (K, thr, Kt, N, T, dist, sil, crit) in enumerate(grid):
+        if i % 5:
+            continue
+        c = cases.case("la%d" % i, dist=dist, u=500 + i, T=T, N=N, K=K, Kt=Kt, thr=thr, sil_score=sil, log_add=True,
+                       crit=crit, trans_seed=(30 + i) if crit == "asg" else None)
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if any(abs(a.score - b.score) < 1e-4 for a, b in zip(want, want[1:])):
+            continue  # (near ties: a different libm may order them differently)
+        got = gpu_session.run(c, inp)
+        assert gpu_session.last_engine == 4
+        ok, why = helpers.hyps_equal(want, got, 1e-5)
+        ran += 1
+        if not ok:
+            bad.append(({k: c[k] for k in ("K", "thr", "Kt", "N", "T", "dist", "sil_score", "crit")}, why))
+    assert ran > 150 and not bad, (ran, bad[:3])

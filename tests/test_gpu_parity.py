@@ -235,7 +235,8 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     ("lf_asg_t40_n29_kt7", 4, {}), ("lf_ctc_sil", 4, {}), ("C2_ctc_u0", 4, {}), ("C2_uniform_u0", 4, {}),
     ("lf_ctc_t60_k10", 3, {"slane": 0}), ("lf_uni_n64_k64", 3, {"slane": 0}), ("lf_ctc_n29_k64", 3, {"slane": 0}),
     ("lf_ctc_t60_k10_kt5", 3, {"slane": 0}), ("C2_ctc_u0", 3, {"slane": 0}),
-    ("lf_ctc_n29_k65", 2, {}), ("lf_ctc_t60_k10_logadd", 3, {}), ("lf_ctc_t300_k100", 2, {}),
+    ("lf_ctc_n29_k65", 2, {}), ("lf_ctc_t60_k10_logadd", 4, {}), ("lf_ctc_t60_k10_logadd", 3, {"slane": 0}),
+    ("C2_ctc_u0_logadd", 4, {}), ("lf_ctc_t300_k100", 2, {}),
     ("lx_spell_t40_k8", 5, {}), ("lx_spell_t60_k12_full", 5, {}), ("lx_uni_t40_k10", 5, {}), ("lx_t0", 5, {}),
     ("C3_spell_u0", 5, {}), ("C3_spell_u255", 5, {}), ("C3_uniform_u0", 5, {}), ("C3_spell_u0", 5, {"slane_threads": 640}),
     ("lx_spell_t60_k12_full", 5, {"slane_threads": 576}), ("lx_spell_t40_k8", 5, {"slane_threads": 640}),
@@ -249,8 +250,8 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
 def test_engine_selection(gpu_session, golden, name, engine, sets):
     """Which engine serves which configuration: the lane = LM state decode (4,
     fltx_slane.h) for offline lexicon-free + ZeroLM max-merge with beam <= 64 and
-    <= 64 tokens (also with a token beam, ASG, silScore); the lane-per-slot step
-    (3) for logAdd and when the former is switched off; the lean step (2) for
+    <= 64 tokens (also with a token beam, ASG, silScore, logAdd); the lane-per-slot step
+    (3) when the former is switched off; the lean step (2) for
     bigger beams; the lane = (LM state, trie node) decode (5, fltx_xlane.h) for
     the offline lexicon decoder + ZeroLM over a lexicon without scores (CTC,
     max-merge, no <unk>, beam <= 64); the same with the LM terms (6, fltx_ylane.h)

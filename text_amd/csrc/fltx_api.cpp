@@ -1348,7 +1348,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   /* lane = LM state decode (fltx_slane.h): offline lexicon-free + ZeroLM max-merge, beam and
    * tokens within one wave's lanes; the history rows are its LM-state memo (23-bit ids) */
   d->slane = 0;
-  if (d->lane && !d->noSlane && d->offlineCall && !d->keepScores && !d->opt.log_add && !forceWorstCaseCap &&
+  if (d->lane && !d->noSlane && d->offlineCall && !d->keepScores && !forceWorstCaseCap &&
       d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
       (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
       (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
@@ -1830,17 +1830,17 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     } else if (xl == 2) {
       xlaneUtterance<2, false>(*pp, smem);
     } else if (sl == 4) {
-      slaneUtterance<4, false>(*pp, smem);
+      pp->logAdd ? slaneUtterance<4, true, false>(*pp, smem) : slaneUtterance<4, false, false>(*pp, smem);
     } else if (sl == 5) {
-      slaneUtterance<5, false>(*pp, smem);
+      pp->logAdd ? slaneUtterance<5, true, false>(*pp, smem) : slaneUtterance<5, false, false>(*pp, smem);
     } else if (sl == 6) {
-      slaneUtterance<6, false>(*pp, smem);
+      pp->logAdd ? slaneUtterance<6, true, false>(*pp, smem) : slaneUtterance<6, false, false>(*pp, smem);
     } else if (sl == 7) {
-      slaneUtterance<7, false>(*pp, smem);
+      pp->logAdd ? slaneUtterance<7, true, false>(*pp, smem) : slaneUtterance<7, false, false>(*pp, smem);
     } else if (sl == 10) {
-      slaneUtterance<10, false>(*pp, smem);
+      pp->logAdd ? slaneUtterance<10, true, false>(*pp, smem) : slaneUtterance<10, false, false>(*pp, smem);
     } else if (sl == 12) {
-      slaneUtterance<12, false>(*pp, smem);
+      pp->logAdd ? slaneUtterance<12, true, false>(*pp, smem) : slaneUtterance<12, false, false>(*pp, smem);
 
     } else if (gt == 4) {
       if (pp->logAdd) {
@@ -1909,11 +1909,14 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   } while (0)
 #define FLTX_LAUNCH_SLANE(WW, GG)                                                                \
   do {                                                                                           \
-    if (d->profile) {                                                                            \
-      hipLaunchKernelGGL((fltx_decode_kernel_slane<WW, GG, true>), dim3(nGrid), dim3(WW),        \
+    if (d->opt.log_add) {                                                                        \
+      hipLaunchKernelGGL((fltx_decode_kernel_slane<WW, GG, true, false>), dim3(nGrid), dim3(WW), \
+                         d->wsBytes, d->ctx->stream, P);                                         \
+    } else if (d->profile) {                                                                     \
+      hipLaunchKernelGGL((fltx_decode_kernel_slane<WW, GG, false, true>), dim3(nGrid), dim3(WW), \
                          d->wsBytes, d->ctx->stream, P);                                         \
     } else {                                                                                     \
-      hipLaunchKernelGGL((fltx_decode_kernel_slane<WW, GG, false>), dim3(nGrid), dim3(WW),       \
+      hipLaunchKernelGGL((fltx_decode_kernel_slane<WW, GG, false, false>), dim3(nGrid), dim3(WW),\
                          d->wsBytes, d->ctx->stream, P);                                         \
     }                                                                                            \
   } while (0)

@@ -29,17 +29,18 @@
 #define FLTX_G8(W) FLTX_INST(fltx_decode_kernel_gws<W>)
 #define FLTX_G9(W) FLTX_INST(fltx_decode_kernel_gwslean<W>)
 /* lane = LM state decode (fltx_slane.h): (threads, list positions per wave) pairs; W is ignored */
-#define FLTX_SLANE_SET(PROF)                               \
-  FLTX_INST(fltx_decode_kernel_slane<320, 10, PROF>)       \
-  FLTX_INST(fltx_decode_kernel_slane<384, 7, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_slane<448, 6, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_slane<512, 5, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_slane<576, 4, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_slane<640, 4, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_slane<512, 12, PROF>)       \
-  FLTX_INST(fltx_decode_kernel_slane<576, 10, PROF>)
-#define FLTX_G10(W) FLTX_SLANE_SET(false)
-#define FLTX_G11(W) FLTX_SLANE_SET(true)
+#define FLTX_SLANE_SET(LA, PROF)                               \
+  FLTX_INST(fltx_decode_kernel_slane<320, 10, LA, PROF>)       \
+  FLTX_INST(fltx_decode_kernel_slane<384, 7, LA, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<448, 6, LA, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<512, 5, LA, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<576, 4, LA, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<640, 4, LA, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_slane<512, 12, LA, PROF>)       \
+  FLTX_INST(fltx_decode_kernel_slane<576, 10, LA, PROF>)
+#define FLTX_G10(W) FLTX_SLANE_SET(false, false)
+#define FLTX_G11(W) FLTX_SLANE_SET(false, true)
+#define FLTX_G15(W) FLTX_SLANE_SET(true, false) /* logAdd */
 /* lane = (LM state, trie node) decode (fltx_xlane.h): three waves do not evaluate listed tokens */
 #define FLTX_XLANE_SET(PROF)                               \
   FLTX_INST(fltx_decode_kernel_xlane<512, 2, PROF>)        \
@@ -79,6 +80,7 @@ FLTX_G11(0)
 FLTX_G12(0)
 FLTX_G13(0)
 FLTX_G14(0)
+FLTX_G15(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -95,6 +97,7 @@ FLTX_G14(0)
 #undef FLTX_G12
 #undef FLTX_G13
 #undef FLTX_G14
+#undef FLTX_G15
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET
 #undef FLTX_SLANE_SET

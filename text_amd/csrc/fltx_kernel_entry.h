@@ -46,10 +46,10 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
   decodeUtterance<1, GT, LOGADD, FULLTOK>(P, fltx_smem);
 }
 /* lane = LM state decode of a whole utterance (fltx_slane.h): the headline configuration */
-template <int W, int GT, bool PROF>
+template <int W, int GT, bool LA, bool PROF>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_slane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  slaneUtterance<GT, PROF>(P, fltx_smem);
+  slaneUtterance<GT, LA, PROF>(P, fltx_smem);
 }
 /* lane = (LM state, trie node) decode of a whole utterance (fltx_xlane.h): lexicon + ZeroLM */
 template <int W, int GT, bool PROF>

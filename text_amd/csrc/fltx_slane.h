@@ -81,7 +81,8 @@ struct SlRow { /* what a frame needs to know about its emission row, 48 B */
   uint32_t dead;  /* no candidate at all / not finite: the utterance goes to the general engines */
   uint32_t nev;   /* re-entry events recorded by the build of the previous frame */
   unsigned long long allow; /* token beam (LexiconFreeDecoder.cpp:42-51): bit n = token n is evaluated */
-  unsigned long long pad;
+  uint32_t ekey;  /* order key of the largest allowed emission other than sil's, 0 = none (logAdd: best = beam's best + this) */
+  float esil;     /* sil's emission */
 };
 
 template <int V>
@@ -106,6 +107,7 @@ struct SlaneLds {
   uint32_t bOrd[kSlBCap];
   uint32_t evLane[64], evSpar[64], evTok[64];
   unsigned long long scanMask;
+  unsigned long long mmaxKey[2]; /* logAdd: order key of the best hypothesis of the beam a frame starts from */
   uint32_t scanMin, pad0;
   float raw[3][64]; /* emission rows on their way in: row r lands in raw[r % 3] two frames before it is staged */
 };
@@ -117,8 +119,14 @@ FLTX_DEV double slNegInf() { return -__builtin_huge_val(); }
  * float bit pattern of best - c (monotone in the score, and any monotone binning
  * gives exact selection); everything nearer than the window shares bin 0,
  * everything farther bin 511 */
+/* above: with logAdd a merged candidate can score above the frame's best raw candidate; it belongs to the
+ * nearest bin (the float bits of a negative difference would put it beyond the window) */
+template <bool ABOVE = false>
 FLTX_DEV int slBin(double best, double c, int shift, int base) {
-  const float d = (float)(best - c);
+  float d = (float)(best - c);
+  if (ABOVE) {
+    d = d > 0.0f ? d : 0.0f;
+  }
   int q = (int)(__float_as_uint(d) >> shift) - base;
   q = q < 0 ? 0 : q;
   return q > kSlNB - 1 ? kSlNB - 1 : q;
@@ -182,7 +190,8 @@ FLTX_DEV SlScan slScan(const uint32_t* hist, int K, bool noFar) {
 struct SlRowRegs {
   unsigned long long allow, listMask;
   double best;
-  float v;
+  float v, esil;
+  uint32_t ekey;
   int nList;
   bool dead;
 };
@@ -226,6 +235,8 @@ FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mm
   }
   r.best = best;
   r.dead = !any || !(best - best == 0.0);
+  r.ekey = ek;
+  r.esil = eSil;
   return r;
 }
 /* padPast: also (re)write the positions past the end of the list (NaN emission = no candidate);
@@ -260,6 +271,8 @@ FLTX_DEV void slRowStore(const DecodeParams& P, LDS& S, int q, const SlRowRegs& 
     S.row[q].silPos = ((r.listMask >> P.sil) & 1ull) ? popc64(r.listMask & ((1ull << P.sil) - 1ull)) : -4096;
     S.row[q].dead = r.dead ? 1u : 0u;
     S.row[q].allow = r.allow;
+    S.row[q].ekey = r.ekey;
+    S.row[q].esil = r.esil;
   }
 }
 
@@ -341,8 +354,16 @@ FLTX_DEV __attribute__((noinline)) void slReenter(SlaneLds& S, const int2* histP
     }                                                         \
   } while (0)
 
-/* GT = list positions per normal wave (nList <= GT * (waves - 2)) */
-template <int GT, bool PROF>
+/* logAdd merge of two members (Utils.h:186-193): hi is the larger */
+FLTX_DEV double slLogAdd(double hi, double lo) { return hi + log1p(exp(lo - hi)); }
+
+/* GT = list positions per normal wave (nList <= GT * (waves - 2)); LA: the members of a merge group are
+ * log-added (DecoderOptions::logAdd) -- the groups have the same fixed shape, the members that pass the
+ * threshold are added in descending order as Utils.h:167-198 does, the back-pointer stays the best member's;
+ * what changes is the frame's best candidate: a merged hypothesis can score above every candidate of its
+ * frame, so the best hypothesis is not the last frame's best candidate any more -- the build publishes the
+ * best surviving score and every wave prices the row with it at the head of the frame. */
+template <int GT, bool LA, bool PROF>
 FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   SlaneLds& S = *(SlaneLds*)smem;
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
@@ -392,6 +413,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     S.row[1].nev = 0u;
     S.row[0].dead = 0u;
     S.row[1].dead = 0u;
+    S.mmaxKey[0] = f64Key(0.0); /* decodeBegin: the root hypothesis, score 0 */
+    S.mmaxKey[1] = 0ull;
     P.histPT[hbase] = make_int2((int)kSlNoHyp, P.sil);
   }
   if (tid > 0 && tid < K) { /* unused slots of a row never look like the record of a new state (slReenter) */
@@ -431,9 +454,23 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const int64_t hrow = hbase + (int64_t)frameOut * K;
     /* ---- phase 1: own state, candidates, histogram ------------------------------------- */
     /* every LDS read of the phase is issued here, before anything waits for one */
-    const double best = S.row[p].best, thr = S.row[p].thr;
+    double best = S.row[p].best, thr = S.row[p].thr;
     const int nList = S.row[p].nList, silPos = S.row[p].silPos;
-    const uint32_t rowDead = S.row[p].dead, nev = S.row[p].nev;
+    uint32_t rowDead = S.row[p].dead;
+    const uint32_t nev = S.row[p].nev;
+    if (LA) { /* best candidate = best hypothesis of the beam + best token (sil priced apart: silScore) */
+      const double mmax = f64FromKey(S.mmaxKey[p]);
+      const uint32_t ek = S.row[p].ekey;
+      const double sS = (mmax + (double)S.row[p].esil) + silScore;
+      bool any = ek != 0u;
+      best = any ? mmax + (double)f32FromKey(ek) : 0.0;
+      if (((S.row[p].allow >> sil) & 1ull) != 0ull && sS == sS && (!any || sS > best)) {
+        best = sS;
+        any = true;
+      }
+      thr = best - P.beamThreshold;
+      rowDead = (!any || !(best - best == 0.0)) ? 1u : 0u;
+    }
     SlRec me = {};
     unsigned long long cm = 0ull, mk = 0ull;
     if (!isSvc) { /* (the staging wave has the longest way to the first barrier: it skips what it does not use) */
@@ -506,6 +543,9 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         bestChain = nextRow.best;
       }
       ldsRowLoad(S.raw[t % 3], em + (size_t)(t + 3) * N + lane, t + 3 < T && lane < N); /* (row t's slot: read last frame) */
+      if (LA && lane == 0) {
+        S.mmaxKey[q] = 0ull; /* (this frame's build raises it) */
+      }
       (void)rowReg;
     } else if (!isSelf) {
       /* tokens this lane does not extend with here: its own last token (the repeat and the
@@ -523,8 +563,18 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         }
         const uint32_t hit = (skLo & (uint32_t)tb[j]) | (skHi & (uint32_t)(tb[j] >> 32));
         const bool ok = hit == 0u && c >= thr;
+        if (LA) { /* the state's other hypothesis reaches the same child state: fl(a + e) is monotone, so it
+                     is the smaller member */
+          double c2 = (whichB ? nb : bb) + ev[j];
+          if (j == silJ) {
+            c2 = c2 + silScore;
+          }
+          if (ok && (whichB ? hypNB : hypB) != kSlNoHyp && c2 >= thr) {
+            c = slLogAdd(c, c2);
+          }
+        }
         cs[j] = c;
-        cbin[j] = ok ? slBin(best, c, winShift, winBase) : kSlInvalid;
+        cbin[j] = ok ? slBin<LA>(best, c, winShift, winBase) : kSlInvalid;
       }
     } else {
       const bool lastOk = live && ((allow >> last) & 1ull) != 0ull && !(ctc && last == blank);
@@ -535,6 +585,15 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         cB = cB + silScore;
       }
       const bool okB = ctc && live && ((allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB >= thr;
+      if (LA) {
+        double cB2 = (whichB ? nb : bb) + eBlank;
+        if (blank == sil) {
+          cB2 = cB2 + silScore;
+        }
+        if (okB && (whichB ? hypNB : hypB) != kSlNoHyp && cB2 >= thr) {
+          cB = slLogAdd(cB, cB2);
+        }
+      }
       /* (S, last, false): the repeat (:98-110) and the parent state's extension by last (:69-85) */
       const int lastP = (int)(par.info & 0xFFu);
       const uint32_t h1 = (par.info >> 16) & 0xFFu, h2 = par.info >> 24;
@@ -567,14 +626,33 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         cR = r2;
         parR = h2;
       }
-      const bool okR = lastOk && (has0 || has1 || has2) && cR >= thr;
+      bool okR = lastOk && (has0 || has1 || has2) && cR >= thr;
+      if (LA) {
+        /* the members that pass the threshold, best first (the best is cR, its slot parR) */
+        const bool v0 = has0 && r0 >= thr, v1 = has1 && r1 >= thr, v2 = has2 && r2 >= thr;
+        okR = lastOk && (v0 || v1 || v2);
+        double a = v0 ? r0 : NEG, bq = v1 ? r1 : NEG, cq = v2 ? r2 : NEG;
+        /* three-element sort, descending */
+        double t0 = a > bq ? a : bq, t1 = a > bq ? bq : a;
+        const double hi = t0 > cq ? t0 : cq;
+        const double mid = t0 > cq ? (t1 > cq ? t1 : cq) : t0;
+        const double lo = t0 > cq ? (t1 > cq ? cq : t1) : t1;
+        double acc = hi;
+        if (mid > NEG) {
+          acc = slLogAdd(acc, mid);
+        }
+        if (lo > NEG) {
+          acc = slLogAdd(acc, lo);
+        }
+        cR = okR ? acc : cR;
+      }
       const bool okL = ctc && lastOk && hasB && ((cm >> last) & 1ull) == 0ull && cL >= thr;
       cs[0] = cB;
       cs[1] = cR;
       cs[2] = cL;
-      cbin[0] = okB ? slBin(best, cB, winShift, winBase) : kSlInvalid;
-      cbin[1] = okR ? slBin(best, cR, winShift, winBase) : kSlInvalid;
-      cbin[2] = okL ? slBin(best, cL, winShift, winBase) : kSlInvalid;
+      cbin[0] = okB ? slBin<LA>(best, cB, winShift, winBase) : kSlInvalid;
+      cbin[1] = okR ? slBin<LA>(best, cR, winShift, winBase) : kSlInvalid;
+      cbin[2] = okL ? slBin<LA>(best, cL, winShift, winBase) : kSlInvalid;
 #pragma unroll
       for (int j = 3; j < GT; ++j) {
         cs[j] = NEG;
@@ -706,7 +784,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         if (cbin[j] != kSlInvalid) {
-          cbin[j] = slBin(best, cs[j], shift, base);
+          cbin[j] = slBin<LA>(best, cs[j], shift, base);
           atomAdd32(&S.hist[p][cbin[j]], 1u);
         }
       }
@@ -765,6 +843,20 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       }
       if (lane == selfWave + 1 && nNewWave > 0) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
+      }
+    }
+    if (LA && !isSvc) { /* the best hypothesis of the next beam */
+      unsigned long long k = 0ull;
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        const unsigned long long kj = ((selMask[j] >> lane) & 1ull) ? f64Key(cs[j]) : 0ull;
+        k = kj > k ? kj : k;
+      }
+      if (waveBallot(k != 0ull) != 0ull) {
+        k = waveMax64(k);
+        if (lane == 0) {
+          atomMax64(&S.mmaxKey[q], k);
+        }
       }
     }
     FLTX_SLPROF(3);
@@ -882,10 +974,20 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const SlRec me = S.rec[pe][live ? lane : 0];
     const double nb = live ? me.nb : NEG, bb = live ? me.b : NEG;
     const bool whichB = bb > nb;
-    const double m = whichB ? bb : nb;
+    double m = whichB ? bb : nb;
     const uint32_t hp = whichB ? (me.info >> 24) : ((me.info >> 16) & 0xFFu);
+    if (LA) { /* the best candidate of decodeEnd is the best hypothesis of the final beam */
+      endBest = f64FromKey(S.mmaxKey[pe]);
+    }
     const double thr = endBest - P.beamThreshold;
     const bool ok = live && m >= thr;
+    if (LA && ok) { /* the state's two hypotheses finish into one (LexiconFreeDecoder.cpp:127-158) */
+      const double lo = whichB ? nb : bb;
+      const uint32_t hl = whichB ? ((me.info >> 16) & 0xFFu) : (me.info >> 24);
+      if (hl != kSlNoHyp && lo >= thr) {
+        m = slLogAdd(m, lo);
+      }
+    }
     const unsigned long long key = ok ? f64Key(m) : 0ull;
     int rank = 0;
     for (int i = 0; i < nState; ++i) {
