@@ -151,37 +151,7 @@ FLTX_DEV unsigned long long xlOrphGet(const XlOrphTab& tab, unsigned long long k
   }
 }
 
-/* The token beam of a row of N <= 32 emissions (LexiconDecoder.cpp:42-51: the beamSizeToken largest,
- * ties to the lower index), all pairs compared with 16 in-row rotations: the four rows of 16
- * lanes take (tokens 0-15 among themselves), (16-31 among themselves), (0-15 against 16-31) and
- * (16-31 against 0-15).  Keys are made unique by the index, so one 64-bit compare orders a pair. */
-struct XlRank {
-  unsigned long long mine, src;
-  int part;
-};
-FLTX_DEV XlRank xlRankBegin(float v, int N) {
-  const int lane = laneId();
-  const int tok = lane & 31;
-  const float vt = __uint_as_float(waveGather32(__float_as_uint(v + 0.0f), tok)); /* (-0 -> +0: equal as floats) */
-  XlRank r;
-  r.mine = tok < N ? (((unsigned long long)f32Key(vt) << 6) | (unsigned long long)(63 - tok)) : 0ull;
-  const unsigned long long other = waveShfl64(r.mine, lane ^ 16);
-  r.src = lane < 32 ? r.mine : other;
-  r.part = 0;
-  return r;
-}
-template <int R0, int R1>
-FLTX_DEV void xlRankRange(XlRank& r) {
-  if constexpr (R0 < R1) {
-    r.part += waveRowRor64<R0>(r.src) > r.mine ? 1 : 0;
-    xlRankRange<R0 + 1, R1>(r);
-  }
-}
-FLTX_DEV unsigned long long xlRankEnd(const XlRank& r, int N, int Kt) {
-  const int lane = laneId();
-  const int tot = r.part + (int)waveGather32((uint32_t)r.part, lane ^ 32);
-  return waveBallot(lane < N && lane < 32 && tot < Kt);
-}
+/* (XlRank -- the token-beam ranking by row rotations -- lives in fltx_slane.h, which uses it too) */
 
 #define FLTX_XLPROF(i)                                        \
   do {                                                        \
