@@ -591,12 +591,15 @@ def streaming(job, B, T, N, chunk=50):
         job.ctx.synchronize()
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
+    redone = d.get("stream_redone")
     d.close()
     lat = np.sort(np.array(lat[len(lat) // 2:]))
     return {"value": B * nchunk * chunk / best, "unit": "frames/s", "streams": B, "chunk_frames": chunk,
             "chunk_latency_ms_median": float(np.median(lat) * 1e3),
             "chunk_latency_ms_p95": float(lat[int(0.95 * (len(lat) - 1))] * 1e3),
-            "note": "stream_step(50 frames, host emissions) + prune(0) + synchronize per chunk"}
+            "stream_chunks_decoded_again": redone,
+            "note": "stream_step(50 frames, host emissions) + prune(0) + synchronize per chunk; lexicon streams start "
+                    "every chunk on the LDS-sized geometry and decode it again from the saved beam if a list overflows"}
 
 
 if __name__ == "__main__":

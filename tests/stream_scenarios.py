@@ -93,6 +93,7 @@ def trace_device(session, c, inp, chunks, look_backs, threads=None, tunables=())
     d.stream_end()
     ev.append({"final": helpers.encode_hyps(d.results(0), True)})
     engine = d.get("engine")
+    session.last_stream_redone = d.get("stream_redone")
     d.close()
     return ev, engine
 

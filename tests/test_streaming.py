@@ -67,3 +67,28 @@ def test_streaming_emulated_over_hbm_workspace(emu_session, stream_golden, name)
 @pytest.mark.parametrize("name", ["lf_ctc_t60_k10", "lx_spell_t60_k12_full", "lx_scores_t50", "ng_word_t60_k16_4g"])
 def test_streaming_on_device_over_hbm_workspace(gpu_session, stream_golden, name, hot):
     _device(gpu_session, stream_golden, name, tunables=[("lds_budget", 2048), ("hot_level", hot)])
+
+
+LEX = ["lx_spell_t60_k12_full", "lx_scores_t50", "ng_word_t60_k16_4g"]
+
+
+@pytest.mark.parametrize("name", LEX[:2])
+def test_stream_chunk_decoded_again_after_an_overflow_emulated(emu_session, stream_golden, name):
+    """Lexicon streams run on the optimistic geometry (LDS-sized candidate lists, cut-off generation); with the
+    cut forced down to K + 1 candidates chunks get flagged, their streams get the saved beam back and decode
+    the chunk again on the general path -- the trace must still be the reference's."""
+    c = cases.BY_NAME[name]
+    _device(emu_session, stream_golden, name, threads=64, tunables=[("cut_m", c["K"] + 1)])
+    assert emu_session.last_stream_redone > 0
+    _device(emu_session, stream_golden, name, threads=64, tunables=[("stream_optimistic", 0)])
+    assert emu_session.last_stream_redone == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", LEX + ["C3_spell_u0"])
+def test_stream_chunk_decoded_again_after_an_overflow(gpu_session, stream_golden, name):
+    c = cases.BY_NAME[name]
+    _device(gpu_session, stream_golden, name, tunables=[("cut_m", c["K"] + 1)])
+    assert gpu_session.last_stream_redone > 0
+    _device(gpu_session, stream_golden, name, tunables=[("stream_optimistic", 0)])
+    assert gpu_session.last_stream_redone == 0

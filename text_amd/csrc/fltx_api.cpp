@@ -29,6 +29,55 @@
 
 using namespace fltx;
 
+/* Streams on the optimistic (LDS-sized) geometry: the parked beam of every stream is saved before a chunk
+ * and put back for the streams whose chunk has to be decoded again on the general path (dir 1, map). */
+struct SnapParams {
+  int32_t K, dir;
+  const int32_t* map; /* utterances to restore, null = all */
+  double *gScore, *gAm, *gLm;
+  float* gLexMax;
+  uint32_t *gState, *gSPar, *gLex, *gTokPb;
+  int32_t* gSEdge;
+  int32_t *uttNBeam, *uttFrame, *uttTotal, *uttStatus;
+  char* snap;
+  int64_t B;
+};
+template <class T>
+FLTX_HD void snapMove(int dir, T* live, char* snap, size_t& off, int64_t B, int32_t K, int b, int i) {
+  T* s = (T*)(snap + off) + (size_t)b * K + i;
+  T* l = live + (size_t)b * K + i;
+  if (dir) {
+    *l = *s;
+  } else {
+    *s = *l;
+  }
+  off += sizeof(T) * (size_t)B * K;
+}
+FLTX_HD void snapUtterance(const SnapParams& Q, int b, int i0, int step) {
+  for (int i = i0; i < Q.K; i += step) {
+    size_t off = 0;
+    snapMove(Q.dir, Q.gScore, Q.snap, off, Q.B, Q.K, b, i);
+    snapMove(Q.dir, Q.gAm, Q.snap, off, Q.B, Q.K, b, i);
+    snapMove(Q.dir, Q.gLm, Q.snap, off, Q.B, Q.K, b, i);
+    snapMove(Q.dir, Q.gLexMax, Q.snap, off, Q.B, Q.K, b, i);
+    snapMove(Q.dir, Q.gState, Q.snap, off, Q.B, Q.K, b, i);
+    snapMove(Q.dir, Q.gSPar, Q.snap, off, Q.B, Q.K, b, i);
+    snapMove(Q.dir, Q.gLex, Q.snap, off, Q.B, Q.K, b, i);
+    snapMove(Q.dir, Q.gTokPb, Q.snap, off, Q.B, Q.K, b, i);
+    snapMove(Q.dir, Q.gSEdge, Q.snap, off, Q.B, Q.K, b, i);
+  }
+  if (i0 == 0) {
+    int32_t* u = (int32_t*)(Q.snap + (size_t)Q.B * Q.K * (3 * 8 + 6 * 4)) + (size_t)b * 4;
+    int32_t* live[4] = {Q.uttNBeam, Q.uttFrame, Q.uttTotal, Q.uttStatus};
+    for (int k = 0; k < 4; ++k) {
+      if (Q.dir) {
+        live[k][b] = u[k];
+      } else {
+        u[k] = live[k][b];
+      }
+    }
+  }
+}
 #ifndef FLTX_EMU
 #define FLTX_INST(...) extern template __global__ void __VA_ARGS__(DecodeParams);
 #include "fltx_instances.h"
@@ -36,6 +85,10 @@ using namespace fltx;
 __global__ void __launch_bounds__(512) fltx_backtrace_kernel(BacktraceParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_bt_smem[];
   backtraceUtterance(P, fltx_bt_smem);
+}
+__global__ void __launch_bounds__(64) fltx_snapshot_kernel(SnapParams Q) {
+  const int b = Q.map ? Q.map[blockIdx.x] : (int)blockIdx.x;
+  snapUtterance(Q, b, (int)threadIdx.x, 64);
 }
 /* fltx_result_fetch_batch_compact: the rows that exist, tokens narrowed to bytes, packed back to back */
 struct PackParams {
@@ -349,6 +402,12 @@ struct fltx_decoder {
   const fltx_lm* xlmwordLm = nullptr;
   int ylane = 0, noYlane = 0, ylaneLm = 0, ylaneRounds = 0, ylaneTpw = 0; /* ylane: lane groups of fltx_ylane.h (0 = not used) */
   int btLdsKb = 0;
+  /* streams of the lexicon decoder on the optimistic geometry (LDS workspace, cut-off generation): a chunk that
+   * overflows is decoded again from the saved beam on the general path (HBM workspace) */
+  int userStreamOpt = 1;
+  bool streamOpt = false;
+  int streamRedone = 0; /* stream-chunks decoded again since fltx_stream_begin */
+  DBuf snap;
   int yshare = 0, userYshare = -1; /* the geometry of fltx_ylane.h that shares a CU (memo in HBM); user: -1 = when the batch exceeds the CUs */
   DBuf ymemo;
   int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
@@ -1135,6 +1194,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->ylane ? d->yshare : 0;
   } else if (!strcmp(key, "redone")) {
     *value = d->lastRedo;
+  } else if (!strcmp(key, "stream_redone")) {
+    *value = d->streamRedone;
   } else if (!strcmp(key, "slane")) {
     *value = d->slane;
   } else if (!strcmp(key, "lane")) {
@@ -1223,6 +1284,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "xlane")) { /* 0: do not use the lane = (LM state, trie node) kernel (fltx_xlane.h) */
     d->noXlane = value ? 0 : 1;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "stream_optimistic")) { /* 0: streams of the lexicon decoder start on the worst-case (HBM) workspace */
+    d->userStreamOpt = (int)value;
     return FLTX_OK;
   }
   if (!strcmp(key, "bt_lds_kb")) { /* LDS the back-trace kernel stages history chunks in (0: 144 KB) */
@@ -2219,6 +2284,95 @@ int accountBytes(fltx_decoder* d) {
   return FLTX_OK;
 }
 
+/* save (dir 0) / put back (dir 1; `map`: device list of n utterances, null = all) the parked beams */
+int streamSnapshot(fltx_decoder* d, int dir, const int32_t* map, int n) {
+  SnapParams Q;
+  memset(&Q, 0, sizeof(Q));
+  Q.K = d->opt.beam_size;
+  Q.dir = dir;
+  Q.map = map;
+  Q.gScore = d->gScore.as<double>();
+  Q.gAm = d->gAm.as<double>();
+  Q.gLm = d->gLm.as<double>();
+  Q.gLexMax = d->gLexMax.as<float>();
+  Q.gState = d->gState.as<uint32_t>();
+  Q.gSPar = d->gSPar.as<uint32_t>();
+  Q.gLex = d->gLex.as<uint32_t>();
+  Q.gTokPb = d->gTokPb.as<uint32_t>();
+  Q.gSEdge = d->gSEdge.as<int32_t>();
+  Q.uttNBeam = d->uttNBeam.as<int32_t>();
+  Q.uttFrame = d->uttFrame.as<int32_t>();
+  Q.uttTotal = d->uttTotal.as<int32_t>();
+  Q.uttStatus = d->uttStatus.as<int32_t>();
+  Q.snap = d->snap.as<char>();
+  Q.B = d->B;
+  if (n <= 0) {
+    return FLTX_OK;
+  }
+#ifdef FLTX_EMU
+  for (int i = 0; i < n; ++i) {
+    snapUtterance(Q, map ? map[i] : i, 0, 1);
+  }
+#else
+  hipLaunchKernelGGL(fltx_snapshot_kernel, dim3(n), dim3(64), 0, d->ctx->stream, Q);
+  HIPCHK(hipGetLastError());
+#endif
+  return FLTX_OK;
+}
+
+/* after an optimistic stream chunk: the streams whose chunk overflowed a candidate list (or whose cut left
+ * fewer than K groups) get their beam back and decode the chunk again on the general path */
+int streamRedoFlagged(fltx_decoder* d) {
+  d->resultsSynced = false;
+  int rc = syncResults(d);
+  if (rc) {
+    return rc;
+  }
+  std::vector<int32_t> again;
+  for (int b = 0; b < d->B; ++b) {
+    if (d->hStatus[b] & (ST_CAND_OVERFLOW | ST_CUT_RETRY)) {
+      again.push_back(b);
+    }
+  }
+  d->resultsSynced = false;
+  if (again.empty()) {
+    return FLTX_OK;
+  }
+  Stream st = d->ctx->stream;
+  if (d->uttMap.ensure(4 * again.size(), st, false) ||
+      devCopyH2D(d->uttMap.p, again.data(), 4 * again.size(), st) || devSync(st)) {
+    return fail(FLTX_ERR_OOM, "re-run list upload failed");
+  }
+  if ((rc = streamSnapshot(d, 1, d->uttMap.as<int32_t>(), (int)again.size()))) {
+    return rc;
+  }
+  const int savedWs = d->forceGlobalWs, savedCut = d->noCut;
+  std::vector<int32_t> Tm(d->B, d->maxFrames);
+  d->forceGlobalWs = 1;
+  d->noCut = 1;
+  d->keepScored = true;
+  rc = prepare(d, d->B, d->N, Tm.data(), true);
+  if (!rc) {
+    DecodeParams P;
+    fillParams(d, P);
+    P.emissions = d->lastEmis;
+    P.doBegin = 0;
+    P.doEnd = 0;
+    P.uttMap = d->uttMap.as<int32_t>();
+    d->nLaunch = (int)again.size();
+    rc = launchDecode(d, P);
+    d->nLaunch = 0;
+  }
+  d->forceGlobalWs = savedWs;
+  d->noCut = savedCut;
+  if (!rc) {
+    rc = prepare(d, d->B, d->N, Tm.data(), false); /* back to the optimistic geometry for the next chunk */
+  }
+  d->keepScored = false;
+  d->streamRedone += (int)again.size();
+  return rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -2382,9 +2536,25 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   d->offlineCall = false;
   d->batchPacked = false;
   d->keepScores = 1; /* streams serve getBestHypothesis(lookBack) of ancestors */
-  int rc = prepare(d, B, N, Tm.data(), true);
+  /* The lexicon decoder's candidate lists are sized for what a frame usually produces (LDS) when a chunk
+   * can be decoded again: the beam a chunk starts from is saved, the state table is idempotent (same
+   * (parent, edge) -> same id), history rows are rewritten in place.  (The lexicon-free engines never
+   * overflow and number their states with a counter: always one pass.) */
+  d->streamOpt = d->kind == FLTX_DECODER_LEXICON && d->userStreamOpt != 0 && !d->forceGlobalWs;
+  d->streamRedone = 0;
+  int rc = prepare(d, B, N, Tm.data(), !d->streamOpt);
   if (rc) {
     return rc;
+  }
+  if (d->streamOpt && (d->lean || !(d->wsInLds || d->CAP2 > 0 || d->cutRecompute))) {
+    d->streamOpt = false; /* nothing optimistic came out of it */
+    if ((rc = prepare(d, B, N, Tm.data(), true))) {
+      return rc;
+    }
+  }
+  if (d->streamOpt &&
+      d->snap.ensure((size_t)B * d->opt.beam_size * (3 * 8 + 6 * 4) + (size_t)B * 16, d->ctx->stream, false)) {
+    return fail(FLTX_ERR_OOM, "stream snapshot allocation failed");
   }
   d->engineFirst = engineOf(d);
   if ((rc = bumpEpoch(d))) {
@@ -2441,7 +2611,13 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
   }
   P.doBegin = 0;
   P.doEnd = 0;
+  if (d->streamOpt && (rc = streamSnapshot(d, 0, nullptr, d->B))) {
+    return rc;
+  }
   if ((rc = launchDecode(d, P))) {
+    return rc;
+  }
+  if (d->streamOpt && (rc = streamRedoFlagged(d))) {
     return rc;
   }
   for (int b = 0; b < d->B; ++b) {
