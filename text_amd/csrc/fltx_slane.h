@@ -277,10 +277,12 @@ FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mm
   r.esil = eSil;
   return r;
 }
-/* padPast: also (re)write the positions past the end of the list (NaN emission = no candidate);
- * with the whole token set listed their content never changes and the prologue writes them once */
+/* padPast: also (re)write the positions past the end of the list (NaN emission = no candidate): 2 = all of them
+ * (the prologue), 1 = those a list can reach (a token beam keeps min(Kt, N) tokens, of which blank is not listed
+ * by the lexicon-free engine: the list is one shorter in the frames whose token beam holds blank), 0 = none (the
+ * list has the same length in every frame) */
 template <typename LDS>
-FLTX_DEV void slRowStore(const DecodeParams& P, LDS& S, int q, const SlRowRegs& r, bool padPast) {
+FLTX_DEV void slRowStore(const DecodeParams& P, LDS& S, int q, const SlRowRegs& r, int padPast) {
   const int lane = laneId();
   const bool inRow = lane < P.N;
   const int pos = wavePrefixCount(r.listMask);
@@ -288,13 +290,20 @@ FLTX_DEV void slRowStore(const DecodeParams& P, LDS& S, int q, const SlRowRegs& 
   if (inRow) {
     S.eAll[q][lane] = (double)r.v;
   }
-  if (padPast) {
+  if (padPast == 2) {
     for (int i = lane; i < kSlList; i += 64) {
       if (i >= r.nList) {
         S.eTok[q][i] = __builtin_nan("");
         S.tokBit[q][i] = 0ull;
         S.tokId[q][i] = (uint8_t)0;
       }
+    }
+  } else if (padPast == 1) {
+    const int reach = P.Kt < P.N ? P.Kt : P.N;
+    if (lane >= r.nList && lane < reach) {
+      S.eTok[q][lane] = __builtin_nan("");
+      S.tokBit[q][lane] = 0ull;
+      S.tokId[q][lane] = (uint8_t)0;
     }
   }
   if (listed) {
@@ -469,8 +478,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     ldsRowLoad(S.raw[2], em + (size_t)2 * N + lane, T > 2 && lane < N);
     SlRowRegs r0 = slRowScan(P, v0, ctc, 0.0);
     bestChain = r0.best;
-    slRowStore(P, S, 0, r0, true);
-    slRowStore(P, S, 1, r0, true); /* (the positions past the list; the rest is rewritten by frame 0) */
+    slRowStore(P, S, 0, r0, 2);
+    slRowStore(P, S, 1, r0, 2); /* (the positions past the list; the rest is rewritten by frame 0) */
   }
   ldsBarrier();
 
@@ -931,7 +940,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       /* (this wave issues no stores to HBM: it loads an emission row per frame, and a wait for that
        * load would wait for every store issued since as well) */
       if (t + 1 < T) {
-        slRowStore(P, S, q, nextRow, P.Kt < N);
+        slRowStore(P, S, q, nextRow, P.Kt < N ? 1 : 0);
       }
       ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
     } else if (!isSelf) {

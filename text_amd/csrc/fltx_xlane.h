@@ -255,8 +255,8 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     /* (the row's `best` is not used by this engine: ctc = false keeps blank in the token list,
      * which is harmless -- no trie node has a child for it) */
     SlRowRegs r0 = slRowScan(P, v0, false, 0.0);
-    slRowStore(P, S, 0, r0, true);
-    slRowStore(P, S, 1, r0, true);
+    slRowStore(P, S, 0, r0, 2);
+    slRowStore(P, S, 1, r0, 2);
   }
   ldsBarrier();
 
@@ -829,7 +829,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     if (isSvc) {
       /* (no stores to HBM from this wave: a wait for its emission-row load would wait for them too) */
       if (t + 1 < T) {
-        slRowStore(P, S, q, nextRow, P.Kt < N);
+        slRowStore(P, S, q, nextRow, P.Kt < N ? 1 : 0);
       }
       ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
       /* the merge table of the next frame starts empty (winHyp / winWord, which the self wave reads

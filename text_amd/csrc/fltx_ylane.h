@@ -329,8 +329,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     rowA = (T > 1 && lane < N) ? em[(size_t)1 * N + lane] : 0.0f;
     rowB = (T > 2 && lane < N) ? em[(size_t)2 * N + lane] : 0.0f;
     SlRowRegs r0 = slRowScan(P, v0, false, 0.0);
-    slRowStore(P, S, 0, r0, true);
-    slRowStore(P, S, 1, r0, true);
+    slRowStore(P, S, 0, r0, 2);
+    slRowStore(P, S, 1, r0, 2);
   }
 #ifndef FLTX_EMU
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the start state's context is read back from HBM */
@@ -1175,7 +1175,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       nextRow.nList = popc64(nextRow.allow);
       nextRow.best = 0.0; /* (this engine takes the frame's best from the candidates) */
       nextRow.dead = false;
-      slRowStore(P, S, q, nextRow, P.Kt < N); /* (here: the lanes' own waves price their next stay / blank in the build) */
+      slRowStore(P, S, q, nextRow, P.Kt < N ? 1 : 0); /* (here: the lanes' own waves price their next stay / blank in the build) */
     }
     FLTX_YLPROF(4);
     ldsBarrier(); /* 2 */
