@@ -433,6 +433,7 @@ struct fltx_decoder {
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
   HBuf hTokens, hWords, hScores; /* fltx_result_fetch_batch */
   HBuf hTok8, hWordsC, hPackMeta;  /* fltx_result_fetch_batch_compact */
+  HBuf hSync;                      /* syncResults */
   DBuf dTok8, dWordsC, dPackMeta;
   std::vector<int64_t> packOff;
   bool compactFetched = false, scoresFetched = false;
@@ -2163,11 +2164,29 @@ int syncResults(fltx_decoder* d) {
   d->hN.resize(B);
   d->hFrame.resize(B);
   d->hStatus.resize(B);
+#ifdef FLTX_EMU
   if (devCopyD2H(d->hN.data(), d->uttNBeam.p, 4 * (size_t)B, st) ||
       devCopyD2H(d->hFrame.data(), d->uttFrame.p, 4 * (size_t)B, st) ||
       devCopyD2H(d->hStatus.data(), d->uttStatus.p, 4 * (size_t)B, st)) {
     return fail(FLTX_ERR_HIP, "result copy failed: %s", devErr());
   }
+#else
+  /* three small arrays, one wait: pinned staging, the copies queued back to back (a stream chunk pays this
+   * after every step and every prune) */
+  if (d->hSync.ensure(12 * (size_t)B)) {
+    return fail(FLTX_ERR_OOM, "pinned staging allocation failed");
+  }
+  int32_t* h = (int32_t*)d->hSync.p;
+  if (hipMemcpyAsync(h, d->uttNBeam.p, 4 * (size_t)B, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(h + B, d->uttFrame.p, 4 * (size_t)B, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(h + 2 * B, d->uttStatus.p, 4 * (size_t)B, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    return fail(FLTX_ERR_HIP, "result copy failed: %s", devErr());
+  }
+  memcpy(d->hN.data(), h, 4 * (size_t)B);
+  memcpy(d->hFrame.data(), h + B, 4 * (size_t)B);
+  memcpy(d->hStatus.data(), h + 2 * B, 4 * (size_t)B);
+#endif
   d->resultsSynced = true;
   return FLTX_OK;
 }
