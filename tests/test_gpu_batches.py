@@ -117,7 +117,7 @@ def test_random_configurations_slice(gpu_session, oracle_lib):
     against the oracle (ties in the reference's n-best are skipped: its own result is order
     dependent there)."""
     bad, ran = [], 0
-    for c in cases.fuzz_cases(160)[40:]:
+    for c in cases.fuzz_cases(460)[40:]:
         inp = helpers.case_inputs(c)
         want = helpers.run_checker(oracle_lib, c, inp)
         if len({h.score for h in want}) != len(want):
@@ -127,7 +127,7 @@ def test_random_configurations_slice(gpu_session, oracle_lib):
         ran += 1
         if not ok:
             bad.append((c["name"], why))
-    assert ran > 60 and not bad, bad[:3]
+    assert ran > 200 and not bad, bad[:3]
 
 
 def test_edge_configurations_of_the_lexicon_free_decoders(gpu_session, oracle_lib):

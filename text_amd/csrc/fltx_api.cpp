@@ -1852,85 +1852,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
 int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   const int W = d->threads;
 #ifdef FLTX_EMU
-  const DecodeParams* pp = &P;
-  const int gmax = d->lean;
-  const int gt = d->lane;
-  const int sl = d->slane;
-  const int xl = d->xlane;
-  const int yl = d->ylane ? d->ylane * 10 + d->ylaneLm + (d->yshare ? 100 : 0) : 0;
-  const bool hot = !d->wsInLds && d->hotBytes > 0;
-  emuLaunch(d->nLaunch > 0 ? d->nLaunch : d->B, W, d->wsInLds ? d->wsBytes : (hot ? d->hotBytes : 16),
-            [pp, gmax, gt, sl, xl, yl, hot](char* smem) {
-    char* base = pp->gws ? pp->gws + (size_t)blockIdx.x * pp->gwsStride : smem;
-    if (hot) {
-      if (gmax == 255) {
-        decodeUtterance<255>(*pp, base, smem);
-      } else {
-        decodeUtterance<0>(*pp, base, smem);
-      }
-      return;
-    }
-    const bool ft = pp->Kt >= pp->N;
-    if (yl == 10) {
-      ylaneUtterance<1, 2, 0, 0, false>(*pp, smem);
-    } else if (yl == 11) {
-      ylaneUtterance<1, 2, 1, 0, false>(*pp, smem);
-    } else if (yl == 20) {
-      ylaneUtterance<2, 4, 0, 0, false>(*pp, smem);
-    } else if (yl == 21) {
-      ylaneUtterance<2, 4, 1, 0, false>(*pp, smem);
-    } else if (yl == 110) {
-      ylaneUtterance<1, 2, 0, 1, false>(*pp, smem);
-    } else if (yl == 111) {
-      ylaneUtterance<1, 2, 1, 1, false>(*pp, smem);
-    } else if (yl == 120) {
-      ylaneUtterance<2, 4, 0, 1, false>(*pp, smem);
-    } else if (yl == 121) {
-      ylaneUtterance<2, 4, 1, 1, false>(*pp, smem);
-    } else if (xl == 3) {
-      xlaneUtterance<3, false>(*pp, smem);
-    } else if (xl == 5) {
-      xlaneUtterance<5, false>(*pp, smem);
-    } else if (xl == 10) {
-      xlaneUtterance<10, false>(*pp, smem);
-    } else if (xl == 2) {
-      xlaneUtterance<2, false>(*pp, smem);
-    } else if (sl == 4) {
-      pp->logAdd ? slaneUtterance<4, true, false>(*pp, smem) : slaneUtterance<4, false, false>(*pp, smem);
-    } else if (sl == 5) {
-      pp->logAdd ? slaneUtterance<5, true, false>(*pp, smem) : slaneUtterance<5, false, false>(*pp, smem);
-    } else if (sl == 6) {
-      pp->logAdd ? slaneUtterance<6, true, false>(*pp, smem) : slaneUtterance<6, false, false>(*pp, smem);
-    } else if (sl == 7) {
-      pp->logAdd ? slaneUtterance<7, true, false>(*pp, smem) : slaneUtterance<7, false, false>(*pp, smem);
-    } else if (sl == 10) {
-      pp->logAdd ? slaneUtterance<10, true, false>(*pp, smem) : slaneUtterance<10, false, false>(*pp, smem);
-    } else if (sl == 12) {
-      pp->logAdd ? slaneUtterance<12, true, false>(*pp, smem) : slaneUtterance<12, false, false>(*pp, smem);
-
-    } else if (gt == 4) {
-      if (pp->logAdd) {
-        ft ? decodeUtterance<1, 4, true, true>(*pp, base) : decodeUtterance<1, 4, true, false>(*pp, base);
-      } else {
-        ft ? decodeUtterance<1, 4, false, true>(*pp, base) : decodeUtterance<1, 4, false, false>(*pp, base);
-      }
-    } else if (gt == 8) {
-      if (pp->logAdd) {
-        ft ? decodeUtterance<1, 8, true, true>(*pp, base) : decodeUtterance<1, 8, true, false>(*pp, base);
-      } else {
-        ft ? decodeUtterance<1, 8, false, true>(*pp, base) : decodeUtterance<1, 8, false, false>(*pp, base);
-      }
-    } else if (gmax == 6) {
-      decodeUtterance<6>(*pp, base);
-    } else if (gmax == 12) {
-      decodeUtterance<12>(*pp, base);
-    } else if (gmax == 255) {
-      decodeUtterance<255>(*pp, base);
-    } else {
-      decodeUtterance<0>(*pp, base);
-    }
-  });
-  return FLTX_OK;
+#include "fltx_emu_launch.inc" /* tests/emu/: host-thread dispatch over the kernel variants */
 #else
   for (int i = 0; i < 3; ++i) {
     if (!d->ev[i]) {
