@@ -92,3 +92,50 @@ def test_stream_chunk_decoded_again_after_an_overflow(gpu_session, stream_golden
     assert gpu_session.last_stream_redone > 0
     _device(gpu_session, stream_golden, name, tunables=[("stream_optimistic", 0)])
     assert gpu_session.last_stream_redone == 0
+
+
+def _random_lexfree_streams(session, oracle_lib, every):
+    """Lexicon-free stream chunks run on the lane = LM state engine (fltx_slane.h, ST): beam in and out in the
+    lane-per-slot engine's parked format, ids from its (parent, token) -> id table.  Random options (beams 1 .. 64,
+    thresholds 2 .. inf, token beams, silScore, CTC and ASG) in chunks with getBestHypothesis / prune between them,
+    event by event against the oracle (itself pinned to the reference's traces above)."""
+    import itertools
+    bad, ran = [], 0
+    grid = itertools.product([1, 3, 10, 50, 64], [2.0, 25.0, float("inf")], [None, 5], [12, 29], [7, 60],
+                             ["ctc", "uniform"], [0.0, -0.6], ["ctc", "asg"])
+    for i, (K, thr, Kt, N, T, dist, sil, crit) in enumerate(grid):
+        if i % every:
+            continue
+        c = cases.case("ss%d" % i, dist=dist, u=700 + i, T=T, N=N, K=K, Kt=Kt, thr=thr, sil_score=sil, crit=crit,
+                       trans_seed=(30 + i) if crit == "asg" else None)
+        inp = helpers.case_inputs(c)
+        chunks, lbs = [3, 9, 1, 12, 20, 30], [0, 2, 0, 5]
+        want = ss.trace_checker(oracle_lib, c, inp, chunks, lbs)
+        got, _ = ss.trace_device(session, c, inp, chunks, lbs)
+        ran += 1
+        d = ss.first_difference(want, got)
+        if d:
+            bad.append(({k: c[k] for k in ("K", "thr", "Kt", "N", "T", "dist", "sil_score", "crit")}, d))
+    return ran, bad
+
+
+def test_lexfree_stream_chunks_on_the_lane_state_engine_emulated(emu_session, oracle_lib, stream_golden):
+    c = cases.BY_NAME["lf_ctc_t60_k10"]
+    d = emu_session.decoder(c, helpers.case_inputs(c))
+    d.stream_begin(1, c["N"], 64)
+    assert d.get("sstream") > 0  # the engine is chosen for the stream's chunks ...
+    d.set("sstream", 0)
+    d.stream_begin(1, c["N"], 64)
+    assert d.get("sstream") == 0  # ... and can be switched off
+    d.close()
+    _device(emu_session, stream_golden, "lf_ctc_t60_k10")
+    ran, bad = _random_lexfree_streams(emu_session, oracle_lib, 97)
+    assert ran > 8 and not bad, bad[:3]
+
+
+@pytest.mark.gpu
+def test_lexfree_stream_chunks_on_the_lane_state_engine(gpu_session, oracle_lib, stream_golden):
+    ran, bad = _random_lexfree_streams(gpu_session, oracle_lib, 3)
+    assert ran > 300 and not bad, bad[:3]
+    # the lane-per-slot step (sstream = 0) still serves the same streams
+    _device(gpu_session, stream_golden, "C1_ctc_u0", tunables=[("sstream", 0)])

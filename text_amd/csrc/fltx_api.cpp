@@ -402,6 +402,10 @@ struct fltx_decoder {
   const fltx_lm* xlmwordLm = nullptr;
   int ylane = 0, noYlane = 0, ylaneLm = 0, ylaneRounds = 0, ylaneTpw = 0; /* ylane: lane groups of fltx_ylane.h (0 = not used) */
   int btLdsKb = 0;
+  /* stream chunks of the lexicon-free decoder on the lane = LM state engine (fltx_slane.h, ST): list positions per
+   * token wave (0 = not used) and threads; begin / end / prune / best stay the lane-per-slot engine's */
+  int sstream = 0, sstreamThreads = 0, noSstream = 0;
+  bool sstreamLaunch = false;
   /* streams of the lexicon decoder on the optimistic geometry (LDS workspace, cut-off generation): a chunk that
    * overflows is decoded again from the saved beam on the general path (HBM workspace) */
   int userStreamOpt = 1;
@@ -1195,6 +1199,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->ylane ? d->yshare : 0;
   } else if (!strcmp(key, "redone")) {
     *value = d->lastRedo;
+  } else if (!strcmp(key, "sstream")) {
+    *value = d->sstream;
   } else if (!strcmp(key, "stream_redone")) {
     *value = d->streamRedone;
   } else if (!strcmp(key, "slane")) {
@@ -1285,6 +1291,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "xlane")) { /* 0: do not use the lane = (LM state, trie node) kernel (fltx_xlane.h) */
     d->noXlane = value ? 0 : 1;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "sstream")) { /* 0: stream chunks stay on the lane-per-slot step (fltx_lane.h) */
+    d->noSstream = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "stream_optimistic")) { /* 0: streams of the lexicon decoder start on the worst-case (HBM) workspace */
@@ -1433,6 +1443,22 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       if (nList <= g[1] * (g[0] / 64 - 2)) {
         d->slane = g[1];
         d->threads = g[0];
+        break;
+      }
+    }
+  }
+  /* ... and the frames of a stream's decodeStep chunks on the same engine (the parked beam, the (parent, token) ->
+   * id tables and the history rows keep the lane-per-slot engine's format) */
+  d->sstream = 0;
+  if (d->lane && !d->noSlane && !d->noSstream && !d->offlineCall && d->keepScores && !d->opt.log_add &&
+      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
+      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N))) {
+    static const int geoS[][2] = {{576, 4}, {512, 5}, {576, 10}};
+    const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
+    for (const auto& g : geoS) {
+      if (nList <= g[1] * (g[0] / 64 - 2)) {
+        d->sstream = g[1];
+        d->sstreamThreads = g[0];
         break;
       }
     }
@@ -1850,7 +1876,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
 }
 
 int launchDecode(fltx_decoder* d, const DecodeParams& P) {
-  const int W = d->threads;
+  const int W = d->sstreamLaunch ? d->sstreamThreads : d->threads;
 #ifdef FLTX_EMU
 #include "fltx_emu_launch.inc" /* tests/emu/: host-thread dispatch over the kernel variants */
 #else
@@ -1936,7 +1962,18 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       FLTX_LAUNCH_LDS(WW, 0);                                                                    \
     }                                                                                            \
   } while (0)
-  if (d->ylane) {
+  if (d->sstreamLaunch) {
+#define FLTX_LAUNCH_SSTREAM(WW, GG)                                                              \
+  hipLaunchKernelGGL((fltx_decode_kernel_slane_stream<WW, GG>), dim3(nGrid), dim3(WW), sizeof(SlaneLds), \
+                     d->ctx->stream, P)
+    switch (W * 100 + d->sstream) {
+      case 57604: FLTX_LAUNCH_SSTREAM(576, 4); break;
+      case 51205: FLTX_LAUNCH_SSTREAM(512, 5); break;
+      case 57610: FLTX_LAUNCH_SSTREAM(576, 10); break;
+      default: return fail(FLTX_ERR_INVALID, "no stream kernel for %d threads x %d positions", W, d->sstream);
+    }
+#undef FLTX_LAUNCH_SSTREAM
+  } else if (d->ylane) {
 #define FLTX_LAUNCH_YLANE(WW, NG, RR, LMK, HM)                                                          \
   do {                                                                                                  \
     HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<WW, NG, RR, LMK, HM, false>,       \
@@ -2555,7 +2592,10 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
   if (d->streamOpt && (rc = streamSnapshot(d, 0, nullptr, d->B))) {
     return rc;
   }
-  if ((rc = launchDecode(d, P))) {
+  d->sstreamLaunch = d->sstream != 0;
+  rc = launchDecode(d, P);
+  d->sstreamLaunch = false;
+  if (rc) {
     return rc;
   }
   if (d->streamOpt && (rc = streamRedoFlagged(d))) {

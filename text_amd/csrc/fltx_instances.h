@@ -41,6 +41,10 @@
 #define FLTX_G10(W) FLTX_SLANE_SET(false, false)
 #define FLTX_G11(W) FLTX_SLANE_SET(false, true)
 #define FLTX_G15(W) FLTX_SLANE_SET(true, false) /* logAdd */
+#define FLTX_G16(W) /* stream chunks */                     \
+  FLTX_INST(fltx_decode_kernel_slane_stream<576, 4>)         \
+  FLTX_INST(fltx_decode_kernel_slane_stream<512, 5>)         \
+  FLTX_INST(fltx_decode_kernel_slane_stream<576, 10>)
 /* lane = (LM state, trie node) decode (fltx_xlane.h): three waves do not evaluate listed tokens */
 #define FLTX_XLANE_SET(PROF)                               \
   FLTX_INST(fltx_decode_kernel_xlane<512, 2, PROF>)        \
@@ -81,6 +85,7 @@ FLTX_G12(0)
 FLTX_G13(0)
 FLTX_G14(0)
 FLTX_G15(0)
+FLTX_G16(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -98,6 +103,7 @@ FLTX_G15(0)
 #undef FLTX_G13
 #undef FLTX_G14
 #undef FLTX_G15
+#undef FLTX_G16
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET
 #undef FLTX_SLANE_SET

@@ -49,7 +49,14 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_lane(DecodeParams P) {
 template <int W, int GT, bool LA, bool PROF>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_slane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  slaneUtterance<GT, LA, PROF>(P, fltx_smem);
+  slaneUtterance<GT, LA, false, PROF>(P, fltx_smem);
+}
+/* the frames of one decodeStep chunk of a stream on the same engine: beam in and out in the parked format of the
+ * lane-per-slot step, whose kernels do decodeBegin / decodeEnd / prune / getBestHypothesis */
+template <int W, int GT>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_slane_stream(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  slaneUtterance<GT, false, true, false>(P, fltx_smem);
 }
 /* lane = (LM state, trie node) decode of a whole utterance (fltx_xlane.h): lexicon + ZeroLM */
 template <int W, int GT, bool PROF>

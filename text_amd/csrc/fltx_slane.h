@@ -108,10 +108,12 @@ struct SlaneLds {
   uint32_t evLane[64], evSpar[64], evTok[64];
   unsigned long long scanMask;
   unsigned long long mmaxKey[2]; /* logAdd: order key of the best hypothesis of the beam a frame starts from */
+  double amNB[2][64], amB[2][64]; /* streams: emitting-model score of a state's two hypotheses */
+  uint8_t rsNB[64], rsB[64];      /* streams, restore: the parked slot of a lane's two hypotheses */
   uint32_t scanMin, pad0;
   float raw[3][64]; /* emission rows on their way in: row r lands in raw[r % 3] two frames before it is staged */
 };
-enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2 };
+enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2, SL_NEXTID = 3, SL_STATUS = 4, SL_NSTATE = 5 };
 
 FLTX_DEV double slNegInf() { return -__builtin_huge_val(); }
 
@@ -392,6 +394,36 @@ FLTX_DEV __attribute__((noinline)) void slReenter(SlaneLds& S, const int2* histP
   ldsBarrier();
 }
 
+/* Streams (ST): a state's id comes from the (parent id, token) -> id table in HBM (DecodeParams::childTab, the
+ * lane-per-slot engine's: the parked beam, the tables and the history rows keep that engine's format, so begin,
+ * end, prune and getBestHypothesis are its code).  A state that is entered again (its parent's mask had the
+ * token) gets its child mask back from maskTab and the lanes whose parent it is get their link back. */
+FLTX_DEV __attribute__((noinline)) void slRelink(SlaneLds& S, const unsigned long long* maskTab, int q, int nState) {
+  const int tid = (int)threadIdx.x;
+  const int nev = (int)S.row[q].nev;
+#ifndef FLTX_EMU
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  ldsBarrier();
+  for (int e = 0; e < nev; ++e) {
+    const int X = (int)S.evLane[e];
+    const uint32_t sid = S.rec[q][X].sid;
+    if (tid == 0) {
+      S.mask[q][X] |= loadCoherent64(&maskTab[sid]);
+    }
+    if (tid < nState && tid != X && S.rec[q][tid].spar == sid) { /* orphans get their parent back */
+      const uint32_t info = S.rec[q][tid].info;
+      S.rec[q][tid].info = (info & ~0xFF00u) | ((uint32_t)(X + 1) << 8);
+      atomOr64(&S.cmask[q][X], 1ull << (info & 0xFFu));
+    }
+    ldsBarrier();
+  }
+  if (tid == 0) {
+    S.row[q].nev = 0u;
+  }
+  ldsBarrier();
+}
+
 #define FLTX_SLPROF(i)                                        \
   do {                                                        \
     if (PROF && P.prof && (int)threadIdx.x == P.profThread) { \
@@ -410,8 +442,9 @@ FLTX_DEV double slLogAdd(double hi, double lo) { return hi + log1p(exp(lo - hi))
  * what changes is the frame's best candidate: a merged hypothesis can score above every candidate of its
  * frame, so the best hypothesis is not the last frame's best candidate any more -- the build publishes the
  * best surviving score and every wave prices the row with it at the head of the frame. */
-template <int GT, bool LA, bool PROF>
+template <int GT, bool LA, bool ST, bool PROF>
 FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
+  static_assert(!(LA && ST), "streams with logAdd stay on the lane-per-slot step");
   SlaneLds& S = *(SlaneLds*)smem;
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x, tid = (int)threadIdx.x;
@@ -447,6 +480,81 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   if (tid < 16) {
     S.scal[tid] = 0u;
   }
+  const int frame0 = ST ? P.uttFrame[b] : 0;   /* streams: rows already in the buffer */
+  const int total0 = ST ? P.uttTotal[b] : 0;   /* ... frames decoded since decodeBegin */
+  if (ST) {
+    /* the beam parked by the last launch (sorted slots, one hypothesis each) -> lanes (one LM state each) */
+    ldsBarrier(); /* (the wipes above) */
+    const int nB = P.uttNBeam[b];
+    if (tid == 0) {
+      S.row[0].nev = 0u;
+      S.row[1].nev = 0u;
+      S.row[0].dead = 0u;
+      S.row[1].dead = 0u;
+      S.scal[SL_NEXTID] = (uint32_t)P.uttNextId[b];
+    }
+    if (wave == 0) {
+      const bool valid = lane < nB;
+      const size_t g = (size_t)b * K + (valid ? lane : 0);
+      const double sc = P.gScore[g], amv = P.gAm[g];
+      const uint32_t sid = valid ? P.gState[g] : 0xFFFFFFFFu, spar = P.gSPar[g], tp = P.gTokPb[g];
+      const int32_t edge = P.gSEdge[g];
+      const unsigned long long mkv = P.gMask[g];
+      const bool isB = (tp & kPrevBlank) != 0u;
+      int leader = lane;
+      for (int i = 0; i < nB; ++i) {
+        const uint32_t si = waveReadLane32(sid, i);
+        leader = (valid && si == sid && i < leader) ? i : leader;
+      }
+      const unsigned long long leaders = waveBallot(valid && leader == lane);
+      const int L = popc64(leaders & ((1ull << leader) - 1ull));
+      if (valid && leader == lane) {
+        SlRec r;
+        r.nb = NEG;
+        r.b = NEG;
+        r.info = (uint32_t)(sid == 0u ? P.sil : (edge & 63));
+        r.sid = sid;
+        r.spar = sid == 0u ? 0x7FFFFFu : spar;
+        r.pad = 0u;
+        S.rec[0][L] = r;
+        S.mask[0][L] = mkv;
+        S.rsNB[L] = (uint8_t)kSlNoHyp;
+        S.rsB[L] = (uint8_t)kSlNoHyp;
+      }
+      waveSync();
+      if (valid) {
+        if (isB) {
+          S.rec[0][L].b = sc;
+          S.amB[0][L] = amv;
+          S.rsB[L] = (uint8_t)lane;
+        } else {
+          S.rec[0][L].nb = sc;
+          S.amNB[0][L] = amv;
+          S.rsNB[L] = (uint8_t)lane;
+        }
+      }
+      waveSync();
+      const int nSt = popc64(leaders);
+      /* lane j: history slots of its hypotheses, the lane of its parent state */
+      const bool lv = lane < nSt;
+      const SlRec mine = S.rec[0][lv ? lane : 0];
+      int plr = -1;
+      for (int i = 0; i < nSt; ++i) {
+        const uint32_t si = waveReadLane32(mine.sid, i);
+        plr = (lv && si == mine.spar && i != lane) ? i : plr;
+      }
+      if (lv) {
+        S.rec[0][lane].info = (mine.info & 0xFFu) | ((uint32_t)(plr + 1) << 8) | ((uint32_t)S.rsNB[lane] << 16) |
+                              ((uint32_t)S.rsB[lane] << 24);
+        if (plr >= 0) {
+          atomOr64(&S.cmask[0][plr], 1ull << (mine.info & 63u));
+        }
+      }
+      if (lane == 0) {
+        S.scal[SL_NSTATE] = (uint32_t)nSt;
+      }
+    }
+  } else {
   if (tid == 0) {
     SlRec r;
     r.nb = 0.0;
@@ -467,6 +575,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   if (tid > 0 && tid < K) { /* unused slots of a row never look like the record of a new state (slReenter) */
     P.histPT[hbase + tid] = make_int2((int)kSlNoHyp, -1);
   }
+  }
   /* emission rows: lane n of the prep wave holds e[t + 1][n] (used by the build of frame t) in one of
    * two registers, alternating with the frame parity; the register is refilled with row t + 3 right
    * after its use, so a load has two frames to arrive and is never moved between registers */
@@ -476,14 +585,15 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const float v0 = (T > 0 && lane < N) ? em[lane] : 0.0f;
     ldsRowLoad(S.raw[1], em + (size_t)1 * N + lane, T > 1 && lane < N);
     ldsRowLoad(S.raw[2], em + (size_t)2 * N + lane, T > 2 && lane < N);
-    SlRowRegs r0 = slRowScan(P, v0, ctc, 0.0);
+    /* (streams: the parked beam is sorted, slot 0 is the best hypothesis; prune has normalised it) */
+    SlRowRegs r0 = slRowScan(P, v0, ctc, ST ? P.gScore[(size_t)b * K] : 0.0);
     bestChain = r0.best;
     slRowStore(P, S, 0, r0, 2);
     slRowStore(P, S, 1, r0, 2); /* (the positions past the list; the rest is rewritten by frame 0) */
   }
   ldsBarrier();
 
-  int nState = 1;
+  int nState = ST ? (int)S.scal[SL_NSTATE] : 1;
   double endBest = 0.0; /* best hypothesis of the final beam (decodeEnd's threshold) */
   int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
   bool dead = false; /* this utterance goes to the general engines */
@@ -497,7 +607,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   auto frameStep = [&](auto PT, auto RL, float& rowReg, const int t) {
     constexpr int p = decltype(PT)::value, q = p ^ 1;
     constexpr bool isSelf = decltype(RL)::value == 1, isSvc = decltype(RL)::value == 2;
-    const int frameOut = t + 1;
+    const int frameOut = frame0 + t + 1;
     const int64_t hrow = hbase + (int64_t)frameOut * K;
     /* ---- phase 1: own state, candidates, histogram ------------------------------------- */
     /* every LDS read of the phase is issued here, before anything waits for one */
@@ -546,7 +656,11 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     }
     (void)nList;
     if (nev != 0u) { /* rare: states re-entered the beam in the previous build */
-      slReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K);
+      if (ST) {
+        slRelink(S, P.maskTab + (size_t)b * P.idCap, p, nState);
+      } else {
+        slReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K);
+      }
       me = S.rec[p][lane];
       cm = S.cmask[p][lane];
       mk = S.mask[p][lane];
@@ -563,17 +677,37 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const bool whichB = bb > nb;
     const double m = whichB ? bb : nb;
     const uint32_t hypM = whichB ? hypB : hypNB;
+    /* streams carry the emitting-model score of every hypothesis (getBestHypothesis returns an ancestor's) */
+    double amNBv = 0.0, amBv = 0.0, parAmNB = 0.0, parAmB = 0.0;
+    if (ST && !isSvc) {
+      amNBv = S.amNB[p][lane];
+      amBv = S.amB[p][lane];
+    }
+    const double amM = whichB ? amBv : amNBv;
+    auto amStep = [&](double amPrev, double e, int n, int prevTok) {
+      double x = e; /* LexiconFreeDecoder.cpp:58-64: the ASG transition enters the emitting-model score only */
+      if (!ctc && P.transitions && total0 + t > 0) {
+        x = x + (double)P.transitions[(size_t)n * N + prevTok];
+      }
+      return amPrev + x;
+    };
     /* self wave: what its groups need beyond the lane's own record (second LDS round trip) */
     SlRec par;
     double eLast = 0.0;
     if (isSelf) {
       par = S.rec[p][pl >= 0 ? pl : 0];
       eLast = S.eAll[p][last];
+      if (ST) {
+        parAmNB = S.amNB[p][pl >= 0 ? pl : 0];
+        parAmB = S.amB[p][pl >= 0 ? pl : 0];
+      }
     }
     FLTX_SLPROF(0);
     double cs[GT];
     int cbin[GT];
     uint32_t parR = kSlNoHyp;
+    double amR = 0.0; /* streams: emitting-model score of the repeat group's winning member ... */
+    int prevR = 0;    /* ... and its token (ASG transition) */
     SlRowRegs nextRow = {};
     if (isSvc) {
       /* the next frame's emission row (the masks and counters this frame's build adds to are wiped
@@ -665,13 +799,19 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
        * exist has slot 255 and score -inf: it never wins against one that does) */
       double cR = r0;
       parR = hypNB;
+      amR = amNBv;
+      prevR = last;
       if (has1 && (r1 > cR || (r1 == cR && h1 < parR))) {
         cR = r1;
         parR = h1;
+        amR = parAmNB;
+        prevR = lastP;
       }
       if (has2 && (r2 > cR || (r2 == cR && h2 < parR))) {
         cR = r2;
         parR = h2;
+        amR = parAmB;
+        prevR = blank;
       }
       bool okR = lastOk && (has0 || has1 || has2) && cR >= thr;
       if (LA) {
@@ -913,7 +1053,16 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const int offW = (int)S.off[wave], nNew = (int)S.off[selfWave + 1];
     const int myNewLane = S.newLane[lane];
     const int plNew = S.newLane[pl >= 0 ? pl : 0];
-    auto newState = [&](int idx, double c, int n, uint32_t hp) {
+    auto plainRec = [&](uint32_t hp, int n) { return make_int2(hp == kSlNoHyp ? -1 : (int)hp, n); };
+    auto scoreRec = [&](int64_t at, double c, double am) {
+      if (P.histS) {
+        double* hs = P.histS + 3 * at;
+        hs[0] = c;
+        hs[1] = am;
+        hs[2] = 0.0;
+      }
+    };
+    auto newState = [&](int idx, double c, int n, uint32_t hp, double amNew) {
       const int nl = nSurv + idx;
       const uint32_t hyp = (uint32_t)(nHSurv + idx);
       SlRec r;
@@ -923,13 +1072,35 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       r.sid = (uint32_t)frameOut * (uint32_t)K + hyp;
       r.spar = me.sid;
       r.pad = 0u;
+      const bool again = ((mk >> n) & 1ull) != 0ull; /* this edge had a child before */
+      if (ST) {
+        uint32_t* slot = &P.childTab[((size_t)b * P.idCap + me.sid) * N + n];
+        if (again) {
+          r.sid = loadCoherent32(slot);
+        } else {
+          r.sid = atomAdd32(&S.scal[SL_NEXTID], 1u);
+          if ((int64_t)r.sid >= P.idCap) {
+            atomOr32(&S.scal[SL_STATUS], ST_TABLE_FULL);
+            r.sid = 0u;
+          }
+          *slot = r.sid;
+          P.maskTab[(size_t)b * P.idCap + r.sid] = 0ull;
+          atomOr64(&P.maskTab[(size_t)b * P.idCap + me.sid], 1ull << n); /* (the parent may leave the beam) */
+        }
+        S.amNB[q][nl] = amNew;
+      }
       S.rec[q][nl] = r;
       if (myNewLane >= 0) {
         atomOr64(&S.cmask[q][myNewLane], 1ull << n);
         atomOr64(&S.mask[q][myNewLane], 1ull << n);
       }
-      histPT[hrow + hyp] = make_int2((int)(hp | kSlNewFlag | (me.sid << 9)), n);
-      if ((mk >> n) & 1ull) { /* this edge had a child before: it may have descendants in the beam */
+      if (ST) {
+        histPT[hrow + hyp] = plainRec(hp, n);
+        scoreRec(hrow + hyp, c, amNew);
+      } else {
+        histPT[hrow + hyp] = make_int2((int)(hp | kSlNewFlag | (me.sid << 9)), n);
+      }
+      if (again) { /* it may have descendants in the beam */
         const uint32_t e = atomAdd32(&S.row[q].nev, 1u);
         S.evLane[e] = (uint32_t)nl;
         S.evSpar[e] = me.sid;
@@ -948,12 +1119,13 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       for (int j = 0; j < GT; ++j) {
         if (selMask[j] != 0ull) { /* (most positions of most frames have no survivor at all) */
           if ((selMask[j] >> lane) & 1ull) {
-            newState(offW + myNew[j], cs[j], (int)S.tokId[p][wave * GT + j], hypM);
+            const int nTok = (int)S.tokId[p][wave * GT + j];
+            newState(offW + myNew[j], cs[j], nTok, hypM, ST ? amStep(amM, ev[j], nTok, whichB ? blank : last) : 0.0);
           }
         }
       }
     } else {
-      if (lane >= nHSurv + nNew && lane < K) { /* unused slots of the history row: see slReenter */
+      if (!ST && lane >= nHSurv + nNew && lane < K) { /* unused slots of the history row: see slReenter */
         histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
       }
       if (surv >= 0) {
@@ -974,15 +1146,30 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         if (pln >= 0) {
           atomOr64(&S.cmask[q][pln], 1ull << last);
         }
-        if (sR) {
-          histPT[hrow + hNB] = make_int2((int)parR, last);
-        }
-        if (sB) {
-          histPT[hrow + hB] = make_int2((int)hypM, blank);
+        if (ST) {
+          if (sR) {
+            const double a = amStep(amR, eLast, last, prevR);
+            S.amNB[q][surv] = a;
+            histPT[hrow + hNB] = plainRec(parR, last);
+            scoreRec(hrow + hNB, cs[1], a);
+          }
+          if (sB) {
+            const double a = amM + eBlank;
+            S.amB[q][surv] = a;
+            histPT[hrow + hB] = plainRec(hypM, blank);
+            scoreRec(hrow + hB, cs[0], a);
+          }
+        } else {
+          if (sR) {
+            histPT[hrow + hNB] = make_int2((int)parR, last);
+          }
+          if (sB) {
+            histPT[hrow + hB] = make_int2((int)hypM, blank);
+          }
         }
       }
       if ((selMask[2] >> lane) & 1ull) {
-        newState(offW + myNew[2], cs[2], last, hypB);
+        newState(offW + myNew[2], cs[2], last, hypB, ST ? amStep(amBv, eLast, last, blank) : 0.0);
       }
     }
     nState = nSurv + nNew;
@@ -1012,6 +1199,82 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     frames(SlParity<0>());
   }
 
+  if (ST) {
+    /* ---- park the beam for the next launch / prune / getBestHypothesis / decodeEnd: slots sorted by score (the
+     * lane-per-slot engine's format), the last history row rewritten in that order ------------------------------- */
+#ifndef FLTX_EMU
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's history records are in L2 */
+#endif
+    ldsBarrier();
+    const int pe = T & 1;
+    if (wave == 0 && T > 0) {
+      const bool live = lane < nState && !dead;
+      const SlRec me = S.rec[pe][live ? lane : 0];
+      const uint32_t sNB = live ? (me.info >> 16) & 0xFFu : kSlNoHyp, sB = live ? me.info >> 24 : kSlNoHyp;
+      const bool hasNB = sNB != kSlNoHyp, hasB = sB != kSlNoHyp;
+      const unsigned long long kNB = hasNB ? f64Key(me.nb) : 0ull, kB = hasB ? f64Key(me.b) : 0ull;
+      int rNB = 0, rB = 0;
+      for (int i = 0; i < nState; ++i) {
+        const unsigned long long k1 = ((unsigned long long)waveReadLane32((uint32_t)(kNB >> 32), i) << 32) |
+                                      waveReadLane32((uint32_t)kNB, i);
+        const unsigned long long k2 = ((unsigned long long)waveReadLane32((uint32_t)(kB >> 32), i) << 32) |
+                                      waveReadLane32((uint32_t)kB, i);
+        const uint32_t s1 = waveReadLane32(sNB, i), s2 = waveReadLane32(sB, i);
+        const bool e1 = s1 != kSlNoHyp, e2 = s2 != kSlNoHyp;
+        rNB += (e1 && (k1 > kNB || (k1 == kNB && s1 < sNB))) ? 1 : 0;
+        rNB += (e2 && (k2 > kNB || (k2 == kNB && s2 < sNB))) ? 1 : 0;
+        rB += (e1 && (k1 > kB || (k1 == kB && s1 < sB))) ? 1 : 0;
+        rB += (e2 && (k2 > kB || (k2 == kB && s2 < sB))) ? 1 : 0;
+      }
+      const int nHyp = popc64(waveBallot(hasNB)) + popc64(waveBallot(hasB));
+      const int64_t hlast = hbase + (int64_t)(frame0 + T) * K;
+      const unsigned long long* hrec = (const unsigned long long*)(P.histPT + hlast);
+      const unsigned long long recNB = hasNB ? loadCoherent64(hrec + sNB) : 0ull;
+      const unsigned long long recB = hasB ? loadCoherent64(hrec + sB) : 0ull;
+      const double aNB = S.amNB[pe][live ? lane : 0], aB = S.amB[pe][live ? lane : 0];
+      const unsigned long long mkv = S.mask[pe][live ? lane : 0];
+      const uint32_t lastTok = me.info & 0xFFu;
+      const uint32_t sparOut = me.sid == 0u ? kNoParent : me.spar;
+      const int32_t edgeOut = me.sid == 0u ? 0 : (int32_t)lastTok;
+#ifndef FLTX_EMU
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every lane has its old records before any is rewritten */
+#endif
+      waveSync();
+      auto put = [&](int r, double sc, double am, uint32_t tokpb, unsigned long long rec) {
+        const size_t g = (size_t)b * K + r;
+        P.gScore[g] = sc;
+        P.gAm[g] = am;
+        P.gLm[g] = 0.0;
+        P.gState[g] = me.sid;
+        P.gSPar[g] = sparOut;
+        P.gSEdge[g] = edgeOut;
+        P.gLex[g] = 0u;
+        P.gLexMax[g] = 0.0f;
+        P.gTokPb[g] = tokpb;
+        P.gMask[g] = mkv;
+        ((unsigned long long*)(P.histPT + hlast))[r] = rec;
+        if (P.histS) {
+          double* hs = P.histS + 3 * (hlast + r);
+          hs[0] = sc;
+          hs[1] = am;
+          hs[2] = 0.0;
+        }
+      };
+      if (hasNB) {
+        put(rNB, me.nb, aNB, lastTok, recNB);
+      }
+      if (hasB) {
+        put(rB, me.b, aB, (uint32_t)blank | kPrevBlank, recB);
+      }
+      if (lane == 0) {
+        P.uttNBeam[b] = dead ? 0 : nHyp;
+        P.uttFrame[b] = frame0 + T;
+        P.uttTotal[b] = total0 + T;
+        P.uttNextId[b] = (int32_t)S.scal[SL_NEXTID];
+        P.uttStatus[b] = P.uttStatus[b] | (int32_t)S.scal[SL_STATUS] | (dead ? ST_SELECT_FALLBACK : 0);
+      }
+    }
+  } else {
   /* ---- decodeEnd (LexiconFreeDecoder.cpp:127-158): finish() keeps the state, token = sil; the two
    * hypotheses of a state merge; sorted n-best (candidatesStore returnSorted) ------------------ */
   const int pe = T & 1;
@@ -1065,6 +1328,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     P.uttFrame[b] = ff;
     P.uttTotal[b] = ff;
     P.uttStatus[b] = ST_SELECT_FALLBACK;
+  }
   }
   if (PROF && P.prof && tid == P.profThread) {
 #pragma unroll
