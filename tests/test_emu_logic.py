@@ -46,16 +46,20 @@ XLANE = [("lx_t0", 0), ("lx_spell_t40_k8", 0), ("lx_spell_t40_k8", 640), ("lx_sp
          ("lx_uni_t40_k10", 0), ("lx_uni_t40_k10", 640)]
 
 
+@pytest.mark.parametrize("yshare", [0, 1], ids=["memo-in-lds", "memo-in-hbm"])
 @pytest.mark.parametrize("name,threads", XLANE)
-def test_emulated_lexicon_lane_engine(emu_session, golden, name, threads):
-    """fltx_xlane.h (LexiconDecoder + ZeroLM, beam <= 64): lane = (LM state, trie node)."""
+def test_emulated_lexicon_lane_engine(emu_session, golden, name, threads, yshare):
+    """fltx_xlane.h (LexiconDecoder + ZeroLM, beam <= 64): lane = (LM state, trie node); yshare = 1: the geometry
+    that shares a CU (LM-state memo in HBM)."""
     c = cases.BY_NAME[name]
     inp = helpers.case_inputs(c)
     d = emu_session.decoder(c, inp)
+    d.set("yshare", yshare)
     if threads:
         d.set("slane_threads", threads)
     d.decode_batch(inp["e"], [c["T"]], c["N"])
     assert d.get("engine") == 5 and d.get("redone") == 0 and (not threads or d.get("threads") == threads)
+    assert d.get("yshare") == yshare
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
     d.close()
     assert ok, why

@@ -87,8 +87,8 @@ def _run_batch(gpu_session, golden, oracle_lib, name0, name255, B, sample, sets=
     d.close()
 
 
-@pytest.mark.parametrize("sets,engine", [({}, 5), ({"xlane": 0}, 6), ({"xlane": 0, "ylane": 0}, 0)],
-                         ids=["lane-engine", "lane-engine-with-lm-terms", "generic-engine"])
+@pytest.mark.parametrize("sets,engine", [({}, 5), ({"yshare": 1}, 5), ({"xlane": 0}, 6), ({"xlane": 0, "ylane": 0}, 0)],
+                         ids=["lane-engine", "lane-engine-sharing-a-cu", "lane-engine-with-lm-terms", "generic-engine"])
 def test_c3_batch_of_256(gpu_session, golden, oracle_lib, sets, engine):
     """C3 as benchmarked: served by the lane = (LM state, trie node) engine (fltx_xlane.h); the
     generic engine, which takes over whenever that one does not apply, on the same batch."""

@@ -1196,7 +1196,7 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
   } else if (!strcmp(key, "ylane")) {
     *value = d->ylane;
   } else if (!strcmp(key, "yshare")) {
-    *value = d->ylane ? d->yshare : 0;
+    *value = (d->ylane || d->xlane) ? d->yshare : 0;
   } else if (!strcmp(key, "redone")) {
     *value = d->lastRedo;
   } else if (!strcmp(key, "sstream")) {
@@ -1466,6 +1466,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   /* lane = (LM state, trie node) decode (fltx_xlane.h): offline LexiconDecoder + ZeroLM over a lexicon
    * without LM scores, CTC max-merge, one word per spelling, every word ending in sil, no <unk> */
   d->xlane = 0;
+  d->yshare = 0;
   if (d->kind == FLTX_DECODER_LEXICON && !d->noXlane && !d->genericAsked && d->offlineCall && !d->keepScores && !d->opt.log_add &&
       !forceWorstCaseCap && !d->forceGlobalWs && d->lm->kind == 0 && !d->isLmToken && d->trie && d->trie->xOk &&
       d->trie->xZeroSmear && d->trie->xEndTok == d->sil && d->sil != d->blank &&
@@ -1480,6 +1481,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       if (nTok <= g[1] * (g[0] / 64 - 3)) {
         d->xlane = g[1];
         d->threads = g[0];
+        /* more utterances than CUs: the LM-state memo moves to HBM, 28 KB of LDS and 81 VGPRs let several
+         * workgroups share a CU (see the lane engine with LM terms below) */
+        d->yshare = (d->userYshare >= 0 ? d->userYshare != 0 : B > d->ctx->numCUs) ? 1 : 0;
         break;
       }
     }
@@ -1503,7 +1507,6 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const int nTokWaves = threads / 64 - ng - 2;
     const int tpw = (nTok + nTokWaves - 1) / nTokWaves;
     const int pairCap = (ng == 2 && share) ? 1024 : 512;
-    d->yshare = 0;
     if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96 && tpw * 64 * ng <= pairCap && nTokWaves <= 8) {
       d->yshare = share ? 1 : 0;
       d->ylane = ng;
@@ -1708,7 +1711,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     d->cutRecompute = 0;
   }
   if (d->xlane) {
-    d->wsBytes = sizeof(XlaneLds);
+    d->wsBytes = d->yshare ? offsetof(XlaneLds, memo) : sizeof(XlaneLds);
     d->wsInLds = true;
     lds = true;
     d->itemCap = 0;
@@ -1763,7 +1766,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     rc |= d->uttNextId.ensure(4 * (size_t)B, st, true);
     rc |= d->gMask.ensure(8 * bk, st, false);
   }
-  if (d->ylane && d->yshare) {
+  if ((d->ylane || d->xlane) && d->yshare) {
     rc |= d->ymemo.ensure(sizeof(unsigned long long) * (size_t)kYlMemo * (size_t)B, st, false); /* (wiped by the kernel) */
   }
   if (d->lm->kind == 1) {
@@ -1863,7 +1866,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xdelta = (d->trie && d->trie->xdelta.p) ? d->trie->xdelta.as<float>() : nullptr;
   P.yTpw = d->ylaneTpw;
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
-  P.ymemo = (d->ylane && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
+  P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;
@@ -2003,15 +2006,18 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   } else if (d->xlane) {
 #define FLTX_LAUNCH_XLANE(WW, GG)                                                                \
   do {                                                                                           \
-    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, false>,             \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
-    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, true>,              \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));    \
-    if (d->profile) {                                                                            \
-      hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, true>), dim3(nGrid), dim3(WW),        \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, 0, false>,          \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XlaneLds))); \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, 0, true>,           \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XlaneLds))); \
+    if (d->yshare) {                                                                             \
+      hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, 1, false>), dim3(nGrid), dim3(WW),    \
+                         d->wsBytes, d->ctx->stream, P);                                         \
+    } else if (d->profile) {                                                                     \
+      hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, 0, true>), dim3(nGrid), dim3(WW),     \
                          d->wsBytes, d->ctx->stream, P);                                         \
     } else {                                                                                     \
-      hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, false>), dim3(nGrid), dim3(WW),       \
+      hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, 0, false>), dim3(nGrid), dim3(WW),    \
                          d->wsBytes, d->ctx->stream, P);                                         \
     }                                                                                            \
   } while (0)

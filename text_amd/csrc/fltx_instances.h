@@ -46,13 +46,14 @@
   FLTX_INST(fltx_decode_kernel_slane_stream<512, 5>)         \
   FLTX_INST(fltx_decode_kernel_slane_stream<576, 10>)
 /* lane = (LM state, trie node) decode (fltx_xlane.h): three waves do not evaluate listed tokens */
-#define FLTX_XLANE_SET(PROF)                               \
-  FLTX_INST(fltx_decode_kernel_xlane<512, 2, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_xlane<640, 2, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_xlane<512, 3, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_xlane<576, 5, PROF>)        \
-  FLTX_INST(fltx_decode_kernel_xlane<640, 10, PROF>)
-#define FLTX_G12(W) FLTX_XLANE_SET(false) FLTX_XLANE_SET(true)
+#define FLTX_XLANE_SET(HM, PROF)                               \
+  FLTX_INST(fltx_decode_kernel_xlane<512, 2, HM, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<640, 2, HM, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<512, 3, HM, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<576, 5, HM, PROF>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<640, 10, HM, PROF>)
+#define FLTX_G12(W) FLTX_XLANE_SET(0, false) FLTX_XLANE_SET(0, true)
+#define FLTX_G17(W) FLTX_XLANE_SET(1, false) /* memo in HBM: shares a CU */
 /* ... with LM terms, two lane groups (fltx_ylane.h): (threads, groups, rounds, LM terms, memo in HBM = shares a CU) */
 #define FLTX_YLANE_SET(PROF)                                  \
   FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 0, 0, PROF>)  \
@@ -86,6 +87,7 @@ FLTX_G13(0)
 FLTX_G14(0)
 FLTX_G15(0)
 FLTX_G16(0)
+FLTX_G17(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -104,6 +106,7 @@ FLTX_G16(0)
 #undef FLTX_G14
 #undef FLTX_G15
 #undef FLTX_G16
+#undef FLTX_G17
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET
 #undef FLTX_SLANE_SET

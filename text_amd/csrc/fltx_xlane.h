@@ -44,6 +44,7 @@
 constexpr int kXlRoot = 128;  /* slots of the per-frame (LM state, word) merge table */
 constexpr int kXlOrph = 128;  /* slots of the per-frame table of lanes without a parent lane */
 constexpr int kXlMemo = 4096; /* slots of the LM-state memo */
+constexpr int kXlMemoH = 8192; /* ... of its HBM form: (LM state + 1) << 40 | (word + 1) << 16 | number of the child state */
 constexpr int kXlWarmBin = kSlMid + kSlMid / 4; /* candidates below this bin of the window (the last K-th sits at kSlMid) get their child node prefetched */
 
 /* the lanes of one frame, one array per field (conflict-free LDS access, and a wave reads only
@@ -94,7 +95,6 @@ struct XlaneLds {
   uint8_t tokId[2][kSlList];
   XlRootTab root;
   XlOrphTab orph[2];
-  XlMemoSlot memo[kXlMemo];
   unsigned long long bestKey[2]; /* the frame's best candidate (all waves add their own) */
   XNode rootNode;
   uint32_t off[32];
@@ -103,6 +103,10 @@ struct XlaneLds {
   unsigned long long bKey[kSlBCap];
   uint32_t bOrd[kSlBCap];
   uint32_t memoUsed, lmNext;
+  /* Last member: with more utterances than CUs (HM = 1) the memo lives in HBM (DecodeParams::ymemo, kXlMemoH
+   * packed slots as in fltx_ylane.h) and the kernel is launched with offsetof(XlaneLds, memo) bytes of LDS --
+   * 28 KB and 81 VGPRs: three workgroups of 512 threads share a CU. */
+  XlMemoSlot memo[kXlMemo];
 };
 
 enum { XL_FLAG = 15 }; /* scal[]: a table ran full -> general path */
@@ -163,7 +167,7 @@ FLTX_DEV unsigned long long xlOrphGet(const XlOrphTab& tab, unsigned long long k
   } while (0)
 
 /* GT = list positions per token wave (allowed tokens <= GT * (waves - 3)) */
-template <int GT, bool PROF>
+template <int GT, int HM, bool PROF>
 FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
   XlaneLds& S = *(XlaneLds*)smem;
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
@@ -207,8 +211,18 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     S.orph[1].key[i] = 0ull;
     S.orph[1].lanes[i] = 0ull;
   }
-  for (int i = tid; i < kXlMemo; i += W) {
-    S.memo[i].key = 0ull;
+  unsigned long long* const gmemo = HM ? P.ymemo + (size_t)(P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x) * kXlMemoH : nullptr;
+  if (HM) {
+    for (int i = tid; i < kXlMemoH; i += W) {
+      gmemo[i] = 0ull; /* (at L2 before the barrier below, where the word wave's atomics will find it) */
+    }
+#ifndef FLTX_EMU
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  } else {
+    for (int i = tid; i < kXlMemo; i += W) {
+      S.memo[i].key = 0ull;
+    }
   }
   if (tid < 32) {
     S.off[tid] = 0u;
@@ -718,6 +732,36 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       }
       if (isWord && ((selMask[0] >> lane) & 1ull)) {
         /* the LM state's number (memo: the same (LM state, word) gives the same state back) */
+        if (HM) {
+          const unsigned long long mkey = ((unsigned long long)(lmSid + 1u) << 24) | (unsigned long long)(uint32_t)(endLabel + 1);
+          uint32_t h = xlHash(mkey) & (kXlMemoH - 1);
+          bool have = false; /* a number was taken from the counter for this state */
+          for (int probe = 0;; ++probe) {
+            unsigned long long cur = loadCoherent64(&gmemo[h]);
+            if (cur == 0ull) {
+              if (!have) {
+                rootSid = atomAdd32(&S.lmNext, 1u);
+                have = true;
+              }
+              cur = atomCas64(&gmemo[h], 0ull, (mkey << 16) | (unsigned long long)(rootSid & 0xFFFFu));
+              if (cur == 0ull) { /* a new LM state */
+                if (rootSid > (uint32_t)(kXlMemoH * 3 / 4) || rootSid >= 0xFFFFu || (uint32_t)(endLabel + 1) >= (1u << 24)) {
+                  atomOr32(&S.scal[XL_FLAG], 1u);
+                }
+                break;
+              }
+            }
+            if ((cur >> 16) == mkey) { /* (a number taken in vain stays unused) */
+              rootSid = (uint32_t)(cur & 0xFFFFull);
+              break;
+            }
+            h = (h + 1u) & (kXlMemoH - 1);
+            if (probe > kXlMemoH) {
+              atomOr32(&S.scal[XL_FLAG], 1u);
+              break;
+            }
+          }
+        } else {
         const unsigned long long mkey = xlKey(lmSid, endLabel);
         uint32_t h = xlHash(mkey) & (kXlMemo - 1);
         for (int probe = 0;; ++probe) {
@@ -739,6 +783,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
             atomOr32(&S.scal[XL_FLAG], 1u);
             break;
           }
+        }
         }
         rootOrph = xlOrphGet(S.orph[p], xlKey(rootSid, 0));
       }

@@ -35,7 +35,8 @@
 constexpr int kYlLanes = 128;
 constexpr int kYlRoot = 256;  /* slots of the per-frame (LM state, word) merge table */
 constexpr int kYlOrph = 256;  /* slots of the per-frame table of lanes without a parent lane */
-constexpr int kYlMemo = 8192; /* slots of the LM-state memo: (LM state + 1) << 40 | (word + 1) << 16 | number of the child state */
+constexpr int kYlMemo = 8192;
+static_assert(kYlMemo == kXlMemoH, "DecodeParams::ymemo is sized for either engine"); /* slots of the LM-state memo: (LM state + 1) << 40 | (word + 1) << 16 | number of the child state */
 constexpr int kYlTokWaves = 8;
 constexpr int kYlPairs = 512; /* (lane, token) pairs a token wave can list: positions per wave x lanes */
 constexpr uint32_t kYlNoLm = 0x7FC00001u; /* endLm: not looked up yet (a NaN no arithmetic produces) */
