@@ -1697,7 +1697,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   d->wsInLds = lds;
   if (d->slane) {
-    d->wsBytes = sizeof(SlaneLds);
+    d->wsBytes = offsetof(SlaneLds, amNB); /* (the stream variant's arrays are its last members) */
     d->wsInLds = true;
     lds = true;
   }
@@ -2185,7 +2185,8 @@ int launchBacktrace(fltx_decoder* d) {
   const int btThreads = 512;
 #endif
   const size_t perFrame = (size_t)Q.K * (2 * (8 + (d->kind == FLTX_DECODER_LEXICON ? 4 : 0)) + 8);
-  const size_t btBudget = (size_t)(d->btLdsKb > 0 ? std::min(d->btLdsKb, 144) : 144) * 1024;
+  /* 140 KB: leaves a CU room for a 16 KB decode workgroup of the next batch beside a back-trace workgroup */
+  const size_t btBudget = (size_t)(d->btLdsKb > 0 ? std::min(d->btLdsKb, 144) : 140) * 1024;
   int F = (int)std::min<size_t>(btBudget / perFrame, 512);
   if (d->batchPacked) { /* the emission rows, transitions and addends of a chunk share the same LDS (amLds below) */
     const size_t fixed = 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;

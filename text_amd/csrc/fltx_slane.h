@@ -108,10 +108,12 @@ struct SlaneLds {
   uint32_t evLane[64], evSpar[64], evTok[64];
   unsigned long long scanMask;
   unsigned long long mmaxKey[2]; /* logAdd: order key of the best hypothesis of the beam a frame starts from */
-  double amNB[2][64], amB[2][64]; /* streams: emitting-model score of a state's two hypotheses */
-  uint8_t rsNB[64], rsB[64];      /* streams, restore: the parked slot of a lane's two hypotheses */
   uint32_t scanMin, pad0;
   float raw[3][64]; /* emission rows on their way in: row r lands in raw[r % 3] two frames before it is staged */
+  /* Last members, streams only (ST): an offline launch takes offsetof(SlaneLds, amNB) bytes -- 16 KB, so that its
+   * workgroup and a back-trace workgroup of the batch before (140 KB) fit a CU together */
+  double amNB[2][64], amB[2][64]; /* emitting-model score of a state's two hypotheses */
+  uint8_t rsNB[64], rsB[64];      /* restore: the parked slot of a lane's two hypotheses */
 };
 enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2, SL_NEXTID = 3, SL_STATUS = 4, SL_NSTATE = 5 };
 
