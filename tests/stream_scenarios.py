@@ -107,3 +107,14 @@ def first_difference(want, got):
             keys = [k for k in a if a.get(k) != b.get(k)]
             return "event %d (%s) differs in %s" % (i, a.get("frames_done", "final"), keys)
     return None
+
+
+def has_ties(trace):
+    """True if some buffer of the trace holds two hypotheses of equal score (their order is then not defined)."""
+    for e in trace:
+        for buf in (e.get("final"), (e.get("after_prune") or {}).get("buffer")):
+            if buf:
+                sc = [x[0] for x in buf["scores"]]
+                if len(set(sc)) != len(sc):
+                    return True
+    return False

@@ -109,8 +109,12 @@ def _random_lexfree_streams(session, oracle_lib, every):
         c = cases.case("ss%d" % i, dist=dist, u=700 + i, T=T, N=N, K=K, Kt=Kt, thr=thr, sil_score=sil, crit=crit,
                        trans_seed=(30 + i) if crit == "asg" else None)
         inp = helpers.case_inputs(c)
-        chunks, lbs = [3, 9, 1, 12, 20, 30], [0, 2, 0, 5]
+        # (one-frame chunks: every frame is a launch's last -- a state entered again there is parked before the
+        # next frame's relink could run)
+        chunks, lbs = [[3, 9, 1, 12, 20, 30], [1] * 60, [25, 25, 25]][i % 3], [[0, 2, 0, 5], [0], [3, 1]][i % 3]
         want = ss.trace_checker(oracle_lib, c, inp, chunks, lbs)
+        if ss.has_ties(want):
+            continue  # (equal scores in a buffer: the order of the reference's own result is not defined)
         got, _ = ss.trace_device(session, c, inp, chunks, lbs)
         ran += 1
         d = ss.first_difference(want, got)
@@ -136,6 +140,6 @@ def test_lexfree_stream_chunks_on_the_lane_state_engine_emulated(emu_session, or
 @pytest.mark.gpu
 def test_lexfree_stream_chunks_on_the_lane_state_engine(gpu_session, oracle_lib, stream_golden):
     ran, bad = _random_lexfree_streams(gpu_session, oracle_lib, 3)
-    assert ran > 300 and not bad, bad[:3]
+    assert ran > 280 and not bad, bad[:3]
     # the lane-per-slot step (sstream = 0) still serves the same streams
     _device(gpu_session, stream_golden, "C1_ctc_u0", tunables=[("sstream", 0)])

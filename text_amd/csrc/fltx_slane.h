@@ -1210,6 +1210,16 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     ldsBarrier();
     const int pe = T & 1;
     if (wave == 0 && T > 0) {
+      /* states entered again in the last frame: the relink of the next frame never runs -- their child masks come
+       * from maskTab now (the links are found again by the restore) */
+      const int nevEnd = (int)S.row[pe].nev;
+      for (int e = 0; e < nevEnd; ++e) {
+        if (lane == 0) {
+          const int X = (int)S.evLane[e];
+          S.mask[pe][X] |= loadCoherent64(&P.maskTab[(size_t)b * P.idCap + S.rec[pe][X].sid]);
+        }
+      }
+      waveSync();
       const bool live = lane < nState && !dead;
       const SlRec me = S.rec[pe][live ? lane : 0];
       const uint32_t sNB = live ? (me.info >> 16) & 0xFFu : kSlNoHyp, sB = live ? me.info >> 24 : kSlNoHyp;
