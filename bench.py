@@ -347,7 +347,8 @@ def main():
         dist.destroy_process_group()
     # a line whose n-best differs from the reference's, or that spent its time in fallbacks,
     # must not look green
-    mism = out.get("cpu_baseline", {}).get("gpu_nbest_mismatches_on_sample", 0)
+    mism = out.get("cpu_baseline", {}).get("gpu_nbest_mismatches_on_sample", 0) + \
+        out.get("streaming", {}).get("final_nbest_mismatches_vs_cpu_on_sample", 0)
     if mism:
         raise SystemExit("bench.py: %d of the sampled utterances differ from the CPU reference" % mism)
     if redone * 4 > B:
@@ -594,6 +595,7 @@ def streaming(job, B, T, N, chunk=50):
     best = None
     # the chunks as a caller's audio front end would hand them over: contiguous [B, chunk, N] host arrays
     pieces = [np.ascontiguousarray(job.e_host[:, k * chunk:(k + 1) * chunk, :]) for k in range(nchunk)]
+    d.set("stream_total_frames", T)  # (LM-state ids are created for as long as the stream runs: T frames, not the buffer's)
     for rep in range(2):
         d.stream_begin(B, N, 4 * chunk + 8)
         job.ctx.synchronize()
@@ -609,12 +611,34 @@ def streaming(job, B, T, N, chunk=50):
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     redone = d.get("stream_redone")
+    # the streams' final n-best (what is left in the buffer after the last prune) against the reference CPU fed the
+    # same chunks, on the first streams; fetching a result also raises if a stream's status is not clean
+    cpu = CpuSide(job)
+    mism, n_chk = 0, min(B, 2 if job.arpa else 4)
+    for b in range(n_chk):
+        rd, rlm = cpu.new_decoder()
+        cpu.lib.decoder_begin(rd)
+        for k in range(nchunk):
+            cpu.lib.decoder_step(rd, pieces[k][b].ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_float)),
+                                 chunk, N)
+            cpu.lib.decoder_prune(rd, 0)
+        cpu.lib.decoder_end(rd)
+        want = cpu.lib.collect(rd)
+        cpu.free(rd, rlm)
+        got = d.results(b)
+        same = len(got) == len(want) and all(
+            g.score == h.score and g.am == h.am and np.array_equal(g.tokens, h.tokens) and
+            np.array_equal(g.words, h.words) for g, h in zip(got, want))
+        mism += 0 if same else 1
+    for b in range(n_chk, B, max(1, B // 16)):
+        d.results(b)  # (status check)
     d.close()
     lat = np.sort(np.array(lat[len(lat) // 2:]))
     return {"value": B * nchunk * chunk / best, "unit": "frames/s", "streams": B, "chunk_frames": chunk,
             "chunk_latency_ms_median": float(np.median(lat) * 1e3),
             "chunk_latency_ms_p95": float(lat[int(0.95 * (len(lat) - 1))] * 1e3),
             "stream_chunks_decoded_again": redone,
+            "final_nbest_mismatches_vs_cpu_on_sample": mism, "streams_checked": n_chk,
             "note": "stream_step(50 frames, host emissions) + prune(0) + synchronize per chunk; lexicon streams start "
                     "every chunk on the LDS-sized geometry and decode it again from the saved beam if a list overflows"}
 

@@ -143,3 +143,25 @@ def test_lexfree_stream_chunks_on_the_lane_state_engine(gpu_session, oracle_lib,
     assert ran > 280 and not bad, bad[:3]
     # the lane-per-slot step (sstream = 0) still serves the same streams
     _device(gpu_session, stream_golden, "C1_ctc_u0", tunables=[("sstream", 0)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sstream", [1, 0], ids=["lane-state-engine", "lane-per-slot-step"])
+def test_long_stream_through_a_small_buffer(gpu_session, oracle_lib, sstream):
+    """1 000 frames in 50-frame chunks with prune(0) through a 208-frame buffer (bench.py's streaming leg): LM states
+    are created for as long as the stream runs, so the id tables follow `stream_total_frames` (default: at least 2 048
+    frames), not max_frames -- round 2 sized them by the buffer and such a stream ended with a full table."""
+    import numpy as np
+    c = cases.case("cap", T=1000, K=50, N=29, u=5)
+    inp = helpers.case_inputs(c)
+    want = ss.trace_checker(oracle_lib, c, inp, [50] * 20, [0])
+    d = gpu_session.decoder(c, inp)
+    d.set("sstream", sstream)
+    d.stream_begin(1, 29, 208)
+    for k in range(20):
+        d.stream_step(np.ascontiguousarray(inp["e"][k * 50:(k + 1) * 50]), [50])
+        d.stream_prune(0)
+    d.stream_end()
+    got = helpers.encode_hyps(d.results(0), True)
+    d.close()
+    assert got == want[-1]["final"]

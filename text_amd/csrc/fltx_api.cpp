@@ -402,6 +402,7 @@ struct fltx_decoder {
   const fltx_lm* xlmwordLm = nullptr;
   int ylane = 0, noYlane = 0, ylaneLm = 0, ylaneRounds = 0, ylaneTpw = 0; /* ylane: lane groups of fltx_ylane.h (0 = not used) */
   int btLdsKb = 0;
+  int streamTotalFrames = 0; /* frames a stream will decode in all (sizes its LM-state id tables), 0 = default */
   /* stream chunks of the lexicon-free decoder on the lane = LM state engine (fltx_slane.h, ST): list positions per
    * token wave (0 = not used) and threads; begin / end / prune / best stay the lane-per-slot engine's */
   int sstream = 0, sstreamThreads = 0, noSstream = 0;
@@ -1293,6 +1294,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noXlane = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "stream_total_frames")) { /* before fltx_stream_begin: see prepare() */
+    d->streamTotalFrames = (int)value;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "sstream")) { /* 0: stream chunks stay on the lane-per-slot step (fltx_lane.h) */
     d->noSstream = value ? 0 : 1;
     return FLTX_OK;
@@ -1383,8 +1388,15 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   d->histOff[B] = off;
   d->histRecords = off;
-  uint64_t wantStates = 2ull * ((uint64_t)K * (uint64_t)(maxT + 2) + 2);
+  /* LM states are created for as long as a stream runs, not for as long as its frames stay buffered: the id
+   * tables of a stream are sized for `stream_total_frames` (default: at least 2 048 frames; a longer stream says
+   * so before fltx_stream_begin, or its status reports a full table), the history for max_frames */
+  const int idT = d->offlineCall ? maxT : std::max(maxT, d->streamTotalFrames > 0 ? d->streamTotalFrames : 2048);
+  uint64_t wantStates = 2ull * ((uint64_t)K * (uint64_t)(idT + 2) + 2);
   uint32_t cap = nextPow2(std::max<uint64_t>(wantStates, 1024));
+  if (cap > (1u << 23) && !d->offlineCall) { /* (a stream takes what the id width allows) */
+    cap = 1u << 23;
+  }
   if (cap > (1u << 23)) {
     return fail(FLTX_ERR_UNSUPPORTED, "K * T = %llu exceeds the 2^23 LM states per utterance this build indexes",
                 (unsigned long long)K * (maxT + 2));
@@ -1760,7 +1772,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     rc |= d->gws.ensure(d->wsBytes * (size_t)B, st, false);
   }
   if (d->lean && !d->slane) {
-    d->idCap = (int64_t)K * (maxT + 2) + 2;
+    d->idCap = std::min<int64_t>((int64_t)K * (idT + 2) + 2, (1ll << 23) - 2);
     rc |= d->childTab.ensure(4 * (size_t)B * d->idCap * N, st, false);
     rc |= d->maskTab.ensure(8 * (size_t)B * d->idCap, st, false);
     rc |= d->uttNextId.ensure(4 * (size_t)B, st, true);
@@ -2700,6 +2712,17 @@ int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
   d->hostFetched = false;
   d->compactFetched = false;
   d->scoresFetched = false;
+  if (d->kind == FLTX_DECODER_LEXFREE) {
+    /* every hypothesis of the lexicon-free decoder is complete (LexiconFreeDecoder.h:84-86): findBestAncestor stops
+     * exactly lookBack frames back, so what stays buffered is known without asking the device (no wait per chunk;
+     * fltx_stream_frames_in_buffer still reads the device's count) */
+    for (int b = 0; b < d->B; ++b) {
+      if (d->frames[b] - lookBack >= 1) {
+        d->frames[b] = lookBack;
+      }
+    }
+    return FLTX_OK;
+  }
   if ((rc = syncResults(d))) {
     return rc;
   }
