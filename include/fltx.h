@@ -299,7 +299,13 @@ FLTX_API int fltx_decoder_profile(fltx_decoder* dec, uint64_t* out);
  * lexicon decoder; "ylane" = 2 prefers fltx_ylane.h where both apply), "keep_scores", "profile", "profile_wave"; lexicon decoder: "cut" (0 = build
  * every candidate's record), "slim" (0 = recompute form of the cut-off
  * generation), "items" (0 = no child-mask item list); test hooks: "cut_m",
- * "lds_budget" (pretend the CU has fewer bytes of LDS), "hot_level". */
+ * "lds_budget" (pretend the CU has fewer bytes of LDS), "hot_level".
+ * Round 3: "yshare" (-1 = the lexicon lane engines take the geometry of which several workgroups share a CU when the
+ * batch exceeds the CUs; 1 / 0 = always / never), "stream_total_frames" (set before fltx_stream_begin: frames the
+ * stream will decode in all -- its LM-state id tables grow with the stream, not with max_frames; default: at least
+ * 2048), "sstream" (0 = a lexicon-free stream's chunks stay on the lane-per-slot step), "stream_optimistic" (0 = lexicon
+ * streams use the worst-case HBM workspace from the start instead of decoding an overflowing chunk again),
+ * "bt_lds_kb".  fltx_decoder_get also answers "engine", "redone", "stream_redone", "yshare", "sstream". */
 FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
 /* Geometry chosen for the last batch: "engine" (0 generic hash merge, 1 generic
  * dense merge, 2 lean register-resident step, 3 lane-per-slot step, 4 lane = LM
