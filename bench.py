@@ -592,11 +592,14 @@ def streaming(job, B, T, N, chunk=50):
     Tc = np.full(B, chunk, dtype=np.int32)
     nchunk = T // chunk
     lat = []
-    best = None
+    best = best_wait = None
     # the chunks as a caller's audio front end would hand them over: contiguous [B, chunk, N] host arrays
     pieces = [np.ascontiguousarray(job.e_host[:, k * chunk:(k + 1) * chunk, :]) for k in range(nchunk)]
     d.set("stream_total_frames", T)  # (LM-state ids are created for as long as the stream runs: T frames, not the buffer's)
-    for rep in range(2):
+    for rep in range(3):
+        # rep 0, 1: every chunk waited for (its latency); rep 2: the caller hands over the next chunk as soon as the
+        # call returns -- the chunk's H2D then runs under the previous chunk's kernel (copy stream, two slots)
+        wait_each = rep < 2
         d.stream_begin(B, N, 4 * chunk + 8)
         job.ctx.synchronize()
         t0 = time.perf_counter()
@@ -604,12 +607,16 @@ def streaming(job, B, T, N, chunk=50):
             tc = time.perf_counter()
             d.stream_step(pieces[k], Tc)
             d.stream_prune(0)
-            job.ctx.synchronize()
-            lat.append(time.perf_counter() - tc)
+            if wait_each:
+                job.ctx.synchronize()
+                lat.append(time.perf_counter() - tc)
         d.stream_end()
         job.ctx.synchronize()
         dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
+        if wait_each:
+            best_wait = dt if rep == 0 else min(best_wait, dt)
+        else:
+            best = dt
     redone = d.get("stream_redone")
     # the streams' final n-best (what is left in the buffer after the last prune) against the reference CPU fed the
     # same chunks, on the first streams; fetching a result also raises if a stream's status is not clean
@@ -635,11 +642,14 @@ def streaming(job, B, T, N, chunk=50):
     d.close()
     lat = np.sort(np.array(lat[len(lat) // 2:]))
     return {"value": B * nchunk * chunk / best, "unit": "frames/s", "streams": B, "chunk_frames": chunk,
+            "value_waiting_for_every_chunk": B * nchunk * chunk / best_wait,
             "chunk_latency_ms_median": float(np.median(lat) * 1e3),
             "chunk_latency_ms_p95": float(lat[int(0.95 * (len(lat) - 1))] * 1e3),
             "stream_chunks_decoded_again": redone,
             "final_nbest_mismatches_vs_cpu_on_sample": mism, "streams_checked": n_chk,
-            "note": "stream_step(50 frames, host emissions) + prune(0) + synchronize per chunk; lexicon streams start "
+            "note": "stream_step(50 frames, host emissions) + prune(0) per chunk; value: chunks handed over back to back "
+                    "(results read at the end), value_waiting_for_every_chunk / latencies: a synchronize after every "
+                    "chunk; lexicon streams start "
                     "every chunk on the LDS-sized geometry and decode it again from the saved beam if a list overflows"}
 
 

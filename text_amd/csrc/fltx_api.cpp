@@ -428,7 +428,11 @@ struct fltx_decoder {
   size_t wsBytes = 0;
   bool wsInLds = true;
   /* device buffers */
-  DBuf emis, emOff, stepT, histOffD, histPT, histW, stateTab, stateCtx;
+  /* what a step uploads, in two slots taking turns: the upload of step k + 1 runs on a copy stream under the kernel of
+   * step k (which reads the other slot) */
+  DBuf emis[2], emOff[2], stepT[2];
+  int upSlot = 0;
+  DBuf histOffD, histPT, histW, stateTab, stateCtx;
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
@@ -458,6 +462,9 @@ struct fltx_decoder {
   /* HIP events on the launch stream bracketing the two kernels of the last
    * fltx_decode_batch (bench.py's roofline leg reads them) */
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipStream_t copyStream = nullptr;
+  hipEvent_t evSlotFree[2] = {nullptr, nullptr}; /* recorded on the launch stream once everything that reads a slot is queued */
+  bool slotUsed[2] = {false, false};
 #endif
   bool timed = false;
 };
@@ -1180,6 +1187,12 @@ int fltx_decoder_destroy(fltx_decoder* d) {
         (void)hipEventDestroy(d->ev[i]);
       }
     }
+    if (d->copyStream) {
+      (void)hipStreamSynchronize(d->copyStream);
+      (void)hipEventDestroy(d->evSlotFree[0]);
+      (void)hipEventDestroy(d->evSlotFree[1]);
+      (void)hipStreamDestroy(d->copyStream);
+    }
 #endif
   }
   delete d;
@@ -1767,7 +1780,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   rc |= d->uttNBeam.ensure(4 * (size_t)B, st, true) | d->uttFrame.ensure(4 * (size_t)B, st, true);
   rc |= d->uttTotal.ensure(4 * (size_t)B, st, true) | d->uttStatus.ensure(4 * (size_t)B, st, true);
   rc |= d->outN.ensure(4 * (size_t)B, st, true) | d->outScores.ensure(8 * bk * 3, st, false);
-  rc |= d->emOff.ensure(sizeof(int64_t) * (size_t)B, st, false) | d->stepT.ensure(4 * (size_t)B, st, false);
+  for (int u = 0; u < 2; ++u) {
+    rc |= d->emOff[u].ensure(sizeof(int64_t) * (size_t)B, st, false) | d->stepT[u].ensure(4 * (size_t)B, st, false);
+  }
   if (!lds) {
     rc |= d->gws.ensure(d->wsBytes * (size_t)B, st, false);
   }
@@ -1831,8 +1846,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.lmEos = d->lm->eos;
   P.lmUnk = d->lm->unk;
   P.stateCtx = d->stateCtx.as<int32_t>();
-  P.emOff = d->emOff.as<int64_t>();
-  P.stepT = d->stepT.as<int32_t>();
+  P.emOff = d->emOff[d->upSlot].as<int64_t>();
+  P.stepT = d->stepT[d->upSlot].as<int32_t>();
   P.uttNBeam = d->uttNBeam.as<int32_t>();
   P.uttFrame = d->uttFrame.as<int32_t>();
   P.uttTotal = d->uttTotal.as<int32_t>();
@@ -2106,26 +2121,53 @@ int uploadStep(fltx_decoder* d, const float* emissions, int onDevice, const int6
   if (maxEnd > 0 && !emissions) {
     return fail(FLTX_ERR_INVALID, "emissions is null");
   }
+#ifdef FLTX_EMU
+  const int slot = d->upSlot;
+  Stream cs = st;
+#else
+  /* Stream chunks go to the other slot on a copy stream: it waits for what read that slot two steps ago, not for
+   * the kernel of the step before, which is still running (the chunk's H2D under the previous chunk's kernel).
+   * Offline batches upload on the launch stream as before (two decoder objects overlap them: bench.py). */
+  int slot = d->upSlot;
+  Stream cs = st;
+  if (!d->offlineCall) {
+    if (!d->copyStream) {
+      HIPCHK(hipStreamCreateWithFlags(&d->copyStream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&d->evSlotFree[0], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&d->evSlotFree[1], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(d->evSlotFree[d->upSlot], st)); /* everything queued so far may read the current slot */
+    d->slotUsed[d->upSlot] = true;
+    slot = d->upSlot ^ 1;
+    cs = d->copyStream;
+    if (d->slotUsed[slot]) {
+      HIPCHK(hipStreamWaitEvent(cs, d->evSlotFree[slot], 0));
+    }
+  }
+#endif
   if (onDevice) {
     P.emissions = emissions;
   } else {
-    if (d->emis.ensure(sizeof(float) * (size_t)std::max<int64_t>(maxEnd, 1), st, false)) {
+    if (d->emis[slot].ensure(sizeof(float) * (size_t)std::max<int64_t>(maxEnd, 1), st, false)) {
       return fail(FLTX_ERR_OOM, "emissions staging allocation failed");
     }
-    if (maxEnd > 0 && devCopyH2D(d->emis.p, emissions, sizeof(float) * (size_t)maxEnd, st)) {
+    if (maxEnd > 0 && devCopyH2D(d->emis[slot].p, emissions, sizeof(float) * (size_t)maxEnd, cs)) {
       return fail(FLTX_ERR_HIP, "emissions upload failed");
     }
-    P.emissions = d->emis.as<float>();
+    P.emissions = d->emis[slot].as<float>();
   }
   d->lastEmis = P.emissions;
-  if (devCopyH2D(d->emOff.p, offs.data(), sizeof(int64_t) * B, st) ||
-      devCopyH2D(d->stepT.p, T, sizeof(int32_t) * B, st)) {
+  if (devCopyH2D(d->emOff[slot].p, offs.data(), sizeof(int64_t) * B, cs) ||
+      devCopyH2D(d->stepT[slot].p, T, sizeof(int32_t) * B, cs)) {
     return fail(FLTX_ERR_HIP, "batch descriptor upload failed");
   }
+  d->upSlot = slot;
+  P.emOff = d->emOff[slot].as<int64_t>();
+  P.stepT = d->stepT[slot].as<int32_t>();
 #ifndef FLTX_EMU
-  /* the H2D copies above read pageable host memory that only lives for this
-   * call (offs); make sure they have been consumed */
-  if (devSync(st)) {
+  /* the H2D copies above read pageable host memory that only lives for this call (offs); when the copy stream is
+   * drained they have been consumed -- and are in place for the launch that follows on the other stream */
+  if (devSync(cs)) {
     return fail(FLTX_ERR_HIP, "stream synchronize failed");
   }
 #endif
@@ -2219,7 +2261,7 @@ int launchBacktrace(fltx_decoder* d) {
     Q.uttStatus = d->uttStatus.as<int32_t>();
     Q.amOut = d->outScores.as<double>();
     Q.emissions = d->lastEmis;
-    Q.emOff = d->emOff.as<int64_t>();
+    Q.emOff = d->emOff[d->upSlot].as<int64_t>();
     Q.N = d->N;
     Q.transitions = (d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? d->transitions.as<float>() : nullptr;
     const size_t amLds = 4 * ((size_t)F * d->N + (Q.transitions ? (size_t)d->N * d->N : 0) + (size_t)Q.K * F) + 16;
