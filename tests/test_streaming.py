@@ -165,3 +165,67 @@ def test_long_stream_through_a_small_buffer(gpu_session, oracle_lib, sstream):
     got = helpers.encode_hyps(d.results(0), True)
     d.close()
     assert got == want[-1]["final"]
+
+
+def _ragged_parallel_streams(session, oracle_lib, name, sets=()):
+    """Several streams of one decoder fed chunks of different lengths (some of them empty) in the same calls: every
+    stream's getBestHypothesis / final n-best against the oracle run on that stream alone."""
+    import numpy as np
+    from text_amd import synth
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    N, B = c["N"], 4
+    Ts = [c["T"], c["T"] // 2, 7, c["T"] - 3]
+    lex = inp["lex"] if c["dist"] == "lexspell" else None
+    es = [synth.emissions(c["dist"], 900 + b, Ts[b], N, lexicon=lex) for b in range(B)]
+    plan = [[5, 0, 3, 9], [7, 11, 0, 1], [0, 4, 4, 20], [30, 30, 30, 30], [100, 100, 100, 100]]
+    ods = [ss.checker_decoder(oracle_lib, c, inp) for _ in range(B)]
+    for od, _, _ in ods:
+        oracle_lib.decoder_begin(od)
+    d = session.decoder(c, inp)
+    for k, v in sets:
+        d.set(k, v)
+    d.stream_begin(B, N, max(Ts) + 4)
+    done = [0] * B
+    for step, row in enumerate(plan):
+        take = [min(row[b], Ts[b] - done[b]) for b in range(B)]
+        parts = [es[b][done[b]:done[b] + take[b]] for b in range(B)]
+        flat = np.concatenate([p.reshape(-1) for p in parts]) if sum(take) else np.zeros(1, np.float32)
+        d.stream_step(flat.astype(np.float32), take)
+        for b in range(B):
+            if take[b]:
+                oracle_lib.decoder_step(ods[b][0], orclib_fp(np.ascontiguousarray(parts[b])), take[b], N)
+            done[b] += take[b]
+        for b in range(B):
+            want = oracle_lib.best(ods[b][0], step % 3, max(Ts) + 8)
+            got = d.best(b, step % 3, max(Ts) + 8)
+            assert ss._enc_one(want) == ss._enc_one(got), "stream %d after call %d" % (b, step)
+        if step == 2:
+            d.stream_prune(1)
+            for od, _, _ in ods:
+                oracle_lib.decoder_prune(od, 1)
+    d.stream_end()
+    for b in range(B):
+        oracle_lib.decoder_end(ods[b][0])
+        ok, why = helpers.hyps_equal(oracle_lib.collect(ods[b][0]), d.results(b))
+        assert ok, "stream %d: %s" % (b, why)
+        oracle_lib.decoder_destroy(ods[b][0])
+    d.close()
+
+
+def orclib_fp(a):
+    from oracle import orclib
+    return orclib._fp(a)
+
+
+def test_ragged_parallel_streams_emulated(emu_session, oracle_lib):
+    _ragged_parallel_streams(emu_session, oracle_lib, "lf_ctc_t60_k10")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,sets", [("lf_ctc_t60_k10", ()), ("lf_ctc_t60_k10", (("sstream", 0),)),
+                                       ("C1_ctc_u0", ()), ("lf_asg_t40_n29_kt7", ()), ("lx_spell_t60_k12_full", ()),
+                                       ("ng_word_t60_k16_4g", ()), ("ng_word_t60_k16_4g", (("cut_m", 17),))],
+                         ids=lambda x: x if isinstance(x, str) else None)
+def test_ragged_parallel_streams(gpu_session, oracle_lib, name, sets):
+    _ragged_parallel_streams(gpu_session, oracle_lib, name, sets)
