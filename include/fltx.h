@@ -305,7 +305,9 @@ FLTX_API int fltx_decoder_profile(fltx_decoder* dec, uint64_t* out);
  * stream will decode in all -- its LM-state id tables grow with the stream, not with max_frames; default: at least
  * 2048), "sstream" (0 = a lexicon-free stream's chunks stay on the lane-per-slot step), "stream_optimistic" (0 = lexicon
  * streams use the worst-case HBM workspace from the start instead of decoding an overflowing chunk again),
- * "bt_lds_kb".  fltx_decoder_get also answers "engine", "redone", "stream_redone", "yshare", "sstream". */
+ * "stream_defer" (0 = fltx_stream_step of a lexicon stream waits for its chunk; default: the chunk is launched and whether
+ * a stream has to decode it again is looked at by the next call that needs the beam -- the next chunk's upload runs
+ * under the kernel; a deferred fltx_stream_prune reports its errors there too), "bt_lds_kb".  fltx_decoder_get also answers "engine", "redone", "stream_redone", "yshare", "sstream". */
 FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
 /* Geometry chosen for the last batch: "engine" (0 generic hash merge, 1 generic
  * dense merge, 2 lean register-resident step, 3 lane-per-slot step, 4 lane = LM

@@ -225,7 +225,8 @@ def test_ragged_parallel_streams_emulated(emu_session, oracle_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,sets", [("lf_ctc_t60_k10", ()), ("lf_ctc_t60_k10", (("sstream", 0),)),
                                        ("C1_ctc_u0", ()), ("lf_asg_t40_n29_kt7", ()), ("lx_spell_t60_k12_full", ()),
-                                       ("ng_word_t60_k16_4g", ()), ("ng_word_t60_k16_4g", (("cut_m", 17),))],
+                                       ("ng_word_t60_k16_4g", ()), ("ng_word_t60_k16_4g", (("cut_m", 17),)),
+                                       ("ng_word_t60_k16_4g", (("cut_m", 17), ("stream_defer", 0)))],
                          ids=lambda x: x if isinstance(x, str) else None)
 def test_ragged_parallel_streams(gpu_session, oracle_lib, name, sets):
     _ragged_parallel_streams(gpu_session, oracle_lib, name, sets)

@@ -117,8 +117,8 @@ __global__ void __launch_bounds__(256) fltx_pack_results_kernel(PackParams Q) {
     }
   }
 }
-__global__ void fltx_streamop_kernel(StreamOpParams Q) {
-  __shared__ int32_t sh[4];
+__global__ void __launch_bounds__(1024) fltx_streamop_kernel(StreamOpParams Q) {
+  __shared__ int32_t sh[kStreamOpLds / 4];
   streamOpUtterance(Q, sh);
 }
 #endif
@@ -383,6 +383,14 @@ struct fltx_decoder {
   int maxFrames = 0;
   std::vector<int32_t> T;       /* frames given in the last step */
   std::vector<int32_t> frames;  /* host mirror of uttFrame after sync */
+  bool framesExact = true;       /* false: frames[] is an upper bound (lexicon prunes not yet asked about) */
+  /* an optimistic stream chunk is launched and left alone: whether it has to be decoded again is looked at by the next
+   * call that needs the beam (settleStream), so the next chunk's upload runs under this chunk's kernel */
+  bool chunkPending = false, settling = false;
+  const float* pendEmis = nullptr;
+  int pendSlot = 0;
+  int pendingPrune = -1;         /* prune(lookBack) asked for while the chunk was pending: runs right after the look */
+  int deferRedo = 1;             /* tunable stream_defer: 0 = look at every chunk before fltx_stream_step returns */
   std::vector<int64_t> histOff; /* records */
   int64_t histRecords = 0;
   uint32_t stateCap = 0;
@@ -443,6 +451,7 @@ struct fltx_decoder {
   HBuf hTokens, hWords, hScores; /* fltx_result_fetch_batch */
   HBuf hTok8, hWordsC, hPackMeta;  /* fltx_result_fetch_batch_compact */
   HBuf hSync;                      /* syncResults */
+  HBuf hStat;                      /* DecodeParams::statusHost */
   DBuf dTok8, dWordsC, dPackMeta;
   std::vector<int64_t> packOff;
   bool compactFetched = false, scoresFetched = false;
@@ -1319,6 +1328,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->userStreamOpt = (int)value;
     return FLTX_OK;
   }
+  if (!strcmp(key, "stream_defer")) { /* 0: fltx_stream_step waits for its chunk and decodes it again there if it must */
+    d->deferRedo = value ? 1 : 0;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "bt_lds_kb")) { /* LDS the back-trace kernel stages history chunks in (0: 144 KB) */
     d->btLdsKb = (int)value;
     return FLTX_OK;
@@ -1894,6 +1907,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.yTpw = d->ylaneTpw;
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
   P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
+  P.statusHost = (!d->offlineCall && d->streamOpt) ? (int32_t*)d->hStat.p : nullptr;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;
@@ -2174,7 +2188,15 @@ int uploadStep(fltx_decoder* d, const float* emissions, int onDevice, const int6
   return FLTX_OK;
 }
 
+int settleStream(fltx_decoder* d);
+
 int syncResults(fltx_decoder* d) {
+  if (!d->settling && (d->chunkPending || d->pendingPrune >= 0)) {
+    int rc = settleStream(d);
+    if (rc) {
+      return rc;
+    }
+  }
   if (d->resultsSynced) {
     return FLTX_OK;
   }
@@ -2363,13 +2385,15 @@ int streamSnapshot(fltx_decoder* d, int dir, const int32_t* map, int n) {
  * fewer than K groups) get their beam back and decode the chunk again on the general path */
 int streamRedoFlagged(fltx_decoder* d) {
   d->resultsSynced = false;
-  int rc = syncResults(d);
-  if (rc) {
-    return rc;
+  int rc = FLTX_OK;
+  /* the chunk's kernel left every stream's status in pinned host memory: wait for the kernel, nothing to copy */
+  if (devSync(d->ctx->stream)) {
+    return fail(FLTX_ERR_HIP, "stream synchronize failed: %s", devErr());
   }
+  const int32_t* status = (const int32_t*)d->hStat.p;
   std::vector<int32_t> again;
   for (int b = 0; b < d->B; ++b) {
-    if (d->hStatus[b] & (ST_CAND_OVERFLOW | ST_CUT_RETRY)) {
+    if (status[b] & (ST_CAND_OVERFLOW | ST_CUT_RETRY)) {
       again.push_back(b);
     }
   }
@@ -2412,6 +2436,71 @@ int streamRedoFlagged(fltx_decoder* d) {
   return rc;
 }
 
+int launchStreamOp(fltx_decoder* d, int op, int lookBack, int cap) {
+  StreamOpParams Q;
+  memset(&Q, 0, sizeof(Q));
+  Q.K = d->opt.beam_size;
+  Q.kind = d->kind;
+  Q.op = op;
+  Q.lookBack = lookBack;
+  Q.histPT = d->histPT.as<int2>();
+  Q.histW = d->histW.as<int32_t>();
+  Q.histS = d->keepScores ? d->histS.as<double>() : nullptr;
+  Q.histOff = d->histOffD.as<int64_t>();
+  Q.uttFrame = d->uttFrame.as<int32_t>();
+  Q.uttNBeam = d->uttNBeam.as<int32_t>();
+  Q.gScore = d->gScore.as<double>();
+  Q.outLen = d->bestLen.as<int32_t>();
+  Q.outScores = d->bestScores.as<double>();
+  Q.outTok = d->bestTok.as<int32_t>();
+  Q.outWrd = d->bestWrd.as<int32_t>();
+  Q.cap = cap;
+#ifdef FLTX_EMU
+  const StreamOpParams* qq = &Q;
+  emuLaunch(d->B, 256, kStreamOpLds, [qq](char* sm) { streamOpUtterance(*qq, (int32_t*)sm); });
+#else
+  /* (sixteen waves: they stage the rows the ancestor walk visits, and prune moves up to lookBack + 101 history rows
+   * -- a thread's loads and stores follow each other, so the fewer rounds the better) */
+  hipLaunchKernelGGL(fltx_streamop_kernel, dim3(d->B), dim3(1024), 0, d->ctx->stream, Q);
+  HIPCHK(hipGetLastError());
+#endif
+  return FLTX_OK;
+}
+
+/* the look at the chunk left pending by fltx_stream_step (decode it again where a list overflowed), then the prune that
+ * was asked for meanwhile */
+int settleStream(fltx_decoder* d) {
+  int rc = FLTX_OK;
+  struct Scope {
+    bool& flag;
+    ~Scope() { flag = false; }
+  } scope{d->settling};
+  d->settling = true;
+  if (d->chunkPending) {
+    d->chunkPending = false;
+    const float* curEmis = d->lastEmis;
+    const int curSlot = d->upSlot;
+    d->lastEmis = d->pendEmis; /* (the next chunk may be uploaded already: the other slot) */
+    d->upSlot = d->pendSlot;
+    const int before = d->streamRedone;
+    rc = streamRedoFlagged(d);
+#ifndef FLTX_EMU
+    if (!rc && d->streamRedone != before && d->copyStream) {
+      HIPCHK(hipEventRecord(d->evSlotFree[d->pendSlot], d->ctx->stream)); /* the second pass read the slot too */
+    }
+#endif
+    d->lastEmis = curEmis;
+    d->upSlot = curSlot;
+  }
+  if (!rc && d->pendingPrune >= 0) {
+    const int lb = d->pendingPrune;
+    d->pendingPrune = -1;
+    rc = launchStreamOp(d, 1, lb, 0);
+    d->resultsSynced = false;
+  }
+  return rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -2426,6 +2515,8 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     return fail(FLTX_ERR_INVALID, "fltx_decode_batch: bad argument");
   }
   d->streaming = false;
+  d->chunkPending = false;
+  d->pendingPrune = -1;
   d->haveResults = false;
   d->resultsSynced = false;
   d->backtraced = false;
@@ -2595,6 +2686,9 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
       d->snap.ensure((size_t)B * d->opt.beam_size * (3 * 8 + 6 * 4) + (size_t)B * 16, d->ctx->stream, false)) {
     return fail(FLTX_ERR_OOM, "stream snapshot allocation failed");
   }
+  if (d->streamOpt && d->hStat.ensure(4 * (size_t)B)) {
+    return fail(FLTX_ERR_OOM, "pinned status allocation failed");
+  }
   d->engineFirst = engineOf(d);
   if ((rc = bumpEpoch(d))) {
     return rc;
@@ -2609,6 +2703,9 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   d->compactFetched = false;
   d->scoresFetched = false;
   d->frames.assign(B, 0);
+  d->framesExact = true;
+  d->chunkPending = false;
+  d->pendingPrune = -1;
   DecodeParams P;
   fillParams(d, P);
   std::vector<int32_t> zeroT(B, 0);
@@ -2636,18 +2733,44 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
   if (!d->streaming || d->ended) {
     return fail(FLTX_ERR_STATE, "fltx_stream_step: call fltx_stream_begin first");
   }
-  for (int b = 0; b < d->B; ++b) {
-    if (T[b] < 0 || d->frames[b] + T[b] > d->maxFrames) {
-      return fail(FLTX_ERR_RANGE, "stream %d: %d buffered + %d new frames exceed max_frames %d", b,
-                  d->frames[b], T[b], d->maxFrames);
+  for (int pass = 0; pass < 2; ++pass) {
+    int bad = -1;
+    for (int b = 0; b < d->B && bad < 0; ++b) {
+      if (T[b] < 0 || d->frames[b] + T[b] > d->maxFrames) {
+        bad = b;
+      }
     }
+    if (bad < 0) {
+      break;
+    }
+    if (pass == 0 && !d->framesExact && T[bad] >= 0) {
+      int rcs = syncResults(d); /* what the prunes since the last look really left in the buffers */
+      if (rcs) {
+        return rcs;
+      }
+      for (int b = 0; b < d->B; ++b) {
+        d->frames[b] = d->hFrame[b];
+      }
+      d->framesExact = true;
+      continue;
+    }
+    return fail(FLTX_ERR_RANGE, "stream %d: %d buffered + %d new frames exceed max_frames %d", bad, d->frames[bad],
+                T[bad], d->maxFrames);
   }
-  DecodeParams P;
-  fillParams(d, P);
-  int rc = uploadStep(d, emissions, onDevice, offsets, T, P);
+  /* the chunk's upload first (copy stream: under the kernel of the chunk before, if that one is still pending), then
+   * the look at the chunk before, then this chunk's launch */
+  DecodeParams up;
+  memset(&up, 0, sizeof(up));
+  int rc = uploadStep(d, emissions, onDevice, offsets, T, up);
   if (rc) {
     return rc;
   }
+  if ((rc = settleStream(d))) {
+    return rc;
+  }
+  DecodeParams P;
+  fillParams(d, P); /* (emOff / stepT: the slot uploadStep has just filled) */
+  P.emissions = up.emissions;
   P.doBegin = 0;
   P.doEnd = 0;
   if (d->streamOpt && (rc = streamSnapshot(d, 0, nullptr, d->B))) {
@@ -2659,8 +2782,13 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
   if (rc) {
     return rc;
   }
-  if (d->streamOpt && (rc = streamRedoFlagged(d))) {
-    return rc;
+  if (d->streamOpt) {
+    d->chunkPending = true;
+    d->pendEmis = P.emissions;
+    d->pendSlot = d->upSlot;
+    if (!d->deferRedo && (rc = settleStream(d))) {
+      return rc;
+    }
   }
   for (int b = 0; b < d->B; ++b) {
     d->frames[b] += T[b];
@@ -2684,11 +2812,14 @@ int fltx_stream_end(fltx_decoder* d) {
   if (!d->streaming || d->ended) {
     return fail(FLTX_ERR_STATE, "fltx_stream_end: no open stream");
   }
+  int rc = settleStream(d);
+  if (rc) {
+    return rc;
+  }
   DecodeParams P;
   fillParams(d, P);
   std::vector<int32_t> zeroT(d->B, 0);
-  int rc = uploadStep(d, nullptr, 1, nullptr, zeroT.data(), P);
-  if (rc) {
+  if ((rc = uploadStep(d, nullptr, 1, nullptr, zeroT.data(), P))) {
     return rc;
   }
   P.doBegin = 0;
@@ -2705,35 +2836,6 @@ int fltx_stream_end(fltx_decoder* d) {
   return FLTX_OK;
 }
 
-static int launchStreamOp(fltx_decoder* d, int op, int lookBack, int cap) {
-  StreamOpParams Q;
-  memset(&Q, 0, sizeof(Q));
-  Q.K = d->opt.beam_size;
-  Q.kind = d->kind;
-  Q.op = op;
-  Q.lookBack = lookBack;
-  Q.histPT = d->histPT.as<int2>();
-  Q.histW = d->histW.as<int32_t>();
-  Q.histS = d->keepScores ? d->histS.as<double>() : nullptr;
-  Q.histOff = d->histOffD.as<int64_t>();
-  Q.uttFrame = d->uttFrame.as<int32_t>();
-  Q.uttNBeam = d->uttNBeam.as<int32_t>();
-  Q.gScore = d->gScore.as<double>();
-  Q.outLen = d->bestLen.as<int32_t>();
-  Q.outScores = d->bestScores.as<double>();
-  Q.outTok = d->bestTok.as<int32_t>();
-  Q.outWrd = d->bestWrd.as<int32_t>();
-  Q.cap = cap;
-#ifdef FLTX_EMU
-  const StreamOpParams* qq = &Q;
-  emuLaunch(d->B, 64, 16, [qq](char* sm) { streamOpUtterance(*qq, (int32_t*)sm); });
-#else
-  hipLaunchKernelGGL(fltx_streamop_kernel, dim3(d->B), dim3(64), 0, d->ctx->stream, Q);
-  HIPCHK(hipGetLastError());
-#endif
-  return FLTX_OK;
-}
-
 int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
   DeviceScope devScope(d ? d->ctx : nullptr);
   if (devScope.failed) {
@@ -2745,8 +2847,10 @@ int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
   if (!d->streaming) {
     return fail(FLTX_ERR_STATE, "fltx_stream_prune: call fltx_stream_begin first");
   }
-  int rc = launchStreamOp(d, 1, lookBack, 0);
-  if (rc) {
+  int rc = FLTX_OK;
+  if (d->chunkPending && d->pendingPrune < 0) {
+    d->pendingPrune = lookBack; /* runs right after the look at the pending chunk (settleStream) */
+  } else if ((rc = settleStream(d)) || (rc = launchStreamOp(d, 1, lookBack, 0))) {
     return rc;
   }
   d->resultsSynced = false;
@@ -2765,12 +2869,10 @@ int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
     }
     return FLTX_OK;
   }
-  if ((rc = syncResults(d))) {
-    return rc;
-  }
-  for (int b = 0; b < d->B; ++b) {
-    d->frames[b] = d->hFrame[b]; /* frames still buffered */
-  }
+  /* the lexicon decoder prunes back to a complete hypothesis (LexiconDecoder.h:97-99), or not at all: what stays buffered
+   * is the device's to say.  No wait here: frames[] stays the upper bound "nothing pruned" and fltx_stream_step asks
+   * the device only when that bound would not fit max_frames */
+  d->framesExact = false;
   return FLTX_OK;
 }
 

@@ -187,6 +187,7 @@ struct DecodeParams {
   const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
   unsigned long long* ymemo;    /* fltx_ylane.h, shared-CU geometry: the LM-state memo of every utterance (kYlMemo slots each) */
+  int32_t* statusHost;          /* optimistic stream chunks: uttStatus mirrored in pinned host memory (read after the kernel, no copy) */
   const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */
   double yBound;                /* ... and the largest lmWeight x smearing difference of the lexicon (>= 0) */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
@@ -2861,7 +2862,11 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     if constexpr (GMAX > 0) {
       P.uttNextId[b] = w.sc[SC_NEXTID];
     }
-    P.uttStatus[b] = P.doBegin ? w.sc[SC_STATUS] : (P.uttStatus[b] | w.sc[SC_STATUS]);
+    const int32_t stNow = P.doBegin ? w.sc[SC_STATUS] : (P.uttStatus[b] | w.sc[SC_STATUS]);
+    P.uttStatus[b] = stNow;
+    if (P.statusHost) {
+      P.statusHost[b] = stNow;
+    }
   }
 }
 
@@ -3166,15 +3171,27 @@ struct StreamOpParams {
 
 constexpr int kLookBackLimit = 100; /* Utils.h:28 */
 
+constexpr int kStageInts = 8192;    /* LDS (32 KB) the walk stages history rows in */
+constexpr int kStreamOpLds = (8 + kStageInts) * 4;
+
 FLTX_DEV void streamOpUtterance(const StreamOpParams& Q, int32_t* sh) {
   const int b = (int)blockIdx.x;
   const int tid = (int)threadIdx.x, W = (int)blockDim.x;
   const int64_t base = Q.histOff[b];
   const int ff = Q.uttFrame[b];
   const int nB = Q.uttNBeam[b];
-  /* sh[0] = frame of the ancestor, sh[1] = slot (-1 none), sh[2] = steps n, sh[3] = go */
+  const int maxLookBack = Q.lookBack + kLookBackLimit;
+  /* findBestAncestor: lookBack steps back from the best hypothesis, then on to a complete one (LexiconDecoder.h:97-99:
+   * no parent, or the parent ended a word; LexiconFreeDecoder.h:84-86: every hypothesis is).  A chain of dependent
+   * loads -- so the rows it is about to visit (their parent and word columns) are fetched into LDS by all threads, R
+   * rows at a time, and one thread walks them there.
+   * sh[0] = frame of the ancestor, sh[1] = slot (-1 none), sh[2] = steps n, sh[3] = go, sh[4] = walk finished */
+  int32_t* stPar = sh + 8;
+  int R = kStageInts / 2 / Q.K;
+  R = R > 64 ? 64 : R;
+  int32_t* stWrd = stPar + R * Q.K;
   if (tid == 0) {
-    int f = ff, s = nB > 0 ? 0 : -1, n = 0; /* the beam is sorted: slot 0 is the best */
+    int s = nB > 0 ? 0 : -1; /* the beam is sorted: slot 0 is the best */
     bool go = true;
     if (Q.op == 1 && ff - Q.lookBack < 1) {
       go = false; /* not enough decoded frames to prune */
@@ -3183,26 +3200,97 @@ FLTX_DEV void streamOpUtterance(const StreamOpParams& Q, int32_t* sh) {
       go = false; /* LexiconDecoder.cpp:286-288 */
       s = -1;
     }
-    if (go) {
-      auto parentOf = [&](int fr, int sl) { return fr == 0 ? -1 : Q.histPT[base + (int64_t)fr * Q.K + sl].x; };
-      while (s >= 0 && n < Q.lookBack) {
-        ++n;
-        s = parentOf(f, s);
-        --f;
-      }
-      const int maxLookBack = Q.lookBack + kLookBackLimit;
-      while (s >= 0) {
-        bool complete = true; /* LexiconFreeDecoder.h:84-86 */
-        if (Q.kind == 1) {    /* LexiconDecoder.h:97-99 */
-          const int p = parentOf(f, s);
-          complete = p < 0 || Q.histW[base + (int64_t)(f - 1) * Q.K + p] >= 0;
+    sh[0] = ff;
+    sh[1] = s;
+    sh[2] = 0;
+    sh[3] = go ? 1 : 0;
+    sh[4] = (!go || s < 0) ? 1 : 0;
+  }
+  __syncthreads();
+  if (R >= 2) {
+    while (sh[4] == 0) {
+      const int fTop = sh[0];
+      const int lo = fTop - R + 1 > 0 ? fTop - R + 1 : 0;
+      const int cnt = (fTop - lo + 1) * Q.K;
+      for (int e = tid; e < cnt; e += W) {
+        stPar[e] = Q.histPT[base + (int64_t)lo * Q.K + e].x;
+        if (Q.kind == 1) {
+          stWrd[e] = Q.histW[base + (int64_t)lo * Q.K + e];
         }
-        if (complete) {
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int f = fTop, s = sh[1], n = sh[2];
+        bool done = false;
+        auto par = [&](int fr, int sl) { return fr == 0 ? -1 : stPar[(fr - lo) * Q.K + sl]; };
+        while (true) {
+          if (s < 0) {
+            done = true;
+            break;
+          }
+          if (f > 0 && f < lo) {
+            break; /* the next rows */
+          }
+          if (n < Q.lookBack) {
+            ++n;
+            s = par(f, s);
+            --f;
+            continue;
+          }
+          if (Q.kind != 1) {
+            done = true;
+            break;
+          }
+          const int p = par(f, s);
+          if (p < 0) {
+            done = true;
+            break;
+          }
+          if (f - 1 < lo) {
+            break; /* the parent's row is not here */
+          }
+          if (stWrd[(f - 1 - lo) * Q.K + p] >= 0) {
+            done = true;
+            break;
+          }
+          ++n;
+          s = p;
+          --f;
+          if (n == maxLookBack) {
+            done = true;
+            break;
+          }
+        }
+        sh[0] = f;
+        sh[1] = s;
+        sh[2] = n;
+        sh[4] = done ? 1 : 0;
+      }
+      __syncthreads();
+    }
+  } else if (tid == 0 && sh[4] == 0) { /* (a beam too wide for the staging area: the loads one after the other) */
+    int f = ff, s = sh[1], n = 0;
+    auto parentOf = [&](int fr, int sl) { return fr == 0 ? -1 : Q.histPT[base + (int64_t)fr * Q.K + sl].x; };
+    while (s >= 0 && n < Q.lookBack) {
+      ++n;
+      s = parentOf(f, s);
+      --f;
+    }
+    if (Q.kind == 1) {
+      int p = s >= 0 ? parentOf(f, s) : -1;
+      while (s >= 0) {
+        int w = -1, pp = -1;
+        if (p >= 0) {
+          w = Q.histW[base + (int64_t)(f - 1) * Q.K + p];
+          pp = parentOf(f - 1, p);
+        }
+        if (p < 0 || w >= 0) {
           break;
         }
         ++n;
-        s = parentOf(f, s);
+        s = p;
         --f;
+        p = pp;
         if (n == maxLookBack) {
           break;
         }
@@ -3211,7 +3299,6 @@ FLTX_DEV void streamOpUtterance(const StreamOpParams& Q, int32_t* sh) {
     sh[0] = f;
     sh[1] = s;
     sh[2] = n;
-    sh[3] = go ? 1 : 0;
   }
   __syncthreads();
   const int f = sh[0], s0 = sh[1], n = sh[2];
@@ -3253,12 +3340,16 @@ FLTX_DEV void streamOpUtterance(const StreamOpParams& Q, int32_t* sh) {
   if (startFrame < 1) {
     return;
   }
-  for (int i = 0; i <= n; ++i) {
-    for (int k = tid; k < Q.K; k += W) {
-      const int64_t src = base + (int64_t)(startFrame + i) * Q.K + k;
-      const int64_t dst = base + (int64_t)i * Q.K + k;
+  /* rows startFrame .. startFrame + n move to 0 .. n.  A group of startFrame rows reads only rows beyond the ones it
+   * writes, so it is copied by all threads at once; groups follow each other in order */
+  const int rows = n + 1;
+  for (int i0 = 0; i0 < rows; i0 += startFrame) {
+    const int cnt = (rows - i0 < startFrame ? rows - i0 : startFrame) * Q.K;
+    for (int e = tid; e < cnt; e += W) {
+      const int64_t dst = base + (int64_t)i0 * Q.K + e;
+      const int64_t src = dst + (int64_t)startFrame * Q.K;
       int2 pt = Q.histPT[src];
-      if (i == 0) {
+      if (i0 == 0 && e < Q.K) {
         pt.x = -1; /* avoid further back-tracking (Utils.h:325-327) */
       }
       Q.histPT[dst] = pt;
@@ -3271,8 +3362,7 @@ FLTX_DEV void streamOpUtterance(const StreamOpParams& Q, int32_t* sh) {
         Q.histS[3 * dst + 2] = Q.histS[3 * src + 2];
       }
     }
-    __threadfence();
-    __syncthreads();
+    __syncthreads(); /* (the rows are this workgroup's alone: its barrier orders them) */
   }
   /* avoid score under/overflow: subtract the largest score of the newest frame
    * (Utils.h:329-341); the beam is sorted, so that is slot 0 */
