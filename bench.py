@@ -650,7 +650,8 @@ def streaming(job, B, T, N, chunk=50):
             "note": "stream_step(50 frames, host emissions) + prune(0) per chunk; value: chunks handed over back to back "
                     "(results read at the end), value_waiting_for_every_chunk / latencies: a synchronize after every "
                     "chunk; lexicon streams start "
-                    "every chunk on the LDS-sized geometry and decode it again from the saved beam if a list overflows"}
+                    "every chunk on the LDS-sized geometry and decode it again from the saved beam if a list overflows "
+                    "(looked at when the next call needs the beam: the next chunk's upload runs under the kernel)"}
 
 
 if __name__ == "__main__":
