@@ -470,13 +470,19 @@ FLTX_HD uint32_t hashKey(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
  * HBM, tens of microseconds with 32 workgroups dirtying it) is not needed.  With the
  * workspace in LDS it waits for this wave's LDS operations only (ldsBarrier):
  * __syncthreads() would also drain the global loads of the emission-row
- * prefetch (~2k clocks) and the history stores at every barrier. */
+ * prefetch (~2k clocks) and the history stores at every barrier.
+ * At hot level 2 (histogram, counters, candidate records and the merge hash in LDS; the beam and its lists in HBM)
+ * nothing in HBM is updated with atomics any more: the invalidate is dropped (beam 500 x 29 tokens with a 4-gram
+ * LM: 215 -> 71 us per frame). */
 FLTX_DEV void wsBarrier(const DecodeParams& P) {
 #ifndef FLTX_EMU
   if (P.gws != nullptr) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* my stores are in L2 */
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (P.hotLevel < 2) { /* (level 2: everything updated with atomics is in LDS; what is left in HBM is written with
+                           * plain stores by waves of this CU, which its write-through L1 sees) */
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     return;
   }
 #endif
@@ -494,7 +500,9 @@ FLTX_DEV void wsBarrierMem(const DecodeParams& P) {
     /* invalidate AFTER the barrier: the L1 is shared by the waves of the CU, so
      * a wave that is still loading before its barrier can re-populate lines
      * another wave already dropped */
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (P.hotLevel < 2) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     return;
   }
 #endif
