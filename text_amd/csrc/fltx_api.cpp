@@ -1908,6 +1908,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
   P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
   P.statusHost = (!d->offlineCall && d->streamOpt) ? (int32_t*)d->hStat.p : nullptr;
+  /* (the lean step on an HBM workspace ORs its addMask words with L2 atomics and reads them back plainly: it keeps the invalidate) */
+  P.wsNoInv = (!d->wsInLds && !d->lean && d->hotLevel >= 1) ? 1 : 0;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;

@@ -187,6 +187,7 @@ struct DecodeParams {
   const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
   unsigned long long* ymemo;    /* fltx_ylane.h, shared-CU geometry: the LM-state memo of every utterance (kYlMemo slots each) */
+  int32_t wsNoInv;              /* HBM workspace of the generic step (hot level >= 1): no L1 invalidate after its barriers (wsBarrier) */
   int32_t* statusHost;          /* optimistic stream chunks: uttStatus mirrored in pinned host memory (read after the kernel, no copy) */
   const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */
   double yBound;                /* ... and the largest lmWeight x smearing difference of the lexicon (>= 0) */
@@ -471,16 +472,17 @@ FLTX_HD uint32_t hashKey(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
  * workspace in LDS it waits for this wave's LDS operations only (ldsBarrier):
  * __syncthreads() would also drain the global loads of the emission-row
  * prefetch (~2k clocks) and the history stores at every barrier.
- * At hot level 2 (histogram, counters, candidate records and the merge hash in LDS; the beam and its lists in HBM)
- * nothing in HBM is updated with atomics any more: the invalidate is dropped (beam 500 x 29 tokens with a 4-gram
- * LM: 215 -> 71 us per frame). */
+ * The generic step at hot level >= 1 (histogram and counters in LDS) reads the two kinds of HBM words that are
+ * still updated with atomics at L2 (wsLoadAtomic32) and drops the invalidate (DecodeParams::wsNoInv; beam 500 x 29
+ * tokens with a 4-gram LM: 215 -> 71 us per frame, beam 1000: 477 -> 177). */
 FLTX_DEV void wsBarrier(const DecodeParams& P) {
 #ifndef FLTX_EMU
   if (P.gws != nullptr) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* my stores are in L2 */
     __syncthreads();
-    if (P.hotLevel < 2) { /* (level 2: everything updated with atomics is in LDS; what is left in HBM is written with
-                           * plain stores by waves of this CU, which its write-through L1 sees) */
+    if (!P.wsNoInv) {     /* (generic step, levels 1, 2: the histogram and the counters are in LDS, the words of the HBM part that
+                           * are updated with atomics are read at L2 (wsLoadAtomic32); everything else there is
+                           * written with plain stores by waves of this CU, which its write-through L1 sees) */
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     return;
@@ -500,13 +502,24 @@ FLTX_DEV void wsBarrierMem(const DecodeParams& P) {
     /* invalidate AFTER the barrier: the L1 is shared by the waves of the CU, so
      * a wave that is still loading before its barrier can re-populate lines
      * another wave already dropped */
-    if (P.hotLevel < 2) {
+    if (!P.wsNoInv) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     return;
   }
 #endif
   __syncthreads();
+}
+
+/* A word of the HBM workspace that other waves update with L2 atomics (hash heads, the rank counts of the select):
+ * read at L2, this CU's L1 may hold the line from before the atomics. */
+FLTX_DEV uint32_t wsLoadAtomic32(const DecodeParams& P, const uint32_t* p) {
+#ifndef FLTX_EMU
+  if (P.gws != nullptr && P.hotLevel < 2) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
+  return *p;
 }
 
 /* exclusive prefix sum of v over the workgroup; *total = block sum.
@@ -1665,7 +1678,7 @@ FLTX_DEV void foldGroups(const DecodeParams& P, const Ws& w, double thr, int nCa
     uint32_t bestIdx = kEmpty;
     double acc = 0;
     if (ci < nCand && w.cNext[ci] == kEmpty) {
-      const uint32_t hd = w.head[w.small[ci]];
+      const uint32_t hd = wsLoadAtomic32(P, &w.head[w.small[ci]]);
       if (hd != kEmpty) {
         /* best member: highest score, ties to the earliest generated */
         uint32_t bestOrd = 0;
@@ -2181,7 +2194,7 @@ FLTX_DEV int selectAndRank(const DecodeParams& P, const Ws& w, int nLead, int K,
     }
     wsBarrier(P);
     for (int j2 = tid; j2 < L; j2 += W) {
-      const int rank = (int)w.small[j2];
+      const int rank = (int)wsLoadAtomic32(P, &w.small[j2]);
       if (rank < K) {
         w.surv[rank] = w.sIdx[j2];
       }
