@@ -429,3 +429,28 @@ def test_big_lexicon_free_beams(gpu_session, oracle_lib, K, T, dist):
         pytest.skip("equal scores in the n-best")
     ok, why = helpers.hyps_equal(want, got)
     assert ok, why
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,hot", [(400, 2), (500, 2), (700, 1)])
+def test_big_lexicon_beams_with_ngram_lm(gpu_session, oracle_lib, K, hot):
+    """Beams of the lexicon decoder beyond the LDS (C4 shape: 90k-word trie, 4-gram word LM): the generic step over the
+    HBM workspace, sixteen waves, no L1 invalidate after its barriers (DecodeParams::wsNoInv) -- level 2 (candidate
+    records and merge hash in LDS) and level 1 (in HBM), two utterances each against the oracle."""
+    from text_amd import synth
+    T = 40
+    c = cases.case("bigbeam_lx", kind="lexicon", dist="lexspell", T=T, N=29, K=K, Kt=29, lexicon=cases.FULL_LEX,
+                   lm=("ngram", 4, 8), lm_weight=2.0, word_score=2.0, sil_score=-1.0, u=31)
+    inp = helpers.case_inputs(c)
+    B = 2
+    e = synth.batch("lexspell", B, T, 29, lexicon=inp["lex"], u0=c["u"])
+    d = gpu_session.decoder(c, inp)
+    d.decode_batch(e, [T] * B, 29)
+    assert d.get("engine") == 0 and d.get("lds") == 0 and d.get("hot_level") == hot and d.get("threads") == 1024
+    for b in range(B):
+        want = helpers.run_checker(oracle_lib, c, dict(inp, e=np.ascontiguousarray(e[b])))
+        if len({h.score for h in want}) != len(want):
+            continue  # equal scores in the n-best
+        ok, why = helpers.hyps_equal(want, d.results(b))
+        assert ok, "beam %d utterance %d: %s" % (K, b, why)
+    d.close()
