@@ -1575,6 +1575,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     if (need > kMaxLds) {
       d->lean = 255; /* too big for LDS: the streaming step over an HBM workspace (leanBarrier) */
       leanInHbm = true;
+      if (!d->userThreads) {
+        d->threads = 1024; /* (C2 shape, beam 1000: 314 -> 234 ms, beam 2500: 1375 -> 1046) */
+      }
     }
   }
   if (d->lean) {
@@ -1913,8 +1916,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
   P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
   P.statusHost = (!d->offlineCall && d->streamOpt) ? (int32_t*)d->hStat.p : nullptr;
-  /* (the lean step on an HBM workspace ORs its addMask words with L2 atomics and reads them back plainly: it keeps the invalidate) */
-  P.wsNoInv = (!d->wsInLds && !d->lean && d->hotLevel >= 1) ? 1 : 0;
+  /* (the lean step on an HBM workspace reads its atomically ORed addMask words at L2 as well: wsLoadAtomic64) */
+  P.wsNoInv = (!d->wsInLds && d->hotLevel >= 1) ? 1 : 0;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;

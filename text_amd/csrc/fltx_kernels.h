@@ -522,6 +522,15 @@ FLTX_DEV uint32_t wsLoadAtomic32(const DecodeParams& P, const uint32_t* p) {
   return *p;
 }
 
+FLTX_DEV unsigned long long wsLoadAtomic64(const DecodeParams& P, const unsigned long long* p) {
+#ifndef FLTX_EMU
+  if (P.gws != nullptr) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
+  return *p;
+}
+
 /* exclusive prefix sum of v over the workgroup; *total = block sum.
  * Contains two barriers; wtmp has >= nWaves+1 entries. */
 FLTX_DEV int blockExclusiveScan(const DecodeParams& P, int v, uint32_t* wtmp, int* total) {

@@ -623,7 +623,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
   /* ---- phase E2: masks incl. this frame's additions; coalesced history write --- */
   for (int r = tid; r < nS; r += W) {
     const int rs = w.eRep[r];
-    w.bMask[no + r] = w.eBase[r] | (rs >= 0 ? w.addMask[rs] : 0ull);
+    w.bMask[no + r] = w.eBase[r] | (rs >= 0 ? wsLoadAtomic64(P, &w.addMask[rs]) : 0ull); /* (ORed with atomics: at L2 on an HBM workspace) */
     const int n = (int)(w.bTokPb[no + r] & 0x7FFFFFFFu);
     P.histPT[hbase + r] = make_int2(w.bPar[r], n);
     if (P.histS) {
@@ -634,7 +634,7 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
     }
   }
   for (int r = tid; r < f.nBeam; r += W) { /* persist the grown masks of the old states */
-    const unsigned long long add = w.addMask[r];
+    const unsigned long long add = wsLoadAtomic64(P, &w.addMask[r]);
     if (add != 0ull) {
       P.maskTab[(size_t)f.b * P.idCap + w.bState[co + r]] = w.bMask[co + r] | add;
     }
