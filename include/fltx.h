@@ -307,7 +307,8 @@ FLTX_API int fltx_decoder_profile(fltx_decoder* dec, uint64_t* out);
  * streams use the worst-case HBM workspace from the start instead of decoding an overflowing chunk again),
  * "stream_defer" (0 = fltx_stream_step of a lexicon stream waits for its chunk; default: the chunk is launched and whether
  * a stream has to decode it again is looked at by the next call that needs the beam -- the next chunk's upload runs
- * under the kernel; a deferred fltx_stream_prune reports its errors there too), "bt_lds_kb".  fltx_decoder_get also answers "engine", "redone", "stream_redone", "yshare", "sstream". */
+ * under the kernel; a deferred fltx_stream_prune reports its errors there too), "lm_cache" (0 = the generic step asks
+ * the n-gram tables for every word-end candidate instead of keeping the last (LM state, word) answers), "bt_lds_kb".  fltx_decoder_get also answers "engine", "redone", "stream_redone", "yshare", "sstream". */
 FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
 /* Geometry chosen for the last batch: "engine" (0 generic hash merge, 1 generic
  * dense merge, 2 lean register-resident step, 3 lane-per-slot step, 4 lane = LM

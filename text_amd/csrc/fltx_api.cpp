@@ -390,6 +390,8 @@ struct fltx_decoder {
   const float* pendEmis = nullptr;
   int pendSlot = 0;
   int pendingPrune = -1;         /* prune(lookBack) asked for while the chunk was pending: runs right after the look */
+  bool useLmCache = false;
+  int noLmCache = 0;             /* tunable lm_cache = 0 */
   int deferRedo = 1;             /* tunable stream_defer: 0 = look at every chunk before fltx_stream_step returns */
   std::vector<int64_t> histOff; /* records */
   int64_t histRecords = 0;
@@ -423,6 +425,7 @@ struct fltx_decoder {
   DBuf snap;
   int yshare = 0, userYshare = -1; /* the geometry of fltx_ylane.h that shares a CU (memo in HBM); user: -1 = when the batch exceeds the CUs */
   DBuf ymemo;
+  DBuf lmCache;               /* DecodeParams::lmCache */
   int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
   bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
   const float* lastEmis = nullptr; /* device emissions of the last offline batch (the back-trace re-reads them) */
@@ -1328,6 +1331,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->userStreamOpt = (int)value;
     return FLTX_OK;
   }
+  if (!strcmp(key, "lm_cache")) { /* 0: the generic step asks the n-gram tables every time (DecodeParams::lmCache) */
+    d->noLmCache = value ? 0 : 1;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "stream_defer")) { /* 0: fltx_stream_step waits for its chunk and decodes it again there if it must */
     d->deferRedo = value ? 1 : 0;
     return FLTX_OK;
@@ -1817,6 +1824,14 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if ((d->ylane || d->xlane) && d->yshare) {
     rc |= d->ymemo.ensure(sizeof(unsigned long long) * (size_t)kYlMemo * (size_t)B, st, false); /* (wiped by the kernel) */
   }
+  d->useLmCache = d->lm->kind == 1 && !d->ylane && !d->xlane && !d->noLmCache;
+  if (d->useLmCache) {
+    /* (emptied here and at every new epoch: LM-state ids are table slots, a new batch gives them new meanings) */
+    rc |= d->lmCache.ensure(8 * (size_t)kLmCache * (size_t)B, st, false);
+    if (!rc) {
+      devMemset(d->lmCache.p, 0xFF, 8 * (size_t)kLmCache * (size_t)B, st);
+    }
+  }
   if (d->lm->kind == 1) {
     rc |= d->scored.ensure(4 * (size_t)B, st, false);
     if (!rc && !d->keepScored) { /* (a partial re-run keeps the counts of the utterances it does not touch) */
@@ -1918,6 +1933,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.statusHost = (!d->offlineCall && d->streamOpt) ? (int32_t*)d->hStat.p : nullptr;
   /* (the lean step on an HBM workspace reads its atomically ORed addMask words at L2 as well: wsLoadAtomic64) */
   P.wsNoInv = (!d->wsInLds && d->hotLevel >= 1) ? 1 : 0;
+  P.lmCache = d->useLmCache ? d->lmCache.as<unsigned long long>() : nullptr;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;
@@ -2126,6 +2142,9 @@ int bumpEpoch(fltx_decoder* d) {
     d->epoch = 0;
   }
   d->epoch += 1;
+  if (d->useLmCache && d->lmCache.p && devMemset(d->lmCache.p, 0xFF, d->lmCache.cap, d->ctx->stream)) {
+    return fail(FLTX_ERR_HIP, "LM score cache reset failed");
+  }
   return FLTX_OK;
 }
 

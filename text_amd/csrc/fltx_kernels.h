@@ -187,6 +187,7 @@ struct DecodeParams {
   const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
   unsigned long long* ymemo;    /* fltx_ylane.h, shared-CU geometry: the LM-state memo of every utterance (kYlMemo slots each) */
+  unsigned long long* lmCache;  /* generic step with an n-gram LM: (LM state, word) -> score of the last look-ups, kLmCache slots per utterance */
   int32_t wsNoInv;              /* HBM workspace of the generic step (hot level >= 1): no L1 invalidate after its barriers (wsBarrier) */
   int32_t* statusHost;          /* optimistic stream chunks: uttStatus mirrored in pinned host memory (read after the kernel, no copy) */
   const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */
@@ -823,6 +824,12 @@ FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t wor
 }
 
 /* LM::score for the hypothesis in beam slot h (state id sid). */
+/* LM::score of the n-gram LM (lm/KenLM.cpp:63-75) for (LM state id, word).  A hypothesis at a word-end node asks the
+ * same question frame after frame until it leaves the beam, and an answer is a chain of dependent table probes
+ * (~4 k clocks): the last answers are kept in a direct-mapped table per utterance.  One 64-bit word per entry
+ * = tag:32 | score bits:32, written and read whole; slot = (word ^ f(state)) mod kLmCache, tag = state:24 | word >> 12,
+ * so slot and tag together determine (state, word): a hit is exact, never a hash coincidence. */
+constexpr int kLmCache = 4096;
 FLTX_DEV float lmScoreDev(const DecodeParams& P, int b, uint32_t sid, int usr) {
   if (P.lmKind == 0) {
     return 0.0f;
@@ -830,6 +837,19 @@ FLTX_DEV float lmScoreDev(const DecodeParams& P, int b, uint32_t sid, int usr) {
   const int L = P.lmOrder - 1;
   const int32_t* ctx = P.stateCtx + ((size_t)b * P.stateCap + sid) * L;
   const uint32_t word = (usr >= 0 && usr < P.nUsr) ? (uint32_t)P.usrToLm[usr] : (uint32_t)P.lmUnk;
+  const uint32_t uk = (uint32_t)(usr + 1);
+  if (P.lmCache != nullptr && uk < (1u << 20) && sid < 0xFFFFFFu) {
+    unsigned long long* c = P.lmCache + (size_t)b * kLmCache;
+    const uint32_t slot = (uk ^ sid ^ (sid >> 12)) & (uint32_t)(kLmCache - 1);
+    const uint32_t tag = (sid << 8) | (uk >> 12);
+    const unsigned long long e = c[slot];
+    if ((uint32_t)(e >> 32) == tag) {
+      return __uint_as_float((uint32_t)e);
+    }
+    const float v = ngScore(P, ctx, word, nullptr);
+    c[slot] = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    return v;
+  }
   return ngScore(P, ctx, word, nullptr);
 }
 FLTX_DEV float lmFinishDev(const DecodeParams& P, int b, uint32_t sid) {
