@@ -246,3 +246,21 @@ def test_compact_result_fetch_on_the_emulator(emu_session):
         for i, h in enumerate(allh[b]):
             assert np.array_equal(d.tokens_of(r, b, i), h.tokens) and np.array_equal(d.words_of(r, b, i), h.words)
     d.close()
+
+
+@pytest.mark.parametrize("K,T,threads", [(100, 12, 0), (200, 10, 0), (70, 12, 256)])
+def test_lean_step_split_relation_scan(emu_session, oracle_lib, K, T, threads):
+    """Beams 65+ of the lexicon-free decoder: the split of a slot's relation scan between threads (fltx_lean.h)."""
+    from text_amd import synth
+    c = cases.case("leanbeam_emu", dist="ctc", T=T, N=29, K=K, u=43)
+    e = synth.emissions("ctc", c["u"], T, c["N"])
+    d = emu_session.decoder(c, dict(tr=None), threads or None)
+    d.decode_batch(e, [T], c["N"])
+    assert d.get("engine") == 2
+    want = helpers.run_checker(oracle_lib, c, dict(e=e, tr=None, lex=None))
+    got = d.results(0)
+    d.close()
+    if len({h.score for h in want}) != len(want):
+        pytest.skip("equal scores in the n-best")
+    ok, why = helpers.hyps_equal(want, got)
+    assert ok, why

@@ -454,3 +454,25 @@ def test_big_lexicon_beams_with_ngram_lm(gpu_session, oracle_lib, K, hot):
         ok, why = helpers.hyps_equal(want, d.results(b))
         assert ok, "beam %d utterance %d: %s" % (K, b, why)
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,T,dist,threads", [(100, 60, "ctc", 0), (130, 50, "ctc", 0), (200, 40, "uniform", 0),
+                                              (256, 40, "ctc", 0), (300, 40, "ctc", 0), (100, 40, "ctc", 1024),
+                                              (70, 40, "uniform", 256), (128, 40, "ctc", 128)])
+def test_lexicon_free_beams_above_the_lane_engines(gpu_session, oracle_lib, K, T, dist, threads):
+    """Beams 65+ of the lexicon-free decoder (lean step): a slot's scan for the hypotheses of its LM state and of its
+    parent state is split between W / stride threads -- every split (4, 2, none; 8 at 1024 threads) against the oracle."""
+    from text_amd import synth
+    c = cases.case("leanbeam", dist=dist, T=T, N=29, K=K, u=41)
+    e = synth.emissions(dist, c["u"], T, c["N"])
+    d = gpu_session.decoder(c, dict(tr=None), threads or None)
+    d.decode_batch(e, [T], c["N"])
+    assert d.get("engine") == 2
+    want = helpers.run_checker(oracle_lib, c, dict(e=e, tr=None, lex=None))
+    got = d.results(0)
+    d.close()
+    if len({h.score for h in want}) != len(want):
+        pytest.skip("equal scores in the n-best")
+    ok, why = helpers.hyps_equal(want, got)
+    assert ok, why

@@ -242,6 +242,9 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
     w.red[0] = 0ull;
   }
   const bool laneBeam = f.nBeam <= 64;
+  const int relStride = (f.nBeam + 63) & ~63;
+  int relParts = laneBeam ? 0 : W / relStride; /* (pMate / pPar hold 16 x 64 partial results) */
+  relParts = relParts * relStride > 16 * 64 ? (16 * 64) / relStride : relParts;
   if (laneBeam) {
     /* every wave holds the beam's state ids in its lanes and scans its share of
      * the slots by lane broadcast; partial results go to this wave's row */
@@ -259,11 +262,33 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
     }
     w.pMate[wave * 64 + lane] = mate;
     w.pPar[wave * 64 + lane] = par;
+  } else if (relParts >= 2) {
+    /* beams of 65 .. W / 2: a slot's scan over the beam is split between relParts threads (rows of relStride partial
+     * results, combined after the barrier like the per-wave rows above); the loads of eight steps go out together */
+    const int part = tid / relStride, h = tid - part * relStride;
+    if (part < relParts && h < f.nBeam) {
+      const uint32_t sid = w.bState[co + h];
+      const uint32_t sp = w.bSPar[co + h];
+      const int per = (f.nBeam + relParts - 1) / relParts;
+      const int lo = part * per;
+      int hi = lo + per;
+      hi = hi > f.nBeam ? f.nBeam : hi;
+      int mate = -1, par = -1;
+#pragma unroll 8
+      for (int h2 = lo; h2 < hi; ++h2) {
+        const uint32_t s2 = w.bState[co + h2];
+        mate = (s2 == sid && h2 != h) ? h2 : mate;
+        par = (s2 == sp && par < 0) ? h2 : par;
+      }
+      w.pMate[part * relStride + h] = mate;
+      w.pPar[part * relStride + h] = par;
+    }
   } else {
     for (int h = tid; h < f.nBeam; h += W) {
       const uint32_t sid = w.bState[co + h];
       const uint32_t sp = w.bSPar[co + h];
       int mate = -1, par = -1;
+#pragma unroll 8
       for (int h2 = 0; h2 < f.nBeam; ++h2) {
         const uint32_t s2 = w.bState[co + h2];
         mate = (s2 == sid && h2 != h) ? h2 : mate;
@@ -301,6 +326,16 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
       par = -1;
       for (int v = 0; v < nW; ++v) {
         const int m = w.pMate[v * 64 + h], p = w.pPar[v * 64 + h];
+        mate = m >= 0 ? m : mate;
+        par = (par < 0 && p >= 0) ? p : par;
+      }
+      w.dMate[h] = mate;
+      w.dPar[h] = par;
+    } else if (relParts >= 2) {
+      mate = -1;
+      par = -1;
+      for (int v = 0; v < relParts; ++v) {
+        const int m = w.pMate[v * relStride + h], p = w.pPar[v * relStride + h];
         mate = m >= 0 ? m : mate;
         par = (par < 0 && p >= 0) ? p : par;
       }
