@@ -1152,14 +1152,11 @@ FLTX_DEV void densePrepare(const DecodeParams& P, const Ws& w, const FrameCtx& f
     const uint32_t sid = w.bState[(cur) * P.K + h];
     const uint32_t sp = w.bSPar[(cur) * P.K + h];
     int mate = -1, par = -1;
-    for (int h2 = 0; h2 < f.nBeam; ++h2) {
+#pragma unroll 8
+    for (int h2 = 0; h2 < f.nBeam; ++h2) { /* (eight loads in flight: one at a time made this scan the longest phase) */
       const uint32_t s2 = w.bState[(cur) * P.K + h2];
-      if (s2 == sid && h2 != h) {
-        mate = h2;
-      }
-      if (s2 == sp && par < 0) {
-        par = h2; /* lowest slot in the parent state = its representative */
-      }
+      mate = (s2 == sid && h2 != h) ? h2 : mate;
+      par = (s2 == sp && par < 0) ? h2 : par; /* lowest slot in the parent state = its representative */
     }
     w.dMate[h] = mate;
     w.dPar[h] = par;
