@@ -264,3 +264,10 @@ def test_lean_step_split_relation_scan(emu_session, oracle_lib, K, T, threads):
         pytest.skip("equal scores in the n-best")
     ok, why = helpers.hyps_equal(want, got)
     assert ok, why
+
+
+def test_emulated_lane_state_engine_with_lane_groups(emu_session, oracle_lib):
+    """fltx_mlane.h on the emulator: a thin slice of the GPU suite's grid (tests/test_gpu_batches.py)."""
+    import test_gpu_batches
+    ran, served, bad = test_gpu_batches._lane_group_grid(emu_session, oracle_lib, 61, lambda i: [2, 17, 9][i % 3], emu=True)
+    assert ran >= 12 and served == ran and not bad, (ran, served, bad[:3])

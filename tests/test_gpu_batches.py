@@ -264,3 +264,49 @@ def test_logadd_on_the_lane_state_engine(gpu_session, oracle_lib):
         if not ok:
             bad.append(({k: c[k] for k in ("K", "thr", "Kt", "N", "T", "dist", "sil_score", "crit")}, why))
     assert ran > 150 and not bad, (ran, bad[:3])
+
+
+def _lane_group_grid(session, oracle_lib, every, T_of, emu=False):
+    """fltx_mlane.h (lane = LM state with 2 / 4 / 8 groups of 64 lanes) against the oracle: beams at and around the
+    group limits (65, 128, 129, 256, 257, 512), small beams forced onto several groups, thresholds 0.5 .. inf, token
+    beams, silScore of both signs, CTC and ASG, max-merge and logAdd, every compiled geometry."""
+    import itertools
+    bad, ran, served = [], 0, 0
+    grid = itertools.product([3, 65, 100, 128, 129, 200, 256, 257, 400, 512], [0.5, 25.0, float("inf")], [None, 5],
+                             [12, 29], ["ctc", "uniform"], [0.0, -0.6, 0.4], ["ctc", "asg"], [False, True])
+    for i, (K, thr, Kt, N, dist, sil, crit, la) in enumerate(grid):
+        if i % every:
+            continue
+        T = T_of(i)
+        c = cases.case("mlg%d" % i, dist=dist, u=1500 + i, T=T, N=N, K=K, Kt=Kt, thr=thr, sil_score=sil, log_add=la,
+                       crit=crit, trans_seed=(60 + i) if crit == "asg" else None)
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if la and any(abs(a.score - b.score) < 1e-4 for a, b in zip(want, want[1:])):
+            continue  # (near ties: a different libm may order them differently)
+        if len({h.score for h in want}) != len(want):
+            continue
+        need = 2 if K <= 128 else (4 if K <= 256 else 8)
+        geos = {2: [0, 1, 2, 3, 4, 5, 6], 4: [3, 4, 5, 6], 8: [6]}[need]
+        d = session.decoder(c, inp)
+        geo = geos[(i // every) % len(geos)]
+        n_list = min(Kt or N, N) - (1 if crit == "ctc" and not Kt else 0)
+        if n_list <= [28, 30, 70, 28, 30, 66, 30][geo]:  # (list positions the geometry's token waves cover)
+            d.set("mlane_geo", geo)
+        if K <= 64:
+            d.set("lane_groups", 2)
+        d.decode_batch(inp["e"], [T], N)
+        got = d.results(0)
+        served += 1 if (d.get("engine") == 4 and d.get("lane_groups") >= need and d.get("redone") == 0) else 0
+        d.close()
+        ok, why = helpers.hyps_equal(want, got, (1e-9 if emu else 1e-5) if la else 0.0)
+        ran += 1
+        if not ok:
+            bad.append(({k: c[k] for k in ("K", "thr", "Kt", "N", "T", "dist", "sil_score", "crit", "log_add")}, why))
+    return ran, served, bad
+
+
+@pytest.mark.gpu
+def test_edge_configurations_of_the_lane_state_engine_with_lane_groups(gpu_session, oracle_lib):
+    ran, served, bad = _lane_group_grid(gpu_session, oracle_lib, 3, lambda i: [1, 2, 23, 90][i % 4])
+    assert ran > 400 and served == ran and not bad, (ran, served, bad[:3])

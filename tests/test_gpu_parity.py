@@ -235,8 +235,15 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     ("lf_asg_t40_n29_kt7", 4, {}), ("lf_ctc_sil", 4, {}), ("C2_ctc_u0", 4, {}), ("C2_uniform_u0", 4, {}),
     ("lf_ctc_t60_k10", 3, {"slane": 0}), ("lf_uni_n64_k64", 3, {"slane": 0}), ("lf_ctc_n29_k64", 3, {"slane": 0}),
     ("lf_ctc_t60_k10_kt5", 3, {"slane": 0}), ("C2_ctc_u0", 3, {"slane": 0}),
-    ("lf_ctc_n29_k65", 2, {}), ("lf_ctc_t60_k10_logadd", 4, {}), ("lf_ctc_t60_k10_logadd", 3, {"slane": 0}),
-    ("C2_ctc_u0_logadd", 4, {}), ("lf_ctc_t300_k100", 2, {}),
+    ("lf_ctc_n29_k65", 4, {}), ("lf_ctc_n29_k65", 2, {"lane_groups": -1}), ("lf_ctc_t60_k10_logadd", 4, {}),
+    ("lf_ctc_t60_k10_logadd", 3, {"slane": 0}), ("C2_ctc_u0_logadd", 4, {}), ("lf_ctc_t300_k100", 4, {}),
+    ("lf_ctc_t300_k100", 2, {"lane_groups": -1}), ("lf_ctc_t300_k100", 2, {"slane": 0}),
+    # every compiled geometry of fltx_mlane.h (rows of kMlaneGeo: 2, 2, 2, 4, 4, 4, 8 lane groups)
+    ("lf_ctc_t300_k100", 4, {"mlane_geo": 0}), ("lf_ctc_t300_k100", 4, {"mlane_geo": 1}),
+    ("lf_ctc_t300_k100", 4, {"mlane_geo": 2}), ("lf_ctc_t300_k100", 4, {"mlane_geo": 3}),
+    ("lf_ctc_t300_k100", 4, {"mlane_geo": 4}), ("lf_ctc_t300_k100", 4, {"mlane_geo": 5}),
+    ("lf_ctc_t300_k100", 4, {"mlane_geo": 6}), ("C2_ctc_u0", 4, {"lane_groups": 2}),
+    ("C2_ctc_u0_logadd", 4, {"lane_groups": 4}), ("C2_ctc_u0_kt10", 4, {"lane_groups": 8}),
     ("lx_spell_t40_k8", 5, {}), ("lx_spell_t60_k12_full", 5, {}), ("lx_uni_t40_k10", 5, {}), ("lx_t0", 5, {}),
     ("C3_spell_u0", 5, {}), ("C3_spell_u255", 5, {}), ("C3_uniform_u0", 5, {}), ("C3_spell_u0", 5, {"slane_threads": 640}),
     ("lx_spell_t60_k12_full", 5, {"slane_threads": 576}), ("lx_spell_t40_k8", 5, {"slane_threads": 640}),
@@ -250,9 +257,10 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
 def test_engine_selection(gpu_session, golden, name, engine, sets):
     """Which engine serves which configuration: the lane = LM state decode (4,
     fltx_slane.h) for offline lexicon-free + ZeroLM max-merge with beam <= 64 and
-    <= 64 tokens (also with a token beam, ASG, silScore, logAdd); the lane-per-slot step
+    <= 64 tokens (also with a token beam, ASG, silScore, logAdd) and, with 2 / 4 / 8 lane groups
+    (fltx_mlane.h), for beams up to 512; the lane-per-slot step
     (3) when the former is switched off; the lean step (2) for
-    bigger beams; the lane = (LM state, trie node) decode (5, fltx_xlane.h) for
+    bigger beams and when the lane groups are switched off; the lane = (LM state, trie node) decode (5, fltx_xlane.h) for
     the offline lexicon decoder + ZeroLM over a lexicon without scores (CTC,
     max-merge, no <unk>, beam <= 64); the same with the LM terms (6, fltx_ylane.h)
     for an n-gram word LM and / or a smeared trie and beams up to 128; the
@@ -467,6 +475,7 @@ def test_lexicon_free_beams_above_the_lane_engines(gpu_session, oracle_lib, K, T
     c = cases.case("leanbeam", dist=dist, T=T, N=29, K=K, u=41)
     e = synth.emissions(dist, c["u"], T, c["N"])
     d = gpu_session.decoder(c, dict(tr=None), threads or None)
+    d.set("lane_groups", -1)  # (beams up to 512 are the lane = LM state engine's otherwise: fltx_mlane.h)
     d.decode_batch(e, [T], c["N"])
     assert d.get("engine") == 2
     want = helpers.run_checker(oracle_lib, c, dict(e=e, tr=None, lex=None))

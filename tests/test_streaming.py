@@ -230,3 +230,39 @@ def test_ragged_parallel_streams_emulated(emu_session, oracle_lib):
                          ids=lambda x: x if isinstance(x, str) else None)
 def test_ragged_parallel_streams(gpu_session, oracle_lib, name, sets):
     _ragged_parallel_streams(gpu_session, oracle_lib, name, sets)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["lx_spell_t60_k12_full", "ng_word_t60_k16_4g"])
+def test_device_chunk_buffer_reused_between_steps(gpu_session, stream_golden, name):
+    """A lexicon stream fed from ONE device buffer that the caller overwrites right after every step: a chunk whose
+    candidate list overflowed (cut forced down to K + 1) is decoded again, and that second pass must not read the
+    caller's buffer after fltx_stream_step has returned (round-3 advisor finding: it was deferred to the next call)."""
+    import ctypes
+    import numpy as np
+    hip = ctypes.CDLL("libamdhip64.so.7")  # (the runtime libfltx.so is linked against: already mapped)
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    N, T = c["N"], c["T"]
+    d = gpu_session.decoder(c, inp)
+    d.set("cut_m", c["K"] + 1)
+    d.stream_begin(1, N, T + 4)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), 4 * 10 * N) == 0
+    junk = np.full(10 * N, -1.0e3, dtype=np.float32)
+    try:
+        for t in range(0, T, 10):
+            chunk = np.ascontiguousarray(inp["e"][t:t + 10], dtype=np.float32).reshape(-1)
+            assert hip.hipMemcpy(buf, chunk.ctypes.data, 4 * chunk.size, 1) == 0  # (synchronous H2D)
+            d.stream_step(None, [chunk.size // N], device_ptr=buf.value)
+            assert hip.hipMemcpy(buf, junk.ctypes.data, 4 * junk.size, 1) == 0  # the caller's buffer again
+        d.stream_end()
+        got = helpers.encode_hyps(d.results(0), True)
+        assert d.get("stream_redone") > 0
+    finally:
+        d.close()
+        hip.hipFree(buf)
+    assert got == stream_golden[name][-1]["final"]

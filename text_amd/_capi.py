@@ -407,11 +407,16 @@ class BatchDecoder:
         self.N = None  # (streams: fltx_result_fetch per utterance)
         self._N = N
 
-    def stream_step(self, emissions, T, offsets=None):
+    def stream_step(self, emissions, T, offsets=None, device_ptr=None):
+        """emissions: host float32 array, or None when device_ptr (int) addresses the chunk in HBM (the buffer
+        is the caller's again as soon as the call returns)."""
         T = np.ascontiguousarray(T, dtype=np.int32)
         if offsets is None:
             offsets = np.concatenate([[0], np.cumsum(T.astype(np.int64) * self._N)[:-1]]).astype(np.int64)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if device_ptr is not None:
+            self.L.check(self.L.lib.fltx_stream_step(self.h, device_ptr, 1, _ptr(offsets), _ptr(T)))
+            return
         e = np.ascontiguousarray(emissions, dtype=np.float32)
         self.L.check(self.L.lib.fltx_stream_step(self.h, _ptr(e), 0, _ptr(offsets), _ptr(T)))
 

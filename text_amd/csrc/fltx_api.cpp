@@ -402,10 +402,14 @@ struct fltx_decoder {
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
   int slaneThreads = 0; /* tuning: workgroup size of the lane = LM state kernel (0 = first that fits) */
   int slane = 0, noSlane = 0; /* slane: list positions per wave of the lane = LM state kernel (fltx_slane.h), 0 = off */
+  /* ... with several lane groups (fltx_mlane.h, beams beyond 64): lane groups (0 / 1 = fltx_slane.h), groups per token
+   * wave, groups per self wave; userLaneGroups: tuning / tests, 0 = as many as the beam needs, -1 = never */
+  int mlaneNG = 0, mlaneGPW = 0, mlaneSPW = 0, userLaneGroups = 0, userMlaneGeo = -1;
   bool preferYlane = false;
   bool genericAsked = false;  /* fltx_decoder_set touched a tunable of the generic engine */
   int engineFirst = 0;
   int lastRedo = 0;           /* utterances of the last offline call that had to be decoded again on a general path */
+  int packedBits = 8;         /* width of the parent-slot field of those records (fltx_mlane.h: 10) */
   bool batchPacked = false;   /* some utterance of the current results has packed history records (ST_PACKED) */
   DBuf xlmword;               /* fltx_ylane.h: LM word id of XNode::endLabel0 per node (this decoder's trie x LM) */
   const fltx_trie* xlmwordTrie = nullptr;
@@ -669,7 +673,12 @@ int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t nNgrams, const in
   lm->eos = eos;
   lm->unk = unk;
   lm->nUsr = nUsr;
-  uint32_t cap = nextPow2((uint64_t)entNode.size() * 4 + 16); /* at most a quarter full: a look-up is a chain of dependent trips to HBM, one more per occupied slot it meets (C4: 2x -> 4x slots = -4 % on the whole kernel) */
+  /* (4x slots: 2^31 slots of 16 B is what the 32-bit slot index reaches; a model beyond 2^29 n-grams takes 2x) */
+  const uint64_t wantSlots = (uint64_t)entNode.size() * ((uint64_t)entNode.size() * 4 + 16 <= (1ull << 31) ? 4 : 2) + 16;
+  if (wantSlots > (1ull << 31)) {
+    return fail(FLTX_ERR_UNSUPPORTED, "too many n-grams for the 32-bit slot index of the look-up table");
+  }
+  uint32_t cap = nextPow2(wantSlots); /* at most a quarter full: a look-up is a chain of dependent trips to HBM, one more per occupied slot it meets (C4: 2x -> 4x slots = -4 % on the whole kernel) */
   lm->mask = cap - 1;
   lm->hTab.assign(cap, NgramSlot{0, kEmpty, 0, 0.0f});
   for (size_t e = 0; e < entNode.size(); ++e) {
@@ -1231,6 +1240,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->streamRedone;
   } else if (!strcmp(key, "slane")) {
     *value = d->slane;
+  } else if (!strcmp(key, "lane_groups")) { /* lane groups of the lane = LM state engine: 1 = fltx_slane.h, 2 / 4 / 8 = fltx_mlane.h */
+    *value = d->slane ? std::max(1, d->mlaneNG) : 0;
   } else if (!strcmp(key, "lane")) {
     *value = d->lane;
   } else if (!strcmp(key, "lean")) {
@@ -1360,6 +1371,14 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noSlane = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "lane_groups")) { /* fltx_mlane.h: 0 = as many lane groups as the beam needs, 2 / 4 / 8 = at least that many, -1 = never */
+    d->userLaneGroups = (int)value;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "mlane_geo")) { /* tuning: row of kMlaneGeo to use (-1 = first that fits) */
+    d->userMlaneGeo = (int)value;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "lane")) { /* 0: beams <= 64 use the lean kernel instead of the lane-per-slot kernel */
     d->noLane = value ? 0 : 1;
     return FLTX_OK;
@@ -1382,6 +1401,14 @@ namespace {
 
 /* geometry + buffers for B streams of up to maxFrames frames (plus seed and
  * decodeEnd slots) */
+/* fltx_mlane.h geometries that are compiled (fltx_instances.h, FLTX_MLANE_SET), fastest first per group count */
+struct MlaneGeo {
+  int threads, gt, ng, gpw, spw;
+};
+static const MlaneGeo kMlaneGeo[] = {{640, 4, 2, 2, 1}, {960, 5, 2, 1, 1}, {640, 10, 2, 2, 1}, {768, 4, 4, 4, 1},
+                                     {960, 5, 4, 2, 2}, {960, 11, 4, 2, 2}, {960, 10, 8, 2, 4}};
+constexpr int kMlaneGeoCount = (int)(sizeof(kMlaneGeo) / sizeof(kMlaneGeo[0]));
+
 int engineOf(const fltx_decoder* d) {
   return d->ylane ? 6 : d->xlane ? 5 : (d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0))));
 }
@@ -1492,6 +1519,32 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       }
     }
   }
+  /* ... with several groups of 64 lanes for beams beyond one wave's lanes (fltx_mlane.h): same candidates, merges and
+   * selection; a wave holds the states of whole lane groups, history records carry 10-bit slots */
+  d->mlaneNG = 0;
+  if ((!d->slane || d->userLaneGroups > 1) && d->lean && !d->noSlane && d->userLaneGroups >= 0 && d->offlineCall && !d->keepScores &&
+      !forceWorstCaseCap && K <= 64 * kMlMaxGroups && (K > 64 || d->userLaneGroups > 1) && N <= 64 &&
+      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
+      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
+      (int64_t)K * (maxT + 2) < (1ll << 31) - 1) {
+    const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
+    const int needNG = std::max((K + 63) / 64, d->userLaneGroups);
+    for (int gi = 0; gi < kMlaneGeoCount; ++gi) {
+      const MlaneGeo& g = kMlaneGeo[gi];
+      if (d->userMlaneGeo >= 0 ? gi != d->userMlaneGeo : (d->userThreads && d->threads != g.threads)) {
+        continue;
+      }
+      const int nBlk = (g.threads / 64 - g.ng / g.spw - 1) / (g.ng / g.gpw);
+      if (g.ng >= needNG && nList <= g.gt * nBlk) {
+        d->slane = g.gt;
+        d->mlaneNG = g.ng;
+        d->mlaneGPW = g.gpw;
+        d->mlaneSPW = g.spw;
+        d->threads = g.threads;
+        break;
+      }
+    }
+  }
   /* ... and the frames of a stream's decodeStep chunks on the same engine (the parked beam, the (parent, token) ->
    * id tables and the history rows keep the lane-per-slot engine's format) */
   d->sstream = 0;
@@ -1576,7 +1629,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       }
     }
   }
-  if (d->lean && !d->lane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
+  if (d->lean && !d->lane && !d->slane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
     Ws t2;
     const size_t need = carveWs(t2, nullptr, K, 1, 64, 1024, N, K + 256, 2, 0, 0, 0, d->threads / 64);
     if (need > kMaxLds) {
@@ -1750,7 +1803,10 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   d->wsInLds = lds;
   if (d->slane) {
-    d->wsBytes = offsetof(SlaneLds, amNB); /* (the stream variant's arrays are its last members) */
+    d->wsBytes = d->mlaneNG == 2   ? sizeof(MlaneLds<2>)
+                 : d->mlaneNG == 4 ? sizeof(MlaneLds<4>)
+                 : d->mlaneNG == 8 ? sizeof(MlaneLds<8>)
+                                   : offsetof(SlaneLds, amNB); /* (the stream variant's arrays are its last members) */
     d->wsInLds = true;
     lds = true;
   }
@@ -2097,6 +2153,34 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       default: return fail(FLTX_ERR_INVALID, "no lane = (LM state, node) kernel for %d threads x %d positions", W, d->xlane);
     }
 #undef FLTX_LAUNCH_XLANE
+  } else if (d->slane && d->mlaneNG > 1) {
+#define FLTX_LAUNCH_MLANE(WW, GG, NG, GPW, SPW)                                                          \
+  do {                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_mlane<WW, GG, NG, GPW, SPW, false>,       \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));            \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_mlane<WW, GG, NG, GPW, SPW, true>,        \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));            \
+    if (d->opt.log_add) {                                                                                \
+      hipLaunchKernelGGL((fltx_decode_kernel_mlane<WW, GG, NG, GPW, SPW, true>), dim3(nGrid), dim3(WW),  \
+                         d->wsBytes, d->ctx->stream, P);                                                 \
+    } else {                                                                                             \
+      hipLaunchKernelGGL((fltx_decode_kernel_mlane<WW, GG, NG, GPW, SPW, false>), dim3(nGrid), dim3(WW), \
+                         d->wsBytes, d->ctx->stream, P);                                                 \
+    }                                                                                                    \
+  } while (0)
+    switch (((W * 100 + d->slane) * 10 + d->mlaneNG) * 100 + d->mlaneGPW * 10 + d->mlaneSPW) {
+      case 64004221: FLTX_LAUNCH_MLANE(640, 4, 2, 2, 1); break;
+      case 96005211: FLTX_LAUNCH_MLANE(960, 5, 2, 1, 1); break;
+      case 64010221: FLTX_LAUNCH_MLANE(640, 10, 2, 2, 1); break;
+      case 76804441: FLTX_LAUNCH_MLANE(768, 4, 4, 4, 1); break;
+      case 96005422: FLTX_LAUNCH_MLANE(960, 5, 4, 2, 2); break;
+      case 96011422: FLTX_LAUNCH_MLANE(960, 11, 4, 2, 2); break;
+      case 96010824: FLTX_LAUNCH_MLANE(960, 10, 8, 2, 4); break;
+      default:
+        return fail(FLTX_ERR_INVALID, "no fltx_mlane.h kernel for %d threads x %d positions x %d lane groups", W, d->slane,
+                    d->mlaneNG);
+    }
+#undef FLTX_LAUNCH_MLANE
   } else if (d->slane) {
     const int key = W * 100 + d->slane;
     switch (key) {
@@ -2285,7 +2369,7 @@ int launchBacktrace(fltx_decoder* d) {
   Q.nbest = 0;
   /* frames per LDS chunk: two record buffers in ({parent, token} 8 B, word 4 B) + token and word tiles out */
 #ifdef FLTX_EMU
-  const int btThreads = d->opt.beam_size > 64 ? 128 : 64; /* (the emitting-model pass is one thread per hypothesis) */
+  const int btThreads = std::min(512, std::max(64, (d->opt.beam_size + 63) / 64 * 64)); /* (the emitting-model pass is one thread per hypothesis) */
 #else
   const int btThreads = 512;
 #endif
@@ -2308,7 +2392,7 @@ int launchBacktrace(fltx_decoder* d) {
   Q.F = F;
   size_t btLds = F > 0 ? (size_t)F * perFrame + 16 : 16;
   if (d->batchPacked && F > 0) { /* packed records; emitting-model scores re-accumulated along the paths */
-    Q.packed = 1;
+    Q.packed = d->packedBits;
     Q.uttStatus = d->uttStatus.as<int32_t>();
     Q.amOut = d->outScores.as<double>();
     Q.emissions = d->lastEmis;
@@ -2581,6 +2665,9 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
       }
     }
     d->batchPacked = d->batchPacked || d->slane || d->xlane || d->ylane;
+    if (d->slane || d->xlane || d->ylane) {
+      d->packedBits = (d->slane && d->mlaneNG > 1) ? 10 : 8; /* (a re-run on a general engine leaves plain records) */
+    }
     if (attempt == 0) {
       d->engineFirst = engineOf(d);
     }
@@ -2815,7 +2902,10 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
     d->chunkPending = true;
     d->pendEmis = P.emissions;
     d->pendSlot = d->upSlot;
-    if (!d->deferRedo && (rc = settleStream(d))) {
+    /* A chunk handed over as a device pointer is the caller's buffer: a second pass deferred to the next call would
+     * read whatever the caller has put there since (one buffer reused chunk after chunk is legal).  Such a chunk is
+     * settled before the call returns; host chunks live in this decoder's own staging slots and may wait. */
+    if ((!d->deferRedo || onDevice) && (rc = settleStream(d))) {
       return rc;
     }
   }
@@ -2908,6 +2998,10 @@ int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
 static int checkStatus(fltx_decoder* d, int b);
 
 int fltx_stream_frames_in_buffer(fltx_decoder* d, int32_t b, int32_t* n) {
+  DeviceScope devScope(d ? d->ctx : nullptr); /* (syncResults may run the deferred second pass of a chunk) */
+  if (devScope.failed) {
+    return fail(FLTX_ERR_HIP, "hipSetDevice failed");
+  }
   if (!d || !n || b < 0 || b >= d->B) {
     return fail(FLTX_ERR_INVALID, "bad argument");
   }

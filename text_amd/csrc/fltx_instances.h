@@ -45,6 +45,18 @@
   FLTX_INST(fltx_decode_kernel_slane_stream<576, 4>)         \
   FLTX_INST(fltx_decode_kernel_slane_stream<512, 5>)         \
   FLTX_INST(fltx_decode_kernel_slane_stream<576, 10>)
+/* ... with several lane groups (fltx_mlane.h): (threads, list positions per wave and group, lane groups, groups per token
+ * wave, groups per self wave).  One line here = one row of kMlaneGeo in fltx_api.cpp. */
+#define FLTX_MLANE_SET(LA)                                     \
+  FLTX_INST(fltx_decode_kernel_mlane<640, 4, 2, 2, 1, LA>)     \
+  FLTX_INST(fltx_decode_kernel_mlane<960, 5, 2, 1, 1, LA>)     \
+  FLTX_INST(fltx_decode_kernel_mlane<640, 10, 2, 2, 1, LA>)    \
+  FLTX_INST(fltx_decode_kernel_mlane<768, 4, 4, 4, 1, LA>)     \
+  FLTX_INST(fltx_decode_kernel_mlane<960, 5, 4, 2, 2, LA>)     \
+  FLTX_INST(fltx_decode_kernel_mlane<960, 11, 4, 2, 2, LA>)    \
+  FLTX_INST(fltx_decode_kernel_mlane<960, 10, 8, 2, 4, LA>)
+#define FLTX_G18(W) FLTX_MLANE_SET(false)
+#define FLTX_G19(W) FLTX_MLANE_SET(true) /* logAdd */
 /* lane = (LM state, trie node) decode (fltx_xlane.h): three waves do not evaluate listed tokens */
 #define FLTX_XLANE_SET(HM, PROF)                               \
   FLTX_INST(fltx_decode_kernel_xlane<512, 2, HM, PROF>)        \
@@ -88,6 +100,8 @@ FLTX_G14(0)
 FLTX_G15(0)
 FLTX_G16(0)
 FLTX_G17(0)
+FLTX_G18(0)
+FLTX_G19(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -107,6 +121,9 @@ FLTX_G17(0)
 #undef FLTX_G15
 #undef FLTX_G16
 #undef FLTX_G17
+#undef FLTX_G18
+#undef FLTX_G19
+#undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET
 #undef FLTX_SLANE_SET

@@ -2626,6 +2626,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 #include "fltx_lean.h"
 #include "fltx_lane.h"
 #include "fltx_slane.h"
+#include "fltx_mlane.h"
 #include "fltx_xlane.h"
 #include "fltx_ylane.h"
 
@@ -2933,7 +2934,8 @@ struct BacktraceParams {
   int32_t* words;
   int32_t nbest;           /* <= 0: all */
   int32_t F;               /* frames per LDS chunk (0: walk straight through HBM) */
-  /* records of the lane = LM state engine (fltx_slane.h): parent slot in the low byte of x (0xFF = none) */
+  /* records of the lane = LM state engines: parent slot in the low `packed` bits of x (all ones = none): 8 for
+   * fltx_slane.h / fltx_xlane.h / fltx_ylane.h, 10 for fltx_mlane.h; 0 = plain {parent, token} records */
   int32_t packed;
   const int32_t* uttStatus; /* ST_PACKED per utterance (a re-run on the generic engine leaves plain records) */
   /* that engine does not carry the emitting-model score through the frames; it is
@@ -2965,6 +2967,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
   const int K = P.K;
   const bool lex = P.kind == 1;
   const bool packed = P.packed && (P.uttStatus[b] & ST_PACKED) != 0;
+  const int pmask = (1 << P.packed) - 1;
   const int64_t hb = P.histOff[b], ob = P.tokOff[b];
   if (P.F <= 0) { /* beam too large for a useful chunk: one thread per hypothesis through HBM */
     for (int k = tid; k < nh; k += W) {
@@ -2978,7 +2981,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
           const int2 pt = P.histPT[idx];
           tokv = packed ? (pt.y < 0 ? pt.y : (pt.y & 0xFF)) : pt.y;
           wv = lex ? P.histW[idx] : -1;
-          slot = packed ? (((pt.x & 0xFF) == 0xFF) ? -1 : (pt.x & 0xFF)) : pt.x;
+          slot = packed ? (((pt.x & pmask) == pmask) ? -1 : (pt.x & pmask)) : pt.x;
         }
         tk[fr] = tokv; /* pruned history: -1 below the cut */
         if (wd) {
@@ -3055,7 +3058,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
               const int2 pt = cPT[j * K + s];
               tokv = packed ? (pt.y < 0 ? pt.y : (pt.y & 0xFF)) : pt.y;
               wv = lex ? cW[j * K + s] : -1;
-              s = packed ? (((pt.x & 0xFF) == 0xFF) ? -1 : (pt.x & 0xFF)) : pt.x;
+              s = packed ? (((pt.x & pmask) == pmask) ? -1 : (pt.x & pmask)) : pt.x;
             }
             oT[k * F + j] = tokv;
             if (P.words) {

@@ -1,0 +1,874 @@
+/*
+ * fltx_mlane.h -- the "lane = LM state" decode of fltx_slane.h with NG groups of 64 lanes: offline
+ * LexiconFreeDecoder + ZeroLM, max-merge or logAdd, beams 65 .. 64 * NG, <= 64 tokens.  Included by
+ * fltx_kernels.h after fltx_slane.h, whose row staging (slRowScan / slRowStore), histogram scan (slScan) and
+ * binning (slBin) it shares.  Same candidates, same merge groups, same selection as
+ * LexiconFreeDecoder::decodeStep (LexiconFreeDecoder.cpp:30-125) with candidatesStore (Utils.h:146-225):
+ * bit-identical n-best.
+ *
+ * What a beam beyond one wave's lanes changes:
+ *   * A wave holds the states of whole lane groups in registers: token wave w evaluates the GT list positions of
+ *     its block for GPW groups (GT * GPW candidates per lane); a self wave owns the blank / repeat /
+ *     blank-then-last groups of SPW lane groups.  Roles are compile-time as in fltx_slane.h.
+ *   * Survivors are compacted group by group: a self wave publishes its groups' counts before barrier 2 and every
+ *     wave adds up the groups in front of the one it addresses after it (NG <= 8 words, one LDS read).
+ *   * Records carry 10-bit history slots and lane numbers; a history record is
+ *       x = parent slot (10 bit, 0x3FF none) | entered-a-new-state (1 bit) | parent state id, low 21 bit
+ *       y = token (8 bit) | parent state id, high bits << 8
+ *     (the back-trace masks the slot field: BacktraceParams::packed = 10).
+ *   * decodeEnd ranks up to 64 * NG states through LDS instead of lane broadcasts.
+ *
+ * Three barriers per frame, as in fltx_slane.h.
+ */
+#pragma once
+
+constexpr uint32_t kMlNoHyp = 0x3FFu;   /* no history slot / no parent slot */
+constexpr uint32_t kMlNewFlag = 0x400u; /* history record: the hypothesis entered a new LM state */
+constexpr int kMlSidShift = 11;         /* x = slot | flag | (sid & 0x1FFFFF) << 11 */
+constexpr int kMlSidLowBits = 21;
+constexpr int kMlMaxGroups = 8;
+
+struct MlRec { /* one LM state of the beam, 32 B */
+  double nb;     /* score of (S, last token, prevBlank = false) */
+  double b;      /* score of (S, blank, prevBlank = true) */
+  uint32_t info; /* last token | (parent lane + 1) << 8 */
+  uint32_t sid;  /* state id = history index (row * K + slot) of the hypothesis that entered it */
+  uint32_t spar; /* id of the parent state */
+  uint32_t hyps; /* history slot of nb | of b << 16 (kMlNoHyp = absent) */
+};
+
+template <int NG>
+struct MlaneLds {
+  static constexpr int kLanes = 64 * NG;
+  MlRec rec[2][kLanes];
+  unsigned long long cmask[2][kLanes]; /* tokens whose child state is in the beam and linked to this lane */
+  unsigned long long mask[2][kLanes];  /* tokens whose child state was ever materialised */
+  uint32_t hist[2][kSlNB];
+  double eAll[2][64];
+  double eTok[2][kSlList];
+  unsigned long long tokBit[2][kSlList];
+  SlRow row[2];
+  uint8_t tokId[2][kSlList];
+  uint32_t off[32];         /* new states of the waves before wave i; [last wave] = all */
+  int32_t newLane[kLanes];  /* old lane -> index among its group's survivors, -1 = dropped */
+  uint32_t grp[kMlMaxGroups]; /* per lane group: surviving states | surviving hypotheses << 16 */
+  uint32_t scal[16];
+  unsigned long long bKey[kSlBCap];
+  uint32_t bOrd[kSlBCap];
+  uint32_t evLane[kLanes], evSpar[kLanes], evTok[kLanes];
+  unsigned long long scanMask;
+  unsigned long long mmaxKey[2];
+  uint32_t scanMin, pad0;
+  float raw[3][64];
+};
+enum { ML_BCNT = 2, ML_NOUT = 6 };
+
+FLTX_DEV uint32_t mlParentSid(uint32_t x, uint32_t y) { return (x >> kMlSidShift) | ((y >> 8) << kMlSidLowBits); }
+FLTX_DEV int2 mlNewRec(uint32_t hp, uint32_t parSid, int n) {
+  return make_int2((int)(hp | kMlNewFlag | (parSid << kMlSidShift)), (int)((uint32_t)n | ((parSid >> kMlSidLowBits) << 8)));
+}
+
+/* Re-entry of LM states that had dropped out of the beam: fltx_slane.h's slReenter over the wider records.
+ * All waves; rare. */
+template <typename LDS>
+FLTX_DEV __attribute__((noinline)) void mlReenter(LDS& S, const int2* histPT, int q, int nState, int64_t hbase,
+                                                   int64_t nRec) {
+  const int tid = (int)threadIdx.x, W = (int)blockDim.x;
+  const int nev = (int)S.row[q].nev;
+#ifndef FLTX_EMU
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's history stores have reached the L2 */
+#endif
+  ldsBarrier();
+  for (int e = 0; e < nev; ++e) {
+    const int X = (int)S.evLane[e];
+    const uint32_t ps = S.evSpar[e], n = S.evTok[e];
+    if (tid == 0) {
+      S.scanMin = 0xFFFFFFFFu;
+      S.scanMask = 0ull;
+    }
+    ldsBarrier();
+    const unsigned long long* h = (const unsigned long long*)(histPT + hbase);
+    uint32_t found = 0xFFFFFFFFu;
+    for (int64_t i = tid; i < nRec; i += W) {
+      const unsigned long long r = loadCoherent64(h + i);
+      const uint32_t x = (uint32_t)r, y = (uint32_t)(r >> 32);
+      if ((x & kMlNewFlag) && (r >> 63) == 0ull && (y & 0xFFu) == n && mlParentSid(x, y) == ps) {
+        found = found < (uint32_t)i ? found : (uint32_t)i;
+      }
+    }
+    if (found != 0xFFFFFFFFu) {
+      atomMin32(&S.scanMin, found);
+    }
+    ldsBarrier();
+    const uint32_t sid = S.scanMin;
+    if (sid != 0xFFFFFFFFu) {
+      unsigned long long kids = 0ull;
+      for (int64_t i = tid; i < nRec; i += W) {
+        const unsigned long long r = loadCoherent64(h + i);
+        const uint32_t x = (uint32_t)r, y = (uint32_t)(r >> 32);
+        if ((x & kMlNewFlag) && (r >> 63) == 0ull && mlParentSid(x, y) == sid) {
+          kids |= 1ull << (y & 63u);
+        }
+      }
+      if (kids) {
+        atomOr64(&S.scanMask, kids);
+      }
+      ldsBarrier();
+      if (tid == 0) {
+        S.rec[q][X].sid = sid;
+        S.mask[q][X] |= S.scanMask;
+      }
+      for (int l = tid; l < nState; l += W) { /* orphans get their parent back */
+        if (l != X && S.rec[q][l].spar == sid) {
+          const uint32_t info = S.rec[q][l].info;
+          S.rec[q][l].info = (info & 0xFFu) | ((uint32_t)(X + 1) << 8);
+          atomOr64(&S.cmask[q][X], 1ull << (info & 63u));
+        }
+      }
+    }
+    ldsBarrier();
+  }
+  if (tid == 0) {
+    S.row[q].nev = 0u;
+  }
+  ldsBarrier();
+}
+
+/* GT = list positions per token wave and group, NG = lane groups, GPW = groups a token wave evaluates, SPW = groups
+ * a self wave owns, LA = logAdd.  Waves: (NG / GPW) x nBlk token waves (block = wave % nBlk, group set = wave / nBlk),
+ * NG / SPW self waves, one wave that stages the emission rows. */
+template <int GT, int NG, int GPW, int SPW, bool LA>
+FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
+  static_assert(NG >= 1 && NG <= kMlMaxGroups && NG % GPW == 0 && NG % SPW == 0, "lane groups per wave");
+  constexpr int NC = GT * GPW; /* candidates per lane of a wave */
+  static_assert(3 * SPW <= NC, "a self wave keeps three groups per lane group in the slot arrays");
+  constexpr int NU = GPW > SPW ? GPW : SPW;
+  constexpr int LN = 64 * NG;
+  constexpr int nSW = NG / SPW, nGS = NG / GPW;
+  using LDS = MlaneLds<NG>;
+  LDS& S = *(LDS*)smem;
+  const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
+  const int W = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int lane = laneId(), wave = waveUniform(waveId());
+  const int nW = W >> 6;
+  const int nTW = nW - nSW - 1;
+  const int nBlk = nTW / nGS;
+  const int prepWave = nW - 1;
+  const bool isTokW = wave < nTW, isSvcW = wave == prepWave;
+  const int blk = isTokW ? wave % nBlk : 0;
+  const int g0 = isTokW ? (wave / nBlk) * GPW : (isSvcW ? 0 : (wave - nTW) * SPW); /* first lane group of this wave */
+  const int pos0 = blk * GT;
+  const int K = P.K, N = P.N;
+  const bool ctc = P.criterion == 1;
+  const int T = P.stepT ? P.stepT[b] : 0;
+  const float* em = P.emissions ? P.emissions + P.emOff[b] : nullptr;
+  const int64_t hbase = P.histOff[b];
+  const double NEG = slNegInf();
+
+  /* ---- decodeBegin (LexiconFreeDecoder.cpp:20-28): the root state ------------------ */
+  for (int i = tid; i < 2 * LN; i += W) {
+    ((unsigned long long*)S.cmask)[i] = 0ull;
+    ((unsigned long long*)S.mask)[i] = 0ull;
+  }
+  for (int i = tid; i < 2 * kSlNB; i += W) {
+    ((uint32_t*)S.hist)[i] = 0u;
+  }
+  if (tid < 32) {
+    S.off[tid] = 0u;
+  }
+  if (tid < 16) {
+    S.scal[tid] = 0u;
+  }
+  if (tid < kMlMaxGroups) {
+    S.grp[tid] = 0u;
+  }
+  if (tid == 0) {
+    MlRec r;
+    r.nb = 0.0;
+    r.b = NEG;
+    r.info = (uint32_t)P.sil;
+    r.sid = 0u;
+    r.spar = 0xFFFFFFFFu;
+    r.hyps = 0u | (kMlNoHyp << 16);
+    S.rec[0][0] = r;
+    S.row[0].nev = 0u;
+    S.row[1].nev = 0u;
+    S.row[0].dead = 0u;
+    S.row[1].dead = 0u;
+    S.mmaxKey[0] = f64Key(0.0);
+    S.mmaxKey[1] = 0ull;
+    P.histPT[hbase] = make_int2((int)kMlNoHyp, P.sil);
+  }
+  for (int i = tid; i < K; i += W) { /* unused slots of a row never look like the record of a new state (mlReenter) */
+    if (i > 0) {
+      P.histPT[hbase + i] = make_int2((int)kMlNoHyp, -1);
+    }
+  }
+  double bestChain = 0.0;
+  if (wave == prepWave) {
+    const float v0 = (T > 0 && lane < N) ? em[lane] : 0.0f;
+    ldsRowLoad(S.raw[1], em + (size_t)1 * N + lane, T > 1 && lane < N);
+    ldsRowLoad(S.raw[2], em + (size_t)2 * N + lane, T > 2 && lane < N);
+    SlRowRegs r0 = slRowScan(P, v0, ctc, 0.0);
+    bestChain = r0.best;
+    slRowStore(P, S, 0, r0, 2);
+    slRowStore(P, S, 1, r0, 2);
+  }
+  ldsBarrier();
+
+  int nState = 1;
+  double endBest = 0.0;
+  int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
+  bool dead = false;
+  const int sil = P.sil, blank = P.blank;
+  const double silScore = P.silScore;
+  int2* const histPT = P.histPT;
+
+  auto frameStep = [&](auto PT, auto RL, const int t) {
+    constexpr int p = decltype(PT)::value, q = p ^ 1;
+    constexpr bool isTok = decltype(RL)::value == 0, isSelf = decltype(RL)::value == 1, isSvc = decltype(RL)::value == 2;
+    constexpr int U = isTok ? GPW : (isSelf ? SPW : 0); /* lane groups this wave holds */
+    const int frameOut = t + 1;
+    const int64_t hrow = hbase + (int64_t)frameOut * K;
+    /* ---- phase 1: own states, candidates, histogram ------------------------------------ */
+    double best = S.row[p].best, thr = S.row[p].thr;
+    const int silPos = S.row[p].silPos;
+    uint32_t rowDead = S.row[p].dead;
+    const uint32_t nev = S.row[p].nev;
+    if (LA) {
+      const double mmax = f64FromKey(S.mmaxKey[p]);
+      const uint32_t ek = S.row[p].ekey;
+      const double sS = (mmax + (double)S.row[p].esil) + silScore;
+      bool any = ek != 0u;
+      best = any ? mmax + (double)f32FromKey(ek) : 0.0;
+      if (((S.row[p].allow >> sil) & 1ull) != 0ull && sS == sS && (!any || sS > best)) {
+        best = sS;
+        any = true;
+      }
+      thr = best - P.beamThreshold;
+      rowDead = (!any || !(best - best == 0.0)) ? 1u : 0u;
+    }
+    MlRec me[NU];
+    unsigned long long cm[NU], mk[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      me[i] = MlRec{};
+      cm[i] = 0ull;
+      mk[i] = 0ull;
+      if (i < U) {
+        const int L = (g0 + i) * 64 + lane;
+        me[i] = S.rec[p][L];
+        cm[i] = S.cmask[p][L];
+        mk[i] = S.mask[p][L];
+      }
+    }
+    double ev[GT];
+    unsigned long long tb[GT];
+    double eBlank = 0.0;
+    unsigned long long allow = 0ull;
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      ev[j] = 0.0;
+      tb[j] = 0ull;
+    }
+    if (isSelf) {
+      eBlank = S.eAll[p][ctc ? blank : 0];
+      allow = S.row[p].allow;
+    } else if (isTok) {
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        ev[j] = S.eTok[p][pos0 + j];
+        tb[j] = S.tokBit[p][pos0 + j];
+      }
+    }
+    if (nev != 0u) { /* rare: states re-entered the beam in the previous build */
+      mlReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        if (i < U) {
+          const int L = (g0 + i) * 64 + lane;
+          me[i] = S.rec[p][L];
+          cm[i] = S.cmask[p][L];
+          mk[i] = S.mask[p][L];
+        }
+      }
+    }
+    if (rowDead) {
+      dead = true;
+      return;
+    }
+    bool live[NU], whichB[NU];
+    double nbv[NU], bbv[NU], m[NU];
+    int last[NU], pl[NU];
+    uint32_t hypNB[NU], hypB[NU], hypM[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      live[i] = i < U && (g0 + i) * 64 + lane < nState;
+      nbv[i] = live[i] ? me[i].nb : NEG;
+      bbv[i] = live[i] ? me[i].b : NEG;
+      last[i] = (int)(me[i].info & 63u);
+      pl[i] = live[i] ? (int)(me[i].info >> 8) - 1 : -1;
+      hypNB[i] = me[i].hyps & 0xFFFFu;
+      hypB[i] = me[i].hyps >> 16;
+      whichB[i] = bbv[i] > nbv[i];
+      m[i] = whichB[i] ? bbv[i] : nbv[i];
+      hypM[i] = whichB[i] ? hypB[i] : hypNB[i];
+    }
+    /* self waves: what their groups need beyond the lanes' own records (second LDS round trip) */
+    MlRec par[NU];
+    double eLast[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      par[i] = MlRec{};
+      eLast[i] = 0.0;
+      if (isSelf && i < U) {
+        par[i] = S.rec[p][pl[i] >= 0 ? pl[i] : 0];
+        eLast[i] = S.eAll[p][last[i]];
+      }
+    }
+    double cs[NC];
+    int cbin[NC];
+    uint32_t parR[NU];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      cs[c] = NEG;
+      cbin[c] = kSlInvalid;
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      parR[i] = kMlNoHyp;
+    }
+    SlRowRegs nextRow = {};
+    if (isSvc) {
+      if (t + 1 < T) {
+        ldsRowWait();
+        const float rv = lane < N ? S.raw[(t + 1) % 3][lane] : 0.0f;
+        nextRow = slRowScan(P, rv, ctc, bestChain);
+        bestChain = nextRow.best;
+      }
+      ldsRowLoad(S.raw[t % 3], em + (size_t)(t + 3) * N + lane, t + 3 < T && lane < N);
+      if (LA && lane == 0) {
+        S.mmaxKey[q] = 0ull;
+      }
+    } else if (isTok) {
+      const int silJ = silPos - pos0;
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        /* tokens this lane does not extend with here: its own last token (repeat and blank-then-last belong to the
+         * self wave) and those whose child state holds a lane (that lane merges the extension into its repeat) */
+        const uint32_t lastLo = last[i] < 32 ? 1u << last[i] : 0u, lastHi = last[i] < 32 ? 0u : 1u << (last[i] - 32);
+        const uint32_t skLo = live[i] ? ((uint32_t)cm[i] | lastLo) : 0xFFFFFFFFu;
+        const uint32_t skHi = live[i] ? ((uint32_t)(cm[i] >> 32) | lastHi) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          double c = m[i] + ev[j]; /* NaN past the end of the list */
+          if (j == silJ) {
+            c = c + silScore;
+          }
+          const uint32_t hit = (skLo & (uint32_t)tb[j]) | (skHi & (uint32_t)(tb[j] >> 32));
+          const bool ok = hit == 0u && c >= thr;
+          if (LA) {
+            double c2 = (whichB[i] ? nbv[i] : bbv[i]) + ev[j];
+            if (j == silJ) {
+              c2 = c2 + silScore;
+            }
+            if (ok && (whichB[i] ? hypNB[i] : hypB[i]) != kMlNoHyp && c2 >= thr) {
+              c = slLogAdd(c, c2);
+            }
+          }
+          cs[i * GT + j] = c;
+          cbin[i * GT + j] = ok ? slBin<LA>(best, c, winShift, winBase) : kSlInvalid;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const bool lastOk = live[i] && ((allow >> last[i]) & 1ull) != 0ull && !(ctc && last[i] == blank);
+        const bool lastSil = last[i] == sil;
+        /* (S, blank, true): LexiconFreeDecoder.cpp:86-97 */
+        double cB = m[i] + eBlank;
+        if (blank == sil) {
+          cB = cB + silScore;
+        }
+        const bool okB = ctc && live[i] && ((allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB >= thr;
+        if (LA) {
+          double cB2 = (whichB[i] ? nbv[i] : bbv[i]) + eBlank;
+          if (blank == sil) {
+            cB2 = cB2 + silScore;
+          }
+          if (okB && (whichB[i] ? hypNB[i] : hypB[i]) != kMlNoHyp && cB2 >= thr) {
+            cB = slLogAdd(cB, cB2);
+          }
+        }
+        /* (S, last, false): the repeat (:98-110) and the parent state's extension by last (:69-85) */
+        const int lastP = (int)(par[i].info & 63u);
+        const uint32_t h1 = par[i].hyps & 0xFFFFu, h2 = par[i].hyps >> 16;
+        const bool has0 = hypNB[i] != kMlNoHyp;
+        const bool has1 = pl[i] >= 0 && last[i] != lastP && h1 != kMlNoHyp;
+        const bool has2 = pl[i] >= 0 && ctc && h2 != kMlNoHyp;
+        const bool hasB = hypB[i] != kMlNoHyp;
+        double r0 = nbv[i] + eLast[i];
+        double r1 = has1 ? par[i].nb + eLast[i] : NEG;
+        double r2 = has2 ? par[i].b + eLast[i] : NEG;
+        double cL = bbv[i] + eLast[i]; /* (S.last, last, false) from (S, blank, true) when no lane holds S.last */
+        if (silScore != 0.0) {
+          r0 = lastSil ? r0 + silScore : r0;
+          r1 = lastSil ? r1 + silScore : r1;
+          r2 = lastSil ? r2 + silScore : r2;
+          cL = lastSil ? cL + silScore : cL;
+        }
+        /* max-merge (Utils.h:194-196); a tie goes to the lower history slot */
+        double cR = r0;
+        uint32_t pR = hypNB[i];
+        if (has1 && (r1 > cR || (r1 == cR && h1 < pR))) {
+          cR = r1;
+          pR = h1;
+        }
+        if (has2 && (r2 > cR || (r2 == cR && h2 < pR))) {
+          cR = r2;
+          pR = h2;
+        }
+        bool okR = lastOk && (has0 || has1 || has2) && cR >= thr;
+        if (LA) {
+          const bool v0 = has0 && r0 >= thr, v1 = has1 && r1 >= thr, v2 = has2 && r2 >= thr;
+          okR = lastOk && (v0 || v1 || v2);
+          double a = v0 ? r0 : NEG, bq = v1 ? r1 : NEG, cq = v2 ? r2 : NEG;
+          double t0 = a > bq ? a : bq, t1 = a > bq ? bq : a;
+          const double hi = t0 > cq ? t0 : cq;
+          const double mid = t0 > cq ? (t1 > cq ? t1 : cq) : t0;
+          const double lo = t0 > cq ? (t1 > cq ? cq : t1) : t1;
+          double acc = hi;
+          if (mid > NEG) {
+            acc = slLogAdd(acc, mid);
+          }
+          if (lo > NEG) {
+            acc = slLogAdd(acc, lo);
+          }
+          cR = okR ? acc : cR;
+        }
+        const bool okL = ctc && lastOk && hasB && ((cm[i] >> last[i]) & 1ull) == 0ull && cL >= thr;
+        parR[i] = pR;
+        cs[3 * i + 0] = cB;
+        cs[3 * i + 1] = cR;
+        cs[3 * i + 2] = cL;
+        cbin[3 * i + 0] = okB ? slBin<LA>(best, cB, winShift, winBase) : kSlInvalid;
+        cbin[3 * i + 1] = okR ? slBin<LA>(best, cR, winShift, winBase) : kSlInvalid;
+        cbin[3 * i + 2] = okL ? slBin<LA>(best, cL, winShift, winBase) : kSlInvalid;
+      }
+    }
+    /* housekeeping: what this frame's build adds to (the first block's waves wipe their groups' masks) */
+    if (isTok && blk == 0) {
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        S.cmask[q][(g0 + i) * 64 + lane] = 0ull;
+        S.mask[q][(g0 + i) * 64 + lane] = 0ull;
+      }
+    }
+    if (wave == 0) {
+      if (lane < 32) {
+        S.off[lane] = 0u;
+      }
+      if (lane == 0) {
+        S.scal[ML_BCNT] = 0u;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (cbin[c] < kSlFar) {
+        atomAdd32(&S.hist[p][cbin[c]], 1u);
+      }
+    }
+    ldsBarrier(); /* 1 */
+    /* ---- phase 2: which candidates survive (Utils.h:200-220) ---------------------------- */
+    unsigned long long selMask[NC];
+    SlScan sc;
+    int shift = winShift, base = winBase;
+    unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+    bool full = false;
+    for (;;) {
+      sc = slScan(S.hist[p], K, !full);
+      if (!full && !sc.crossed) {
+        int nFar = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          nFar += popc64(waveBallot(cbin[c] == kSlFar));
+        }
+        if (lane == 0 && nFar > 0) {
+          atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
+        }
+        full = true;
+        ldsBarrier();
+        continue;
+      }
+      if (sc.total <= K) {
+        const int lim = full ? kSlFar : kSlFar - 1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          selMask[c] = waveBallot(cbin[c] <= lim);
+        }
+        break;
+      }
+      const int need = K - sc.cum;
+      if (sc.cnt == need) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          selMask[c] = waveBallot(cbin[c] <= sc.bstar);
+        }
+        break;
+      }
+      if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
+        uint32_t take = 0u;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (cbin[c] == sc.bstar) {
+            const uint32_t i = atomAdd32(&S.scal[ML_BCNT], 1u);
+            S.bKey[i] = f64Key(cs[c]);
+            S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
+          }
+        }
+        ldsBarrier();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (cbin[c] == sc.bstar) {
+            const unsigned long long k = f64Key(cs[c]);
+            const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
+            int rank = 0;
+            for (int i = 0; i < sc.cnt; ++i) {
+              const unsigned long long k2 = S.bKey[i];
+              rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
+            }
+            take |= rank < need ? (1u << c) : 0u;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          selMask[c] = waveBallot(cbin[c] < sc.bstar || ((take >> c) & 1u) != 0u);
+        }
+        break;
+      }
+      { /* too many in one bin: look again through the finest window that spans the bracket */
+        const unsigned long long v = (unsigned long long)(sc.bstar + base);
+        if (sc.bstar > 0 || base == 0) {
+          const unsigned long long l2 = v << shift;
+          bLo = l2 > bLo ? l2 : bLo;
+        }
+        if (sc.bstar < kSlNB - 1) {
+          const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
+          bHi = h2 < bHi ? h2 : bHi;
+        }
+        if (bLo >= bHi) {
+          dead = true;
+          break;
+        }
+        int ns = 0;
+        while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
+          ++ns;
+        }
+        shift = ns;
+        base = (int)(bLo >> ns);
+      }
+      ldsBarrier();
+      for (int i = tid; i < kSlNB; i += W) {
+        S.hist[p][i] = 0u;
+      }
+      ldsBarrier();
+      full = true;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (cbin[c] != kSlInvalid) {
+          cbin[c] = slBin<LA>(best, cs[c], shift, base);
+          atomAdd32(&S.hist[p][cbin[c]], 1u);
+        }
+      }
+      ldsBarrier();
+    }
+    if (dead) {
+      return;
+    }
+    if (sc.total > K) { /* next frame's window: the K-th best in the middle, 128 bins per octave */
+      const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
+                                            : (sc.bstar + base) >> (kSlFineShift - shift);
+      winShift = kSlFineShift;
+      winBase = q15 > kSlMid ? q15 - kSlMid : 0;
+    }
+    /* new lanes: survivors first (group by group), then the new states wave by wave */
+    int nNewWave = 0;
+    int myNew[NC];
+    int surv[NU];
+    uint32_t hNB[NU], hB[NU];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      myNew[c] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      surv[i] = -1;
+      hNB[i] = 0u;
+      hB[i] = 0u;
+    }
+    if (isTok) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (selMask[c] != 0ull) {
+          myNew[c] = nNewWave + wavePrefixCount(selMask[c]);
+          nNewWave += popc64(selMask[c]);
+        }
+      }
+    } else if (isSelf) {
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const unsigned long long balB = selMask[3 * i], balR = selMask[3 * i + 1], balL = selMask[3 * i + 2];
+        const unsigned long long balS = balB | balR;
+        const bool sR = ((balR >> lane) & 1ull) != 0ull;
+        surv[i] = ((balS >> lane) & 1ull) ? wavePrefixCount(balS) : -1;
+        hNB[i] = (uint32_t)(wavePrefixCount(balR) + wavePrefixCount(balB));
+        hB[i] = hNB[i] + (sR ? 1u : 0u);
+        myNew[3 * i + 2] = nNewWave + wavePrefixCount(balL);
+        nNewWave += popc64(balL);
+        S.newLane[(g0 + i) * 64 + lane] = surv[i];
+        if (lane == 0) {
+          S.grp[g0 + i] = (uint32_t)popc64(balS) | ((uint32_t)(popc64(balR) + popc64(balB)) << 16);
+        }
+      }
+    }
+    if (!isSvc && lane > wave && lane < nW && nNewWave > 0) {
+      atomAdd32(&S.off[lane], (uint32_t)nNewWave);
+    }
+    if (LA && !isSvc) { /* the best hypothesis of the next beam */
+      unsigned long long k = 0ull;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const unsigned long long kj = ((selMask[c] >> lane) & 1ull) ? f64Key(cs[c]) : 0ull;
+        k = kj > k ? kj : k;
+      }
+      if (waveBallot(k != 0ull) != 0ull) {
+        k = waveMax64(k);
+        if (lane == 0) {
+          atomMax64(&S.mmaxKey[q], k);
+        }
+      }
+    }
+    ldsBarrier(); /* 2 */
+    /* ---- phase 3: every survivor is written by the lane that evaluated it ---------------- */
+    uint32_t gcnt[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      gcnt[g] = S.grp[g];
+    }
+    const int offW = (int)S.off[wave], nNew = (int)S.off[nW - 1];
+    int mySlot[NU], plSlot[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      mySlot[i] = -1;
+      plSlot[i] = -1;
+      if (i < U) {
+        mySlot[i] = S.newLane[(g0 + i) * 64 + lane];
+        if (isSelf) {
+          plSlot[i] = S.newLane[pl[i] >= 0 ? pl[i] : 0];
+        }
+      }
+    }
+    int nSurv = 0, nHSurv = 0;
+    int baseS[NU], baseH[NU], basePl[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      baseS[i] = 0;
+      baseH[i] = 0;
+      basePl[i] = 0;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int cS = (int)(gcnt[g] & 0xFFFFu), cH = (int)(gcnt[g] >> 16);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        if (i < U) {
+          baseS[i] += g < g0 + i ? cS : 0;
+          baseH[i] += g < g0 + i ? cH : 0;
+          if (isSelf) {
+            basePl[i] += g < (pl[i] >> 6) ? cS : 0;
+          }
+        }
+      }
+      nSurv += cS;
+      nHSurv += cH;
+    }
+    auto newState = [&](int idx, double c, int n, uint32_t hp, const MlRec& src, unsigned long long srcMask, int srcNew) {
+      const int nl = nSurv + idx;
+      const uint32_t hyp = (uint32_t)(nHSurv + idx);
+      MlRec r;
+      r.nb = c;
+      r.b = NEG;
+      r.info = (uint32_t)n | ((uint32_t)(srcNew + 1) << 8);
+      r.hyps = hyp | (kMlNoHyp << 16);
+      r.sid = (uint32_t)frameOut * (uint32_t)K + hyp;
+      r.spar = src.sid;
+      const bool again = ((srcMask >> n) & 1ull) != 0ull; /* this edge had a child before */
+      S.rec[q][nl] = r;
+      if (srcNew >= 0) {
+        atomOr64(&S.cmask[q][srcNew], 1ull << n);
+        atomOr64(&S.mask[q][srcNew], 1ull << n);
+      }
+      histPT[hrow + hyp] = mlNewRec(hp, src.sid, n);
+      if (again) { /* it may have descendants in the beam */
+        const uint32_t e = atomAdd32(&S.row[q].nev, 1u);
+        S.evLane[e] = (uint32_t)nl;
+        S.evSpar[e] = src.sid;
+        S.evTok[e] = (uint32_t)n;
+      }
+    };
+    if (isSvc) {
+      if (t + 1 < T) {
+        slRowStore(P, S, q, nextRow, P.Kt < N ? 1 : 0);
+      }
+      ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
+    } else if (isTok) {
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int srcNew = mySlot[i] >= 0 ? baseS[i] + mySlot[i] : -1;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          const int c = i * GT + j;
+          if (selMask[c] != 0ull) {
+            if ((selMask[c] >> lane) & 1ull) {
+              const int nTok = (int)S.tokId[p][pos0 + j];
+              newState(offW + myNew[c], cs[c], nTok, hypM[i], me[i], mk[i], srcNew);
+            }
+          }
+        }
+      }
+    } else {
+      for (int i = (wave - nTW) * 64 + lane; i < K; i += nSW * 64) { /* unused slots of the history row: see mlReenter */
+        if (i >= nHSurv + nNew) {
+          histPT[hrow + i] = make_int2((int)kMlNoHyp, -1);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int srcNew = mySlot[i] >= 0 ? baseS[i] + mySlot[i] : -1;
+        if (surv[i] >= 0) {
+          const bool sB = ((selMask[3 * i] >> lane) & 1ull) != 0ull, sR = ((selMask[3 * i + 1] >> lane) & 1ull) != 0ull;
+          const int pln = (pl[i] >= 0 && plSlot[i] >= 0) ? basePl[i] + plSlot[i] : -1;
+          const uint32_t slotNB = (uint32_t)baseH[i] + hNB[i], slotB = (uint32_t)baseH[i] + hB[i];
+          MlRec r;
+          r.nb = sR ? cs[3 * i + 1] : NEG;
+          r.b = sB ? cs[3 * i] : NEG;
+          r.info = (uint32_t)last[i] | ((uint32_t)(pln + 1) << 8);
+          r.hyps = (sR ? slotNB : kMlNoHyp) | ((sB ? slotB : kMlNoHyp) << 16);
+          r.sid = me[i].sid;
+          r.spar = me[i].spar;
+          S.rec[q][srcNew] = r;
+          if (mk[i]) {
+            atomOr64(&S.mask[q][srcNew], mk[i]);
+          }
+          if (pln >= 0) {
+            atomOr64(&S.cmask[q][pln], 1ull << last[i]);
+          }
+          if (sR) {
+            histPT[hrow + slotNB] = make_int2((int)parR[i], last[i]);
+          }
+          if (sB) {
+            histPT[hrow + slotB] = make_int2((int)hypM[i], blank);
+          }
+        }
+        if ((selMask[3 * i + 2] >> lane) & 1ull) {
+          newState(offW + myNew[3 * i + 2], cs[3 * i + 2], last[i], hypB[i], me[i], mk[i], srcNew);
+        }
+      }
+    }
+    nState = nSurv + nNew;
+    endBest = best;
+    ldsBarrier(); /* 3 */
+  };
+  auto frames = [&](auto RL) {
+    int t = 0;
+    for (; t + 1 < T && !dead; t += 2) {
+      frameStep(SlParity<0>(), RL, t);
+      if (dead) {
+        break;
+      }
+      frameStep(SlParity<1>(), RL, t + 1);
+    }
+    if (!dead && t < T) {
+      frameStep(SlParity<0>(), RL, t);
+    }
+  };
+  if (isSvcW) {
+    frames(SlParity<2>());
+  } else if (!isTokW) {
+    frames(SlParity<1>());
+  } else {
+    frames(SlParity<0>());
+  }
+
+  /* ---- decodeEnd (LexiconFreeDecoder.cpp:127-158): finish() keeps the state, token = sil; the two hypotheses of
+   * a state merge; sorted n-best (candidatesStore returnSorted).  Up to 64 * NG states: keys through LDS. ---- */
+  const int pe = T & 1;
+  const int ff = T + 1;
+  if (!dead) {
+    unsigned long long* keyTab = S.cmask[pe ^ 1]; /* (free: the next build never runs) */
+    uint32_t* hpTab = (uint32_t*)S.newLane;
+    if (LA) {
+      endBest = f64FromKey(S.mmaxKey[pe]);
+    }
+    const double thr = endBest - P.beamThreshold;
+    for (int base = 0; base < LN; base += W) {
+      const int l = base + tid;
+      if (l < LN) {
+        const bool lv = l < nState;
+        const MlRec me = S.rec[pe][lv ? l : 0];
+        const double nb = lv ? me.nb : NEG, bb = lv ? me.b : NEG;
+        const bool wB = bb > nb;
+        double mm = wB ? bb : nb;
+        const uint32_t hp = wB ? (me.hyps >> 16) : (me.hyps & 0xFFFFu);
+        const bool ok = lv && mm >= thr;
+        if (LA && ok) {
+          const double lo = wB ? nb : bb;
+          const uint32_t hl = wB ? (me.hyps & 0xFFFFu) : (me.hyps >> 16);
+          if (hl != kMlNoHyp && lo >= thr) {
+            mm = slLogAdd(mm, lo);
+          }
+        }
+        keyTab[l] = ok ? f64Key(mm) : 0ull;
+        hpTab[l] = hp;
+      }
+    }
+    ldsBarrier();
+    for (int base = 0; base < LN; base += W) {
+      const int l = base + tid;
+      if (l < nState) {
+        const unsigned long long key = keyTab[l];
+        const uint32_t hp = hpTab[l];
+        if (key != 0ull) {
+          int rank = 0;
+          for (int i = 0; i < nState; ++i) {
+            const unsigned long long k2 = keyTab[i];
+            const uint32_t h2 = hpTab[i];
+            rank += (k2 > key || (k2 == key && h2 < hp)) ? 1 : 0;
+          }
+          const size_t g = ((size_t)b * K + rank) * 3;
+          P.outScores[g + 0] = f64FromKey(key);
+          P.outScores[g + 1] = 0.0; /* emitting-model score: the back-trace kernel fills it in */
+          P.outScores[g + 2] = 0.0; /* ZeroLM */
+          P.histPT[hbase + (int64_t)ff * K + rank] = make_int2((int)hp, P.sil);
+          atomAdd32(&S.scal[ML_NOUT], 1u);
+        }
+      }
+    }
+    ldsBarrier();
+    if (tid == 0) {
+      const int n = (int)S.scal[ML_NOUT];
+      P.outN[b] = n;
+      P.uttNBeam[b] = n;
+      P.uttFrame[b] = ff;
+      P.uttTotal[b] = ff;
+      P.uttStatus[b] = ST_PACKED;
+    }
+  }
+  if (dead && tid == 0) {
+    P.outN[b] = 0;
+    P.uttNBeam[b] = 0;
+    P.uttFrame[b] = ff;
+    P.uttTotal[b] = ff;
+    P.uttStatus[b] = ST_SELECT_FALLBACK;
+  }
+}
