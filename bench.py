@@ -61,6 +61,9 @@ WORKLOADS = {
     "C3": dict(lex=True, batch=256, T=1000, K=50, Kt=10, lm=False),
     "C4": dict(lex=True, batch=256, T=1500, K=100, Kt=29, lm=True),
     "C5": dict(lex=True, batch=1024, T=1500, K=100, Kt=29, lm=True, total=8192),
+    # word-piece token sets (the reference is N-agnostic: LexiconFreeDecoder.cpp:42-51 short-lists beamSizeToken
+    # tokens per frame): lexicon-free + ZeroLM, beam 50, beamToken 50; N = 1024 by default, --tokens 8192 with --batch 64
+    "WP": dict(lex=False, batch=256, T=1000, K=50, Kt=50, lm=False, tokens=1024),
 }
 
 
@@ -72,7 +75,7 @@ def parse():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (0 = the workload's)")
     ap.add_argument("--frames", type=int, default=0)
-    ap.add_argument("--tokens", type=int, default=29)
+    ap.add_argument("--tokens", type=int, default=0, help="token-set size N (0 = the workload's: 29, WP: 1024)")
     ap.add_argument("--beam", type=int, default=0)
     ap.add_argument("--beam-token", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0, help="threads per utterance (0 = library default)")
@@ -83,6 +86,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip every CPU / host-side leg (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip all-cores / steady / end-to-end / streaming")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
+    ap.add_argument("--profile-out", default="", help="... and append it to this file (profiles/rNN/phase_split_*.txt)")
+    ap.add_argument("--mode", default="process", choices=["process", "group"],
+                    help="process: one rank per GPU (the driver's contract); group: ONE process, fltx_group_* over "
+                         "--gpus devices (one context, decoder and host thread per device)")
     ap.add_argument("--profile-waves", default="0", help="comma-separated wave indices to sample with --profile")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=-1, help="override the device (default: LOCAL_RANK)")
@@ -115,7 +122,8 @@ class Job:
         from text_amd import _capi, synth
         self.capi = _capi
         self.a, self.B = a, B
-        self.T, self.N, self.K, self.Kt = cfg["T"], a.tokens, cfg["K"], min(cfg["Kt"], a.tokens)
+        self.N = a.tokens or cfg.get("tokens", 29)
+        self.T, self.K, self.Kt = cfg["T"], cfg["K"], min(cfg["Kt"], self.N)
         self.lex, self.haslm = cfg["lex"], cfg["lm"]
         N = self.N
         self.lexicon = synth.lexicon() if self.lex else None
@@ -171,6 +179,8 @@ class Job:
 
 def main():
     a = parse()
+    if a.mode == "group":
+        return group_mode(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)
     import torch
@@ -283,7 +293,8 @@ def main():
                                 else "ZeroLM", B, T, N, K, Kt, job.dist),
                    "parallelism": "utterance-sharded x%d, no collective" % world,
                    "threads_per_utterance": st["threads_per_utt"], "lds_bytes_per_workgroup": st["lds_bytes"],
-                   "engine": engine, "redone": redone,
+                   "engine": engine, "redone": redone, "lane_groups": dec.get("lane_groups"),
+                   "why_not_lane": dec.get("why_not_lane"),
                    "pipeline": "%d decoder object(s), one HIP stream each, taking turns batch by batch%s" % (
                        len(decs), " (the back-trace of a batch runs under the decode kernel of the next)"
                        if len(decs) > 1 else "")},
@@ -297,6 +308,8 @@ def main():
           "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBS, "us_per_frame_step": k_ms * 1e3 / T,
           "ngram_query_bytes": by["lm"],
           "kernel_ms_in_timed_region": float(np.mean(over_k)),
+          "achieved_in_timed_region": by["decode"] / (float(np.mean(over_k)) * 1e-3) / 1e9,
+          "frac_in_timed_region": by["decode"] / (float(np.mean(over_k)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
           "timing": "HIP events on the launch stream; kernel_ms: %s" % (
               "3 launches on one stream right after the timed region (the timed region alternates two streams: "
               "kernel_ms_in_timed_region includes sharing the CUs with the other stream's back-trace)"
@@ -311,8 +324,12 @@ def main():
     # over this same command (tools/pmc_traffic.py); it is quoted only for the geometry and
     # engine it was measured on.
     tr = pmc_traffic(a.workload, st["threads_per_utt"], B, T, N, K, engine)
+    rl["frac_counter_bytes"] = None
     if tr is not None:
         rl["traffic"], rl["traffic_source"] = tr
+        # what the hardware saw: HBM bytes of the PMC passes over the kernel's own duration, against the peak
+        # (section 8(d)'s formula charges the lexicon decoder an edge gather the lane engines do not execute)
+        rl["frac_counter_bytes"] = tr[0] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out["roofline"] = rl
 
     # ---- configs[4]: the same 8192 utterances over however many GPUs run (strong scaling) ----
@@ -355,6 +372,82 @@ def main():
         raise SystemExit("bench.py: %d of %d utterances fell back to a general engine" % (redone, B))
 
 
+def group_mode(a):
+    """ONE process, the batch of --gpus x B utterances handed to fltx_group_decode_batch: the library cuts it into
+    contiguous shards, one context / decoder / host thread per device, tables replicated, no inter-device traffic
+    (SURVEY.md section 8e).  --device D puts every part on device D (plumbing check on a one-GPU box: not a scaling
+    number).  Inputs resident in each device's HBM before the timed region."""
+    import torch
+    from text_amd import _capi
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decoder has no CPU path")
+    cfg = dict(WORKLOADS[a.workload])
+    for key, val in (("T", a.frames), ("K", a.beam), ("Kt", a.beam_token)):
+        if val:
+            cfg[key] = val
+    B = a.batch or cfg["batch"]
+    n = a.gpus
+    devices = [a.device] * n if a.device >= 0 else list(range(n))
+    if max(devices) >= torch.cuda.device_count():
+        raise SystemExit("bench.py --mode group: device %d of %d" % (max(devices), torch.cuda.device_count()))
+    from text_amd import synth
+    j0 = Job(a, 0, devices[0], B, cfg)  # (host trie, LM, options; the group makes its own contexts and device tries)
+    T, N, K, Kt = j0.T, j0.N, j0.K, j0.Kt
+    e_hosts = [j0.e_host] + [synth.batch(j0.dist, B, T, N, lexicon=j0.lexicon, u0=i * B) for i in range(1, n)]
+    bufs = []
+    for i in range(n):
+        with torch.cuda.device(devices[i]):
+            bufs.append(torch.from_numpy(e_hosts[i]).cuda())
+    torch.cuda.synchronize()
+    grp = _capi.DecoderGroup(devices, _capi.LEXICON if j0.lex else _capi.LEXFREE, j0.opt, j0.lm, 0, N - 1,
+                             unk=j0.W if j0.lex else -1, host_trie=j0.host_trie)
+    Ts = np.full(n * B, T, dtype=np.int32)
+    offs = (np.arange(n * B, dtype=np.int64) % B) * T * N  # utterance b of part i sits at b - i * B in that device's buffer
+    ptrs = [t.data_ptr() for t in bufs]
+
+    def step():
+        grp.decode_batch(None, Ts, N, offsets=offs, device_ptrs=ptrs)
+
+    for _ in range(a.warmup):
+        step()
+    grp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    grp.synchronize()
+    dt = time.perf_counter() - t0
+    parts = grp.parts()
+    out = {"metric": "decoded frames/sec (whole node), T=%d N=%d beam=%d; hyp bit-exact vs CPU" % (T, N, K),
+           "value": n * B * T * a.steps / dt, "unit": "frames/s", "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%s, batch=%d utterances/GPU, T=%d, N=%d, beam=%d, beamToken=%d" % (a.workload, B, T, N, K, Kt),
+                      "mode": "group: one process, fltx_group_decode_batch over devices %s (one context, decoder and host "
+                              "thread per device, contiguous shards, no collective)" % devices,
+                      "shards": [[f, c] for _, f, c in parts],
+                      "same_device_plumbing_check": len(set(devices)) < n}}
+    # parity spot check: first and last utterance of every shard against the reference CPU
+    if not a.no_cpu:
+        cpu = CpuSide(j0)
+        mism = chk = 0
+        for i, (_, first, count) in enumerate(parts):
+            for b in (first, first + count - 1):
+                d, lm = cpu.new_decoder()
+                want = cpu.lib.decode(d, e_hosts[i][b - i * B], T, N)
+                cpu.free(d, lm)
+                got = grp.results(b)
+                same = len(got) == len(want) and all(
+                    g.score == h.score and g.am == h.am and np.array_equal(g.tokens, h.tokens) and
+                    np.array_equal(g.words, h.words) for g, h in zip(got, want))
+                mism += 0 if same else 1
+                chk += 1
+        out["cpu_baseline"] = {"kind": cpu.kind, "gpu_nbest_mismatches_on_sample": mism, "utterances_checked": chk}
+    print(json.dumps(out))
+    grp.close()
+    if out.get("cpu_baseline", {}).get("gpu_nbest_mismatches_on_sample", 0):
+        raise SystemExit("bench.py --mode group: n-best differs from the CPU reference")
+
+
 def phase_profile(a, dec, job, step, B, T):
     for pw in [int(x) for x in a.profile_waves.split(",")]:
         dec.set("profile", 1)
@@ -381,9 +474,13 @@ def phase_profile(a, dec, job, step, B, T):
         names = [names[i] for i in order]
         pr = pr[order]
         tot = pr[:8].sum()
-        sys.stderr.write("wave %d phase split (shader clocks, %% of %.3g): " % (pw, tot) + ", ".join(
-            ("%s %.3f" if n == "select paths" or n.startswith("(") else "%s %.0f") % (n, v / (B * T)) for n, v in zip(names, pr[:8])) +
-            " | clocks/frame/utt %.0f\n" % (tot / (B * T)))
+        line = "wave %d phase split (shader clocks, %% of %.3g): " % (pw, tot) + ", ".join(
+            ("%s %.3f" if n == "select paths" or n.startswith("(") else "%s %.0f") % (n, v / (B * T)) for n, v in zip(names, pr[:8])) + \
+            " | clocks/frame/utt %.0f\n" % (tot / (B * T))
+        sys.stderr.write(line)
+        if a.profile_out:
+            with open(a.profile_out, "a") as f:
+                f.write("%s engine %d threads %d beam %d: %s" % (a.workload, eng, dec.get("threads"), job.K, line))
         dec.set("profile", 0)
 
 

@@ -274,6 +274,25 @@ FLTX_API int fltx_group_result_fetch(fltx_group* group, int32_t b, int32_t max_h
                                      int32_t* tokens, int32_t* words, int32_t* n_copied);
 FLTX_API int fltx_group_synchronize(fltx_group* group);
 
+/* fltx_decoder_get(dec, "why_not_lane"): 0 when the last call started on a lane engine ("engine" 4 / 5 / 6), else the
+ * eligibility terms it failed (the lane engines run the reference's LexiconFreeDecoder.cpp:30-125 /
+ * LexiconDecoder.cpp:32-229 under these assumptions; everything else runs on the lean / generic engines) */
+enum {
+  FLTX_WHY_TOKENS = 1,        /* more than 64 tokens */
+  FLTX_WHY_BEAM = 2,          /* beam beyond the lane groups (lexicon-free: 512, lexicon: 128) */
+  FLTX_WHY_STREAM = 4,        /* a stream the lane engines do not serve (lexicon streams, logAdd streams) */
+  FLTX_WHY_LM = 8,            /* LM kind (token-level LM; n-gram LM on the lexicon-free decoder) */
+  FLTX_WHY_LOGADD = 16,       /* lexicon decoder with logAdd */
+  FLTX_WHY_ASG = 32,          /* lexicon decoder with the ASG criterion */
+  FLTX_WHY_UNK = 64,          /* lexicon decoder with <unk> enabled (unk_score > -inf) */
+  FLTX_WHY_TRIE_SHAPE = 128,  /* trie without a breadth-first layout (several labels per spelling, not a tree) */
+  FLTX_WHY_WORD_END = 256,    /* words do not all end in the separator (= sil), or sil == blank */
+  FLTX_WHY_OPTIONS = 512,     /* negative beam threshold, sil / blank outside the token set */
+  FLTX_WHY_LENGTH = 1024,     /* beam x frames beyond the state-id width of the history records */
+  FLTX_WHY_SWITCHED_OFF = 2048, /* a tunable switched the engine off / a fallback is in force */
+  FLTX_WHY_GEOMETRY = 4096    /* no compiled (threads, positions) geometry covers the token list */
+};
+
 /* ---- introspection for bench.py ------------------------------------------ */
 /* Frames decoded and kernel launches issued by the last decode call, plus the
  * algorithmic HBM bytes of SURVEY.md section 8(d) for it. */

@@ -485,3 +485,46 @@ def test_lexicon_free_beams_above_the_lane_engines(gpu_session, oracle_lib, K, T
         pytest.skip("equal scores in the n-best")
     ok, why = helpers.hyps_equal(want, got)
     assert ok, why
+
+
+def _tied_emissions(T, N, u):
+    """`ctc` rows with token 5's column copied from token 3's: hypotheses that differ only by 3 <-> 5 swaps tie to the
+    last bit, so the n-best is full of equal scores (the reference's own order is then undefined)."""
+    from text_amd import synth
+    e = synth.emissions("ctc", u, T, N).copy()
+    e[:, 5] = e[:, 3]
+    return e
+
+
+def _nbest_bits(d, b=0):
+    return [(float(h.score).hex(), float(h.am).hex(), h.tokens.tobytes()) for h in d.results(b)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,sets_a,sets_b", [
+    (20, {"slane_threads": 576}, {"slane_threads": 512}),   # fltx_slane.h: 4 and 5 list positions per wave
+    (20, {"slane_threads": 576}, {"slane_threads": 320}),   # ... and 10
+    (100, {"mlane_geo": 0}, {"mlane_geo": 0}),              # fltx_mlane.h: the same geometry twice
+    (100, {"lane_groups": -1}, {"lane_groups": -1}),        # lean step
+])
+def test_tied_input_is_decoded_deterministically(gpu_session, K, sets_a, sets_b):
+    """The device's tie policy (a tie goes to the earlier generated candidate -- list position,
+    then lane, then the lanes' own groups) is a function of the input: the same tied utterance decoded twice, and on
+    two geometries of the lane = LM state engine (whose generation order does not depend on how the list positions
+    are dealt to the waves), gives the same n-best bit for bit.  Nothing is claimed about the reference's order."""
+    T, N = 120, 29
+    e = _tied_emissions(T, N, 77)
+    c = cases.case("tied", T=T, N=N, K=K)
+    runs = []
+    for sets in (sets_a, sets_b, sets_a):
+        d = gpu_session.decoder(c, dict(tr=None))
+        for k, v in sets.items():
+            d.set(k, v)
+        d.decode_batch(e, [T], N)
+        nb = _nbest_bits(d)
+        scores = [x[0] for x in nb]
+        runs.append((nb, d.get("engine"), d.get("threads")))
+        d.close()
+    assert len(set(scores)) < len(scores), "the input was meant to produce equal scores"
+    assert runs[0][0] == runs[2][0], "two runs of one geometry differ"
+    assert runs[0][0] == runs[1][0], "geometries %r and %r differ" % (runs[0][1:], runs[1][1:])

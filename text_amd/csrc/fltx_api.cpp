@@ -405,6 +405,7 @@ struct fltx_decoder {
   /* ... with several lane groups (fltx_mlane.h, beams beyond 64): lane groups (0 / 1 = fltx_slane.h), groups per token
    * wave, groups per self wave; userLaneGroups: tuning / tests, 0 = as many as the beam needs, -1 = never */
   int mlaneNG = 0, mlaneGPW = 0, mlaneSPW = 0, userLaneGroups = 0, userMlaneGeo = -1;
+  int64_t whyNotLane = 0; /* FLTX_WHY_* bits: the eligibility terms that kept the last call off the lane engines (0 = it ran there) */
   bool preferYlane = false;
   bool genericAsked = false;  /* fltx_decoder_set touched a tunable of the generic engine */
   int engineFirst = 0;
@@ -1240,6 +1241,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->streamRedone;
   } else if (!strcmp(key, "slane")) {
     *value = d->slane;
+  } else if (!strcmp(key, "why_not_lane")) { /* FLTX_WHY_* (include/fltx.h): why the last call did not start on a lane engine */
+    *value = d->whyNotLane;
   } else if (!strcmp(key, "lane_groups")) { /* lane groups of the lane = LM state engine: 1 = fltx_slane.h, 2 / 4 / 8 = fltx_mlane.h */
     *value = d->slane ? std::max(1, d->mlaneNG) : 0;
   } else if (!strcmp(key, "lane")) {
@@ -1401,7 +1404,7 @@ namespace {
 
 /* geometry + buffers for B streams of up to maxFrames frames (plus seed and
  * decodeEnd slots) */
-/* fltx_mlane.h geometries that are compiled (fltx_instances.h, FLTX_MLANE_SET), fastest first per group count */
+/* fltx_mlane.h geometries that are compiled (fltx_instances.h, FLTX_MLANE_SET); "mlane_geo" = row */
 struct MlaneGeo {
   int threads, gt, ng, gpw, spw;
 };
@@ -1529,7 +1532,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       (int64_t)K * (maxT + 2) < (1ll << 31) - 1) {
     const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
     const int needNG = std::max((K + 63) / 64, d->userLaneGroups);
-    for (int gi = 0; gi < kMlaneGeoCount; ++gi) {
+    /* fastest first per group count (C2 shape, profiles/r04: beam 100 3.17 ms on row 1 against 3.23 on row 0, beam 200
+     * 5.79 on row 4 against 6.21 on row 3; the wide rows 2 / 5 spill registers and are for token lists beyond 30) */
+    static const int order[kMlaneGeoCount] = {1, 0, 2, 4, 3, 5, 6};
+    for (int oi = 0; oi < kMlaneGeoCount; ++oi) {
+      const int gi = order[oi];
       const MlaneGeo& g = kMlaneGeo[gi];
       if (d->userMlaneGeo >= 0 ? gi != d->userMlaneGeo : (d->userThreads && d->threads != g.threads)) {
         continue;
@@ -1628,6 +1635,33 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         d->xlmwordLm = d->lm;
       }
     }
+  }
+  { /* which eligibility terms kept this call off the lane engines (fltx_decoder_get "why_not_lane") */
+    int64_t why = 0;
+    if (!(d->slane || d->xlane || d->ylane || d->sstream)) {
+      const bool lexi = d->kind == FLTX_DECODER_LEXICON;
+      const bool unkOn = d->opt.unk_score > -std::numeric_limits<double>::infinity();
+      const int nListAll = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
+      why |= N > 64 ? FLTX_WHY_TOKENS : 0;
+      why |= (lexi ? K > 128 : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
+      why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
+      why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
+      why |= (lexi && d->opt.log_add) ? FLTX_WHY_LOGADD : 0;
+      why |= (lexi && d->opt.criterion != FLTX_CRITERION_CTC) ? FLTX_WHY_ASG : 0;
+      why |= (lexi && unkOn) ? FLTX_WHY_UNK : 0;
+      why |= (lexi && d->trie && !d->trie->xOk) ? FLTX_WHY_TRIE_SHAPE : 0;
+      why |= (lexi && d->trie && d->trie->xOk && (d->trie->xEndTok != d->sil || d->sil == d->blank)) ? FLTX_WHY_WORD_END : 0;
+      why |= (!(d->opt.beam_threshold >= 0.0) || d->sil < 0 || d->sil >= N ||
+              (d->opt.criterion == FLTX_CRITERION_CTC && (d->blank < 0 || d->blank >= N))) ? FLTX_WHY_OPTIONS : 0;
+      why |= ((int64_t)K * (maxT + 2) >= (lexi || K <= 64 ? (1ll << 23) - 1 : (1ll << 31) - 1)) ? FLTX_WHY_LENGTH : 0;
+      why |= (d->noSlane || d->noXlane || d->noYlane || d->genericAsked || d->forceGlobalWs || d->noLean || d->noDense ||
+              d->userLaneGroups < 0 || forceWorstCaseCap) ? FLTX_WHY_SWITCHED_OFF : 0;
+      why |= (!lexi && nListAll > 70) ? FLTX_WHY_GEOMETRY : 0;
+      if (!why) {
+        why = FLTX_WHY_GEOMETRY; /* (no compiled geometry covers this token list / thread count) */
+      }
+    }
+    d->whyNotLane = why;
   }
   if (d->lean && !d->lane && !d->slane) { /* the lean steps keep their (record-free) workspace in LDS or are not used */
     Ws t2;

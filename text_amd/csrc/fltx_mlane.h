@@ -271,10 +271,10 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       ev[j] = 0.0;
       tb[j] = 0ull;
     }
-    if (isSelf) {
+    if constexpr (isSelf) {
       eBlank = S.eAll[p][ctc ? blank : 0];
       allow = S.row[p].allow;
-    } else if (isTok) {
+    } else if constexpr (isTok) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         ev[j] = S.eTok[p][pos0 + j];
@@ -326,12 +326,17 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         eLast[i] = S.eAll[p][last[i]];
       }
     }
-    double cs[NC];
+    /* candidate scores: token waves without logAdd recompute m + e where they need it (one addition, the same
+     * double) instead of keeping GT * GPW of them in registers through the selection */
+    constexpr bool kKeep = !(isTok && !LA);
+    double cs[kKeep ? NC : 1];
     int cbin[NC];
     uint32_t parR[NU];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      cs[c] = NEG;
+      if (kKeep) {
+        cs[c] = NEG;
+      }
       cbin[c] = kSlInvalid;
     }
 #pragma unroll
@@ -339,7 +344,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       parR[i] = kMlNoHyp;
     }
     SlRowRegs nextRow = {};
-    if (isSvc) {
+    if constexpr (isSvc) {
       if (t + 1 < T) {
         ldsRowWait();
         const float rv = lane < N ? S.raw[(t + 1) % 3][lane] : 0.0f;
@@ -350,7 +355,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       if (LA && lane == 0) {
         S.mmaxKey[q] = 0ull;
       }
-    } else if (isTok) {
+    } else if constexpr (isTok) {
       const int silJ = silPos - pos0;
 #pragma unroll
       for (int i = 0; i < U; ++i) {
@@ -376,7 +381,9 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
               c = slLogAdd(c, c2);
             }
           }
-          cs[i * GT + j] = c;
+          if (kKeep) {
+            cs[i * GT + j] = c;
+          }
           cbin[i * GT + j] = ok ? slBin<LA>(best, c, winShift, winBase) : kSlInvalid;
         }
       }
@@ -456,6 +463,18 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         cbin[3 * i + 2] = okL ? slBin<LA>(best, cL, winShift, winBase) : kSlInvalid;
       }
     }
+    const int silJ0 = silPos - pos0;
+    auto csAt = [&](int c) -> double {
+      if constexpr (kKeep) {
+        return cs[c];
+      } else {
+        double v = m[c / GT] + ev[c % GT];
+        if (c % GT == silJ0) {
+          v = v + silScore;
+        }
+        return v;
+      }
+    };
     /* housekeeping: what this frame's build adds to (the first block's waves wipe their groups' masks) */
     if (isTok && blk == 0) {
 #pragma unroll
@@ -522,7 +541,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         for (int c = 0; c < NC; ++c) {
           if (cbin[c] == sc.bstar) {
             const uint32_t i = atomAdd32(&S.scal[ML_BCNT], 1u);
-            S.bKey[i] = f64Key(cs[c]);
+            S.bKey[i] = f64Key(csAt(c));
             S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
           }
         }
@@ -530,7 +549,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           if (cbin[c] == sc.bstar) {
-            const unsigned long long k = f64Key(cs[c]);
+            const unsigned long long k = f64Key(csAt(c));
             const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
             int rank = 0;
             for (int i = 0; i < sc.cnt; ++i) {
@@ -576,7 +595,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         if (cbin[c] != kSlInvalid) {
-          cbin[c] = slBin<LA>(best, cs[c], shift, base);
+          cbin[c] = slBin<LA>(best, csAt(c), shift, base);
           atomAdd32(&S.hist[p][cbin[c]], 1u);
         }
       }
@@ -593,28 +612,20 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
     }
     /* new lanes: survivors first (group by group), then the new states wave by wave */
     int nNewWave = 0;
-    int myNew[NC];
     int surv[NU];
     uint32_t hNB[NU], hB[NU];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      myNew[c] = 0;
-    }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       surv[i] = -1;
       hNB[i] = 0u;
       hB[i] = 0u;
     }
-    if (isTok) {
+    if constexpr (isTok) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        if (selMask[c] != 0ull) {
-          myNew[c] = nNewWave + wavePrefixCount(selMask[c]);
-          nNewWave += popc64(selMask[c]);
-        }
+        nNewWave += popc64(selMask[c]);
       }
-    } else if (isSelf) {
+    } else if constexpr (isSelf) {
 #pragma unroll
       for (int i = 0; i < U; ++i) {
         const unsigned long long balB = selMask[3 * i], balR = selMask[3 * i + 1], balL = selMask[3 * i + 2];
@@ -623,7 +634,6 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         surv[i] = ((balS >> lane) & 1ull) ? wavePrefixCount(balS) : -1;
         hNB[i] = (uint32_t)(wavePrefixCount(balR) + wavePrefixCount(balB));
         hB[i] = hNB[i] + (sR ? 1u : 0u);
-        myNew[3 * i + 2] = nNewWave + wavePrefixCount(balL);
         nNewWave += popc64(balL);
         S.newLane[(g0 + i) * 64 + lane] = surv[i];
         if (lane == 0) {
@@ -638,7 +648,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       unsigned long long k = 0ull;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const unsigned long long kj = ((selMask[c] >> lane) & 1ull) ? f64Key(cs[c]) : 0ull;
+        const unsigned long long kj = ((selMask[c] >> lane) & 1ull) ? f64Key(csAt(c)) : 0ull;
         k = kj > k ? kj : k;
       }
       if (waveBallot(k != 0ull) != 0ull) {
@@ -716,23 +726,25 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         S.evTok[e] = (uint32_t)n;
       }
     };
-    if (isSvc) {
+    if constexpr (isSvc) {
       if (t + 1 < T) {
         slRowStore(P, S, q, nextRow, P.Kt < N ? 1 : 0);
       }
       ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
-    } else if (isTok) {
+    } else if constexpr (isTok) {
+      int before = offW; /* new states of the waves before this one and of this wave's earlier slots */
 #pragma unroll
       for (int i = 0; i < U; ++i) {
         const int srcNew = mySlot[i] >= 0 ? baseS[i] + mySlot[i] : -1;
 #pragma unroll
         for (int j = 0; j < GT; ++j) {
           const int c = i * GT + j;
-          if (selMask[c] != 0ull) {
+          if (selMask[c] != 0ull) { /* (most positions of most frames have no survivor at all) */
             if ((selMask[c] >> lane) & 1ull) {
               const int nTok = (int)S.tokId[p][pos0 + j];
-              newState(offW + myNew[c], cs[c], nTok, hypM[i], me[i], mk[i], srcNew);
+              newState(before + wavePrefixCount(selMask[c]), csAt(c), nTok, hypM[i], me[i], mk[i], srcNew);
             }
+            before += popc64(selMask[c]);
           }
         }
       }
@@ -742,6 +754,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           histPT[hrow + i] = make_int2((int)kMlNoHyp, -1);
         }
       }
+      int before = offW;
 #pragma unroll
       for (int i = 0; i < U; ++i) {
         const int srcNew = mySlot[i] >= 0 ? baseS[i] + mySlot[i] : -1;
@@ -771,8 +784,9 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           }
         }
         if ((selMask[3 * i + 2] >> lane) & 1ull) {
-          newState(offW + myNew[3 * i + 2], cs[3 * i + 2], last[i], hypB[i], me[i], mk[i], srcNew);
+          newState(before + wavePrefixCount(selMask[3 * i + 2]), cs[3 * i + 2], last[i], hypB[i], me[i], mk[i], srcNew);
         }
+        before += popc64(selMask[3 * i + 2]);
       }
     }
     nState = nSurv + nNew;
