@@ -213,6 +213,7 @@ def main():
     job = Job(a, rank, local, B, cfg)
     T, N, K, Kt = job.T, job.N, job.K, job.Kt
     e_dev = torch.from_numpy(job.e_host).cuda()  # resident in HBM before timing
+    job.e_dev_ptr = e_dev.data_ptr()
     torch.cuda.synchronize()
     dec = job.decoder()
     decs = [dec] + [job.decoder(second_stream=True) for _ in range(a.pipeline - 1)]
@@ -452,7 +453,7 @@ def phase_profile(a, dec, job, step, B, T):
     for pw in [int(x) for x in a.profile_waves.split(",")]:
         dec.set("profile", 1)
         dec.set("profile_wave", pw)
-        step()
+        dec.decode_batch(None, job.Ts, job.N, device_ptr=job.e_dev_ptr)  # (this decoder object: `step` takes turns)
         job.ctx.synchronize()
         pr = dec.profile().astype(np.float64)
         names = ["A2(combine)", "B(eval+bin)", "C(prefix)", "D(shortlist)", "E(build)", "row", "A1(relations)", "E-rank"]

@@ -187,7 +187,12 @@ FLTX_API int fltx_decode_batch(fltx_decoder* dec, const float* emissions,
 
 /* Streaming interface for B parallel streams (Decoder::decodeBegin /
  * decodeStep / decodeEnd / prune, decoder/Decoder.h:42-61).  max_frames bounds
- * the total frames buffered per stream between prunes. */
+ * the total frames buffered per stream between prunes.
+ * Lifetime of a device buffer (emissions_on_device != 0; the same holds for fltx_decode_batch): every read of it
+ * is queued on the context's stream before the call returns -- also the second pass of a lexicon stream's chunk
+ * whose candidate list overflowed, which is therefore not deferred to a later call for such a chunk.  The caller
+ * may overwrite the buffer in stream order on that stream, or from anywhere after fltx_ctx_synchronize / after
+ * any call that returns results of this chunk.  A host buffer is only borrowed for the duration of the call. */
 FLTX_API int fltx_stream_begin(fltx_decoder* dec, int32_t B, int32_t N,
                                int32_t max_frames);
 FLTX_API int fltx_stream_step(fltx_decoder* dec, const float* emissions,

@@ -488,11 +488,15 @@ def test_lexicon_free_beams_above_the_lane_engines(gpu_session, oracle_lib, K, T
 
 
 def _tied_emissions(T, N, u):
-    """`ctc` rows with token 5's column copied from token 3's: hypotheses that differ only by 3 <-> 5 swaps tie to the
-    last bit, so the n-best is full of equal scores (the reference's own order is then undefined)."""
+    """`ctc` rows in which the most used token has a twin column: hypotheses that differ only by swapping the two tie
+    to the last bit, so the n-best is full of equal scores (the reference's own order is then undefined, SURVEY.md
+    section 0)."""
     from text_amd import synth
+    import numpy as np
     e = synth.emissions("ctc", u, T, N).copy()
-    e[:, 5] = e[:, 3]
+    top = np.bincount(np.argmax(e[:, :N - 1], axis=1), minlength=N - 1)  # the non-blank token the best path uses most
+    a = int(np.argmax(top))
+    e[:, (a + 1) % (N - 1)] = e[:, a]  # ... gets a twin: every occurrence can be swapped at no cost
     return e
 
 

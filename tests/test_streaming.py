@@ -258,6 +258,9 @@ def test_device_chunk_buffer_reused_between_steps(gpu_session, stream_golden, na
             chunk = np.ascontiguousarray(inp["e"][t:t + 10], dtype=np.float32).reshape(-1)
             assert hip.hipMemcpy(buf, chunk.ctypes.data, 4 * chunk.size, 1) == 0  # (synchronous H2D)
             d.stream_step(None, [chunk.size // N], device_ptr=buf.value)
+            # the chunk is read in stream order on the context's stream (include/fltx.h): a caller writing from
+            # elsewhere waits for that stream first -- and after that, nothing may read the buffer any more
+            gpu_session.ctx.synchronize()
             assert hip.hipMemcpy(buf, junk.ctypes.data, 4 * junk.size, 1) == 0  # the caller's buffer again
         d.stream_end()
         got = helpers.encode_hyps(d.results(0), True)
