@@ -284,7 +284,7 @@ FLTX_API int fltx_group_synchronize(fltx_group* group);
  * LexiconDecoder.cpp:32-229 under these assumptions; everything else runs on the lean / generic engines) */
 enum {
   FLTX_WHY_TOKENS = 1,        /* more than 64 tokens */
-  FLTX_WHY_BEAM = 2,          /* beam beyond the lane groups (lexicon-free: 512, lexicon: 128) */
+  FLTX_WHY_BEAM = 2,          /* beam beyond the lane groups (lexicon-free: 512, lexicon: 256) */
   FLTX_WHY_STREAM = 4,        /* a stream the lane engines do not serve (lexicon streams, logAdd streams) */
   FLTX_WHY_LM = 8,            /* LM kind (token-level LM; n-gram LM on the lexicon-free decoder) */
   FLTX_WHY_LOGADD = 16,       /* lexicon decoder with logAdd */

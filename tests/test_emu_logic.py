@@ -271,3 +271,10 @@ def test_emulated_lane_state_engine_with_lane_groups(emu_session, oracle_lib):
     import test_gpu_batches
     ran, served, bad = test_gpu_batches._lane_group_grid(emu_session, oracle_lib, 61, lambda i: [2, 17, 9][i % 3], emu=True)
     assert ran >= 12 and served == ran and not bad, (ran, served, bad[:3])
+
+
+def test_emulated_four_lane_groups(emu_session, oracle_lib):
+    """fltx_ylane.h with four lane groups on the emulator: a thin slice of the GPU suite's grid."""
+    import test_gpu_batches
+    ran, served, bad = test_gpu_batches._four_lane_group_grid(emu_session, oracle_lib, 173, lambda i: [2, 17, 9][i % 3])
+    assert ran >= 10 and served == ran and not bad, (ran, served, bad[:3])

@@ -310,3 +310,60 @@ def _lane_group_grid(session, oracle_lib, every, T_of, emu=False):
 def test_edge_configurations_of_the_lane_state_engine_with_lane_groups(gpu_session, oracle_lib):
     ran, served, bad = _lane_group_grid(gpu_session, oracle_lib, 3, lambda i: [1, 2, 23, 90][i % 4])
     assert ran > 400 and served == ran and not bad, (ran, served, bad[:3])
+
+
+def _four_lane_group_grid(session, oracle_lib, every, T_of):
+    """fltx_ylane.h with four groups of 64 lanes (beams 129 .. 256; smaller beams forced onto four groups): n-gram
+    word LMs of order 2 .. 4 and label scores without an LM, thresholds 0 .. inf, token beams, lmWeight / wordScore /
+    silScore of both signs, `lexspell` and `uniform` rows, against the oracle."""
+    import itertools
+    bad, ran, served = [], 0, 0
+    grid = itertools.product([5, 100, 129, 160, 200, 256], [0.0, 2.0, 25.0, float("inf")], [None, 3, 10],
+                             [("ngram", 2, 71), ("ngram", 4, 72), "scores", "zero"], [0.7, 2.0, -0.5], [0.0, 1.5, -2.0],
+                             [0.0, -0.7], ["lexspell", "uniform"])
+    for i, (K, thr, Kt, lm, lw, ws, sil, dist) in enumerate(grid):
+        if i % every:
+            continue
+        T = T_of(i)
+        plain = lm in ("scores", "zero")
+        c = cases.case("y4_%d" % i, kind="lexicon", dist=dist, u=1900 + i, T=T, K=K, Kt=Kt, thr=thr, sil_score=sil,
+                       word_score=ws, lm_weight=0.0 if lm == "zero" else lw, lexicon=cases.SMALL_LEX,
+                       lm="zero" if plain else lm, label_scores=(50 + i % 7) if lm == "scores" else None)
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue
+        d = session.decoder(c, inp)
+        d.set("ylane", 2)
+        d.set("ylane_groups", 4)
+        d.decode_batch(inp["e"], [T], c["N"])
+        got = d.results(0)
+        served += 1 if (d.get("engine") == 6 and d.get("lane_groups") == 4 and d.get("redone") == 0) else 0
+        d.close()
+        ok, why = helpers.hyps_equal(want, got)
+        ran += 1
+        if not ok:
+            bad.append(({k: c[k] for k in ("K", "Kt", "thr", "lm", "lm_weight", "sil_score", "word_score", "T", "dist",
+                                           "label_scores")}, why))
+    return ran, served, bad
+
+
+def test_edge_configurations_of_the_lexicon_lane_engine_with_four_lane_groups(gpu_session, oracle_lib):
+    ran, served, bad = _four_lane_group_grid(gpu_session, oracle_lib, 11, lambda i: [1, 17, 90, 40][i % 4])
+    assert ran > 150 and served == ran and not bad, (ran, served, bad[:3])
+
+
+def test_long_utterance_stays_on_the_lexicon_lane_engine(gpu_session, oracle_lib):
+    """A C4-shaped utterance of 4 000 frames creates more LM states than the memo in LDS numbers (6 144): it takes the
+    memo in HBM, sized for its frames, and stays on engine 6 (round 3 handed it to the generic engine half way)."""
+    c = dict(cases.BY_NAME["C4_spell_u0"], T=4000, u=17)
+    inp = helpers.case_inputs(c)
+    d = gpu_session.decoder(c, inp)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    got = d.results(0)
+    info = (d.get("engine"), d.get("redone"), d.get("yshare"), d.get("ymemo_slots"))
+    d.close()
+    assert info[0] == 6 and info[1] == 0 and info[2] == 1 and info[3] > 8192, info
+    want = helpers.run_checker(oracle_lib, c, inp)
+    ok, why = helpers.hyps_equal(want, got)
+    assert ok, why

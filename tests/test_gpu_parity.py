@@ -253,7 +253,10 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     ("lx_scores_t50", 6, {}), ("ng_word_t40_k10", 6, {}), ("ng_word_t60_k16_4g", 6, {}), ("C4_spell_u0", 6, {}),
     ("C4_spell_u255", 6, {}), ("C4z_spell_u0", 6, {}), ("lx_spell_t40_k8", 6, {"ylane": 2}),
     ("lx_uni_t40_k10", 6, {"ylane": 2}), ("C3_spell_u0", 6, {"ylane": 2}), ("C3_uniform_u0", 6, {"ylane": 2}),
-    ("ng_word_t40_k10", 0, {"ylane": 0}), ("C4_spell_u0", 0, {"ylane": 0}), ("lx_scores_t50", 0, {"slim": 1})])
+    ("ng_word_t40_k10", 0, {"ylane": 0}), ("C4_spell_u0", 0, {"ylane": 0}), ("lx_scores_t50", 0, {"slim": 1}),
+    # four lane groups of fltx_ylane.h (beams 129 .. 256): forced here on goldens of smaller beams
+    ("C4_spell_u0", 6, {"ylane_groups": 4}), ("C4z_spell_u0", 6, {"ylane_groups": 4}),
+    ("ng_word_t60_k16_4g", 6, {"ylane_groups": 4}), ("C3_spell_u0", 6, {"ylane": 2, "ylane_groups": 4})])
 def test_engine_selection(gpu_session, golden, name, engine, sets):
     """Which engine serves which configuration: the lane = LM state decode (4,
     fltx_slane.h) for offline lexicon-free + ZeroLM max-merge with beam <= 64 and

@@ -405,6 +405,8 @@ struct fltx_decoder {
   /* ... with several lane groups (fltx_mlane.h, beams beyond 64): lane groups (0 / 1 = fltx_slane.h), groups per token
    * wave, groups per self wave; userLaneGroups: tuning / tests, 0 = as many as the beam needs, -1 = never */
   int mlaneNG = 0, mlaneGPW = 0, mlaneSPW = 0, userLaneGroups = 0, userMlaneGeo = -1;
+  int userYlaneGroups = 0;   /* tests: at least this many lane groups on fltx_ylane.h (0 = what the beam needs) */
+  uint32_t ymemoSlots = 8192; /* slots per utterance of the LM-state memo in HBM (fltx_ylane.h: follows the frames) */
   int64_t whyNotLane = 0; /* FLTX_WHY_* bits: the eligibility terms that kept the last call off the lane engines (0 = it ran there) */
   bool preferYlane = false;
   bool genericAsked = false;  /* fltx_decoder_set touched a tunable of the generic engine */
@@ -1243,8 +1245,11 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->slane;
   } else if (!strcmp(key, "why_not_lane")) { /* FLTX_WHY_* (include/fltx.h): why the last call did not start on a lane engine */
     *value = d->whyNotLane;
-  } else if (!strcmp(key, "lane_groups")) { /* lane groups of the lane = LM state engine: 1 = fltx_slane.h, 2 / 4 / 8 = fltx_mlane.h */
-    *value = d->slane ? std::max(1, d->mlaneNG) : 0;
+  } else if (!strcmp(key, "lane_groups")) { /* lane groups of the lane = LM state engine: 1 = fltx_slane.h, 2 / 4 / 8 = fltx_mlane.h;
+                                                fltx_ylane.h: 1 / 2 / 4 */
+    *value = d->slane ? std::max(1, d->mlaneNG) : d->ylane;
+  } else if (!strcmp(key, "ymemo_slots")) {
+    *value = (d->ylane || d->xlane) && d->yshare ? (int64_t)d->ymemoSlots : 0;
   } else if (!strcmp(key, "lane")) {
     *value = d->lane;
   } else if (!strcmp(key, "lean")) {
@@ -1372,6 +1377,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "slane")) { /* 0: do not use the lane = LM state kernel (fltx_slane.h) */
     d->noSlane = value ? 0 : 1;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "ylane_groups")) { /* fltx_ylane.h: at least this many lane groups (tests) */
+    d->userYlaneGroups = (int)value;
     return FLTX_OK;
   }
   if (!strcmp(key, "lane_groups")) { /* fltx_mlane.h: 0 = as many lane groups as the beam needs, 2 / 4 / 8 = at least that many, -1 = never */
@@ -1589,6 +1598,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         /* more utterances than CUs: the LM-state memo moves to HBM, 28 KB of LDS and 81 VGPRs let several
          * workgroups share a CU (see the lane engine with LM terms below) */
         d->yshare = (d->userYshare >= 0 ? d->userYshare != 0 : B > d->ctx->numCUs) ? 1 : 0;
+        d->ymemoSlots = kXlMemoH;
         break;
       }
     }
@@ -1600,19 +1610,32 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       d->offlineCall && !d->keepScores && !d->opt.log_add && !forceWorstCaseCap && !d->forceGlobalWs &&
       (d->lm->kind == 0 || d->lm->kind == 1) && !d->isLmToken && d->trie && d->trie->xOk &&
       d->trie->xEndTok == d->sil && d->sil != d->blank && d->opt.criterion == FLTX_CRITERION_CTC &&
-      !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) && K <= 128 && N <= 64 &&
+      !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) && K <= 256 && N <= 64 &&
       d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N && d->blank >= 0 && d->blank < N) {
-    const int ng = K <= 64 ? 1 : 2;
+    const int ng = std::max(K <= 64 ? 1 : (K <= 128 ? 2 : 4), d->userYlaneGroups);
     /* More utterances than CUs: the geometry of which two workgroups fit a CU (512 threads, <= 128
      * VGPRs, 77 KB of LDS: the LM-state memo moves to HBM) -- one utterance's waits are the other's
      * time to run (C5's 1 024 utterances per GPU: 1.6x).  With no more utterances than CUs the second
      * workgroup would not exist and the memo in LDS is the faster one. */
-    const bool share = d->userYshare >= 0 ? d->userYshare != 0 : B > d->ctx->numCUs;
-    const int threads = ng == 1 ? 512 : (share ? 512 : 768);
+    /* Four lane groups (beams 129 .. 256): sixteen waves, the memo in HBM whatever the batch (the lanes, the merge
+     * and orphan tables and ten token waves' pair lists fill the LDS); a long utterance creates more LM states than
+     * the memo in LDS numbers (about 2.2 per frame on the C4 shape, 6 144 at most): it takes the HBM memo as well,
+     * sized for its frames, instead of leaving the engine half way */
+    const bool longUtt = (int64_t)maxT * 5 / 2 + 64 > kYlMemo * 3 / 4;
+    const bool share = ng == 4 ? true : (d->userYshare >= 0 ? d->userYshare != 0 : (B > d->ctx->numCUs || longUtt));
+    const int threads = ng == 4 ? 1024 : (ng == 1 ? 512 : (share ? 512 : 768));
     const int nTokWaves = threads / 64 - ng - 2;
     const int tpw = (nTok + nTokWaves - 1) / nTokWaves;
-    const int pairCap = (ng == 2 && share) ? 1024 : 512;
-    if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96 && tpw * 64 * ng <= pairCap && nTokWaves <= 8) {
+    const int pairCap = ng == 4 ? kYlPairs4 : ((ng == 2 && share) ? 1024 : 512);
+    const int maxTokWaves = ng == 4 ? 10 : 8;
+    if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96 && tpw * 64 * ng <= pairCap &&
+        nTokWaves <= maxTokWaves) {
+      /* slots of the memo in HBM: four per LM state the utterance can create, a power of two, 16-bit state numbers */
+      uint32_t ms = kYlMemo;
+      while (ms < 65536u && (int64_t)ms * 3 / 4 < (int64_t)maxT * (ng == 4 ? 8 : 4) + 256) {
+        ms *= 2;
+      }
+      d->ymemoSlots = share ? ms : kYlMemo;
       d->yshare = share ? 1 : 0;
       d->ylane = ng;
       d->ylaneRounds = ng == 1 ? 2 : 4;
@@ -1643,7 +1666,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       const bool unkOn = d->opt.unk_score > -std::numeric_limits<double>::infinity();
       const int nListAll = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
       why |= N > 64 ? FLTX_WHY_TOKENS : 0;
-      why |= (lexi ? K > 128 : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
+      why |= (lexi ? K > 256 : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
       why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
       why |= (lexi && d->opt.log_add) ? FLTX_WHY_LOGADD : 0;
@@ -1845,7 +1868,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     lds = true;
   }
   if (d->ylane) {
-    d->wsBytes = d->yshare ? offsetof(YlaneLds, memo) : sizeof(YlaneLds);
+    d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsT<4>, memo) : (d->yshare ? offsetof(YlaneLds, memo) : sizeof(YlaneLds));
     d->wsInLds = true;
     lds = true;
     d->itemCap = 0;
@@ -1912,7 +1935,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     rc |= d->gMask.ensure(8 * bk, st, false);
   }
   if ((d->ylane || d->xlane) && d->yshare) {
-    rc |= d->ymemo.ensure(sizeof(unsigned long long) * (size_t)kYlMemo * (size_t)B, st, false); /* (wiped by the kernel) */
+    rc |= d->ymemo.ensure(sizeof(unsigned long long) * (size_t)d->ymemoSlots * (size_t)B, st, false); /* (wiped by the kernel) */
   }
   d->useLmCache = d->lm->kind == 1 && !d->ylane && !d->xlane && !d->noLmCache;
   if (d->useLmCache) {
@@ -2020,6 +2043,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.yTpw = d->ylaneTpw;
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
   P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
+  P.ymemoSlots = d->ymemoSlots;
   P.statusHost = (!d->offlineCall && d->streamOpt) ? (int32_t*)d->hStat.p : nullptr;
   /* (the lean step on an HBM workspace reads its atomically ORed addMask words at L2 as well: wsLoadAtomic64) */
   P.wsNoInv = (!d->wsInLds && d->hotLevel >= 1) ? 1 : 0;
@@ -2148,6 +2172,13 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
                          d->wsBytes, d->ctx->stream, P);                                                \
     }                                                                                                   \
   } while (0)
+#define FLTX_LAUNCH_YLANE4(LMK)                                                                        \
+  do {                                                                                                  \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<1024, 4, 4, LMK, 1, false>,        \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));           \
+    hipLaunchKernelGGL((fltx_decode_kernel_ylane<1024, 4, 4, LMK, 1, false>), dim3(nGrid), dim3(1024),  \
+                       d->wsBytes, d->ctx->stream, P);                                                  \
+  } while (0)
     switch (d->ylane * 10 + d->ylaneLm + (d->yshare ? 100 : 0)) {
       case 10: FLTX_LAUNCH_YLANE(512, 1, 2, 0, 0); break;
       case 11: FLTX_LAUNCH_YLANE(512, 1, 2, 1, 0); break;
@@ -2157,9 +2188,12 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       case 111: FLTX_LAUNCH_YLANE(512, 1, 2, 1, 1); break;
       case 120: FLTX_LAUNCH_YLANE(512, 2, 4, 0, 1); break;
       case 121: FLTX_LAUNCH_YLANE(512, 2, 4, 1, 1); break;
+      case 140: FLTX_LAUNCH_YLANE4(0); break;
+      case 141: FLTX_LAUNCH_YLANE4(1); break;
       default: return fail(FLTX_ERR_INVALID, "no fltx_ylane.h kernel for %d lane groups", d->ylane);
     }
 #undef FLTX_LAUNCH_YLANE
+#undef FLTX_LAUNCH_YLANE4
   } else if (d->xlane) {
 #define FLTX_LAUNCH_XLANE(WW, GG)                                                                \
   do {                                                                                           \
@@ -2700,7 +2734,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     }
     d->batchPacked = d->batchPacked || d->slane || d->xlane || d->ylane;
     if (d->slane || d->xlane || d->ylane) {
-      d->packedBits = (d->slane && d->mlaneNG > 1) ? 10 : 8; /* (a re-run on a general engine leaves plain records) */
+      d->packedBits = (d->slane && d->mlaneNG > 1) ? 10 : (d->ylane == 4 ? 13 : 8); /* (a re-run on a general engine leaves plain records) */
     }
     if (attempt == 0) {
       d->engineFirst = engineOf(d);

@@ -77,6 +77,11 @@
   FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 0, 1, PROF>)  \
   FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 1, 1, PROF>)
 #define FLTX_G13(W) FLTX_YLANE_SET(false)
+/* four lane groups (beams 129 .. 256): 1024 threads = ten token waves, four waves for the lanes' own groups, the
+ * word wave and the staging wave; LM-state memo in HBM */
+#define FLTX_G20(W)                                           \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 0, 1, false>) \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 1, 1, false>)
 #define FLTX_G14(W) FLTX_YLANE_SET(true)
 
 #ifdef FLTX_INST_W
@@ -102,6 +107,7 @@ FLTX_G16(0)
 FLTX_G17(0)
 FLTX_G18(0)
 FLTX_G19(0)
+FLTX_G20(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -123,6 +129,7 @@ FLTX_G19(0)
 #undef FLTX_G17
 #undef FLTX_G18
 #undef FLTX_G19
+#undef FLTX_G20
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET

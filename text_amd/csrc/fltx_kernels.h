@@ -186,7 +186,8 @@ struct DecodeParams {
   int32_t xEndTok;              /* the token every word ends with in that layout */
   const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
-  unsigned long long* ymemo;    /* fltx_ylane.h, shared-CU geometry: the LM-state memo of every utterance (kYlMemo slots each) */
+  unsigned long long* ymemo;    /* fltx_ylane.h / fltx_xlane.h, memo in HBM: the LM-state memo of every utterance (ymemoSlots each) */
+  uint32_t ymemoSlots;          /* power of two; fltx_xlane.h: kXlMemoH */
   unsigned long long* lmCache;  /* generic step with an n-gram LM: (LM state, word) -> score of the last look-ups, kLmCache slots per utterance */
   int32_t wsNoInv;              /* HBM workspace of the generic step (hot level >= 1): no L1 invalidate after its barriers (wsBarrier) */
   int32_t* statusHost;          /* optimistic stream chunks: uttStatus mirrored in pinned host memory (read after the kernel, no copy) */
@@ -2935,7 +2936,8 @@ struct BacktraceParams {
   int32_t nbest;           /* <= 0: all */
   int32_t F;               /* frames per LDS chunk (0: walk straight through HBM) */
   /* records of the lane = LM state engines: parent slot in the low `packed` bits of x (all ones = none): 8 for
-   * fltx_slane.h / fltx_xlane.h / fltx_ylane.h, 10 for fltx_mlane.h; 0 = plain {parent, token} records */
+   * fltx_slane.h / fltx_xlane.h / fltx_ylane.h, 10 for fltx_mlane.h, 13 for fltx_ylane.h with four lane groups;
+   * 0 = plain {parent, token} records */
   int32_t packed;
   const int32_t* uttStatus; /* ST_PACKED per utterance (a re-run on the generic engine leaves plain records) */
   /* that engine does not carry the emitting-model score through the frames; it is

@@ -1,7 +1,7 @@
 /*
  * fltx_ylane.h -- "lane = (LM state, trie node)" decode of a whole utterance for the
  * lexicon decoder with a word LM: LexiconDecoder + ZeroLM or n-gram LM, smeared trie
- * (TrieNode::maxScore), CTC, max-merge, beam <= 128, <= 64 tokens, one word per
+ * (TrieNode::maxScore), CTC, max-merge, beam <= 256 (one, two or four groups of 64 lanes), <= 64 tokens, one word per
  * spelling, every word ending in the separator token, no <unk>, offline.  Included by
  * fltx_kernels.h after fltx_xlane.h, whose lane formulation it keeps (read the head of
  * that file first) and whose row staging, token-beam ranking, histogram window and scan
@@ -32,16 +32,17 @@
  */
 #pragma once
 
-constexpr int kYlLanes = 128;
-constexpr int kYlRoot = 256;  /* slots of the per-frame (LM state, word) merge table */
-constexpr int kYlOrph = 256;  /* slots of the per-frame table of lanes without a parent lane */
-constexpr int kYlMemo = 8192;
-static_assert(kYlMemo == kXlMemoH, "DecodeParams::ymemo is sized for either engine"); /* slots of the LM-state memo: (LM state + 1) << 40 | (word + 1) << 16 | number of the child state */
-constexpr int kYlTokWaves = 8;
+/* Sizes follow the lane groups: LG = 2 serves one and two groups (the C4 / C5 geometries), LG = 4 beams up to 256 */
+constexpr int kYlMemo = 8192; /* slots of the LM-state memo in LDS: (LM state + 1) << 40 | (word + 1) << 16 | number of the child state */
+static_assert(kYlMemo == kXlMemoH, "DecodeParams::ymemo is sized for either engine");
 constexpr int kYlPairs = 512; /* (lane, token) pairs a token wave can list: positions per wave x lanes */
+constexpr int kYlPairs4 = 768; /* ... with four lane groups: three positions x 256 lanes */
 constexpr uint32_t kYlNoLm = 0x7FC00001u; /* endLm: not looked up yet (a NaN no arithmetic produces) */
+constexpr int kYlMaxGroups = 8;
 
-struct YlLanes { /* in place: slot = lane for as long as the lane lives */
+template <int LG>
+struct YlLanesT { /* in place: slot = lane for as long as the lane lives */
+  static constexpr int kYlLanes = 64 * LG;
   double nb[kYlLanes], b[kYlLanes];
   double lmNB[kYlLanes], lmB[kYlLanes];                 /* LM score of the two hypotheses */
   unsigned long long childMask[kYlLanes], kidsMask[kYlLanes]; /* XNode of the lane's node */
@@ -61,7 +62,8 @@ struct YlLanes { /* in place: slot = lane for as long as the lane lives */
   int32_t endCtx[kMaxNgramOrder - 1][kYlLanes]; /* ... and the n-gram context of the LM state that word leads to */
 };
 
-struct alignas(16) YlRootTab {
+template <int kYlRoot>
+struct alignas(16) YlRootTabT {
   unsigned long long key[kYlRoot];  /* 0 = free */
   unsigned long long best[kYlRoot]; /* order-preserving score key */
   double winLm[kYlRoot];            /* LM score of the arrival that represents the slot */
@@ -70,13 +72,23 @@ struct alignas(16) YlRootTab {
   uint32_t winHyp[kYlRoot];         /* its history slot ... */
   int32_t winWord[kYlRoot];         /* ... and word (for the root lane's back-pointer) */
 };
-struct alignas(16) YlOrphTab {
+template <int LG, int kYlOrph>
+struct alignas(16) YlOrphTabT {
+  static constexpr int kSlots = kYlOrph;
   unsigned long long key[kYlOrph]; /* 0 = free */
-  unsigned long long lanes[2][kYlOrph];
+  unsigned long long lanes[LG][kYlOrph];
 };
 
-struct YlaneLds {
-  YlLanes L;
+template <int LG>
+struct YlaneLdsT {
+  static constexpr int kYlLanes = 64 * LG;
+  static constexpr int kYlRoot = 128 * LG;  /* slots of the per-frame (LM state, word) merge table */
+  static constexpr int kYlOrph = 128 * LG;  /* slots of the per-frame table of lanes without a parent lane */
+  static constexpr int kYlTokWaves = LG <= 2 ? 8 : 10;
+  static constexpr int kYlPairs = LG <= 2 ? fltx::kYlPairs : fltx::kYlPairs4;
+  using YlRootTab = YlRootTabT<kYlRoot>;
+  using YlOrphTab = YlOrphTabT<LG, kYlOrph>;
+  YlLanesT<LG> L;
   unsigned long long cmask[2][kYlLanes]; /* tokens whose child node holds a lane that links here */
   uint32_t hist[2][kSlNB];
   double eAll[2][64];
@@ -87,16 +99,16 @@ struct YlaneLds {
   YlRootTab root;
   YlOrphTab orph[2];
   unsigned long long bestKey[2];
-  unsigned long long alive[2][2];    /* lanes of the frame, per group */
-  unsigned long long surv[2];        /* ... that stay for the next frame (alive[next] = these + the new lanes) */
+  unsigned long long alive[2][LG];   /* lanes of the frame, per group */
+  unsigned long long surv[LG];       /* ... that stay for the next frame (alive[next] = these + the new lanes) */
   XNode rootNode;
   int32_t rootWord, pad1;            /* LM word id of the root's endLabel */
   uint32_t off[32];                  /* new lanes of the waves before wave i (token waves, then the word wave); [last + 1] = all */
-  uint32_t offH[4];                  /* surviving hypotheses of the lane groups before group g; [NG] = all */
-  uint32_t nFree[2];
-  uint8_t freeList[2][64];           /* free slots of a group, in slot order */
-  uint8_t lmReq[kYlLanes];           /* lanes whose word has no n-gram score yet */
-  uint8_t nrList[kYlLanes];          /* arrivals that become root lanes, and what was found out for them */
+  uint32_t offH[kYlMaxGroups + 4];   /* surviving hypotheses of the lane groups before group g; [NG] = all */
+  uint32_t nFree[LG];
+  uint8_t freeList[LG][64];          /* free slots of a group, in slot order */
+  uint16_t lmReq[kYlLanes];          /* lanes whose word has no n-gram score yet */
+  uint16_t nrList[kYlLanes];         /* arrivals that become root lanes, and what was found out for them */
   int16_t nrOrph[kYlLanes];
   uint32_t nrSid[kYlLanes];
   uint16_t cand[kYlTokWaves][kYlPairs]; /* (lane | list position << 8) pairs of a token wave */
@@ -116,10 +128,13 @@ struct YlaneLds {
    * one utterance's waits (two thirds of its wave cycles) are the other's time to run. */
   unsigned long long memo[kYlMemo];
 };
+using YlaneLds = YlaneLdsT<2>; /* one and two lane groups */
 
 enum { YL_FLAG = 15, YL_NICE = 14 };
 
-FLTX_DEV int ylRootFind(YlaneLds& S, unsigned long long key) {
+template <typename LDS>
+FLTX_DEV int ylRootFind(LDS& S, unsigned long long key) {
+  constexpr int kYlRoot = LDS::kYlRoot;
   uint32_t h = xlHash(key) & (kYlRoot - 1);
   for (int probe = 0; probe < kYlRoot; ++probe) {
     const unsigned long long old = atomCas64(&S.root.key[h], 0ull, key);
@@ -130,7 +145,9 @@ FLTX_DEV int ylRootFind(YlaneLds& S, unsigned long long key) {
   }
   return -1;
 }
+template <typename YlOrphTab>
 FLTX_DEV void ylOrphAdd(YlOrphTab& tab, unsigned long long key, int li) {
+  constexpr int kYlOrph = YlOrphTab::kSlots;
   uint32_t h = xlHash(key) & (kYlOrph - 1);
   for (;;) {
     const unsigned long long old = atomCas64(&tab.key[h], 0ull, key);
@@ -141,7 +158,9 @@ FLTX_DEV void ylOrphAdd(YlOrphTab& tab, unsigned long long key, int li) {
     h = (h + 1u) & (kYlOrph - 1);
   }
 }
+template <typename YlOrphTab>
 FLTX_DEV int ylOrphFind(const YlOrphTab& tab, unsigned long long key) {
+  constexpr int kYlOrph = YlOrphTab::kSlots;
   uint32_t h = xlHash(key) & (kYlOrph - 1);
   for (;;) {
     const unsigned long long k = tab.key[h];
@@ -201,10 +220,24 @@ FLTX_DEV uint32_t ylLmWord(const DecodeParams& P, int usr) {
  * pairs each (512 threads: two workgroups share a CU) */
 template <int NG, int R, int LMK, int HM, bool PROF>
 FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
-  YlaneLds& S = *(YlaneLds*)smem;
-  constexpr int PAIRS = (NG == 2 && HM) ? 2 * kYlPairs : kYlPairs; /* pairs a token wave can list */
+  constexpr int LG = NG > 2 ? NG : 2;
+  using LDS = YlaneLdsT<LG>;
+  LDS& S = *(LDS*)smem;
+  constexpr int kYlLanes = LDS::kYlLanes, kYlRoot = LDS::kYlRoot, kYlOrph = LDS::kYlOrph;
+  constexpr int PAIRS = (NG == 2 && HM) ? 2 * kYlPairs : LDS::kYlPairs; /* pairs a token wave can list */
   constexpr int NS = R > NG ? R : (NG > 2 ? NG : 2); /* candidate slots of a thread */
-  static_assert(NG == 1 || NG == 2, "one or two lane groups");
+  static_assert(NG == 1 || NG == 2 || NG == 4, "one, two or four lane groups");
+  static_assert(NG <= 2 || HM == 1, "four lane groups: the LM-state memo lives in HBM");
+  /* History slots in the lanes' records: 8 bits (0xFF = none) up to two groups, 13 bits beyond -- the back-trace masks
+   * the parent-slot field of a record accordingly (BacktraceParams::packed = 8 / 13) */
+  constexpr bool WIDE = NG > 2;
+  constexpr uint32_t kNoHyp = WIDE ? 0x1FFFu : kSlNoHyp;
+  auto infoTok = [](uint32_t i) { return (int)(i & 63u); };
+  auto infoNB = [](uint32_t i) { return WIDE ? ((i >> 6) & 0x1FFFu) : ((i >> 16) & 0xFFu); };
+  auto infoB = [](uint32_t i) { return WIDE ? (i >> 19) : (i >> 24); };
+  auto mkInfo = [](uint32_t tok, uint32_t hNBv, uint32_t hBv) {
+    return WIDE ? (tok | (hNBv << 6) | (hBv << 19)) : (tok | (hNBv << 16) | (hBv << 24));
+  };
   static_assert(R * 64 <= PAIRS, "cand[] holds PAIRS pairs per token wave");
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x, tid = (int)threadIdx.x;
@@ -231,7 +264,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   int32_t* const histW = P.histW;
   const XNode* const xnode = P.xnode;
   const float* const xdelta = P.xdelta;
-  YlLanes& L = S.L;
+  auto& L = S.L;
   unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
   unsigned long long tPrev = devClock();
   uint32_t nScored = 0u;
@@ -251,16 +284,20 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   }
   for (int i = tid; i < kYlOrph; i += W) {
     S.orph[0].key[i] = 0ull;
-    S.orph[0].lanes[0][i] = 0ull;
-    S.orph[0].lanes[1][i] = 0ull;
     S.orph[1].key[i] = 0ull;
-    S.orph[1].lanes[0][i] = 0ull;
-    S.orph[1].lanes[1][i] = 0ull;
+#pragma unroll
+    for (int g = 0; g < LG; ++g) {
+      S.orph[0].lanes[g][i] = 0ull;
+      S.orph[1].lanes[g][i] = 0ull;
+    }
   }
-  unsigned long long* const memo = HM ? P.ymemo + (size_t)b * kYlMemo : S.memo;
+  /* memo in HBM: as many slots as the host sized it for (long utterances create more LM states than the LDS memo holds) */
+  const int memoSlots = HM ? (int)P.ymemoSlots : kYlMemo;
+  const uint32_t memoMask = (uint32_t)memoSlots - 1u;
+  unsigned long long* const memo = HM ? P.ymemo + (size_t)b * (size_t)memoSlots : S.memo;
   uint16_t* const candW = &S.cand[0][0] + (size_t)wave * PAIRS; /* (token waves: wave < 8, or < 4 with twice the pairs) */
   uint16_t* const pbinW = &S.pbin[0][0] + (size_t)wave * PAIRS;
-  for (int i = tid; i < kYlMemo; i += W) {
+  for (int i = tid; i < memoSlots; i += W) {
     memo[i] = 0ull; /* (HBM: at L2 before the barrier below, where the word wave's atomics will find it) */
   }
   if (tid < 32) {
@@ -269,7 +306,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   if (tid < 16) {
     S.scal[tid] = 0u;
   }
-  if (tid < 4) {
+  if (tid < kYlMaxGroups + 4) {
     S.offH[tid] = 0u;
   }
   if (tid == 0) {
@@ -281,7 +318,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     L.lmB[0] = 0.0;
     L.childMask[0] = r0.childMask;
     L.kidsMask[0] = r0.kidsMask;
-    L.info[0] = (uint32_t)sil | (0u << 16) | (kSlNoHyp << 24);
+    L.info[0] = mkInfo((uint32_t)sil, 0u, kNoHyp);
     L.link[0] = 0u;
     L.lmSid[0] = 0u;
     L.node[0] = 0u;
@@ -295,10 +332,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     L.endLm[0] = kYlNoLm;
     L.endWord[0] = (ngram && r0.endLabel0 >= 0) ? (int32_t)ylLmWord(P, r0.endLabel0) : -1;
     S.rootWord = L.endWord[0];
-    S.alive[0][0] = 1ull;
-    S.alive[0][1] = 0ull;
-    S.alive[1][0] = 0ull;
-    S.alive[1][1] = 0ull;
+#pragma unroll
+    for (int g = 0; g < LG; ++g) {
+      S.alive[0][g] = g == 0 ? 1ull : 0ull;
+      S.alive[1][g] = 0ull;
+    }
     S.row[0].nev = 0u;
     S.row[1].nev = 0u;
     S.row[0].dead = 0u;
@@ -308,7 +346,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     S.lb[0] = 0ull;
     S.lb[1] = 0ull;
     S.lmNext = 1u;
-    histPT[hbase] = make_int2((int)kSlNoHyp, sil);
+    histPT[hbase] = make_int2((int)kNoHyp, sil);
     histW[hbase] = -1;
     if (ngram) { /* KenLM::start(false): context = <s> (KenLM.cpp:57) */
       const int Lc = P.lmOrder - 1;
@@ -322,7 +360,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     }
   }
   if (tid > 0 && tid < K) {
-    histPT[hbase + tid] = make_int2((int)kSlNoHyp, -1);
+    histPT[hbase + tid] = make_int2((int)kNoHyp, -1);
   }
   float rowA = 0.0f, rowB = 0.0f;
   if (isSvc) {
@@ -352,7 +390,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     /* ---- phase 1a: candidates, the merge table, the frame's best --------------------------- */
     const int silPos = S.row[p].silPos;
     const unsigned long long allow = S.row[p].allow;
-    const unsigned long long alive0 = S.alive[p][0], alive1 = NG > 1 ? S.alive[p][1] : 0ull;
+    unsigned long long aliveG[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      aliveG[g] = S.alive[p][g];
+    }
     double cs[NS], clm[NS];
     int cbin[NS];
     bool cok[NS];
@@ -376,7 +418,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     /* own lane (self waves) */
     bool live = false, atRoot = false;
     double nb = NEG, bb = NEG, m = NEG, lmM = 0.0, lmOwnNB = 0.0;
-    uint32_t info = 0u, hypNB = kSlNoHyp, hypB = kSlNoHyp, hypM = kSlNoHyp, parR = kSlNoHyp;
+    uint32_t info = 0u, hypNB = kNoHyp, hypB = kNoHyp, hypM = kNoHyp, parR = kNoHyp;
     int last = 0, pl = -1, rootSlot = -1;
     bool whichB = false;
     double lmR = 0.0; /* LM score of the winning member of the stay group */
@@ -388,8 +430,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     for (int g = 0; g < NG; ++g) {
       wSlot[g] = -1;
       wUseB[g] = false;
-      wHypB[g] = kSlNoHyp;
-      wHypM[g] = kSlNoHyp;
+      wHypB[g] = kNoHyp;
+      wHypM[g] = kNoHyp;
     }
     int nCand = 0; /* token waves: pairs in cand[wave] */
     /* staging wave: ranks the token beam of the next row in three pieces (see fltx_xlane.h) */
@@ -408,12 +450,14 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     XlRank rs = {};
     FLTX_YLPROF(0);
     if (isSvc) {
-      S.cmask[q][lane] = 0ull;
-      S.cmask[q][lane + 64] = 0ull;
+#pragma unroll
+      for (int g = 0; g < LG; ++g) {
+        S.cmask[q][g * 64 + lane] = 0ull;
+      }
       if (lane < 32) {
         S.off[lane] = 0u;
       }
-      if (lane < 4) {
+      if (lane < kYlMaxGroups + 4) {
         S.offH[lane] = 0u;
       }
       if (lane == 0) {
@@ -433,15 +477,15 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int x = g * 64 + lane;
-        const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+        const bool lv = ((aliveG[g] >> lane) & 1ull) != 0ull;
         const double xb = lv ? L.b[x] : NEG;
         const uint32_t xi = L.info[x];
-        const int xl = (int)(xi & 0xFFu) & 63;
-        const uint32_t xhB = xi >> 24;
+        const int xl = infoTok(xi);
+        const uint32_t xhB = infoB(xi);
         const unsigned long long cmk = L.childMask[x];
         const bool extLast = ((cmk & L.kidsMask[x]) >> xl) & 1ull;
         const bool allowLast = ((allow >> xl) & 1ull) != 0ull;
-        const bool go = lv && xhB != kSlNoHyp && extLast && allowLast && ((S.cmask[p][x] >> xl) & 1ull) == 0ull;
+        const bool go = lv && xhB != kNoHyp && extLast && allowLast && ((S.cmask[p][x] >> xl) & 1ull) == 0ull;
         double cL = xb + S.eAll[p][xl];
         if (xl == sil) {
           cL = cL + silScore;
@@ -458,7 +502,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         }
         cs[g] = cL;
         cok[g] = go && cL == cL;
-        cinf[g] = (uint32_t)x | ((uint32_t)xl << 8) | (xhB << 16);
+        cinf[g] = (uint32_t)x | ((uint32_t)xl << 9) | (xhB << 16);
       }
     } else if (isTok) {
       /* the (lane, token) pairs with a child that has children and no lane of its own yet, the
@@ -468,7 +512,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int x = g * 64 + lane;
-        const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+        const bool lv = ((aliveG[g] >> lane) & 1ull) != 0ull;
         const unsigned long long own = 1ull << (L.info[x] & 63u);
         ext[g] = lv ? (L.childMask[x] & L.kidsMask[x] & ~S.cmask[p][x] & ~own) : 0ull;
         const double xnb = L.nb[x], xb = L.b[x];
@@ -498,7 +542,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           if (bal != 0ull) {
             const int at = nCand + wavePrefixCount(bal);
             if (has && at < PAIRS) {
-              candW[at] = (uint16_t)((g * 64 + lane) | (j << 8));
+              candW[at] = (uint16_t)((g * 64 + lane) | (j << 9));
             }
             nCand += popc64(bal);
           }
@@ -521,7 +565,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           const int id = c0 + lane;
           const bool valid = id < nCand;
           const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
-          const int x = (int)(c16 & 0xFFu), pos = wave * TPW + (int)(c16 >> 8);
+          const int x = (int)(c16 & 0x1FFu), pos = wave * TPW + (int)(c16 >> 9);
           const double xnb = L.nb[x], xb = L.b[x];
           const int n = (int)S.tokId[p][pos];
           double c = (xb > xnb ? xb : xnb) + S.eTok[p][pos];
@@ -575,7 +619,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         if (r * 64 < nCand) {
           const bool valid = id < nCand;
           const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
-          const int x = (int)(c16 & 0xFFu), pos = wave * TPW + (int)(c16 >> 8);
+          const int x = (int)(c16 & 0x1FFu), pos = wave * TPW + (int)(c16 >> 9);
           const double xnb = L.nb[x], xb = L.b[x];
           const uint32_t xi = L.info[x];
           const double ev = S.eTok[p][pos];
@@ -585,8 +629,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           if (pos == silPos) {
             c = c + silScore;
           }
-          const uint32_t hp = wb ? (xi >> 24) : ((xi >> 16) & 0xFFu);
-          cinf[r] = (uint32_t)x | ((uint32_t)n << 8) | (hp << 16);
+          const uint32_t hp = wb ? infoB(xi) : infoNB(xi);
+          cinf[r] = (uint32_t)x | ((uint32_t)n << 9) | (hp << 16);
           const uint32_t child = L.firstChild[x] + (uint32_t)popc64(L.childMask[x] & ((1ull << n) - 1ull));
           cnode[r] = child;
           cpl[r] = L.lmSid[x];
@@ -602,13 +646,18 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
     } else if (isSelf) {
-      live = (((grp == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+      unsigned long long aliveMine = aliveG[0];
+#pragma unroll
+      for (int g = 1; g < NG; ++g) {
+        aliveMine = g == grp ? aliveG[g] : aliveMine;
+      }
+      live = ((aliveMine >> lane) & 1ull) != 0ull;
       nb = live ? L.nb[li] : NEG;
       bb = live ? L.b[li] : NEG;
       info = L.info[li];
-      last = (int)(info & 0xFFu) & 63;
-      hypNB = (info >> 16) & 0xFFu;
-      hypB = info >> 24;
+      last = infoTok(info);
+      hypNB = infoNB(info);
+      hypB = infoB(info);
       whichB = bb > nb;
       m = whichB ? bb : nb;
       hypM = whichB ? hypB : hypNB;
@@ -634,13 +683,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       cok[0] = live;
       /* stay (:168-194) + the trie parent's extension by the node's token (a "(1) try children"
        * candidate: needs the token in the token beam, carries the smearing difference) */
-      const int lastP = (int)(parInfo & 0xFFu);
-      const uint32_t h1 = (parInfo >> 16) & 0xFFu, h2 = parInfo >> 24;
+      const int lastP = infoTok(parInfo);
+      const uint32_t h1 = infoNB(parInfo), h2 = infoB(parInfo);
       const bool allowLast = ((allow >> last) & 1ull) != 0ull;
-      const bool hasNB = hypNB != kSlNoHyp;
+      const bool hasNB = hypNB != kNoHyp;
       const bool has0 = atRoot ? true : hasNB;
-      const bool has1 = pl >= 0 && allowLast && last != lastP && h1 != kSlNoHyp;
-      const bool has2 = pl >= 0 && allowLast && h2 != kSlNoHyp;
+      const bool has1 = pl >= 0 && allowLast && last != lastP && h1 != kNoHyp;
+      const bool has2 = pl >= 0 && allowLast && h2 != kNoHyp;
       double r0 = (atRoot ? m : nb) + (atRoot ? eSil : eLast);
       double r1 = has1 ? parNB + eLast : NEG;
       double r2 = has2 ? parB + eLast : NEG;
@@ -685,11 +734,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const int x = g * 64 + lane;
-          const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+          const bool lv = ((aliveG[g] >> lane) & 1ull) != 0ull;
           const bool need = lv && L.endLabel[x] >= 0 && L.endLm[x] == kYlNoLm;
           const unsigned long long bal = waveBallot(need);
           if (need) {
-            S.lmReq[nReq + wavePrefixCount(bal)] = (uint8_t)x;
+            S.lmReq[nReq + wavePrefixCount(bal)] = (uint16_t)x;
           }
           nReq += popc64(bal);
         }
@@ -719,11 +768,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int x = g * 64 + lane;
-        const bool lv = (((g == 0 ? alive0 : alive1) >> lane) & 1ull) != 0ull;
+        const bool lv = ((aliveG[g] >> lane) & 1ull) != 0ull;
         const double xnb = lv ? L.nb[x] : NEG, xb = lv ? L.b[x] : NEG;
         const uint32_t xi = L.info[x];
-        const int xl = (int)(xi & 0xFFu) & 63;
-        const uint32_t xhNB = (xi >> 16) & 0xFFu, xhB = xi >> 24;
+        const int xl = infoTok(xi);
+        const uint32_t xhNB = infoNB(xi), xhB = infoB(xi);
         const bool wb = xb > xnb;
         const double xm = wb ? xb : xnb;
         const bool xRoot = L.node[x] == 0u;
@@ -732,7 +781,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         const double eEnd = S.eAll[p][endTok], eLast = S.eAll[p][xl];
         /* a word ends (:113-142); on the root the nb hypothesis would repeat its token (:114-122) */
         const bool useB = xRoot && xl == endTok;
-        const bool can = lv && el >= 0 && ((allow >> endTok) & 1ull) != 0ull && (useB ? xhB != kSlNoHyp : true);
+        const bool can = lv && el >= 0 && ((allow >> endTok) & 1ull) != 0ull && (useB ? xhB != kNoHyp : true);
         double c = (useB ? xb : xm) + eEnd;
         if (endTok == sil) {
           c = c + silScore;
@@ -812,7 +861,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const unsigned long long rb = S.root.best[rootSlot];
       if (rb > f64Key(cs[1])) {
         cs[1] = f64FromKey(rb);
-        parR = kSlNoHyp; /* back-pointer and LM score: read from the slot in the build */
+        parR = kNoHyp; /* back-pointer and LM score: read from the slot in the build */
       }
     }
     if (isWord) {
@@ -1012,7 +1061,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     bool wroteCtx = false; /* a new LM state's context is on its way to HBM */
     int rootOrph[NG];
     bool surv = false;
-    uint32_t hNB = kSlNoHyp, hB = kSlNoHyp;
+    uint32_t hNB = kNoHyp, hB = kNoHyp;
     unsigned long long balS = 0ull;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
@@ -1077,7 +1126,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           const bool want = ((pend >> g) & 1u) != 0u;
           const unsigned long long bal = waveBallot(want);
           if (want) {
-            S.nrList[nr + wavePrefixCount(bal)] = (uint8_t)(g * 64 + lane);
+            S.nrList[nr + wavePrefixCount(bal)] = (uint16_t)(g * 64 + lane);
           }
           nr += popc64(bal);
         }
@@ -1089,7 +1138,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
               const uint32_t xlm = L.lmSid[x];
               const int32_t el = L.endLabel[x];
               const unsigned long long mkey = ((unsigned long long)(xlm + 1u) << 24) | (unsigned long long)(uint32_t)(el + 1);
-              uint32_t h = xlHash(mkey) & (kYlMemo - 1);
+              uint32_t h = xlHash(mkey) & memoMask;
               uint32_t sid = 0u;
               bool have = false; /* a number was taken from the counter for this state */
               for (int probe = 0;; ++probe) {
@@ -1101,7 +1150,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
                   }
                   cur = atomCas64(&memo[h], 0ull, (mkey << 16) | (unsigned long long)(sid & 0xFFFFu));
                   if (cur == 0ull) { /* a new LM state */
-                    if (sid > (uint32_t)(kYlMemo * 3 / 4) || sid + 1u >= P.stateCap || sid >= 0xFFFFu ||
+                    if (sid > (uint32_t)(memoSlots / 4 * 3) || sid + 1u >= P.stateCap || sid >= 0xFFFFu ||
                         (uint32_t)(el + 1) >= (1u << 24)) {
                       atomOr32(&S.scal[YL_FLAG], 1u); /* memo nearly full: general path from the next frame on */
                     } else if (ngram) { /* its n-gram context: kept with the lane since the look-up */
@@ -1122,8 +1171,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
                   sid = (uint32_t)(cur & 0xFFFFull);
                   break;
                 }
-                h = (h + 1u) & (kYlMemo - 1);
-                if (probe > kYlMemo) {
+                h = (h + 1u) & memoMask;
+                if (probe > memoSlots) {
                   atomOr32(&S.scal[YL_FLAG], 1u);
                   break;
                 }
@@ -1185,9 +1234,27 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     const int nHSurv = (int)S.offH[NG];
     const int nNew = (int)S.off[nTok + 2];
     const uint32_t nFree0 = S.nFree[0];
-    auto survives = [&](int x) { return (((x < 64 ? surv0 : surv1) >> (x & 63)) & 1ull) != 0ull; };
+    auto survives = [&](int x) {
+      if constexpr (NG <= 2) {
+        return (((x < 64 ? surv0 : surv1) >> (x & 63)) & 1ull) != 0ull;
+      } else {
+        return ((S.surv[x >> 6] >> (x & 63)) & 1ull) != 0ull;
+      }
+    };
     auto freeSlot = [&](int idx) {
-      return (uint32_t)idx < nFree0 ? (int)S.freeList[0][idx] : 64 + (int)S.freeList[1][(idx - (int)nFree0) & 63];
+      if constexpr (NG <= 2) {
+        return (uint32_t)idx < nFree0 ? (int)S.freeList[0][idx] : 64 + (int)S.freeList[1][(idx - (int)nFree0) & 63];
+      } else { /* the idx-th free slot over the groups in order */
+        int g = 0, at = idx;
+#pragma unroll
+        for (int k = 0; k < NG - 1; ++k) {
+          const int nf = (int)S.nFree[k];
+          const bool past = g == k && at >= nf;
+          at = past ? at - nf : at;
+          g = past ? k + 1 : g;
+        }
+        return g * 64 + (int)S.freeList[g][at & 63];
+      }
     };
     /* the lanes in the beam whose parent pair is the one in orphan slot `os`: they link to lane nl */
     auto adopt = [&](int os, int nl) {
@@ -1215,7 +1282,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     auto newChild = [&](int idx, double c, double lmc, uint32_t ci, uint32_t child, float dl) {
       const int nl = freeSlot(idx);
       const uint32_t hyp = (uint32_t)(nHSurv + idx);
-      const int x = (int)(ci & 0xFFu), n = (int)((ci >> 8) & 0xFFu);
+      const int x = (int)(ci & 0x1FFu), n = (int)((ci >> 9) & 0x7Fu);
       const uint32_t hp = ci >> 16;
       const XNode cx = planX;
       const bool ps = survives(x);
@@ -1225,7 +1292,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       L.lmB[nl] = 0.0;
       L.childMask[nl] = cx.childMask;
       L.kidsMask[nl] = cx.kidsMask;
-      L.info[nl] = (uint32_t)n | (hyp << 16) | (kSlNoHyp << 24);
+      L.info[nl] = mkInfo((uint32_t)n, hyp, kNoHyp);
       L.link[nl] = ps ? (uint32_t)x + 1u : 0u;
       L.lmSid[nl] = planLm;
       L.node[nl] = child;
@@ -1250,20 +1317,26 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
       /* the merge table of the next frame starts empty (winHyp / winWord / winLm, which the self
        * waves read now, stay), and so does its orphan table: 16 bytes per lane and store */
-      static_assert(kYlRoot == 256 && kYlOrph == 256, "the wipes below cover 256 slots");
+      static_assert(kYlRoot % 256 == 0 && kYlOrph % 128 == 0, "the wipes below cover whole rounds of 64 lanes");
       const uint4 z4 = make_uint4(0u, 0u, 0u, 0u), f4 = make_uint4(~0u, ~0u, ~0u, ~0u);
-      ((uint4*)S.root.key)[lane] = z4;
-      ((uint4*)S.root.key)[lane + 64] = z4;
-      ((uint4*)S.root.best)[lane] = z4;
-      ((uint4*)S.root.best)[lane + 64] = z4;
-      ((uint4*)S.root.lane)[lane] = z4;
-      ((uint4*)S.root.minLane)[lane] = f4;
-      ((uint4*)S.orph[q].key)[lane] = z4;
-      ((uint4*)S.orph[q].key)[lane + 64] = z4;
-      ((uint4*)S.orph[q].lanes[0])[lane] = z4;
-      ((uint4*)S.orph[q].lanes[0])[lane + 64] = z4;
-      ((uint4*)S.orph[q].lanes[1])[lane] = z4;
-      ((uint4*)S.orph[q].lanes[1])[lane + 64] = z4;
+#pragma unroll
+      for (int i = 0; i < kYlRoot / 128; ++i) { /* 64-bit words: two per lane and store */
+        ((uint4*)S.root.key)[lane + 64 * i] = z4;
+        ((uint4*)S.root.best)[lane + 64 * i] = z4;
+      }
+#pragma unroll
+      for (int i = 0; i < kYlRoot / 256; ++i) { /* 32-bit words: four */
+        ((uint4*)S.root.lane)[lane + 64 * i] = z4;
+        ((uint4*)S.root.minLane)[lane + 64 * i] = f4;
+      }
+#pragma unroll
+      for (int i = 0; i < kYlOrph / 128; ++i) {
+        ((uint4*)S.orph[q].key)[lane + 64 * i] = z4;
+#pragma unroll
+        for (int g = 0; g < LG; ++g) {
+          ((uint4*)S.orph[q].lanes[g])[lane + 64 * i] = z4;
+        }
+      }
       /* blank-then-own-token lanes */
       const int offS = (int)S.off[nTok + 1];
       uint32_t cp = pend;
@@ -1319,14 +1392,14 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       }
     } else if (isSelf) {
       if (li >= nHSurv + nNew && li < K) { /* unused slots of the history row */
-        histPT[hrow + li] = make_int2((int)kSlNoHyp, -1);
+        histPT[hrow + li] = make_int2((int)kNoHyp, -1);
       }
       if (surv) {
         const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
         const uint32_t hb = S.offH[grp];
         L.nb[li] = sR ? cs[1] : NEG;
         L.b[li] = sB ? cs[0] : NEG;
-        L.info[li] = (uint32_t)last | ((sR ? hNB + hb : kSlNoHyp) << 16) | ((sB ? hB + hb : kSlNoHyp) << 24);
+        L.info[li] = mkInfo((uint32_t)last, sR ? hNB + hb : kNoHyp, sB ? hB + hb : kNoHyp);
         if (pl >= 0) {
           if (survives(pl)) {
             atomOr64(&S.cmask[q][pl], 1ull << last);
@@ -1338,7 +1411,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         if (sR) {
           uint32_t hp = parR;
           int32_t wd = -1;
-          if (hp == kSlNoHyp) { /* a word ending on this root beat its own stay */
+          if (hp == kNoHyp) { /* a word ending on this root beat its own stay */
             hp = S.root.winHyp[rootSlot];
             wd = S.root.winWord[rootSlot];
             lmStay = S.root.winLm[rootSlot];
@@ -1399,7 +1472,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           L.lmB[nl] = 0.0;
           L.childMask[nl] = r0.childMask;
           L.kidsMask[nl] = r0.kidsMask;
-          L.info[nl] = (uint32_t)endTok | (hyp << 16) | (kSlNoHyp << 24);
+          L.info[nl] = mkInfo((uint32_t)endTok, hyp, kNoHyp);
           L.link[nl] = 0u;
           L.lmSid[nl] = sid;
           L.node[nl] = 0u;
@@ -1463,7 +1536,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   if (!dead) {
     bool liveE = false, onRoot = false;
     double mE = NEG, lmE = 0.0;
-    uint32_t hpE = kSlNoHyp, lmSidE = 0u;
+    uint32_t hpE = kNoHyp, lmSidE = 0u;
     if (wave < NG) {
       const int x = wave * 64 + lane;
       liveE = ((S.alive[pe][wave] >> lane) & 1ull) != 0ull;
@@ -1471,7 +1544,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const uint32_t xi = L.info[x];
       const bool wb = xb > xnb;
       mE = wb ? xb : xnb;
-      hpE = wb ? (xi >> 24) : ((xi >> 16) & 0xFFu);
+      hpE = wb ? infoB(xi) : infoNB(xi);
       lmE = LMK ? (wb ? L.lmB[x] : L.lmNB[x]) : 0.0;
       lmSidE = L.lmSid[x];
       onRoot = L.node[x] == 0u;
