@@ -231,7 +231,8 @@ def test_edge_configurations_of_the_lexicon_lane_engine_with_lm_terms(gpu_sessio
         want = helpers.run_checker(oracle_lib, c, inp)
         if len({h.score for h in want}) != len(want):
             continue
-        got = gpu_session.run(c, inp, sets={"yshare": yshare})
+        # (every third: token waves with more than max(8, beam) pairs rank their own -- the fan-out path)
+        got = gpu_session.run(c, inp, sets={"yshare": yshare, "ylane_rank_at": 8 if ran % 3 == 0 else 0})
         served += gpu_session.last_engine == 6
         ok, why = helpers.hyps_equal(want, got)
         ran += 1
@@ -336,6 +337,8 @@ def _four_lane_group_grid(session, oracle_lib, every, T_of):
         d = session.decoder(c, inp)
         d.set("ylane", 2)
         d.set("ylane_groups", 4)
+        if i % (3 * every) == 0:  # token waves with more than max(8, beam) pairs rank their own: the fan-out path
+            d.set("ylane_rank_at", 8)
         d.decode_batch(inp["e"], [T], c["N"])
         got = d.results(0)
         served += 1 if (d.get("engine") == 6 and d.get("lane_groups") == 4 and d.get("redone") == 0) else 0

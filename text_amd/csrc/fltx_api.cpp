@@ -405,6 +405,7 @@ struct fltx_decoder {
   /* ... with several lane groups (fltx_mlane.h, beams beyond 64): lane groups (0 / 1 = fltx_slane.h), groups per token
    * wave, groups per self wave; userLaneGroups: tuning / tests, 0 = as many as the beam needs, -1 = never */
   int mlaneNG = 0, mlaneGPW = 0, mlaneSPW = 0, userLaneGroups = 0, userMlaneGeo = -1;
+  int userYRankAt = 0;       /* tests: DecodeParams::yRankAt */
   int userYlaneGroups = 0;   /* tests: at least this many lane groups on fltx_ylane.h (0 = what the beam needs) */
   uint32_t ymemoSlots = 8192; /* slots per utterance of the LM-state memo in HBM (fltx_ylane.h: follows the frames) */
   int64_t whyNotLane = 0; /* FLTX_WHY_* bits: the eligibility terms that kept the last call off the lane engines (0 = it ran there) */
@@ -1379,6 +1380,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noSlane = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "ylane_rank_at")) { /* tests: see DecodeParams::yRankAt */
+    d->userYRankAt = (int)value;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "ylane_groups")) { /* fltx_ylane.h: at least this many lane groups (tests) */
     d->userYlaneGroups = (int)value;
     return FLTX_OK;
@@ -2044,6 +2049,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
   P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
   P.ymemoSlots = d->ymemoSlots;
+  P.yRankAt = d->userYRankAt;
   P.statusHost = (!d->offlineCall && d->streamOpt) ? (int32_t*)d->hStat.p : nullptr;
   /* (the lean step on an HBM workspace reads its atomically ORed addMask words at L2 as well: wsLoadAtomic64) */
   P.wsNoInv = (!d->wsInLds && d->hotLevel >= 1) ? 1 : 0;

@@ -112,8 +112,7 @@ struct YlaneLdsT {
   int16_t nrOrph[kYlLanes];
   uint32_t nrSid[kYlLanes];
   uint16_t cand[kYlTokWaves][kYlPairs]; /* (lane | list position << 8) pairs of a token wave */
-  uint16_t pbin[kYlTokWaves][kYlPairs]; /* a wave with more pairs than its rounds take ranks them: bins ... */
-  uint32_t whist[kYlTokWaves][kSlNB];   /* ... and their counts */
+  uint32_t whist[kYlTokWaves][kSlNB];   /* a wave with more pairs than its rounds take ranks them: counts per bin */
   unsigned long long lb[2];          /* a candidate the frame is known to have (stay / blank of a surviving lane): best >= this */
   uint32_t scal[16];
   unsigned long long bKey[kSlBCap];
@@ -260,6 +259,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   const double silScore = P.silScore, wordScore = P.wordScore, beamThreshold = P.beamThreshold;
   const double lmWeight = P.lmWeight;
   const bool ngram = LMK != 0 && P.lmKind != 0;
+  /* pairs beyond which a token wave ranks its own (tests lower it, never below the beam: the wave's K best must fit) */
+  const int rankAt = (P.yRankAt > 0 && P.yRankAt < R * 64) ? (P.yRankAt > K ? P.yRankAt : K) : R * 64;
   int2* const histPT = P.histPT;
   int32_t* const histW = P.histW;
   const XNode* const xnode = P.xnode;
@@ -296,7 +297,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   const uint32_t memoMask = (uint32_t)memoSlots - 1u;
   unsigned long long* const memo = HM ? P.ymemo + (size_t)b * (size_t)memoSlots : S.memo;
   uint16_t* const candW = &S.cand[0][0] + (size_t)wave * PAIRS; /* (token waves: wave < 8, or < 4 with twice the pairs) */
-  uint16_t* const pbinW = &S.pbin[0][0] + (size_t)wave * PAIRS;
   for (int i = tid; i < memoSlots; i += W) {
     memo[i] = 0ull; /* (HBM: at L2 before the barrier below, where the word wave's atomics will find it) */
   }
@@ -553,16 +553,15 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         nCand = PAIRS;
       }
       waveSync();
-      if (nCand > R * 64 && !dead) {
-        /* More pairs than the threads' rounds take (the beam fans out at the start of an utterance):
-         * none but the K best of this wave's own pairs can be among the frame's K best, so the wave
-         * ranks its pairs by itself -- bins of the distance to lb, whole bins kept -- and goes on with
-         * those. */
+      if (nCand > rankAt && !dead) {
+        /* More pairs than the threads' rounds take (the beam fans out at the start of an utterance): none but the K
+         * best of this wave's own pairs can be among the frame's K best, so the wave ranks its pairs by itself and
+         * goes on with the best R * 64 >= K of them at most.  The order key is the float bit pattern of the distance to
+         * lb (monotone in the score); the cut is found by counting per bin -- the coarse window first, then, as long
+         * as the bin that holds the K-th best would overfill the rounds, the finest window that spans that bin -- and
+         * is a plain threshold on the key, so what is kept is a superset of the wave's K best whatever the ties. */
         uint32_t* wh = S.whist[wave];
-        ((uint4*)wh)[lane] = make_uint4(0u, 0u, 0u, 0u);
-        waveSync();
-        for (int c0 = 0; c0 < nCand; c0 += 64) {
-          const int id = c0 + lane;
+        auto pairKey = [&](int id) -> uint32_t { /* 0xFFFFFFFF: not a candidate */
           const bool valid = id < nCand;
           const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
           const int x = (int)(c16 & 0x1FFu), pos = wave * TPW + (int)(c16 >> 9);
@@ -577,24 +576,68 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             const float dl = valid ? xdelta[child] : 0.0f;
             c = c + lmWeight * (double)dl;
           }
-          int bin = kSlInvalid;
-          if (valid && c == c) {
-            bin = c >= lbBest ? 0 : slBin(lbBest, c, kSlCoarseShift, kSlCoarseBase);
-            atomAdd32(&wh[bin], 1u);
+          if (!(valid && c == c)) {
+            return 0xFFFFFFFFu;
           }
-          if (valid) {
-            pbinW[id] = (uint16_t)bin;
+          float dd = (float)(lbBest - c);
+          dd = dd > 0.0f ? dd : 0.0f;
+          return __float_as_uint(dd);
+        };
+        unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+        int shift = kSlCoarseShift, base = kSlCoarseBase, before = 0;
+        uint32_t hiCut = 0x7FFFFFFFu;
+        bool okCut = lbk != 0ull;
+        while (okCut) {
+          ((uint4*)wh)[lane] = make_uint4(0u, 0u, 0u, 0u);
+          waveSync();
+          for (int c0 = 0; c0 < nCand; c0 += 64) {
+            const uint32_t kb = pairKey(c0 + lane);
+            if (kb != 0xFFFFFFFFu && (unsigned long long)kb >= bLo && (unsigned long long)kb <= bHi) {
+              int q = (int)(kb >> shift) - base;
+              q = q < 0 ? 0 : (q > kSlNB - 1 ? kSlNB - 1 : q);
+              atomAdd32(&wh[q], 1u);
+            }
           }
+          waveSync();
+          const SlScan ws = slScan(wh, K - before, false);
+          if (!ws.crossed) { /* fewer than that in the bracket: all of them stay */
+            hiCut = (uint32_t)bHi;
+            break;
+          }
+          const unsigned long long v = (unsigned long long)(ws.bstar + base);
+          unsigned long long l2 = bLo, h2 = bHi;
+          if (ws.bstar > 0 || base == 0) {
+            const unsigned long long e = v << shift;
+            l2 = e > l2 ? e : l2;
+          }
+          if (ws.bstar < kSlNB - 1) {
+            const unsigned long long e = ((v + 1ull) << shift) - 1ull;
+            h2 = e < h2 ? e : h2;
+          }
+          if (before + ws.cum + ws.cnt <= rankAt) {
+            hiCut = (uint32_t)h2;
+            break;
+          }
+          before += ws.cum;
+          bLo = l2;
+          bHi = h2;
+          if (bLo >= bHi) { /* equal to the last bit, and more of them than the rounds take */
+            okCut = false;
+            break;
+          }
+          int ns = 0;
+          while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
+            ++ns;
+          }
+          shift = ns;
+          base = (int)(bLo >> ns);
+          waveSync();
         }
-        waveSync();
-        const SlScan ws = slScan(wh, K, false);
-        const int cut = ws.crossed ? ws.bstar : kSlNB - 1;
         int kept = 0;
         for (int c0 = 0; c0 < nCand; c0 += 64) {
           const int id = c0 + lane;
-          const bool valid = id < nCand;
-          const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
-          const bool keep = valid && (int)pbinW[valid ? id : 0] <= cut;
+          const uint32_t c16 = id < nCand ? (uint32_t)candW[id] : 0u;
+          const bool keep = pairKey(id) <= hiCut; /* (0xFFFFFFFF: never) */
           const unsigned long long bal = waveBallot(keep);
           waveSync();
           if (keep) {
@@ -604,9 +647,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           waveSync();
         }
         nCand = kept;
-        if (!(lbk != 0ull) || nCand > R * 64) { /* still too many (ties by the hundred): general path */
+        if (!okCut || nCand > rankAt) { /* ties by the hundred, or no bound to rank against: general path */
           dead = true; YL_WHY(1);
-          nCand = R * 64;
+          nCand = nCand > R * 64 ? R * 64 : nCand;
         }
       }
       if (dead && lane == 0) {
