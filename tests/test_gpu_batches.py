@@ -341,11 +341,12 @@ def _four_lane_group_grid(session, oracle_lib, every, T_of):
             d.set("ylane_rank_at", 8)
         d.decode_batch(inp["e"], [T], c["N"])
         got = d.results(0)
-        served += 1 if (d.get("engine") == 6 and d.get("lane_groups") == 4 and d.get("redone") == 0) else 0
+        srv = d.get("engine") == 6 and d.get("lane_groups") == 4 and d.get("redone") == 0
+        served += 1 if srv else 0
         d.close()
         ok, why = helpers.hyps_equal(want, got)
         ran += 1
-        if not ok:
+        if not ok or not srv:
             bad.append(({k: c[k] for k in ("K", "Kt", "thr", "lm", "lm_weight", "sil_score", "word_score", "T", "dist",
                                            "label_scores")}, why))
     return ran, served, bad
@@ -353,7 +354,7 @@ def _four_lane_group_grid(session, oracle_lib, every, T_of):
 
 def test_edge_configurations_of_the_lexicon_lane_engine_with_four_lane_groups(gpu_session, oracle_lib):
     ran, served, bad = _four_lane_group_grid(gpu_session, oracle_lib, 11, lambda i: [1, 17, 90, 40][i % 4])
-    assert ran > 150 and served == ran and not bad, (ran, served, bad[:3])
+    assert ran > 150 and served == ran and not bad, (ran, served, bad[:8])
 
 
 def test_long_utterance_stays_on_the_lexicon_lane_engine(gpu_session, oracle_lib):

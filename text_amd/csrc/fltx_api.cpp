@@ -1637,7 +1637,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         nTokWaves <= maxTokWaves) {
       /* slots of the memo in HBM: four per LM state the utterance can create, a power of two, 16-bit state numbers */
       uint32_t ms = kYlMemo;
-      while (ms < 65536u && (int64_t)ms * 3 / 4 < (int64_t)maxT * (ng == 4 ? 8 : 4) + 256) {
+      /* (C4 shape: 2.2 new LM states per frame at beam 100, 4 .. 6.5 at beam 256: twice that and more) */
+      while (ms < 65536u && (int64_t)ms * 3 / 4 < (int64_t)maxT * (ng == 4 ? 16 : 5) + 256) {
         ms *= 2;
       }
       d->ymemoSlots = share ? ms : kYlMemo;
@@ -2323,7 +2324,8 @@ int uploadStep(fltx_decoder* d, const float* emissions, int onDevice, const int6
     return fail(FLTX_ERR_INVALID, "emissions is null");
   }
 #ifdef FLTX_EMU
-  const int slot = d->upSlot;
+  const int slot = d->offlineCall ? d->upSlot : d->upSlot ^ 1; /* (streams take turns on the two slots as on the device:
+                                                                   a deferred second pass reads the previous chunk's) */
   Stream cs = st;
 #else
   /* Stream chunks go to the other slot on a copy stream: it waits for what read that slot two steps ago, not for
