@@ -295,7 +295,7 @@ def main():
                    "parallelism": "utterance-sharded x%d, no collective" % world,
                    "threads_per_utterance": st["threads_per_utt"], "lds_bytes_per_workgroup": st["lds_bytes"],
                    "engine": engine, "redone": redone, "lane_groups": dec.get("lane_groups"),
-                   "why_not_lane": dec.get("why_not_lane"),
+                   "why_not_lane": dec.get("why_not_lane"), "fallback_reasons": dec.get("fallback_reasons"),
                    "pipeline": "%d decoder object(s), one HIP stream each, taking turns batch by batch%s" % (
                        len(decs), " (the back-trace of a batch runs under the decode kernel of the next)"
                        if len(decs) > 1 else "")},

@@ -408,6 +408,7 @@ struct fltx_decoder {
   int userYRankAt = 0;       /* tests: DecodeParams::yRankAt */
   int userYlaneGroups = 0;   /* tests: at least this many lane groups on fltx_ylane.h (0 = what the beam needs) */
   uint32_t ymemoSlots = 8192; /* slots per utterance of the LM-state memo in HBM (fltx_ylane.h: follows the frames) */
+  int64_t fallbackReasons = 0; /* bit r: an utterance of the last batch left fltx_ylane.h for reason r (see YL_WHY there) */
   int64_t whyNotLane = 0; /* FLTX_WHY_* bits: the eligibility terms that kept the last call off the lane engines (0 = it ran there) */
   bool preferYlane = false;
   bool genericAsked = false;  /* fltx_decoder_set touched a tunable of the generic engine */
@@ -1244,6 +1245,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->streamRedone;
   } else if (!strcmp(key, "slane")) {
     *value = d->slane;
+  } else if (!strcmp(key, "fallback_reasons")) {
+    *value = d->fallbackReasons;
   } else if (!strcmp(key, "why_not_lane")) { /* FLTX_WHY_* (include/fltx.h): why the last call did not start on a lane engine */
     *value = d->whyNotLane;
   } else if (!strcmp(key, "lane_groups")) { /* lane groups of the lane = LM state engine: 1 = fltx_slane.h, 2 / 4 / 8 = fltx_mlane.h;
@@ -2720,6 +2723,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
    * only when a large part of the batch needed it. */
   std::vector<int32_t> redoList;
   size_t firstRedo = 0;
+  d->fallbackReasons = 0;
   bool recomputeRetry = false; /* this attempt is the recompute form of the cut-off generation */
   bool recomputeTried = false;
   const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
@@ -2784,6 +2788,9 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
       for (int i = 0; i < nScan; ++i) {
         const int b = attempt == 0 ? i : redoList[i];
         const int st = d->hStatus[b];
+        if (attempt == 0 && (st & ST_SELECT_FALLBACK)) {
+          d->fallbackReasons |= 1ll << ((st >> 8) & 31); /* (the lexicon lane engine says why: fltx_ylane.h) */
+        }
         const bool o = (st & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON;
         const bool c = (st & ST_CUT_RETRY) && cutMode;
         const bool l = (st & ST_SELECT_FALLBACK) && d->lean;

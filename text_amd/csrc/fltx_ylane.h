@@ -129,7 +129,7 @@ struct YlaneLdsT {
 };
 using YlaneLds = YlaneLdsT<2>; /* one and two lane groups */
 
-enum { YL_FLAG = 15, YL_NICE = 14 };
+enum { YL_FLAG = 15, YL_NICE = 14, YL_WHYCODE = 13 };
 
 template <typename LDS>
 FLTX_DEV int ylRootFind(LDS& S, unsigned long long key) {
@@ -194,15 +194,27 @@ FLTX_DEV uint32_t ylLmWord(const DecodeParams& P, int usr) {
   return (usr >= 0 && usr < P.nUsr) ? (uint32_t)P.usrToLm[usr] : (uint32_t)P.lmUnk;
 }
 
+/* why an utterance leaves this engine for the general one (fltx_decoder_get "fallback_reasons": bit r set):
+ * 1 = a token wave's pairs tie beyond its rounds / no bound to rank them against, 2 = merge table full, 4 = the frame's
+ * best candidate is not finite, 5 = more exact ties in the K-th best's bin than the pairwise list holds, 6 = LM-state
+ * memo nearly full, 7 = more pairs than a token wave can list (3: another wave gave up -- not recorded) */
 #ifdef FLTX_EMU
 #define YL_WHY(r)                                                                          \
   do {                                                                                     \
+    if ((r) != 3 && lane == 0) {                                                           \
+      atomCas32(&S.scal[YL_WHYCODE], 0u, (uint32_t)(r));                                   \
+    }                                                                                      \
     if (getenv("FLTX_YL_WHY") && lane == 0) {                                              \
       fprintf(stderr, "ylane: utterance %d wave %d gives up, reason %d\n", b, wave, (r)); \
     }                                                                                      \
   } while (0)
 #else
-#define YL_WHY(r) ((void)0)
+#define YL_WHY(r)                                        \
+  do {                                                   \
+    if ((r) != 3 && lane == 0) {                         \
+      atomCas32(&S.scal[YL_WHYCODE], 0u, (uint32_t)(r)); \
+    }                                                    \
+  } while (0)
 #endif
 #define FLTX_YLPROF(i)                                        \
   do {                                                        \
@@ -553,7 +565,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         nCand = PAIRS;
       }
       waveSync();
-      if (nCand > rankAt && !dead) {
+      if (nCand > rankAt && !dead && (lbk != 0ull || nCand > R * 64)) { /* (no bound yet: only when the rounds force it) */
         /* More pairs than the threads' rounds take (the beam fans out at the start of an utterance): none but the K
          * best of this wave's own pairs can be among the frame's K best, so the wave ranks its pairs by itself and
          * goes on with the best R * 64 >= K of them at most.  The order key is the float bit pattern of the distance to
@@ -561,7 +573,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
          * as the bin that holds the K-th best would overfill the rounds, the finest window that spans that bin -- and
          * is a plain threshold on the key, so what is kept is a superset of the wave's K best whatever the ties. */
         uint32_t* wh = S.whist[wave];
-        auto pairKey = [&](int id) -> uint32_t { /* 0xFFFFFFFF: not a candidate */
+        auto pairKey = [&](int id, double& cOut) -> uint32_t { /* 0xFFFFFFFF: not a candidate */
           const bool valid = id < nCand;
           const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
           const int x = (int)(c16 & 0x1FFu), pos = wave * TPW + (int)(c16 >> 9);
@@ -576,6 +588,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             const float dl = valid ? xdelta[child] : 0.0f;
             c = c + lmWeight * (double)dl;
           }
+          cOut = c;
           if (!(valid && c == c)) {
             return 0xFFFFFFFFu;
           }
@@ -587,11 +600,21 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         int shift = kSlCoarseShift, base = kSlCoarseBase, before = 0;
         uint32_t hiCut = 0x7FFFFFFFu;
         bool okCut = lbk != 0ull;
+        /* pairs whose key equals tieVal (a float holds fewer bits than the scores: different scores can share one) are
+         * ranked by the scores themselves when they straddle the cut: their order keys and list indices go to the
+         * wave's count area, tieRoom of them stay */
+        constexpr int kTieCap = 96;
+        unsigned long long* const tieKey = (unsigned long long*)wh;         /* [kTieCap] */
+        uint16_t* const tieId = (uint16_t*)(wh + 2 * kTieCap);             /* [2 * (kSlNB - 2 * kTieCap)] >= kTieCap */
+        static_assert(2 * kTieCap + kTieCap / 2 <= kSlNB, "the tie list fits the wave's count area");
+        uint32_t tieVal = 0xFFFFFFFFu;
+        int tieRoom = 0, nTie = 0;
+        double cTmp = 0.0;
         while (okCut) {
           ((uint4*)wh)[lane] = make_uint4(0u, 0u, 0u, 0u);
           waveSync();
           for (int c0 = 0; c0 < nCand; c0 += 64) {
-            const uint32_t kb = pairKey(c0 + lane);
+            const uint32_t kb = pairKey(c0 + lane, cTmp);
             if (kb != 0xFFFFFFFFu && (unsigned long long)kb >= bLo && (unsigned long long)kb <= bHi) {
               int q = (int)(kb >> shift) - base;
               q = q < 0 ? 0 : (q > kSlNB - 1 ? kSlNB - 1 : q);
@@ -621,8 +644,27 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           before += ws.cum;
           bLo = l2;
           bHi = h2;
-          if (bLo >= bHi) { /* equal to the last bit, and more of them than the rounds take */
-            okCut = false;
+          if (bLo >= bHi) { /* one key value, and more pairs of it than the rounds take */
+            if (ws.cnt > kTieCap) {
+              okCut = false;
+              break;
+            }
+            tieVal = (uint32_t)bLo;
+            tieRoom = rankAt - before;
+            hiCut = tieVal; /* (the members of tieVal among them: decided below) */
+            waveSync();
+            for (int c0 = 0; c0 < nCand; c0 += 64) {
+              const int id = c0 + lane;
+              const bool mem = pairKey(id, cTmp) == tieVal;
+              const unsigned long long bal = waveBallot(mem);
+              if (mem && nTie + wavePrefixCount(bal) < kTieCap) {
+                tieKey[nTie + wavePrefixCount(bal)] = f64Key(cTmp);
+                tieId[nTie + wavePrefixCount(bal)] = (uint16_t)id;
+              }
+              nTie += popc64(bal);
+            }
+            okCut = nTie <= kTieCap;
+            waveSync();
             break;
           }
           int ns = 0;
@@ -637,7 +679,17 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         for (int c0 = 0; c0 < nCand; c0 += 64) {
           const int id = c0 + lane;
           const uint32_t c16 = id < nCand ? (uint32_t)candW[id] : 0u;
-          const bool keep = pairKey(id) <= hiCut; /* (0xFFFFFFFF: never) */
+          const uint32_t kb = pairKey(id, cTmp);
+          bool keep = kb <= hiCut; /* (0xFFFFFFFF: never) */
+          if (kb == tieVal && keep) { /* among equal keys the better scores, then the lower list index */
+            const unsigned long long k = f64Key(cTmp);
+            int rank = 0;
+            for (int i = 0; i < nTie && i < kTieCap; ++i) {
+              const unsigned long long k2 = tieKey[i];
+              rank += (k2 > k || (k2 == k && (int)tieId[i] < id)) ? 1 : 0;
+            }
+            keep = rank < tieRoom;
+          }
           const unsigned long long bal = waveBallot(keep);
           waveSync();
           if (keep) {
@@ -1659,7 +1711,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     P.uttNBeam[b] = 0;
     P.uttFrame[b] = ff;
     P.uttTotal[b] = ff;
-    P.uttStatus[b] = ST_SELECT_FALLBACK;
+    P.uttStatus[b] = ST_SELECT_FALLBACK | (int32_t)((S.scal[YL_WHYCODE] & 31u) << 8);
   }
   if (P.scored && nScored != 0u) {
     atomAdd32(&P.scored[b], nScored);
