@@ -343,12 +343,12 @@ def _four_lane_group_grid(session, oracle_lib, every, T_of):
         got = d.results(0)
         srv = d.get("engine") == 6 and d.get("lane_groups") == 4 and d.get("redone") == 0
         served += 1 if srv else 0
+        reasons = d.get("fallback_reasons")
         d.close()
         ok, why = helpers.hyps_equal(want, got)
         ran += 1
         if not ok or not srv:
-            bad.append(({k: c[k] for k in ("K", "Kt", "thr", "lm", "lm_weight", "sil_score", "word_score", "T", "dist",
-                                           "label_scores")}, why))
+            bad.append((i, why or "left the engine, reasons %#x" % reasons))
     return ran, served, bad
 
 

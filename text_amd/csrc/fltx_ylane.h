@@ -201,19 +201,19 @@ FLTX_DEV uint32_t ylLmWord(const DecodeParams& P, int usr) {
 #ifdef FLTX_EMU
 #define YL_WHY(r)                                                                          \
   do {                                                                                     \
-    if ((r) != 3 && lane == 0) {                                                           \
-      atomCas32(&S.scal[YL_WHYCODE], 0u, (uint32_t)(r));                                   \
+    if ((r) != 3 && deadWhy == 0) {                                                        \
+      deadWhy = (r);                                                                       \
     }                                                                                      \
     if (getenv("FLTX_YL_WHY") && lane == 0) {                                              \
       fprintf(stderr, "ylane: utterance %d wave %d gives up, reason %d\n", b, wave, (r)); \
     }                                                                                      \
   } while (0)
 #else
-#define YL_WHY(r)                                        \
-  do {                                                   \
-    if ((r) != 3 && lane == 0) {                         \
-      atomCas32(&S.scal[YL_WHYCODE], 0u, (uint32_t)(r)); \
-    }                                                    \
+#define YL_WHY(r)                     \
+  do {                                \
+    if ((r) != 3 && deadWhy == 0) {   \
+      deadWhy = (r);                  \
+    }                                 \
   } while (0)
 #endif
 #define FLTX_YLPROF(i)                                        \
@@ -390,6 +390,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
 
   int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
   bool dead = false;
+  int deadWhy = 0; /* this wave's own reason for giving up (YL_WHY), 0 = none / another wave's */
 
   /* RL = role of the wave, compile time as the parity (0 token, 1 own groups, 2 word ends, 3 staging):
    * see fltx_xlane.h */
@@ -1706,12 +1707,18 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     fprintf(stderr, "ylane: utterance %d ends dead=%d with %u LM states\n", b, (int)dead, S.lmNext);
   }
 #endif
-  if (dead && tid == 0) {
-    P.outN[b] = 0;
-    P.uttNBeam[b] = 0;
-    P.uttFrame[b] = ff;
-    P.uttTotal[b] = ff;
-    P.uttStatus[b] = ST_SELECT_FALLBACK | (int32_t)((S.scal[YL_WHYCODE] & 31u) << 8);
+  if (dead) { /* (uniform: every way out of the frame loop passes a barrier that spreads it) */
+    if (deadWhy != 0 && lane == 0) {
+      atomCas32(&S.scal[YL_WHYCODE], 0u, (uint32_t)deadWhy);
+    }
+    ldsBarrier();
+    if (tid == 0) {
+      P.outN[b] = 0;
+      P.uttNBeam[b] = 0;
+      P.uttFrame[b] = ff;
+      P.uttTotal[b] = ff;
+      P.uttStatus[b] = ST_SELECT_FALLBACK | (int32_t)((S.scal[YL_WHYCODE] & 31u) << 8);
+    }
   }
   if (P.scored && nScored != 0u) {
     atomAdd32(&P.scored[b], nScored);
