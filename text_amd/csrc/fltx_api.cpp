@@ -1640,8 +1640,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         nTokWaves <= maxTokWaves) {
       /* slots of the memo in HBM: four per LM state the utterance can create, a power of two, 16-bit state numbers */
       uint32_t ms = kYlMemo;
-      /* (C4 shape: 2.2 new LM states per frame at beam 100, 4 .. 6.5 at beam 256: twice that and more) */
-      while (ms < 65536u && (int64_t)ms * 3 / 4 < (int64_t)maxT * (ng == 4 ? 16 : 5) + 256) {
+      /* (C4 shape: 2.2 new LM states per frame at beam 100, 4 .. 6.5 at beam 256; a memo no bigger than it has to be
+       * stays in the L2: 8 192 slots unless the utterance is long or the beam needs four groups) */
+      while ((longUtt || ng == 4) && ms < 65536u && (int64_t)ms * 3 / 4 < (int64_t)maxT * (ng == 4 ? 8 : 5) + 256) {
         ms *= 2;
       }
       d->ymemoSlots = share ? ms : kYlMemo;

@@ -566,7 +566,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         nCand = PAIRS;
       }
       waveSync();
-      if (nCand > rankAt && !dead && (lbk != 0ull || nCand > R * 64)) { /* (no bound yet: only when the rounds force it) */
+      if (nCand > rankAt && !dead) {
         /* More pairs than the threads' rounds take (the beam fans out at the start of an utterance): none but the K
          * best of this wave's own pairs can be among the frame's K best, so the wave ranks its pairs by itself and
          * goes on with the best R * 64 >= K of them at most.  The order key is the float bit pattern of the distance to
@@ -574,6 +574,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
          * as the bin that holds the K-th best would overfill the rounds, the finest window that spans that bin -- and
          * is a plain threshold on the key, so what is kept is a superset of the wave's K best whatever the ties. */
         uint32_t* wh = S.whist[wave];
+        double rankRef = lbBest; /* the distance is taken to lb, or -- no lane survived the last frame -- to the wave's best pair */
         auto pairKey = [&](int id, double& cOut) -> uint32_t { /* 0xFFFFFFFF: not a candidate */
           const bool valid = id < nCand;
           const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
@@ -593,14 +594,14 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           if (!(valid && c == c)) {
             return 0xFFFFFFFFu;
           }
-          float dd = (float)(lbBest - c);
+          float dd = (float)(rankRef - c);
           dd = dd > 0.0f ? dd : 0.0f;
           return __float_as_uint(dd);
         };
         unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
         int shift = kSlCoarseShift, base = kSlCoarseBase, before = 0;
         uint32_t hiCut = 0x7FFFFFFFu;
-        bool okCut = lbk != 0ull;
+        bool okCut = true;
         /* pairs whose key equals tieVal (a float holds fewer bits than the scores: different scores can share one) are
          * ranked by the scores themselves when they straddle the cut: their order keys and list indices go to the
          * wave's count area, tieRoom of them stay */
@@ -611,6 +612,16 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         uint32_t tieVal = 0xFFFFFFFFu;
         int tieRoom = 0, nTie = 0;
         double cTmp = 0.0;
+        if (lbk == 0ull) {
+          unsigned long long mk = 0ull;
+          for (int c0 = 0; c0 < nCand; c0 += 64) {
+            const unsigned long long k1 = pairKey(c0 + lane, cTmp) != 0xFFFFFFFFu ? f64Key(cTmp) : 0ull;
+            mk = k1 > mk ? k1 : mk;
+          }
+          mk = waveMax64(mk);
+          okCut = mk != 0ull;
+          rankRef = okCut ? f64FromKey(mk) : 0.0;
+        }
         while (okCut) {
           ((uint4*)wh)[lane] = make_uint4(0u, 0u, 0u, 0u);
           waveSync();
@@ -700,7 +711,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           waveSync();
         }
         nCand = kept;
-        if (!okCut || nCand > rankAt) { /* ties by the hundred, or no bound to rank against: general path */
+        if (!okCut || nCand > rankAt) { /* ties by the hundred: general path */
           dead = true; YL_WHY(1);
           nCand = nCand > R * 64 ? R * 64 : nCand;
         }
