@@ -70,8 +70,10 @@ FLTX_DEV int2 mlNewRec(uint32_t hp, uint32_t parSid, int n) {
 
 /* Re-entry of LM states that had dropped out of the beam: fltx_slane.h's slReenter over the wider records.
  * All waves; rare. */
+/* (inlined: the kernels with many candidates per lane spill registers, and a call from there would need a stack
+ * frame beyond the spill area) */
 template <typename LDS>
-FLTX_DEV __attribute__((noinline)) void mlReenter(LDS& S, const int2* histPT, int q, int nState, int64_t hbase,
+FLTX_DEV void mlReenter(LDS& S, const int2* histPT, int q, int nState, int64_t hbase,
                                                    int64_t nRec) {
   const int tid = (int)threadIdx.x, W = (int)blockDim.x;
   const int nev = (int)S.row[q].nev;
