@@ -570,11 +570,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         /* More pairs than the threads' rounds take (the beam fans out at the start of an utterance): none but the K
          * best of this wave's own pairs can be among the frame's K best, so the wave ranks its pairs by itself and
          * goes on with the best R * 64 >= K of them at most.  The order key is the float bit pattern of the distance to
-         * lb (monotone in the score); the cut is found by counting per bin -- the coarse window first, then, as long
+         * the wave's best pair (monotone in the score); the cut is found by counting per bin -- the coarse window first, then, as long
          * as the bin that holds the K-th best would overfill the rounds, the finest window that spans that bin -- and
          * is a plain threshold on the key, so what is kept is a superset of the wave's K best whatever the ties. */
         uint32_t* wh = S.whist[wave];
-        double rankRef = lbBest; /* the distance is taken to lb, or -- no lane survived the last frame -- to the wave's best pair */
+        double rankRef = 0.0; /* the distance is taken to the wave's best pair */
         auto pairKey = [&](int id, double& cOut) -> uint32_t { /* 0xFFFFFFFF: not a candidate */
           const bool valid = id < nCand;
           const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
@@ -612,7 +612,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         uint32_t tieVal = 0xFFFFFFFFu;
         int tieRoom = 0, nTie = 0;
         double cTmp = 0.0;
-        if (lbk == 0ull) {
+        { /* (lb would do as long as no pair beats it; pairs above it would all share key 0) */
           unsigned long long mk = 0ull;
           for (int c0 = 0; c0 < nCand; c0 += 64) {
             const unsigned long long k1 = pairKey(c0 + lane, cTmp) != 0xFFFFFFFFu ? f64Key(cTmp) : 0ull;
