@@ -278,3 +278,18 @@ def test_emulated_four_lane_groups(emu_session, oracle_lib):
     import test_gpu_batches
     ran, served, bad = test_gpu_batches._four_lane_group_grid(emu_session, oracle_lib, 173, lambda i: [2, 17, 9][i % 3])
     assert ran >= 10 and served == ran and not bad, (ran, served, bad[:3])
+
+
+def test_emulated_asg_on_the_lexicon_lane_engine(emu_session, oracle_lib, golden):
+    """ASG on fltx_ylane.h: the golden case, then a thin slice of the GPU suite's grid."""
+    import test_gpu_batches
+    c = cases.BY_NAME["lx_asg_t40"]
+    inp = helpers.case_inputs(c)
+    d = emu_session.decoder(c, inp)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    assert d.get("engine") == 6 and d.get("redone") == 0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
+    d.close()
+    assert ok, why
+    ran, served, bad = test_gpu_batches._asg_lexicon_grid(emu_session, oracle_lib, 211, lambda i: [2, 17, 9][i % 3])
+    assert ran >= 10 and served == ran and not bad, (ran, served, bad[:3])

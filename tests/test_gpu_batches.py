@@ -371,3 +371,45 @@ def test_long_utterance_stays_on_the_lexicon_lane_engine(gpu_session, oracle_lib
     want = helpers.run_checker(oracle_lib, c, inp)
     ok, why = helpers.hyps_equal(want, got)
     assert ok, why
+
+
+def _asg_lexicon_grid(session, oracle_lib, every, T_of):
+    """LexiconDecoder with the ASG criterion on fltx_ylane.h (no blank; transitions enter score and emitting-model
+    score from the second frame on, LexiconDecoder.cpp:69-72,172-175): beams over one, two and four lane groups,
+    ZeroLM / label scores / n-gram LMs, thresholds, token beams, silScore, a lexicon without doubled letters (what
+    replabels guarantee: helpers.lexicon), against the oracle."""
+    import itertools
+    bad, ran, served = [], 0, 0
+    grid = itertools.product([1, 3, 10, 64, 70, 128, 150, 256], [0.0, 2.0, 25.0, float("inf")], [None, 5, 10],
+                             ["zero", ("ngram", 3, 91), ("ngram", 4, 92), "scores"], [0.0, -0.6, 0.4], [0.7, -1.0],
+                             [0, 1], ["lexspell", "uniform"])
+    for i, (K, thr, Kt, lm, sil, ws, share, dist) in enumerate(grid):
+        if i % every:
+            continue
+        T = T_of(i)
+        plain = lm in ("scores", "zero")
+        c = cases.case("yasg%d" % i, kind="lexicon", dist=dist, u=2500 + i, T=T, K=K, Kt=Kt, thr=thr, sil_score=sil,
+                       word_score=ws, lm_weight=0.0 if lm == "zero" else 1.3, lexicon=cases.NODUP_LEX, crit="asg",
+                       trans_seed=70 + i, lm="zero" if plain else lm, label_scores=(50 + i % 7) if lm == "scores" else None)
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue
+        d = session.decoder(c, inp)
+        d.set("yshare", share if K <= 128 else -1)
+        d.decode_batch(inp["e"], [T], c["N"])
+        got = d.results(0)
+        srv = d.get("engine") == 6 and d.get("redone") == 0
+        reasons = d.get("fallback_reasons")
+        d.close()
+        served += 1 if srv else 0
+        ok, why = helpers.hyps_equal(want, got)
+        ran += 1
+        if not ok or not srv:
+            bad.append((i, why or "left the engine, reasons %#x" % reasons))
+    return ran, served, bad
+
+
+def test_asg_on_the_lexicon_lane_engine(gpu_session, oracle_lib):
+    ran, served, bad = _asg_lexicon_grid(gpu_session, oracle_lib, 7, lambda i: [1, 17, 90, 40][i % 4])
+    assert ran > 300 and served == ran and not bad, (ran, served, bad[:8])

@@ -372,6 +372,7 @@ struct fltx_decoder {
   const fltx_lm* lm = nullptr;
   int sil = 0, blank = 0, unk = 0, isLmToken = 0;
   int nTrans = 0;
+  double transMax = 0.0; /* largest transition score, at least 0 */
   DBuf transitions;
   /* tunables */
   int threads = 0; /* 0 = pick per configuration (prepare()) */
@@ -405,6 +406,7 @@ struct fltx_decoder {
   /* ... with several lane groups (fltx_mlane.h, beams beyond 64): lane groups (0 / 1 = fltx_slane.h), groups per token
    * wave, groups per self wave; userLaneGroups: tuning / tests, 0 = as many as the beam needs, -1 = never */
   int mlaneNG = 0, mlaneGPW = 0, mlaneSPW = 0, userLaneGroups = 0, userMlaneGeo = -1;
+  int noYlaneAsg = 0;        /* tests: ASG lexicon decodes stay on the generic engine */
   int userYRankAt = 0;       /* tests: DecodeParams::yRankAt */
   int userYlaneGroups = 0;   /* tests: at least this many lane groups on fltx_ylane.h (0 = what the beam needs) */
   uint32_t ymemoSlots = 8192; /* slots per utterance of the LM-state memo in HBM (fltx_ylane.h: follows the frames) */
@@ -1189,6 +1191,10 @@ int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, co
   d->isLmToken = isLmToken ? 1 : 0;
   if (transitions && nTrans > 0) {
     d->nTrans = nTrans;
+    d->transMax = 0.0;
+    for (int i = 0; i < nTrans; ++i) {
+      d->transMax = std::max(d->transMax, (double)transitions[i]);
+    }
     if (d->transitions.ensure(sizeof(float) * (size_t)nTrans, ctx->stream, false) ||
         devCopyH2D(d->transitions.p, transitions, sizeof(float) * (size_t)nTrans, ctx->stream) ||
         devSync(ctx->stream)) {
@@ -1381,6 +1387,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "slane")) { /* 0: do not use the lane = LM state kernel (fltx_slane.h) */
     d->noSlane = value ? 0 : 1;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "ylane_asg")) { /* 0: the ASG criterion keeps the lexicon decoder on the generic engine */
+    d->noYlaneAsg = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "ylane_rank_at")) { /* tests: see DecodeParams::yRankAt */
@@ -1617,9 +1627,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (d->kind == FLTX_DECODER_LEXICON && !d->noYlane && !d->genericAsked && (!d->xlane || d->preferYlane) &&
       d->offlineCall && !d->keepScores && !d->opt.log_add && !forceWorstCaseCap && !d->forceGlobalWs &&
       (d->lm->kind == 0 || d->lm->kind == 1) && !d->isLmToken && d->trie && d->trie->xOk &&
-      d->trie->xEndTok == d->sil && d->sil != d->blank && d->opt.criterion == FLTX_CRITERION_CTC &&
+      d->trie->xEndTok == d->sil &&
+      (d->opt.criterion == FLTX_CRITERION_CTC ? (d->sil != d->blank && d->blank >= 0 && d->blank < N)
+                                               : (d->nTrans == N * N && !d->noYlaneAsg)) &&
       !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) && K <= 256 && N <= 64 &&
-      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N && d->blank >= 0 && d->blank < N) {
+      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N) {
     const int ng = std::max(K <= 64 ? 1 : (K <= 128 ? 2 : 4), d->userYlaneGroups);
     /* More utterances than CUs: the geometry of which two workgroups fit a CU (512 threads, <= 128
      * VGPRs, 77 KB of LDS: the LM-state memo moves to HBM) -- one utterance's waits are the other's
@@ -1650,7 +1662,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       d->ylane = ng;
       d->ylaneRounds = ng == 1 ? 2 : 4;
       d->ylaneTpw = tpw;
-      d->ylaneLm = (d->lm->kind != 0 || !d->trie->xZeroSmear) ? 1 : 0;
+      d->ylaneLm = ((d->lm->kind != 0 || !d->trie->xZeroSmear) ? 1 : 0) | (d->opt.criterion == FLTX_CRITERION_CTC ? 0 : 2);
       d->threads = threads;
       d->xlane = 0;
       if (d->lm->kind == 1 && (d->xlmwordTrie != d->trie || d->xlmwordLm != d->lm)) {
@@ -1680,7 +1692,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
       why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
       why |= (lexi && d->opt.log_add) ? FLTX_WHY_LOGADD : 0;
-      why |= (lexi && d->opt.criterion != FLTX_CRITERION_CTC) ? FLTX_WHY_ASG : 0;
+      why |= (lexi && d->opt.criterion != FLTX_CRITERION_CTC && d->noYlaneAsg) ? FLTX_WHY_ASG : 0;
       why |= (lexi && unkOn) ? FLTX_WHY_UNK : 0;
       why |= (lexi && d->trie && !d->trie->xOk) ? FLTX_WHY_TRIE_SHAPE : 0;
       why |= (lexi && d->trie && d->trie->xOk && (d->trie->xEndTok != d->sil || d->sil == d->blank)) ? FLTX_WHY_WORD_END : 0;
@@ -2062,6 +2074,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;
+  P.yTransMax = d->transMax;
   P.scored = (d->lm->kind == 1 && d->scored.p) ? d->scored.as<uint32_t>() : nullptr;
   P.profThread = 64 * d->profWave;
   if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {
@@ -2183,6 +2196,13 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
                          d->wsBytes, d->ctx->stream, P);                                                \
     }                                                                                                   \
   } while (0)
+#define FLTX_LAUNCH_YLANE_NP(WW, NG, RR, LMK, HM) /* (no profiling variant) */                         \
+  do {                                                                                                  \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<WW, NG, RR, LMK, HM, false>,       \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));           \
+    hipLaunchKernelGGL((fltx_decode_kernel_ylane<WW, NG, RR, LMK, HM, false>), dim3(nGrid), dim3(WW),   \
+                       d->wsBytes, d->ctx->stream, P);                                                  \
+  } while (0)
 #define FLTX_LAUNCH_YLANE4(LMK)                                                                        \
   do {                                                                                                  \
     HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_ylane<1024, 4, 4, LMK, 1, false>,        \
@@ -2201,10 +2221,21 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       case 121: FLTX_LAUNCH_YLANE(512, 2, 4, 1, 1); break;
       case 140: FLTX_LAUNCH_YLANE4(0); break;
       case 141: FLTX_LAUNCH_YLANE4(1); break;
+      case 12: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 2, 0); break; /* ASG (LMK bit 1) */
+      case 13: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 3, 0); break;
+      case 22: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 2, 0); break;
+      case 23: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 3, 0); break;
+      case 112: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 2, 1); break;
+      case 113: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 3, 1); break;
+      case 122: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 2, 1); break;
+      case 123: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 3, 1); break;
+      case 142: FLTX_LAUNCH_YLANE4(2); break;
+      case 143: FLTX_LAUNCH_YLANE4(3); break;
       default: return fail(FLTX_ERR_INVALID, "no fltx_ylane.h kernel for %d lane groups", d->ylane);
     }
 #undef FLTX_LAUNCH_YLANE
 #undef FLTX_LAUNCH_YLANE4
+#undef FLTX_LAUNCH_YLANE_NP
   } else if (d->xlane) {
 #define FLTX_LAUNCH_XLANE(WW, GG)                                                                \
   do {                                                                                           \

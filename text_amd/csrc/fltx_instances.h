@@ -81,7 +81,19 @@
  * word wave and the staging wave; LM-state memo in HBM */
 #define FLTX_G20(W)                                           \
   FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 0, 1, false>) \
-  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 1, 1, false>)
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 1, 1, false>) \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 2, 1, false>) \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 3, 1, false>)
+/* ASG criterion (LMK bit 1): the geometries of FLTX_YLANE_SET */
+#define FLTX_G21(W)                                           \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 2, 0, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 3, 0, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 2, 0, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 3, 0, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 2, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 3, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 2, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 3, 1, false>)
 #define FLTX_G14(W) FLTX_YLANE_SET(true)
 
 #ifdef FLTX_INST_W
@@ -108,6 +120,7 @@ FLTX_G17(0)
 FLTX_G18(0)
 FLTX_G19(0)
 FLTX_G20(0)
+FLTX_G21(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -130,6 +143,7 @@ FLTX_G20(0)
 #undef FLTX_G18
 #undef FLTX_G19
 #undef FLTX_G20
+#undef FLTX_G21
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET

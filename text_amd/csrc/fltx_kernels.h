@@ -194,6 +194,7 @@ struct DecodeParams {
   int32_t* statusHost;          /* optimistic stream chunks: uttStatus mirrored in pinned host memory (read after the kernel, no copy) */
   const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */
   double yBound;                /* ... and the largest lmWeight x smearing difference of the lexicon (>= 0) */
+  double yTransMax;             /* ASG: the largest transition score, at least 0 (upper bound of what a pair can gain) */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
   int32_t profThread; /* the thread whose clock is sampled (lane 0 of the wave under study) */

@@ -231,6 +231,10 @@ FLTX_DEV uint32_t ylLmWord(const DecodeParams& P, int usr) {
  * pairs each (512 threads: two workgroups share a CU) */
 template <int NG, int R, int LMK, int HM, bool PROF>
 FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
+  /* LMK: bit 0 = the LM terms (smeared trie and / or n-gram LM), bit 1 = ASG criterion (no blank; transitions[n * N + previous
+   * token] enters the emitting-model score from the second frame on, LexiconDecoder.cpp:69-72,172-175) */
+  constexpr int LMT = LMK & 1;
+  constexpr bool ASG = (LMK & 2) != 0;
   constexpr int LG = NG > 2 ? NG : 2;
   using LDS = YlaneLdsT<LG>;
   LDS& S = *(LDS*)smem;
@@ -270,7 +274,16 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   const int endTok = P.xEndTok;
   const double silScore = P.silScore, wordScore = P.wordScore, beamThreshold = P.beamThreshold;
   const double lmWeight = P.lmWeight;
-  const bool ngram = LMK != 0 && P.lmKind != 0;
+  const bool ngram = LMT != 0 && P.lmKind != 0;
+  const float* const trans = P.transitions;
+  /* emitting-model score of token n after a hypothesis whose token is `prev` (the reference adds the two floats as
+   * doubles before the hypothesis' score) */
+  auto emScore = [&](double e, int n, int prev, int t) {
+    if (ASG && t > 0) {
+      e = e + (double)trans[n * N + prev];
+    }
+    return e;
+  };
   /* pairs beyond which a token wave ranks its own (tests lower it, never below the beam: the wave's K best must fit) */
   const int rankAt = (P.yRankAt > 0 && P.yRankAt < R * 64) ? (P.yRankAt > K ? P.yRankAt : K) : R * 64;
   int2* const histPT = P.histPT;
@@ -507,7 +520,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         cnode[g] = child;
         cpl[g] = L.lmSid[x];
         cpn[g] = L.node[x];
-        if (LMK) {
+        if (LMT) {
           const float dl = go ? xdelta[child] : 0.0f;
           cdl[g] = dl;
           cL = cL + lmWeight * (double)dl;
@@ -527,7 +540,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         const int x = g * 64 + lane;
         const bool lv = ((aliveG[g] >> lane) & 1ull) != 0ull;
         const unsigned long long own = 1ull << (L.info[x] & 63u);
-        ext[g] = lv ? (L.childMask[x] & L.kidsMask[x] & ~S.cmask[p][x] & ~own) : 0ull;
+        ext[g] = lv ? (L.childMask[x] & L.kidsMask[x] & ~S.cmask[p][x] & (ASG ? ~0ull : ~own)) : 0ull;
         const double xnb = L.nb[x], xb = L.b[x];
         mg[g] = xb > xnb ? xb : xnb;
       }
@@ -537,7 +550,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const unsigned long long lbk = S.lb[p];
       const double lbBest = lbk != 0ull ? f64FromKey(lbk) : NEG;
       const double thrLB = lbBest - beamThreshold;
-      const double bterm = LMK ? P.yBound : 0.0;
+      const double bterm = (LMT ? P.yBound : 0.0) + (ASG ? P.yTransMax : 0.0);
       for (int j = 0; j < TPW; ++j) {
         const int pos = wave * TPW + j;
         const unsigned long long tbj = S.tokBit[p][pos];
@@ -581,11 +594,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           const int x = (int)(c16 & 0x1FFu), pos = wave * TPW + (int)(c16 >> 9);
           const double xnb = L.nb[x], xb = L.b[x];
           const int n = (int)S.tokId[p][pos];
-          double c = (xb > xnb ? xb : xnb) + S.eTok[p][pos];
+          double c = (xb > xnb ? xb : xnb) + emScore(S.eTok[p][pos], n, (int)(L.info[x] & 63u), t);
           if (pos == silPos) {
             c = c + silScore;
           }
-          if (LMK) {
+          if (LMT) {
             const uint32_t child = L.firstChild[x] + (uint32_t)popc64(L.childMask[x] & ((1ull << n) - 1ull));
             const float dl = valid ? xdelta[child] : 0.0f;
             c = c + lmWeight * (double)dl;
@@ -732,7 +745,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           const double ev = S.eTok[p][pos];
           const int n = (int)S.tokId[p][pos];
           const bool wb = xb > xnb;
-          double c = (wb ? xb : xnb) + ev;
+          double c = (wb ? xb : xnb) + emScore(ev, n, infoTok(xi), t);
           if (pos == silPos) {
             c = c + silScore;
           }
@@ -742,7 +755,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           cnode[r] = child;
           cpl[r] = L.lmSid[x];
           cpn[r] = L.node[x];
-          if (LMK) {
+          if (LMT) {
             const float dl = valid ? xdelta[child] : 0.0f;
             cdl[r] = dl;
             c = c + lmWeight * (double)dl; /* lmScore = lex->maxScore - lexMaxScore, LexiconDecoder.cpp:96,101 */
@@ -774,7 +787,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const double parNB = L.nb[pi], parB = L.b[pi];
       const uint32_t parInfo = L.info[pi];
       double lmNBv = 0.0, lmBv = 0.0, parLmNB = 0.0, parLmB = 0.0, dl = 0.0;
-      if (LMK) {
+      if (LMT) {
         lmNBv = L.lmNB[li];
         lmBv = L.lmB[li];
         parLmNB = L.lmNB[pi];
@@ -783,11 +796,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       }
       lmM = whichB ? lmBv : lmNBv;
       lmOwnNB = lmNBv;
-      const double eBlank = S.eAll[p][blank], eLast = S.eAll[p][last], eSil = S.eAll[p][sil];
+      const double eBlank = S.eAll[p][ASG ? 0 : blank], eLast = S.eAll[p][last], eSil = S.eAll[p][sil];
       /* blank (:197-213): always tried */
       cs[0] = m + eBlank;
       clm[0] = lmM;
-      cok[0] = live;
+      cok[0] = live && !ASG;
       /* stay (:168-194) + the trie parent's extension by the node's token (a "(1) try children"
        * candidate: needs the token in the token beam, carries the smearing difference) */
       const int lastP = infoTok(parInfo);
@@ -795,18 +808,18 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const bool allowLast = ((allow >> last) & 1ull) != 0ull;
       const bool hasNB = hypNB != kNoHyp;
       const bool has0 = atRoot ? true : hasNB;
-      const bool has1 = pl >= 0 && allowLast && last != lastP && h1 != kNoHyp;
+      const bool has1 = pl >= 0 && allowLast && (ASG || last != lastP) && h1 != kNoHyp;
       const bool has2 = pl >= 0 && allowLast && h2 != kNoHyp;
-      double r0 = (atRoot ? m : nb) + (atRoot ? eSil : eLast);
-      double r1 = has1 ? parNB + eLast : NEG;
-      double r2 = has2 ? parB + eLast : NEG;
+      double r0 = (atRoot ? m : nb) + emScore(atRoot ? eSil : eLast, atRoot ? sil : last, last, t);
+      double r1 = has1 ? parNB + emScore(eLast, last, lastP, t) : NEG;
+      double r2 = has2 ? parB + eLast : NEG; /* (from the blank hypothesis: CTC only) */
       if (silScore != 0.0) {
         const bool ls = atRoot || last == sil;
         r0 = ls ? r0 + silScore : r0;
         r1 = ls ? r1 + silScore : r1;
         r2 = ls ? r2 + silScore : r2;
       }
-      if (LMK) {
+      if (LMT) {
         r1 = r1 + lmWeight * dl;
         r2 = r2 + lmWeight * dl;
       }
@@ -889,13 +902,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         /* a word ends (:113-142); on the root the nb hypothesis would repeat its token (:114-122) */
         const bool useB = xRoot && xl == endTok;
         const bool can = lv && el >= 0 && ((allow >> endTok) & 1ull) != 0ull && (useB ? xhB != kNoHyp : true);
-        double c = (useB ? xb : xm) + eEnd;
+        double c = (useB ? xb : xm) + emScore(eEnd, endTok, xl, t);
         if (endTok == sil) {
           c = c + silScore;
         }
         float lmS = 0.0f;
         double srcLm = 0.0;
-        if (LMK) {
+        if (LMT) {
           float sc = 0.0f;
           if (ngram && can) {
             sc = __uint_as_float(L.endLm[x]);
@@ -1530,7 +1543,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           histPT[hrow + hB + hb] = make_int2((int)hypM, blank);
           histW[hrow + hB + hb] = -1;
         }
-        if (LMK) {
+        if (LMT) {
           L.lmNB[li] = lmStay;
           L.lmB[li] = lmM;
         }
@@ -1541,10 +1554,10 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
           const double nnb = sR ? cs[1] : NEG, nbb = sB ? cs[0] : NEG;
           const double nm = nbb > nnb ? nbb : nnb;
-          const double c0 = nm + S.eAll[q][blank];
-          k = c0 == c0 ? f64Key(c0) : 0ull;
+          const double c0 = ASG ? NEG : nm + S.eAll[q][ASG ? 0 : blank];
+          k = (c0 == c0 && !ASG) ? f64Key(c0) : 0ull;
           if (atRoot || sR) {
-            double c1 = (atRoot ? nm : nnb) + S.eAll[q][atRoot ? sil : last];
+            double c1 = (atRoot ? nm : nnb) + emScore(S.eAll[q][atRoot ? sil : last], atRoot ? sil : last, last, t + 1);
             if (atRoot || last == sil) {
               c1 = c1 + silScore;
             }
@@ -1652,7 +1665,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const bool wb = xb > xnb;
       mE = wb ? xb : xnb;
       hpE = wb ? infoB(xi) : infoNB(xi);
-      lmE = LMK ? (wb ? L.lmB[x] : L.lmNB[x]) : 0.0;
+      lmE = LMT ? (wb ? L.lmB[x] : L.lmNB[x]) : 0.0;
       lmSidE = L.lmSid[x];
       onRoot = L.node[x] == 0u;
       if (liveE && onRoot) {
