@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=-1, help="override the device (default: LOCAL_RANK)")
     ap.add_argument("--set", action="append", default=[], help="decoder tunable key=value (repeatable)")
+    ap.add_argument("--asg", action="store_true", help="ASG criterion (no blank, synthetic transitions; the lexicon without "
+                                                        "doubled letters, as replabels guarantee) -- a secondary line")
+    ap.add_argument("--log-add", action="store_true", help="logAdd merges -- a secondary line")
     return ap.parse_args()
 
 
@@ -115,6 +118,23 @@ def self_launch(a):
     print(line[-1])
 
 
+TOL = [0.0]  # 1e-5 with --log-add (device libm: BASELINE.json's float-score tolerance), else bit equality
+
+
+def nbest_same(got, want):
+    if len(got) != len(want):
+        return False
+    for g, h in zip(got, want):
+        if TOL[0] == 0.0:
+            if not (g.score == h.score and g.am == h.am):
+                return False
+        elif abs(g.score - h.score) > TOL[0] or abs(g.am - h.am) > TOL[0]:
+            return False
+        if not (np.array_equal(g.tokens, h.tokens) and np.array_equal(g.words, h.words)):
+            return False
+    return True
+
+
 class Job:
     """Everything one rank needs to decode its shard: synthetic inputs, LM, trie, decoder."""
 
@@ -127,17 +147,27 @@ class Job:
         self.lex, self.haslm = cfg["lex"], cfg["lm"]
         N = self.N
         self.lexicon = synth.lexicon() if self.lex else None
+        self.crit = "asg" if a.asg else "ctc"
+        self.blank = -1 if a.asg else N - 1
+        self.tr = synth.floats(4243, N * N, 0.0, 1.0) if a.asg else None
+        if self.lex and a.asg:  # (a doubled letter makes "stay" and "advance" tie exactly: tests/helpers.py lexicon())
+            sf, so = self.lexicon
+            keep = [w for w in range(len(so) - 1) if not np.any(sf[so[w]:so[w + 1] - 1][1:] == sf[so[w]:so[w + 1] - 1][:-1])]
+            nsf = np.concatenate([sf[so[w]:so[w + 1]] for w in keep]).astype(np.int32)
+            nso = np.zeros(len(keep) + 1, dtype=np.int64)
+            nso[1:] = np.cumsum([so[w + 1] - so[w] for w in keep])
+            self.lexicon = (nsf, nso)
         self.dist = "lexspell" if self.lex else "ctc"
         self.u0 = rank * B
         self.e_host = synth.batch(self.dist, B, self.T, N, lexicon=self.lexicon, u0=self.u0)
         self.ctx = _capi.Context(device=local)
         self.ctx_device, self.more_ctx, self.more_tries = local, [], []
         self.lm = _capi.ZeroLM(self.ctx)
-        self.opt = _capi.make_options(self.K, self.Kt, 25.0)
+        self.opt = _capi.make_options(self.K, self.Kt, 25.0, 0.0, 0.0, float("-inf"), 0.0, bool(a.log_add), self.crit)
         self.arpa = None
         if self.haslm:
             # same options as the parity case C4_spell_u0 (tests/cases.py)
-            self.opt = _capi.make_options(self.K, self.Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, False, "ctc")
+            self.opt = _capi.make_options(self.K, self.Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, bool(a.log_add), self.crit)
             self.arpa = synthetic_arpa(len(self.lexicon[1]) - 1)
             self.lm = _capi.ArpaLM(self.arpa[0], self.arpa[1])
         self.trie = self.host_trie = self.wscore = None
@@ -166,9 +196,9 @@ class Job:
                 trie = self.host_trie.upload(ctx)
                 self.more_tries.append(trie)
         if self.lex:
-            d = c.BatchDecoder(ctx, c.LEXICON, self.opt, self.lm, 0, self.N - 1, unk=self.W, trie=trie)
+            d = c.BatchDecoder(ctx, c.LEXICON, self.opt, self.lm, 0, self.blank, unk=self.W, trie=trie, transitions=self.tr)
         else:
-            d = c.BatchDecoder(ctx, c.LEXFREE, self.opt, self.lm, 0, self.N - 1)
+            d = c.BatchDecoder(ctx, c.LEXFREE, self.opt, self.lm, 0, self.blank, transitions=self.tr)
         if self.a.threads:
             d.set("threads", self.a.threads)
         for kv in self.a.set:
@@ -179,6 +209,7 @@ class Job:
 
 def main():
     a = parse()
+    TOL[0] = 1e-5 if a.log_add else 0.0
     if a.mode == "group":
         return group_mode(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -437,9 +468,7 @@ def group_mode(a):
                 want = cpu.lib.decode(d, e_hosts[i][b - i * B], T, N)
                 cpu.free(d, lm)
                 got = grp.results(b)
-                same = len(got) == len(want) and all(
-                    g.score == h.score and g.am == h.am and np.array_equal(g.tokens, h.tokens) and
-                    np.array_equal(g.words, h.words) for g, h in zip(got, want))
+                same = nbest_same(got, want)
                 mism += 0 if same else 1
                 chk += 1
         out["cpu_baseline"] = {"kind": cpu.kind, "gpu_nbest_mismatches_on_sample": mism, "utterances_checked": chk}
@@ -528,9 +557,9 @@ class CpuSide:
         self.kind = "reference" if orclib.have_ref() else "port"
         self.lib = lib = orclib.load("ref" if self.kind == "reference" else "oracle")
         self.job = job
-        self.opt = orclib.make_options(job.K, job.Kt, 25.0)
+        self.opt = orclib.make_options(job.K, job.Kt, 25.0, 0.0, 0.0, float("-inf"), 0.0, bool(job.a.log_add), job.crit)
         if job.arpa:
-            self.opt = orclib.make_options(job.K, job.Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, False, "ctc")
+            self.opt = orclib.make_options(job.K, job.Kt, 25.0, 2.0, 2.0, float("-inf"), -1.0, bool(job.a.log_add), job.crit)
         self.trie = None
         if job.lexicon is not None:
             self.trie = lib.build_trie(job.N, 0, job.lexicon[0], job.lexicon[1], np.arange(job.W), job.wscore, 1)
@@ -540,8 +569,8 @@ class CpuSide:
     def new_decoder(self):
         lib, job = self.lib, self.job
         lm = self.lm_shared if self.lm_shared else lib.lm_zero_create()
-        d = lib.lexicon(self.opt, self.trie, lm, 0, job.N - 1, job.W) if self.trie \
-            else lib.lexfree(self.opt, lm, 0, job.N - 1)
+        d = lib.lexicon(self.opt, self.trie, lm, 0, job.blank, job.W, job.tr, False) if self.trie \
+            else lib.lexfree(self.opt, lm, 0, job.blank, job.tr)
         return d, lm
 
     def free(self, d, lm):
@@ -566,9 +595,7 @@ def cpu_baseline(a, dec, job):
         t_total += time.perf_counter() - t0
         cpu.free(d, lm)
         got = dec.results(b)
-        same = len(got) == len(hyps) and all(
-            g.score == h.score and g.am == h.am and np.array_equal(g.tokens, h.tokens) and
-            np.array_equal(g.words, h.words) for g, h in zip(got, hyps))
+        same = nbest_same(got, hyps)
         mism += 0 if same else 1
     return {"value": n * job.T / t_total, "unit": "frames/s", "cores": 1, "kind": cpu.kind,
             "sample": "first %d utterances of the batch, one thread, fresh decoder per utterance, "
@@ -731,9 +758,7 @@ def streaming(job, B, T, N, chunk=50):
         want = cpu.lib.collect(rd)
         cpu.free(rd, rlm)
         got = d.results(b)
-        same = len(got) == len(want) and all(
-            g.score == h.score and g.am == h.am and np.array_equal(g.tokens, h.tokens) and
-            np.array_equal(g.words, h.words) for g, h in zip(got, want))
+        same = nbest_same(got, want)
         mism += 0 if same else 1
     for b in range(n_chk, B, max(1, B // 16)):
         d.results(b)  # (status check)

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""The reference's own end-to-end configuration (DecoderTest.cpp:57-195: LexiconDecoder + 3-gram + ASG, 26k-word
+lexicon, T = 235, N = 31) timed on the device and on one CPU thread of the same host (the compiled reference,
+oracle/_ref, or the oracle restatement if that prebuilt .so is absent), at the test's beam (2 500) and at beams the lane
+engines serve; n-best compared on every line.  Prints one JSON line per (beam, batch).
+Test infrastructure: the CPU side is only the checker / baseline."""
+import gzip, json, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import helpers
+from golden.make_golden import parse_lexicon_dump
+from oracle import orclib
+from text_amd import _capi
+
+d = os.path.join(helpers.GOLDEN_DIR, "decodertest")
+rd = lambda n: gzip.open(os.path.join(d, n + ".gz"), "rb").read()
+lex = parse_lexicon_dump(rd("lexicon_dump.txt").decode())
+TN = np.frombuffer(rd("TN.bin"), dtype=np.int32)
+T, N = int(TN[0]), int(TN[1])
+em = np.frombuffer(rd("emission.bin"), dtype=np.float32).copy()
+tr = np.frombuffer(rd("transition.bin"), dtype=np.float32).copy()
+tmp = tempfile.NamedTemporaryFile(suffix=".arpa", delete=False)
+tmp.write(rd("lm.arpa")); tmp.close()
+
+sess = helpers.FltxSession(None)
+lm = _capi.ArpaLM(tmp.name, lex["words"])
+ht = _capi.HostTrie(lex["ntok"], lex["sil"])
+cache = {}
+for wi, w, sp in lex["entries"]:
+    if wi not in cache:
+        cache[wi] = lm.score_sequence([wi], False)[0][0]
+    ht.insert(sp, wi, cache[wi])
+ht.smear(1)
+trie = ht.upload(sess.ctx)
+
+kind = "reference" if orclib.have_ref() else "port"
+cpu = orclib.load("ref" if kind == "reference" else "oracle")
+clm = cpu.lm_arpa_create(tmp.name.encode(), "\n".join(lex["words"]).encode())
+ctrie = cpu.trie_create(lex["ntok"], lex["sil"])
+for wi, w, sp in lex["entries"]:
+    a = np.array(sp, dtype=np.int32)
+    cpu.trie_insert(ctrie, orclib._ip(a), len(sp), wi, cache[wi])
+cpu.trie_smear(ctrie, 1)
+
+for K, B in ((2500, 1), (2500, 64), (500, 64), (256, 256), (128, 256), (50, 256)):
+    opt = _capi.make_options(K, 25000, 100.0, 2.0, 2.0, -float("inf"), -1.0, False, "asg")
+    dec = _capi.BatchDecoder(sess.ctx, _capi.LEXICON, opt, lm, lex["sil"], -1, unk=lex["unk"], trie=trie,
+                             transitions=tr, is_lm_token=False)
+    e = np.tile(em, B)
+    Ts = np.full(B, T, dtype=np.int32)
+    dec.decode_batch(e, Ts, N); sess.ctx.synchronize()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        dec.decode_batch(e, Ts, N); sess.ctx.synchronize()
+        dt = time.perf_counter() - t0
+        k_ms, b_ms = dec.timing()
+        best = (dt, k_ms, b_ms) if best is None or dt < best[0] else best
+    got = dec.results(0)
+    copt = orclib.make_options(K, 25000, 100.0, 2.0, 2.0, -float("inf"), -1.0, False, "asg")
+    cdec = cpu.lexicon(copt, ctrie, clm, lex["sil"], -1, lex["unk"], tr, False)
+    t0 = time.perf_counter()
+    want = cpu.decode(cdec, em, T, N)
+    t_cpu = time.perf_counter() - t0
+    cpu.decoder_destroy(cdec)
+    ok, why = helpers.hyps_equal(want, got)
+    print(json.dumps({"workload": "DecoderTest replay: LexiconDecoder + 3-gram ARPA LM + ASG, 26k-word lexicon, T=%d, N=%d" % (T, N),
+                      "beam": K, "batch": B, "engine": dec.get("engine"), "lane_groups": dec.get("lane_groups"),
+                      "redone": dec.get("redone"), "why_not_lane": dec.get("why_not_lane"),
+                      "device_ms_per_batch_wall": best[0] * 1e3, "decode_kernel_ms": best[1], "backtrace_ms": best[2],
+                      "device_frames_per_s": B * T / best[0], "n_hyp": len(got),
+                      "cpu": {"kind": kind, "cores": 1, "ms_per_utterance": t_cpu * 1e3, "frames_per_s": T / t_cpu},
+                      "nbest_equal_to_cpu": bool(ok), "difference": why}), flush=True)
+    dec.close()
+os.unlink(tmp.name)
