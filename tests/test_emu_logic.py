@@ -255,6 +255,7 @@ def test_lean_step_split_relation_scan(emu_session, oracle_lib, K, T, threads):
     c = cases.case("leanbeam_emu", dist="ctc", T=T, N=29, K=K, u=43)
     e = synth.emissions("ctc", c["u"], T, c["N"])
     d = emu_session.decoder(c, dict(tr=None), threads or None)
+    d.set("lane_groups", -1)  # (these beams start on fltx_mlane.h since round 4: the lean step is what is tested here)
     d.decode_batch(e, [T], c["N"])
     assert d.get("engine") == 2
     want = helpers.run_checker(oracle_lib, c, dict(e=e, tr=None, lex=None))

@@ -278,9 +278,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   const float* const trans = P.transitions;
   /* emitting-model score of token n after a hypothesis whose token is `prev` (the reference adds the two floats as
    * doubles before the hypothesis' score) */
+  /* (threads without a live lane or pair come through here with whatever their slot holds -- six-bit token fields, so
+   * up to 63 * N + 63: the index is clamped to the table, their result is never used) */
+  const uint32_t transLast = (uint32_t)(N * N - 1);
   auto emScore = [&](double e, int n, int prev, int t) {
     if (ASG && t > 0) {
-      e = e + (double)trans[n * N + prev];
+      const uint32_t at = (uint32_t)(n * N + prev);
+      e = e + (double)trans[at < transLast ? at : transLast];
     }
     return e;
   };
