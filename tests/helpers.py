@@ -78,8 +78,9 @@ def arpa_path(c, inp):
     os.makedirs(NGRAM_DIR, exist_ok=True)
     path = os.path.join(NGRAM_DIR, "lm_o%d_s%d_v%d.arpa" % (order, seed, len(vocab)))
     if not os.path.exists(path):
-        ngram_synth.write_arpa(path + ".tmp", [w for w in vocab if w != "<unk>"], order, counts, seed)
-        os.replace(path + ".tmp", path)
+        tmp = "%s.tmp%d" % (path, os.getpid())  # (pytest-xdist workers may build the same file at the same time)
+        ngram_synth.write_arpa(tmp, [w for w in vocab if w != "<unk>"], order, counts, seed)
+        os.replace(tmp, path)
     return path, vocab
 
 

@@ -111,6 +111,7 @@ def test_generic_engine_equals_lean_kernel(gpu_session, golden, c, mode):
     d = gpu_session.decoder(c, inp)
     if mode == "lean":
         d.set("lane", 0)
+        d.set("lane_groups", -1)  # (beams 65-512 are fltx_mlane.h's otherwise)
     else:
         d.set("lean", 0)
     if mode == "hash":

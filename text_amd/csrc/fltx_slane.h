@@ -231,7 +231,9 @@ struct SlRowRegs {
   int nList;
   bool dead;
 };
-FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mmax) {
+/* (silScore: handed over by callers that keep the option in a register -- read through P it is a scalar load from the
+ * kernel arguments, and a full wait, in every frame) */
+FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mmax, double silScore) {
   const int lane = laneId();
   const int N = P.N;
   const bool inRow = lane < N;
@@ -269,7 +271,7 @@ FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mm
     any = true;
   }
   if ((r.allow >> P.sil) & 1ull) {
-    const double sS = (mmax + (double)eSil) + P.silScore;
+    const double sS = (mmax + (double)eSil) + silScore;
     if (sS == sS && (!any || sS > best)) {
       best = sS;
       any = true;
@@ -280,6 +282,9 @@ FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mm
   r.ekey = ek;
   r.esil = eSil;
   return r;
+}
+FLTX_DEV SlRowRegs slRowScan(const DecodeParams& P, float v, bool ctc, double mmax) {
+  return slRowScan(P, v, ctc, mmax, P.silScore);
 }
 /* padPast: also (re)write the positions past the end of the list (NaN emission = no candidate): 2 = all of them
  * (the prologue), 1 = those a list can reach (a token beam keeps min(Kt, N) tokens, of which blank is not listed
@@ -600,7 +605,12 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
   bool dead = false; /* this utterance goes to the general engines */
   const int sil = P.sil, blank = P.blank;
-  const double silScore = P.silScore;
+  double silScore = P.silScore;
+#ifndef FLTX_EMU
+  /* (kept in a vector register: the frame loop is short of scalar ones, and the compiler would rather load the option
+   * from the kernel arguments again at each of its uses -- a scalar load and a full wait per candidate) */
+  __asm__ volatile("" : "+v"(silScore));
+#endif
   int2* const histPT = P.histPT;
 
   /* one frame; PT = parity of the frame (compile time: every LDS address is an immediate) */
@@ -657,6 +667,17 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       }
     }
     (void)nList;
+#ifndef FLTX_EMU
+    /* The compiler otherwise sinks the record loads below the two rare branches that follow and predicates the
+     * score loads on `live`: three LDS round trips one after the other.  An empty statement that "uses" every value
+     * loaded above keeps the loads where they are written -- all issued, one wait. */
+    if (isSelf) {
+      __asm__ volatile("" : "+v"(me.nb), "+v"(me.b), "+v"(me.info), "+v"(me.sid), "+v"(me.spar), "+v"(cm), "+v"(mk),
+                       "+v"(eBlank), "+v"(allow));
+    } else if (!isSvc) {
+      __asm__ volatile("" : "+v"(me.nb), "+v"(me.b), "+v"(me.info), "+v"(me.sid), "+v"(me.spar), "+v"(cm), "+v"(mk));
+    }
+#endif
     if (nev != 0u) { /* rare: states re-entered the beam in the previous build */
       if (ST) {
         slRelink(S, P.maskTab + (size_t)b * P.idCap, p, nState);
@@ -722,7 +743,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       if (t + 1 < T) {
         ldsRowWait(); /* (issued two frames ago) */
         const float rv = lane < N ? S.raw[(t + 1) % 3][lane] : 0.0f;
-        nextRow = slRowScan(P, rv, ctc, bestChain);
+        nextRow = slRowScan(P, rv, ctc, bestChain, silScore);
         bestChain = nextRow.best;
       }
       ldsRowLoad(S.raw[t % 3], em + (size_t)(t + 3) * N + lane, t + 3 < T && lane < N); /* (row t's slot: read last frame) */
@@ -871,113 +892,130 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     ldsBarrier(); /* 1 */
     /* ---- phase 2: which candidates survive (Utils.h:200-220) ---------------------------- */
     unsigned long long selMask[GT]; /* per slot: the lanes whose candidate survives */
-    SlScan sc;
+    /* The usual frame: the window holds at least K and the bins up to the K-th best's hold exactly K (or everything
+     * counted survives) -- one scan, a bin limit, four ballots, in a straight line.  Everything else (fewer than K
+     * inside the window, a boundary bin of which only some survive, a bin too crowded to rank) is the loop below,
+     * out of the usual frame's way: the selection is (bin <= lim) or one of the `take` bits either way. */
+    SlScan sc = slScan(S.hist[p], K, true);
     int shift = winShift, base = winBase;
-    unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
-    bool full = false; /* the counts include what lies beyond the window */
-    for (;;) {
-      sc = slScan(S.hist[p], K, !full);
-      if (!full && !sc.crossed) {
-        /* fewer than K inside the window: count the far ones too (one add per wave) */
-        int nFar = 0;
-#pragma unroll
-        for (int j = 0; j < GT; ++j) {
-          nFar += popc64(waveBallot(cbin[j] == kSlFar));
-        }
-        if (lane == 0 && nFar > 0) {
-          atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
-        }
-        full = true;
-        ldsBarrier();
-        continue;
+    int lim = -1;
+    uint32_t take = 0u;
+    bool usual = false;
+    if (sc.crossed) {
+      if (sc.total <= K) {
+        lim = kSlFar - 1;
+        usual = true;
+      } else if (sc.cnt == K - sc.cum) {
+        lim = sc.bstar;
+        usual = true;
       }
-      if (sc.total <= K) { /* everything counted survives (with the far ones: all above the threshold) */
-        const int lim = full ? kSlFar : kSlFar - 1;
-#pragma unroll
-        for (int j = 0; j < GT; ++j) {
-          selMask[j] = waveBallot(cbin[j] <= lim);
-        }
-        break;
-      }
-      const int need = K - sc.cum;
-      if (sc.cnt == need) {
-#pragma unroll
-        for (int j = 0; j < GT; ++j) {
-          selMask[j] = waveBallot(cbin[j] <= sc.bstar);
-        }
-        break;
-      }
-      if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
-        if (PROF) {
-          acc[6] += 1ull;
-          acc[7] += (unsigned long long)sc.cnt;
-        }
-        uint32_t take = 0u;
-#pragma unroll
-        for (int j = 0; j < GT; ++j) {
-          if (cbin[j] == sc.bstar) {
-            const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
-            S.bKey[i] = f64Key(cs[j]);
-            S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
-          }
-        }
-        ldsBarrier();
-#pragma unroll
-        for (int j = 0; j < GT; ++j) {
-          if (cbin[j] == sc.bstar) {
-            const unsigned long long k = f64Key(cs[j]);
-            const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
-            int rank = 0;
-            for (int i = 0; i < sc.cnt; ++i) {
-              const unsigned long long k2 = S.bKey[i];
-              rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
-            }
-            take |= rank < need ? (1u << j) : 0u;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < GT; ++j) {
-          selMask[j] = waveBallot(cbin[j] < sc.bstar || ((take >> j) & 1u) != 0u);
-        }
-        break;
-      }
-      /* too many in one bin: the K-th best's float bits lie in [lo, hi]; look again
-       * through the finest window that spans that bracket (<= 4 rounds: 32 bits, 9 per round) */
-      {
-        const unsigned long long v = (unsigned long long)(sc.bstar + base);
-        if (sc.bstar > 0 || base == 0) {
-          const unsigned long long l2 = v << shift;
-          bLo = l2 > bLo ? l2 : bLo;
-        }
-        if (sc.bstar < kSlNB - 1) {
-          const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
-          bHi = h2 < bHi ? h2 : bHi;
-        }
-        if (bLo >= bHi) { /* equal to the last bit and more of them than the pairwise list holds */
-          dead = true;
-          break;
-        }
-        int ns = 0;
-        while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
-          ++ns;
-        }
-        shift = ns;
-        base = (int)(bLo >> ns);
-      }
-      ldsBarrier();
-      for (int i = tid; i < kSlNB; i += W) {
-        S.hist[p][i] = 0u;
-      }
-      ldsBarrier();
-      full = true;
+    }
+    if (__builtin_expect(usual, 1)) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
-        if (cbin[j] != kSlInvalid) {
-          cbin[j] = slBin<LA>(best, cs[j], shift, base);
-          atomAdd32(&S.hist[p][cbin[j]], 1u);
-        }
+        selMask[j] = waveBallot(cbin[j] <= lim);
       }
-      ldsBarrier();
+    } else {
+      unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+      bool full = false; /* the counts include what lies beyond the window */
+      for (;;) {
+        if (!full && !sc.crossed) {
+          /* fewer than K inside the window: count the far ones too (one add per wave) */
+          int nFar = 0;
+#pragma unroll
+          for (int j = 0; j < GT; ++j) {
+            nFar += popc64(waveBallot(cbin[j] == kSlFar));
+          }
+          if (lane == 0 && nFar > 0) {
+            atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
+          }
+          full = true;
+          ldsBarrier();
+          sc = slScan(S.hist[p], K, false);
+          continue;
+        }
+        if (sc.total <= K) { /* everything counted survives (with the far ones: all above the threshold) */
+          lim = full ? kSlFar : kSlFar - 1;
+          break;
+        }
+        const int need = K - sc.cum;
+        if (sc.cnt == need) {
+          lim = sc.bstar;
+          break;
+        }
+        if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
+          if (PROF) {
+            acc[6] += 1ull;
+            acc[7] += (unsigned long long)sc.cnt;
+          }
+#pragma unroll
+          for (int j = 0; j < GT; ++j) {
+            if (cbin[j] == sc.bstar) {
+              const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
+              S.bKey[i] = f64Key(cs[j]);
+              S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+            }
+          }
+          ldsBarrier();
+#pragma unroll
+          for (int j = 0; j < GT; ++j) {
+            if (cbin[j] == sc.bstar) {
+              const unsigned long long k = f64Key(cs[j]);
+              const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+              int rank = 0;
+              for (int i = 0; i < sc.cnt; ++i) {
+                const unsigned long long k2 = S.bKey[i];
+                rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
+              }
+              take |= rank < need ? (1u << j) : 0u;
+            }
+          }
+          lim = sc.bstar - 1;
+          break;
+        }
+        /* too many in one bin: the K-th best's float bits lie in [lo, hi]; look again
+         * through the finest window that spans that bracket (<= 4 rounds: 32 bits, 9 per round) */
+        {
+          const unsigned long long v = (unsigned long long)(sc.bstar + base);
+          if (sc.bstar > 0 || base == 0) {
+            const unsigned long long l2 = v << shift;
+            bLo = l2 > bLo ? l2 : bLo;
+          }
+          if (sc.bstar < kSlNB - 1) {
+            const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
+            bHi = h2 < bHi ? h2 : bHi;
+          }
+          if (bLo >= bHi) { /* equal to the last bit and more of them than the pairwise list holds */
+            dead = true;
+            break;
+          }
+          int ns = 0;
+          while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
+            ++ns;
+          }
+          shift = ns;
+          base = (int)(bLo >> ns);
+        }
+        ldsBarrier();
+        for (int i = tid; i < kSlNB; i += W) {
+          S.hist[p][i] = 0u;
+        }
+        ldsBarrier();
+        full = true;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          if (cbin[j] != kSlInvalid) {
+            cbin[j] = slBin<LA>(best, cs[j], shift, base);
+            atomAdd32(&S.hist[p][cbin[j]], 1u);
+          }
+        }
+        ldsBarrier();
+        sc = slScan(S.hist[p], K, false);
+      }
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        selMask[j] = waveBallot(cbin[j] <= lim || ((take >> j) & 1u) != 0u);
+      }
     }
     if (dead) {
       return;
@@ -1002,12 +1040,9 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       }
     } else if (!isSelf) {
 #pragma unroll
-      for (int j = 0; j < GT; ++j) {
-        myNew[j] = 0;
-        if (selMask[j] != 0ull) {
-          myNew[j] = nNewWave + wavePrefixCount(selMask[j]);
-          nNewWave += popc64(selMask[j]);
-        }
+      for (int j = 0; j < GT; ++j) { /* (no branch around an empty position: it costs what it would skip) */
+        myNew[j] = nNewWave + wavePrefixCount(selMask[j]);
+        nNewWave += popc64(selMask[j]);
       }
       if (lane > wave && lane <= selfWave + 1 && nNewWave > 0) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
@@ -1121,7 +1156,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       for (int j = 0; j < GT; ++j) {
         if (selMask[j] != 0ull) { /* (most positions of most frames have no survivor at all) */
           if ((selMask[j] >> lane) & 1ull) {
-            const int nTok = (int)S.tokId[p][wave * GT + j];
+            /* (the position's token from its bit: reading tokId here is an LDS round trip per surviving position) */
+            const int nTok = tb[j] != 0ull ? __builtin_ctzll(tb[j]) : 0;
             newState(offW + myNew[j], cs[j], nTok, hypM, ST ? amStep(amM, ev[j], nTok, whichB ? blank : last) : 0.0);
           }
         }
