@@ -408,6 +408,7 @@ struct fltx_decoder {
   int mlaneNG = 0, mlaneGPW = 0, mlaneSPW = 0, userLaneGroups = 0, userMlaneGeo = -1;
   int noYlaneAsg = 0;        /* tests: ASG lexicon decodes stay on the generic engine */
   int userYRankAt = 0;       /* tests: DecodeParams::yRankAt */
+  int userTune = 0;          /* development: DecodeParams::tune */
   int userYlaneGroups = 0;   /* tests: at least this many lane groups on fltx_ylane.h (0 = what the beam needs) */
   uint32_t ymemoSlots = 8192; /* slots per utterance of the LM-state memo in HBM (fltx_ylane.h: follows the frames) */
   int64_t fallbackReasons = 0; /* bit r: an utterance of the last batch left fltx_ylane.h for reason r (see YL_WHY there) */
@@ -1393,6 +1394,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noYlaneAsg = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "tune")) { /* development: see DecodeParams::tune */
+    d->userTune = (int)value;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "ylane_rank_at")) { /* tests: see DecodeParams::yRankAt */
     d->userYRankAt = (int)value;
     return FLTX_OK;
@@ -2067,6 +2072,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
   P.ymemoSlots = d->ymemoSlots;
   P.yRankAt = d->userYRankAt;
+  P.tune = d->userTune;
   P.statusHost = (!d->offlineCall && d->streamOpt) ? (int32_t*)d->hStat.p : nullptr;
   /* (the lean step on an HBM workspace reads its atomically ORed addMask words at L2 as well: wsLoadAtomic64) */
   P.wsNoInv = (!d->wsInLds && d->hotLevel >= 1) ? 1 : 0;

@@ -463,6 +463,13 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   const int selfWave = nW - 2;
   const int prepWave = nW - 1;
   const bool isSelfW = wave == selfWave, isSvcW = wave == prepWave;
+#ifndef FLTX_EMU
+  /* The two waves everybody waits for at the barriers win the issue arbitration of their SIMD (C2: 1.86 -> 1.79 ms;
+   * tune bit 0 switches it off for measurements) */
+  if (!(P.tune & 1) && (isSelfW || isSvcW)) {
+    __builtin_amdgcn_s_setprio(3);
+  }
+#endif
   const int K = P.K, N = P.N;
   const bool ctc = P.criterion == 1;
   const int T = P.stepT ? P.stepT[b] : 0;
@@ -824,18 +831,17 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       parR = hypNB;
       amR = amNBv;
       prevR = last;
-      if (has1 && (r1 > cR || (r1 == cR && h1 < parR))) {
-        cR = r1;
-        parR = h1;
-        amR = parAmNB;
-        prevR = lastP;
-      }
-      if (has2 && (r2 > cR || (r2 == cR && h2 < parR))) {
-        cR = r2;
-        parR = h2;
-        amR = parAmB;
-        prevR = blank;
-      }
+      /* (selects, not branches: the lanes disagree about who wins, and a divergent branch costs more than both sides) */
+      const bool t1 = has1 & ((r1 > cR) | ((r1 == cR) & (h1 < parR)));
+      cR = t1 ? r1 : cR;
+      parR = t1 ? h1 : parR;
+      amR = t1 ? parAmNB : amR;
+      prevR = t1 ? lastP : prevR;
+      const bool t2 = has2 & ((r2 > cR) | ((r2 == cR) & (h2 < parR)));
+      cR = t2 ? r2 : cR;
+      parR = t2 ? h2 : parR;
+      amR = t2 ? parAmB : amR;
+      prevR = t2 ? blank : prevR;
       bool okR = lastOk && (has0 || has1 || has2) && cR >= thr;
       if (LA) {
         /* the members that pass the threshold, best first (the best is cR, its slot parR) */
@@ -1038,6 +1044,14 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       for (int j = 0; j < GT; ++j) {
         myNew[j] = 0;
       }
+      /* The next frame's row and the other parity's histogram (last read a frame ago) are written here, while the
+       * other waves count their new lanes: this wave then has nothing left between the second and the third barrier.
+       * (It issues no stores to HBM: it loads an emission row per frame, and a wait for that load would wait for
+       * every store issued since as well.) */
+      if (t + 1 < T) {
+        slRowStore(P, S, q, nextRow, P.Kt < N ? 1 : 0);
+      }
+      ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
     } else if (!isSelf) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) { /* (no branch around an empty position: it costs what it would skip) */
@@ -1145,13 +1159,12 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       }
     };
     if (isSvc) {
-      /* (this wave issues no stores to HBM: it loads an emission row per frame, and a wait for that
-       * load would wait for every store issued since as well) */
-      if (t + 1 < T) {
-        slRowStore(P, S, q, nextRow, P.Kt < N ? 1 : 0);
-      }
-      ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
+      /* (its part of the build went ahead of the second barrier) */
     } else if (!isSelf) {
+      if (!ST && wave == 0 && lane >= nHSurv + nNew && lane < K) { /* unused slots of the history row: see slReenter
+                                                                       (a token wave: they wait at the third barrier) */
+        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
+      }
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         if (selMask[j] != 0ull) { /* (most positions of most frames have no survivor at all) */
@@ -1163,9 +1176,6 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
     } else {
-      if (!ST && lane >= nHSurv + nNew && lane < K) { /* unused slots of the history row: see slReenter */
-        histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
-      }
       if (surv >= 0) {
         const bool sB = ((selMask[0] >> lane) & 1ull) != 0ull, sR = ((selMask[1] >> lane) & 1ull) != 0ull;
         const int pln = pl >= 0 ? plNew : -1;
