@@ -1895,7 +1895,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     lds = true;
   }
   if (d->ylane) {
-    d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsT<4>, memo) : (d->yshare ? offsetof(YlaneLds, memo) : sizeof(YlaneLds));
+    /* (shared-CU geometries: the part of YlaneLds::pscore their token waves use -- five waves x 512 floats with one lane
+     * group, four with two -- so that two workgroups still fit a CU's 160 KB) */
+    d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsT<4>, memo)
+                               : (d->yshare ? offsetof(YlaneLds, pscore) + (size_t)(d->ylane == 2 ? 4 : 5) * 512 * sizeof(float)
+                                            : sizeof(YlaneLds));
     d->wsInLds = true;
     lds = true;
     d->itemCap = 0;

@@ -122,6 +122,11 @@ struct YlaneLdsT {
   unsigned long long endKey[kYlLanes];
   double endScore[kYlLanes], endLmS[kYlLanes];
   uint32_t endHyp[kYlLanes];
+  /* A token wave that ranks its own pairs prices each once and keeps the score here as a float (the order key of every
+   * counting pass is taken from that float): 512 per token wave; the shared-CU geometries are launched with the part
+   * of it they use (fltx_api.cpp: ten of the sixteen KB with one lane group, eight -- four waves, the first 512 of
+   * a wave's 1 024 pairs -- with two).  Four lane groups have no room for it and price a pair in every pass. */
+  float pscore[LG <= 2 ? kYlTokWaves * fltx::kYlPairs : 4];
   /* Last member: the shared-CU geometry (HM = 1) keeps the memo in HBM (DecodeParams::ymemo) and is
    * launched with offsetof(YlaneLds, memo) bytes of LDS -- 77 KB, so that two workgroups fit a CU and
    * one utterance's waits (two thirds of its wave cycles) are the other's time to run. */
@@ -332,6 +337,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   const uint32_t memoMask = (uint32_t)memoSlots - 1u;
   unsigned long long* const memo = HM ? P.ymemo + (size_t)b * (size_t)memoSlots : S.memo;
   uint16_t* const candW = &S.cand[0][0] + (size_t)wave * PAIRS; /* (token waves: wave < 8, or < 4 with twice the pairs) */
+  constexpr int PC = LG > 2 ? 0 : 512; /* pairs of a token wave whose score is kept in LDS while the wave ranks them */
+  float* const pcW = S.pscore + (size_t)(LG > 2 ? 0 : wave) * PC;
   for (int i = tid; i < memoSlots; i += W) {
     memo[i] = 0ull; /* (HBM: at L2 before the barrier below, where the word wave's atomics will find it) */
   }
@@ -598,7 +605,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
          * is a plain threshold on the key, so what is kept is a superset of the wave's K best whatever the ties. */
         uint32_t* wh = S.whist[wave];
         double rankRef = 0.0; /* the distance is taken to the wave's best pair */
-        auto pairKey = [&](int id, double& cOut) -> uint32_t { /* 0xFFFFFFFF: not a candidate */
+        /* the score of pair `id` (NaN: not a candidate) -- LDS reads and, with the LM terms, a load from the trie's
+         * smearing table in HBM: done once per pair, the float of it kept in pcW for the passes that follow */
+        auto pairScore = [&](int id) -> double {
           const bool valid = id < nCand;
           const uint32_t c16 = valid ? (uint32_t)candW[id] : 0u;
           const int x = (int)(c16 & 0x1FFu), pos = wave * TPW + (int)(c16 >> 9);
@@ -613,11 +622,21 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             const float dl = valid ? xdelta[child] : 0.0f;
             c = c + lmWeight * (double)dl;
           }
-          cOut = c;
-          if (!(valid && c == c)) {
+          return valid ? c : __builtin_nan("");
+        };
+        /* order key of a pair: the float bits of the distance from the wave's best pair to the pair's score AS A FLOAT
+         * (one function for every pair, kept or priced again: monotone in the score, which is all the cut needs) */
+        auto pairKey = [&](int id) -> uint32_t { /* 0xFFFFFFFF: not a candidate */
+          float cf;
+          if (PC > 0 && id < PC) {
+            cf = pcW[id];
+          } else {
+            cf = (float)pairScore(id);
+          }
+          if (!(cf == cf) || id >= nCand) {
             return 0xFFFFFFFFu;
           }
-          float dd = (float)(rankRef - c);
+          float dd = (float)(rankRef - (double)cf);
           dd = dd > 0.0f ? dd : 0.0f;
           return __float_as_uint(dd);
         };
@@ -634,22 +653,42 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         static_assert(2 * kTieCap + kTieCap / 2 <= kSlNB, "the tie list fits the wave's count area");
         uint32_t tieVal = 0xFFFFFFFFu;
         int tieRoom = 0, nTie = 0;
-        double cTmp = 0.0;
-        { /* (lb would do as long as no pair beats it; pairs above it would all share key 0) */
+        { /* Every pair is priced once.  The listing above left out what an upper bound of the score puts below the
+           * threshold; the score itself does so for more (the bound carries the largest smearing term of the lexicon),
+           * and often for enough that nothing is left to rank.  The list is compacted in place, in order.
+           * (The reference of the distances: lb would do as long as no pair beats it; pairs above it would all share
+           * key 0 -- it is the wave's best pair.) */
           unsigned long long mk = 0ull;
+          int kept0 = 0;
           for (int c0 = 0; c0 < nCand; c0 += 64) {
-            const unsigned long long k1 = pairKey(c0 + lane, cTmp) != 0xFFFFFFFFu ? f64Key(cTmp) : 0ull;
+            const int id = c0 + lane;
+            const uint32_t c16 = id < nCand ? (uint32_t)candW[id] : 0u;
+            const double c = pairScore(id);
+            const bool k0 = c == c && c >= thrLB;
+            const unsigned long long bal = waveBallot(k0);
+            waveSync();
+            if (k0) {
+              const int at = kept0 + wavePrefixCount(bal);
+              candW[at] = (uint16_t)c16;
+              if (PC > 0 && at < PC) {
+                pcW[at] = (float)c;
+              }
+            }
+            const unsigned long long k1 = k0 ? f64Key(c) : 0ull;
             mk = k1 > mk ? k1 : mk;
+            kept0 += popc64(bal);
+            waveSync();
           }
+          nCand = kept0;
           mk = waveMax64(mk);
           okCut = mk != 0ull;
           rankRef = okCut ? f64FromKey(mk) : 0.0;
         }
-        while (okCut) {
+        while (okCut && nCand > rankAt) {
           ((uint4*)wh)[lane] = make_uint4(0u, 0u, 0u, 0u);
           waveSync();
           for (int c0 = 0; c0 < nCand; c0 += 64) {
-            const uint32_t kb = pairKey(c0 + lane, cTmp);
+            const uint32_t kb = pairKey(c0 + lane);
             if (kb != 0xFFFFFFFFu && (unsigned long long)kb >= bLo && (unsigned long long)kb <= bHi) {
               int q = (int)(kb >> shift) - base;
               q = q < 0 ? 0 : (q > kSlNB - 1 ? kSlNB - 1 : q);
@@ -690,10 +729,10 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             waveSync();
             for (int c0 = 0; c0 < nCand; c0 += 64) {
               const int id = c0 + lane;
-              const bool mem = pairKey(id, cTmp) == tieVal;
+              const bool mem = pairKey(id) == tieVal;
               const unsigned long long bal = waveBallot(mem);
               if (mem && nTie + wavePrefixCount(bal) < kTieCap) {
-                tieKey[nTie + wavePrefixCount(bal)] = f64Key(cTmp);
+                tieKey[nTie + wavePrefixCount(bal)] = f64Key(pairScore(id));
                 tieId[nTie + wavePrefixCount(bal)] = (uint16_t)id;
               }
               nTie += popc64(bal);
@@ -711,13 +750,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           waveSync();
         }
         int kept = 0;
-        for (int c0 = 0; c0 < nCand; c0 += 64) {
+        for (int c0 = 0; c0 < nCand && nCand > rankAt; c0 += 64) {
           const int id = c0 + lane;
           const uint32_t c16 = id < nCand ? (uint32_t)candW[id] : 0u;
-          const uint32_t kb = pairKey(id, cTmp);
+          const uint32_t kb = pairKey(id);
           bool keep = kb <= hiCut; /* (0xFFFFFFFF: never) */
           if (kb == tieVal && keep) { /* among equal keys the better scores, then the lower list index */
-            const unsigned long long k = f64Key(cTmp);
+            const unsigned long long k = f64Key(pairScore(id));
             int rank = 0;
             for (int i = 0; i < nTie && i < kTieCap; ++i) {
               const unsigned long long k2 = tieKey[i];
@@ -733,8 +772,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           kept += popc64(bal);
           waveSync();
         }
-        nCand = kept;
-        if (!okCut || nCand > rankAt) { /* ties by the hundred: general path */
+        nCand = nCand > rankAt ? kept : nCand;
+        if ((!okCut && nCand > 0) || nCand > rankAt) { /* ties by the hundred: general path */
           dead = true; YL_WHY(1);
           nCand = nCand > R * 64 ? R * 64 : nCand;
         }
@@ -1048,127 +1087,138 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     for (int j = 0; j < NS; ++j) {
       selMask[j] = 0ull;
     }
-    SlScan sc;
+    /* (the usual frame in a straight line, the rare cases in a loop out of its way: see fltx_slane.h) */
+    SlScan sc = slScan(S.hist[p], K, true);
     int shift = winShift, base = winBase;
-    unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
-    bool full = false;
-    for (;;) {
-      sc = slScan(S.hist[p], K, !full);
-      if (!full && !sc.crossed) {
-        int nFar = 0;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if (j >= nUsed) {
-            continue;
-          }
-          nFar += popc64(waveBallot(cbin[j] == kSlFar));
-        }
-        if (lane == 0 && nFar > 0) {
-          atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
-        }
-        full = true;
-        ldsBarrier();
-        continue;
-      }
+    int lim = -1;
+    uint32_t take = 0u;
+    bool usual = false;
+    if (sc.crossed) {
       if (sc.total <= K) {
-        const int lim = full ? kSlFar : kSlFar - 1;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if (j >= nUsed) {
-            continue;
-          }
-          selMask[j] = waveBallot(cbin[j] <= lim);
-        }
-        break;
+        lim = kSlFar - 1;
+        usual = true;
+      } else if (sc.cnt == K - sc.cum) {
+        lim = sc.bstar;
+        usual = true;
       }
-      const int need = K - sc.cum;
-      if (sc.cnt == need) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if (j >= nUsed) {
-            continue;
-          }
-          selMask[j] = waveBallot(cbin[j] <= sc.bstar);
-        }
-        break;
-      }
-      if (sc.cnt <= kSlBCap) {
-        uint32_t take = 0u;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if (j >= nUsed) {
-            continue;
-          }
-          if (cbin[j] == sc.bstar) {
-            const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
-            S.bKey[i] = f64Key(cs[j]);
-            S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
-          }
-        }
-        ldsBarrier();
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if (j >= nUsed) {
-            continue;
-          }
-          if (cbin[j] == sc.bstar) {
-            const unsigned long long k = f64Key(cs[j]);
-            const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
-            int rank = 0;
-            for (int i = 0; i < sc.cnt; ++i) {
-              const unsigned long long k2 = S.bKey[i];
-              rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
-            }
-            take |= rank < need ? (1u << j) : 0u;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          if (j >= nUsed) {
-            continue;
-          }
-          selMask[j] = waveBallot(cbin[j] < sc.bstar || ((take >> j) & 1u) != 0u);
-        }
-        break;
-      }
-      {
-        const unsigned long long v = (unsigned long long)(sc.bstar + base);
-        if (sc.bstar > 0 || base == 0) {
-          const unsigned long long l2 = v << shift;
-          bLo = l2 > bLo ? l2 : bLo;
-        }
-        if (sc.bstar < kSlNB - 1) {
-          const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
-          bHi = h2 < bHi ? h2 : bHi;
-        }
-        if (bLo >= bHi) {
-          dead = true; YL_WHY(5);
-          break;
-        }
-        int ns = 0;
-        while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
-          ++ns;
-        }
-        shift = ns;
-        base = (int)(bLo >> ns);
-      }
-      ldsBarrier();
-      for (int i = tid; i < kSlNB; i += W) {
-        S.hist[p][i] = 0u;
-      }
-      ldsBarrier();
-      full = true;
+    }
+    if (__builtin_expect(usual, 1)) {
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
         if (j >= nUsed) {
           continue;
         }
-        if (cbin[j] != kSlInvalid) {
-          cbin[j] = slBin(best, cs[j], shift, base);
-          atomAdd32(&S.hist[p][cbin[j]], 1u);
-        }
+        selMask[j] = waveBallot(cbin[j] <= lim);
       }
-      ldsBarrier();
+    } else {
+      unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+      bool full = false;
+      for (;;) {
+        if (!full && !sc.crossed) {
+          int nFar = 0;
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            if (j >= nUsed) {
+              continue;
+            }
+            nFar += popc64(waveBallot(cbin[j] == kSlFar));
+          }
+          if (lane == 0 && nFar > 0) {
+            atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
+          }
+          full = true;
+          ldsBarrier();
+          sc = slScan(S.hist[p], K, false);
+          continue;
+        }
+        if (sc.total <= K) {
+          lim = full ? kSlFar : kSlFar - 1;
+          break;
+        }
+        const int need = K - sc.cum;
+        if (sc.cnt == need) {
+          lim = sc.bstar;
+          break;
+        }
+        if (sc.cnt <= kSlBCap) {
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            if (j >= nUsed) {
+              continue;
+            }
+            if (cbin[j] == sc.bstar) {
+              const uint32_t i = atomAdd32(&S.scal[SL_BCNT], 1u);
+              S.bKey[i] = f64Key(cs[j]);
+              S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+            }
+          }
+          ldsBarrier();
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            if (j >= nUsed) {
+              continue;
+            }
+            if (cbin[j] == sc.bstar) {
+              const unsigned long long k = f64Key(cs[j]);
+              const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
+              int rank = 0;
+              for (int i = 0; i < sc.cnt; ++i) {
+                const unsigned long long k2 = S.bKey[i];
+                rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
+              }
+              take |= rank < need ? (1u << j) : 0u;
+            }
+          }
+          lim = sc.bstar - 1;
+          break;
+        }
+        {
+          const unsigned long long v = (unsigned long long)(sc.bstar + base);
+          if (sc.bstar > 0 || base == 0) {
+            const unsigned long long l2 = v << shift;
+            bLo = l2 > bLo ? l2 : bLo;
+          }
+          if (sc.bstar < kSlNB - 1) {
+            const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
+            bHi = h2 < bHi ? h2 : bHi;
+          }
+          if (bLo >= bHi) {
+            dead = true; YL_WHY(5);
+            break;
+          }
+          int ns = 0;
+          while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
+            ++ns;
+          }
+          shift = ns;
+          base = (int)(bLo >> ns);
+        }
+        ldsBarrier();
+        for (int i = tid; i < kSlNB; i += W) {
+          S.hist[p][i] = 0u;
+        }
+        ldsBarrier();
+        full = true;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          if (j >= nUsed) {
+            continue;
+          }
+          if (cbin[j] != kSlInvalid) {
+            cbin[j] = slBin(best, cs[j], shift, base);
+            atomAdd32(&S.hist[p][cbin[j]], 1u);
+          }
+        }
+        ldsBarrier();
+        sc = slScan(S.hist[p], K, false);
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        if (j >= nUsed) {
+          continue;
+        }
+        selMask[j] = waveBallot(cbin[j] <= lim || ((take >> j) & 1u) != 0u);
+      }
     }
     if (dead) {
       return;

@@ -5,7 +5,7 @@ OUT="$1"; shift
 BEAMS="${@:-100 128 129 160 200 256 300}"
 : > "$OUT"
 for K in $BEAMS; do
-  python "$R/bench.py" --workload C4 --beam $K --steps 2 --warmup 1 --no-extras --cpu-sample 2 >> "$OUT" 2>> "$OUT.err" || echo "{\"beam\": $K, \"failed\": true}" >> "$OUT"
+  python "$R/bench.py" --workload C4 --beam $K --steps 3 --warmup 2 --no-extras --cpu-sample 2 >> "$OUT" 2>> "$OUT.err" || echo "{\"beam\": $K, \"failed\": true}" >> "$OUT"
 done
 python - "$OUT" <<'PY'
 import json, sys
