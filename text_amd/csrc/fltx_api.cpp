@@ -402,6 +402,7 @@ struct fltx_decoder {
   int lean = 0, noLean = 0; /* lean: GMAX of the lean lexicon-free kernel, 0 = generic engine */
   int lane = 0, noLane = 0; /* lane: tokens per wave of the lane-per-slot kernel (fltx_lane.h), 0 = off */
   int slaneThreads = 0; /* tuning: workgroup size of the lane = LM state kernel (0 = first that fits) */
+  int wlane = 0, noWlane = 0; /* wlane: the lane = LM state kernel is fltx_wlane.h's (token sets beyond 64, token beam <= 64); slane = its list positions per wave */
   int slane = 0, noSlane = 0; /* slane: list positions per wave of the lane = LM state kernel (fltx_slane.h), 0 = off */
   /* ... with several lane groups (fltx_mlane.h, beams beyond 64): lane groups (0 / 1 = fltx_slane.h), groups per token
    * wave, groups per self wave; userLaneGroups: tuning / tests, 0 = as many as the beam needs, -1 = never */
@@ -1250,6 +1251,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->sstream;
   } else if (!strcmp(key, "stream_redone")) {
     *value = d->streamRedone;
+  } else if (!strcmp(key, "wlane")) { /* 1: the last call ran on fltx_wlane.h (token sets beyond 64) */
+    *value = d->wlane;
   } else if (!strcmp(key, "slane")) {
     *value = d->slane;
   } else if (!strcmp(key, "fallback_reasons")) {
@@ -1384,6 +1387,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   }
   if (!strcmp(key, "slane_threads")) {
     d->slaneThreads = (int)value;
+    return FLTX_OK;
+  }
+  if (!strcmp(key, "wlane")) { /* 0: large token sets stay off the lane = LM state engine (fltx_wlane.h) */
+    d->noWlane = value ? 0 : 1;
     return FLTX_OK;
   }
   if (!strcmp(key, "slane")) { /* 0: do not use the lane = LM state kernel (fltx_slane.h) */
@@ -1554,6 +1561,27 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       }
     }
   }
+  /* ... for token sets beyond 64 (word pieces) when the token beam keeps at most 64 of them (fltx_wlane.h): masks and
+   * lists by position in the frame's token beam, a front-end wave that cuts the row to it */
+  d->wlane = 0;
+  if (d->kind == FLTX_DECODER_LEXFREE && !d->noSlane && !d->noWlane && !d->genericAsked && d->offlineCall && !d->keepScores &&
+      !forceWorstCaseCap && !d->forceGlobalWs && !d->opt.log_add && d->lm->kind == 0 && !d->isLmToken && N > 64 &&
+      N <= kWlMaxN && K <= 64 && nTok <= 64 && d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
+      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
+      (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
+    static const int geoW[][2] = {{576, 5}, {576, 8}, {576, 10}};
+    for (const auto& g : geoW) {
+      if (d->userThreads && d->threads != g[0]) {
+        continue;
+      }
+      if (nTok <= g[1] * (g[0] / 64 - 2)) {
+        d->slane = g[1];
+        d->wlane = 1;
+        d->threads = g[0];
+        break;
+      }
+    }
+  }
   /* ... with several groups of 64 lanes for beams beyond one wave's lanes (fltx_mlane.h): same candidates, merges and
    * selection; a wave holds the states of whole lane groups, history records carry 10-bit slots */
   d->mlaneNG = 0;
@@ -1692,7 +1720,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       const bool lexi = d->kind == FLTX_DECODER_LEXICON;
       const bool unkOn = d->opt.unk_score > -std::numeric_limits<double>::infinity();
       const int nListAll = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
-      why |= N > 64 ? FLTX_WHY_TOKENS : 0;
+      why |= (N > 64 && (lexi || N > kWlMaxN || nTok > 64)) ? FLTX_WHY_TOKENS : 0; /* (lexicon-free: the token BEAM has to fit, fltx_wlane.h) */
       why |= (lexi ? K > 256 : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
       why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
@@ -1887,7 +1915,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   }
   d->wsInLds = lds;
   if (d->slane) {
-    d->wsBytes = d->mlaneNG == 2   ? sizeof(MlaneLds<2>)
+    d->wsBytes = d->wlane          ? sizeof(WlaneLds)
+                 : d->mlaneNG == 2 ? sizeof(MlaneLds<2>)
                  : d->mlaneNG == 4 ? sizeof(MlaneLds<4>)
                  : d->mlaneNG == 8 ? sizeof(MlaneLds<8>)
                                    : offsetof(SlaneLds, amNB); /* (the stream variant's arrays are its last members) */
@@ -2301,6 +2330,20 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
                     d->mlaneNG);
     }
 #undef FLTX_LAUNCH_MLANE
+  } else if (d->slane && d->wlane) {
+#define FLTX_LAUNCH_WLANE(WW, GG)                                                                          \
+  do {                                                                                                     \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_wlane<WW, GG>,                              \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));              \
+    hipLaunchKernelGGL((fltx_decode_kernel_wlane<WW, GG>), dim3(nGrid), dim3(WW), d->wsBytes, d->ctx->stream, P); \
+  } while (0)
+    switch (W * 100 + d->slane) {
+      case 57605: FLTX_LAUNCH_WLANE(576, 5); break;
+      case 57608: FLTX_LAUNCH_WLANE(576, 8); break;
+      case 57610: FLTX_LAUNCH_WLANE(576, 10); break;
+      default: return fail(FLTX_ERR_INVALID, "no fltx_wlane.h kernel for %d threads x %d positions", W, d->slane);
+    }
+#undef FLTX_LAUNCH_WLANE
   } else if (d->slane) {
     const int key = W * 100 + d->slane;
     switch (key) {
@@ -2499,8 +2542,9 @@ int launchBacktrace(fltx_decoder* d) {
   const size_t btBudget = (size_t)(d->btLdsKb > 0 ? std::min(d->btLdsKb, 144) : 140) * 1024;
   int F = (int)std::min<size_t>(btBudget / perFrame, 512);
   if (d->batchPacked) { /* the emission rows, transitions and addends of a chunk share the same LDS (amLds below) */
-    const size_t fixed = 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;
-    const size_t perAm = 4 * ((size_t)d->N + (size_t)Q.K);
+    /* (fltx_wlane.h's token sets: the tokens of the paths only, emissions and transitions read where needed) */
+    const size_t fixed = d->wlane ? 16 : 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;
+    const size_t perAm = 4 * ((d->wlane ? 0 : (size_t)d->N) + (size_t)Q.K);
     const size_t room = btBudget > fixed ? btBudget - fixed : 0;
     F = (int)std::min<size_t>((size_t)F, room / perAm);
   }
@@ -2514,13 +2558,16 @@ int launchBacktrace(fltx_decoder* d) {
   size_t btLds = F > 0 ? (size_t)F * perFrame + 16 : 16;
   if (d->batchPacked && F > 0) { /* packed records; emitting-model scores re-accumulated along the paths */
     Q.packed = d->packedBits;
+    Q.packedTokMask = d->wlane ? 0x7FFFFFFF : 0xFF;
+    Q.amGather = d->wlane ? 1 : 0;
     Q.uttStatus = d->uttStatus.as<int32_t>();
     Q.amOut = d->outScores.as<double>();
     Q.emissions = d->lastEmis;
     Q.emOff = d->emOff[d->upSlot].as<int64_t>();
     Q.N = d->N;
     Q.transitions = (d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? d->transitions.as<float>() : nullptr;
-    const size_t amLds = 4 * ((size_t)F * d->N + (Q.transitions ? (size_t)d->N * d->N : 0) + (size_t)Q.K * F) + 16;
+    const size_t amLds = Q.amGather ? 4 * (size_t)Q.K * F + 16
+                                    : 4 * ((size_t)F * d->N + (Q.transitions ? (size_t)d->N * d->N : 0) + (size_t)Q.K * F) + 16;
     btLds = std::max(btLds, amLds);
   }
 #ifdef FLTX_EMU

@@ -95,6 +95,11 @@
   FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 2, 1, false>)  \
   FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 3, 1, false>)
 #define FLTX_G14(W) FLTX_YLANE_SET(true)
+/* lane = LM state decode over a token beam of a large token set (fltx_wlane.h): (threads, list positions per wave) */
+#define FLTX_G22(W)                                   \
+  FLTX_INST(fltx_decode_kernel_wlane<576, 5>)         \
+  FLTX_INST(fltx_decode_kernel_wlane<576, 8>)         \
+  FLTX_INST(fltx_decode_kernel_wlane<576, 10>)
 
 #ifdef FLTX_INST_W
 #define FLTX_CAT2_(a, b) a##b
@@ -121,6 +126,7 @@ FLTX_G18(0)
 FLTX_G19(0)
 FLTX_G20(0)
 FLTX_G21(0)
+FLTX_G22(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -144,6 +150,7 @@ FLTX_G21(0)
 #undef FLTX_G19
 #undef FLTX_G20
 #undef FLTX_G21
+#undef FLTX_G22
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET

@@ -57,6 +57,12 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_mlane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   mlaneUtterance<GT, NG, GPW, SPW, LA>(P, fltx_smem);
 }
+/* ... for token sets beyond 64 (word pieces) with a token beam of at most 64 (fltx_wlane.h) */
+template <int W, int GT>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_wlane(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  wlaneUtterance<GT>(P, fltx_smem);
+}
 /* the frames of one decodeStep chunk of a stream on the same engine: beam in and out in the parked format of the
  * lane-per-slot step, whose kernels do decodeBegin / decodeEnd / prune / getBestHypothesis */
 template <int W, int GT>

@@ -2631,6 +2631,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
 #include "fltx_lane.h"
 #include "fltx_slane.h"
 #include "fltx_mlane.h"
+#include "fltx_wlane.h"
 #include "fltx_xlane.h"
 #include "fltx_ylane.h"
 
@@ -2942,6 +2943,8 @@ struct BacktraceParams {
    * fltx_slane.h / fltx_xlane.h / fltx_ylane.h, 10 for fltx_mlane.h, 13 for fltx_ylane.h with four lane groups;
    * 0 = plain {parent, token} records */
   int32_t packed;
+  int32_t amGather;      /* the emission (and transition) of a path's token is read from HBM where it is needed instead of staging whole rows in LDS (large token sets) */
+  int32_t packedTokMask; /* the token in y of those records: 0xFF (fltx_mlane.h keeps state-id bits above it), all bits for fltx_wlane.h */
   const int32_t* uttStatus; /* ST_PACKED per utterance (a re-run on the generic engine leaves plain records) */
   /* that engine does not carry the emitting-model score through the frames; it is
    * re-accumulated here along each returned path, in the reference's order
@@ -2984,7 +2987,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
         if (slot >= 0) {
           const int64_t idx = hb + (int64_t)fr * K + slot;
           const int2 pt = P.histPT[idx];
-          tokv = packed ? (pt.y < 0 ? pt.y : (pt.y & 0xFF)) : pt.y;
+          tokv = packed ? (pt.y < 0 ? pt.y : (pt.y & P.packedTokMask)) : pt.y;
           wv = lex ? P.histW[idx] : -1;
           slot = packed ? (((pt.x & pmask) == pmask) ? -1 : (pt.x & pmask)) : pt.x;
         }
@@ -3061,7 +3064,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
             int tokv = -1, wv = -1;
             if (s >= 0) {
               const int2 pt = cPT[j * K + s];
-              tokv = packed ? (pt.y < 0 ? pt.y : (pt.y & 0xFF)) : pt.y;
+              tokv = packed ? (pt.y < 0 ? pt.y : (pt.y & P.packedTokMask)) : pt.y;
               wv = lex ? cW[j * K + s] : -1;
               s = packed ? (((pt.x & pmask) == pmask) ? -1 : (pt.x & pmask)) : pt.x;
             }
@@ -3095,15 +3098,16 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
      * emission rows are staged F frames at a time, then hypothesis k (thread k) adds up
      * its path with LDS reads only (the chain is the additions, not the loads) */
     float* eT = (float*)smem;                       /* [F][N] */
-    float* trT = eT + (size_t)F * P.N;              /* [N][N] (ASG) */
-    int32_t* tT = (int32_t*)(trT + (P.transitions ? (size_t)P.N * P.N : 0)); /* [nh][F] */
+    float* trT = eT + (P.amGather ? 0 : (size_t)F * P.N);              /* [N][N] (ASG) */
+    int32_t* tT = (int32_t*)(trT + ((P.transitions && !P.amGather) ? (size_t)P.N * P.N : 0)); /* [nh][F] */
     const int N = P.N;
     const float* em = P.emissions + P.emOff[b];
-    if (P.transitions) {
+    if (P.transitions && !P.amGather) {
       for (int i = tid; i < N * N; i += W) {
         trT[i] = P.transitions[i];
       }
     }
+    const float* const trG = P.amGather ? P.transitions : trT;
     const int Tb = ff - 1; /* frames decoded: history rows 1 .. Tb */
     double am = 0.0;
     int prevTok = (tid < nh && len > 0) ? P.tokens[ob + (int64_t)tid * len] : 0;
@@ -3131,7 +3135,7 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
             }
           }
         }
-        const int nEm = nf * N; /* emission rows of the chunk: contiguous */
+        const int nEm = P.amGather ? 0 : nf * N; /* emission rows of the chunk: contiguous */
         for (int base = tid; base < nEm; base += 8 * W) {
           float v[8];
 #pragma unroll
@@ -3165,14 +3169,15 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              ev[u] = eT[(j0 + u < nf ? j0 + u : nf - 1) * N + (tk[u] >= 0 ? tk[u] : 0)];
+              const int jj = j0 + u < nf ? j0 + u : nf - 1;
+              ev[u] = P.amGather ? em[(size_t)(lo - 1 + jj) * N + (tk[u] >= 0 ? tk[u] : 0)] : eT[jj * N + (tk[u] >= 0 ? tk[u] : 0)];
               tr[u] = 0.0f;
             }
             if (TR) {
 #pragma unroll
               for (int u = 0; u < U; ++u) {
                 const int pv = u == 0 ? prevTok : tk[u - 1];
-                tr[u] = (tk[u] >= 0 && pv >= 0 && lo - 1 + j0 + u > 0) ? trT[tk[u] * N + pv] : 0.0f;
+                tr[u] = (tk[u] >= 0 && pv >= 0 && lo - 1 + j0 + u > 0) ? trG[(size_t)tk[u] * N + pv] : 0.0f;
               }
             }
 #pragma unroll
