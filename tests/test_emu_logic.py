@@ -294,3 +294,10 @@ def test_emulated_asg_on_the_lexicon_lane_engine(emu_session, oracle_lib, golden
     assert ok, why
     ran, served, bad = test_gpu_batches._asg_lexicon_grid(emu_session, oracle_lib, 211, lambda i: [2, 17, 9][i % 3])
     assert ran >= 10 and served == ran and not bad, (ran, served, bad[:3])
+
+
+def test_emulated_word_piece_engine(emu_session, oracle_lib):
+    """fltx_wlane.h on the emulator: a thin slice of the GPU suite's grid (tests/test_gpu_batches.py)."""
+    import test_gpu_batches
+    ran, served, bad = test_gpu_batches._word_piece_grid(emu_session, oracle_lib, 331, lambda i: [2, 11, 7][i % 3], emu=True)
+    assert ran >= 8 and served == ran and not bad, (ran, served, bad[:3])

@@ -413,3 +413,62 @@ def _asg_lexicon_grid(session, oracle_lib, every, T_of):
 def test_asg_on_the_lexicon_lane_engine(gpu_session, oracle_lib):
     ran, served, bad = _asg_lexicon_grid(gpu_session, oracle_lib, 7, lambda i: [1, 17, 90, 40][i % 4])
     assert ran > 300 and served == ran and not bad, (ran, served, bad[:8])
+
+
+def _word_piece_grid(session, oracle_lib, every, T_of, emu=False):
+    """LexiconFreeDecoder + ZeroLM over word-piece sized token sets on fltx_wlane.h (token beam <= 64, beam <= 64):
+    token-set sizes around the front end's chunk of 1 024, beams, token beams, thresholds, silScore, both criteria
+    (ASG with transitions: they enter the emitting-model score only, LexiconFreeDecoder.cpp:58-64), against the oracle."""
+    import itertools
+    bad, ran, served = [], 0, 0
+    grid = itertools.product([65, 100, 257, 1024, 1025, 3000, 8192], [1, 7, 50, 64], [1, 5, 30, 50, 64],
+                             [0.0, 3.0, 25.0, float("inf")], [0.0, -0.7, 0.4], ["ctc", "asg"], ["ctc", "uniform"])
+    for i, (N, K, Kt, thr, sil, crit, dist) in enumerate(grid):
+        if i % every:
+            continue
+        T = T_of(i)
+        if emu and N > 1100:  # (host threads: keep the emulator's share of the grid small)
+            T = min(T, 6)
+        c = cases.case("wp%d" % i, dist=dist, T=T, N=N, K=K, Kt=Kt, u=7000 + i, crit=crit, sil_score=sil, thr=thr,
+                       trans_seed=(90 + i % 5) if (crit == "asg" and N <= 1100) else None)
+        if crit == "asg" and N > 1100:
+            continue  # (an N x N transition table per case: covered at the smaller sizes)
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue
+        d = session.decoder(c, inp)
+        d.decode_batch(inp["e"], [T], N)
+        got = d.results(0)
+        srv = d.get("engine") == 4 and d.get("wlane") == 1 and d.get("redone") == 0
+        d.close()
+        served += 1 if srv else 0
+        ok, why = helpers.hyps_equal(want, got)
+        ran += 1
+        if not ok or not srv:
+            bad.append((i, (N, K, Kt, thr, sil, crit, dist, T), why or "left the engine"))
+    return ran, served, bad
+
+
+def test_word_piece_token_sets_on_the_lane_state_engine(gpu_session, oracle_lib):
+    ran, served, bad = _word_piece_grid(gpu_session, oracle_lib, 11, lambda i: [1, 23, 60, 9][i % 4])
+    assert ran > 150 and served == ran and not bad, (ran, served, bad[:6])
+
+
+@pytest.mark.parametrize("N,Kt", [(1024, 50), (8192, 50)])
+def test_word_piece_long_utterance(gpu_session, oracle_lib, N, Kt):
+    """T = 400 frames of a 1 024 / 8 192 token set, beam 50: re-entries of LM states, the front end's window following
+    the rows, the back-trace reading emissions where it needs them."""
+    c = cases.case("wp_long%d" % N, dist="ctc", T=400, N=N, K=50, Kt=Kt, u=4242)
+    inp = helpers.case_inputs(c)
+    want = helpers.run_checker(oracle_lib, c, inp)
+    d = gpu_session.decoder(c, inp)
+    d.decode_batch(inp["e"], [c["T"]], N)
+    got = d.results(0)
+    info = (d.get("engine"), d.get("wlane"), d.get("redone"))
+    d.close()
+    assert info == (4, 1, 0), info
+    if len({h.score for h in want}) != len(want):
+        pytest.skip("equal scores in the n-best")
+    ok, why = helpers.hyps_equal(want, got)
+    assert ok, why

@@ -82,6 +82,11 @@ FLTX_HD void snapUtterance(const SnapParams& Q, int b, int i0, int step) {
 #define FLTX_INST(...) extern template __global__ void __VA_ARGS__(DecodeParams);
 #include "fltx_instances.h"
 #undef FLTX_INST
+/* the front end of fltx_wlane.h: the token beam of every row of the batch, one wave per row */
+__global__ void __launch_bounds__(256) fltx_tokbeam_kernel(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_tb_smem[];
+  wlTokBeamRows(P, fltx_tb_smem);
+}
 __global__ void __launch_bounds__(512) fltx_backtrace_kernel(BacktraceParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_bt_smem[];
   backtraceUtterance(P, fltx_bt_smem);
@@ -457,6 +462,8 @@ struct fltx_decoder {
   DBuf emis[2], emOff[2], stepT[2];
   int upSlot = 0;
   DBuf histOffD, histPT, histW, stateTab, stateCtx;
+  DBuf tokRowsBuf; /* fltx_wlane.h: the token beams of all rows (fltx_tokbeam_kernel) */
+  int wlMaxT = 0;  /* ... longest utterance of the call (the front-end kernel's grid) */
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
@@ -1577,6 +1584,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       if (nTok <= g[1] * (g[0] / 64 - 2)) {
         d->slane = g[1];
         d->wlane = 1;
+        d->wlMaxT = maxT;
         d->threads = g[0];
         break;
       }
@@ -1950,6 +1958,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   int rc = 0;
   rc |= d->histOffD.ensure(sizeof(int64_t) * (B + 1), st, false);
   rc |= d->histPT.ensure(sizeof(int2) * (size_t)off, st, false);
+  if (d->wlane) {
+    rc |= d->tokRowsBuf.ensure(sizeof(WlTokRow) * ((size_t)off / (size_t)K + 1), st, false);
+  }
   if (d->kind == FLTX_DECODER_LEXICON) {
     rc |= d->histW.ensure(sizeof(int32_t) * (size_t)off, st, false);
   }
@@ -2070,6 +2081,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.gLex = d->gLex.as<uint32_t>();
   P.gTokPb = d->gTokPb.as<uint32_t>();
   P.histPT = d->histPT.as<int2>();
+  P.tokRows = d->wlane ? d->tokRowsBuf.p : nullptr;
+  P.tokRowBlocks = d->wlane ? std::max(1, (d->wlMaxT + 3) / 4) : 1;
   P.histW = d->histW.as<int32_t>();
   P.histS = d->keepScores ? d->histS.as<double>() : nullptr;
   P.histOff = d->histOffD.as<int64_t>();
@@ -2331,6 +2344,13 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     }
 #undef FLTX_LAUNCH_MLANE
   } else if (d->slane && d->wlane) {
+    { /* the token beams of all rows first (same stream) */
+      const int maxT = d->wlMaxT;
+      if (maxT > 0) {
+        hipLaunchKernelGGL(fltx_tokbeam_kernel, dim3((unsigned)(P.tokRowBlocks * nGrid)), dim3(256), 4 * sizeof(WlFrontLds),
+                           d->ctx->stream, P);
+      }
+    }
 #define FLTX_LAUNCH_WLANE(WW, GG)                                                                          \
   do {                                                                                                     \
     HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_wlane<WW, GG>,                              \

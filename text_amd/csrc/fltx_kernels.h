@@ -188,6 +188,8 @@ struct DecodeParams {
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
   unsigned long long* ymemo;    /* fltx_ylane.h / fltx_xlane.h, memo in HBM: the LM-state memo of every utterance (ymemoSlots each) */
   uint32_t ymemoSlots;          /* power of two; fltx_xlane.h: kXlMemoH */
+  int32_t tokRowBlocks;         /* fltx_tokbeam_kernel: workgroups per utterance (four rows each) */
+  void* tokRows;                /* fltx_wlane.h: the token beams of all rows (WlTokRow records), row = histOff[b] / K + t */
   int32_t tune;                 /* development: experiment bits of the lane engines (fltx_decoder_set "tune"), 0 in production */
   int32_t yRankAt;              /* tests: (lane, token) pairs beyond which a token wave of fltx_ylane.h ranks its own (0 = its rounds' capacity) */
   unsigned long long* lmCache;  /* generic step with an n-gram LM: (LM state, word) -> score of the last look-ups, kLmCache slots per utterance */

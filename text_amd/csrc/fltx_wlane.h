@@ -14,11 +14,11 @@
  *     to the token itself; cmask[lane] has a bit per list position; the token waves' skip test is a bit test
  *     with their own position numbers.  The staging wave keeps a token -> position table (posOf, one byte per
  *     token) of the newest list, which the build step reads for the records it writes;
- *   * the staging wave is a front end: it reads the row of N emissions from HBM a frame ahead (up to 1 024 of
- *     them stay in registers between the frames; longer rows are read again pass by pass), finds the
- *     beamSizeToken largest with the histogram selection the frames use (a window over the float bits of the
- *     distance to the row's largest, the members of the one boundary bin ranked pairwise, ties to the lower
- *     token) and writes the list in token order;
+ *   * the token beams are found before the decode kernel starts, by a kernel of their own (fltx_tokbeam_kernel: one
+ *     wave per row of N emissions, all rows of the batch in parallel): the histogram selection the frames use (a
+ *     window over the float bits of the distance to the row's largest, the members of the one boundary bin ranked
+ *     pairwise, ties to the lower token), the list written in token order, one 416-byte record per row; the staging
+ *     wave of the decode kernel takes a record per frame, a frame ahead;
  *   * "this (LM state, token) edge had a child before" (LMState::child's memo, lm/LM.h:24-34) is a Bloom filter
  *     over (state id, token) in LDS -- two bits per edge in 512 Kbit -- instead of a 64-bit mask per lane: a
  *     hit, true or false, makes the next frame look the edge up in the history rows (slReenter's scan, which finds the
@@ -59,9 +59,6 @@ struct WlaneLds {
   uint32_t bOrd[kSlBCap];
   uint32_t evLane[64], evSpar[64], evTok[64];
   uint32_t scanMin, pad0;
-  uint32_t fhist[kSlNB];           /* front end: counts of the row's values per bin */
-  unsigned long long fKey[kSlBCap]; /* ... members of the boundary bin: value key << 32 | ~token */
-  uint32_t fScal[4];
   uint32_t bloom[kWlBloomWords];
   uint8_t posOf[kWlMaxN];          /* token -> position in the newest list (the frame after the current one), 0xFF = not listed */
 };
@@ -134,44 +131,68 @@ FLTX_DEV __attribute__((noinline)) void wlReenter(WlaneLds& S, const int2* histP
   ldsBarrier();
 }
 
-/* ---- front end: the token beam of one row ------------------------------------------------------------------- */
-struct WlFront {
-  float rv[kWlRowRegs]; /* chunk 0 of the row the next call stages, loaded a frame ahead */
-  int fShift, fBase;    /* window of the value histogram: where the beamSizeToken-th largest was a row ago */
-  double bestChain;     /* best candidate of the newest staged frame */
+/* ---- front end: the token beams of all rows, a kernel of its own ------------------------------------------------ */
+/* Which tokens a frame works with does not depend on the beam: the beamSizeToken largest emissions of every row of the
+ * batch are found by fltx_tokbeam_kernel before the decode kernel starts -- one wave per row, all rows of all
+ * utterances in parallel over the chip (inside the decode kernel the same selection was one wave's serial work per
+ * frame: 15 k .. 23 k clocks against the 4 k of the frame's own) -- and left in HBM as one 416-byte record per row. */
+struct WlTokRow {
+  float e[64];       /* emissions of the listed tokens (in the token beam, not blank), in token order */
+  uint16_t tok[64];  /* ... the tokens */
+  float eBlank;      /* blank's emission, NaN when blank is not in the token beam (or the criterion has none) */
+  float eSil;        /* sil's emission when it is in the token beam */
+  uint32_t ek;       /* order key of the largest emission in the token beam other than sil's (blank's included), 0 = none */
+  int32_t nList;
+  int32_t silPos;    /* list position of sil, -4096 = not listed */
+  uint32_t flags;    /* bit 0: sil is in the token beam; bit 1: the row cannot be cut (NaN, or more equal values at the
+                        cut than the pairwise list holds): the utterance goes to the general engines */
+  uint32_t pad[2];
+};
+static_assert(sizeof(WlTokRow) == 416, "one record per row");
+constexpr int kWlShift = 18;    /* the counting pass after the coarse one: 32 bins per octave */
+constexpr int kWlPairwise = 16; /* members of the boundary bin ranked against each other; beyond that the bin is looked at again */
+
+struct WlFrontLds { /* per wave of the front-end kernel */
+  uint32_t fhist[kSlNB];            /* counts of the row's values per bin */
+  unsigned long long fKey[kSlBCap]; /* members of the boundary bin: value key << 32 | ~token */
+  unsigned long long fSel[kWlMaxN / 64]; /* those of them the token beam takes: a bit per value of the row */
+  uint32_t fScal[4];
 };
 
-FLTX_DEV void wlLoadChunk(const float* row, int N, int chunk, float (&v)[kWlRowRegs], bool any) {
+FLTX_DEV void wlLoadChunk(const float* row, int N, int chunk, float (&v)[kWlRowRegs]) {
   const int lane = laneId();
 #pragma unroll
   for (int k = 0; k < kWlRowRegs; ++k) {
     const int idx = chunk * (64 * kWlRowRegs) + k * 64 + lane;
-    v[k] = (any && idx < N) ? row[idx] : -__builtin_huge_valf();
+    v[k] = idx < N ? row[idx] : -__builtin_huge_valf();
   }
 }
 
-/* Stages row `r` of the utterance into parity q: list (eTok / tokTok / posOf), blank's emission, the frame's best
- * candidate.  One wave.  `oldList`: the positions of parity q^1's list are taken out of posOf first. */
-FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const float* em, int r, int T, int q, bool ctc,
-                         double silScore, int nListOld) {
+/* The token beam of one row = its Kt largest values (LexiconFreeDecoder.cpp:42-51).  One wave.  A counting pass over
+ * a window of the float bits of the distance to the row's largest (16 bins per octave, 2^-7 .. 2^9; the two ends of a
+ * window would take hundreds of counts on one LDS address and are counted with ballots instead), one scan; a bin
+ * with more than a handful of members is looked at again through the finest window that spans it; the members of
+ * the bin that holds the Kt-th largest are then ranked against each other (value, then the lower token) by one lane
+ * each, and the winners marked in a bitmap over the row.  The list is written in token order. */
+FLTX_DEV void wlTokBeamRow(const DecodeParams& P, WlFrontLds& S, const float* row, WlTokRow* out, bool ctc) {
   const int lane = laneId();
   const int N = P.N, Kt = P.Kt < 64 ? P.Kt : 64;
-  const int nChunk = (N + 64 * kWlRowRegs - 1) / (64 * kWlRowRegs);
-  const float* row = em + (size_t)r * N;
+  constexpr int CH = 64 * kWlRowRegs;
+  const int nChunk = (N + CH - 1) / CH;
   const float NEGF = -__builtin_huge_valf();
   float v[kWlRowRegs];
-  bool anyNan = false;
+  int lastChunk = -1;
+  auto chunk = [&](int c) { /* -> v: this lane's sixteen values of chunk c (rows of up to 1 024 tokens: read once) */
+    if (c != lastChunk) {
+      lastChunk = c;
+      wlLoadChunk(row, N, c, v);
+    }
+  };
   /* pass A: the row's largest value */
+  bool anyNan = false;
   float mx = NEGF;
   for (int c = 0; c < nChunk; ++c) {
-    if (c == 0) {
-#pragma unroll
-      for (int k = 0; k < kWlRowRegs; ++k) {
-        v[k] = F.rv[k];
-      }
-    } else {
-      wlLoadChunk(row, N, c, v, true);
-    }
+    chunk(c);
 #pragma unroll
     for (int k = 0; k < kWlRowRegs; ++k) {
       anyNan = anyNan || !(v[k] == v[k]);
@@ -181,7 +202,7 @@ FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const f
   const uint32_t mxKey = waveMax32((mx == mx && mx > NEGF) ? f32Key(mx) : 0u);
   const bool rowBad = waveBallot(anyNan) != 0ull || mxKey == 0u;
   const float rowMax = mxKey != 0u ? f32FromKey(mxKey) : 0.0f;
-  auto binOf = [&](float x, int shift, int base) -> int { /* NaN / -inf: beyond everything */
+  auto binOf = [&](float x, int shift, int base) -> int { /* -inf (and NaN): not a candidate */
     const float d = rowMax - x;
     if (!(d == d) || !(x > NEGF)) {
       return kSlInvalid;
@@ -190,43 +211,38 @@ FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const f
     qn = qn < 0 ? 0 : qn;
     return qn > kSlNB - 1 ? kSlNB - 1 : qn;
   };
-  /* pass B: counts per bin, the bin of the Kt-th largest; the rare cases as in the frames' selection */
-  int shift = F.fShift, base = F.fBase;
-  int lim = -1;
-  int need = 0, nBnd = 0; /* boundary bin: members kept, members listed in fKey */
-  int bstar = -1;
+  /* pass B: counts per bin and the bin of the Kt-th largest */
+  int shift = kSlCoarseShift, base = kSlCoarseBase;
+  int lim = -1, need = 0, nBnd = 0, bstar = -1;
   unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
-  bool first = true, giveUp = rowBad;
+  bool giveUp = rowBad;
   SlScan sc = {};
   while (!giveUp) {
     ((uint4*)S.fhist)[lane] = make_uint4(0u, 0u, 0u, 0u);
     waveSync();
+    int nNear = 0, nFarV = 0;
     for (int c = 0; c < nChunk; ++c) {
-      if (c == 0) {
-#pragma unroll
-        for (int k = 0; k < kWlRowRegs; ++k) {
-          v[k] = F.rv[k];
-        }
-      } else {
-        wlLoadChunk(row, N, c, v, true);
-      }
+      chunk(c);
 #pragma unroll
       for (int k = 0; k < kWlRowRegs; ++k) {
         const int b = binOf(v[k], shift, base);
-        /* (first pass: what lies beyond the window is not counted -- most of the row --, later passes count all) */
-        if (b < (first ? kSlFar : kSlInvalid)) {
+        nNear += b == 0 ? 1 : 0;
+        nFarV += b == kSlNB - 1 ? 1 : 0;
+        if (b > 0 && b < kSlNB - 1) {
           atomAdd32(&S.fhist[b], 1u);
         }
       }
     }
+    nNear = (int)waveReadLane32((uint32_t)waveInclusiveScan(nNear), 63);
+    nFarV = (int)waveReadLane32((uint32_t)waveInclusiveScan(nFarV), 63);
+    if (lane == 0) {
+      S.fhist[0] = (uint32_t)nNear;
+      S.fhist[kSlNB - 1] = (uint32_t)nFarV;
+    }
     waveSync();
     sc = slScan(S.fhist, Kt, false);
-    if (first && !sc.crossed) { /* fewer than Kt inside the window: count again with the far ones */
-      first = false;
-      continue;
-    }
-    if (sc.total <= Kt) {
-      lim = kSlFar;
+    if (sc.total <= Kt) { /* fewer values than the token beam takes: all of them */
+      lim = kSlNB - 1;
       break;
     }
     need = Kt - sc.cum;
@@ -234,33 +250,43 @@ FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const f
       lim = sc.bstar;
       break;
     }
-    if (sc.cnt <= kSlBCap) { /* the members of the boundary bin: the larger values, ties to the lower token */
+    if (sc.cnt <= kWlPairwise || (bLo >= bHi && sc.cnt <= kSlBCap)) { /* the members of the boundary bin: the larger values, ties to the lower token */
       bstar = sc.bstar;
       lim = sc.bstar - 1;
+      nBnd = sc.cnt;
       if (lane == 0) {
         S.fScal[0] = 0u;
       }
+      for (int i = lane; i < 8 * nChunk; i += 64) { /* (the winners' bitmap: a bit per value of the row) */
+        ((uint4*)S.fSel)[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
       waveSync();
       for (int c = 0; c < nChunk; ++c) {
-        if (c == 0) {
-#pragma unroll
-          for (int k = 0; k < kWlRowRegs; ++k) {
-            v[k] = F.rv[k];
-          }
-        } else {
-          wlLoadChunk(row, N, c, v, true);
-        }
+        chunk(c);
 #pragma unroll
         for (int k = 0; k < kWlRowRegs; ++k) {
           if (binOf(v[k], shift, base) == bstar) {
-            const uint32_t tok = (uint32_t)(c * (64 * kWlRowRegs) + k * 64 + lane);
+            const uint32_t tok = (uint32_t)(c * CH + k * 64 + lane);
             const uint32_t i = atomAdd32(&S.fScal[0], 1u);
             S.fKey[i] = ((unsigned long long)f32Key(v[k] + 0.0f) << 32) | (unsigned long long)(~tok);
           }
         }
       }
       waveSync();
-      nBnd = sc.cnt;
+      for (int m0 = 0; m0 < nBnd; m0 += 64) { /* member m0 + lane: its rank among the members */
+        const int m = m0 + lane;
+        const unsigned long long mine = S.fKey[m < nBnd ? m : 0];
+        int rank = 0;
+#pragma unroll 4
+        for (int i = 0; i < nBnd; ++i) {
+          rank += S.fKey[i] > mine ? 1 : 0;
+        }
+        if (m < nBnd && rank < need) {
+          const uint32_t tok = ~(uint32_t)mine;
+          atomOr64(&S.fSel[tok >> 6], 1ull << (tok & 63u));
+        }
+      }
+      waveSync();
       break;
     }
     { /* too many in one bin: the finest window that spans its bracket */
@@ -273,9 +299,12 @@ FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const f
         const unsigned long long h2 = ((vv + 1ull) << shift) - 1ull;
         bHi = h2 < bHi ? h2 : bHi;
       }
-      if (bLo >= bHi) { /* more equal values at the cut than the pairwise list holds */
-        giveUp = true;
-        break;
+      if (bLo >= bHi) { /* one value of the distance, and many of it: the next pass ranks them pairwise, or gives up */
+        if (sc.cnt > kSlBCap) {
+          giveUp = true;
+          break;
+        }
+        continue;
       }
       int ns = 0;
       while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
@@ -283,47 +312,28 @@ FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const f
       }
       shift = ns;
       base = (int)(bLo >> ns);
-      first = false;
     }
   }
-  if (!giveUp && sc.total > Kt) { /* next row's window: the Kt-th largest in the middle, 128 bins per octave */
-    const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
-                                          : (sc.bstar + base) >> (kSlFineShift - shift);
-    F.fShift = kSlFineShift;
-    F.fBase = q15 > kSlMid ? q15 - kSlMid : 0;
-  }
-  /* the old list leaves the position table (its tokens: parity q ^ 1) */
-  if (lane < nListOld) {
-    S.posOf[S.tokTok[q ^ 1][lane]] = (uint8_t)kWlNoPos;
-  }
-  waveSync();
   /* pass C: the list, in token order */
   int nList = 0;
   float eBlankF = __builtin_nanf(""), eSilF = 0.0f;
   int silPos = -4096;
   bool silSel = false; /* sil is in the token beam (listed, unless it is the blank) */
-  uint32_t ek = 0u; /* order key of the largest listed emission other than sil's (blank's included) */
+  uint32_t ek = 0u;
   for (int c = 0; c < nChunk && !giveUp; ++c) {
-    if (c == 0) {
-#pragma unroll
-      for (int k = 0; k < kWlRowRegs; ++k) {
-        v[k] = F.rv[k];
-      }
-    } else {
-      wlLoadChunk(row, N, c, v, true);
-    }
+    chunk(c);
+    /* (the winners' words of this chunk: lane k holds word k) */
+    const unsigned long long fsMine = nBnd > 0 ? S.fSel[c * kWlRowRegs + (lane & (kWlRowRegs - 1))] : 0ull;
 #pragma unroll
     for (int k = 0; k < kWlRowRegs; ++k) {
-      const int tok = c * (64 * kWlRowRegs) + k * 64 + lane;
-      const int b = binOf(v[k], shift, base);
+      const int tok = c * CH + k * 64 + lane;
+      const float x = v[k];
+      const int b = binOf(x, shift, base);
       bool sel = b <= lim;
-      if (b == bstar && nBnd > 0) {
-        const unsigned long long mine = ((unsigned long long)f32Key(v[k] + 0.0f) << 32) | (unsigned long long)(~(uint32_t)tok);
-        int rank = 0;
-        for (int i = 0; i < nBnd; ++i) {
-          rank += S.fKey[i] > mine ? 1 : 0;
-        }
-        sel = rank < need;
+      if (nBnd > 0) {
+        const unsigned long long w = ((unsigned long long)waveReadLane32((uint32_t)(fsMine >> 32), k) << 32) |
+                                     (unsigned long long)waveReadLane32((uint32_t)fsMine, k);
+        sel = sel || ((w >> lane) & 1ull) != 0ull;
       }
       const bool isBlank = ctc && tok == P.blank;
       const unsigned long long selAll = waveBallot(sel);
@@ -332,21 +342,20 @@ FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const f
       }
       const unsigned long long bal = waveBallot(sel && !isBlank);
       if (sel && isBlank) {
-        eBlankF = v[k];
+        eBlankF = x;
       }
       if (sel && tok != P.sil) {
-        const uint32_t kk = f32Key(v[k]);
+        const uint32_t kk = f32Key(x);
         ek = kk > ek ? kk : ek;
       }
       if (sel && tok == P.sil) {
-        eSilF = v[k];
+        eSilF = x;
         silSel = true;
       }
       if (sel && !isBlank) {
         const int pos = nList + wavePrefixCount(bal);
-        S.eTok[q][pos] = (double)v[k];
-        S.tokTok[q][pos] = (uint32_t)tok;
-        S.posOf[tok] = (uint8_t)pos;
+        out->e[pos] = x;
+        out->tok[pos] = (uint16_t)tok;
         if (tok == P.sil) {
           silPos = pos;
         }
@@ -366,20 +375,81 @@ FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const f
     eSilF = __uint_as_float(waveReadLane32(__float_as_uint(eSilF), sl));
     silPos = (int)waveReadLane32((uint32_t)silPos, sl);
   }
-  if (lane >= nList) {
-    S.eTok[q][lane] = __builtin_nan("");
-    S.tokTok[q][lane] = 0u;
+  if (lane == 0) {
+    out->eBlank = eBlankF;
+    out->eSil = eSilF;
+    out->ek = ek;
+    out->nList = nList;
+    out->silPos = silPos;
+    out->flags = (silAt != 0ull ? 1u : 0u) | (giveUp ? 2u : 0u);
+  }
+}
+
+/* the front-end kernel: workgroup = utterance * tokRowBlocks + row block, (row block) * (waves per workgroup) + wave = row */
+FLTX_DEV void wlTokBeamRows(const DecodeParams& P, char* smem) {
+  const int wave = waveUniform(waveId());
+  const int ub = (int)blockIdx.x / P.tokRowBlocks, rb = (int)blockIdx.x % P.tokRowBlocks;
+  const int b = P.uttMap ? P.uttMap[ub] : ub;
+  const int t = rb * ((int)blockDim.x >> 6) + wave;
+  const int T = P.stepT ? P.stepT[b] : 0;
+  if (t >= T) {
+    return;
+  }
+  WlFrontLds& S = ((WlFrontLds*)smem)[wave];
+  const float* row = P.emissions + P.emOff[b] + (size_t)t * P.N;
+  WlTokRow* out = (WlTokRow*)P.tokRows + (P.histOff[b] / P.K + t);
+  wlTokBeamRow(P, S, row, out, P.criterion == 1);
+}
+
+struct WlFront {
+  double bestChain; /* best candidate of the newest staged frame */
+  /* the record of the row the next call stages, loaded a frame ahead: lane l holds list position l */
+  float pe;
+  uint32_t ptok;
+  float pBlank, pSil;
+  uint32_t pEk, pFlags;
+  int32_t pNList, pSilPos;
+};
+FLTX_DEV void wlRowPrefetch(const DecodeParams& P, WlFront& F, int64_t rowIdx, bool any) {
+  const int lane = laneId();
+  const WlTokRow* rec = (const WlTokRow*)P.tokRows + rowIdx;
+  if (any) {
+    F.pe = rec->e[lane];
+    F.ptok = (uint32_t)rec->tok[lane];
+    F.pBlank = rec->eBlank;
+    F.pSil = rec->eSil;
+    F.pEk = rec->ek;
+    F.pFlags = rec->flags;
+    F.pNList = rec->nList;
+    F.pSilPos = rec->silPos;
+  }
+}
+/* Stages the prefetched row into parity q: list (eTok / tokTok / posOf), blank's emission, the frame's best candidate.
+ * One wave.  nListOld: the positions of parity q ^ 1's list are taken out of posOf first. */
+FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, int64_t rowIdxNext, bool anyNext, int q,
+                         double silScore, int nListOld) {
+  const int lane = laneId();
+  if (lane < nListOld) {
+    S.posOf[S.tokTok[q ^ 1][lane]] = (uint8_t)kWlNoPos;
+  }
+  waveSync();
+  const int nList = F.pNList;
+  const bool listed = lane < nList;
+  S.eTok[q][lane] = listed ? (double)F.pe : __builtin_nan("");
+  S.tokTok[q][lane] = listed ? F.ptok : 0u;
+  if (listed) {
+    S.posOf[F.ptok] = (uint8_t)lane;
   }
   /* best candidate of the frame: best hypothesis (= the last frame's best candidate) + best token, sil priced apart */
   const double mmax = F.bestChain;
   double best = 0.0;
   bool any = false;
-  if (ek != 0u) {
-    best = mmax + (double)f32FromKey(ek);
+  if (F.pEk != 0u) {
+    best = mmax + (double)f32FromKey(F.pEk);
     any = true;
   }
-  if (silAt != 0ull) {
-    const double sS = (mmax + (double)eSilF) + silScore;
+  if (F.pFlags & 1u) {
+    const double sS = (mmax + (double)F.pSil) + silScore;
     if (sS == sS && (!any || sS > best)) {
       best = sS;
       any = true;
@@ -389,13 +459,12 @@ FLTX_DEV void wlStageRow(const DecodeParams& P, WlaneLds& S, WlFront& F, const f
   if (lane == 0) {
     S.row[q].best = best;
     S.row[q].thr = best - P.beamThreshold;
-    S.row[q].eBlank = (double)eBlankF;
+    S.row[q].eBlank = (double)F.pBlank;
     S.row[q].nList = nList;
-    S.row[q].silPos = silPos;
-    S.row[q].dead = (giveUp || !any || !(best - best == 0.0)) ? 1u : 0u;
+    S.row[q].silPos = F.pSilPos;
+    S.row[q].dead = ((F.pFlags & 2u) || !any || !(best - best == 0.0)) ? 1u : 0u;
   }
-  /* the row after this one: its first chunk on its way into the registers */
-  wlLoadChunk(em + (size_t)(r + 1) * N, N, 0, F.rv, r + 1 < T);
+  wlRowPrefetch(P, F, rowIdxNext, anyNext); /* the row after this one on its way into the registers */
 }
 
 template <int GT>
@@ -464,17 +533,20 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
   }
   ldsBarrier();
   WlFront F;
-  F.fShift = kSlCoarseShift;
-  F.fBase = kSlCoarseBase;
   F.bestChain = 0.0; /* decodeBegin: the root hypothesis, score 0 */
-#pragma unroll
-  for (int k = 0; k < kWlRowRegs; ++k) {
-    F.rv[k] = 0.0f;
-  }
+  F.pe = 0.0f;
+  F.ptok = 0u;
+  F.pBlank = 0.0f;
+  F.pSil = 0.0f;
+  F.pEk = 0u;
+  F.pFlags = 0u;
+  F.pNList = 0;
+  F.pSilPos = -4096;
+  const int64_t rowBase = hbase / K; /* this utterance's records of fltx_tokbeam_kernel */
   if (wave == prepWave) {
-    wlLoadChunk(em, N, 0, F.rv, T > 0);
+    wlRowPrefetch(P, F, rowBase, T > 0);
     if (T > 0) {
-      wlStageRow(P, S, F, em, 0, T, 0, ctc, silScore, 0);
+      wlStageRow(P, S, F, rowBase + 1, T > 1, 0, silScore, 0);
     } else if (lane == 0) {
       S.row[0].nList = 0;
     }
@@ -491,6 +563,17 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
   bool dead = false; /* this utterance goes to the general engines */
   const int blank = P.blank;
   int2* const histPT = P.histPT;
+  /* per-phase clocks of one thread (bench.py --profile: the marks of fltx_slane.h) */
+  unsigned long long acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long tPrev = devClock();
+  const bool profMe = P.prof != nullptr && tid == P.profThread;
+  auto mark = [&](int i) {
+    if (profMe) {
+      const unsigned long long t_ = devClock();
+      acc[i] += t_ - tPrev;
+      tPrev = t_;
+    }
+  };
 
   auto frameStep = [&](auto PT, auto RL, const int t) {
     constexpr int p = decltype(PT)::value, q = p ^ 1;
@@ -557,6 +640,7 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
       par = S.rec[p][pl >= 0 ? pl : 0];
       eLast = S.eTok[p][lastPos < 64u ? lastPos : 0u];
     }
+    mark(0);
     double cs[GT];
     int cbin[GT];
     uint32_t parR = kSlNoHyp;
@@ -566,11 +650,12 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
         cs[j] = NEG;
         cbin[j] = kSlInvalid;
       }
-      /* the front end: the next frame's list, position table and best candidate, while the other waves evaluate
-       * this frame's candidates (everything it writes belongs to the next frame; the position table is read by the
-       * build below, after the second barrier, and by nothing before that) */
+      /* the next frame's list (found by the front-end kernel, on its way since the last frame), position table and
+       * best candidate, while the other waves evaluate this frame's candidates (everything written here belongs to
+       * the next frame; the position table is read by the build below, after the second barrier, and by nothing
+       * before that) */
       if (t + 1 < T) {
-        wlStageRow(P, S, F, em, t + 1, T, q, ctc, silScore, nList);
+        wlStageRow(P, S, F, rowBase + t + 2, t + 2 < T, q, silScore, nList);
       }
     } else if (!isSelf) {
       /* positions this lane does not extend with here: its own last token's (the repeat and the blank-then-last case
@@ -653,6 +738,7 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
         atomAdd32(&S.hist[p][cbin[j]], 1u);
       }
     }
+    mark(1);
     ldsBarrier(); /* 1 */
     /* ---- phase 2: which candidates survive (Utils.h:200-220; as fltx_slane.h) ------------ */
     unsigned long long selMask[GT];
@@ -779,6 +865,7 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
       winShift = kSlFineShift;
       winBase = q15 > kSlMid ? q15 - kSlMid : 0;
     }
+    mark(2);
     /* new lanes: survivors first (self wave), then the new states wave by wave */
     int nNewWave = 0;
     int myNew[GT];
@@ -821,6 +908,7 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
       }
     }
+    mark(3);
     ldsBarrier(); /* 2 */
     /* ---- phase 3: every survivor is written by the lane that evaluated it ---------------- */
     const int nSurv = (int)S.scal[SL_NSURV], nHSurv = (int)S.scal[SL_NHSURV];
@@ -896,7 +984,9 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
     }
     nState = nSurv + nNew;
     endBest = best;
+    mark(4);
     ldsBarrier(); /* 3 */
+    mark(5);
   };
   auto frames = [&](auto RL) {
     int t = 0;
@@ -962,5 +1052,11 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
     P.uttFrame[b] = ff;
     P.uttTotal[b] = ff;
     P.uttStatus[b] = ST_SELECT_FALLBACK;
+  }
+  if (profMe) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      P.prof[(size_t)b * 8 + i] = acc[i];
+    }
   }
 }
