@@ -508,120 +508,108 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
     ldsBarrier(); /* 1 */
     /* ---- phase 2: which candidates survive (Utils.h:200-220) ---------------------------- */
     unsigned long long selMask[NC];
-    /* (the usual frame in a straight line, the rare cases in a loop out of its way: see fltx_slane.h) */
-    SlScan sc = slScan(S.hist[p], K, true);
+    /* (the loop form: the straight-line form of fltx_slane.h costs the eight-group geometry a fifth of its frame --
+     * beam 500 on the C2 shape 22.7 -> 27.6 ms -- and gains the others 2 %) */
+    SlScan sc;
     int shift = winShift, base = winBase;
-    int lim = -1;
-    uint32_t take = 0u;
-    bool usual = false;
-    if (sc.crossed) {
-      if (sc.total <= K) {
-        lim = kSlFar - 1;
-        usual = true;
-      } else if (sc.cnt == K - sc.cum) {
-        lim = sc.bstar;
-        usual = true;
-      }
-    }
-    if (__builtin_expect(usual, 1)) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        selMask[c] = waveBallot(cbin[c] <= lim);
-      }
-    } else {
-      unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
-      bool full = false;
-      for (;;) {
-        if (!full && !sc.crossed) {
-          int nFar = 0;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            nFar += popc64(waveBallot(cbin[c] == kSlFar));
-          }
-          if (lane == 0 && nFar > 0) {
-            atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
-          }
-          full = true;
-          ldsBarrier();
-          sc = slScan(S.hist[p], K, false);
-          continue;
-        }
-        if (sc.total <= K) {
-          lim = full ? kSlFar : kSlFar - 1;
-          break;
-        }
-        const int need = K - sc.cum;
-        if (sc.cnt == need) {
-          lim = sc.bstar;
-          break;
-        }
-        if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            if (cbin[c] == sc.bstar) {
-              const uint32_t i = atomAdd32(&S.scal[ML_BCNT], 1u);
-              S.bKey[i] = f64Key(csAt(c));
-              S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
-            }
-          }
-          ldsBarrier();
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            if (cbin[c] == sc.bstar) {
-              const unsigned long long k = f64Key(csAt(c));
-              const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
-              int rank = 0;
-              for (int i = 0; i < sc.cnt; ++i) {
-                const unsigned long long k2 = S.bKey[i];
-                rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
-              }
-              take |= rank < need ? (1u << c) : 0u;
-            }
-          }
-          lim = sc.bstar - 1;
-          break;
-        }
-        { /* too many in one bin: look again through the finest window that spans the bracket */
-          const unsigned long long v = (unsigned long long)(sc.bstar + base);
-          if (sc.bstar > 0 || base == 0) {
-            const unsigned long long l2 = v << shift;
-            bLo = l2 > bLo ? l2 : bLo;
-          }
-          if (sc.bstar < kSlNB - 1) {
-            const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
-            bHi = h2 < bHi ? h2 : bHi;
-          }
-          if (bLo >= bHi) {
-            dead = true;
-            break;
-          }
-          int ns = 0;
-          while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
-            ++ns;
-          }
-          shift = ns;
-          base = (int)(bLo >> ns);
-        }
-        ldsBarrier();
-        for (int i = tid; i < kSlNB; i += W) {
-          S.hist[p][i] = 0u;
-        }
-        ldsBarrier();
-        full = true;
+    unsigned long long bLo = 0ull, bHi = 0x7FFFFFFFull;
+    bool full = false;
+    for (;;) {
+      sc = slScan(S.hist[p], K, !full);
+      if (!full && !sc.crossed) {
+        int nFar = 0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          if (cbin[c] != kSlInvalid) {
-            cbin[c] = slBin<LA>(best, csAt(c), shift, base);
-            atomAdd32(&S.hist[p][cbin[c]], 1u);
+          nFar += popc64(waveBallot(cbin[c] == kSlFar));
+        }
+        if (lane == 0 && nFar > 0) {
+          atomAdd32(&S.hist[p][kSlFar], (uint32_t)nFar);
+        }
+        full = true;
+        ldsBarrier();
+        continue;
+      }
+      if (sc.total <= K) {
+        const int lim = full ? kSlFar : kSlFar - 1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          selMask[c] = waveBallot(cbin[c] <= lim);
+        }
+        break;
+      }
+      const int need = K - sc.cum;
+      if (sc.cnt == need) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          selMask[c] = waveBallot(cbin[c] <= sc.bstar);
+        }
+        break;
+      }
+      if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
+        uint32_t take = 0u;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (cbin[c] == sc.bstar) {
+            const uint32_t i = atomAdd32(&S.scal[ML_BCNT], 1u);
+            S.bKey[i] = f64Key(csAt(c));
+            S.bOrd[i] = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
           }
         }
         ldsBarrier();
-        sc = slScan(S.hist[p], K, false);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (cbin[c] == sc.bstar) {
+            const unsigned long long k = f64Key(csAt(c));
+            const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
+            int rank = 0;
+            for (int i = 0; i < sc.cnt; ++i) {
+              const unsigned long long k2 = S.bKey[i];
+              rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
+            }
+            take |= rank < need ? (1u << c) : 0u;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          selMask[c] = waveBallot(cbin[c] < sc.bstar || ((take >> c) & 1u) != 0u);
+        }
+        break;
       }
+      { /* too many in one bin: look again through the finest window that spans the bracket */
+        const unsigned long long v = (unsigned long long)(sc.bstar + base);
+        if (sc.bstar > 0 || base == 0) {
+          const unsigned long long l2 = v << shift;
+          bLo = l2 > bLo ? l2 : bLo;
+        }
+        if (sc.bstar < kSlNB - 1) {
+          const unsigned long long h2 = ((v + 1ull) << shift) - 1ull;
+          bHi = h2 < bHi ? h2 : bHi;
+        }
+        if (bLo >= bHi) {
+          dead = true;
+          break;
+        }
+        int ns = 0;
+        while (((bHi >> ns) - (bLo >> ns)) > (unsigned long long)(kSlNB - 1)) {
+          ++ns;
+        }
+        shift = ns;
+        base = (int)(bLo >> ns);
+      }
+      ldsBarrier();
+      for (int i = tid; i < kSlNB; i += W) {
+        S.hist[p][i] = 0u;
+      }
+      ldsBarrier();
+      full = true;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        selMask[c] = waveBallot(cbin[c] <= lim || ((take >> c) & 1u) != 0u);
+        if (cbin[c] != kSlInvalid) {
+          cbin[c] = slBin<LA>(best, csAt(c), shift, base);
+          atomAdd32(&S.hist[p][cbin[c]], 1u);
+        }
       }
+      ldsBarrier();
     }
     if (dead) {
       return;
