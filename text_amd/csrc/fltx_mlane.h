@@ -91,21 +91,11 @@ FLTX_DEV void mlReenter(LDS& S, const int2* histPT, int q, int nState, int64_t h
     ldsBarrier();
     const unsigned long long* h = (const unsigned long long*)(histPT + hbase);
     uint32_t found = 0xFFFFFFFFu;
-    for (int64_t i0 = tid; i0 < nRec; i0 += 8 * (int64_t)W) { /* (eight loads in flight: see slReenter) */
-      unsigned long long rr[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t i = i0 + (int64_t)u * W;
-        rr[u] = i < nRec ? loadCoherent64(h + i) : 0ull;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t i = i0 + (int64_t)u * W;
-        const unsigned long long r = rr[u];
-        const uint32_t x = (uint32_t)r, y = (uint32_t)(r >> 32);
-        if (i < nRec && (x & kMlNewFlag) && (r >> 63) == 0ull && (y & 0xFFu) == n && mlParentSid(x, y) == ps) {
-          found = found < (uint32_t)i ? found : (uint32_t)i;
-        }
+    for (int64_t i = tid; i < nRec; i += W) {
+      const unsigned long long r = loadCoherent64(h + i);
+      const uint32_t x = (uint32_t)r, y = (uint32_t)(r >> 32);
+      if ((x & kMlNewFlag) && (r >> 63) == 0ull && (y & 0xFFu) == n && mlParentSid(x, y) == ps) {
+        found = found < (uint32_t)i ? found : (uint32_t)i;
       }
     }
     if (found != 0xFFFFFFFFu) {
@@ -115,20 +105,11 @@ FLTX_DEV void mlReenter(LDS& S, const int2* histPT, int q, int nState, int64_t h
     const uint32_t sid = S.scanMin;
     if (sid != 0xFFFFFFFFu) {
       unsigned long long kids = 0ull;
-      for (int64_t i0 = tid; i0 < nRec; i0 += 8 * (int64_t)W) {
-        unsigned long long rr[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int64_t i = i0 + (int64_t)u * W;
-          rr[u] = i < nRec ? loadCoherent64(h + i) : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const unsigned long long r = rr[u];
-          const uint32_t x = (uint32_t)r, y = (uint32_t)(r >> 32);
-          if ((x & kMlNewFlag) && (r >> 63) == 0ull && mlParentSid(x, y) == sid) { /* (0 past the end: no flag) */
-            kids |= 1ull << (y & 63u);
-          }
+      for (int64_t i = tid; i < nRec; i += W) {
+        const unsigned long long r = loadCoherent64(h + i);
+        const uint32_t x = (uint32_t)r, y = (uint32_t)(r >> 32);
+        if ((x & kMlNewFlag) && (r >> 63) == 0ull && mlParentSid(x, y) == sid) {
+          kids |= 1ull << (y & 63u);
         }
       }
       if (kids) {
