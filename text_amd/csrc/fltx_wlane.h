@@ -33,6 +33,8 @@ constexpr int kWlMaxN = 16384;        /* tokens the position table covers */
 constexpr int kWlBloomWords = 16384;  /* 64 KB = 2^19 bits */
 constexpr int kWlRowRegs = 16;        /* row values a lane of the front end holds: one chunk of 1 024 tokens */
 constexpr uint32_t kWlNoPos = 0xFFu;
+constexpr int kWlEdgeSlots = 4096;    /* direct-mapped memo of the newest (state id, token) -> child state id edges, 32 KB */
+constexpr uint32_t kWlNoSid = 0xFFFFFFFFu;
 
 struct WlRow { /* what a frame needs to know about its emission row */
   double best;    /* the frame's best candidate (Utils.h:131-137) */
@@ -58,7 +60,9 @@ struct WlaneLds {
   unsigned long long bKey[kSlBCap];
   uint32_t bOrd[kSlBCap];
   uint32_t evLane[64], evSpar[64], evTok[64];
+  uint32_t evSid[64];              /* the state's id when the edge memo still had it (no look-up in the history rows), else kWlNoSid */
   uint32_t scanMin, pad0;
+  unsigned long long edge[kWlEdgeSlots]; /* bit 63 | parent id:23 << 37 | token:14 << 23 | child id:23 */
   uint32_t bloom[kWlBloomWords];
   uint8_t posOf[kWlMaxN];          /* token -> position in the newest list (the frame after the current one), 0xFF = not listed */
 };
@@ -79,19 +83,41 @@ FLTX_DEV bool wlEdgeSeen(WlaneLds& S, uint32_t sid, uint32_t tok) {
   return (o1 & b1) != 0u && (o2 & b2) != 0u;
 }
 
+FLTX_DEV unsigned long long wlEdgePack(uint32_t psid, uint32_t tok, uint32_t csid) {
+  return (1ull << 63) | ((unsigned long long)(psid & 0x7FFFFFu) << 37) | ((unsigned long long)(tok & 0x3FFFu) << 23) |
+         (unsigned long long)(csid & 0x7FFFFFu);
+}
+FLTX_DEV uint32_t wlEdgeSlot(uint32_t psid, uint32_t tok) { return wlHash(psid, tok, 0x5bd1e995u) & (uint32_t)(kWlEdgeSlots - 1); }
+
 /* Re-entry of LM states (see slReenter): the earliest history record {new state, parent id, token} names the
  * state of a lane whose edge the filter had seen; lanes whose parent id it is get their link back.  All waves. */
 FLTX_DEV __attribute__((noinline)) void wlReenter(WlaneLds& S, const int2* histPT, int q, int nState, int64_t hbase,
                                                    int64_t nRec) {
   const int tid = (int)threadIdx.x, W = (int)blockDim.x;
   const int nev = (int)S.row[q].nev;
-#ifndef FLTX_EMU
-  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's history stores have reached the L2 */
-#endif
-  ldsBarrier();
+  ldsBarrier(); /* (everybody has read the count before the first one through resets it) */
+  bool settled = false; /* the history stores of the last build have reached the L2 (needed by the look-ups only) */
   for (int e = 0; e < nev; ++e) {
     const int X = (int)S.evLane[e];
     const uint32_t ps = S.evSpar[e], n = S.evTok[e];
+    const uint32_t known = S.evSid[e]; /* (uniform) */
+    if (known != kWlNoSid) { /* the edge memo had the state's id: the record carries it already; its orphans: */
+      if (tid < nState && tid != X && S.rec[q][tid].spar == known) {
+        const uint32_t info = S.rec[q][tid].info;
+        S.rec[q][tid].info = (info & ~0xFF00u) | ((uint32_t)(X + 1) << 8);
+        if ((info & 0xFFu) < 64u) {
+          atomOr64(&S.cmask[q][X], 1ull << (info & 0xFFu));
+        }
+      }
+      continue;
+    }
+    if (!settled) { /* (waiting for a wave's stores costs 2 - 4 k clocks: only when the rows are read) */
+      settled = true;
+#ifndef FLTX_EMU
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      ldsBarrier();
+    }
     if (tid == 0) {
       S.scanMin = 0xFFFFFFFFu;
     }
@@ -120,6 +146,9 @@ FLTX_DEV __attribute__((noinline)) void wlReenter(WlaneLds& S, const int2* histP
     }
     ldsBarrier();
     const uint32_t sid = S.scanMin;
+    if (sid != 0xFFFFFFFFu && tid == 0) {
+      S.edge[wlEdgeSlot(ps, n)] = wlEdgePack(ps, n, sid); /* (the memo learns the edge, again or for the first time) */
+    }
     if (sid != 0xFFFFFFFFu && sid != S.rec[q][X].sid) { /* (its own record: the filter's hit was a false one) */
       ldsBarrier();
       if (tid == 0) {
@@ -514,6 +543,9 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
   for (int i = tid; i < kWlBloomWords / 4; i += W) {
     ((uint4*)S.bloom)[i] = make_uint4(0u, 0u, 0u, 0u);
   }
+  for (int i = tid; i < kWlEdgeSlots / 2; i += W) {
+    ((uint4*)S.edge)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   for (int i = tid; i < kWlMaxN / 16; i += W) {
     ((uint4*)S.posOf)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
   }
@@ -585,6 +617,14 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
     }
   };
 
+  /* the first list position of this token wave, kept in a vector register: as a scalar the compiler derives sixteen more
+   * scalars per frame from it (position numbers, 64-bit masks), which the frame loop has no scalar registers for --
+   * it recomputed and spilled them at the head of every frame */
+  int posBase = wave * GT;
+#ifndef FLTX_EMU
+  __asm__ volatile("" : "+v"(posBase));
+#endif
+
   auto frameStep = [&](auto PT, auto RL, const int t) {
     constexpr int p = decltype(PT)::value, q = p ^ 1;
     constexpr bool isSelf = decltype(RL)::value == 1, isSvc = decltype(RL)::value == 2;
@@ -614,7 +654,7 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
     } else if (!isSvc) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
-        const int pos = wave * GT + j;
+        const int pos = posBase + j;
         ev[j] = pos < 64 ? S.eTok[p][pos < 64 ? pos : 0] : __builtin_nan("");
         tk[j] = S.tokTok[p][pos < 64 ? pos : 0];
       }
@@ -674,7 +714,7 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
       const unsigned long long skip = live ? (cm | (lastPos < 64u ? 1ull << lastPos : 0ull)) : ~0ull;
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
-        const int pos = wave * GT + j;
+        const int pos = posBase + j;
         double c = m + ev[j]; /* NaN past the end of the list */
         if (pos == silPos) {
           c = c + silScore;
@@ -938,6 +978,17 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
       r.spar = me.sid;
       r.pad = n;
       const bool again = wlEdgeSeen(S, me.sid, n); /* this edge may have had a child before */
+      const uint32_t eslot = wlEdgeSlot(me.sid, n);
+      uint32_t known = kWlNoSid;
+      if (again) { /* ... and the memo may still know which: the state keeps its id, the history rows are not searched */
+        const unsigned long long cur = S.edge[eslot];
+        if ((cur >> 23) == (wlEdgePack(me.sid, n, 0u) >> 23)) {
+          known = (uint32_t)cur & 0x7FFFFFu;
+          r.sid = known;
+        }
+      } else {
+        S.edge[eslot] = wlEdgePack(me.sid, n, r.sid);
+      }
       S.rec[q][nl] = r;
       if (myNewLane >= 0 && np < 64u) {
         atomOr64(&S.cmask[q][myNewLane], 1ull << np);
@@ -948,6 +999,7 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
         S.evLane[e] = (uint32_t)nl;
         S.evSpar[e] = me.sid;
         S.evTok[e] = n;
+        S.evSid[e] = known;
       }
     };
     if (isSvc) {
