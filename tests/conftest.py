@@ -59,9 +59,12 @@ def emu_session():
         glob.glob(os.path.join(ROOT, "tests", "emu", "*.h")) + \
         glob.glob(os.path.join(ROOT, "tests", "emu", "*.cpp")) + \
         [os.path.join(ROOT, "tests", "emu", "build.sh")]
-    if (not os.path.exists(helpers.EMU_LIB) or
-            os.path.getmtime(helpers.EMU_LIB) < max(os.path.getmtime(s) for s in src)):
-        subprocess.run([os.path.join(ROOT, "tests", "emu", "build.sh")], check=True)
+    import fcntl
+    with open(os.path.join(ROOT, "tests", "emu", ".build.lock"), "w") as lock:  # (pytest-xdist: one worker builds, the others wait)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if (not os.path.exists(helpers.EMU_LIB) or
+                os.path.getmtime(helpers.EMU_LIB) < max(os.path.getmtime(s) for s in src)):
+            subprocess.run([os.path.join(ROOT, "tests", "emu", "build.sh")], check=True)
     return helpers.FltxSession(helpers.EMU_LIB)
 
 

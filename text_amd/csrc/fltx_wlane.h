@@ -21,8 +21,9 @@
  *     wave of the decode kernel takes a record per frame, a frame ahead;
  *   * "this (LM state, token) edge had a child before" (LMState::child's memo, lm/LM.h:24-34) is a Bloom filter
  *     over (state id, token) in LDS -- two bits per edge in 512 Kbit -- instead of a 64-bit mask per lane: a
- *     hit, true or false, makes the next frame look the edge up in the history rows (slReenter's scan, which finds the
- *     new record itself when the hit was false), so the filter only has to be free of false negatives.
+ *     hit, true or false, makes the next frame look the edge up -- first in an exact direct-mapped memo of the newest
+ *     4 096 edges in LDS, then in the history rows (slReenter's scan, which finds the new record itself when the hit
+ *     was false) --, so the filter only has to be free of false negatives.
  *
  * Roles and barriers as in fltx_slane.h: token waves (GT list positions each), one wave for the lanes' own groups
  * (blank, repeat + the parent state's extension, blank-then-last), the staging wave; three barriers per frame.
