@@ -19,7 +19,7 @@ def main():
     cfg = dict(bench.WORKLOADS[wl])
     res = []
     for sset in ([], sets):
-        args = types.SimpleNamespace(tokens=29, threads=0, set=sset)
+        args = types.SimpleNamespace(tokens=29, threads=0, set=sset, asg=False, log_add=False, frames=0, beam=0, beam_token=0)
         job = bench.Job(args, 0, 0, B, cfg)
         d = job.decoder()
         d.decode_batch(job.e_host, job.Ts, job.N)
