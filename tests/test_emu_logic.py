@@ -301,3 +301,25 @@ def test_emulated_word_piece_engine(emu_session, oracle_lib):
     import test_gpu_batches
     ran, served, bad = test_gpu_batches._word_piece_grid(emu_session, oracle_lib, 331, lambda i: [2, 11, 7][i % 3], emu=True)
     assert ran >= 8 and served == ran and not bad, (ran, served, bad[:3])
+
+
+def test_emulated_word_piece_fallback_reaches_the_generic_engine(emu_session):
+    """a row without a defined token beam makes fltx_wlane.h flag its utterance; that utterance --
+    and only that one -- is decoded again on the generic engine, the others keep their packed (wide-token) records."""
+    from text_amd import synth
+    N, T, B = 300, 12, 3
+    c = cases.case("wp_ties_emu", dist="ctc", T=T, N=N, K=20, Kt=30, u=515)
+    e = synth.batch("ctc", B, T, N)
+    e[1, 5, :] = -3.0
+    d = emu_session.decoder(c, dict(tr=None))
+    d.decode_batch(e, [T] * B, N)
+    assert (d.get("engine"), d.get("wlane"), d.get("redone")) == (4, 1, 1)
+    g = emu_session.decoder(c, dict(tr=None))
+    g.set("wlane", 0)
+    g.decode_batch(e, [T] * B, N)
+    assert g.get("engine") != 4
+    for b in range(B):
+        ok, why = helpers.hyps_equal(g.results(b), d.results(b))
+        assert ok, "utterance %d: %s" % (b, why)
+    d.close()
+    g.close()

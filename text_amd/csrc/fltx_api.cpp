@@ -422,9 +422,13 @@ struct fltx_decoder {
   bool preferYlane = false;
   bool genericAsked = false;  /* fltx_decoder_set touched a tunable of the generic engine */
   int engineFirst = 0;
+  /* diagnostics of the engine a call STARTED on (a retry's prepare() must not overwrite them) */
+  int64_t whyFirst = 0;
+  int wlaneFirst = 0, slaneFirst = 0, laneGroupsFirst = 0, xlaneFirst = 0, ylaneFirst = 0;
   int lastRedo = 0;           /* utterances of the last offline call that had to be decoded again on a general path */
   int packedBits = 8;         /* width of the parent-slot field of those records (fltx_mlane.h: 10) */
   bool batchPacked = false;   /* some utterance of the current results has packed history records (ST_PACKED) */
+  bool batchWlane = false;    /* ... written by fltx_wlane.h (tokens beyond a byte, emissions gathered by the back-trace) */
   DBuf xlmword;               /* fltx_ylane.h: LM word id of XNode::endLabel0 per node (this decoder's trie x LM) */
   const fltx_trie* xlmwordTrie = nullptr;
   const fltx_lm* xlmwordLm = nullptr;
@@ -1247,9 +1251,9 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
   if (!strcmp(key, "engine")) { /* the engine the last call started on ("redone" counts what it handed on) */
     *value = d->engineFirst;
   } else if (!strcmp(key, "xlane")) {
-    *value = d->xlane;
+    *value = d->xlaneFirst;
   } else if (!strcmp(key, "ylane")) {
-    *value = d->ylane;
+    *value = d->ylaneFirst;
   } else if (!strcmp(key, "yshare")) {
     *value = (d->ylane || d->xlane) ? d->yshare : 0;
   } else if (!strcmp(key, "redone")) {
@@ -1259,16 +1263,16 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
   } else if (!strcmp(key, "stream_redone")) {
     *value = d->streamRedone;
   } else if (!strcmp(key, "wlane")) { /* 1: the last call ran on fltx_wlane.h (token sets beyond 64) */
-    *value = d->wlane;
+    *value = d->wlaneFirst;
   } else if (!strcmp(key, "slane")) {
-    *value = d->slane;
+    *value = d->slaneFirst;
   } else if (!strcmp(key, "fallback_reasons")) {
     *value = d->fallbackReasons;
   } else if (!strcmp(key, "why_not_lane")) { /* FLTX_WHY_* (include/fltx.h): why the last call did not start on a lane engine */
-    *value = d->whyNotLane;
+    *value = d->whyFirst;
   } else if (!strcmp(key, "lane_groups")) { /* lane groups of the lane = LM state engine: 1 = fltx_slane.h, 2 / 4 / 8 = fltx_mlane.h;
                                                 fltx_ylane.h: 1 / 2 / 4 */
-    *value = d->slane ? std::max(1, d->mlaneNG) : d->ylane;
+    *value = d->laneGroupsFirst;
   } else if (!strcmp(key, "ymemo_slots")) {
     *value = (d->ylane || d->xlane) && d->yshare ? (int64_t)d->ymemoSlots : 0;
   } else if (!strcmp(key, "lane")) {
@@ -1460,6 +1464,16 @@ constexpr int kMlaneGeoCount = (int)(sizeof(kMlaneGeo) / sizeof(kMlaneGeo[0]));
 
 int engineOf(const fltx_decoder* d) {
   return d->ylane ? 6 : d->xlane ? 5 : (d->slane ? 4 : (d->lane ? 3 : (d->lean ? 2 : (d->dense ? 1 : 0))));
+}
+/* what fltx_decoder_get reports about the engine a call started on */
+void latchFirst(fltx_decoder* d) {
+  d->engineFirst = engineOf(d);
+  d->whyFirst = d->whyNotLane;
+  d->wlaneFirst = d->wlane;
+  d->slaneFirst = d->slane;
+  d->xlaneFirst = d->xlane;
+  d->ylaneFirst = d->ylane;
+  d->laneGroupsFirst = d->slane ? std::max(1, d->mlaneNG) : d->ylane;
 }
 
 int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstCaseCap) {
@@ -1741,7 +1755,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
               (d->opt.criterion == FLTX_CRITERION_CTC && (d->blank < 0 || d->blank >= N))) ? FLTX_WHY_OPTIONS : 0;
       why |= ((int64_t)K * (maxT + 2) >= (lexi || K <= 64 ? (1ll << 23) - 1 : (1ll << 31) - 1)) ? FLTX_WHY_LENGTH : 0;
       why |= (d->noSlane || d->noXlane || d->noYlane || d->genericAsked || d->forceGlobalWs || d->noLean || d->noDense ||
-              d->userLaneGroups < 0 || forceWorstCaseCap) ? FLTX_WHY_SWITCHED_OFF : 0;
+              d->userLaneGroups < 0 || forceWorstCaseCap || (d->offlineCall && d->keepScores) ||
+              (!lexi && N > 64 && d->noWlane)) ? FLTX_WHY_SWITCHED_OFF : 0;
+      why |= (!lexi && N > 64 && d->opt.log_add) ? FLTX_WHY_LOGADD : 0; /* (fltx_wlane.h has no logAdd variant) */
       why |= (!lexi && nListAll > 70) ? FLTX_WHY_GEOMETRY : 0;
       if (!why) {
         why = FLTX_WHY_GEOMETRY; /* (no compiled geometry covers this token list / thread count) */
@@ -2563,8 +2579,8 @@ int launchBacktrace(fltx_decoder* d) {
   int F = (int)std::min<size_t>(btBudget / perFrame, 512);
   if (d->batchPacked) { /* the emission rows, transitions and addends of a chunk share the same LDS (amLds below) */
     /* (fltx_wlane.h's token sets: the tokens of the paths only, emissions and transitions read where needed) */
-    const size_t fixed = d->wlane ? 16 : 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;
-    const size_t perAm = 4 * ((d->wlane ? 0 : (size_t)d->N) + (size_t)Q.K);
+    const size_t fixed = d->batchWlane ? 16 : 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;
+    const size_t perAm = 4 * ((d->batchWlane ? 0 : (size_t)d->N) + (size_t)Q.K);
     const size_t room = btBudget > fixed ? btBudget - fixed : 0;
     F = (int)std::min<size_t>((size_t)F, room / perAm);
   }
@@ -2578,8 +2594,8 @@ int launchBacktrace(fltx_decoder* d) {
   size_t btLds = F > 0 ? (size_t)F * perFrame + 16 : 16;
   if (d->batchPacked && F > 0) { /* packed records; emitting-model scores re-accumulated along the paths */
     Q.packed = d->packedBits;
-    Q.packedTokMask = d->wlane ? 0x7FFFFFFF : 0xFF;
-    Q.amGather = d->wlane ? 1 : 0;
+    Q.packedTokMask = d->batchWlane ? 0x7FFFFFFF : 0xFF;
+    Q.amGather = d->batchWlane ? 1 : 0;
     Q.uttStatus = d->uttStatus.as<int32_t>();
     Q.amOut = d->outScores.as<double>();
     Q.emissions = d->lastEmis;
@@ -2836,9 +2852,10 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   bool recomputeRetry = false; /* this attempt is the recompute form of the cut-off generation */
   bool recomputeTried = false;
   const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
-  const int savedNoSlane = d->noSlane, savedNoXlane = d->noXlane, savedNoYlane = d->noYlane;
+  const int savedNoSlane = d->noSlane, savedNoXlane = d->noXlane, savedNoYlane = d->noYlane, savedNoWlane = d->noWlane;
   d->offlineCall = true;
   d->batchPacked = false;
+  d->batchWlane = false;
   d->keepScores = d->userKeepScores; /* a stream on this decoder had switched the score history on */
   for (int attempt = 0; attempt < 3; ++attempt) {
     const bool finalForm = attempt > 0 && !recomputeRetry; /* the general path: nothing left to fall back to */
@@ -2856,9 +2873,10 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     d->batchPacked = d->batchPacked || d->slane || d->xlane || d->ylane;
     if (d->slane || d->xlane || d->ylane) {
       d->packedBits = (d->slane && d->mlaneNG > 1) ? 10 : (d->ylane == 4 ? 13 : 8); /* (a re-run on a general engine leaves plain records) */
+      d->batchWlane = d->wlane != 0; /* ... and so is the records' token width (the back-trace reads it, not d->wlane) */
     }
     if (attempt == 0) {
-      d->engineFirst = engineOf(d);
+      latchFirst(d);
     }
     if ((rc = bumpEpoch(d))) {
       return rc;
@@ -2885,12 +2903,12 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
       return rc;
     }
     const bool cutMode = d->CAP2 > 0 || d->cutRecompute;
-    if (!finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->xlane || d->ylane)) {
+    if (!finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->wlane || d->xlane || d->ylane)) {
       d->resultsSynced = false;
       if ((rc = syncResults(d))) {
         return rc;
       }
-      bool ws = false, cut = false, lean = false, slaneMiss = false, xlaneMiss = false;
+      bool ws = false, cut = false, lean = false, slaneMiss = false, xlaneMiss = false, wlaneMiss = false;
       const bool slimMode = d->CAP2 > 0;
       std::vector<int32_t> again;
       const int nScan = attempt == 0 ? B : (int)redoList.size();
@@ -2904,13 +2922,15 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         const bool c = (st & ST_CUT_RETRY) && cutMode;
         const bool l = (st & ST_SELECT_FALLBACK) && d->lean;
         const bool x = (st & ST_SELECT_FALLBACK) && (d->xlane || d->ylane);
-        if (o || c || l || x) {
+        const bool wl = (st & ST_SELECT_FALLBACK) && d->wlane; /* fltx_wlane.h: a row without a defined token beam, a select that did not converge */
+        if (o || c || l || x || wl) {
           again.push_back(b);
           ws |= o;
           cut |= c;
           lean |= l;
           slaneMiss |= l && d->slane;
           xlaneMiss |= x;
+          wlaneMiss |= wl;
         }
       }
       redoList.swap(again);
@@ -2932,6 +2952,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         d->noCut = cut ? 1 : d->noCut;
         d->noLean = lean ? 1 : d->noLean;
         d->noSlane = slaneMiss ? 1 : d->noSlane; /* (re-run on the generic engine) */
+        d->noWlane = wlaneMiss ? 1 : d->noWlane;
         d->noXlane = xlaneMiss ? 1 : d->noXlane;
         d->noYlane = xlaneMiss ? 1 : d->noYlane;
         d->resultsSynced = false;
@@ -2947,6 +2968,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     d->noLean = savedNoLean;
     d->noSlim = savedNoSlim;
     d->noSlane = savedNoSlane;
+    d->noWlane = savedNoWlane;
     d->noXlane = savedNoXlane;
     d->noYlane = savedNoYlane;
   }
@@ -2997,7 +3019,7 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   if (d->streamOpt && d->hStat.ensure(4 * (size_t)B)) {
     return fail(FLTX_ERR_OOM, "pinned status allocation failed");
   }
-  d->engineFirst = engineOf(d);
+  latchFirst(d);
   if ((rc = bumpEpoch(d))) {
     return rc;
   }
