@@ -37,7 +37,8 @@ enum {
   FLTX_ERR_OOM = 3,         /* device allocation failed */
   FLTX_ERR_UNSUPPORTED = 4, /* configuration the device path does not cover */
   FLTX_ERR_RANGE = 5,       /* index out of range (std::out_of_range) */
-  FLTX_ERR_STATE = 6        /* call sequence error (e.g. results before decode) */
+  FLTX_ERR_STATE = 6,       /* call sequence error (e.g. results before decode) */
+  FLTX_ERR_CALLBACK = 7     /* a host-LM callback reported failure (the binding rethrows what the user's LM threw) */
 };
 
 /* CriterionType, decoder/Decoder.h:16 (S2S is out of scope). */
@@ -101,6 +102,37 @@ FLTX_API int fltx_lm_ngram_create(fltx_ctx* ctx, int32_t order, int64_t n_ngrams
  * (index = user dictionary index) to an LM word id, unknown strings to <unk>.
  * No device is needed until a decoder is created with the LM. */
 FLTX_API int fltx_lm_arpa_load(const char* path, const char* usr_words, fltx_lm** out);
+/* A user-defined LM: any subclass of `LM` (decoder/lm/LM.h:61-85), e.g. through the reference's Python trampoline
+ * PyLM (bindings/python/flashlight/lib/text/_decoder.cpp:39-56).  It has no tables to flatten, so LM::start / score /
+ * finish stay calls into host code -- but the beam search does not: candidates, merge, prune and history run in the
+ * HIP kernels as for every other LM.  Once per frame a kernel lists the (LM state, index) pairs the frame's candidate
+ * generation will ask about, for the whole batch; the library asks the callbacks below about each DISTINCT pair
+ * once (what LMState::child's memo gives the reference, lm/LM.h:24-34: LM::score must be a function of its arguments)
+ * and uploads the answers; the frame's kernel reads them.  The shape is the reference's own for LMs that batch
+ * their queries (decoder/lm/ConvLM.cpp:144-240 behind Utils.h:346-354 updateLMCache).
+ *
+ * LM states cross this boundary as int32 ids, per utterance, handed out by the callee: 0 is what LM::start returned;
+ * `score` must return the SAME id whenever the user's LM returns the same LMState object and a new id otherwise --
+ * the reference merges hypotheses on the state's address (lm/LM.h:37-49), the kernels merge on this id.
+ * Every callback returns 0, or non-zero to abort the decode call with FLTX_ERR_CALLBACK.  Callbacks are made on the
+ * thread that called the decoder, never concurrently (decoder/Utils.h:60-62).  Not usable with fltx_group_*. */
+typedef struct fltx_host_lm {
+  void* user;
+  /* decodeBegin: LM::start(false) (LexiconFreeDecoder.cpp:24, LexiconDecoder.cpp:24) for utterances 0 .. n_utt-1;
+   * ids of an earlier decode on this decoder are void */
+  int32_t (*start)(void* user, int32_t n_utt);
+  /* n questions: idx[i] >= 0: LM::score(state[i] of utterance utt[i], idx[i]); idx[i] == -1: LM::finish(state[i]).
+   * out_state[i] = id of the returned state, out_score[i] = the returned score */
+  int32_t (*score)(void* user, int32_t n, const int32_t* utt, const int32_t* state, const int32_t* idx,
+                   int32_t* out_state, float* out_score);
+  /* may be NULL.  LM::updateCache(states of utterance utt's beam) after every frame (Utils.h:346-354) */
+  int32_t (*update_cache)(void* user, int32_t utt, int32_t n, const int32_t* states);
+  /* may be NULL.  After Decoder::prune: only these states of utterance utt are still held by a hypothesis; ids of
+   * the others will not be passed again and their LMState objects may be released (what dropping the pruned
+   * hypotheses' shared_ptrs does in the reference, Utils.h:312-342) */
+  int32_t (*retain)(void* user, int32_t utt, int32_t n, const int32_t* states);
+} fltx_host_lm;
+FLTX_API int fltx_lm_host_create(const fltx_host_lm* callbacks, fltx_lm** out);
 FLTX_API int fltx_lm_destroy(fltx_lm* lm);
 /* LM::start + LM::score chain + optional LM::finish on the device tables
  * (decoder/lm/LM.h:61-78); per_word may be NULL.  Used by known-answer tests
@@ -286,8 +318,8 @@ enum {
   FLTX_WHY_TOKENS = 1,        /* more than 64 tokens (lexicon-free decoder: a token BEAM of more than 64, or more than 16 384 tokens) */
   FLTX_WHY_BEAM = 2,          /* beam beyond the lane groups (lexicon-free: 512, lexicon: 256) */
   FLTX_WHY_STREAM = 4,        /* a stream the lane engines do not serve (lexicon streams, logAdd streams) */
-  FLTX_WHY_LM = 8,            /* LM kind (token-level LM; n-gram LM on the lexicon-free decoder) */
-  FLTX_WHY_LOGADD = 16,       /* lexicon decoder with logAdd */
+  FLTX_WHY_LM = 8,            /* LM kind (token-level LM; n-gram LM on the lexicon-free decoder; a host LM, fltx_lm_host_create) */
+  FLTX_WHY_LOGADD = 16,       /* lexicon decoder with logAdd; lexicon-free decoder with logAdd over more than 64 tokens */
   FLTX_WHY_ASG = 32,          /* lexicon decoder with the ASG criterion */
   FLTX_WHY_UNK = 64,          /* lexicon decoder with <unk> enabled (unk_score > -inf) */
   FLTX_WHY_TRIE_SHAPE = 128,  /* trie without a breadth-first layout (several labels per spelling, not a tree) */

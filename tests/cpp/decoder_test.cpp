@@ -46,12 +46,39 @@ std::vector<T> readBin(const std::string& path, size_t n) {
   return v;
 }
 
-struct CustomLM : LM { /* an LM with no device form */
+/* user-defined LMs: subclasses of LM without device tables (the reference's extension point, lm/LM.h:61-85).  The
+ * decoders run them through the per-frame host exchange (decoder/lm/HostLM.h), the search stays on the device. */
+struct CustomLM : LM {
   LMStatePtr start(bool) override { return std::make_shared<LMState>(); }
   std::pair<LMStatePtr, float> score(const LMStatePtr& s, const int i) override {
-    return {s->child<LMState>(i), -1.0f};
+    ++calls;
+    return {s->child<LMState>(i), -0.125f * (float)(i % 7)};
   }
+  std::pair<LMStatePtr, float> finish(const LMStatePtr& s) override { return {s, -0.5f}; }
+  void updateCache(std::vector<LMStatePtr> states) override { cacheCalls += 1; lastCache = states.size(); }
+  long calls = 0, cacheCalls = 0;
+  size_t lastCache = 0;
+};
+struct ZeroClone : LM { /* lm/ZeroLM.cpp:14-26 as a user would write it */
+  LMStatePtr start(bool) override { return std::make_shared<LMState>(); }
+  std::pair<LMStatePtr, float> score(const LMStatePtr& s, const int i) override { return {s->child<LMState>(i), 0.0f}; }
   std::pair<LMStatePtr, float> finish(const LMStatePtr& s) override { return {s, 0.0f}; }
+};
+struct WrappedLM : LM { /* delegates to another LM: same states, same scores, but no deviceHandle() */
+  explicit WrappedLM(LMPtr in) : inner(std::move(in)) {}
+  LMStatePtr start(bool n) override { return inner->start(n); }
+  std::pair<LMStatePtr, float> score(const LMStatePtr& s, const int i) override { return inner->score(s, i); }
+  std::pair<LMStatePtr, float> finish(const LMStatePtr& s) override { return inner->finish(s); }
+  LMPtr inner;
+};
+struct ThrowingLM : ZeroClone {
+  std::pair<LMStatePtr, float> score(const LMStatePtr& s, const int i) override {
+    if (++n > 100) {
+      throw std::domain_error("user LM failed on purpose");
+    }
+    return ZeroClone::score(s, i);
+  }
+  int n = 0;
 };
 
 static bool sameResult(const DecodeResult& a, const DecodeResult& b) {
@@ -230,13 +257,75 @@ int main(int argc, char** argv) {
     threw = true;
   }
   ASSERT_TRUE(threw);
-  threw = false;
-  try {
-    LexiconFreeDecoder bad(fopt, std::make_shared<CustomLM>(), silIdx, N - 1, {});
-  } catch (const std::runtime_error&) {
-    threw = true; /* no device tables and no CPU fallback */
+
+  /* -------- user-defined LM subclasses (lm/LM.h:61-85): search on the device, LM on the host -------- */
+  {
+    /* a ZeroLM written by the user == the device's ZeroLM */
+    LexiconFreeDecoder zdec(fopt, std::make_shared<ZeroClone>(), silIdx, N - 1, {});
+    auto zr = zdec.decode(emission.data(), T, N);
+    ASSERT_EQ(zr.size(), off.size());
+    for (size_t i = 0; i < std::min(zr.size(), off.size()); ++i) {
+      ASSERT_TRUE(sameResult(zr[i], off[i]));
+    }
+    /* KenLM behind a user subclass == KenLM on the device tables (LexiconDecoder, the fixture's lexicon) */
+    LexiconDecoderOptions o2{60, 25000, 50.0, 2.0, 2.0, -std::numeric_limits<float>::infinity(), -1, false,
+                             CriterionType::ASG};
+    LexiconDecoder dDev(o2, trie, lm, silIdx, blankIdx, unkIdx, transitions, false);
+    LexiconDecoder dUsr(o2, trie, std::make_shared<WrappedLM>(lm), silIdx, blankIdx, unkIdx, transitions, false);
+    auto rDev = dDev.decode(emission.data(), T, N);
+    auto rUsr = dUsr.decode(emission.data(), T, N);
+    ASSERT_TRUE(!rDev.empty());
+    ASSERT_EQ(rDev.size(), rUsr.size());
+    for (size_t i = 0; i < std::min(rDev.size(), rUsr.size()); ++i) {
+      ASSERT_TRUE(sameResult(rDev[i], rUsr[i]));
+    }
+    /* a scoring user LM on the lexicon-free decoder: offline == streaming chunks; updateCache is called per frame
+     * with the beam's states (Utils.h:346-354); prune() releases the states the beam no longer holds */
+    auto custom = std::make_shared<CustomLM>();
+    LexiconFreeDecoderOptions copt{12, 8, 25.0, 1.5, -0.25, false, CriterionType::CTC};
+    LexiconFreeDecoder cdec(copt, custom, silIdx, N - 1, {});
+    auto c1 = cdec.decode(emission.data(), T, N);
+    ASSERT_EQ((int)c1.size(), 12);
+    ASSERT_TRUE(custom->calls > 0);
+    ASSERT_EQ(custom->cacheCalls, (long)T);
+    ASSERT_TRUE(custom->lastCache >= 1 && custom->lastCache <= 12);
+    ASSERT_TRUE(c1[0].lmScore < 0.0);
+    cdec.decodeBegin();
+    int tc = 0;
+    for (int chunk : {1, 30, 64, 140}) {
+      cdec.decodeStep(emission.data() + (size_t)tc * N, chunk, N);
+      tc += chunk;
+    }
+    cdec.decodeEnd();
+    auto c2 = cdec.getAllFinalHypothesis();
+    ASSERT_EQ(c1.size(), c2.size());
+    for (size_t i = 0; i < std::min(c1.size(), c2.size()); ++i) {
+      ASSERT_TRUE(sameResult(c1[i], c2[i]));
+    }
+    cdec.decodeBegin();
+    cdec.decodeStep(emission.data(), 120, N);
+    const size_t before = cdec.hostLmStates();
+    cdec.prune(10);
+    ASSERT_TRUE(cdec.hostLmStates() <= 12 && cdec.hostLmStates() < before);
+    cdec.decodeStep(emission.data() + (size_t)120 * N, T - 120, N);
+    cdec.decodeEnd();
+    auto c3 = cdec.getAllFinalHypothesis();
+    ASSERT_EQ(c3.size(), c1.size());
+    if (!c3.empty() && !c1.empty()) {
+      std::vector<int> tailA(c3[0].tokens.end() - 50, c3[0].tokens.end());
+      std::vector<int> tailB(c1[0].tokens.end() - 50, c1[0].tokens.end());
+      ASSERT_TRUE(tailA == tailB);
+    }
+    /* what the user's LM throws is what the decode call throws */
+    threw = false;
+    try {
+      LexiconFreeDecoder tdec(fopt, std::make_shared<ThrowingLM>(), silIdx, N - 1, {});
+      tdec.decode(emission.data(), T, N);
+    } catch (const std::domain_error&) {
+      threw = true;
+    }
+    ASSERT_TRUE(threw);
   }
-  ASSERT_TRUE(threw);
 
   std::cout << (g_fail ? "FAILED" : "PASSED") << " (" << g_fail << " failures)\n";
   return g_fail ? 1 : 0;

@@ -32,6 +32,10 @@ struct int2 {
 };
 static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
 static inline int2 make_int2(int a, int b) { return int2{a, b}; }
+struct uint2 {
+  uint32_t x, y;
+};
+static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }
 
 struct EmuDim {
   unsigned x;

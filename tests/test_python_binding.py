@@ -261,3 +261,107 @@ def test_replabels_and_contiguity_known_answers():
     d2.add_entry("z", 1)
     assert d2.is_contiguous() and d2.entry_size() == 3 and d2.index_size() == 2
     assert d2.map_entries_to_indices(["z", "x"]) == [1, 0] and d2.map_indices_to_entries([1, 0]) == ["z", "x"]
+
+
+@pytest.mark.gpu
+def test_python_lm_subclass_decodes_on_the_device(gpu_session, golden, oracle_lib):
+    """The reference's PyLM extension point (bindings/python/flashlight/lib/text/_decoder.cpp:39-56): a Python
+    subclass of `LM` passed to the decoders.  (i) a ZeroLM clone reproduces the reference's golden n-best for C1;
+    (ii) a Python LM over the KenLM object's scores equals the device n-gram path; (iii) a Python exception raised
+    inside score() is what decode() raises."""
+    import cases
+    from flashlight.lib.text.decoder import (LM, CriterionType, KenLM, LexiconDecoder, LexiconDecoderOptions,
+                                             LexiconFreeDecoder, LexiconFreeDecoderOptions, LMState, SmearingMode,
+                                             Trie, ZeroLM)
+    from flashlight.lib.text.dictionary import Dictionary
+
+    class PyZero(LM):
+        def __init__(self):
+            LM.__init__(self)
+            self.calls = 0
+
+        def start(self, start_with_nothing):
+            return LMState()
+
+        def score(self, state, idx):
+            self.calls += 1
+            return state.child(idx), 0.0
+
+        def finish(self, state):
+            return state, 0.0
+
+    c = cases.BY_NAME["C1_ctc_u0"]
+    inp = helpers.case_inputs(c)
+    e = np.ascontiguousarray(inp["e"], dtype=np.float32)
+    opts = LexiconFreeDecoderOptions(beam_size=c["K"], beam_size_token=c["Kt"], beam_threshold=c["thr"], lm_weight=0.0,
+                                     sil_score=0.0, log_add=False, criterion_type=CriterionType.CTC)
+    user = PyZero()
+    dec = LexiconFreeDecoder(opts, user, 0, c["N"] - 1, [])
+    res = dec.decode(e.ctypes.data, c["T"], c["N"])
+    assert user.calls > 0
+    exp = golden["C1_ctc_u0"]
+    assert len(res) == exp["n"]
+    for r, sc in zip(res, exp["scores"]):
+        assert r.score == float.fromhex(sc[0]) and r.emittingModelScore == float.fromhex(sc[1])
+    assert list(res[0].tokens) == exp["tokens"][0]
+    # the same through decode_step chunks
+    dec.decode_begin()
+    for a, b in ((0, 1), (1, 90), (90, c["T"])):
+        chunk = np.ascontiguousarray(e[a:b])
+        dec.decode_step(chunk.ctypes.data, b - a, c["N"])
+    dec.decode_end()
+    res2 = dec.get_all_final_hypothesis()
+    assert [r.score for r in res2] == [r.score for r in res] and list(res2[0].tokens) == list(res[0].tokens)
+
+    # (ii) word LM: KenLM wrapped in a Python LM (states are KenLM's own LMState objects)
+    cw = cases.BY_NAME["ng_word_t60_k16_4g"]
+    inpw = helpers.case_inputs(cw)
+    path, vocab = helpers.arpa_path(cw, inpw)
+    wd = Dictionary(vocab)
+    kenlm = KenLM(path, wd)
+
+    class Wrapped(LM):
+        def __init__(self, inner):
+            LM.__init__(self)
+            self.inner = inner
+
+        def start(self, n):
+            return self.inner.start(n)
+
+        def score(self, state, idx):
+            return self.inner.score(state, idx)
+
+        def finish(self, state):
+            return self.inner.finish(state)
+
+    trie = Trie(cw["N"], 0)
+    sf, so = inpw["lex"]
+    st0 = kenlm.start(False)
+    for w in range(inpw["W"]):
+        trie.insert([int(t) for t in sf[so[w]:so[w + 1]]], w, kenlm.score(st0, w)[1])
+    trie.smear(SmearingMode.MAX)
+    lo = LexiconDecoderOptions(beam_size=cw["K"], beam_size_token=cw["Kt"], beam_threshold=cw["thr"],
+                               lm_weight=cw["lm_weight"], word_score=cw["word_score"], unk_score=cw["unk_score"],
+                               sil_score=cw["sil_score"], log_add=False, criterion_type=CriterionType.CTC)
+    ew = np.ascontiguousarray(inpw["e"], dtype=np.float32)
+    d_dev = LexiconDecoder(lo, trie, kenlm, 0, cw["N"] - 1, inpw["W"], [], False)
+    d_usr = LexiconDecoder(lo, trie, Wrapped(kenlm), 0, cw["N"] - 1, inpw["W"], [], False)
+    r_dev = d_dev.decode(ew.ctypes.data, cw["T"], cw["N"])
+    r_usr = d_usr.decode(ew.ctypes.data, cw["T"], cw["N"])
+    expw = golden["ng_word_t60_k16_4g"]
+    assert len(r_dev) == len(r_usr) == expw["n"]
+    for a, b, sc in zip(r_dev, r_usr, expw["scores"]):
+        assert (a.score, a.emittingModelScore, a.lmScore) == (b.score, b.emittingModelScore, b.lmScore)
+        assert list(a.tokens) == list(b.tokens) and list(a.words) == list(b.words)
+        assert b.score == float.fromhex(sc[0])
+
+    # (iii) exceptions
+    class Bad(PyZero):
+        def score(self, state, idx):
+            if self.calls > 50:
+                raise KeyError("user LM failed on purpose")
+            return PyZero.score(self, state, idx)
+
+    bad = LexiconFreeDecoder(opts, Bad(), 0, c["N"] - 1, [])
+    with pytest.raises(KeyError):
+        bad.decode(e.ctypes.data, c["T"], c["N"])

@@ -48,7 +48,7 @@ class Lib:
     SYMBOLS = [
         "fltx_last_error", "fltx_version", "fltx_ctx_create", "fltx_ctx_destroy",
         "fltx_ctx_synchronize", "fltx_ctx_stream", "fltx_lm_zero_create",
-        "fltx_lm_ngram_create", "fltx_lm_arpa_load", "fltx_lm_state_size", "fltx_lm_start", "fltx_lm_step", "fltx_lm_destroy", "fltx_lm_score_sequence",
+        "fltx_lm_ngram_create", "fltx_lm_host_create", "fltx_lm_arpa_load", "fltx_lm_state_size", "fltx_lm_start", "fltx_lm_step", "fltx_lm_destroy", "fltx_lm_score_sequence",
         "fltx_trie_create", "fltx_trie_destroy", "fltx_decoder_create",
         "fltx_decoder_destroy", "fltx_decode_batch", "fltx_stream_begin",
         "fltx_stream_step", "fltx_stream_end", "fltx_stream_prune",
@@ -81,6 +81,7 @@ class Lib:
             "fltx_lm_zero_create": [vp, pvp],
             "fltx_lm_ngram_create": [vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, pvp],
             "fltx_lm_arpa_load": [C.c_char_p, C.c_char_p, pvp],
+            "fltx_lm_host_create": [vp, pvp],
             "fltx_lm_state_size": [vp, vp],
             "fltx_lm_start": [vp, i32, vp],
             "fltx_lm_step": [vp, vp, i32, vp, vp],
@@ -211,6 +212,24 @@ class ZeroLM:
     def score_sequence(self, words, with_finish=True):
         return self._score(words, with_finish)
 
+    # explicit-state LM::start / score / finish on the host copy of the tables (decoder/lm/LM.h:61-78)
+    def state_size(self):
+        n = C.c_int32(0)
+        self.L.check(self.L.lib.fltx_lm_state_size(self.h, C.addressof(n)))
+        return n.value
+
+    def start(self, start_with_nothing=False):
+        ctx = np.zeros(max(1, self.state_size()), dtype=np.int32)
+        self.L.check(self.L.lib.fltx_lm_start(self.h, int(start_with_nothing), _ptr(ctx)))
+        return ctx
+
+    def step(self, ctx, usr_idx):
+        """-> (context of the next state, score); usr_idx == -1: LM::finish"""
+        out = np.zeros_like(ctx)
+        sc = C.c_float(0)
+        self.L.check(self.L.lib.fltx_lm_step(self.h, _ptr(ctx), int(usr_idx), _ptr(out), C.addressof(sc)))
+        return out, sc.value
+
     def _score(self, words, with_finish):
         w = np.ascontiguousarray(words, dtype=np.int32)
         per = np.zeros(len(w), dtype=np.float32)
@@ -258,6 +277,99 @@ class ArpaLM(ZeroLM):
         self.L.check(self.L.lib.fltx_lm_arpa_load(path.encode(), "\n".join(usr_words).encode(), C.byref(h)))
         self.h = h
         _live["lm"].add(self)
+
+
+_HLM_START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32)
+_HLM_SCORE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float))
+_HLM_STATES = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32))
+
+
+class _HostLmStruct(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("start", _HLM_START), ("score", _HLM_SCORE),
+                ("update_cache", _HLM_STATES), ("retain", _HLM_STATES)]
+
+
+class HostLM(ZeroLM):
+    """A user-defined LM behind fltx_lm_host_create (include/fltx.h): `lm` is any object with the reference's LM
+    methods (decoder/lm/LM.h:61-85) -- start(start_with_nothing) -> state, score(state, idx) -> (state, score),
+    finish(state) -> (state, score), optionally update_cache(states).  States are arbitrary Python objects; as in
+    the reference two hypotheses share an LM state iff the LM returned the SAME object (`is`).  The beam search runs
+    in the HIP kernels; once per frame the distinct (state, idx) questions of the whole batch are answered here."""
+
+    def __init__(self, lm, lib=None):
+        self.ctx, self.L = None, lib or default_lib()
+        self.lm = lm
+        self.states = []     # per utterance: id -> state object
+        self.ids = []        # per utterance: id(state object) -> id
+        self.error = None    # the exception a callback raised (re-raised by the decoder call)
+        self.calls = 0       # LM.score / LM.finish calls made
+        self.released = 0    # states dropped after prune
+
+        def guard(fn):
+            def run(*a):
+                try:
+                    return fn(*a)
+                except BaseException as e:  # noqa: BLE001 -- must not unwind through the C frames
+                    self.error = e
+                    return 1
+            return run
+
+        def start(_user, n_utt):
+            self.states, self.ids = [], []
+            for _ in range(n_utt):
+                s0 = self.lm.start(False)
+                self.states.append({0: s0})
+                self.ids.append({id(s0): 0})
+            self.next = [1] * n_utt
+            return 0
+
+        def score(_user, n, utt, state, idx, out_state, out_score):
+            for i in range(n):
+                b = utt[i]
+                st = self.states[b][state[i]]
+                self.calls += 1
+                ns, sc = self.lm.finish(st) if idx[i] < 0 else self.lm.score(st, idx[i])
+                k = self.ids[b].get(id(ns))
+                if k is None or self.states[b][k] is not ns:
+                    k = self.next[b]
+                    self.next[b] += 1
+                    self.ids[b][id(ns)] = k
+                    self.states[b][k] = ns
+                out_state[i] = k
+                out_score[i] = sc
+            return 0
+
+        def update_cache(_user, b, n, states):
+            f = getattr(self.lm, "update_cache", None)
+            if f is not None:
+                f([self.states[b][states[i]] for i in range(n)])
+            return 0
+
+        def retain(_user, b, n, states):
+            keep = {states[i] for i in range(n)}
+            for k in [k for k in self.states[b] if k not in keep]:
+                self.ids[b].pop(id(self.states[b][k]), None)
+                del self.states[b][k]
+                self.released += 1
+            return 0
+
+        self._cb = _HostLmStruct(None, _HLM_START(guard(start)), _HLM_SCORE(guard(score)),
+                                 _HLM_STATES(guard(update_cache)), _HLM_STATES(guard(retain)))
+        h = C.c_void_p()
+        self.L.check(self.L.lib.fltx_lm_host_create(C.byref(self._cb), C.byref(h)))
+        self.h = h
+        _live["lm"].add(self)
+
+    def score_sequence(self, words, with_finish=True):
+        st = self.lm.start(False)
+        per = np.zeros(len(words), dtype=np.float32)
+        for i, w in enumerate(words):
+            st, per[i] = self.lm.score(st, int(w))
+        tot = float(per.sum())
+        if with_finish:
+            tot += self.lm.finish(st)[1]
+        return per, tot
 
 
 class Trie:
@@ -382,6 +494,14 @@ class BatchDecoder:
         self.N = None  # token-set size of the last offline batch
         _live["dec"].add(self)
 
+    def _chk(self, rc):
+        """Like Lib.check; a failure reported by a host-LM callback re-raises what the user's LM raised."""
+        lm = self._keep[0]
+        if rc == 7 and getattr(lm, "error", None) is not None:
+            e, lm.error = lm.error, None
+            raise e
+        self.L.check(rc)
+
     def set(self, key, value):
         self.L.check(self.L.lib.fltx_decoder_set(self.h, key.encode(), int(value)))
 
@@ -394,15 +514,15 @@ class BatchDecoder:
             offsets = np.concatenate([[0], np.cumsum(T.astype(np.int64) * N)[:-1]]).astype(np.int64)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         if device_ptr is not None:
-            self.L.check(self.L.lib.fltx_decode_batch(self.h, device_ptr, 1, _ptr(offsets), _ptr(T), B, N))
+            self._chk(self.L.lib.fltx_decode_batch(self.h, device_ptr, 1, _ptr(offsets), _ptr(T), B, N))
         else:
             e = np.ascontiguousarray(emissions, dtype=np.float32)
-            self.L.check(self.L.lib.fltx_decode_batch(self.h, _ptr(e), 0, _ptr(offsets), _ptr(T), B, N))
+            self._chk(self.L.lib.fltx_decode_batch(self.h, _ptr(e), 0, _ptr(offsets), _ptr(T), B, N))
         self.B = B
         self.N = N
 
     def stream_begin(self, B, N, max_frames):
-        self.L.check(self.L.lib.fltx_stream_begin(self.h, B, N, max_frames))
+        self._chk(self.L.lib.fltx_stream_begin(self.h, B, N, max_frames))
         self.B = B
         self.N = None  # (streams: fltx_result_fetch per utterance)
         self._N = N
@@ -415,16 +535,16 @@ class BatchDecoder:
             offsets = np.concatenate([[0], np.cumsum(T.astype(np.int64) * self._N)[:-1]]).astype(np.int64)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         if device_ptr is not None:
-            self.L.check(self.L.lib.fltx_stream_step(self.h, device_ptr, 1, _ptr(offsets), _ptr(T)))
+            self._chk(self.L.lib.fltx_stream_step(self.h, device_ptr, 1, _ptr(offsets), _ptr(T)))
             return
         e = np.ascontiguousarray(emissions, dtype=np.float32)
-        self.L.check(self.L.lib.fltx_stream_step(self.h, _ptr(e), 0, _ptr(offsets), _ptr(T)))
+        self._chk(self.L.lib.fltx_stream_step(self.h, _ptr(e), 0, _ptr(offsets), _ptr(T)))
 
     def stream_end(self):
-        self.L.check(self.L.lib.fltx_stream_end(self.h))
+        self._chk(self.L.lib.fltx_stream_end(self.h))
 
     def stream_prune(self, look_back=0):
-        self.L.check(self.L.lib.fltx_stream_prune(self.h, look_back))
+        self._chk(self.L.lib.fltx_stream_prune(self.h, look_back))
 
     def frames_in_buffer(self, b):
         n = C.c_int32(0)

@@ -10,6 +10,7 @@
 
 #include "flashlight/lib/text/decoder/Decoder.h"
 #include "flashlight/lib/text/decoder/Fltx.h"
+#include "flashlight/lib/text/decoder/lm/HostLM.h"
 
 namespace fl {
 namespace lib {
@@ -61,12 +62,16 @@ class DeviceDecoder {
     transitions_ = transitions;
     isLmToken_ = isLmToken;
     hostTrie_ = hostTrie;
-    if (!lm || !lm->deviceHandle()) {
-      throw std::runtime_error(
-          "[decoder] this LM has no device tables (ZeroLM and KenLM/ARPA are supported); "
-          "the MI355X decoder has no CPU path to fall back to");
+    if (!lm) {
+      throw std::runtime_error("[decoder] the LM is null");
     }
-    check(fltx_decoder_create(ctx_->h, kind, &opt, trie, lm->deviceHandle(), sil, blank, unk,
+    /* an LM without device tables (a user subclass, PyLM): the search still runs on the device, its
+     * start / score / finish are answered on the host once per frame (decoder/lm/HostLM.h) */
+    if (!lm->deviceHandle()) {
+      bridge_ = std::make_unique<HostLmBridge>(lm);
+    }
+    lmHandle_ = bridge_ ? bridge_->handle() : lm->deviceHandle();
+    check(fltx_decoder_create(ctx_->h, kind, &opt, trie, lmHandle_, sil, blank, unk,
                               transitions.empty() ? nullptr : transitions.data(), (int32_t)transitions.size(),
                               isLmToken ? 1 : 0, &h_));
     sil_ = sil;
@@ -87,12 +92,12 @@ class DeviceDecoder {
     ensureOpen(N);
     const int64_t off = 0;
     const int32_t t32 = T;
-    check(fltx_stream_step(h_, emissions, 0, &off, &t32));
+    chk(fltx_stream_step(h_, emissions, 0, &off, &t32));
   }
 
   void end() {
     ensureOpen(guessN());
-    check(fltx_stream_end(h_));
+    chk(fltx_stream_end(h_));
   }
 
   std::vector<DecodeResult> decodeOne(const float* emissions, int T, int N) {
@@ -101,7 +106,7 @@ class DeviceDecoder {
     /* getBestHypothesis(lookBack) after decode() reports an ancestor's scores (Utils.h:236-238):
      * the single-utterance call keeps the per-frame score history, the batched one does not */
     check(fltx_decoder_set(h_, "keep_scores", 1));
-    check(fltx_decode_batch(h_, emissions, 0, &off, &t32, 1, N));
+    chk(fltx_decode_batch(h_, emissions, 0, &off, &t32, 1, N));
     open_ = true;
     pendingBegin_ = false;
     return results(0);
@@ -112,7 +117,7 @@ class DeviceDecoder {
                             int N, bool onDevice) {
     std::vector<int32_t> t32(T.begin(), T.end());
     check(fltx_decoder_set(h_, "keep_scores", 0));
-    check(fltx_decode_batch(h_, emissions, onDevice ? 1 : 0, offsets.empty() ? nullptr : offsets.data(),
+    chk(fltx_decode_batch(h_, emissions, onDevice ? 1 : 0, offsets.empty() ? nullptr : offsets.data(),
                             t32.data(), (int32_t)t32.size(), N));
     open_ = true;
     pendingBegin_ = false;
@@ -157,14 +162,14 @@ class DeviceDecoder {
         group_ = nullptr;
       }
       std::vector<int32_t> dv(devices.begin(), devices.end());
-      check(fltx_group_create(dv.data(), (int32_t)dv.size(), kind_, &opt_, hostTrie_, lmKeep_->deviceHandle(), sil_,
+      check(fltx_group_create(dv.data(), (int32_t)dv.size(), kind_, &opt_, hostTrie_, lmHandle_, sil_,
                               blank_, unk_, transitions_.empty() ? nullptr : transitions_.data(),
                               (int32_t)transitions_.size(), isLmToken_ ? 1 : 0, &group_));
       groupDevices_ = devices;
     }
     std::vector<int32_t> t32(T.begin(), T.end());
     std::vector<const float*> ptrs(devices.size(), emissions);
-    check(fltx_group_decode_batch(group_, ptrs.data(), nullptr, offsets.empty() ? nullptr : offsets.data(),
+    chk(fltx_group_decode_batch(group_, ptrs.data(), nullptr, offsets.empty() ? nullptr : offsets.data(),
                                   t32.data(), (int32_t)t32.size(), N));
     std::vector<std::vector<DecodeResult>> out(T.size());
     for (size_t i = 0; i < devices.size(); ++i) {
@@ -189,7 +194,7 @@ class DeviceDecoder {
     if (!open_) {
       return;
     }
-    check(fltx_stream_prune(h_, lookBack));
+    chk(fltx_stream_prune(h_, lookBack));
   }
 
   int framesInBuffer() const {
@@ -259,8 +264,19 @@ class DeviceDecoder {
   }
 
   void setMaxStreamFrames(int n) { maxFrames_ = n; }
+  /* a user LM's states held on the host for the single-utterance stream (0 for LMs with device tables) */
+  size_t hostLmStates() const { return bridge_ ? bridge_->liveStates(0) : 0; }
 
  private:
+  /* like check(); a failure inside a user LM's start / score / finish surfaces as what the LM threw */
+  void chk(int rc) const {
+    if (rc == FLTX_ERR_CALLBACK && bridge_) {
+      bridge_->rethrow();
+    }
+    check(rc);
+  }
+  std::unique_ptr<HostLmBridge> bridge_;
+  fltx_lm* lmHandle_ = nullptr;
   /* n-best of utterance b of a fetched batch -> DecodeResult objects */
   void fill(std::vector<DecodeResult>& dst, int b, const int32_t* nHyp, const int32_t* len, const double* sc,
             const int32_t* tok, const int32_t* wrd, const int64_t* off) const {
@@ -302,7 +318,7 @@ class DeviceDecoder {
   }
   void ensureOpen(int N) {
     if (pendingBegin_ || !open_) {
-      check(fltx_stream_begin(h_, 1, N, maxFrames_));
+      chk(fltx_stream_begin(h_, 1, N, maxFrames_));
       pendingBegin_ = false;
       open_ = true;
     }

@@ -69,6 +69,8 @@ class FL_TEXT_API LexiconFreeDecoder : public Decoder {
   std::vector<DecodeResult> materialise(const detail::BatchView& v, int b) const { return dev_.materialise(v, b); }
   /* additive: frames one stream may buffer between prune() calls (decodeStep path) */
   void setMaxStreamFrames(int n) { dev_.setMaxStreamFrames(n); }
+  /* additive: LM states a user-defined LM (no device tables) has alive for this decoder's stream; prune() bounds it */
+  size_t hostLmStates() const { return dev_.hostLmStates(); }
   /* additive: the batch sharded over `devices` (one host thread + stream per device, results in
    * input order) */
   std::vector<std::vector<DecodeResult>> decodeBatch(const float* emissions, const std::vector<int>& T, int N,

@@ -4,9 +4,12 @@
  *
  * Host-side objects: they serve user code that scores words outside the
  * decoder (e.g. trie label scores, DecoderTest.cpp:137-146).  During decoding
- * the LM is evaluated on the device from flat tables; an LM that has no device
- * form (a user subclass) makes the decoder constructors throw -- there is no
- * CPU decode path to fall back to.
+ * ZeroLM and KenLM are evaluated on the device from flat tables (deviceHandle());
+ * any other subclass -- a user's own LM, C++ or Python -- keeps its start /
+ * score / finish on the host: the beam search still runs in the kernels and
+ * asks the LM once per frame about the frame's distinct (state, index) pairs
+ * (decoder/lm/HostLM.h).  LM::score must therefore be a function of its
+ * arguments, which LMState::child's memo already makes it in the reference.
  */
 #pragma once
 #include <memory>

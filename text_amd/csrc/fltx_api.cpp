@@ -87,6 +87,11 @@ __global__ void __launch_bounds__(256) fltx_tokbeam_kernel(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_tb_smem[];
   wlTokBeamRows(P, fltx_tb_smem);
 }
+/* host LM: the (LM state, index) questions of the next frame, one workgroup per utterance (hostLmQuestions) */
+__global__ void __launch_bounds__(256) fltx_hostlm_questions_kernel(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_hq_smem[];
+  hostLmQuestions(P, fltx_hq_smem);
+}
 __global__ void __launch_bounds__(512) fltx_backtrace_kernel(BacktraceParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_bt_smem[];
   backtraceUtterance(P, fltx_bt_smem);
@@ -331,7 +336,8 @@ struct DeviceScope {
 
 struct fltx_lm {
   fltx_ctx* ctx = nullptr;
-  int kind = 0; /* 0 zero, 1 ngram */
+  int kind = 0; /* 0 zero, 1 ngram, 2 host callbacks (fltx_lm_host_create) */
+  fltx_host_lm host{};
   int order = 0;
   int32_t bos = 0, eos = 0, unk = 0, nUsr = 0;
   uint32_t mask = 0;
@@ -472,6 +478,13 @@ struct fltx_decoder {
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
   DBuf scored; /* n-gram LM queries per utterance (accounting) */
+  /* host LM (lm->kind == 2): question lists and beam states in pinned host memory (written by the kernel), the
+   * answer tables staged in pinned memory and uploaded once per frame */
+  HBuf hlmQCount, hlmQ, hlmBeamN, hlmBeam, hlmStage;
+  DBuf hlmTabD;
+  int hlmQCap = 0;
+  bool hlmAnnounce = false; /* a frame has been decoded since decodeBegin: the beam is announced through update_cache */
+  int64_t hlmAsked = 0, hlmDistinct = 0; /* questions listed / answered by the callbacks since decodeBegin ("hlm_asked", "hlm_distinct") */
   bool keepScored = false;
   int64_t idCap = 0;
   DBuf tokens, words, prof, histS, bestLen, bestScores, bestTok, bestWrd;
@@ -514,6 +527,8 @@ __attribute__((visibility("hidden"))) int fltx_set_error_(int code, const char* 
   g_err = msg ? msg : "";
   return code;
 }
+/* internal (fltx_group.cpp): 0 ZeroLM, 1 n-gram tables, 2 host callbacks */
+__attribute__((visibility("hidden"))) int fltx_lm_kind_(const fltx_lm* lm) { return lm ? lm->kind : -1; }
 const char* fltx_version(void) {
 #ifdef FLTX_EMU
   return "fltx 0.1 (host-thread emulation, tests only)";
@@ -613,6 +628,22 @@ int fltx_lm_zero_create(fltx_ctx* ctx, fltx_lm** out) {
   lm->kind = 0;
   {
     std::lock_guard<std::mutex> reg(g_lmRegMu);
+    g_lmReg.insert(lm);
+  }
+  *out = lm;
+  return FLTX_OK;
+}
+
+/* a user subclass of LM behind callbacks (include/fltx.h): nothing to upload */
+int fltx_lm_host_create(const fltx_host_lm* cb, fltx_lm** out) {
+  if (!cb || !out || !cb->start || !cb->score) {
+    return fail(FLTX_ERR_INVALID, "fltx_lm_host_create: null argument (start and score are required)");
+  }
+  auto* lm = new fltx_lm();
+  lm->kind = 2;
+  lm->host = *cb;
+  {
+    std::lock_guard<std::mutex> lock(g_lmRegMu);
     g_lmReg.insert(lm);
   }
   *out = lm;
@@ -739,6 +770,9 @@ int fltx_lm_score_sequence(fltx_lm* lm, const int32_t* usrWords, int32_t n, int3
   if (!lm || (!usrWords && n > 0)) {
     return fail(FLTX_ERR_INVALID, "fltx_lm_score_sequence: null argument");
   }
+  if (lm->kind == 2) {
+    return fail(FLTX_ERR_UNSUPPORTED, "a host LM keeps its own states (call the LM object)");
+  }
   float tot = 0;
   if (lm->kind == 0) {
     for (int i = 0; i < n; ++i) {
@@ -858,6 +892,9 @@ int fltx_lm_state_size(fltx_lm* lm, int32_t* n) {
   if (!lm || !n) {
     return fail(FLTX_ERR_INVALID, "null argument");
   }
+  if (lm->kind == 2) {
+    return fail(FLTX_ERR_UNSUPPORTED, "a host LM keeps its own states (call the LM object)");
+  }
   *n = lm->kind == 0 ? 0 : std::max(1, lm->order - 1);
   return FLTX_OK;
 }
@@ -865,6 +902,9 @@ int fltx_lm_state_size(fltx_lm* lm, int32_t* n) {
 int fltx_lm_start(fltx_lm* lm, int32_t startWithNothing, int32_t* ctxOut) {
   if (!lm) {
     return fail(FLTX_ERR_INVALID, "null lm");
+  }
+  if (lm->kind == 2) {
+    return fail(FLTX_ERR_UNSUPPORTED, "a host LM keeps its own states (call the LM object)");
   }
   if (lm->kind == 0) {
     return FLTX_OK;
@@ -885,6 +925,9 @@ int fltx_lm_start(fltx_lm* lm, int32_t startWithNothing, int32_t* ctxOut) {
 int fltx_lm_step(fltx_lm* lm, const int32_t* ctxIn, int32_t usrIdx, int32_t* ctxOut, float* score) {
   if (!lm || !score) {
     return fail(FLTX_ERR_INVALID, "null argument");
+  }
+  if (lm->kind == 2) {
+    return fail(FLTX_ERR_UNSUPPORTED, "a host LM keeps its own states (call the LM object)");
   }
   if (lm->kind == 0) {
     *score = 0.0f;
@@ -1127,8 +1170,8 @@ int fltx_trie_destroy(fltx_trie* t) {
 /* upload the flat n-gram tables to the context's device (once) */
 static int lmEnsureUploaded(fltx_lm* lm, fltx_ctx* ctx, fltx_lm::Dev** out) {
   *out = nullptr;
-  if (lm->kind == 0) {
-    return FLTX_OK;
+  if (lm->kind != 1) {
+    return FLTX_OK; /* (ZeroLM: nothing to compute; host LM: answered on the host) */
   }
   std::lock_guard<std::mutex> lock(lm->devMu);
   auto it = lm->dev.find(ctx->uid);
@@ -1260,6 +1303,10 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->lastRedo;
   } else if (!strcmp(key, "sstream")) {
     *value = d->sstream;
+  } else if (!strcmp(key, "hlm_asked")) { /* host LM: questions the frames listed since decodeBegin ... */
+    *value = d->hlmAsked;
+  } else if (!strcmp(key, "hlm_distinct")) { /* ... and how many the callbacks were asked (distinct per frame) */
+    *value = d->hlmDistinct;
   } else if (!strcmp(key, "stream_redone")) {
     *value = d->streamRedone;
   } else if (!strcmp(key, "wlane")) { /* 1: the last call ran on fltx_wlane.h (token sets beyond 64) */
@@ -1477,6 +1524,10 @@ void latchFirst(fltx_decoder* d) {
 }
 
 int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstCaseCap) {
+  /* host LM: the generic engine, a frame per launch, every candidate's record built in one pass (the cut-off
+   * generation rebuilds LM-state keys from (state, label) pairs, which a host LM's states are not) */
+  const bool hostLm = d->lm->kind == 2;
+  forceWorstCaseCap = forceWorstCaseCap || hostLm;
   const size_t kMaxLdsHw = kMaxLds;
   const size_t kMaxLds = d->ldsBudget ? d->ldsBudget : kMaxLdsHw;
   Stream st = d->ctx->stream;
@@ -1529,7 +1580,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   /* lexicon-free frames merge through the dense (hash-free) path: one slot per
    * (LM state, token) group plus one per orphan repeat; the hash is then only
    * used by decodeEnd (<= K candidates) */
-  d->dense = (d->kind == FLTX_DECODER_LEXFREE && !d->noDense) ? 1 : 0;
+  /* (not for a host LM: the dense merge assumes at most two hypotheses per LM state -- true of states that are a trie
+   * over their inputs, not of whatever a user's LM::score returns) */
+  d->dense = (d->kind == FLTX_DECODER_LEXFREE && !d->noDense && !hostLm) ? 1 : 0;
   /* threads per utterance: the frame step is latency bound, so more waves per
    * utterance win as long as the batch does not fill the CUs on its own
    * (measured on C2: 256 -> 15.3 ms, 512 -> 13.0 ms per 256-utterance batch) */
@@ -2144,6 +2197,13 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
                      : 0.0;
   P.yTransMax = d->transMax;
   P.scored = (d->lm->kind == 1 && d->scored.p) ? d->scored.as<uint32_t>() : nullptr;
+  if (d->lm->kind == 2) {
+    P.hlmQCap = d->hlmQCap;
+    P.hlmQCount = (int32_t*)d->hlmQCount.p;
+    P.hlmQ = (uint2*)d->hlmQ.p;
+    P.hlmBeamN = (int32_t*)d->hlmBeamN.p;
+    P.hlmBeam = (uint32_t*)d->hlmBeam.p;
+  }
   P.profThread = 64 * d->profWave;
   if (d->profile && !d->prof.ensure(8 * 8 * (size_t)d->B, d->ctx->stream, true)) {
     devMemset(d->prof.p, 0, 8 * 8 * (size_t)d->B, d->ctx->stream);
@@ -2230,7 +2290,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       FLTX_LAUNCH_LDS(WW, 255);                                                                  \
     } else if (d->kind == FLTX_DECODER_LEXICON && !d->isLmToken && d->lm->kind == 0) {           \
       FLTX_LAUNCH_SPEC(WW, true, true);                                                          \
-    } else if (d->kind == FLTX_DECODER_LEXICON && !d->isLmToken) {                               \
+    } else if (d->kind == FLTX_DECODER_LEXICON && !d->isLmToken && d->lm->kind == 1) {           \
       FLTX_LAUNCH_SPEC(WW, true, false);                                                         \
     } else if (d->lm->kind == 0 && !d->isLmToken) {                                              \
       FLTX_LAUNCH_SPEC(WW, false, true);                                                         \
@@ -2818,6 +2878,238 @@ int settleStream(fltx_decoder* d) {
   return rc;
 }
 
+/* ---- host LM (fltx_lm_host_create): one frame per launch, the frame's LM questions answered on the host ------- */
+int hostLmEnsure(fltx_decoder* d) {
+  const int64_t K = d->opt.beam_size, N = d->N, B = d->B;
+  const int64_t nTok = std::min<int64_t>(d->opt.beam_size_token, N);
+  /* what a frame can ask: one question per (hypothesis, token); the lexicon decoder with a word LM one per word a
+   * child ends (<= 6, Trie.h:19) or the unknown word; decodeEnd one per hypothesis */
+  int64_t cap = K * nTok * ((d->kind == FLTX_DECODER_LEXICON && !d->isLmToken) ? 6 : 1);
+  cap = std::max<int64_t>(cap, K);
+  if (cap * B * 8 > (1ll << 32)) {
+    return fail(FLTX_ERR_UNSUPPORTED, "host LM: %lld questions per frame x %lld utterances exceed the question buffer",
+                (long long)cap, (long long)B);
+  }
+  d->hlmQCap = (int)cap;
+  if (d->hlmQCount.ensure(4 * (size_t)B) || d->hlmQ.ensure(8 * (size_t)B * (size_t)cap) ||
+      d->hlmBeamN.ensure(4 * (size_t)B) || d->hlmBeam.ensure(4 * (size_t)B * (size_t)K)) {
+    return fail(FLTX_ERR_OOM, "host LM: pinned buffers");
+  }
+  return FLTX_OK;
+}
+
+int hostLmCall(int rc, const char* what) {
+  return rc ? fail(FLTX_ERR_CALLBACK, "host LM: the %s callback reported failure (%d)", what, rc) : FLTX_OK;
+}
+
+/* list the questions of frame `frame` of the chunk (or of decodeEnd), have the user's LM answer each distinct one
+ * and leave the answers where the frame's launch finds them (P.hlmTab / P.hlmDir) */
+int hostLmExchange(fltx_decoder* d, DecodeParams& P, int frame, bool end) {
+  Stream st = d->ctx->stream;
+  const int B = d->B, K = d->opt.beam_size;
+  const fltx_host_lm& cb = d->lm->host;
+  P.hlmFrame = frame;
+  P.hlmEnd = end ? 1 : 0;
+  const size_t qLds = 4 * (size_t)(std::min(d->opt.beam_size_token, d->N) + 4);
+#ifdef FLTX_EMU
+  {
+    const DecodeParams* pp = &P;
+    emuLaunch(B, 256, qLds, [pp](char* smem) { hostLmQuestions(*pp, smem); });
+  }
+#else
+  HIPCHK(hipFuncSetAttribute((const void*)fltx_hostlm_questions_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)qLds));
+  hipLaunchKernelGGL(fltx_hostlm_questions_kernel, dim3(B), dim3(256), qLds, st, P);
+  HIPCHK(hipGetLastError());
+#endif
+  if (devSync(st)) { /* (also: the previous frame's table upload has been consumed, the staging buffer is free) */
+    return fail(FLTX_ERR_HIP, "host LM: questions kernel failed: %s", devErr());
+  }
+  const int32_t* qCount = (const int32_t*)d->hlmQCount.p;
+  const uint2* q = (const uint2*)d->hlmQ.p;
+  const int32_t* beamN = (const int32_t*)d->hlmBeamN.p;
+  const int32_t* beam = (const int32_t*)d->hlmBeam.p;
+  int rc;
+  if (d->hlmAnnounce && cb.update_cache) { /* updateLMCache(lm_, hyp_[t + 1]) of the frame before (Utils.h:346-354) */
+    for (int b = 0; b < B; ++b) {
+      if (beamN[b] > 0 && (rc = hostLmCall(cb.update_cache(cb.user, b, beamN[b], beam + (size_t)b * K), "update_cache"))) {
+        return rc;
+      }
+    }
+  }
+  /* one open-addressing table per utterance, at most half full; the tables double as the set of distinct questions */
+  std::vector<uint2> dir((size_t)B);
+  size_t slots = 0;
+  for (int b = 0; b < B; ++b) {
+    if (qCount[b] > d->hlmQCap) {
+      return fail(FLTX_ERR_UNSUPPORTED, "host LM: utterance %d asked %d questions in one frame (capacity %d)", b, qCount[b],
+                  d->hlmQCap);
+    }
+    const uint32_t n = nextPow2(std::max<uint64_t>(2ull * (uint64_t)qCount[b], 2));
+    dir[(size_t)b] = make_uint2((uint32_t)slots, n - 1u);
+    slots += n;
+  }
+  const size_t dirBytes = alignUp(sizeof(uint2) * (size_t)B, 16);
+  const size_t bytes = dirBytes + 16 * slots;
+  if (d->hlmStage.ensure(bytes) || d->hlmTabD.ensure(bytes, st, false)) {
+    return fail(FLTX_ERR_OOM, "host LM: answer table");
+  }
+  char* stage = (char*)d->hlmStage.p;
+  memcpy(stage, dir.data(), sizeof(uint2) * (size_t)B);
+  uint4* tab = (uint4*)(stage + dirBytes);
+  memset(tab, 0xFF, 16 * slots);
+  std::vector<int32_t> qu, qs, qi, os;
+  std::vector<float> of;
+  std::vector<size_t> where;
+  for (int b = 0; b < B; ++b) {
+    const uint2 dd = dir[(size_t)b];
+    const uint2* qb = q + (size_t)b * d->hlmQCap;
+    d->hlmAsked += qCount[b];
+    for (int i = 0; i < qCount[b]; ++i) {
+      const uint32_t sid = qb[i].x, idx = qb[i].y;
+      uint32_t s = hashKey(sid, idx, 0x7f4a7c15u, 0) & dd.y;
+      for (;;) {
+        uint4& e = tab[(size_t)dd.x + s];
+        if (e.x == sid && e.y == idx) {
+          break;
+        }
+        if (e.x == kEmpty && e.y == kEmpty) {
+          e.x = sid;
+          e.y = idx;
+          qu.push_back(b);
+          qs.push_back((int32_t)sid);
+          qi.push_back((int32_t)idx);
+          where.push_back((size_t)dd.x + s);
+          break;
+        }
+        s = (s + 1) & dd.y;
+      }
+    }
+  }
+  const size_t nq = qu.size();
+  d->hlmDistinct += (int64_t)nq;
+  if (nq > 0) {
+    os.assign(nq, 0);
+    of.assign(nq, 0.0f);
+    if ((rc = hostLmCall(cb.score(cb.user, (int32_t)nq, qu.data(), qs.data(), qi.data(), os.data(), of.data()), "score"))) {
+      return rc;
+    }
+    for (size_t i = 0; i < nq; ++i) {
+      uint32_t bits;
+      memcpy(&bits, &of[i], 4);
+      tab[where[i]].z = (uint32_t)os[i];
+      tab[where[i]].w = bits;
+    }
+  }
+  if (devCopyH2D(d->hlmTabD.p, stage, bytes, st)) {
+    return fail(FLTX_ERR_HIP, "host LM: answer upload failed");
+  }
+  P.hlmDir = (const uint2*)d->hlmTabD.p;
+  P.hlmTab = (const uint4*)((const char*)d->hlmTabD.p + dirBytes);
+  return FLTX_OK;
+}
+
+/* the frames of one chunk (T[b] frames of utterance b), a launch each */
+int hostLmFrames(fltx_decoder* d, DecodeParams& P, const int32_t* T) {
+  int maxT = 0;
+  for (int b = 0; b < d->B; ++b) {
+    maxT = std::max(maxT, T[b]);
+  }
+  P.doBegin = 0;
+  P.doEnd = 0;
+  for (int t = 0; t < maxT; ++t) {
+    int rc = hostLmExchange(d, P, t, false);
+    if (rc || (rc = launchDecode(d, P))) {
+      return rc;
+    }
+    d->hlmAnnounce = true;
+  }
+  return FLTX_OK;
+}
+
+/* decodeBegin on the device (the seed hypothesis in LM state 0) and LM::start on the host */
+int hostLmBegin(fltx_decoder* d, DecodeParams& P) {
+  int rc = hostLmEnsure(d);
+  if (rc) {
+    return rc;
+  }
+  fillParams(d, P); /* (the question buffers exist now) */
+  d->hlmAnnounce = false;
+  d->hlmAsked = 0;
+  d->hlmDistinct = 0;
+  return hostLmCall(d->lm->host.start(d->lm->host.user, d->B), "start");
+}
+
+/* Decoder::prune: the LM states the beam still holds (the callee may release the others) */
+int hostLmRetain(fltx_decoder* d) {
+  const fltx_host_lm& cb = d->lm->host;
+  if (!cb.retain) {
+    return FLTX_OK;
+  }
+  const int B = d->B, K = d->opt.beam_size;
+  std::vector<int32_t> nb((size_t)B), st((size_t)B * K);
+  if (devCopyD2H(nb.data(), d->uttNBeam.p, 4 * (size_t)B, d->ctx->stream) ||
+      devCopyD2H(st.data(), d->gState.p, 4 * (size_t)B * K, d->ctx->stream)) {
+    return fail(FLTX_ERR_HIP, "host LM: beam copy failed");
+  }
+  for (int b = 0; b < B; ++b) {
+    int rc = hostLmCall(cb.retain(cb.user, b, nb[(size_t)b], st.data() + (size_t)b * K), "retain");
+    if (rc) {
+      return rc;
+    }
+  }
+  return FLTX_OK;
+}
+
+/* fltx_decode_batch with a host LM: begin, a launch per frame, end, back-trace */
+int hostLmDecodeBatch(fltx_decoder* d, const float* emissions, int32_t onDevice, const int64_t* offsets, const int32_t* T,
+                      int32_t B, int32_t N) {
+  d->offlineCall = true;
+  d->batchPacked = false;
+  d->batchWlane = false;
+  d->keepScores = d->userKeepScores;
+  d->fallbackReasons = 0;
+  int rc = prepare(d, B, N, T, true);
+  if (rc) {
+    return rc;
+  }
+  latchFirst(d);
+  if ((rc = bumpEpoch(d))) {
+    return rc;
+  }
+  DecodeParams P;
+  fillParams(d, P);
+  if ((rc = hostLmBegin(d, P)) || (rc = uploadStep(d, emissions, onDevice, offsets, T, P))) {
+    return rc;
+  }
+  d->nLaunch = 0;
+  P.doBegin = 1;
+  P.doEnd = 0;
+  P.hlmFrame = 1 << 30; /* (no frame in this launch: decodeBegin only) */
+  if ((rc = launchDecode(d, P)) || (rc = hostLmFrames(d, P, T))) {
+    return rc;
+  }
+  if ((rc = hostLmExchange(d, P, 1 << 30, true))) {
+    return rc;
+  }
+  P.doBegin = 0;
+  P.doEnd = 1;
+  P.hlmFrame = 1 << 30;
+  if ((rc = launchDecode(d, P))) {
+    return rc;
+  }
+  d->lastRedo = 0;
+  d->resultsSynced = false;
+  if ((rc = launchBacktrace(d))) {
+    return rc;
+  }
+  d->T.assign(T, T + B);
+  d->statsDone = false;
+  d->haveResults = true;
+  d->ended = true;
+  return FLTX_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -2840,6 +3132,9 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   d->hostFetched = false;
   d->compactFetched = false;
   d->scoresFetched = false;
+  if (d->lm->kind == 2) {
+    return hostLmDecodeBatch(d, emissions, onDevice, offsets, T, B, N);
+  }
   /* The optimistic fast paths (LDS-sized candidate lists of the lexicon
    * decoder, the score cut, the one-pass histogram select of the lean / lane
    * steps) flag the rare utterance they cannot serve.  Only those utterances
@@ -3000,7 +3295,7 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
    * can be decoded again: the beam a chunk starts from is saved, the state table is idempotent (same
    * (parent, edge) -> same id), history rows are rewritten in place.  (The lexicon-free engines never
    * overflow and number their states with a counter: always one pass.) */
-  d->streamOpt = d->kind == FLTX_DECODER_LEXICON && d->userStreamOpt != 0 && !d->forceGlobalWs;
+  d->streamOpt = d->kind == FLTX_DECODER_LEXICON && d->userStreamOpt != 0 && !d->forceGlobalWs && d->lm->kind != 2;
   d->streamRedone = 0;
   int rc = prepare(d, B, N, Tm.data(), !d->streamOpt);
   if (rc) {
@@ -3038,12 +3333,16 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   d->pendingPrune = -1;
   DecodeParams P;
   fillParams(d, P);
+  if (d->lm->kind == 2 && (rc = hostLmBegin(d, P))) {
+    return rc;
+  }
   std::vector<int32_t> zeroT(B, 0);
   if ((rc = uploadStep(d, nullptr, 1, nullptr, zeroT.data(), P))) {
     return rc;
   }
   P.doBegin = 1;
   P.doEnd = 0;
+  P.hlmFrame = 1 << 30;
   if ((rc = launchDecode(d, P))) {
     return rc;
   }
@@ -3107,7 +3406,7 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
     return rc;
   }
   d->sstreamLaunch = d->sstream != 0;
-  rc = launchDecode(d, P);
+  rc = d->lm->kind == 2 ? hostLmFrames(d, P, T) : launchDecode(d, P);
   d->sstreamLaunch = false;
   if (rc) {
     return rc;
@@ -3155,8 +3454,12 @@ int fltx_stream_end(fltx_decoder* d) {
   if ((rc = uploadStep(d, nullptr, 1, nullptr, zeroT.data(), P))) {
     return rc;
   }
+  if (d->lm->kind == 2 && (rc = hostLmExchange(d, P, 1 << 30, true))) {
+    return rc;
+  }
   P.doBegin = 0;
   P.doEnd = 1;
+  P.hlmFrame = 1 << 30;
   if ((rc = launchDecode(d, P))) {
     return rc;
   }
@@ -3184,6 +3487,9 @@ int fltx_stream_prune(fltx_decoder* d, int32_t lookBack) {
   if (d->chunkPending && d->pendingPrune < 0) {
     d->pendingPrune = lookBack; /* runs right after the look at the pending chunk (settleStream) */
   } else if ((rc = settleStream(d)) || (rc = launchStreamOp(d, 1, lookBack, 0))) {
+    return rc;
+  }
+  if (d->lm->kind == 2 && (rc = hostLmRetain(d))) {
     return rc;
   }
   d->resultsSynced = false;
@@ -3237,6 +3543,9 @@ static int checkStatus(fltx_decoder* d, int b) {
   }
   if (s & ST_SELECT_FALLBACK) {
     return fail(FLTX_ERR_UNSUPPORTED, "utterance %d: top-K select did not converge (non-finite scores?)", b);
+  }
+  if (s & ST_HLM_MISS) {
+    return fail(FLTX_ERR_STATE, "utterance %d: host LM: a frame asked a question that had not been listed (internal error)", b);
   }
   return FLTX_OK;
 }

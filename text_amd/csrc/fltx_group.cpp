@@ -22,6 +22,7 @@
 #include "fltx.h"
 
 extern "C" int fltx_set_error_(int code, const char* msg);
+extern "C" int fltx_lm_kind_(const fltx_lm* lm);
 
 struct fltx_group {
   /* one host thread per device, alive for as long as the group (a thread per call would cost
@@ -135,6 +136,11 @@ int fltx_group_create(const int32_t* devices, int32_t nDevices, int32_t kind, co
   }
   if (kind == FLTX_DECODER_LEXICON && !htrie) {
     return gfail(FLTX_ERR_INVALID, "fltx_group_create: the lexicon decoder needs a host trie to replicate");
+  }
+  if (nDevices > 1 && fltx_lm_kind_(lm) == 2) {
+    /* its callbacks are made on the caller's thread and never concurrently (decoder/Utils.h:60-62); a group drives
+     * its devices from one host thread each */
+    return gfail(FLTX_ERR_UNSUPPORTED, "fltx_group_create: a host LM (fltx_lm_host_create) serves one device");
   }
   auto* g = new fltx_group();
   g->parts.resize((size_t)nDevices);

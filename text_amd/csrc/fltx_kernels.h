@@ -98,11 +98,13 @@ constexpr uint32_t kExtend = 0x40000000u;   /* cSrc flag: cAux holds the child's
 constexpr uint32_t kSrcMask = 0x3FFFFFFFu;
 constexpr uint32_t kPrevBlank = 0x80000000u; /* tokPb flag */
 constexpr int kFinishEdge = -1;              /* KenLM::finish child key (KenLM.cpp:79) */
+constexpr uint32_t kHostEdge = 0x00FFFFFEu;  /* host LM: a state is named by its id alone, key = (id, kHostEdge) */
 constexpr uint32_t kPhantomNode = 0x80000000u; /* NgramSlot.node: navigation-only prefix */
 constexpr int kMaxNgramOrder = 6;            /* FL_TEXT_KENLM_MAX_ORDER (lm/CMakeLists.txt:3) */
 
 enum { ST_OK = 0, ST_CAND_OVERFLOW = 1, ST_TABLE_FULL = 2, ST_SELECT_FALLBACK = 4, ST_CUT_RETRY = 8,
-       ST_PACKED = 16 /* not an error: the history holds the packed records of fltx_slane.h / fltx_xlane.h */ };
+       ST_PACKED = 16 /* not an error: the history holds the packed records of fltx_slane.h / fltx_xlane.h */,
+       ST_HLM_MISS = 32 /* host LM: a frame asked a question hostLmQuestions() had not listed (a bug, never a user error) */ };
 
 struct DecodeParams {
   /* options (LexiconDecoderOptions, LexiconDecoder.h:21-31) */
@@ -117,7 +119,7 @@ struct DecodeParams {
   const unsigned long long* trieMask; /* [nNodes] bit n set <=> the node has a child for token n (N <= 64), or null */
   int32_t itemCap;                    /* capacity of the (hypothesis, token) item list = K * min(Kt, N), 0 = unused */
   /* LM */
-  int32_t lmKind; /* 0 ZeroLM, 1 n-gram */
+  int32_t lmKind; /* 0 ZeroLM, 1 n-gram, 2 host LM (a user subclass of LM answers the frame's questions on the host) */
   int32_t lmOrder;
   const NgramSlot* ngTab;
   uint32_t ngMask;
@@ -198,6 +200,21 @@ struct DecodeParams {
   const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */
   double yBound;                /* ... and the largest lmWeight x smearing difference of the lexicon (>= 0) */
   double yTransMax;             /* ASG: the largest transition score, at least 0 (upper bound of what a pair can gain) */
+  /* host LM (lmKind == 2, fltx_lm_host_create): the search runs one frame per launch.  Before it, hostLmQuestions()
+   * lists every (LM state, index) pair the frame will ask LM::score / LM::finish about into pinned host memory; the
+   * host answers them (one call of the user's LM per distinct pair) and uploads the answers as one open-addressing
+   * table per utterance, which the frame's lmAsk() reads.  LM states are numbered by the host (the ADDRESS of the
+   * LMState object the user's LM returned, lm/LM.h:37-49), so candidates merge exactly where the reference's
+   * pointer comparison merges them. */
+  int32_t hlmFrame;             /* frame of this launch inside the call's chunk: utterance b takes part iff stepT[b] > hlmFrame */
+  int32_t hlmEnd;               /* hostLmQuestions: list the LM::finish questions of decodeEnd instead of a frame's */
+  int32_t hlmQCap;              /* questions per utterance the list holds */
+  const uint4* hlmTab;          /* answers: {state, index, state the LM returned, score bits} */
+  const uint2* hlmDir;          /* [B] {first slot, slots - 1 (a power of two minus one)} of utterance b's table */
+  int32_t* hlmQCount;           /* [B] pinned host: questions listed (may exceed hlmQCap: the host then reports the overflow) */
+  uint2* hlmQ;                  /* [B*hlmQCap] pinned host: {state, index}; index -1 = LM::finish */
+  int32_t* hlmBeamN;            /* [B] pinned host: hypotheses in the beam ... */
+  uint32_t* hlmBeam;            /* [B*K] ... and their LM states (LM::updateCache, Utils.h:346-354; which states are live) */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
   int32_t profThread; /* the thread whose clock is sampled (lane 0 of the wave under study) */
@@ -867,6 +884,40 @@ FLTX_DEV float lmFinishDev(const DecodeParams& P, int b, uint32_t sid) {
   return ngScore(P, ctx, (uint32_t)P.lmEos, nullptr);
 }
 
+/* Host LM: the answer to LM::score(state sid, usr) / LM::finish (usr == -1) of this frame, from the table the host
+ * uploaded for utterance b (same hash as the host's insert, fltx_api.cpp hostLmAnswer). */
+FLTX_DEV float hostLmLookup(const DecodeParams& P, int b, uint32_t sid, int usr, uint32_t& child, uint32_t* status) {
+  const uint2 dir = P.hlmDir[b];
+  uint32_t s = hashKey(sid, (uint32_t)usr, 0x7f4a7c15u, 0) & dir.y;
+  for (uint32_t probes = 0; probes <= dir.y; ++probes) {
+    const uint4 e = P.hlmTab[(size_t)dir.x + s];
+    if (e.x == sid && e.y == (uint32_t)usr) {
+      child = e.z;
+      return __uint_as_float(e.w);
+    }
+    if (e.x == kEmpty && e.y == kEmpty) {
+      break;
+    }
+    s = (s + 1) & dir.y;
+  }
+  atomOr32(status, ST_HLM_MISS);
+  child = sid;
+  return 0.0f;
+}
+
+/* LM::score(state of a hypothesis, usr) as candidate generation needs it: the score and the merge key (kp, ke) of the
+ * state it leads to -- (parent id, edge) for the LMs whose states are a trie over their inputs (ZeroLM, the n-gram
+ * tables: lm/LM.h:24-34), (id the host gave the returned state, kHostEdge) for a host LM. */
+FLTX_DEV float lmAsk(const DecodeParams& P, const Ws& w, int b, uint32_t sid, int usr, uint32_t& kp, uint32_t& ke) {
+  if (P.lmKind == 2) {
+    ke = kHostEdge;
+    return hostLmLookup(P, b, sid, usr, kp, (uint32_t*)&w.sc[SC_STATUS]);
+  }
+  kp = sid;
+  ke = (uint32_t)usr;
+  return lmScoreDev(P, b, sid, usr);
+}
+
 /* ------------------------------------------------------------------------ */
 /* LM-state identity: lookup-or-insert (parent id, edge) -> id in HBM          */
 /* (LMState::child, lm/LM.h:24-34).  Key = epoch:16 | parent:24 | edge+1:24.  */
@@ -963,11 +1014,9 @@ FLTX_DEV void genLexFree(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       src = (uint32_t)h;
       const bool newTok = ctc ? (n != P.blank && (n != prevTok || prevBlank)) : (n != prevTok);
       if (newTok) { /* :69-85 */
-        lm = lmScoreDev(P, f.b, w.bState[(f.cur) * P.K + h], n);
+        lm = lmAsk(P, w, f.b, w.bState[(f.cur) * P.K + h], n, kp, ke);
         f.nScored += P.lmKind != 0 ? 1u : 0u;
         score = score + P.lmWeight * (double)lm;
-        kp = w.bState[(f.cur) * P.K + h];
-        ke = (uint32_t)n;
         ktp = (uint32_t)n;
         src |= kNewState;
       } else { /* blank :86-97 / repeat :98-110 keep the LM state */
@@ -1340,6 +1389,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     double base = 0, amDelta = 0;
     float lmTok = 0.0f, lexMax = 0.0f, childMax = 0.0f;
     uint32_t sid = 0, spar = 0, lexId = 0;
+    uint32_t tokKp = 0, tokKe = 0; /* token LM: the key of the state lm->score(state, n) leads to (:82-86) */
     int32_t sedge = 0;
     uint32_t ordI = 0;
     if (valid) { /* (1) children, :62-165 */
@@ -1382,7 +1432,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
           base += P.silScore;
         }
         if (P.isLmToken) {
-          lmTok = lmScoreDev(P, f.b, sid, n); /* :82-86 */
+          lmTok = lmAsk(P, w, f.b, sid, n, tokKp, tokKe); /* :82-86 */
           f.nScored += (P.lmKind != 0 && MODE != 3) ? 1u : 0u;
         }
         const int nl = (int)(ed.meta & 7u);
@@ -1438,8 +1488,8 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     {
       float l = P.isLmToken ? lmTok : (childMax - lexMax); /* float subtraction, :94 */
       double sc = base + P.lmWeight * (double)l;
-      uint32_t kp = P.isLmToken ? sid : spar;
-      uint32_t ke = P.isLmToken ? (uint32_t)n : (uint32_t)sedge;
+      uint32_t kp = P.isLmToken ? tokKp : spar;
+      uint32_t ke = P.isLmToken ? tokKe : (uint32_t)sedge;
       uint32_t src = (uint32_t)h | (P.isLmToken ? kNewState : 0u) | kExtend;
       if constexpr (SLIM) {
         pushSlim(P, w, cExt, sc, ordBase, P.isLmToken ? l : childMax, (int32_t)childId, bestKey, preThr);
@@ -1463,14 +1513,12 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       if (on) {
         label = j == 0 ? lab0 : P.trieLabels[labOff + j];
         if (!P.isLmToken) {
-          l = lmScoreDev(P, f.b, sid, label) - lexMax; /* float subtraction, :127 */
+          l = lmAsk(P, w, f.b, sid, label, kp, ke) - lexMax; /* float subtraction, :127 */
           f.nScored += (P.lmKind != 0 && MODE != 3) ? 1u : 0u;
-          kp = sid;
-          ke = (uint32_t)label;
         } else {
           l = lmTok;
-          kp = sid;
-          ke = (uint32_t)n;
+          kp = tokKp;
+          ke = tokKe;
         }
         sc = base + P.lmWeight * (double)l + P.wordScore;
       }
@@ -1486,12 +1534,11 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     /* (1c) unknown word */
     if (waveBallot(cUnk) != 0ull) {
       float l = 0.0f;
-      uint32_t kp = sid, ke = (uint32_t)n;
+      uint32_t kp = tokKp, ke = tokKe;
       if (cUnk) {
         if (!P.isLmToken) {
-          l = lmScoreDev(P, f.b, sid, P.unk) - lexMax;
+          l = lmAsk(P, w, f.b, sid, P.unk, kp, ke) - lexMax;
           f.nScored += (P.lmKind != 0 && MODE != 3) ? 1u : 0u;
-          ke = (uint32_t)P.unk;
         } else {
           l = lmTok;
         }
@@ -1681,11 +1728,15 @@ FLTX_DEV void genEnd(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     }
     if (valid) {
       const uint32_t sid = w.bState[(f.cur) * P.K + h];
-      l = lmFinishDev(P, f.b, sid);
-      sc = w.bScore[(f.cur) * P.K + h] + P.lmWeight * (double)l;
-      if (finishChild) {
+      if (P.lmKind == 2) { /* the user's LM::finish: score and the state it returns (LM.h:76) */
+        l = lmAsk(P, w, f.b, sid, kFinishEdge, kp, ke);
+      } else {
+        l = lmFinishDev(P, f.b, sid);
         kp = sid;
         ke = (uint32_t)kFinishEdge;
+      }
+      sc = w.bScore[(f.cur) * P.K + h] + P.lmWeight * (double)l;
+      if (finishChild) {
         src = (uint32_t)h | kNewState;
       } else {
         kp = w.bSPar[(f.cur) * P.K + h];
@@ -2284,10 +2335,12 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
       am += d;
     }
     uint32_t sid;
-    if (src & kNewState) {
+    if ((src & kNewState) && P.lmKind == 2) {
+      sid = key.x; /* host LM: the key is the id the host gave the state */
+    } else if (src & kNewState) {
       bool fresh;
       sid = stateChild(P, f.b, key.x, (int32_t)key.y, (uint32_t*)&w.sc[SC_STATUS], fresh);
-      if (fresh && P.lmKind != 0) {
+      if (fresh && P.lmKind == 1) {
         /* materialise the n-gram context of the new state */
         const int L = P.lmOrder - 1;
         const int32_t* cin = P.stateCtx + ((size_t)f.b * P.stateCap + key.x) * L;
@@ -2672,8 +2725,8 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
         w.bLm[(0) * P.K + 0] = 0.0;
       }
       w.bState[(0) * P.K + 0] = 0u;
-      w.bSPar[(0) * P.K + 0] = kNoParent;
-      w.bSEdge[(0) * P.K + 0] = 0;
+      w.bSPar[(0) * P.K + 0] = P.lmKind == 2 ? 0u : kNoParent; /* host LM: LM::start's state is id 0, named (0, kHostEdge) */
+      w.bSEdge[(0) * P.K + 0] = P.lmKind == 2 ? (int32_t)kHostEdge : 0;
       if constexpr (GMAX == 0) {
         w.bLex[(0) * P.K + 0] = 0u;
       }
@@ -2696,7 +2749,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
         P.histS[3 * hb + 1] = 0.0;
         P.histS[3 * hb + 2] = 0.0;
       }
-      if (P.lmKind != 0) { /* KenLM::start(false): context = <s> (KenLM.cpp:57) */
+      if (P.lmKind == 1) { /* KenLM::start(false): context = <s> (KenLM.cpp:57) */
         const int L = P.lmOrder - 1;
         int32_t* c0 = P.stateCtx + (size_t)b * P.stateCap * L;
         uint32_t node = 0;
@@ -2741,9 +2794,13 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
       }
     }
   }
-  const int T = P.stepT ? P.stepT[b] : 0;
+  int T = P.stepT ? P.stepT[b] : 0;
   const float* em = P.emissions ? P.emissions + P.emOff[b] : nullptr;
   const int N = P.N;
+  if (P.lmKind == 2) { /* host LM: one frame of the chunk per launch */
+    em = em ? em + (size_t)P.hlmFrame * N : em;
+    T = T > P.hlmFrame ? 1 : 0;
+  }
   LaneCarry lcarry;
   laneCarryInit(lcarry);
   if constexpr (GT > 0) { /* relation tables start empty; the first frame compares state ids */
@@ -2922,6 +2979,161 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     if (P.statusHost) {
       P.statusHost[b] = stNow;
     }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* host LM: the questions of one frame (fltx_hostlm_questions_kernel, one     */
+/* workgroup per utterance, before the frame's decode launch).                */
+/* Lists, for the parked beam of utterance b and the frame's emission row,    */
+/* every (LM state, index) pair candidate generation will pass to lmAsk():    */
+/*   lexicon-free  lm->score(state, n) of every new-token extension           */
+/*                 (LexiconFreeDecoder.cpp:69-85);                            */
+/*   lexicon       lm->score(state, n) per existing trie child with a token   */
+/*                 LM (LexiconDecoder.cpp:82-86), else lm->score(state, label)*/
+/*                 per word the child ends (:124-127) and lm->score(state,    */
+/*                 unk) for a child without words (:145-149);                 */
+/*   decodeEnd     lm->finish(state) of the hypotheses that finish            */
+/*                 (LexiconFreeDecoder.cpp:131-133, LexiconDecoder.cpp:236-   */
+/*                 247: only those at the root if there is one).              */
+/* The reference asks per hypothesis; hypotheses that share a state repeat a  */
+/* question, the host answers each distinct one once (LMState::child's memo). */
+/* Also copies the beam's LM states out (LM::updateCache, Utils.h:346-354).   */
+/* LDS: min(Kt, N) + 4 int32.                                                  */
+/* ------------------------------------------------------------------------ */
+FLTX_DEV void hostLmQuestions(const DecodeParams& P, char* smem) {
+  const int b = (int)blockIdx.x;
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  const int N = P.N;
+  const int nTok = P.Kt < N ? P.Kt : N;
+  int32_t* cnt = (int32_t*)smem; /* [0] questions, [1] tokens listed */
+  int32_t* tokIdx = cnt + 4;
+  const int nBeam = P.uttNBeam[b];
+  const size_t g0 = (size_t)b * P.K;
+  for (int i = tid; i < nBeam; i += W) {
+    P.hlmBeam[g0 + i] = P.gState[g0 + i];
+  }
+  if (tid == 0) {
+    P.hlmBeamN[b] = nBeam;
+    cnt[0] = 0;
+    cnt[1] = 0;
+  }
+  const bool active = P.hlmEnd ? true : (P.stepT[b] > P.hlmFrame);
+  if (!active || nBeam <= 0) {
+    if (tid == 0) {
+      P.hlmQCount[b] = 0;
+    }
+    return;
+  }
+  ldsBarrier();
+  uint2* out = P.hlmQ + (size_t)b * P.hlmQCap;
+  const int lane = laneId();
+  auto push = [&](bool on, uint32_t sid, int idx) { /* every lane of the wave calls it together */
+    const unsigned long long m = waveBallot(on);
+    if (m == 0ull) {
+      return;
+    }
+    const int leader = __builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) {
+      base = atomAdd32((uint32_t*)&cnt[0], (uint32_t)popc64(m));
+    }
+    base = waveShfl32(base, leader);
+    if (on) {
+      const uint32_t qi = base + (uint32_t)popc64(m & ((1ull << lane) - 1ull));
+      if (qi < (uint32_t)P.hlmQCap) {
+        out[qi] = make_uint2(sid, (uint32_t)idx);
+      }
+    }
+  };
+  if (P.hlmEnd) {
+    bool nice = false;
+    if (P.kind == 1) {
+      for (int h = 0; h < nBeam; ++h) {
+        if (P.gLex[g0 + h] == 0u) {
+          nice = true;
+          break;
+        }
+      }
+    }
+    const int rounds = (nBeam + W - 1) / W;
+    for (int it = 0; it < rounds; ++it) {
+      const int h = it * W + tid;
+      bool on = h < nBeam;
+      if (on && P.kind == 1 && nice && P.gLex[g0 + h] != 0u) {
+        on = false;
+      }
+      push(on, on ? P.gState[g0 + h] : 0u, kFinishEdge);
+    }
+  } else {
+    const float* e = P.emissions + P.emOff[b] + (size_t)P.hlmFrame * N;
+    if (nTok < N) { /* the frame's token beam (LexiconFreeDecoder.cpp:42-51): emission descending, ties to the lower index */
+      for (int n = tid; n < N; n += W) {
+        const float v = e[n];
+        int rank = 0;
+        for (int m = 0; m < N; ++m) {
+          const float o = e[m];
+          rank += (o > v || (o == v && m < n)) ? 1 : 0;
+        }
+        if (rank < nTok) {
+          tokIdx[atomAdd32((uint32_t*)&cnt[1], 1u)] = n;
+        }
+      }
+      ldsBarrier();
+    }
+    const bool ctc = P.criterion == 1;
+    const bool hasUnk = P.unkScore > -__builtin_huge_val();
+    const long long total = (long long)nBeam * nTok;
+    const int rounds = (int)((total + W - 1) / W);
+    for (int it = 0; it < rounds; ++it) {
+      const long long i = (long long)it * W + tid;
+      const bool valid = i < total;
+      uint32_t sid = 0;
+      int n = 0;
+      bool qTok = false, qUnk = false;
+      int nLab = 0, labOff = 0, lab0 = -1;
+      if (valid) {
+        const int h = (int)(i / nTok), r = (int)(i - (long long)h * nTok);
+        n = nTok == N ? r : tokIdx[r];
+        const uint32_t tp = P.gTokPb[g0 + h];
+        const int prevTok = (int)(tp & 0x7FFFFFFFu);
+        const bool prevBlank = (tp & kPrevBlank) != 0;
+        sid = P.gState[g0 + h];
+        if (P.kind == 0) {
+          qTok = ctc ? (n != P.blank && (n != prevTok || prevBlank)) : (n != prevTok);
+        } else {
+          const uint32_t lexId = P.gLex[g0 + h];
+          const TrieEdge ed = P.trieEdge[(size_t)lexId * N + n];
+          if (ed.child >= 0) {
+            if (P.isLmToken) {
+              qTok = true;
+            } else {
+              const int nl = (int)(ed.meta & 7u);
+              if (!(lexId == 0u && prevTok == n)) { /* :114-122 */
+                nLab = nl;
+                labOff = (int)(ed.meta >> 4);
+                lab0 = ed.label0;
+              }
+              qUnk = nl == 0 && hasUnk;
+            }
+          }
+        }
+      }
+      push(qTok, sid, n);
+      for (int j = 0; j < 6; ++j) {
+        const bool on = j < nLab;
+        if (waveBallot(on) == 0ull) {
+          break;
+        }
+        push(on, sid, on ? (j == 0 ? lab0 : P.trieLabels[labOff + j]) : 0);
+      }
+      push(qUnk, sid, P.unk);
+    }
+  }
+  ldsBarrier();
+  if (tid == 0) {
+    P.hlmQCount[b] = cnt[0];
   }
 }
 

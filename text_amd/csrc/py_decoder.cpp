@@ -27,9 +27,8 @@ using namespace py::literals;
 
 namespace {
 
-/* Python subclasses of LM (the reference's PyLM trampoline, _decoder.cpp:39-56).
- * They work for host-side scoring; a decoder refuses them (no device tables,
- * no CPU decode path). */
+/* Python subclasses of LM (the reference's PyLM trampoline, _decoder.cpp:39-56).  A decoder runs them through the
+ * per-frame host exchange of decoder/lm/HostLM.h: the search on the device, start / score / finish in Python. */
 class PyLM : public LM {
  public:
   using LM::LM;
@@ -260,12 +259,15 @@ PYBIND11_MODULE(flashlight_lib_text_decoder, m) {
   lex.def(py::init<LexiconDecoderOptions, const TriePtr, const LMPtr, const int, const int, const int,
                    const std::vector<float>&, const bool>(),
           "options"_a, "trie"_a, "lm"_a, "sil_token_idx"_a, "blank_token_idx"_a, "unk_token_idx"_a,
-          "transitions"_a, "is_token_lm"_a);
+          "transitions"_a, "is_token_lm"_a,
+          /* a Python subclass of LM lives in its Python object: the decoder keeps that alive, not just the C++ base
+           * the shared_ptr holds (an LM passed as a temporary would otherwise lose its overrides) */
+          py::keep_alive<1, 4>());
   bindDecoderMethods(lex);
 
   py::class_<LexiconFreeDecoder> lf(m, "LexiconFreeDecoder");
   lf.def(py::init<LexiconFreeDecoderOptions, const LMPtr, const int, const int, const std::vector<float>&>(),
-         "options"_a, "lm"_a, "sil_token_idx"_a, "blank_token_idx"_a, "transitions"_a)
+         "options"_a, "lm"_a, "sil_token_idx"_a, "blank_token_idx"_a, "transitions"_a, py::keep_alive<1, 3>())
       .def("get_options", &LexiconFreeDecoder::getOptions)
       .def("get_sil_idx", &LexiconFreeDecoder::getSilIdx)
       .def("get_blank_idx", &LexiconFreeDecoder::getBlankIdx)
