@@ -56,6 +56,10 @@ struct LMModel {
                          std::vector<int32_t>& out) const = 0;
   virtual float finishCtx(const std::vector<int32_t>& ctx,
                           std::vector<int32_t>& out) const = 0;
+  /* true: the LM hands out ONE state object per input, whatever the history (a user LM whose state is its last
+   * input): child(state, key) is then the same node for every `state` -- the reference compares LM states by
+   * address (lm/LM.h:37-49), so hypotheses with different histories merge. */
+  virtual bool sharesStatesByInput() const { return false; }
 };
 
 /* lm/ZeroLM.cpp:14-26 */
@@ -98,6 +102,29 @@ struct ArpaLM : LMModel {
   }
 };
 
+/* orc_api.h lm_lastword_create: score = integer hash of (previous input, input, seed) / 2^13 */
+static float pairScore(int prev, int w, int seed) {
+  uint32_t h = (uint32_t)prev * 1000003u + (uint32_t)w * 7919u + (uint32_t)seed;
+  h ^= h >> 13;
+  h *= 0x5BD1E995u;
+  h ^= h >> 15;
+  return -(float)(h & 0xFFFFu) / 8192.0f;
+}
+struct LastWordModel : LMModel {
+  int seed = 0;
+  bool finishMakesChild() const override { return false; }
+  bool sharesStatesByInput() const override { return true; }
+  void startCtx(bool, std::vector<int32_t>& ctx) const override { ctx.assign(1, -1); }
+  float scoreCtx(const std::vector<int32_t>& ctx, int usr, std::vector<int32_t>& out) const override {
+    out.assign(1, usr);
+    return pairScore(ctx.at(0) + 2, usr + 2, seed);
+  }
+  float finishCtx(const std::vector<int32_t>& ctx, std::vector<int32_t>& out) const override {
+    out = ctx;
+    return pairScore(ctx.at(0) + 2, 1, seed);
+  }
+};
+
 /* LMState trie (lm/LM.h:21-50): child(parent, key) is memoised, identity is
  * the node (here: the id). */
 struct StateArena {
@@ -108,13 +135,15 @@ struct StateArena {
     ctx.clear();
   }
   int32_t root(const LMModel& lm, bool nothing) {
+    byInput = lm.sharesStatesByInput();
     ctx.emplace_back();
     lm.startCtx(nothing, ctx.back());
     return (int32_t)ctx.size() - 1;
   }
   /* LM.h:24-34 */
+  bool byInput = false; /* LMModel::sharesStatesByInput */
   int32_t child(int32_t s, int32_t key, bool& fresh) {
-    uint64_t k = ((uint64_t)(uint32_t)s << 32) | (uint32_t)key;
+    uint64_t k = ((uint64_t)(byInput ? 0xFFFFFFFFu : (uint32_t)s) << 32) | (uint32_t)key;
     auto it = kids.find(k);
     if (it != kids.end()) {
       fresh = false;
@@ -865,6 +894,12 @@ void* ORC_FN(lm_arpa_create)(const char* arpa_path, const char* usr_words) {
   } catch (...) {
     return nullptr;
   }
+}
+
+void* ORC_FN(lm_lastword_create)(int32_t, int32_t seed) {
+  auto* m = new LastWordModel();
+  m->seed = seed;
+  return m;
 }
 
 void ORC_FN(lm_destroy)(void* lm) { delete (LMModel*)lm; }

@@ -51,6 +51,11 @@ void* ORC_FN(lm_zero_create)(void);
  * `usr_words` = '\n'-joined user dictionary entries, index i = usr idx i
  * (KenLM.cpp:44-49 builds the usr->LM id map from exactly this). */
 void* ORC_FN(lm_arpa_create)(const char* arpa_path, const char* usr_words);
+/* A user-defined LM whose state is its last input only: ONE LMState object per index, shared by every history that
+ * ends in it (tests/host_lms.py LastWordLM is its Python twin).  Hypotheses with different histories then hold the
+ * same LMState and merge -- on the state's address in the reference (decoder/lm/LM.h:37-49).  Scores are a fixed
+ * integer hash of (previous index, index, seed) over 2^13, exact in float. */
+void* ORC_FN(lm_lastword_create)(int32_t n_idx, int32_t seed);
 void ORC_FN(lm_destroy)(void* lm);
 /* score a word sequence from start(false); per_word[i] = score of word i;
  * returns total incl. finish() when with_finish (DecoderTest.cpp:107-120). */

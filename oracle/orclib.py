@@ -72,6 +72,7 @@ class CheckerLib:
         sig = {
             "lm_zero_create": (vp, []),
             "lm_arpa_create": (vp, [C.c_char_p, C.c_char_p]),
+            "lm_lastword_create": (vp, [i32, i32]),
             "lm_destroy": (None, [vp]),
             "lm_score_sequence": (f32, [vp, pi, i32, i32, pf]),
             "trie_create": (vp, [i32, i32]),

@@ -79,6 +79,43 @@ class ArpaRefLM : public LM {
   }
 };
 
+static float pairScore(int prev, int w, int seed) {
+  uint32_t h = (uint32_t)prev * 1000003u + (uint32_t)w * 7919u + (uint32_t)seed;
+  h ^= h >> 13;
+  h *= 0x5BD1E995u;
+  h ^= h >> 15;
+  return -(float)(h & 0xFFFFu) / 8192.0f;
+}
+
+/* a user LM with one shared state object per last input (orc_api.h lm_lastword_create) */
+struct LastWordState : LMState {
+  int last = -1;
+};
+class LastWordRefLM : public LM {
+ public:
+  LastWordRefLM(int n, int seed) : seed_(seed) {
+    begin_ = std::make_shared<LastWordState>();
+    for (int i = 0; i < n; ++i) {
+      states_.push_back(std::make_shared<LastWordState>());
+      states_.back()->last = i;
+    }
+  }
+  LMStatePtr start(bool) override { return begin_; }
+  std::pair<LMStatePtr, float> score(const LMStatePtr& state, const int idx) override {
+    const int prev = std::static_pointer_cast<LastWordState>(state)->last;
+    return {states_.at((size_t)idx), pairScore(prev + 2, idx + 2, seed_)};
+  }
+  std::pair<LMStatePtr, float> finish(const LMStatePtr& state) override {
+    const int prev = std::static_pointer_cast<LastWordState>(state)->last;
+    return {state, pairScore(prev + 2, 1, seed_)}; /* (the state itself, as ZeroLM::finish: the final n-best keeps one entry per last input) */
+  }
+
+ private:
+  int seed_;
+  std::shared_ptr<LastWordState> begin_;
+  std::vector<std::shared_ptr<LastWordState>> states_;
+};
+
 struct LMBox {
   LMPtr lm;
 };
@@ -141,6 +178,12 @@ void* ref_lm_arpa_create(const char* arpa_path, const char* usr_words) {
   } catch (...) {
     return nullptr;
   }
+}
+
+void* ref_lm_lastword_create(int32_t n_idx, int32_t seed) {
+  auto* b = new LMBox();
+  b->lm = std::make_shared<LastWordRefLM>(n_idx, seed);
+  return b;
 }
 
 void ref_lm_destroy(void* lm) { delete (LMBox*)lm; }

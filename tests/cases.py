@@ -64,6 +64,13 @@ CASES = [
     case("lx_scores_t50", kind="lexicon", dist="lexspell", T=50, K=10, lexicon=SMALL_LEX, u=5,
          lm_weight=1.5, word_score=1.0, label_scores=33),
     case("lx_t0", kind="lexicon", dist="lexspell", T=0, K=4, lexicon=SMALL_LEX),
+    # thicker n-best for the features whose first fixtures hold one or two hypotheses (round-4 review, weak #1)
+    case("lx_unk_uni_k32", kind="lexicon", dist="uniform", T=50, K=32, lexicon=SMALL_LEX, u=31,
+         unk_score=-1.5, word_score=1.5, sil_score=-0.3),
+    case("lx_asg_t40_k24", kind="lexicon", dist="lexspell", T=40, K=24, lexicon=NODUP_LEX, crit="asg",
+         trans_seed=21, u=31),
+    case("lx_tokenlm_t80_k24", kind="lexicon", dist="lexspell", T=80, K=24, lexicon=SMALL_LEX, u=33,
+         is_lm_token=True, word_score=0.5),
     # ---- n-gram LM (ARPA semantics, standing in for KenLM) --------------------
     # lm = ("ngram", order, seed): synthetic model over the lexicon words (word LM)
     # or over the tokens (token LM); trie label scores = lm.score(start, word).
@@ -80,6 +87,19 @@ CASES = [
          sil_score=-0.4),
     case("ng_tok_lexicon_t40", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=SMALL_LEX, u=12,
          lm=("ngram", 3, 13), lm_weight=0.9, word_score=0.5, is_lm_token=True),
+    # ---- a user-defined LM whose states are shared between histories (one state object per last input:
+    # oracle/orc_api.h lm_lastword_create, tests/host_lms.py LastWordLM): the reference merges on the state's address
+    case("hl_lastword_lexfree", dist="ctc", T=40, K=10, u=20, lm=("lastword", 5), lm_weight=0.7, is_lm_token=True),
+    case("hl_lastword_lexfree_kt6_logadd", dist="ctc", T=40, K=12, Kt=6, u=21, lm=("lastword", 6), lm_weight=0.5,
+         sil_score=-0.3, log_add=True, is_lm_token=True),
+    case("hl_lastword_word", kind="lexicon", dist="lexspell", T=60, K=12, lexicon=SMALL_LEX, u=22,
+         lm=("lastword", 7), lm_weight=0.8, word_score=0.6, sil_score=-0.2),
+    case("hl_lastword_word_unk", kind="lexicon", dist="uniform", T=50, K=16, lexicon=SMALL_LEX, u=32,
+         lm=("lastword", 8), lm_weight=0.6, unk_score=-1.5, word_score=1.0),
+    case("hl_lastword_toklex", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=SMALL_LEX, u=24,
+         lm=("lastword", 9), lm_weight=0.9, word_score=0.5, is_lm_token=True),
+    case("hl_lastword_asg", dist="ctc", T=40, N=29, K=8, Kt=7, crit="asg", trans_seed=14, u=25,
+         lm=("lastword", 10), lm_weight=0.6, is_lm_token=True),
     # ---- lexicon decoder, BASELINE shapes -------------------------------------
     case("C3_spell_u0", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, size="large"),
     case("C3_spell_u255", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, u=255,

@@ -84,9 +84,16 @@ def arpa_path(c, inp):
     return path, vocab
 
 
+def lastword_size(c, inp):
+    """indices a ("lastword", seed) LM is asked about: words + <unk> for a word LM, tokens otherwise"""
+    return inp["W"] + 1 if (c["kind"] == "lexicon" and not c["is_lm_token"]) else c["N"]
+
+
 def checker_lm(lib, c, inp):
     if c["lm"] == "zero":
         return lib.lm_zero_create()
+    if c["lm"][0] == "lastword":
+        return lib.lm_lastword_create(lastword_size(c, inp), c["lm"][1])
     path, vocab = arpa_path(c, inp)
     lm = lib.lm_arpa_create(path.encode(), "\n".join(vocab).encode())
     assert lm, "lm_arpa_create failed"
@@ -146,6 +153,12 @@ class FltxSession:
     def lm_for(self, c, inp):
         if c["lm"] == "zero":
             return self.zero
+        if c["lm"][0] == "lastword":  # a user-defined LM: decoded through the per-frame host exchange
+            import host_lms
+            key = ("lastword", lastword_size(c, inp), c["lm"][1])
+            if key not in self._lms:
+                self._lms[key] = _capi.HostLM(host_lms.LastWordLM(key[1], key[2]), lib=self.lib)
+            return self._lms[key]
         path, vocab = arpa_path(c, inp)
         key = (path,)
         if key not in self._lms:

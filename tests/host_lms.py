@@ -76,7 +76,6 @@ class LastWordLM:
         self.seed = seed
         self.begin = State(-1)
         self.states = [State(i) for i in range(n_idx)]
-        self.end = State(-2)
 
     def start(self, start_with_nothing):
         return self.begin
@@ -85,7 +84,7 @@ class LastWordLM:
         return self.states[idx], pair_score(state.data + 2, idx + 2, self.seed)
 
     def finish(self, state):
-        return self.end, pair_score(state.data + 2, 1, self.seed)
+        return state, pair_score(state.data + 2, 1, self.seed)
 
 
 class FailingLM(PyZeroLM):
