@@ -84,7 +84,9 @@ def parse():
                          "back-trace of one batch runs under the decode kernel of the next")
     ap.add_argument("--cpu-sample", type=int, default=160, help="utterances timed on the one-thread CPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip every CPU / host-side leg (profiling runs)")
-    ap.add_argument("--no-extras", action="store_true", help="skip all-cores / steady / end-to-end / streaming")
+    ap.add_argument("--no-extras", action="store_true", help="skip all-cores / steady / end-to-end / streaming / sustained / secondary")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / C5-share / WP lines of the default run")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the back-to-back leg (0 = off)")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
     ap.add_argument("--profile-out", default="", help="... and append it to this file (profiles/rNN/phase_split_*.txt)")
     ap.add_argument("--mode", default="process", choices=["process", "group"],
@@ -184,6 +186,15 @@ class Job:
             self.trie = ht.upload(self.ctx)
         self.Ts = np.full(B, self.T, dtype=np.int32)
 
+    def close(self):
+        """(a secondary workload's tables and contexts go before the next one is set up)"""
+        for t in self.more_tries + ([self.trie] if self.trie is not None else []):
+            t.close()
+        self.lm.close()
+        for c in self.more_ctx:
+            c.close()
+        self.ctx.close()
+
     def decoder(self, second_stream=False):
         """second_stream: a decoder on a context (= HIP stream) of its own, with its own copy of the
         trie; the LM object is shared (its tables are uploaded once per context)."""
@@ -236,6 +247,19 @@ def main():
         else:
             dist.init_process_group(a.backend)
 
+    out, fail = measure(a, torch, dist, rank, local, world, primary=True)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+    if fail:
+        raise SystemExit(fail)
+
+
+def measure(a, torch, dist, rank, local, world, primary):
+    """One workload through the timed loop -> (the JSON line's dict, None or why the line must not look green).
+    primary: the judged line with every leg; otherwise a `secondary` entry (kernel timing, roofline, a small CPU
+    sample for the n-best comparison)."""
     cfg = dict(WORKLOADS[a.workload])
     for key, val in (("T", a.frames), ("K", a.beam), ("Kt", a.beam_token)):
         if val:
@@ -388,28 +412,72 @@ def main():
         if dec_s is not dec:
             dec_s.close()
 
+    # ---- sustained: back-to-back batches for >= --sustained-seconds (clock / thermal settling: the timed region
+    # above is tens of milliseconds), frames/s over the whole leg and per window of 100 steps ----
+    if primary and rank == 0 and world == 1 and a.sustained_seconds > 0 and not a.no_extras:
+        win, rates = 100, []
+        fence()
+        t_start = time.perf_counter()
+        while time.perf_counter() - t_start < a.sustained_seconds or len(rates) < 2:
+            t0 = time.perf_counter()
+            for _ in range(win):
+                step()
+            fence()
+            rates.append(B * T * win / (time.perf_counter() - t0))
+        t_all = time.perf_counter() - t_start
+        for i in range(len(decs)):
+            read_events(i)
+        out["sustained"] = {"seconds": t_all, "steps": win * len(rates), "value": B * T * win * len(rates) / t_all,
+                            "unit": "frames/s", "window_steps": win, "window_min": min(rates), "window_max": max(rates),
+                            "windows": len(rates), "first_window": rates[0], "last_window": rates[-1],
+                            "note": "the timed loop's step, back to back; a fence (stream synchronize) after every window"}
+
     # ---- CPU baselines + parity spot check, end to end, streaming (rank 0, N=1 only) --------
     if rank == 0 and world == 1 and not a.no_cpu:
         dec.decode_batch(None, job.Ts, N, device_ptr=e_dev.data_ptr())  # the n-best compared below
         out["cpu_baseline"] = cpu_baseline(a, dec, job)
-        if not a.no_extras:
+        if primary and not a.no_extras:
             out["cpu_baseline_steady"], out["cpu_baseline_all_cores"] = cpu_more(a, job)
             out["end_to_end"] = end_to_end(job, dec, B, T, N)
             out["streaming"] = streaming(job, B, T, N)
-    if rank == 0:
-        print(json.dumps(out))
     for d in decs:
         d.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    job.close()
+    del e_dev
     # a line whose n-best differs from the reference's, or that spent its time in fallbacks,
     # must not look green
+    fail = None
     mism = out.get("cpu_baseline", {}).get("gpu_nbest_mismatches_on_sample", 0) + \
         out.get("streaming", {}).get("final_nbest_mismatches_vs_cpu_on_sample", 0)
     if mism:
-        raise SystemExit("bench.py: %d of the sampled utterances differ from the CPU reference" % mism)
+        fail = "bench.py: %s: %d of the sampled utterances differ from the CPU reference" % (a.workload, mism)
     if redone * 4 > B:
-        raise SystemExit("bench.py: %d of %d utterances fell back to a general engine" % (redone, B))
+        fail = "bench.py: %s: %d of %d utterances fell back to a general engine" % (a.workload, redone, B)
+
+    # ---- secondary: the other BASELINE configurations under the same clock (default invocation, N = 1) ----
+    if primary and rank == 0 and world == 1 and a.workload == "C2" and not a.no_secondary and not a.no_extras and \
+            not (a.batch or a.frames or a.beam or a.beam_token or a.tokens or a.asg or a.log_add or a.set):
+        import copy
+        out["secondary"] = {}
+        for name, wl, batch, sample in (("C3", "C3", 0, 24), ("C4", "C4", 0, 12), ("C5_share", "C5", 1024, 8),
+                                        ("WP", "WP", 0, 8)):
+            a2 = copy.copy(a)
+            a2.workload, a2.batch, a2.cpu_sample = wl, batch, sample
+            a2.steps, a2.warmup = max(4, a.steps // 2), 2
+            t0 = time.perf_counter()
+            o2, f2 = measure(a2, torch, dist, rank, local, world, primary=False)
+            r2, c2 = o2["roofline"], o2.get("cpu_baseline", {})
+            out["secondary"][name] = {
+                "workload": o2["config"]["workload"], "value": o2["value"], "unit": "frames/s", "steps": o2["steps"],
+                "ms_per_step": o2["ms_per_step"], "kernel_ms": r2["kernel_ms"], "engine": o2["config"]["engine"],
+                "redone": o2["config"]["redone"], "why_not_lane": o2["config"]["why_not_lane"],
+                "roofline": {"frac": r2["frac"], "frac_counter_bytes": r2["frac_counter_bytes"], "achieved": r2["achieved"],
+                             "algorithmic_bytes_per_launch": r2["algorithmic_bytes_per_launch"], "traffic": r2["traffic"]},
+                "mismatches_vs_reference_on_sample": c2.get("gpu_nbest_mismatches_on_sample"),
+                "cpu_baseline_1thread": c2.get("value"), "cpu_sample_utterances": sample, "cpu_kind": c2.get("kind"),
+                "wall_s_including_setup": time.perf_counter() - t0}
+            fail = fail or f2
+    return out, fail
 
 
 def group_mode(a):
@@ -439,8 +507,8 @@ def group_mode(a):
         with torch.cuda.device(devices[i]):
             bufs.append(torch.from_numpy(e_hosts[i]).cuda())
     torch.cuda.synchronize()
-    grp = _capi.DecoderGroup(devices, _capi.LEXICON if j0.lex else _capi.LEXFREE, j0.opt, j0.lm, 0, N - 1,
-                             unk=j0.W if j0.lex else -1, host_trie=j0.host_trie)
+    grp = _capi.DecoderGroup(devices, _capi.LEXICON if j0.lex else _capi.LEXFREE, j0.opt, j0.lm, 0, j0.blank,
+                             unk=j0.W if j0.lex else -1, host_trie=j0.host_trie, transitions=j0.tr)
     Ts = np.full(n * B, T, dtype=np.int32)
     offs = (np.arange(n * B, dtype=np.int64) % B) * T * N  # utterance b of part i sits at b - i * B in that device's buffer
     ptrs = [t.data_ptr() for t in bufs]

@@ -26,6 +26,7 @@ def _run(sess, c, inp, lm, sets=None):
     return out, info
 
 
+EMU_SETS = {"threads": 64}  # (the emulator runs a workgroup's threads as host threads, a launch per frame)
 ZERO_CASES = ["lf_ctc_t20_k4", "lf_ctc_t60_k10_kt5", "lf_ctc_t60_k10_logadd", "lf_ctc_t0", "lf_ctc_t1",
               "lf_asg_t40_n29_kt7", "lx_spell_t40_k8", "lx_spell_t60_k12_logadd", "lx_spell_unk", "lx_asg_t40",
               "lx_tokenlm_t40", "lx_scores_t50", "lx_t0"]
@@ -33,11 +34,11 @@ NGRAM_CASES = ["ng_word_t60_k16_4g", "ng_tok_lexfree_t40", "ng_word_unk_t40", "n
                "ng_tok_lexfree_kt8", "ng_tok_lexicon_t40"]
 
 
-def _zero_clone(sess, golden, name):
+def _zero_clone(sess, golden, name, sets=None):
     c = cases.BY_NAME[name]
     inp = helpers.case_inputs(c)
     lm = _capi.HostLM(host_lms.PyZeroLM(), lib=sess.lib)
-    got, info = _run(sess, c, inp, lm)
+    got, info = _run(sess, c, inp, lm, sets)
     assert info["engine"] == 0, info
     tol = 1e-9 if c["log_add"] else 0.0
     ok, why = helpers.check_against_golden(got, golden[name], score_tol=tol)
@@ -47,7 +48,7 @@ def _zero_clone(sess, golden, name):
     lm.close()
 
 
-def _ngram_wrapper(sess, golden, oracle_lib, name, gpu):
+def _ngram_wrapper(sess, golden, oracle_lib, name, gpu, sets=None):
     """A Python LM over the ARPA tables gives the n-best of the device n-gram path, the oracle's and the reference's."""
     c = cases.BY_NAME[name]
     inp = helpers.case_inputs(c)
@@ -55,7 +56,7 @@ def _ngram_wrapper(sess, golden, oracle_lib, name, gpu):
     want_dev = sess.run(c, inp)
     user = host_lms.PyNgramLM(arpa)
     lm = _capi.HostLM(user, lib=sess.lib)
-    got, info = _run(sess, c, inp, lm)
+    got, info = _run(sess, c, inp, lm, sets)
     assert info["engine"] == 0 and user.calls > 0
     tol = (1e-5 if gpu else 1e-9) if c["log_add"] else 0.0
     ok, why = helpers.hyps_equal(want_dev, got, score_tol=tol)
@@ -69,12 +70,12 @@ def _ngram_wrapper(sess, golden, oracle_lib, name, gpu):
 
 @pytest.mark.parametrize("name", ZERO_CASES)
 def test_emulated_python_zero_lm_clone_matches_golden(emu_session, golden, name):
-    _zero_clone(emu_session, golden, name)
+    _zero_clone(emu_session, golden, name, EMU_SETS)
 
 
 @pytest.mark.parametrize("name", NGRAM_CASES)
 def test_emulated_python_lm_over_arpa_tables(emu_session, golden, oracle_lib, name):
-    _ngram_wrapper(emu_session, golden, oracle_lib, name, gpu=False)
+    _ngram_wrapper(emu_session, golden, oracle_lib, name, gpu=False, sets=EMU_SETS)
 
 
 def _raises(sess):
@@ -144,3 +145,36 @@ def test_user_lm_exception_surfaces(gpu_session):
 @pytest.mark.gpu
 def test_ragged_batch_with_a_user_lm(gpu_session, oracle_lib):
     _batch_of_ragged_utterances(gpu_session, oracle_lib)
+
+
+# ---- streams: decodeStep chunks, getBestHypothesis(lookBack), prune(lookBack) with a user LM -----------------------
+STREAM_CASES = ["hl_lastword_lexfree", "hl_lastword_toklex", "hl_lastword_word", "hl_lastword_asg"]
+
+
+def _stream(sess, oracle_lib, name, threads=None):
+    """Event by event against the oracle's trace (the oracle streams like the compiled reference:
+    tests/test_streaming.py, and decodes this LM like it: tests/test_oracle_golden.py)."""
+    import stream_scenarios as ss
+    c = cases.BY_NAME[name]
+    inp = helpers.case_inputs(c)
+    chunks, lbs = [7, 9, 1, 12, 20, 30], [0, 2, 0, 5]
+    want = ss.trace_checker(oracle_lib, c, inp, chunks, lbs)
+    assert not ss.has_ties(want)
+    lm = sess.lm_for(c, inp)
+    before = lm.released
+    got, engine = ss.trace_device(sess, c, inp, chunks, lbs, threads)
+    d = ss.first_difference(want, got)
+    assert d is None, d
+    assert engine == 0
+    assert lm.released > before  # prune() released LM states the beam no longer holds
+
+
+@pytest.mark.parametrize("name", STREAM_CASES[:2])
+def test_emulated_stream_with_a_user_lm(emu_session, oracle_lib, name):
+    _stream(emu_session, oracle_lib, name, threads=64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", STREAM_CASES)
+def test_stream_with_a_user_lm(gpu_session, oracle_lib, name):
+    _stream(gpu_session, oracle_lib, name)

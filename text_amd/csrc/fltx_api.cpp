@@ -2914,7 +2914,7 @@ int hostLmExchange(fltx_decoder* d, DecodeParams& P, int frame, bool end) {
 #ifdef FLTX_EMU
   {
     const DecodeParams* pp = &P;
-    emuLaunch(B, 256, qLds, [pp](char* smem) { hostLmQuestions(*pp, smem); });
+    emuLaunch(B, 64, qLds, [pp](char* smem) { hostLmQuestions(*pp, smem); }); /* (one wave: host threads are expensive) */
   }
 #else
   HIPCHK(hipFuncSetAttribute((const void*)fltx_hostlm_questions_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
