@@ -109,6 +109,7 @@ FLTX_DEV unsigned long long atomOr64(unsigned long long* p, unsigned long long v
   return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST);
 }
 FLTX_DEV uint32_t loadCoherent32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+FLTX_DEV void storeCoherent32(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 FLTX_DEV unsigned long long atomCas64(unsigned long long* p, unsigned long long cmp, unsigned long long val) {
   __atomic_compare_exchange_n(p, &cmp, val, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
   return cmp;

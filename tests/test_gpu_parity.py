@@ -181,7 +181,8 @@ def test_decodertest_replay_on_device(gpu_session, tmp_path):
     dec.close()
 
 
-LEX_CUT = [c for c in cases.CASES if c["kind"] == "lexicon" and not c["log_add"]]
+LEX_CUT = [c for c in cases.CASES if c["kind"] == "lexicon" and not c["log_add"] and
+           (c["lm"] == "zero" or c["lm"][0] != "lastword")]  # (a host LM runs without the score cut: fltx_api.cpp prepare())
 
 
 @pytest.mark.gpu

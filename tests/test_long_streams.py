@@ -1,0 +1,124 @@
+"""Unbounded streams (round-4 review, missing #2; reference: LexiconFreeDecoder.cpp:205-227, LexiconDecoder.cpp:304-325,
+Utils.h:312-342 -- prune() bounds the reference's memory and a stream may run forever).  LM-state ids are recycled
+(fltx_compact_states_kernel): a stream far longer than its buffer runs with constant tables, and every
+getBestHypothesis() on the way and the final n-best equal the oracle's (which streams like the compiled reference:
+tests/test_streaming.py)."""
+import numpy as np
+import pytest
+
+import cases
+import helpers
+import stream_scenarios as ss
+from oracle import orclib
+from text_amd import synth
+
+
+def _long_stream(sess, orc, c, inp, chunk, max_frames, look_back, sets=None, threads=None, every=1):
+    """-> (events compared, compactions, id_cap).  Feeds c["T"] frames in chunks; after every chunk
+    getBestHypothesis(look_back) on both sides, then prune(look_back)."""
+    N, T = c["N"], c["T"]
+    od, olm, otrie = ss.checker_decoder(orc, c, inp)
+    orc.decoder_begin(od)
+    d = sess.decoder(c, inp, threads)
+    for k, v in (sets or {}).items():
+        d.set(k, v)
+    d.stream_begin(1, N, max_frames)
+    cap0 = d.get("id_cap")
+    t, i, compared = 0, 0, 0
+    while t < T:
+        ch = min(chunk, T - t)
+        row = np.ascontiguousarray(inp["e"][t:t + ch])
+        orc.decoder_step(od, orclib._fp(row), ch, N)
+        d.stream_step(row, [ch])
+        t += ch
+        if i % every == 0:
+            want = orc.best(od, look_back, max_frames + 8)
+            got = d.best(0, look_back)
+            assert (got.score, got.am, got.lm) == (want.score, want.am, want.lm), (t, got.score, want.score)
+            assert np.array_equal(got.tokens, want.tokens) and np.array_equal(got.words, want.words), t
+            compared += 1
+        orc.decoder_prune(od, look_back)
+        d.stream_prune(look_back)
+        i += 1
+    orc.decoder_end(od)
+    d.stream_end()
+    ok, why = helpers.hyps_equal(orc.collect(od), d.results(0))
+    assert ok, why
+    out = (compared, d.get("compactions"), cap0, d.get("id_cap"), d.get("engine"))
+    d.close()
+    orc.decoder_destroy(od)
+    if otrie is not None:
+        orc.trie_destroy(otrie)
+    orc.lm_destroy(olm)
+    return out
+
+
+EMU = [
+    # lexicon-free + ZeroLM: the lane = LM state stream engine over childTab / maskTab
+    dict(name="ls_lexfree", dist="ctc", T=360, N=12, K=6, u=800),
+    # ... with logAdd: the lean step
+    dict(name="ls_lexfree_logadd", dist="ctc", T=240, N=12, K=6, u=801, log_add=True),
+    # token n-gram LM on the lexicon-free decoder: generic engine, stateTab + stateVal
+    dict(name="ls_lexfree_ngram", dist="ctc", T=240, N=12, K=6, u=802, lm=("ngram", 3, 91), lm_weight=0.8),
+    # lexicon + word n-gram LM
+    dict(name="ls_lexicon_ngram", kind="lexicon", dist="lexspell", T=240, N=29, K=8, Kt=10, u=803,
+         lexicon=cases.SMALL_LEX, lm=("ngram", 3, 92), lm_weight=1.2, word_score=0.8, sil_score=-0.3),
+    # lexicon + ZeroLM
+    dict(name="ls_lexicon_zero", kind="lexicon", dist="lexspell", T=240, N=29, K=8, Kt=10, u=804,
+         lexicon=cases.SMALL_LEX),
+]
+
+
+@pytest.mark.parametrize("spec", EMU, ids=lambda s: s["name"])
+@pytest.mark.parametrize("always", [0, 1])
+def test_emulated_stream_longer_than_its_tables(emu_session, oracle_lib, spec, always):
+    c = cases.case(**spec)
+    inp = helpers.case_inputs(c)
+    tol_sets = {"compact_always": always}
+    # (the lexicon decoder prunes back to a complete hypothesis, LexiconDecoder.h:97-99: its buffer holds a few words)
+    mf = 96 if c["kind"] == "lexicon" else 24
+    compared, compactions, cap0, cap1, engine = _long_stream(emu_session, oracle_lib, c, inp, chunk=10, max_frames=mf,
+                                                             look_back=[0, 3][always], sets=tol_sets, threads=64)
+    assert cap0 == cap1 and 0 < cap0 <= c["K"] * (mf + 2) + 8 * c["K"] + 64
+    assert compactions >= (c["T"] // 10 - 1 if always else (1 if c["kind"] == "lexicon" else 2)), compactions
+    assert compared == (c["T"] + 9) // 10
+
+
+@pytest.mark.gpu
+def test_lexicon_free_stream_of_100000_frames(gpu_session, oracle_lib):
+    """100 000 frames through a 208-frame buffer, default settings: constant tables (id_cap), getBestHypothesis
+    after every chunk and the final n-best equal to the oracle."""
+    T, N = 100000, 29
+    c = cases.case("ls_100k", dist="ctc", T=T, N=N, K=50, u=810)
+    inp = dict(e=synth.emissions("ctc", 810, T, N), tr=None, lex=None)
+    compared, compactions, cap0, cap1, engine = _long_stream(gpu_session, oracle_lib, c, inp, chunk=50, max_frames=208,
+                                                             look_back=0)
+    assert engine == 3 and cap0 == cap1 == 50 * 210 + 8 * 50 + 64
+    assert compactions >= T // 208 // 2 and compared == T // 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lm", ["zero", ("ngram", 4, 4242)])
+def test_lexicon_stream_of_20000_frames(gpu_session, oracle_lib, lm):
+    """A C3-shaped (and a C4-shaped) lexicon stream of 20 000 frames through a 208-frame buffer."""
+    T, N = 20000, 29
+    c = cases.case("ls_20k", kind="lexicon", dist="lexspell", T=T, N=N, K=50, Kt=10, u=811, lexicon=cases.FULL_LEX,
+                   lm=lm, lm_weight=2.0 if lm != "zero" else 0.0, word_score=2.0 if lm != "zero" else 0.0,
+                   sil_score=-1.0 if lm != "zero" else 0.0)
+    inp = helpers.case_inputs(c)
+    compared, compactions, cap0, cap1, engine = _long_stream(gpu_session, oracle_lib, c, inp, chunk=50, max_frames=208,
+                                                             look_back=0, every=4)
+    assert cap0 == cap1 and compactions >= 10
+    assert compared == T // 50 // 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", EMU, ids=lambda s: s["name"])
+def test_stream_longer_than_its_tables(gpu_session, oracle_lib, spec):
+    c = cases.case(**dict(spec, T=3000))
+    inp = helpers.case_inputs(c)
+    for always, lb in ((0, 0), (1, 3)):
+        mf = 208 if c["kind"] == "lexicon" else 24
+        compared, compactions, cap0, cap1, engine = _long_stream(gpu_session, oracle_lib, c, inp, chunk=10, max_frames=mf,
+                                                                 look_back=lb, sets={"compact_always": always})
+        assert cap0 == cap1 and compactions >= 2

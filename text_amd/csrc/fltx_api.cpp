@@ -87,6 +87,11 @@ __global__ void __launch_bounds__(256) fltx_tokbeam_kernel(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_tb_smem[];
   wlTokBeamRows(P, fltx_tb_smem);
 }
+/* streams: LM-state ids nothing can meet again go back to the utterance's free list (compactStates) */
+__global__ void __launch_bounds__(1024) fltx_compact_states_kernel(CompactParams Q) {
+  __shared__ int32_t sh[4];
+  compactStates(Q, sh);
+}
 /* host LM: the (LM state, index) questions of the next frame, one workgroup per utterance (hostLmQuestions) */
 __global__ void __launch_bounds__(256) fltx_hostlm_questions_kernel(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_hq_smem[];
@@ -477,6 +482,14 @@ struct fltx_decoder {
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
+  /* streams: recycled LM-state ids (DecodeParams::idFree ...) */
+  DBuf idFree, idPar, idEdge, idBorn, idKeep, uttIdLimit, stateVal;
+  bool recycle = false;       /* this stream hands ids out from free lists */
+  int idFamily = 0;           /* 0: childTab / maskTab engines, 1: generic engine (stateTab + stateVal) */
+  int64_t idsUsedBound = 0;   /* upper bound of the ids any stream has taken since its free list was last rebuilt */
+  int64_t idsFreeBound = 0;   /* lower bound of what a rebuilt free list holds (beam x max_frames) */
+  int compactions = 0;        /* fltx_compact_states_kernel launches since fltx_stream_begin ("compactions") */
+  int userCompactAlways = 0;  /* tests ("compact_always"): rebuild the free lists before every chunk */
   DBuf scored; /* n-gram LM queries per utterance (accounting) */
   /* host LM (lm->kind == 2): question lists and beam states in pinned host memory (written by the kernel), the
    * answer tables staged in pinned memory and uploaded once per frame */
@@ -1303,6 +1316,10 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->lastRedo;
   } else if (!strcmp(key, "sstream")) {
     *value = d->sstream;
+  } else if (!strcmp(key, "compactions")) { /* streams: times the LM-state free lists were rebuilt since fltx_stream_begin */
+    *value = d->compactions;
+  } else if (!strcmp(key, "id_cap")) {     /* streams: LM-state ids per stream (constant however long the stream runs) */
+    *value = d->recycle ? d->idCap : 0;
   } else if (!strcmp(key, "hlm_asked")) { /* host LM: questions the frames listed since decodeBegin ... */
     *value = d->hlmAsked;
   } else if (!strcmp(key, "hlm_distinct")) { /* ... and how many the callbacks were asked (distinct per frame) */
@@ -1351,6 +1368,10 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
 int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   if (!d || !key) {
     return fail(FLTX_ERR_INVALID, "null argument");
+  }
+  if (!strcmp(key, "compact_always")) {
+    d->userCompactAlways = value ? 1 : 0;
+    return FLTX_OK;
   }
   if (!strcmp(key, "threads")) {
     if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) {
@@ -1565,12 +1586,14 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   /* LM states are created for as long as a stream runs, not for as long as its frames stay buffered: the id
    * tables of a stream are sized for `stream_total_frames` (default: at least 2 048 frames; a longer stream says
    * so before fltx_stream_begin, or its status reports a full table), the history for max_frames */
-  const int idT = d->offlineCall ? maxT : std::max(maxT, d->streamTotalFrames > 0 ? d->streamTotalFrames : 2048);
-  uint64_t wantStates = 2ull * ((uint64_t)K * (uint64_t)(idT + 2) + 2);
+  /* A stream's ids are recycled (fltx_compact_states_kernel): its tables are sized for what the buffer can hold --
+   * beam x max_frames states made between two rebuilds of the free list, plus the states a rebuild keeps -- however
+   * long the stream runs ("stream_total_frames" is accepted and ignored).  A host LM numbers its own states. */
+  d->recycle = !d->offlineCall && !hostLm;
+  const int idT = maxT;
+  const int64_t streamIds = (int64_t)K * (idT + 2) + 8 * (int64_t)K + 64;
+  uint64_t wantStates = d->recycle ? 2ull * (uint64_t)streamIds : 2ull * ((uint64_t)K * (uint64_t)(idT + 2) + 2);
   uint32_t cap = nextPow2(std::max<uint64_t>(wantStates, 1024));
-  if (cap > (1u << 23) && !d->offlineCall) { /* (a stream takes what the id width allows) */
-    cap = 1u << 23;
-  }
   if (cap > (1u << 23)) {
     return fail(FLTX_ERR_UNSUPPORTED, "K * T = %llu exceeds the 2^23 LM states per utterance this build indexes",
                 (unsigned long long)K * (maxT + 2));
@@ -2067,12 +2090,27 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (!lds) {
     rc |= d->gws.ensure(d->wsBytes * (size_t)B, st, false);
   }
+  d->idFamily = d->lean ? 0 : 1;
   if (d->lean && !d->slane) {
-    d->idCap = std::min<int64_t>((int64_t)K * (idT + 2) + 2, (1ll << 23) - 2);
+    d->idCap = std::min<int64_t>(d->recycle ? streamIds : (int64_t)K * (idT + 2) + 2, (1ll << 23) - 2);
     rc |= d->childTab.ensure(4 * (size_t)B * d->idCap * N, st, false);
     rc |= d->maskTab.ensure(8 * (size_t)B * d->idCap, st, false);
     rc |= d->uttNextId.ensure(4 * (size_t)B, st, true);
     rc |= d->gMask.ensure(8 * bk, st, false);
+  } else if (d->recycle) {
+    d->idCap = std::min<int64_t>(streamIds, (1ll << 23) - 2);
+    rc |= d->uttNextId.ensure(4 * (size_t)B, st, true);
+    rc |= d->stateVal.ensure(4 * (size_t)B * cap, st, false);
+    rc |= d->idEdge.ensure(4 * (size_t)B * d->idCap, st, false);
+  }
+  if (d->recycle) {
+    if (streamIds > (1ll << 23) - 2) {
+      return fail(FLTX_ERR_UNSUPPORTED, "beam %d x max_frames %d exceeds the 2^23 LM-state ids a stream indexes", K, idT);
+    }
+    rc |= d->idFree.ensure(4 * (size_t)B * d->idCap, st, false) | d->idPar.ensure(4 * (size_t)B * d->idCap, st, false);
+    rc |= d->idBorn.ensure(4 * (size_t)B * d->idCap, st, false) | d->idKeep.ensure((size_t)B * d->idCap, st, false);
+    rc |= d->uttIdLimit.ensure(4 * (size_t)B, st, true);
+    d->idsFreeBound = (int64_t)K * (idT + 2);
   }
   if ((d->ylane || d->xlane) && d->yshare) {
     rc |= d->ymemo.ensure(sizeof(unsigned long long) * (size_t)d->ymemoSlots * (size_t)B, st, false); /* (wiped by the kernel) */
@@ -2197,6 +2235,16 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
                      : 0.0;
   P.yTransMax = d->transMax;
   P.scored = (d->lm->kind == 1 && d->scored.p) ? d->scored.as<uint32_t>() : nullptr;
+  if (d->recycle) {
+    P.idFree = d->idFree.as<uint32_t>();
+    P.uttIdLimit = d->uttIdLimit.as<int32_t>();
+    P.idPar = d->idPar.as<uint32_t>();
+    P.idBorn = d->idBorn.as<uint32_t>();
+    if (d->idFamily == 1) {
+      P.idEdge = d->idEdge.as<int32_t>();
+      P.stateVal = d->stateVal.as<uint32_t>();
+    }
+  }
   if (d->lm->kind == 2) {
     P.hlmQCap = d->hlmQCap;
     P.hlmQCount = (int32_t*)d->hlmQCount.p;
@@ -2878,6 +2926,51 @@ int settleStream(fltx_decoder* d) {
   return rc;
 }
 
+/* streams: mode 0 = every id free (a new stream), mode 1 = give back the ids nothing can meet again.  Runs on the launch
+ * stream between two decode launches; nothing is waited for. */
+int launchCompact(fltx_decoder* d, int mode) {
+  if (!d->recycle) {
+    return FLTX_OK;
+  }
+  int rc;
+  if (mode == 1 && d->idFamily == 1 && (rc = bumpEpoch(d))) { /* (the rebuilt table's epoch; empties the LM score cache too) */
+    return rc;
+  }
+  CompactParams Q;
+  memset(&Q, 0, sizeof(Q));
+  Q.K = d->opt.beam_size;
+  Q.N = d->N;
+  Q.mode = mode;
+  Q.family = d->idFamily;
+  Q.idCap = d->idCap;
+  Q.uttNBeam = d->uttNBeam.as<int32_t>();
+  Q.gState = d->gState.as<uint32_t>();
+  Q.idFree = d->idFree.as<uint32_t>();
+  Q.uttIdLimit = d->uttIdLimit.as<int32_t>();
+  Q.uttNextId = d->uttNextId.as<int32_t>();
+  Q.idPar = d->idPar.as<uint32_t>();
+  Q.idEdge = d->idEdge.as<int32_t>();
+  Q.idBorn = d->idBorn.as<uint32_t>();
+  Q.keep = d->idKeep.as<uint8_t>();
+  Q.childTab = d->childTab.as<uint32_t>();
+  Q.maskTab = d->maskTab.as<unsigned long long>();
+  Q.gMask = d->gMask.as<unsigned long long>();
+  Q.stateTab = d->stateTab.as<unsigned long long>();
+  Q.stateVal = d->stateVal.as<uint32_t>();
+  Q.stateCap = d->stateCap;
+  Q.epoch = d->epoch;
+#ifdef FLTX_EMU
+  const CompactParams* qq = &Q;
+  emuLaunch(d->B, 64, 64, [qq](char* sm) { compactStates(*qq, (int32_t*)sm); });
+#else
+  hipLaunchKernelGGL(fltx_compact_states_kernel, dim3(d->B), dim3(1024), 0, d->ctx->stream, Q);
+  HIPCHK(hipGetLastError());
+#endif
+  d->idsUsedBound = mode == 0 ? 1 : 0;
+  d->compactions += mode;
+  return FLTX_OK;
+}
+
 /* ---- host LM (fltx_lm_host_create): one frame per launch, the frame's LM questions answered on the host ------- */
 int hostLmEnsure(fltx_decoder* d) {
   const int64_t K = d->opt.beam_size, N = d->N, B = d->B;
@@ -3331,6 +3424,10 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   d->framesExact = true;
   d->chunkPending = false;
   d->pendingPrune = -1;
+  d->compactions = 0;
+  if ((rc = launchCompact(d, 0))) {
+    return rc;
+  }
   DecodeParams P;
   fillParams(d, P);
   if (d->lm->kind == 2 && (rc = hostLmBegin(d, P))) {
@@ -3396,6 +3493,21 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
   }
   if ((rc = settleStream(d))) {
     return rc;
+  }
+  if (d->recycle) {
+    /* a frame makes at most beam new LM states per stream: when this chunk could run the free lists dry, the ids
+     * nothing can meet again are given back first (beam x max_frames ids are free after that, or the chunk's status
+     * says the table is full) */
+    int maxT = 0;
+    for (int b = 0; b < d->B; ++b) {
+      maxT = std::max(maxT, T[b]);
+    }
+    const int64_t want = (int64_t)d->opt.beam_size * maxT * (d->streamOpt ? 2 : 1); /* (a chunk decoded again may name states twice) */
+    const int64_t room = (d->compactions ? d->idsFreeBound : d->idCap) - d->idsUsedBound;
+    if ((want > room || d->userCompactAlways) && (rc = launchCompact(d, 1))) {
+      return rc;
+    }
+    d->idsUsedBound += want;
   }
   DecodeParams P;
   fillParams(d, P); /* (emOff / stepT: the slot uploadStep has just filled) */

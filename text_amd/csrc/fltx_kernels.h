@@ -98,6 +98,7 @@ constexpr uint32_t kExtend = 0x40000000u;   /* cSrc flag: cAux holds the child's
 constexpr uint32_t kSrcMask = 0x3FFFFFFFu;
 constexpr uint32_t kPrevBlank = 0x80000000u; /* tokPb flag */
 constexpr int kFinishEdge = -1;              /* KenLM::finish child key (KenLM.cpp:79) */
+constexpr uint32_t kNoParent32 = 0xFFFFFFFFu; /* idPar: no parent on record */
 constexpr uint32_t kHostEdge = 0x00FFFFFEu;  /* host LM: a state is named by its id alone, key = (id, kHostEdge) */
 constexpr uint32_t kPhantomNode = 0x80000000u; /* NgramSlot.node: navigation-only prefix */
 constexpr int kMaxNgramOrder = 6;            /* FL_TEXT_KENLM_MAX_ORDER (lm/CMakeLists.txt:3) */
@@ -215,6 +216,17 @@ struct DecodeParams {
   uint2* hlmQ;                  /* [B*hlmQCap] pinned host: {state, index}; index -1 = LM::finish */
   int32_t* hlmBeamN;            /* [B] pinned host: hypotheses in the beam ... */
   uint32_t* hlmBeam;            /* [B*K] ... and their LM states (LM::updateCache, Utils.h:346-354; which states are live) */
+  /* Streams: LM-state ids are recycled (a stream may run forever, LexiconFreeDecoder.cpp:205-227 / Utils.h:312-342 bound
+   * the reference's memory the same way).  An id is taken from the utterance's free list -- position k of idFree, k =
+   * the per-utterance counter that used to BE the id -- and remembers who made it (idPar / idEdge / idBorn);
+   * fltx_compact_states_kernel (compactStates below) returns to the list every id that no hypothesis of the beam can
+   * ever meet again.  Null for offline decodes: ids are the counter's values (lean / lane engines) or table slots. */
+  const uint32_t* idFree;       /* [B*idCap] */
+  const int32_t* uttIdLimit;    /* [B] entries of the free list */
+  uint32_t* idPar;              /* [B*idCap] parent state of an id (kNoParent32: the root, or cut loose by a compaction) */
+  int32_t* idEdge;              /* [B*idCap] generic engine: the edge that leads to it (token / word / -1), for the table's rebuild */
+  uint32_t* idBorn;             /* [B*idCap] frame (stream clock: uttTotal) in which it was made */
+  uint32_t* stateVal;           /* [B*stateCap] generic engine, streams: the id stored beside a stateTab key (ids are no longer slots) */
   /* optional phase profile: [B*8] accumulated shader clocks (bench/tuning) */
   unsigned long long* prof;
   int32_t profThread; /* the thread whose clock is sampled (lane 0 of the wave under study) */
@@ -955,6 +967,92 @@ FLTX_DEV uint32_t stateChild(const DecodeParams& P, int b, uint32_t par, int32_t
   return 0;
 }
 
+/* A fresh LM-state id for the k-th state utterance b makes since its free list was last rebuilt (k comes from the
+ * engine's per-utterance counter).  Offline: the id is k.  Streams: entry k of the free list, and the id remembers its
+ * parent, edge and frame for compactStates(). */
+FLTX_DEV uint32_t allocStateId(const DecodeParams& P, int b, uint32_t k, uint32_t parent, int32_t edge, uint32_t born,
+                               uint32_t* status) {
+  if (P.idFree == nullptr) {
+    if ((int64_t)k >= P.idCap) {
+      atomOr32(status, ST_TABLE_FULL);
+      return 0u;
+    }
+    return k;
+  }
+  if ((int64_t)k >= (int64_t)P.uttIdLimit[b]) {
+    atomOr32(status, ST_TABLE_FULL);
+    return 0u;
+  }
+  const size_t at = (size_t)b * P.idCap;
+  const uint32_t id = P.idFree[at + k];
+  P.idPar[at + id] = parent;
+  P.idBorn[at + id] = born;
+  if (P.idEdge) {
+    P.idEdge[at + id] = edge;
+  }
+  return id;
+}
+
+/* stateChild() for streams of the generic engine: the table maps (parent id, edge) to an id kept BESIDE the key
+ * (stateVal), taken from the free list by whoever inserts the key.  Several survivors of a frame may ask for the same
+ * key at once (same LM state, different trie nodes): the one whose compare-and-swap installs the key allocates, the
+ * others read the value once it is there.  The three phases are straight-line code for the whole wave -- a lane never
+ * waits for a lane of its own wave that has not had its turn (waves of a workgroup all make progress). */
+FLTX_DEV uint32_t stateChildIds(const DecodeParams& P, const Ws& w, int b, bool want, uint32_t par, int32_t edge, uint32_t born,
+                                bool& fresh) {
+  unsigned long long* tab = P.stateTab + (size_t)b * P.stateCap;
+  uint32_t* val = P.stateVal + (size_t)b * P.stateCap;
+  const unsigned long long key = ((unsigned long long)P.epoch << 48) |
+      ((unsigned long long)(par & 0xFFFFFFu) << 24) | (unsigned long long)((uint32_t)(edge + 1) & 0xFFFFFFu);
+  const uint32_t mask = P.stateCap - 1;
+  uint32_t s = hashKey(par, (uint32_t)edge, 0x9747b28cu, 0) & mask;
+  bool won = false, found = false;
+  if (want) { /* phase 1: find the key or install it */
+    for (uint32_t probes = 0; probes < P.stateCap && !found && !won; ++probes) {
+      unsigned long long cur = loadCoherent64(&tab[s]);
+      for (;;) {
+        if (cur == key) {
+          found = true;
+          break;
+        }
+        if ((cur >> 48) == (unsigned long long)P.epoch) {
+          break; /* live entry of another state: next slot */
+        }
+        const unsigned long long old = atomCas64(&tab[s], cur, key);
+        if (old == cur) {
+          won = true;
+          break;
+        }
+        cur = old;
+      }
+      if (!found && !won) {
+        s = (s + 1) & mask;
+      }
+    }
+    if (!found && !won) {
+      atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_TABLE_FULL);
+    }
+  }
+  waveSync();
+  uint32_t id = 0u;
+  fresh = won;
+  if (won) { /* phase 2: the installer names the state */
+    const uint32_t k = atomAdd32((uint32_t*)&w.sc[SC_NEXTID], 1u);
+    id = allocStateId(P, b, k, par, edge, born, (uint32_t*)&w.sc[SC_STATUS]);
+    storeCoherent32(&val[s], id);
+  }
+  waveSync();
+  if (found) { /* phase 3: everybody else reads the name */
+    for (;;) {
+      id = loadCoherent32(&val[s]);
+      if (id != kEmpty) {
+        break;
+      }
+    }
+  }
+  return id;
+}
+
 /* ------------------------------------------------------------------------ */
 /* candidate generation                                                      */
 /* ------------------------------------------------------------------------ */
@@ -984,6 +1082,7 @@ struct FrameCtx {
   int nBeam;
   int nTok;      /* min(beamSizeToken, N) */
   bool useTrans; /* ASG and global frame > 0 */
+  uint32_t clock = 0; /* frames decoded since decodeBegin, this one included (a stream's clock: DecodeParams::idBorn) */
   const float* e; /* emission row in LDS */
   mutable uint32_t nScored = 0; /* n-gram LM queries of this thread (roofline accounting) */
 };
@@ -2314,14 +2413,25 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
   const int tid = (int)threadIdx.x;
   const int nxt = f.cur ^ 1;
   const int64_t hbase = f.histBase + (int64_t)frameOut * P.K;
-  for (int rank = tid; rank < nS; rank += W) {
-    const uint32_t c = w.surv[rank];
-    const double sc = w.cScore[c];
-    const uint4 key = w.cKey[c];
-    const uint32_t src = w.cSrc[c];
+  for (int rank0 = 0; rank0 < nS; rank0 += W) { /* (uniform trips: stateChildIds is a wave-wide call) */
+    const int rank = rank0 + tid;
+    const bool on = rank < nS;
+    const uint32_t c = on ? w.surv[rank] : 0u;
+    const double sc = on ? w.cScore[c] : 0.0;
+    const uint4 key = on ? w.cKey[c] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t src = on ? w.cSrc[c] : 0u;
     const int h = (int)(src & kSrcMask);
     const int n = (int)(key.w & 0x7FFFFFFFu);
-    const float lmd = w.cLm[c];
+    const float lmd = on ? w.cLm[c] : 0.0f;
+    uint32_t sidIds = 0u;
+    bool freshIds = false;
+    if (P.stateVal != nullptr) {
+      sidIds = stateChildIds(P, w, f.b, on && (src & kNewState) != 0u && P.lmKind != 2, key.x, (int32_t)key.y, f.clock,
+                             freshIds);
+    }
+    if (!on) {
+      continue;
+    }
     /* emitting-model score: recompute the candidate's delta (LexiconFree:
      * transition goes into am only, :59-64; Lexicon: am == score delta) */
     double am = w.bAm[(f.cur) * P.K + h];
@@ -2339,7 +2449,12 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
       sid = key.x; /* host LM: the key is the id the host gave the state */
     } else if (src & kNewState) {
       bool fresh;
-      sid = stateChild(P, f.b, key.x, (int32_t)key.y, (uint32_t*)&w.sc[SC_STATUS], fresh);
+      if (P.stateVal != nullptr) {
+        sid = sidIds;
+        fresh = freshIds;
+      } else {
+        sid = stateChild(P, f.b, key.x, (int32_t)key.y, (uint32_t*)&w.sc[SC_STATUS], fresh);
+      }
       if (fresh && P.lmKind == 1) {
         /* materialise the n-gram context of the new state */
         const int L = P.lmOrder - 1;
@@ -2738,6 +2853,8 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
         w.bMask[0] = 0ull;
         w.sc[SC_NEXTID] = 1;
         P.maskTab[(size_t)b * P.idCap] = 0ull;
+      } else if (P.stateVal != nullptr) {
+        w.sc[SC_NEXTID] = 1; /* (streams: ids from the free list, 0 is the root state) */
       }
       const int64_t hb = P.histOff[b];
       P.histPT[hb] = make_int2(-1, P.sil);
@@ -2789,6 +2906,10 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
       }
     }
     if constexpr (GMAX > 0) {
+      if (tid == 0) {
+        w.sc[SC_NEXTID] = P.uttNextId[b];
+      }
+    } else if (P.stateVal != nullptr) {
       if (tid == 0) {
         w.sc[SC_NEXTID] = P.uttNextId[b];
       }
@@ -2874,6 +2995,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     f.nBeam = nBeam;
     f.e = w.erow + rb * P.N;
     f.useTrans = (P.criterion == 0) && (total + t > 0) && P.transitions != nullptr;
+    f.clock = (uint32_t)(total + t + 1);
     if constexpr (GT > 0) {
       nBeam = runFrameLane<GT, LOGADD, FULLTOK>(P, w, *(LaneLds*)wsBase, f, lcarry, frame + t + 1, rb, pre[0],
                                                 t + 1 < T);
@@ -2973,12 +3095,236 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
     P.uttTotal[b] = total;
     if constexpr (GMAX > 0) {
       P.uttNextId[b] = w.sc[SC_NEXTID];
+    } else if (P.stateVal != nullptr) {
+      P.uttNextId[b] = w.sc[SC_NEXTID];
     }
     const int32_t stNow = P.doBegin ? w.sc[SC_STATUS] : (P.uttStatus[b] | w.sc[SC_STATUS]);
     P.uttStatus[b] = stNow;
     if (P.statusHost) {
       P.statusHost[b] = stNow;
     }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Streams: giving LM-state ids back (fltx_compact_states_kernel, one         */
+/* workgroup per stream, between two launches of the decode kernel).          */
+/*                                                                            */
+/* The reference keeps an LMState alive while a hypothesis in the buffer, or  */
+/* the children map of a live ancestor, holds it (lm/LM.h:21-34); prune()     */
+/* drops the hypotheses of the frames it cuts (Utils.h:312-342) and with them */
+/* every state nothing reaches any more, so a stream's memory is bounded.     */
+/* Here a state is an id; what must survive is what can still be OBSERVED:    */
+/* identity only shows when two candidates of one frame meet in a state, and  */
+/* candidates descend from the states of the current beam.  Needed are        */
+/*   (1) the states the beam's hypotheses are in ("live"),                    */
+/*   (2) their parents (a hypothesis names its state (parent, edge)),         */
+/*   (3) every state on the way from a live state up to a live ancestor: a    */
+/*       hypothesis in the ancestor that takes the same edges again must      */
+/*       arrive in the live descendant's state, not in a copy of it.          */
+/* A state below a live state that is none of these can be entered again, but */
+/* only by hypotheses that all get the same fresh id for it -- nobody holds   */
+/* the old one.  Everything else goes back to the free list; a kept state     */
+/* whose parent went is cut loose (idPar = kNoParent32), so a walk up a chain */
+/* ends where the kept states end.  The walk also ends at the first ancestor  */
+/* born before the oldest live state: nothing above it can be live.           */
+/* Ids are stable: the beam, the history and stateCtx are not touched.        */
+/* ------------------------------------------------------------------------ */
+struct CompactParams {
+  int32_t K, N;
+  int32_t mode;    /* 0: a new stream (free list = every id in order, nothing kept); 1: compact */
+  int32_t family;  /* 0: childTab / maskTab (lean, lane, lane = LM state engines); 1: stateTab + stateVal (generic engine) */
+  int64_t idCap;
+  const int32_t* uttNBeam;
+  const uint32_t* gState;
+  uint32_t* idFree;
+  int32_t* uttIdLimit;
+  int32_t* uttNextId;
+  uint32_t* idPar;
+  const int32_t* idEdge;
+  const uint32_t* idBorn;
+  uint8_t* keep;   /* [B*idCap] scratch: bit 1 = live, bit 0 = needed */
+  uint32_t* childTab;
+  unsigned long long* maskTab;
+  unsigned long long* gMask;
+  unsigned long long* stateTab;
+  uint32_t* stateVal;
+  uint32_t stateCap;
+  uint32_t epoch;  /* the table's new epoch: entries of the old one are free slots */
+};
+
+FLTX_DEV void compactStates(const CompactParams& Q, int32_t* sh) {
+  const int b = (int)blockIdx.x;
+  const int W = (int)blockDim.x;
+  const int tid = (int)threadIdx.x;
+  const size_t at = (size_t)b * Q.idCap;
+  uint32_t* idFree = Q.idFree + at;
+  uint32_t* idPar = Q.idPar + at;
+  uint8_t* keep = Q.keep + at;
+  const int64_t cap = Q.idCap;
+  if (Q.mode == 0) {
+    for (int64_t i = tid; i < cap; i += W) {
+      idFree[i] = (uint32_t)i;
+    }
+    if (tid == 0) {
+      idPar[0] = kNoParent32;
+      Q.uttIdLimit[b] = (int32_t)cap;
+    }
+    if (Q.family == 1) {
+      for (uint32_t s = (uint32_t)tid; s < Q.stateCap; s += (uint32_t)W) {
+        Q.stateVal[(size_t)b * Q.stateCap + s] = kEmpty;
+      }
+    }
+    return;
+  }
+  const int nBeam = Q.uttNBeam[b];
+  const uint32_t* gState = Q.gState + (size_t)b * Q.K;
+  const uint32_t* idBorn = Q.idBorn + at;
+  uint32_t* shMin = (uint32_t*)sh;      /* [0] birth frame of the oldest live state */
+  uint32_t* shCnt = (uint32_t*)sh + 1;  /* [1] free ids listed */
+  for (int64_t i = tid; i < cap; i += W) {
+    keep[i] = 0;
+  }
+  if (tid == 0) {
+    *shMin = 0xFFFFFFFFu;
+    *shCnt = 0u;
+  }
+  __syncthreads();
+  for (int h = tid; h < nBeam; h += W) { /* (1) */
+    const uint32_t s = gState[h];
+    keep[s] = 3;
+    atomMin32(shMin, s == 0u ? 0u : idBorn[s]);
+  }
+  __syncthreads();
+  const uint32_t oldest = *shMin;
+  for (int h = tid; h < nBeam; h += W) { /* (2), (3) */
+    uint32_t c = gState[h];
+    int depth = 0, lastLive = 0;
+    for (;;) {
+      const uint32_t p = c == 0u ? kNoParent32 : idPar[c];
+      if (p == kNoParent32) {
+        break;
+      }
+      ++depth;
+      if (keep[p] & 2) {
+        lastLive = depth;
+      }
+      if (p == 0u || idBorn[p] < oldest || depth >= (int)cap) {
+        break; /* nothing above was made late enough to be in the beam */
+      }
+      c = p;
+    }
+    const int need = lastLive > 1 ? lastLive : 1;
+    c = gState[h];
+    for (int d = 0; d < need; ++d) {
+      const uint32_t p = c == 0u ? kNoParent32 : idPar[c];
+      if (p == kNoParent32) {
+        break;
+      }
+      keep[p] = (uint8_t)(keep[p] | 1); /* (racing writers agree: the live bits are final) */
+      c = p;
+    }
+  }
+  __syncthreads();
+  /* cut kept states loose from parents that go; list the free ids (0, the root's id, is never handed out again) */
+  const int lane = laneId();
+  const int64_t rounds = (cap + W - 1) / W;
+  for (int64_t it = 0; it < rounds; ++it) {
+    const int64_t i = it * W + tid;
+    bool freeId = false;
+    if (i >= 1 && i < cap) {
+      if (keep[i]) {
+        const uint32_t p = idPar[i];
+        if (p != kNoParent32 && !keep[p]) {
+          idPar[i] = kNoParent32;
+        }
+      } else {
+        freeId = true;
+      }
+    }
+    const unsigned long long m = waveBallot(freeId);
+    if (m != 0ull) {
+      const int leader = __builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) {
+        base = atomAdd32(shCnt, (uint32_t)popc64(m));
+      }
+      base = waveShfl32(base, leader);
+      if (freeId) {
+        idFree[base + (uint32_t)popc64(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+      }
+    }
+  }
+  __syncthreads();
+  if (Q.family == 0) {
+    /* a kept state forgets the children that went (their ids will name other states); so do the beam's parked masks */
+    const int N = Q.N;
+    for (int64_t i = tid; i < cap; i += W) {
+      if (keep[i] || i == 0) {
+        unsigned long long m = Q.maskTab[at + i], out = m;
+        while (m != 0ull) {
+          const int n = __builtin_ctzll(m);
+          m &= m - 1ull;
+          const uint32_t c = Q.childTab[(at + (size_t)i) * N + n];
+          if ((int64_t)c >= cap || !keep[c]) {
+            out &= ~(1ull << n);
+          }
+        }
+        Q.maskTab[at + i] = out;
+      }
+    }
+    for (int h = tid; h < nBeam; h += W) {
+      const uint32_t sid = gState[h];
+      unsigned long long m = Q.gMask[(size_t)b * Q.K + h], out = m;
+      while (m != 0ull) {
+        const int n = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t c = Q.childTab[(at + (size_t)sid) * N + n];
+        if ((int64_t)c >= cap || !keep[c]) {
+          out &= ~(1ull << n);
+        }
+      }
+      Q.gMask[(size_t)b * Q.K + h] = out;
+    }
+  } else {
+    /* the table again, under its new epoch, from the ids that stay and still have their parent */
+    unsigned long long* tab = Q.stateTab + (size_t)b * Q.stateCap;
+    uint32_t* val = Q.stateVal + (size_t)b * Q.stateCap;
+    for (uint32_t s = (uint32_t)tid; s < Q.stateCap; s += (uint32_t)W) {
+      val[s] = kEmpty;
+    }
+    __syncthreads();
+    const uint32_t mask = Q.stateCap - 1;
+    for (int64_t i = tid; i < cap; i += W) {
+      if (i >= 1 && keep[i] && idPar[i] != kNoParent32) {
+        const uint32_t par = idPar[i];
+        const int32_t edge = Q.idEdge[at + i];
+        const unsigned long long key = ((unsigned long long)Q.epoch << 48) |
+            ((unsigned long long)(par & 0xFFFFFFu) << 24) | (unsigned long long)((uint32_t)(edge + 1) & 0xFFFFFFu);
+        uint32_t s = hashKey(par, (uint32_t)edge, 0x9747b28cu, 0) & mask;
+        for (uint32_t probes = 0; probes < Q.stateCap; ++probes) {
+          unsigned long long cur = loadCoherent64(&tab[s]);
+          bool done = false;
+          while ((cur >> 48) != (unsigned long long)Q.epoch) {
+            const unsigned long long old = atomCas64(&tab[s], cur, key);
+            if (old == cur) {
+              storeCoherent32(&val[s], (uint32_t)i);
+              done = true;
+              break;
+            }
+            cur = old;
+          }
+          if (done) {
+            break;
+          }
+          s = (s + 1) & mask;
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    Q.uttNextId[b] = 0;
+    Q.uttIdLimit[b] = (int32_t)*shCnt;
   }
 }
 

@@ -626,11 +626,8 @@ FLTX_DEV int runFrameLane(const DecodeParams& P, const Ws& w, LaneLds& S, FrameC
           base = loadCoherent64(&P.maskTab[(size_t)f.b * P.idCap + sid]);
           S.sc[SC_RELSLOW] = 1; /* its children may be in the beam: relations by id next frame */
         } else { /* first time this state is materialised */
-          sid = atomAdd32((uint32_t*)&S.sc[SC_NEXTID], 1u);
-          if ((int64_t)sid >= P.idCap) {
-            atomOr32((uint32_t*)&S.sc[SC_STATUS], ST_TABLE_FULL);
-            sid = 0;
-          }
+          sid = allocStateId(P, f.b, atomAdd32((uint32_t*)&S.sc[SC_NEXTID], 1u), kp, n, f.clock,
+                             (uint32_t*)&S.sc[SC_STATUS]);
           base = 0ull;
           atomOr64(&S.addMask[rep], 1ull << n);
           P.childTab[((size_t)f.b * P.idCap + kp) * N + n] = sid;

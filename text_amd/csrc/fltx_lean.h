@@ -627,11 +627,8 @@ FLTX_DEV int runFrameLean(const DecodeParams& P, const Ws& w, FrameCtx& f,
         base = loadCoherent64(&P.maskTab[(size_t)f.b * P.idCap + sid]);
         repSlot = -1;
       } else { /* first time this state is materialised */
-        sid = atomAdd32((uint32_t*)&w.sc[SC_NEXTID], 1u);
-        if ((int64_t)sid >= P.idCap) {
-          atomOr32((uint32_t*)&w.sc[SC_STATUS], ST_TABLE_FULL);
-          sid = 0;
-        }
+        sid = allocStateId(P, f.b, atomAdd32((uint32_t*)&w.sc[SC_NEXTID], 1u), kp, n, f.clock,
+                           (uint32_t*)&w.sc[SC_STATUS]);
         base = 0ull;
         repSlot = -1;
         atomOr64(&w.addMask[rep], 1ull << n);

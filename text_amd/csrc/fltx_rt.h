@@ -57,6 +57,9 @@ FLTX_DEV unsigned long long loadCoherent64(const unsigned long long* p) {
 FLTX_DEV uint32_t loadCoherent32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+FLTX_DEV void storeCoherent32(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 FLTX_DEV uint32_t ldsLoad32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

@@ -1129,11 +1129,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         if (again) {
           r.sid = loadCoherent32(slot);
         } else {
-          r.sid = atomAdd32(&S.scal[SL_NEXTID], 1u);
-          if ((int64_t)r.sid >= P.idCap) {
-            atomOr32(&S.scal[SL_STATUS], ST_TABLE_FULL);
-            r.sid = 0u;
-          }
+          r.sid = allocStateId(P, b, atomAdd32(&S.scal[SL_NEXTID], 1u), me.sid, n, (uint32_t)(total0 + t + 1),
+                               &S.scal[SL_STATUS]);
           *slot = r.sid;
           P.maskTab[(size_t)b * P.idCap + r.sid] = 0ull;
           atomOr64(&P.maskTab[(size_t)b * P.idCap + me.sid], 1ull << n); /* (the parent may leave the beam) */
