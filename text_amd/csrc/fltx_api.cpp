@@ -89,8 +89,8 @@ __global__ void __launch_bounds__(256) fltx_tokbeam_kernel(DecodeParams P) {
 }
 /* streams: LM-state ids nothing can meet again go back to the utterance's free list (compactStates) */
 __global__ void __launch_bounds__(1024) fltx_compact_states_kernel(CompactParams Q) {
-  __shared__ int32_t sh[4];
-  compactStates(Q, sh);
+  extern __shared__ __attribute__((aligned(16))) char fltx_cs_smem[];
+  compactStates(Q, fltx_cs_smem);
 }
 /* host LM: the (LM state, index) questions of the next frame, one workgroup per utterance (hostLmQuestions) */
 __global__ void __launch_bounds__(256) fltx_hostlm_questions_kernel(DecodeParams P) {
@@ -482,8 +482,8 @@ struct fltx_decoder {
   DBuf gScore, gAm, gLm, gState, gSPar, gSEdge, gLex, gTokPb;
   DBuf uttNBeam, uttFrame, uttTotal, uttStatus, outN, outScores, gws;
   DBuf childTab, maskTab, uttNextId, gMask, gLexMax;
-  /* streams: recycled LM-state ids (DecodeParams::idFree ...) */
-  DBuf idFree, idPar, idEdge, idBorn, idKeep, uttIdLimit, stateVal;
+  /* streams: recycled LM-state ids (DecodeParams::idPar ...) */
+  DBuf idPar, idEdge, idBorn, idKeep, idNew, idList, stateVal;
   bool recycle = false;       /* this stream hands ids out from free lists */
   int idFamily = 0;           /* 0: childTab / maskTab engines, 1: generic engine (stateTab + stateVal) */
   int64_t idsUsedBound = 0;   /* upper bound of the ids any stream has taken since its free list was last rebuilt */
@@ -1594,7 +1594,10 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   const int64_t streamIds = (int64_t)K * (idT + 2) + 8 * (int64_t)K + 64;
   uint64_t wantStates = d->recycle ? 2ull * (uint64_t)streamIds : 2ull * ((uint64_t)K * (uint64_t)(idT + 2) + 2);
   uint32_t cap = nextPow2(std::max<uint64_t>(wantStates, 1024));
-  if (cap > (1u << 23)) {
+  if (d->recycle && cap > (1u << 24)) { /* (a stream's ids are bounded below: 2^23 of them fill half of this) */
+    cap = 1u << 24;
+  }
+  if (cap > (1u << 23) && !d->recycle) {
     return fail(FLTX_ERR_UNSUPPORTED, "K * T = %llu exceeds the 2^23 LM states per utterance this build indexes",
                 (unsigned long long)K * (maxT + 2));
   }
@@ -2070,7 +2073,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     d->stateCap = cap;
     d->epoch = 0;
   }
-  rc |= d->stateTab.ensure(sizeof(unsigned long long) * (size_t)B * cap, st, true, &grewTab);
+  /* (the lean / lane engines name their states with a counter and childTab: no table) */
+  rc |= d->stateTab.ensure(sizeof(unsigned long long) * (d->lean ? 1 : (size_t)B * cap), st, true, &grewTab);
   if (grewTab) {
     d->epoch = 0;
   }
@@ -2107,9 +2111,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     if (streamIds > (1ll << 23) - 2) {
       return fail(FLTX_ERR_UNSUPPORTED, "beam %d x max_frames %d exceeds the 2^23 LM-state ids a stream indexes", K, idT);
     }
-    rc |= d->idFree.ensure(4 * (size_t)B * d->idCap, st, false) | d->idPar.ensure(4 * (size_t)B * d->idCap, st, false);
-    rc |= d->idBorn.ensure(4 * (size_t)B * d->idCap, st, false) | d->idKeep.ensure((size_t)B * d->idCap, st, false);
-    rc |= d->uttIdLimit.ensure(4 * (size_t)B, st, true);
+    rc |= d->idPar.ensure(4 * (size_t)B * d->idCap, st, false) | d->idBorn.ensure(4 * (size_t)B * d->idCap, st, false);
+    rc |= d->idKeep.ensure((size_t)B * d->idCap, st, false) | d->idNew.ensure(4 * (size_t)B * d->idCap, st, false);
+    rc |= d->idList.ensure(4 * (size_t)B * d->idCap, st, false);
     d->idsFreeBound = (int64_t)K * (idT + 2);
   }
   if ((d->ylane || d->xlane) && d->yshare) {
@@ -2236,8 +2240,6 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.yTransMax = d->transMax;
   P.scored = (d->lm->kind == 1 && d->scored.p) ? d->scored.as<uint32_t>() : nullptr;
   if (d->recycle) {
-    P.idFree = d->idFree.as<uint32_t>();
-    P.uttIdLimit = d->uttIdLimit.as<int32_t>();
     P.idPar = d->idPar.as<uint32_t>();
     P.idBorn = d->idBorn.as<uint32_t>();
     if (d->idFamily == 1) {
@@ -2926,7 +2928,7 @@ int settleStream(fltx_decoder* d) {
   return rc;
 }
 
-/* streams: mode 0 = every id free (a new stream), mode 1 = give back the ids nothing can meet again.  Runs on the launch
+/* streams: mode 0 = a new stream, mode 1 = renumber the LM-state ids the beam can still meet to the front.  Runs on the launch
  * stream between two decode launches; nothing is waited for. */
 int launchCompact(fltx_decoder* d, int mode) {
   if (!d->recycle) {
@@ -2945,9 +2947,14 @@ int launchCompact(fltx_decoder* d, int mode) {
   Q.idCap = d->idCap;
   Q.uttNBeam = d->uttNBeam.as<int32_t>();
   Q.gState = d->gState.as<uint32_t>();
-  Q.idFree = d->idFree.as<uint32_t>();
-  Q.uttIdLimit = d->uttIdLimit.as<int32_t>();
+  Q.gSPar = d->gSPar.as<uint32_t>();
   Q.uttNextId = d->uttNextId.as<int32_t>();
+  Q.newId = d->idNew.as<uint32_t>();
+  Q.list = d->idList.as<uint32_t>();
+  if (d->lm->kind == 1 && d->idFamily == 1) {
+    Q.stateCtx = d->stateCtx.as<int32_t>();
+    Q.ctxL = std::max(1, d->lm->order - 1);
+  }
   Q.idPar = d->idPar.as<uint32_t>();
   Q.idEdge = d->idEdge.as<int32_t>();
   Q.idBorn = d->idBorn.as<uint32_t>();
@@ -2961,9 +2968,11 @@ int launchCompact(fltx_decoder* d, int mode) {
   Q.epoch = d->epoch;
 #ifdef FLTX_EMU
   const CompactParams* qq = &Q;
-  emuLaunch(d->B, 64, 64, [qq](char* sm) { compactStates(*qq, (int32_t*)sm); });
+  emuLaunch(d->B, 64, kCompactLds, [qq](char* sm) { compactStates(*qq, sm); });
 #else
-  hipLaunchKernelGGL(fltx_compact_states_kernel, dim3(d->B), dim3(1024), 0, d->ctx->stream, Q);
+  HIPCHK(hipFuncSetAttribute((const void*)fltx_compact_states_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             kCompactLds));
+  hipLaunchKernelGGL(fltx_compact_states_kernel, dim3(d->B), dim3(1024), kCompactLds, d->ctx->stream, Q);
   HIPCHK(hipGetLastError());
 #endif
   d->idsUsedBound = mode == 0 ? 1 : 0;
@@ -3495,7 +3504,7 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
     return rc;
   }
   if (d->recycle) {
-    /* a frame makes at most beam new LM states per stream: when this chunk could run the free lists dry, the ids
+    /* a frame makes at most beam new LM states per stream: when this chunk could run a stream out of ids, the ids
      * nothing can meet again are given back first (beam x max_frames ids are free after that, or the chunk's status
      * says the table is full) */
     int maxT = 0;

@@ -216,13 +216,10 @@ struct DecodeParams {
   uint2* hlmQ;                  /* [B*hlmQCap] pinned host: {state, index}; index -1 = LM::finish */
   int32_t* hlmBeamN;            /* [B] pinned host: hypotheses in the beam ... */
   uint32_t* hlmBeam;            /* [B*K] ... and their LM states (LM::updateCache, Utils.h:346-354; which states are live) */
-  /* Streams: LM-state ids are recycled (a stream may run forever, LexiconFreeDecoder.cpp:205-227 / Utils.h:312-342 bound
-   * the reference's memory the same way).  An id is taken from the utterance's free list -- position k of idFree, k =
-   * the per-utterance counter that used to BE the id -- and remembers who made it (idPar / idEdge / idBorn);
-   * fltx_compact_states_kernel (compactStates below) returns to the list every id that no hypothesis of the beam can
-   * ever meet again.  Null for offline decodes: ids are the counter's values (lean / lane engines) or table slots. */
-  const uint32_t* idFree;       /* [B*idCap] */
-  const int32_t* uttIdLimit;    /* [B] entries of the free list */
+  /* Streams: LM-state ids are recycled (a stream may run forever; LexiconFreeDecoder.cpp:205-227 / Utils.h:312-342 bound
+   * the reference's memory the same way).  Every id remembers who made it (idPar / idEdge / idBorn);
+   * fltx_compact_states_kernel (compactStates below) renumbers the ids that a hypothesis of the beam can still meet
+   * to 1 .. M and the engine's per-utterance id counter goes on from M + 1.  Null for offline decodes. */
   uint32_t* idPar;              /* [B*idCap] parent state of an id (kNoParent32: the root, or cut loose by a compaction) */
   int32_t* idEdge;              /* [B*idCap] generic engine: the edge that leads to it (token / word / -1), for the table's rebuild */
   uint32_t* idBorn;             /* [B*idCap] frame (stream clock: uttTotal) in which it was made */
@@ -967,34 +964,27 @@ FLTX_DEV uint32_t stateChild(const DecodeParams& P, int b, uint32_t par, int32_t
   return 0;
 }
 
-/* A fresh LM-state id for the k-th state utterance b makes since its free list was last rebuilt (k comes from the
- * engine's per-utterance counter).  Offline: the id is k.  Streams: entry k of the free list, and the id remembers its
- * parent, edge and frame for compactStates(). */
+/* A fresh LM-state id: k, the value of the engine's per-utterance counter.  Streams remember its parent, edge and
+ * frame for compactStates(), which renumbers the ids still needed and puts the counter behind them. */
 FLTX_DEV uint32_t allocStateId(const DecodeParams& P, int b, uint32_t k, uint32_t parent, int32_t edge, uint32_t born,
                                uint32_t* status) {
-  if (P.idFree == nullptr) {
-    if ((int64_t)k >= P.idCap) {
-      atomOr32(status, ST_TABLE_FULL);
-      return 0u;
-    }
-    return k;
-  }
-  if ((int64_t)k >= (int64_t)P.uttIdLimit[b]) {
+  if ((int64_t)k >= P.idCap) {
     atomOr32(status, ST_TABLE_FULL);
     return 0u;
   }
-  const size_t at = (size_t)b * P.idCap;
-  const uint32_t id = P.idFree[at + k];
-  P.idPar[at + id] = parent;
-  P.idBorn[at + id] = born;
-  if (P.idEdge) {
-    P.idEdge[at + id] = edge;
+  if (P.idPar != nullptr) {
+    const size_t at = (size_t)b * P.idCap + k;
+    P.idPar[at] = parent;
+    P.idBorn[at] = born;
+    if (P.idEdge) {
+      P.idEdge[at] = edge;
+    }
   }
-  return id;
+  return k;
 }
 
 /* stateChild() for streams of the generic engine: the table maps (parent id, edge) to an id kept BESIDE the key
- * (stateVal), taken from the free list by whoever inserts the key.  Several survivors of a frame may ask for the same
+ * (stateVal), taken from the utterance's id counter by whoever inserts the key.  Several survivors of a frame may ask for the same
  * key at once (same LM state, different trie nodes): the one whose compare-and-swap installs the key allocates, the
  * others read the value once it is there.  The three phases are straight-line code for the whole wave -- a lane never
  * waits for a lane of its own wave that has not had its turn (waves of a workgroup all make progress). */
@@ -2854,7 +2844,7 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
         w.sc[SC_NEXTID] = 1;
         P.maskTab[(size_t)b * P.idCap] = 0ull;
       } else if (P.stateVal != nullptr) {
-        w.sc[SC_NEXTID] = 1; /* (streams: ids from the free list, 0 is the root state) */
+        w.sc[SC_NEXTID] = 1; /* (streams: ids from a counter, 0 is the root state) */
       }
       const int64_t hb = P.histOff[b];
       P.histPT[hb] = make_int2(-1, P.sil);
@@ -3124,51 +3114,52 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
 /*       arrive in the live descendant's state, not in a copy of it.          */
 /* A state below a live state that is none of these can be entered again, but */
 /* only by hypotheses that all get the same fresh id for it -- nobody holds   */
-/* the old one.  Everything else goes back to the free list; a kept state     */
-/* whose parent went is cut loose (idPar = kNoParent32), so a walk up a chain */
-/* ends where the kept states end.  The walk also ends at the first ancestor  */
-/* born before the oldest live state: nothing above it can be live.           */
-/* Ids are stable: the beam, the history and stateCtx are not touched.        */
+/* the old one.  The needed ids are renumbered 1 .. M in their old order      */
+/* (new <= old, so everything moves towards the front in place), a kept state */
+/* whose parent went is cut loose (idPar = kNoParent32: a walk up a chain     */
+/* ends where the kept states end; it also ends at the first ancestor born    */
+/* before the oldest live state -- nothing above it can be live), the beam's  */
+/* parked ids follow, and the id counter goes on from M + 1.  The history     */
+/* holds no ids.                                                              */
 /* ------------------------------------------------------------------------ */
 struct CompactParams {
   int32_t K, N;
-  int32_t mode;    /* 0: a new stream (free list = every id in order, nothing kept); 1: compact */
+  int32_t mode;    /* 0: a new stream; 1: compact */
   int32_t family;  /* 0: childTab / maskTab (lean, lane, lane = LM state engines); 1: stateTab + stateVal (generic engine) */
   int64_t idCap;
   const int32_t* uttNBeam;
-  const uint32_t* gState;
-  uint32_t* idFree;
-  int32_t* uttIdLimit;
+  uint32_t* gState;
+  uint32_t* gSPar;
   int32_t* uttNextId;
   uint32_t* idPar;
-  const int32_t* idEdge;
-  const uint32_t* idBorn;
-  uint8_t* keep;   /* [B*idCap] scratch: bit 1 = live, bit 0 = needed */
+  int32_t* idEdge;
+  uint32_t* idBorn;
+  uint8_t* keep;    /* [B*idCap] scratch: bit 1 = live, bit 0 = needed */
+  uint32_t* newId;  /* [B*idCap] scratch: old id -> new id */
+  uint32_t* list;   /* [B*idCap] scratch: new id - 1 -> old id */
   uint32_t* childTab;
   unsigned long long* maskTab;
   unsigned long long* gMask;
   unsigned long long* stateTab;
   uint32_t* stateVal;
   uint32_t stateCap;
-  uint32_t epoch;  /* the table's new epoch: entries of the old one are free slots */
+  uint32_t epoch;   /* the table's new epoch: entries of the old one are free slots */
+  int32_t* stateCtx;  /* n-gram LM: [B*stateCap*ctxL] context of a state, moves with its id */
+  int32_t ctxL;
 };
+constexpr int kCompactChunk = 256; /* ids moved per round (their childTab rows are staged in LDS: 256 x 64 x 4 B) */
+constexpr int kCompactLds = 16 + 4 * 32 + kCompactChunk * (64 * 4 + 8 + 4 + 4 + 4 + 4 * 8);
 
-FLTX_DEV void compactStates(const CompactParams& Q, int32_t* sh) {
+FLTX_DEV void compactStates(const CompactParams& Q, char* smem) {
   const int b = (int)blockIdx.x;
   const int W = (int)blockDim.x;
   const int tid = (int)threadIdx.x;
   const size_t at = (size_t)b * Q.idCap;
-  uint32_t* idFree = Q.idFree + at;
   uint32_t* idPar = Q.idPar + at;
-  uint8_t* keep = Q.keep + at;
   const int64_t cap = Q.idCap;
   if (Q.mode == 0) {
-    for (int64_t i = tid; i < cap; i += W) {
-      idFree[i] = (uint32_t)i;
-    }
     if (tid == 0) {
       idPar[0] = kNoParent32;
-      Q.uttIdLimit[b] = (int32_t)cap;
     }
     if (Q.family == 1) {
       for (uint32_t s = (uint32_t)tid; s < Q.stateCap; s += (uint32_t)W) {
@@ -3177,17 +3168,24 @@ FLTX_DEV void compactStates(const CompactParams& Q, int32_t* sh) {
     }
     return;
   }
+  uint8_t* keep = Q.keep + at;
+  uint32_t* newId = Q.newId + at;
+  uint32_t* list = Q.list + at;
+  uint32_t* idBorn = Q.idBorn + at;
   const int nBeam = Q.uttNBeam[b];
-  const uint32_t* gState = Q.gState + (size_t)b * Q.K;
-  const uint32_t* idBorn = Q.idBorn + at;
-  uint32_t* shMin = (uint32_t*)sh;      /* [0] birth frame of the oldest live state */
-  uint32_t* shCnt = (uint32_t*)sh + 1;  /* [1] free ids listed */
-  for (int64_t i = tid; i < cap; i += W) {
+  uint32_t* gState = Q.gState + (size_t)b * Q.K;
+  uint32_t* gSPar = Q.gSPar + (size_t)b * Q.K;
+  uint32_t* shMin = (uint32_t*)smem;       /* [0] birth frame of the oldest live state */
+  uint32_t* shRun = (uint32_t*)smem + 1;   /* [1] kept ids counted so far */
+  uint32_t* shWave = (uint32_t*)smem + 4;  /* [32] per-wave counts of a scan round */
+  const int used = Q.uttNextId[b];         /* ids handed out so far: [0, used) */
+  const int64_t top = used < cap ? used : cap;
+  for (int64_t i = tid; i < top; i += W) {
     keep[i] = 0;
   }
   if (tid == 0) {
     *shMin = 0xFFFFFFFFu;
-    *shCnt = 0u;
+    *shRun = 0u;
   }
   __syncthreads();
   for (int h = tid; h < nBeam; h += W) { /* (1) */
@@ -3226,67 +3224,148 @@ FLTX_DEV void compactStates(const CompactParams& Q, int32_t* sh) {
     }
   }
   __syncthreads();
-  /* cut kept states loose from parents that go; list the free ids (0, the root's id, is never handed out again) */
-  const int lane = laneId();
-  const int64_t rounds = (cap + W - 1) / W;
-  for (int64_t it = 0; it < rounds; ++it) {
-    const int64_t i = it * W + tid;
-    bool freeId = false;
-    if (i >= 1 && i < cap) {
-      if (keep[i]) {
-        const uint32_t p = idPar[i];
-        if (p != kNoParent32 && !keep[p]) {
-          idPar[i] = kNoParent32;
-        }
-      } else {
-        freeId = true;
-      }
+  /* new ids: rank among the kept ids, in id order (id 0, the root state, keeps its name whether needed or not) */
+  const int lane = laneId(), wave = waveId(), nWaves = (W + 63) >> 6;
+  for (int64_t base = 1; base < top; base += W) {
+    const int64_t i = base + tid;
+    const bool on = i < top && keep[i] != 0;
+    const unsigned long long m = waveBallot(on);
+    if (lane == 0) {
+      shWave[wave] = (uint32_t)popc64(m);
     }
-    const unsigned long long m = waveBallot(freeId);
-    if (m != 0ull) {
-      const int leader = __builtin_ctzll(m);
-      uint32_t base = 0;
-      if (lane == leader) {
-        base = atomAdd32(shCnt, (uint32_t)popc64(m));
-      }
-      base = waveShfl32(base, leader);
-      if (freeId) {
-        idFree[base + (uint32_t)popc64(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
-      }
+    __syncthreads();
+    uint32_t before = *shRun;
+    for (int q = 0; q < wave; ++q) {
+      before += shWave[q];
     }
+    if (on) {
+      const uint32_t r = before + (uint32_t)popc64(m & ((1ull << lane) - 1ull)); /* 0-based rank */
+      newId[i] = r + 1u;
+      list[r] = (uint32_t)i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t tot = *shRun;
+      for (int q = 0; q < nWaves; ++q) {
+        tot += shWave[q];
+      }
+      *shRun = tot;
+    }
+    __syncthreads();
+  }
+  const int M = (int)*shRun;
+  if (tid == 0) {
+    newId[0] = 0u;
+    keep[0] = (uint8_t)(keep[0] | 1);
   }
   __syncthreads();
-  if (Q.family == 0) {
-    /* a kept state forgets the children that went (their ids will name other states); so do the beam's parked masks */
-    const int N = Q.N;
-    for (int64_t i = tid; i < cap; i += W) {
-      if (keep[i] || i == 0) {
-        unsigned long long m = Q.maskTab[at + i], out = m;
-        while (m != 0ull) {
-          const int n = __builtin_ctzll(m);
-          m &= m - 1ull;
-          const uint32_t c = Q.childTab[(at + (size_t)i) * N + n];
-          if ((int64_t)c >= cap || !keep[c]) {
-            out &= ~(1ull << n);
-          }
-        }
-        Q.maskTab[at + i] = out;
-      }
-    }
+  auto renamed = [&](uint32_t old) -> uint32_t { /* kNoParent32 when that id goes */
+    return ((int64_t)old < top && keep[old]) ? newId[old] : kNoParent32;
+  };
+  const int N = Q.N;
+  if (Q.family == 0) { /* the beam's parked child masks forget the children that go (old ids, old rows: before the move) */
     for (int h = tid; h < nBeam; h += W) {
       const uint32_t sid = gState[h];
       unsigned long long m = Q.gMask[(size_t)b * Q.K + h], out = m;
       while (m != 0ull) {
         const int n = __builtin_ctzll(m);
         m &= m - 1ull;
-        const uint32_t c = Q.childTab[(at + (size_t)sid) * N + n];
-        if ((int64_t)c >= cap || !keep[c]) {
+        if (renamed(Q.childTab[(at + (size_t)sid) * N + n]) == kNoParent32) {
           out &= ~(1ull << n);
         }
       }
       Q.gMask[(size_t)b * Q.K + h] = out;
     }
-  } else {
+    if (tid == 0) { /* ... and so does the root's row, which stays where it is */
+      unsigned long long m = Q.maskTab[at], out = m;
+      while (m != 0ull) {
+        const int n = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t c = renamed(Q.childTab[at * N + n]);
+        if (c == kNoParent32) {
+          out &= ~(1ull << n);
+        } else {
+          Q.childTab[at * N + n] = c;
+        }
+      }
+      Q.maskTab[at] = out;
+    }
+  }
+  __syncthreads();
+  /* move what an id owns from its old place to its new one, kCompactChunk ids per round in id order: a round reads
+   * everything it moves before it writes, and what it writes (new ids of this round) lies in front of every old id a
+   * later round reads (new <= old) */
+  char* sp = smem + 16 + 4 * 32;
+  uint32_t* stRow = (uint32_t*)sp;                                  /* [chunk][64] children, renamed */
+  unsigned long long* stMask = (unsigned long long*)(stRow + kCompactChunk * 64);
+  uint32_t* stPar = (uint32_t*)(stMask + kCompactChunk);
+  uint32_t* stBorn = stPar + kCompactChunk;
+  int32_t* stEdge = (int32_t*)(stBorn + kCompactChunk);
+  int32_t* stCtx = stEdge + kCompactChunk;                          /* [chunk][8] */
+  for (int c0 = 0; c0 < M; c0 += kCompactChunk) {
+    const int nc = M - c0 < kCompactChunk ? M - c0 : kCompactChunk;
+    for (int q = tid; q < nc; q += W) {
+      const uint32_t old = list[c0 + q];
+      const uint32_t p = idPar[old];
+      stPar[q] = p == kNoParent32 ? kNoParent32 : renamed(p);
+      stBorn[q] = idBorn[old];
+      if (Q.family == 1) {
+        stEdge[q] = Q.idEdge[at + old];
+        if (Q.stateCtx) {
+          for (int x = 0; x < Q.ctxL; ++x) {
+            stCtx[q * 8 + x] = Q.stateCtx[((size_t)b * Q.stateCap + old) * Q.ctxL + x];
+          }
+        }
+      } else {
+        stMask[q] = Q.maskTab[at + old];
+      }
+    }
+    __syncthreads();
+    if (Q.family == 0) { /* rows: one (id, token) pair per thread */
+      for (int e = tid; e < nc * N; e += W) {
+        const int q = e / N, n = e - q * N;
+        if ((stMask[q] >> n) & 1ull) {
+          stRow[q * 64 + n] = renamed(Q.childTab[(at + (size_t)list[c0 + q]) * N + n]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int q = tid; q < nc; q += W) {
+      const uint32_t j = (uint32_t)(c0 + q + 1);
+      idPar[j] = stPar[q];
+      idBorn[j] = stBorn[q];
+      if (Q.family == 1) {
+        Q.idEdge[at + j] = stEdge[q];
+        if (Q.stateCtx) {
+          for (int x = 0; x < Q.ctxL; ++x) {
+            Q.stateCtx[((size_t)b * Q.stateCap + j) * Q.ctxL + x] = stCtx[q * 8 + x];
+          }
+        }
+      } else {
+        unsigned long long m = stMask[q], out = m;
+        while (m != 0ull) {
+          const int n = __builtin_ctzll(m);
+          m &= m - 1ull;
+          const uint32_t c = stRow[q * 64 + n];
+          if (c == kNoParent32) {
+            out &= ~(1ull << n);
+          } else {
+            Q.childTab[(at + (size_t)j) * N + n] = c;
+          }
+        }
+        Q.maskTab[at + j] = out;
+      }
+    }
+    __syncthreads();
+  }
+  for (int h = tid; h < nBeam; h += W) { /* the beam's ids follow (a live state and its parent are kept by construction) */
+    const uint32_t sp0 = gSPar[h];
+    gState[h] = newId[gState[h]];
+    if ((int64_t)sp0 < top && keep[sp0]) {
+      gSPar[h] = newId[sp0];
+    }
+  }
+  if (Q.family == 1) {
     /* the table again, under its new epoch, from the ids that stay and still have their parent */
     unsigned long long* tab = Q.stateTab + (size_t)b * Q.stateCap;
     uint32_t* val = Q.stateVal + (size_t)b * Q.stateCap;
@@ -3295,36 +3374,37 @@ FLTX_DEV void compactStates(const CompactParams& Q, int32_t* sh) {
     }
     __syncthreads();
     const uint32_t mask = Q.stateCap - 1;
-    for (int64_t i = tid; i < cap; i += W) {
-      if (i >= 1 && keep[i] && idPar[i] != kNoParent32) {
-        const uint32_t par = idPar[i];
-        const int32_t edge = Q.idEdge[at + i];
-        const unsigned long long key = ((unsigned long long)Q.epoch << 48) |
-            ((unsigned long long)(par & 0xFFFFFFu) << 24) | (unsigned long long)((uint32_t)(edge + 1) & 0xFFFFFFu);
-        uint32_t s = hashKey(par, (uint32_t)edge, 0x9747b28cu, 0) & mask;
-        for (uint32_t probes = 0; probes < Q.stateCap; ++probes) {
-          unsigned long long cur = loadCoherent64(&tab[s]);
-          bool done = false;
-          while ((cur >> 48) != (unsigned long long)Q.epoch) {
-            const unsigned long long old = atomCas64(&tab[s], cur, key);
-            if (old == cur) {
-              storeCoherent32(&val[s], (uint32_t)i);
-              done = true;
-              break;
-            }
-            cur = old;
-          }
-          if (done) {
+    for (int j = 1 + tid; j <= M; j += W) {
+      const uint32_t par = idPar[j];
+      if (par == kNoParent32) {
+        continue;
+      }
+      const int32_t edge = Q.idEdge[at + j];
+      const unsigned long long key = ((unsigned long long)Q.epoch << 48) |
+          ((unsigned long long)(par & 0xFFFFFFu) << 24) | (unsigned long long)((uint32_t)(edge + 1) & 0xFFFFFFu);
+      uint32_t s = hashKey(par, (uint32_t)edge, 0x9747b28cu, 0) & mask;
+      for (uint32_t probes = 0; probes < Q.stateCap; ++probes) {
+        unsigned long long cur = loadCoherent64(&tab[s]);
+        bool done = false;
+        while ((cur >> 48) != (unsigned long long)Q.epoch) {
+          const unsigned long long old = atomCas64(&tab[s], cur, key);
+          if (old == cur) {
+            storeCoherent32(&val[s], (uint32_t)j);
+            done = true;
             break;
           }
-          s = (s + 1) & mask;
+          cur = old;
         }
+        if (done) {
+          break;
+        }
+        s = (s + 1) & mask;
       }
     }
   }
+  __syncthreads();
   if (tid == 0) {
-    Q.uttNextId[b] = 0;
-    Q.uttIdLimit[b] = (int32_t)*shCnt;
+    Q.uttNextId[b] = M + 1;
   }
 }
 
