@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=160, help="utterances timed on the one-thread CPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip every CPU / host-side leg (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip all-cores / steady / end-to-end / streaming / sustained / secondary")
+    ap.add_argument("--no-corun", action="store_true", help="with --pipeline 2: do not ask for the settings that let the decode "
+                    "kernels of the two decoder objects share the CUs (defer_check, the 512-thread / shared-CU geometries)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / C5-share / WP lines of the default run")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the back-to-back leg (0 = off)")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
@@ -212,6 +214,20 @@ class Job:
             d = c.BatchDecoder(ctx, c.LEXFREE, self.opt, self.lm, 0, self.blank, transitions=self.tr)
         if self.a.threads:
             d.set("threads", self.a.threads)
+        if self.a.pipeline > 1 and not self.a.no_corun and not self.a.profile:
+            # Two batches in flight, one per decoder object / HIP stream: a workgroup waits half of its cycles (the
+            # frame step is a chain of LDS round trips and barriers), so a second utterance on the CU runs in those
+            # gaps.  That needs (a) calls that return with their kernels queued -- the look at the utterances'
+            # statuses is deferred to the first read of results ("defer_check"; the emissions stay in HBM), (b) the
+            # geometries of which two workgroups fit a CU: 512 threads (8 waves x <= 128 VGPRs) instead of 576 for the
+            # lexicon-free engine, the LM-state memo in HBM for the lexicon engines ("yshare"), and a back-trace
+            # workgroup that leaves the LDS to them.
+            d.set("defer_check", 1)
+            d.set("bt_lds_kb", 64)
+            if not self.lex and self.N <= 64 and self.K <= 64:
+                d.set("slane_threads", 512)
+            if self.lex:
+                d.set("yshare", 1)
         for kv in self.a.set:
             k, v = kv.split("=")
             d.set(k, int(v))
@@ -342,7 +358,7 @@ def measure(a, torch, dist, rank, local, world, primary):
     st = dec.stats()
     by = dec.bytes()
     engine = dec.get("engine")
-    redone = dec.get("redone")  # utterances of the last timed batch the engine handed to a more general one
+    redone = max(d.get("redone") for d in decs)  # utterances of the last timed batches the engine handed to a more general one
     value = B * T * a.steps * world / dt
 
     out = {
@@ -365,6 +381,12 @@ def measure(a, torch, dist, rank, local, world, primary):
     }
     # ---- roofline (rank-local): each kernel's own algorithmic bytes over its own duration ----
     k_ms, b_ms = float(np.mean(kern_ms)), float(np.mean(bt_ms))
+    corun = len(decs) > 1 and not a.no_corun and not a.profile
+    solo_ms = k_ms
+    if corun:
+        # the launches of the timed region overlap in pairs: a launch's own duration is the in-region average (what
+        # rocprofv3's per-kernel average of this command shows); the chip's rate is the launches' bytes over the wall time
+        k_ms = float(np.mean(over_k))
     ach = by["decode"] / (k_ms * 1e-3) / 1e9
     rl = {"bound": "hbm", "kernel": "fltx_decode_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
@@ -374,7 +396,12 @@ def measure(a, torch, dist, rank, local, world, primary):
           "kernel_ms_in_timed_region": float(np.mean(over_k)),
           "achieved_in_timed_region": by["decode"] / (float(np.mean(over_k)) * 1e-3) / 1e9,
           "frac_in_timed_region": by["decode"] / (float(np.mean(over_k)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          "kernel_ms_alone": solo_ms, "concurrent_launches": 2 if corun else 1,
+          "aggregate_achieved": by["decode"] * a.steps / dt / 1e9, "aggregate_frac": by["decode"] * a.steps / dt / 1e9 / HBM_PEAK_GBS,
           "timing": "HIP events on the launch stream; kernel_ms: %s" % (
+              "the launches of the timed region, two in flight at a time on two streams (their workgroups share the CUs: "
+              "kernel_ms_alone is one launch with the chip to itself, aggregate_* the launches' bytes over the wall time)"
+              if corun else
               "3 launches on one stream right after the timed region (the timed region alternates two streams: "
               "kernel_ms_in_timed_region includes sharing the CUs with the other stream's back-trace)"
               if len(decs) > 1 else "the launches of the timed region")}
@@ -455,7 +482,7 @@ def measure(a, torch, dist, rank, local, world, primary):
         fail = "bench.py: %s: %d of %d utterances fell back to a general engine" % (a.workload, redone, B)
 
     # ---- secondary: the other BASELINE configurations under the same clock (default invocation, N = 1) ----
-    if primary and rank == 0 and world == 1 and a.workload == "C2" and not a.no_secondary and not a.no_extras and \
+    if primary and rank == 0 and world == 1 and a.workload == "C2" and not a.no_secondary and not a.no_extras and not a.no_cpu and \
             not (a.batch or a.frames or a.beam or a.beam_token or a.tokens or a.asg or a.log_add or a.set):
         import copy
         out["secondary"] = {}

@@ -365,6 +365,12 @@ FLTX_API int fltx_decoder_profile(fltx_decoder* dec, uint64_t* out);
  * a stream has to decode it again is looked at by the next call that needs the beam -- the next chunk's upload runs
  * under the kernel; a deferred fltx_stream_prune reports its errors there too), "lm_cache" (0 = the generic step asks
  * the n-gram tables for every word-end candidate instead of keeping the last (LM state, word) answers), "bt_lds_kb".  fltx_decoder_get also answers "engine", "redone", "stream_redone", "yshare", "sstream". */
+/* Round 5: "defer_check" (1 = fltx_decode_batch returns as soon as its kernels are queued.  By default the call waits
+ * for the decode kernel when the batch ran on a fast path that may flag an utterance, decodes the flagged ones again
+ * and only then queues the back-trace -- every read of a device buffer is then queued before the call returns.  With
+ * defer_check the look at the statuses, and that second pass, wait for the first call that reads results or "redone":
+ * the caller keeps a device emissions buffer unchanged until then.  Batches of several decoder objects / streams
+ * then run side by side on the CUs), "compact_always" (tests: streams rebuild their LM-state ids before every chunk). */
 FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value);
 /* Geometry chosen for the last batch: "engine" (0 generic hash merge, 1 generic
  * dense merge, 2 lean register-resident step, 3 lane-per-slot step, 4 lane = LM

@@ -323,3 +323,54 @@ def test_emulated_word_piece_fallback_reaches_the_generic_engine(emu_session):
         assert ok, "utterance %d: %s" % (b, why)
     d.close()
     g.close()
+
+
+def _deferred_look(sess, golden, T_wp):
+    """fltx_decoder_set("defer_check", 1): fltx_decode_batch returns with its kernels queued; the look at the statuses
+    and the second pass of what a fast path flagged happen when results are first read -- same results."""
+    from text_amd import synth
+    # (1) a fast path that flags one utterance (fltx_wlane.h, a row without a defined token beam)
+    N, B = 300, 3
+    c = cases.case("wp_ties_defer", dist="ctc", T=T_wp, N=N, K=20, Kt=30, u=515)
+    e = synth.batch("ctc", B, T_wp, N)
+    e[1, 5, :] = -3.0
+    want = sess.decoder(c, dict(tr=None))
+    want.decode_batch(e, [T_wp] * B, N)
+    d = sess.decoder(c, dict(tr=None))
+    d.set("defer_check", 1)
+    d.decode_batch(e, [T_wp] * B, N)
+    assert d.get("redone") == 1 and want.get("redone") == 1
+    for b in range(B):
+        ok, why = helpers.hyps_equal(want.results(b), d.results(b))
+        assert ok, "utterance %d: %s" % (b, why)
+    # ... and a second batch on the same decoder object starts clean
+    d.decode_batch(e[:1], [T_wp], N)
+    ok, why = helpers.hyps_equal(want.results(0), d.results(0))
+    assert ok, why
+    d.close()
+    want.close()
+    # (2) the lexicon decoder's score cut forced tight: flagged utterances are decoded again without it
+    c = cases.BY_NAME["lx_spell_t40_k8"]
+    inp = helpers.case_inputs(c)
+    d = sess.decoder(c, inp)
+    d.set("defer_check", 1)
+    d.set("xlane", 0)
+    d.set("ylane", 0)
+    d.set("cut_m", c["K"] + 1)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
+    d.close()
+    assert ok, why
+    # (3) the headline shape's engine, nothing flagged
+    c = cases.BY_NAME["lf_ctc_t60_k10"]
+    inp = helpers.case_inputs(c)
+    d = sess.decoder(c, inp)
+    d.set("defer_check", 1)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
+    assert ok and d.get("engine") == 4 and d.get("redone") == 0, why
+    d.close()
+
+
+def test_emulated_deferred_status_look(emu_session, golden):
+    _deferred_look(emu_session, golden, 12)

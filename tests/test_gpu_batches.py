@@ -505,3 +505,9 @@ def test_word_piece_row_without_a_defined_token_beam(gpu_session, oracle_lib):
         assert ok, "utterance %d vs the generic engine: %s" % (b, why)
     d.close()
     g.close()
+
+
+@pytest.mark.gpu
+def test_deferred_status_look(gpu_session, golden):
+    import test_emu_logic
+    test_emu_logic._deferred_look(gpu_session, golden, 40)

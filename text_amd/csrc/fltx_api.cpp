@@ -461,6 +461,14 @@ struct fltx_decoder {
   DBuf lmCache;               /* DecodeParams::lmCache */
   int xlane = 0, noXlane = 0; /* xlane: list positions per token wave of the lane = (LM state, trie node) kernel (fltx_xlane.h) */
   bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
+  /* "defer_check": fltx_decode_batch returns with its kernels queued; the look at the utterances' statuses (and the
+   * second pass of what a fast path flagged) waits for the first call that reads results */
+  int deferCheck = 0;
+  bool offlinePending = false;
+  std::vector<int32_t> offT;
+  std::vector<int64_t> offOffsets;
+  int offN = 0, offUpSlot = 0;
+  const float* offEmis = nullptr;
   const float* lastEmis = nullptr; /* device emissions of the last offline batch (the back-trace re-reads them) */
   size_t hotBytes = 0; /* LDS part of a split (HBM + LDS) workspace */
   int hotLevel = 0;    /* what the LDS part holds (carveWs) */
@@ -1300,6 +1308,7 @@ int fltx_decoder_destroy(fltx_decoder* d) {
   return FLTX_OK;
 }
 
+static int settlePendingLook(fltx_decoder* d); /* (defined after syncResults) */
 int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
   if (!d || !key || !value) {
     return fail(FLTX_ERR_INVALID, "fltx_decoder_get: null argument");
@@ -1313,6 +1322,13 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
   } else if (!strcmp(key, "yshare")) {
     *value = (d->ylane || d->xlane) ? d->yshare : 0;
   } else if (!strcmp(key, "redone")) {
+    if (d->offlinePending) { /* ("defer_check": the look has not happened yet) */
+      DeviceScope devScope(d->ctx);
+      int rc = settlePendingLook(d);
+      if (rc) {
+        return rc;
+      }
+    }
     *value = d->lastRedo;
   } else if (!strcmp(key, "sstream")) {
     *value = d->sstream;
@@ -1368,6 +1384,10 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
 int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
   if (!d || !key) {
     return fail(FLTX_ERR_INVALID, "null argument");
+  }
+  if (!strcmp(key, "defer_check")) {
+    d->deferCheck = value ? 1 : 0;
+    return FLTX_OK;
   }
   if (!strcmp(key, "compact_always")) {
     d->userCompactAlways = value ? 1 : 0;
@@ -2612,10 +2632,21 @@ int uploadStep(fltx_decoder* d, const float* emissions, int onDevice, const int6
 }
 
 int settleStream(fltx_decoder* d);
+} // namespace
+static int offlineAttempts(fltx_decoder* d, const float* emissions, int32_t onDevice, int firstAttempt);
+namespace {
 
 int syncResults(fltx_decoder* d) {
   if (!d->settling && (d->chunkPending || d->pendingPrune >= 0)) {
     int rc = settleStream(d);
+    if (rc) {
+      return rc;
+    }
+  }
+  if (d->offlinePending) { /* "defer_check": the look at the batch's statuses, and the second pass of what the fast path flagged */
+    d->offlinePending = false;
+    d->upSlot = d->offUpSlot;
+    int rc = offlineAttempts(d, d->offEmis, 1, 1);
     if (rc) {
       return rc;
     }
@@ -3237,6 +3268,26 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   if (d->lm->kind == 2) {
     return hostLmDecodeBatch(d, emissions, onDevice, offsets, T, B, N);
   }
+  d->offT.assign(T, T + B);
+  d->offOffsets.clear();
+  if (offsets) {
+    d->offOffsets.assign(offsets, offsets + B);
+  }
+  d->offN = N;
+  d->offlinePending = false;
+  return offlineAttempts(d, emissions, onDevice, 0);
+}
+
+/* The attempts of one offline batch.  firstAttempt 0: the call itself (the fast path); 1: the look at a batch whose
+ * status scan was deferred (fltx_decoder_set "defer_check"): the decode kernel and the back-trace were launched and
+ * the call returned -- the scan, and the second pass of whatever the fast path flagged, happen when the results are
+ * first asked for (syncResults), on the emissions where the first pass left them in HBM. */
+} /* extern "C" */
+static int settlePendingLook(fltx_decoder* d) { return syncResults(d); }
+static int offlineAttempts(fltx_decoder* d, const float* emissions, int32_t onDevice, int firstAttempt) {
+  const int32_t* T = d->offT.data();
+  const int64_t* offsets = d->offOffsets.empty() ? nullptr : d->offOffsets.data();
+  const int32_t B = (int32_t)d->offT.size(), N = d->offN;
   /* The optimistic fast paths (LDS-sized candidate lists of the lexicon
    * decoder, the score cut, the one-pass histogram select of the lean / lane
    * steps) flag the rare utterance they cannot serve.  Only those utterances
@@ -3245,28 +3296,37 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
    * only when a large part of the batch needed it. */
   std::vector<int32_t> redoList;
   size_t firstRedo = 0;
-  d->fallbackReasons = 0;
+  if (firstAttempt == 0) {
+    d->fallbackReasons = 0;
+  }
   bool recomputeRetry = false; /* this attempt is the recompute form of the cut-off generation */
   bool recomputeTried = false;
   const int savedGlobalWs = d->forceGlobalWs, savedNoCut = d->noCut, savedNoLean = d->noLean, savedNoSlim = d->noSlim;
   const int savedNoSlane = d->noSlane, savedNoXlane = d->noXlane, savedNoYlane = d->noYlane, savedNoWlane = d->noWlane;
   d->offlineCall = true;
-  d->batchPacked = false;
-  d->batchWlane = false;
+  if (firstAttempt == 0) {
+    d->batchPacked = false;
+    d->batchWlane = false;
+  }
   d->keepScores = d->userKeepScores; /* a stream on this decoder had switched the score history on */
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    const bool finalForm = attempt > 0 && !recomputeRetry; /* the general path: nothing left to fall back to */
-    d->keepScored = attempt > 0;
-    int rc = prepare(d, B, N, T, finalForm);
-    d->keepScored = false;
-    if (rc) {
-      return rc;
+  for (int attempt = firstAttempt; attempt < 3 + firstAttempt; ++attempt) {
+    const bool finalForm = attempt > firstAttempt && !recomputeRetry; /* the general path: nothing left to fall back to */
+    const bool look = firstAttempt > 0 && attempt == firstAttempt; /* the deferred look at what is already decoded */
+    int rc;
+    if (!look) {
+      d->keepScored = attempt > 0;
+      rc = prepare(d, B, N, T, finalForm);
+      d->keepScored = false;
+      if (rc) {
+        return rc;
+      }
     }
-    if (attempt > 0 && d->lm->kind == 1 && d->scored.p) {
+    if (!look && attempt > 0 && d->lm->kind == 1 && d->scored.p) {
       for (int32_t b : redoList) { /* only the utterances decoded again start their query count over */
         devMemset(d->scored.as<uint32_t>() + b, 0, 4, d->ctx->stream);
       }
     }
+    if (!look) {
     d->batchPacked = d->batchPacked || d->slane || d->xlane || d->ylane;
     if (d->slane || d->xlane || d->ylane) {
       d->packedBits = (d->slane && d->mlaneNG > 1) ? 10 : (d->ylane == 4 ? 13 : 8); /* (a re-run on a general engine leaves plain records) */
@@ -3299,20 +3359,32 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     if (rc) {
       return rc;
     }
+    } /* !look */
     const bool cutMode = d->CAP2 > 0 || d->cutRecompute;
-    if (!finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->wlane || d->xlane || d->ylane)) {
+    const bool needLook = !finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->wlane || d->xlane || d->ylane);
+    if (needLook && attempt == 0 && d->deferCheck) {
+      /* the caller keeps the emissions where they are until the results are read: launch the back-trace and return;
+       * the look happens in syncResults() */
+      d->offlinePending = true;
+      d->offEmis = d->lastEmis;
+      d->offUpSlot = d->upSlot;
+      break;
+    }
+    if (needLook) {
       d->resultsSynced = false;
+      d->offlinePending = false; /* (syncResults below must not come back here) */
       if ((rc = syncResults(d))) {
         return rc;
       }
       bool ws = false, cut = false, lean = false, slaneMiss = false, xlaneMiss = false, wlaneMiss = false;
       const bool slimMode = d->CAP2 > 0;
       std::vector<int32_t> again;
-      const int nScan = attempt == 0 ? B : (int)redoList.size();
+      const bool firstScan = attempt == 0 || look;
+      const int nScan = firstScan ? B : (int)redoList.size();
       for (int i = 0; i < nScan; ++i) {
-        const int b = attempt == 0 ? i : redoList[i];
+        const int b = firstScan ? i : redoList[i];
         const int st = d->hStatus[b];
-        if (attempt == 0 && (st & ST_SELECT_FALLBACK)) {
+        if (firstScan && (st & ST_SELECT_FALLBACK)) {
           d->fallbackReasons |= 1ll << ((st >> 8) & 31); /* (the lexicon lane engine says why: fltx_ylane.h) */
         }
         const bool o = (st & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON;
@@ -3331,7 +3403,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
         }
       }
       redoList.swap(again);
-      if (attempt == 0) {
+      if (firstScan) {
         firstRedo = redoList.size();
       }
       if (!redoList.empty()) {
@@ -3358,7 +3430,12 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
     }
     break;
   }
-  d->lastRedo = (int)firstRedo;
+  if (!d->offlinePending) {
+    d->lastRedo = (int)firstRedo;
+  }
+  if (firstAttempt > 0 && firstRedo == 0) {
+    return FLTX_OK; /* the deferred look found nothing to decode again: the back-trace already ran */
+  }
   if (firstRedo > 0 && firstRedo * 4 <= (size_t)B) { /* a few outliers: next batch tries the fast path again */
     d->forceGlobalWs = savedGlobalWs;
     d->noCut = savedNoCut;
@@ -3380,6 +3457,7 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   d->ended = true;
   return FLTX_OK;
 }
+extern "C" {
 
 int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) {
   DeviceScope devScope(d ? d->ctx : nullptr);
