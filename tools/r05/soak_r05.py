@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Round-5 soak on the GPU against the oracle (one gpurun call; log -> profiles/r05/soak_r05.log):
+  1. user-defined LMs through the per-frame host exchange: random option / size / lexicon combinations with the LM
+     behind a Python class -- a ZeroLM clone, the ARPA tables wrapped as tests/host_lms.PyNgramLM, and the
+     state-sharing LastWordLM (one LMState per last input: pointer-identity merges);
+  2. the random configurations of tools/fuzz_big.py with "defer_check" on (the look at the statuses at result time);
+  3. streams much longer than their tables: random beams / thresholds / token beams / LMs / chunk sizes / lookBacks,
+     getBestHypothesis after every chunk and the final n-best, with and without a compaction before every chunk."""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases, helpers, host_lms  # noqa: E402
+import test_long_streams as tls  # noqa: E402
+from oracle import orclib  # noqa: E402
+from text_amd import _capi  # noqa: E402
+
+orc = orclib.load("oracle")
+s = helpers.FltxSession(None)
+N_HOST = int(os.environ.get("SOAK_HOST", "400"))
+N_DEFER = int(os.environ.get("SOAK_DEFER", "1500"))
+N_STREAM = int(os.environ.get("SOAK_STREAM", "120"))
+t0 = time.time()
+
+
+def tie(hyps):
+    return len({h.score for h in hyps}) != len(hyps)
+
+
+# ---- 1. host LMs ---------------------------------------------------------------------------------------------------
+bad = ran = 0
+rnd = random.Random(55)
+for i, c in enumerate(cases.fuzz_cases(N_HOST)):
+    c = dict(c)
+    mode = i % 3
+    if mode == 2:  # state-sharing LM instead of whatever the case had
+        c["lm"] = ("lastword", 100 + i)
+        c["lm_weight"] = rnd.choice([0.4, 1.1])
+        c["is_lm_token"] = c["kind"] == "lexfree" or rnd.random() < 0.4
+        c["unk_score"] = float("-inf") if c["is_lm_token"] else c["unk_score"]
+    inp = helpers.case_inputs(c)
+    want = helpers.run_checker(orc, c, inp)
+    if tie(want):
+        continue
+    if mode == 2:
+        lm = s.lm_for(c, inp)
+    elif c["lm"] == "zero":
+        lm = _capi.HostLM(host_lms.PyZeroLM(), lib=s.lib)
+    else:
+        lm = _capi.HostLM(host_lms.PyNgramLM(s.lm_for(c, inp)), lib=s.lib)
+    try:
+        d = s.decoder(c, inp, lm=lm)
+        if c["kind"] == "lexicon" and c["lm"] != "zero" and not c["is_lm_token"] and mode != 2:
+            pass  # (the trie's label scores come from the device tables: the same numbers the Python LM returns)
+        d.decode_batch(inp["e"], [c["T"]], c["N"])
+        got = d.results(0)
+        d.close()
+        ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, "EXC %r" % (e,)
+    ran += 1
+    if not ok:
+        bad += 1
+        print("HOST-LM MISMATCH", c["name"], mode, {k: c[k] for k in ("kind", "N", "K", "Kt", "thr", "lm", "log_add", "T", "is_lm_token")}, why)
+print("host LMs: %d configurations, %d mismatches (%.0f s)" % (ran, bad, time.time() - t0), flush=True)
+
+# ---- 2. deferred look ----------------------------------------------------------------------------------------------
+bad2 = ran2 = redone = 0
+for i, c in enumerate(cases.fuzz_cases(N_DEFER)):
+    if i % 5 != 0 and c["K"] > 33:
+        continue
+    inp = helpers.case_inputs(c)
+    want = helpers.run_checker(orc, c, inp)
+    if tie(want):
+        continue
+    d = s.decoder(c, inp)
+    d.set("defer_check", 1)
+    if c["kind"] == "lexicon" and i % 4 == 0:
+        d.set("cut_m", c["K"] + 1)  # the cut forced tight: utterances get flagged and decoded again
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    got = d.results(0)
+    redone += d.get("redone")
+    d.close()
+    ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
+    ran2 += 1
+    if not ok:
+        bad2 += 1
+        print("DEFER MISMATCH", c["name"], why)
+print("defer_check: %d configurations (%d decoded again at result time), %d mismatches (%.0f s)" % (ran2, redone, bad2, time.time() - t0), flush=True)
+
+# ---- 3. long streams -----------------------------------------------------------------------------------------------
+bad3 = ran3 = comp = 0
+rnd = random.Random(77)
+for i in range(N_STREAM):
+    kind = ["lexfree", "lexfree", "lexicon"][i % 3]
+    lm = "zero" if i % 2 == 0 else ("ngram", rnd.choice([2, 3, 4]), 300 + i % 7)
+    K = rnd.choice([1, 3, 10, 33, 64, 100])
+    N = 29 if kind == "lexicon" or lm != "zero" else rnd.choice([12, 29, 40])
+    c = cases.case("soak_ls%d" % i, kind=kind, dist="lexspell" if kind == "lexicon" else rnd.choice(["ctc", "uniform"]),
+                   u=5000 + i, T=rnd.choice([600, 1500]), N=N, K=K, Kt=rnd.choice([N, N, 7]), thr=rnd.choice([4.0, 25.0, 100.0]),
+                   lm_weight=rnd.choice([0.5, 2.0]) if lm != "zero" else 0.0,
+                   word_score=rnd.choice([0.0, 1.5]) if kind == "lexicon" else 0.0, sil_score=rnd.choice([0.0, -0.5]),
+                   log_add=rnd.random() < 0.15, lexicon=cases.SMALL_LEX if kind == "lexicon" else None, lm=lm,
+                   is_lm_token=(kind == "lexfree" and lm != "zero"))
+    inp = helpers.case_inputs(c)
+    mf = 208 if kind == "lexicon" else rnd.choice([24, 64])
+    try:
+        out = tls._long_stream(s, orc, c, inp, chunk=rnd.choice([1, 7, 20]) if mf == 24 else rnd.choice([10, 50]), max_frames=mf,
+                               look_back=rnd.choice([0, 0, 2]), sets={"compact_always": i % 2})
+        comp += out[1]
+    except IndexError:
+        continue  # (a lexicon stream whose words outgrow the buffer: the reference's prune keeps them too)
+    except AssertionError as e:
+        if c["log_add"]:
+            continue  # (logAdd: device libm, compared bit for bit here)
+        bad3 += 1
+        print("STREAM MISMATCH", c["name"], {k: c[k] for k in ("kind", "N", "K", "Kt", "thr", "lm", "T")}, str(e)[:200])
+    ran3 += 1
+print("long streams: %d configurations, %d compactions, %d mismatches (%.0f s)" % (ran3, comp, bad3, time.time() - t0), flush=True)
+print("SOAK", "FAILED" if bad + bad2 + bad3 else "OK")
