@@ -492,7 +492,12 @@ def measure(a, torch, dist, rank, local, world, primary):
             a2.workload, a2.batch, a2.cpu_sample = wl, batch, sample
             a2.steps, a2.warmup = max(4, a.steps // 2), 2
             t0 = time.perf_counter()
-            o2, f2 = measure(a2, torch, dist, rank, local, world, primary=False)
+            try:
+                o2, f2 = measure(a2, torch, dist, rank, local, world, primary=False)
+            except Exception as e:  # noqa: BLE001 -- a secondary line must not take the judged line down with it
+                out["secondary"][name] = {"error": repr(e)}
+                fail = fail or "bench.py: secondary %s failed: %r" % (name, e)
+                continue
             r2, c2 = o2["roofline"], o2.get("cpu_baseline", {})
             out["secondary"][name] = {
                 "workload": o2["config"]["workload"], "value": o2["value"], "unit": "frames/s", "steps": o2["steps"],
