@@ -222,11 +222,26 @@ def test_ragged_parallel_streams_emulated(emu_session, oracle_lib):
     _ragged_parallel_streams(emu_session, oracle_lib, "lf_ctc_t60_k10")
 
 
+@pytest.mark.parametrize("name", ["lf_ctc_t60_k10", "ng_tok_lexfree_t40", "hl_lastword_lexfree"])
+def test_ragged_parallel_streams_with_recycled_ids_emulated(emu_session, oracle_lib, name):
+    """... with the LM-state ids renumbered before every chunk (round 5), and with a user-defined LM answering for
+    several streams at once (a host LM numbers its own states: nothing to recycle on the device)."""
+    _ragged_parallel_streams(emu_session, oracle_lib, name, (("compact_always", 1), ("threads", 64)))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,sets", [("lf_ctc_t60_k10", ()), ("lf_ctc_t60_k10", (("sstream", 0),)),
                                        ("C1_ctc_u0", ()), ("lf_asg_t40_n29_kt7", ()), ("lx_spell_t60_k12_full", ()),
                                        ("ng_word_t60_k16_4g", ()), ("ng_word_t60_k16_4g", (("cut_m", 17),)),
-                                       ("ng_word_t60_k16_4g", (("cut_m", 17), ("stream_defer", 0)))],
+                                       ("ng_word_t60_k16_4g", (("cut_m", 17), ("stream_defer", 0))),
+                                       ("lf_ctc_t60_k10", (("compact_always", 1),)),
+                                       ("lf_ctc_t60_k10", (("compact_always", 1), ("sstream", 0))),
+                                       ("lf_asg_t40_n29_kt7", (("compact_always", 1),)),
+                                       ("lx_spell_t60_k12_full", (("compact_always", 1),)),
+                                       ("ng_word_t60_k16_4g", (("compact_always", 1),)),
+                                       ("ng_word_t60_k16_4g", (("compact_always", 1), ("cut_m", 17))),
+                                       ("ng_tok_lexfree_t40", (("compact_always", 1),)),
+                                       ("hl_lastword_lexfree", ()), ("hl_lastword_word", ()), ("hl_lastword_toklex", ())],
                          ids=lambda x: x if isinstance(x, str) else None)
 def test_ragged_parallel_streams(gpu_session, oracle_lib, name, sets):
     _ragged_parallel_streams(gpu_session, oracle_lib, name, sets)

@@ -474,7 +474,7 @@ struct fltx_decoder {
   int hotLevel = 0;    /* what the LDS part holds (carveWs) */
   size_t ldsBudget = 0; /* tests: smaller LDS than the hardware's */
   int maxHotLevel = 2;
-  int itemCap = 0, noItems = 0; /* lexicon decoder: list of existing (hypothesis, token) children */
+  int itemCap = 0, noItems = 0, itemWide = 0; /* lexicon decoder: list of existing (hypothesis, token) children */
   int CAP2 = 0, cutM = 0, noCut = 0, userCutM = 0;
   int cutRecompute = 0, noSlim = 0; /* cut-off generation without the slim list (beams it does not fit) */ /* lexicon decoder: slim score-pass list + cut-off (runFrame) */
   size_t wsBytes = 0;
@@ -1898,9 +1898,13 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   /* lexicon decoder: generate from a list of the (hypothesis, token) pairs that
    * have a child in the trie when the full grid would take several rounds */
   d->itemCap = 0;
+  d->itemWide = 0;
   if (d->kind == FLTX_DECODER_LEXICON && !d->noItems && !d->forceGlobalWs && N <= 64 && d->trie &&
-      d->trie->mask.p && (int64_t)K * nTok > d->threads && K <= 1024) {
-    d->itemCap = K * nTok;
+      d->trie->mask.p && (int64_t)K * nTok > d->threads && (int64_t)K * nTok < (1 << 29)) {
+    /* (an item is hypothesis << 6 | token: 16 bits up to beam 1 024, a 32-bit word -- two of the list's uint16 words --
+     * beyond: the reference's own test decodes at beam 2 500, where the full grid is 76 rounds of mostly empty cells) */
+    d->itemWide = K > 1024 ? 1 : 0;
+    d->itemCap = K * nTok * (d->itemWide ? 2 : 1);
   }
   const int itemCap0 = d->itemCap;
   auto bytesFor = [&](int64_t c) {
@@ -2184,6 +2188,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
     P.trieEdge = d->trie->edge.as<TrieEdge>();
     P.trieMask = d->trie->mask.p ? d->trie->mask.as<unsigned long long>() : nullptr;
     P.itemCap = P.trieMask ? d->itemCap : 0;
+    P.itemWide = d->itemWide;
     P.trieLabels = d->trie->labels.as<int32_t>();
   }
   P.lmKind = d->lm->kind;
@@ -3469,6 +3474,7 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   }
   std::vector<int32_t> Tm(B, maxFrames);
   d->offlineCall = false;
+  d->offlinePending = false; /* (an offline batch whose results were never read) */
   d->batchPacked = false;
   d->keepScores = 1; /* streams serve getBestHypothesis(lookBack) of ancestors */
   /* The lexicon decoder's candidate lists are sized for what a frame usually produces (LDS) when a chunk
@@ -4090,6 +4096,12 @@ int fltx_result_device(fltx_decoder* d, const int32_t** nHyp, const double** sco
   }
   if (!d || !d->haveResults) {
     return fail(FLTX_ERR_STATE, "no decode has been run");
+  }
+  if (d->offlinePending) { /* "defer_check": the look at the statuses (and the second pass) before anybody reads the results */
+    int rc = syncResults(d);
+    if (rc) {
+      return rc;
+    }
   }
   if (!d->backtraced) {
     int rc = launchBacktrace(d);

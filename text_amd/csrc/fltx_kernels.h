@@ -118,7 +118,8 @@ struct DecodeParams {
   const TrieEdge* trieEdge; /* [nNodes*N] */
   const int32_t* trieLabels;
   const unsigned long long* trieMask; /* [nNodes] bit n set <=> the node has a child for token n (N <= 64), or null */
-  int32_t itemCap;                    /* capacity of the (hypothesis, token) item list = K * min(Kt, N), 0 = unused */
+  int32_t itemCap;                    /* uint16 words of the (hypothesis, token) item list: K * min(Kt, N) items, 0 = unused */
+  int32_t itemWide;                   /* 1: beams beyond 1 024 -- an item is a 32-bit word (two uint16 words of itemCap each) */
   /* LM */
   int32_t lmKind; /* 0 ZeroLM, 1 n-gram, 2 host LM (a user subclass of LM answers the frame's questions on the host) */
   int32_t lmOrder;
@@ -1383,6 +1384,11 @@ FLTX_DEV void denseLeaders(const DecodeParams& P, const Ws& w, const FrameCtx& f
  * item = (hypothesis, r): r < nTok tries the r-th short-listed token as a trie
  * child, r == nTok is "same node" (2), r == nTok+1 is CTC blank (3). */
 /* linear bins over [preThr, hi] for the recompute form of the cut-off generation */
+/* item i of the list of existing (hypothesis, token) children: hypothesis << 6 | token */
+FLTX_DEV uint32_t itemCode(const DecodeParams& P, const Ws& w, int i) {
+  return P.itemWide ? ((const uint32_t*)w.itemList)[i] : (uint32_t)w.itemList[i];
+}
+
 struct CutBins {
   double hi, scale;
   int bM;
@@ -1437,7 +1443,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     if (i0 < total) {
       int h0, n0;
       if (listed) {
-        const uint32_t code = w.itemList[i0];
+        const uint32_t code = itemCode(P, w, i0);
         h0 = (int)(code >> 6);
         n0 = (int)(code & 63u);
       } else {
@@ -1457,7 +1463,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
       if (i1 < total) {
         int h1, n1;
         if (listed) {
-          const uint32_t code = w.itemList[i1];
+          const uint32_t code = itemCode(P, w, i1);
           h1 = (int)(code >> 6);
           n1 = (int)(code & 63u);
         } else {
@@ -1484,7 +1490,7 @@ FLTX_DEV void genLexicon(const DecodeParams& P, const Ws& w, const FrameCtx& f,
     if (valid) { /* (1) children, :62-165 */
       int r;
       if (listed) {
-        const uint32_t code = w.itemList[i];
+        const uint32_t code = itemCode(P, w, i);
         h = (int)(code >> 6);
         n = (int)(code & 63u);
         r = (f.nTok == P.N) ? n : (int)w.tokPos[n];
@@ -2550,6 +2556,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
     tokenShortlist(P, w, f.e, f.nTok);
   }
   const bool listItems = !isEnd && P.kind == 1 && P.itemCap > 0;
+  const int itemLimit = P.itemWide ? P.itemCap >> 1 : P.itemCap; /* items the list holds */
   if (listItems) { /* which tokens lead anywhere from each slot's trie node (one 8-byte load per slot) */
     for (int h = tid; h < f.nBeam; h += W) {
       w.bLexMask[h] = P.trieMask[w.bLex[f.cur * P.K + h]];
@@ -2607,15 +2614,19 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
         while (m != 0ull) { /* slot h lists its own children: a few stores per thread */
           const int n = __builtin_ctzll(m);
           m &= m - 1ull;
-          if (pos < P.itemCap) {
-            w.itemList[pos] = (uint16_t)(((uint32_t)h << 6) | (uint32_t)n);
+          if (pos < itemLimit) {
+            if (P.itemWide) {
+              ((uint32_t*)w.itemList)[pos] = ((uint32_t)h << 6) | (uint32_t)n;
+            } else {
+              w.itemList[pos] = (uint16_t)(((uint32_t)h << 6) | (uint32_t)n);
+            }
           }
           ++pos;
         }
         run += tot;
       }
       wsBarrier(P);
-      nItems = run > P.itemCap ? P.itemCap : run;
+      nItems = run > itemLimit ? itemLimit : run;
       if (tid == 0) {
         w.red[3] = 0ull; /* next frame's short-list mask starts empty */
       }
@@ -2693,6 +2704,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
       genLexicon<0, false>(P, w, f, bestKey, preThr, nItems, cb);
     }
   }
+  FLTX_PROF(6); /* (lexicon decoder: item list + the score pass / the one-pass generation) */
   bestKey = waveMax64(bestKey);
   if (laneId() == 0 && bestKey != 0ull) {
     atomMax64(&w.red[2], bestKey);
@@ -2756,6 +2768,7 @@ FLTX_DEV int runFrame(const DecodeParams& P, const Ws& w, FrameCtx& f, int frame
       wsBarrier(P);
       bM = w.sc[SC_BM];
     }
+    FLTX_PROF(7); /* (the cut: histogram of the slim scores, the bin of the cutM-th best) */
     genLexiconSelected(P, w, f, nSlim, bM, best, thr, scale);
     wsBarrier(P);
   }
