@@ -490,7 +490,7 @@ def measure(a, torch, dist, rank, local, world, primary):
                                         ("WP", "WP", 0, 8)):
             a2 = copy.copy(a)
             a2.workload, a2.batch, a2.cpu_sample = wl, batch, sample
-            a2.steps, a2.warmup = max(4, a.steps // 2), 2
+            a2.steps, a2.warmup = max(12, a.steps), 2  # (two batches in flight: a short region is mostly ramp-up)
             t0 = time.perf_counter()
             try:
                 o2, f2 = measure(a2, torch, dist, rank, local, world, primary=False)
