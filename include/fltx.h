@@ -322,7 +322,9 @@ enum {
   FLTX_WHY_LOGADD = 16,       /* lexicon decoder with logAdd; lexicon-free decoder with logAdd over more than 64 tokens */
   FLTX_WHY_ASG = 32,          /* lexicon decoder with the ASG criterion */
   FLTX_WHY_UNK = 64,          /* lexicon decoder with <unk> enabled (unk_score > -inf) */
-  FLTX_WHY_TRIE_SHAPE = 128,  /* trie without a breadth-first layout (several labels per spelling, not a tree) */
+  FLTX_WHY_TRIE_SHAPE = 128,  /* trie without a breadth-first layout (not a tree, a word that ends without the separator); several
+                               * words per spelling (Trie.h:19) under ZeroLM -- those words tie in one LM state (round 5: with an
+                               * n-gram LM such lexicons, the reference's own test lexicon among them, run on fltx_ylane.h) */
   FLTX_WHY_WORD_END = 256,    /* words do not all end in the separator (= sil), or sil == blank */
   FLTX_WHY_OPTIONS = 512,     /* negative beam threshold, sil / blank outside the token set */
   FLTX_WHY_LENGTH = 1024,     /* beam x frames beyond the state-id width of the history records */

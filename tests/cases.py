@@ -18,6 +18,10 @@ def case(name, kind="lexfree", dist="ctc", u=0, T=20, N=29, K=4, Kt=None, thr=25
 
 SMALL_LEX = (300, 4242)   # (W, seed): 300-word synthetic lexicon
 NODUP_LEX = (300, 4242, True)  # same, without doubled letters (ASG: see helpers.lexicon)
+MULTI_LEX = (300, 4242, "multi")  # homophones: one, two or three words per spelling (helpers.lexicon)
+MULTI_NODUP_LEX = (300, 4242, "multi_nodup")
+MULTI_LEX_3K = (3000, 77, "multi")
+MULTI_NODUP_LEX_3K = (3000, 77, "multi_nodup")
 FULL_LEX = (90000, 4242)  # SURVEY.md Appendix A lexicon (513 786 trie nodes)
 
 CASES = [
@@ -87,6 +91,18 @@ CASES = [
          sil_score=-0.4),
     case("ng_tok_lexicon_t40", kind="lexicon", dist="lexspell", T=40, K=10, lexicon=SMALL_LEX, u=12,
          lm=("ngram", 3, 13), lm_weight=0.9, word_score=0.5, is_lm_token=True),
+    # ---- several words per spelling (LexiconDecoder.cpp:113-142 loops over lex->labels; the reference's own test lexicon has
+    # 169 such spellings): n-gram word LM, so that the words of a spelling differ in score and LM state
+    case("ml_word_t60_k16", kind="lexicon", dist="lexspell", T=60, K=16, lexicon=MULTI_LEX, u=40,
+         lm=("ngram", 3, 41), lm_weight=1.3, word_score=0.7, sil_score=-0.2),
+    case("ml_word_uni_t50_k48", kind="lexicon", dist="uniform", T=50, K=48, lexicon=MULTI_LEX, u=41,
+         lm=("ngram", 4, 42), lm_weight=1.0, word_score=1.5),
+    case("ml_word_asg_t40_k24", kind="lexicon", dist="lexspell", T=40, K=24, lexicon=MULTI_NODUP_LEX, crit="asg",
+         trans_seed=23, u=42, lm=("ngram", 3, 43), lm_weight=1.1, word_score=0.5),
+    case("ml_word_t80_k100", kind="lexicon", dist="lexspell", T=80, K=100, lexicon=MULTI_LEX_3K, u=43, size="medium",
+         lm=("ngram", 3, 44), lm_weight=2.0, word_score=2.0, sil_score=-1.0),
+    case("ml_word_asg_t80_k200", kind="lexicon", dist="lexspell", T=80, K=200, lexicon=MULTI_NODUP_LEX_3K, crit="asg",
+         trans_seed=24, u=44, size="medium", lm=("ngram", 3, 45), lm_weight=1.5, word_score=1.0),
     # ---- a user-defined LM whose states are shared between histories (one state object per last input:
     # oracle/orc_api.h lm_lastword_create, tests/host_lms.py LastWordLM): the reference merges on the state's address
     case("hl_lastword_lexfree", dist="ctc", T=40, K=10, u=20, lm=("lastword", 5), lm_weight=0.7, is_lm_token=True),

@@ -20,19 +20,35 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "libfltx_emu.so")
 
 
-@functools.lru_cache(maxsize=4)
-def lexicon(W, seed, nodup=False):
-    """Synthetic lexicon; nodup drops spellings with adjacent repeated letters
+@functools.lru_cache(maxsize=8)
+def lexicon(W, seed, mode=False):
+    """Synthetic lexicon.  mode True / "nodup" drops spellings with adjacent repeated letters
     (what replabels guarantee for ASG lexicons: with a doubled letter, "stay in
     the node" and "advance to the child" consume the same token at the same
-    score, an exact tie whose resolution the reference leaves to nth_element)."""
+    score, an exact tie whose resolution the reference leaves to nth_element).
+    mode "multi" / "multi_nodup": homophones, as the reference's own test lexicon has them -- word w takes the
+    spelling of word w - 1 when w % 3 == 1 and of word w - 2 when w % 9 == 2, so spellings carry one, two or three
+    words (Trie.h:19 allows six); "multi6": six on every spelling."""
     sf, so = synth.lexicon(W, seed)
-    if not nodup:
+    if not mode:
         return sf, so
-    keep = [w for w in range(W) if not np.any(sf[so[w]:so[w + 1] - 1][1:] == sf[so[w]:so[w + 1] - 1][:-1])]
-    nsf = np.concatenate([sf[so[w]:so[w + 1]] for w in keep]).astype(np.int32)
-    nso = np.zeros(len(keep) + 1, dtype=np.int64)
-    nso[1:] = np.cumsum([so[w + 1] - so[w] for w in keep])
+    spell = [sf[so[w]:so[w + 1]] for w in range(W)]
+    if mode in (True, "nodup", "multi_nodup"):
+        spell = [sp for sp in spell if not np.any(sp[:-1][1:] == sp[:-1][:-1])]
+    if mode in ("multi", "multi_nodup"):
+        for w in range(len(spell)):
+            if w % 3 == 1:
+                spell[w] = spell[w - 1]
+            elif w % 9 == 2:
+                spell[w] = spell[w - 2]
+    if mode == "multi6":  # six words on every spelling: the most a trie node takes
+        spell = [spell[w - w % 6] for w in range(len(spell))]
+    if mode == "short6":  # ... on spellings of one or two letters: most lanes of a beam can end a word in every frame
+        spell = [np.array(([1 + (w // 6)] if w // 6 < 24 else [1 + (w // 6) % 24, 1 + (w // 6) // 24]) + [0], dtype=np.int32)
+                 for w in range(W)]
+    nsf = np.concatenate(spell).astype(np.int32)
+    nso = np.zeros(len(spell) + 1, dtype=np.int64)
+    nso[1:] = np.cumsum([len(sp) for sp in spell])
     return nsf, nso
 
 

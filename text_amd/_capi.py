@@ -15,6 +15,10 @@ DEFAULT_LIB = os.path.join(_HERE, "lib", "libfltx.so")
 FLTX_OK, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_RANGE, ERR_STATE = range(7)
 CRITERION = {"asg": 0, "ctc": 1}
 LEXFREE, LEXICON = 0, 1
+# fltx_decoder_get "why_not_lane" (include/fltx.h FLTX_WHY_*)
+(FLTX_WHY_TOKENS, FLTX_WHY_BEAM, FLTX_WHY_STREAM, FLTX_WHY_LM, FLTX_WHY_LOGADD, FLTX_WHY_ASG, FLTX_WHY_UNK,
+ FLTX_WHY_TRIE_SHAPE, FLTX_WHY_WORD_END, FLTX_WHY_OPTIONS, FLTX_WHY_LENGTH, FLTX_WHY_SWITCHED_OFF,
+ FLTX_WHY_GEOMETRY) = (1 << i for i in range(13))
 
 
 class Options(C.Structure):

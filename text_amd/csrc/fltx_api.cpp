@@ -371,7 +371,8 @@ struct fltx_trie {
   /* breadth-first re-layout for the lane = (LM state, trie node) engine (fltx_xlane.h): a node's
    * children are contiguous and in token order, so a child's id is the first child's id plus the
    * number of children with a smaller token; one 32-byte XNode per node, root = 0 */
-  DBuf xnode, xdelta;
+  DBuf xnode, xdelta, xextra;
+  bool xMulti = false;  /* some spelling has several words (Trie.h:19: up to 6 labels per node): fltx_ylane.h's LMK bit 2 */
   std::vector<int32_t> xEndHost; /* XNode::endLabel0 per node (host copy: decoders map it to LM word ids) */
   bool xOk = false;     /* the layout exists and the trie has the shape that engine assumes: */
   int32_t xEndTok = -1; /* every node that carries labels is entered by this one token (the word separator) */
@@ -1085,9 +1086,10 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
     order.reserve((size_t)nNodes);
     order.push_back(0);
     xn.resize((size_t)nNodes);
-    bool ok = true;
+    bool ok = true, multi = false;
     int endTok = -1;
     bool zero = true;
+    std::vector<uint32_t> xextraHost((size_t)nNodes, 0u);
     std::vector<uint8_t> seen((size_t)nNodes, 0);
     seen[0] = 1;
     for (size_t q = 0; q < order.size() && ok; ++q) {
@@ -1121,8 +1123,10 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
           if (endTok < 0) {
             endTok = tk;
           }
-          ok = ok && tk == endTok && nl == 1; /* one word-ending token, one word per spelling */
+          ok = ok && tk == endTok && nl <= 6 && labelOff[c] < (1 << 28); /* one word-ending token; Trie.h:19: at most 6 words per spelling */
           x.endLabel0 = labels[labelOff[c]];
+          xextraHost[q] = ((uint32_t)labelOff[c] << 3) | (uint32_t)nl;
+          multi = multi || nl > 1;
         }
       }
       xn[q] = x;
@@ -1134,7 +1138,15 @@ int fltx_trie_create(fltx_ctx* ctx, int64_t nNodes, int32_t nTokens, const int32
     }
     ok = ok && order.size() == (size_t)nNodes && (labelOff[1] - labelOff[0]) == 0; /* a tree; no label on the root */
     t->xOk = ok;
+    t->xMulti = ok && multi;
     t->xEndTok = endTok;
+    if (ok && multi) {
+      if (t->xextra.ensure(sizeof(uint32_t) * xextraHost.size(), st, false) ||
+          devCopyH2D(t->xextra.p, xextraHost.data(), sizeof(uint32_t) * xextraHost.size(), st) || devSync(st)) {
+        delete t;
+        return fail(FLTX_ERR_OOM, "trie upload: labels of the spellings");
+      }
+    }
     t->xZeroSmear = zero;
     if (!ok) {
       xn.clear();
@@ -1755,7 +1767,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   d->yshare = 0;
   if (d->kind == FLTX_DECODER_LEXICON && !d->noXlane && !d->genericAsked && d->offlineCall && !d->keepScores && !d->opt.log_add &&
       !forceWorstCaseCap && !d->forceGlobalWs && d->lm->kind == 0 && !d->isLmToken && d->trie && d->trie->xOk &&
-      d->trie->xZeroSmear && d->trie->xEndTok == d->sil && d->sil != d->blank &&
+      !d->trie->xMulti && d->trie->xZeroSmear && d->trie->xEndTok == d->sil && d->sil != d->blank &&
       d->opt.criterion == FLTX_CRITERION_CTC && !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) &&
       K <= 64 && N <= 64 && d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N && d->blank >= 0 &&
       d->blank < N && (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
@@ -1781,7 +1793,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (d->kind == FLTX_DECODER_LEXICON && !d->noYlane && !d->genericAsked && (!d->xlane || d->preferYlane) &&
       d->offlineCall && !d->keepScores && !d->opt.log_add && !forceWorstCaseCap && !d->forceGlobalWs &&
       (d->lm->kind == 0 || d->lm->kind == 1) && !d->isLmToken && d->trie && d->trie->xOk &&
-      d->trie->xEndTok == d->sil &&
+      /* (several words per spelling: with an n-gram LM only -- under ZeroLM the words of a spelling tie in one LM state) */
+      (!d->trie->xMulti || d->lm->kind == 1) && d->trie->xEndTok == d->sil &&
       (d->opt.criterion == FLTX_CRITERION_CTC ? (d->sil != d->blank && d->blank >= 0 && d->blank < N)
                                                : (d->nTrans == N * N && !d->noYlaneAsg)) &&
       !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) && K <= 256 && N <= 64 &&
@@ -1796,7 +1809,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
      * the memo in LDS numbers (about 2.2 per frame on the C4 shape, 6 144 at most): it takes the HBM memo as well,
      * sized for its frames, instead of leaving the engine half way */
     const bool longUtt = (int64_t)maxT * 5 / 2 + 64 > kYlMemo * 3 / 4;
-    const bool share = ng == 4 ? true : (d->userYshare >= 0 ? d->userYshare != 0 : (B > d->ctx->numCUs || longUtt));
+    /* (several words per spelling: the larger merge table takes the memo's place in LDS -- memo in HBM always) */
+    const bool share = (ng == 4 || d->trie->xMulti) ? true : (d->userYshare >= 0 ? d->userYshare != 0 : (B > d->ctx->numCUs || longUtt));
     const int threads = ng == 4 ? 1024 : (ng == 1 ? 512 : (share ? 512 : 768));
     const int nTokWaves = threads / 64 - ng - 2;
     const int tpw = (nTok + nTokWaves - 1) / nTokWaves;
@@ -1808,7 +1822,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       uint32_t ms = kYlMemo;
       /* (C4 shape: 2.2 new LM states per frame at beam 100, 4 .. 6.5 at beam 256; a memo no bigger than it has to be
        * stays in the L2: 8 192 slots unless the utterance is long or the beam needs four groups) */
-      while ((longUtt || ng == 4) && ms < 65536u && (int64_t)ms * 3 / 4 < (int64_t)maxT * (ng == 4 ? 8 : 5) + 256) {
+      /* (several words per spelling: every further word that stays in the beam is one more LM state -- four times as many) */
+      const int perFrame = (ng == 4 ? 8 : 5) * (d->trie->xMulti ? 4 : 1);
+      while ((longUtt || ng == 4 || d->trie->xMulti) && ms < 65536u && (int64_t)ms * 3 / 4 < (int64_t)maxT * perFrame + 256) {
         ms *= 2;
       }
       d->ymemoSlots = share ? ms : kYlMemo;
@@ -1816,7 +1832,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       d->ylane = ng;
       d->ylaneRounds = ng == 1 ? 2 : 4;
       d->ylaneTpw = tpw;
-      d->ylaneLm = ((d->lm->kind != 0 || !d->trie->xZeroSmear) ? 1 : 0) | (d->opt.criterion == FLTX_CRITERION_CTC ? 0 : 2);
+      d->ylaneLm = ((d->lm->kind != 0 || !d->trie->xZeroSmear) ? 1 : 0) | (d->opt.criterion == FLTX_CRITERION_CTC ? 0 : 2) |
+                   (d->trie->xMulti ? 4 : 0);
       d->threads = threads;
       d->xlane = 0;
       if (d->lm->kind == 1 && (d->xlmwordTrie != d->trie || d->xlmwordLm != d->lm)) {
@@ -1848,7 +1865,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (lexi && d->opt.log_add) ? FLTX_WHY_LOGADD : 0;
       why |= (lexi && d->opt.criterion != FLTX_CRITERION_CTC && d->noYlaneAsg) ? FLTX_WHY_ASG : 0;
       why |= (lexi && unkOn) ? FLTX_WHY_UNK : 0;
-      why |= (lexi && d->trie && !d->trie->xOk) ? FLTX_WHY_TRIE_SHAPE : 0;
+      why |= (lexi && d->trie && (!d->trie->xOk || (d->trie->xMulti && d->lm->kind == 0))) ? FLTX_WHY_TRIE_SHAPE : 0;
       why |= (lexi && d->trie && d->trie->xOk && (d->trie->xEndTok != d->sil || d->sil == d->blank)) ? FLTX_WHY_WORD_END : 0;
       why |= (!(d->opt.beam_threshold >= 0.0) || d->sil < 0 || d->sil >= N ||
               (d->opt.criterion == FLTX_CRITERION_CTC && (d->blank < 0 || d->blank >= N))) ? FLTX_WHY_OPTIONS : 0;
@@ -2053,9 +2070,17 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (d->ylane) {
     /* (shared-CU geometries: the part of YlaneLds::pscore their token waves use -- five waves x 512 floats with one lane
      * group, four with two -- so that two workgroups still fit a CU's 160 KB) */
-    d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsT<4>, memo)
-                               : (d->yshare ? offsetof(YlaneLds, pscore) + (size_t)(d->ylane == 2 ? 4 : 5) * 512 * sizeof(float)
-                                            : sizeof(YlaneLds));
+    const size_t pscorePart = (size_t)(d->ylane == 2 ? 4 : 5) * 512 * sizeof(float);
+    if (d->ylaneLm & 4) { /* several words per spelling: a larger merge table and the further words' lists (one workgroup per CU) */
+      using YlaneLdsMl = YlaneLdsT<2, true>;
+      using YlaneLdsMl4 = YlaneLdsT<4, true>;
+      static_assert(offsetof(YlaneLdsMl, pscore) + 5 * 512 * sizeof(float) <= 160 * 1024 && offsetof(YlaneLdsMl4, memo) <= 160 * 1024,
+                    "one CU's LDS");
+      d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsMl4, memo) : offsetof(YlaneLdsMl, pscore) + pscorePart; /* (memo in HBM) */
+    } else {
+      d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsT<4>, memo)
+                                 : (d->yshare ? offsetof(YlaneLds, pscore) + pscorePart : sizeof(YlaneLds));
+    }
     d->wsInLds = true;
     lds = true;
     d->itemCap = 0;
@@ -2249,6 +2274,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xnode = (d->trie && d->trie->xnode.p) ? d->trie->xnode.as<XNode>() : nullptr;
   P.xEndTok = d->trie ? d->trie->xEndTok : -1;
   P.xdelta = (d->trie && d->trie->xdelta.p) ? d->trie->xdelta.as<float>() : nullptr;
+  P.xextra = (d->trie && d->trie->xextra.p) ? d->trie->xextra.as<uint32_t>() : nullptr;
   P.yTpw = d->ylaneTpw;
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
   P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
@@ -2434,6 +2460,13 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       case 123: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 3, 1); break;
       case 142: FLTX_LAUNCH_YLANE4(2); break;
       case 143: FLTX_LAUNCH_YLANE4(3); break;
+      /* several words per spelling (LMK bit 2; with the LM terms) */
+      case 115: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 5, 1); break;
+      case 117: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 7, 1); break;
+      case 125: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 5, 1); break;
+      case 127: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 7, 1); break;
+      case 145: FLTX_LAUNCH_YLANE4(5); break;
+      case 147: FLTX_LAUNCH_YLANE4(7); break;
       default: return fail(FLTX_ERR_INVALID, "no fltx_ylane.h kernel for %d lane groups", d->ylane);
     }
 #undef FLTX_LAUNCH_YLANE

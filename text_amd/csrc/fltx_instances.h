@@ -94,6 +94,14 @@
   FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 3, 1, false>)  \
   FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 2, 1, false>)  \
   FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 3, 1, false>)
+/* spellings shared by several words (LMK bit 2), with the LM terms: memo in HBM (the larger merge table takes its place) */
+#define FLTX_G23(W)                                           \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 5, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 7, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 5, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 7, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 5, 1, false>) \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 7, 1, false>)
 #define FLTX_G14(W) FLTX_YLANE_SET(true)
 /* lane = LM state decode over a token beam of a large token set (fltx_wlane.h): (threads, list positions per wave) */
 #define FLTX_G22(W)                                   \
@@ -127,6 +135,7 @@ FLTX_G19(0)
 FLTX_G20(0)
 FLTX_G21(0)
 FLTX_G22(0)
+FLTX_G23(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -151,6 +160,7 @@ FLTX_G22(0)
 #undef FLTX_G20
 #undef FLTX_G21
 #undef FLTX_G22
+#undef FLTX_G23
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET

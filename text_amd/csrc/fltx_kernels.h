@@ -189,6 +189,7 @@ struct DecodeParams {
   const XNode* xnode;           /* breadth-first trie layout (fltx_xlane.h), or null */
   int32_t xEndTok;              /* the token every word ends with in that layout */
   const float* xdelta;          /* per node of that layout: maxScore - (parent is the root ? 0 : parent's maxScore) */
+  const uint32_t* xextra;       /* ... the words its word-ending child carries: place of the first in trieLabels << 3 | words (fltx_ylane.h, several words per spelling), or null */
   int32_t yTpw;                 /* fltx_ylane.h: list positions per token wave */
   unsigned long long* ymemo;    /* fltx_ylane.h / fltx_xlane.h, memo in HBM: the LM-state memo of every utterance (ymemoSlots each) */
   uint32_t ymemoSlots;          /* power of two; fltx_xlane.h: kXlMemoH */

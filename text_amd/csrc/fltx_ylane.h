@@ -39,8 +39,10 @@ constexpr int kYlPairs = 512; /* (lane, token) pairs a token wave can list: posi
 constexpr int kYlPairs4 = 768; /* ... with four lane groups: three positions x 256 lanes */
 constexpr uint32_t kYlNoLm = 0x7FC00001u; /* endLm: not looked up yet (a NaN no arithmetic produces) */
 constexpr int kYlMaxGroups = 8;
+constexpr int kYlExtraPerGroup = 128; /* (lane, further word of its spelling) pairs the word wave takes per frame and lane group: 64
+                                       * per extra candidate slot of its threads, two slots per lane group */
 
-template <int LG>
+template <int LG, bool ML = false>
 struct YlLanesT { /* in place: slot = lane for as long as the lane lives */
   static constexpr int kYlLanes = 64 * LG;
   double nb[kYlLanes], b[kYlLanes];
@@ -60,6 +62,7 @@ struct YlLanesT { /* in place: slot = lane for as long as the lane lives */
   int32_t endWord[kYlLanes];     /* LM word id of endLabel (n-gram LM) */
   uint32_t endLm[kYlLanes];      /* float bits: lm.score(LM state, endLabel), kYlNoLm = not looked up */
   int32_t endCtx[kMaxNgramOrder - 1][kYlLanes]; /* ... and the n-gram context of the LM state that word leads to */
+  uint32_t endExtra[ML ? kYlLanes : 1]; /* (LMK bit 2) several words per spelling (Trie.h:19: up to 6): place of the first in trieLabels << 3 | words */
 };
 
 template <int kYlRoot>
@@ -79,16 +82,19 @@ struct alignas(16) YlOrphTabT {
   unsigned long long lanes[LG][kYlOrph];
 };
 
-template <int LG>
+template <int LG, bool ML = false> /* ML: several words per spelling (LMK bit 2) -- room for their arrivals */
 struct YlaneLdsT {
   static constexpr int kYlLanes = 64 * LG;
-  static constexpr int kYlRoot = 128 * LG;  /* slots of the per-frame (LM state, word) merge table */
+  static constexpr int kYlX = ML ? kYlExtraPerGroup * LG : 0; /* further words of the frame's lanes */
+  /* slots of the per-frame (LM state, word) merge table: twice the lanes; with further words, the lanes plus the
+   * further words and half as much again (768 with four groups: not a power of two, ylRootFind wraps by comparison) */
+  static constexpr int kYlRoot = ML ? (LG == 4 ? 768 : 512) : 128 * LG;
   static constexpr int kYlOrph = 128 * LG;  /* slots of the per-frame table of lanes without a parent lane */
   static constexpr int kYlTokWaves = LG <= 2 ? 8 : 10;
   static constexpr int kYlPairs = LG <= 2 ? fltx::kYlPairs : fltx::kYlPairs4;
   using YlRootTab = YlRootTabT<kYlRoot>;
   using YlOrphTab = YlOrphTabT<LG, kYlOrph>;
-  YlLanesT<LG> L;
+  YlLanesT<LG, ML> L;
   unsigned long long cmask[2][kYlLanes]; /* tokens whose child node holds a lane that links here */
   uint32_t hist[2][kSlNB];
   double eAll[2][64];
@@ -108,9 +114,16 @@ struct YlaneLdsT {
   uint32_t nFree[LG];
   uint8_t freeList[LG][64];          /* free slots of a group, in slot order */
   uint16_t lmReq[kYlLanes];          /* lanes whose word has no n-gram score yet */
-  uint16_t nrList[kYlLanes];         /* arrivals that become root lanes, and what was found out for them */
-  int16_t nrOrph[kYlLanes];
-  uint32_t nrSid[kYlLanes];
+  /* arrivals that become root lanes, and what was found out for them; an arrival = slot * 64 + thread of the word
+   * wave: slot g < NG is the word of lane g * 64 + thread, slot NG + r the further word xEmit[r * 64 + thread] */
+  uint16_t nrList[kYlLanes + kYlX];
+  int16_t nrOrph[kYlLanes + kYlX];
+  uint32_t nrSid[kYlLanes + kYlX];
+  /* further words of a spelling (LMK bit 2): this frame's (lane | index of the word << 8) pairs, 64 per extra slot of the
+   * word wave, with the word (its n-gram score is asked every frame: nothing is kept with the lane) */
+  uint16_t xEmit[ML ? kYlX : 4];
+  int32_t xLabel[ML ? kYlX : 2];
+  uint32_t rootExtra, nExtra;
   uint16_t cand[kYlTokWaves][kYlPairs]; /* (lane | list position << 8) pairs of a token wave */
   uint32_t whist[kYlTokWaves][kSlNB];   /* a wave with more pairs than its rounds take ranks them: counts per bin */
   unsigned long long lb[2];          /* a candidate the frame is known to have (stay / blank of a surviving lane): best >= this */
@@ -139,13 +152,14 @@ enum { YL_FLAG = 15, YL_NICE = 14, YL_WHYCODE = 13 };
 template <typename LDS>
 FLTX_DEV int ylRootFind(LDS& S, unsigned long long key) {
   constexpr int kYlRoot = LDS::kYlRoot;
-  uint32_t h = xlHash(key) & (kYlRoot - 1);
+  constexpr bool pow2 = (kYlRoot & (kYlRoot - 1)) == 0;
+  uint32_t h = pow2 ? (xlHash(key) & (uint32_t)(kYlRoot - 1)) : (xlHash(key) % (uint32_t)kYlRoot);
   for (int probe = 0; probe < kYlRoot; ++probe) {
     const unsigned long long old = atomCas64(&S.root.key[h], 0ull, key);
     if (old == 0ull || old == key) {
       return (int)h;
     }
-    h = (h + 1u) & (kYlRoot - 1);
+    h = h + 1u == (uint32_t)kYlRoot ? 0u : h + 1u;
   }
   return -1;
 }
@@ -240,12 +254,20 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
    * token] enters the emitting-model score from the second frame on, LexiconDecoder.cpp:69-72,172-175) */
   constexpr int LMT = LMK & 1;
   constexpr bool ASG = (LMK & 2) != 0;
+  /* bit 2 = several words per spelling (LexiconDecoder.cpp:113-142 loops over lex->labels): the word wave gets XR more
+   * candidate slots per thread for the further words of the frame's lanes (short homophones fill a beam: the
+   * reference's own test lexicon has 34 of 50 lanes on one three-word spelling in a frame) */
+  constexpr bool ML = (LMK & 4) != 0;
+  constexpr int XR = ML ? 2 * NG : 0;
+  constexpr int NW = NG + XR; /* candidate slots of a word-wave thread */
   constexpr int LG = NG > 2 ? NG : 2;
-  using LDS = YlaneLdsT<LG>;
+  using LDS = YlaneLdsT<LG, ML>;
   LDS& S = *(LDS*)smem;
   constexpr int kYlLanes = LDS::kYlLanes, kYlRoot = LDS::kYlRoot, kYlOrph = LDS::kYlOrph;
+  static_assert(XR * 64 <= (ML ? LDS::kYlX : 0), "xEmit / xLabel / nrList hold the extra slots' arrivals");
   constexpr int PAIRS = (NG == 2 && HM) ? 2 * kYlPairs : LDS::kYlPairs; /* pairs a token wave can list */
-  constexpr int NS = R > NG ? R : (NG > 2 ? NG : 2); /* candidate slots of a thread */
+  constexpr int NS0 = R > NG ? R : (NG > 2 ? NG : 2);
+  constexpr int NS = NS0 > NW ? NS0 : NW; /* candidate slots of a thread */
   static_assert(NG == 1 || NG == 2 || NG == 4, "one, two or four lane groups");
   static_assert(NG <= 2 || HM == 1, "four lane groups: the LM-state memo lives in HBM");
   /* History slots in the lanes' records: 8 bits (0xFF = none) up to two groups, 13 bits beyond -- the back-trace masks
@@ -367,6 +389,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     L.parent[0] = 0u;
     L.firstChild[0] = r0.firstChild;
     L.endLabel[0] = r0.endLabel0;
+    if constexpr (ML) {
+      L.endExtra[0] = P.xextra ? P.xextra[0] : 0u;
+      S.rootExtra = L.endExtra[0];
+    }
+    S.nExtra = 0u;
     L.dPar[0] = 0x7FFFFFFFu;
     L.dWord[0] = -1;
     L.maxScore[0] = r0.maxScore;
@@ -465,12 +492,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     int last = 0, pl = -1, rootSlot = -1;
     bool whichB = false;
     double lmR = 0.0; /* LM score of the winning member of the stay group */
-    /* word wave, per group */
-    int wSlot[NG];
-    bool wUseB[NG];
-    uint32_t wHypB[NG], wHypM[NG];
+    /* word wave, per slot (a lane group's lane, or the thread's further word) */
+    int nXtra = 0; /* further words this frame (word wave) */
+    int wSlot[NW];
+    bool wUseB[NW];
+    uint32_t wHypB[NW], wHypM[NW];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = 0; g < NW; ++g) {
       wSlot[g] = -1;
       wUseB[g] = false;
       wHypB[g] = kNoHyp;
@@ -934,10 +962,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
       FLTX_YLPROF(7);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int x = g * 64 + lane;
-        const bool lv = ((aliveG[g] >> lane) & 1ull) != 0ull;
+      /* the word-end candidate of lane x for word `el` (n-gram score lmBits when there is an n-gram LM) into slot J */
+      auto wordEnd = [&](auto JT, int x, bool lv, int32_t el, uint32_t lmBits) {
+        constexpr int g = decltype(JT)::value;
         const double xnb = lv ? L.nb[x] : NEG, xb = lv ? L.b[x] : NEG;
         const uint32_t xi = L.info[x];
         const int xl = infoTok(xi);
@@ -945,7 +972,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         const bool wb = xb > xnb;
         const double xm = wb ? xb : xnb;
         const bool xRoot = L.node[x] == 0u;
-        const int32_t el = L.endLabel[x];
         const uint32_t xlm = L.lmSid[x];
         const double eEnd = S.eAll[p][endTok], eLast = S.eAll[p][xl];
         /* a word ends (:113-142); on the root the nb hypothesis would repeat its token (:114-122) */
@@ -960,7 +986,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         if (LMT) {
           float sc = 0.0f;
           if (ngram && can) {
-            sc = __uint_as_float(L.endLm[x]);
+            sc = __uint_as_float(lmBits);
           }
           lmS = sc - (xRoot ? 0.0f : L.maxScore[x]); /* lmScore - lexMaxScore, LexiconDecoder.cpp:47,125 */
           srcLm = useB ? L.lmB[x] : (wb ? L.lmB[x] : L.lmNB[x]);
@@ -981,12 +1007,95 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             atomMax64(&S.root.best[wSlot[g]], f64Key(c));
           }
         }
+        (void)eLast;
+      };
+      auto wordEndOfGroup = [&](auto GT) {
+        constexpr int g = decltype(GT)::value;
+        const int x = g * 64 + lane;
+        const bool lv = ((aliveG[g] >> lane) & 1ull) != 0ull;
+        wordEnd(GT, x, lv, L.endLabel[x], L.endLm[x]);
+      };
+      wordEndOfGroup(SlParity<0>());
+      if constexpr (NG > 1) {
+        wordEndOfGroup(SlParity<1>());
+      }
+      if constexpr (NG > 2) {
+        wordEndOfGroup(SlParity<2>());
+        wordEndOfGroup(SlParity<3>());
+      }
+      if constexpr (ML) {
+        /* the further words of the spellings the frame's lanes can end (Trie.h:19: up to 6 per node): listed, one per
+         * thread, and priced like the first -- their n-gram scores asked now (rare: nothing is kept with the lane) */
+        int nX = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int x = g * 64 + lane;
+          const bool lv = ((aliveG[g] >> lane) & 1ull) != 0ull;
+          const int nl = lv ? (int)(L.endExtra[x] & 7u) : 0;
+          for (int l = 1; l < 6; ++l) {
+            const bool more = nl > l;
+            const unsigned long long bal = waveBallot(more);
+            if (bal == 0ull) {
+              break;
+            }
+            const int at = nX + wavePrefixCount(bal);
+            if (more && at < XR * 64) {
+              S.xEmit[at] = (uint16_t)(x | (l << 8));
+            }
+            nX += popc64(bal);
+          }
+        }
+        if (nX > XR * 64) {
+          dead = true; YL_WHY(8); /* more further words in one frame than the word wave has slots for: general path */
+          if (lane == 0) {
+            S.bestKey[p] = ~0ull;
+          }
+          nX = 0;
+        }
+        nXtra = nX;
+        if (nX > 0) {
+          waveSync();
+          auto extraRound = [&](auto RT) {
+            constexpr int r = decltype(RT)::value;
+            const int idx = r * 64 + lane;
+            if (r * 64 >= nX) {
+              return;
+            }
+            const bool mine = idx < nX;
+            const int e = mine ? (int)S.xEmit[idx] : 0;
+            const int x = e & 0xFF, l = e >> 8;
+            int32_t el = -1;
+            uint32_t lmBits = 0u;
+            if (mine) {
+              el = P.trieLabels[(int)(L.endExtra[x] >> 3) + l];
+              S.xLabel[idx] = el;
+              if (ngram) {
+                int32_t out[kMaxNgramOrder];
+                lmBits = __float_as_uint(ylNgram(P, b, L.lmSid[x], ylLmWord(P, el), out));
+                ++nScored;
+              }
+            }
+            wordEnd(SlParity<NG + r>(), x, mine, el, lmBits);
+          };
+          extraRound(SlParity<0>());
+          extraRound(SlParity<1>());
+          if constexpr (XR > 2) {
+            extraRound(SlParity<2>());
+            extraRound(SlParity<3>());
+          }
+          if constexpr (XR > 4) {
+            extraRound(SlParity<4>());
+            extraRound(SlParity<5>());
+            extraRound(SlParity<6>());
+            extraRound(SlParity<7>());
+          }
+        }
       }
     }
     {
       bool full = isSelf && live && atRoot && rootSlot < 0;
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
+      for (int g = 0; g < NW; ++g) {
         full = full || (isWord && cok[g] && wSlot[g] < 0);
       }
       if (waveBallot(full) != 0ull) {
@@ -1013,7 +1122,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     FLTX_YLPROF(1);
     ldsBarrier(); /* A */
     /* slots this wave uses (uniform per wave): the loops over the slots stop there */
-    const int nUsed = isTok ? (nCand + 63) >> 6 : (isSelf ? 2 : NG);
+    const int nUsed = isTok ? (nCand + 63) >> 6 : (isSelf ? 2 : NG + ((nXtra + 63) >> 6));
     /* ---- phase 1b: threshold, merge-table verdicts, histogram ---------------------------- */
     const unsigned long long bk = S.bestKey[p];
     if (bk == 0ull || bk == ~0ull) {
@@ -1038,9 +1147,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
        * root lane takes when a word ending on it beats its own stay, and the candidate for a new
        * root lane when nobody stands there.  (One wave handles the arrivals of all groups: the two
        * steps below need no barrier.) */
-      bool top[NG];
+      bool top[NW];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
+      for (int g = 0; g < NW; ++g) {
         top[g] = cok[g] && S.root.best[wSlot[g] >= 0 ? wSlot[g] : 0] == f64Key(cs[g]);
         if (top[g]) {
           atomMin32(&S.root.minLane[wSlot[g]], (uint32_t)(g * 64 + lane));
@@ -1048,7 +1157,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       }
       waveSync();
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
+      for (int g = 0; g < NW; ++g) {
         const int sl = wSlot[g] >= 0 ? wSlot[g] : 0;
         const bool rep = top[g] && S.root.minLane[sl] == (uint32_t)(g * 64 + lane);
         if (rep) {
@@ -1237,9 +1346,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     XNode planX = {};           /* record of the child the first new lane of this thread stands on ... */
     int planOrph = -1;          /* ... and the slot of the orphan table that lists the lanes it adopts */
     int planSlot = -1;
-    uint32_t rootSid[NG];
+    uint32_t rootSid[NW];
     bool wroteCtx = false; /* a new LM state's context is on its way to HBM */
-    int rootOrph[NG];
+    int rootOrph[NW];
     bool surv = false;
     uint32_t hNB = kNoHyp, hB = kNoHyp;
     unsigned long long balS = 0ull;
@@ -1251,11 +1360,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       myNew[j] = 0;
     }
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = 0; g < NW; ++g) {
       rootSid[g] = 0u;
       rootOrph[g] = -1;
     }
-    uint32_t planLm = 0u, planPar = 0u;
+    uint32_t planLm = 0u, planPar = 0u, planExtra = 0u;
     int32_t planWord = -1;
     /* (reads nothing of the lanes: a slot whose lane drops out this frame is taken again in the same build) */
     auto planChild = [&](int j) {
@@ -1270,6 +1379,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       }
       planSlot = j;
       planX = xnode[cn];
+      planExtra = (ML && P.xextra) ? P.xextra[cn] : 0u;
       planWord = ngram ? P.xlmword[cn] : -1;
       planOrph = ylOrphFind(S.orph[p], xlKey(planLm, (int32_t)cn));
       return cn;
@@ -1302,7 +1412,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
          * groups side by side, one per thread. */
         int nr = 0;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+        for (int g = 0; g < NW; ++g) {
           const bool want = ((pend >> g) & 1u) != 0u;
           const unsigned long long bal = waveBallot(want);
           if (want) {
@@ -1314,9 +1424,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           waveSync();
           for (int i0 = 0; i0 < nr; i0 += 64) {
             if (i0 + lane < nr) {
-              const int x = (int)S.nrList[i0 + lane];
+              const int ar = (int)S.nrList[i0 + lane]; /* the arrival: slot * 64 + thread */
+              const bool further = ML && ar >= NG * 64; /* a further word of its lane's spelling */
+              const int x = further ? (int)(S.xEmit[ar - NG * 64] & 0xFFu) : ar;
               const uint32_t xlm = L.lmSid[x];
-              const int32_t el = L.endLabel[x];
+              const int32_t el = further ? S.xLabel[ar - NG * 64] : L.endLabel[x];
               const unsigned long long mkey = ((unsigned long long)(xlm + 1u) << 24) | (unsigned long long)(uint32_t)(el + 1);
               uint32_t h = xlHash(mkey) & memoMask;
               uint32_t sid = 0u;
@@ -1336,10 +1448,18 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
                     } else if (ngram) { /* its n-gram context: kept with the lane since the look-up */
                       const int Lc = P.lmOrder - 1;
                       int32_t* dst = P.stateCtx + ((size_t)b * P.stateCap + sid) * Lc;
+                      int32_t fctx[kMaxNgramOrder];
+                      if (further) { /* (a further word's was not kept: asked again, for the state's sake this time) */
+#pragma unroll
+                        for (int k = 0; k < kMaxNgramOrder; ++k) {
+                          fctx[k] = 0;
+                        }
+                        (void)ylNgram(P, b, xlm, ylLmWord(P, el), fctx);
+                      }
 #pragma unroll
                       for (int k = 0; k < kMaxNgramOrder - 1; ++k) {
                         if (k < Lc) {
-                          dst[k] = L.endCtx[k][x];
+                          dst[k] = further ? fctx[k] : L.endCtx[k][x];
                         }
                       }
                       wroteCtx = true;
@@ -1357,13 +1477,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
                   break;
                 }
               }
-              S.nrSid[x] = sid;
-              S.nrOrph[x] = (int16_t)ylOrphFind(S.orph[p], xlKey(sid, 0));
+              S.nrSid[ar] = sid;
+              S.nrOrph[ar] = (int16_t)ylOrphFind(S.orph[p], xlKey(sid, 0));
             }
           }
           waveSync();
 #pragma unroll
-          for (int g = 0; g < NG; ++g) {
+          for (int g = 0; g < NW; ++g) {
             if ((pend >> g) & 1u) {
               rootSid[g] = S.nrSid[g * 64 + lane];
               rootOrph[g] = (int)S.nrOrph[g * 64 + lane];
@@ -1479,6 +1599,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       L.parent[nl] = planPar;
       L.firstChild[nl] = cx.firstChild;
       L.endLabel[nl] = cx.endLabel0;
+      if constexpr (ML) {
+        L.endExtra[nl] = planExtra;
+      }
       L.dPar[nl] = 0u;
       L.dWord[nl] = -1;
       L.maxScore[nl] = cx.maxScore;
@@ -1635,7 +1758,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     } else if (isWord) {
       const int offW = (int)S.off[nTok];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
+      for (int g = 0; g < NW; ++g) {
         const int x = g * 64 + lane;
         if ((pend >> g) & 1u) { /* a word ended and nobody stood on that root: a new root lane */
           const int idx = offW + myNew[g];
@@ -1659,6 +1782,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           L.parent[nl] = 0u;
           L.firstChild[nl] = r0.firstChild;
           L.endLabel[nl] = r0.endLabel0;
+          if constexpr (ML) {
+            L.endExtra[nl] = S.rootExtra;
+          }
           L.dPar[nl] = xlm;
           L.dWord[nl] = el;
           L.maxScore[nl] = r0.maxScore;

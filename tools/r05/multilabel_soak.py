@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Random lexicon-decoder configurations over lexicons whose spellings carry one, two or three words (helpers.lexicon
+mode "multi"), with a synthetic n-gram word LM, on the device against the oracle: beams across the one / two / four
+lane-group geometries of fltx_ylane.h (LMK bit 2), CTC and ASG.  Prints one summary JSON line.
+Test infrastructure: the oracle is the checker."""
+import json, os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import cases, helpers
+from oracle import orclib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+sess = helpers.FltxSession(os.environ.get("EMU_LIB") or None)
+orc = orclib.load("oracle")
+rnd = random.Random(int(os.environ.get("SEED", "20260930")))
+stats = {"configs": 0, "mismatches": 0, "on_lane_engine": 0, "redone": 0, "by_groups": {}, "fallback_reasons": {}, "cut_ties": 0}
+t0 = time.time()
+bad = []
+for i in range(n):
+    asg = rnd.random() < 0.4
+    big = rnd.random() < 0.5
+    lexi = (cases.MULTI_NODUP_LEX_3K if big else cases.MULTI_NODUP_LEX) if asg else (cases.MULTI_LEX_3K if big else cases.MULTI_LEX)
+    K = rnd.choice([3, 10, 24, 50, 64, 65, 100, 128, 129, 180, 256])
+    c = cases.case("mls%d" % i, kind="lexicon", dist=rnd.choice(["lexspell", "lexspell", "uniform"]), T=rnd.choice([1, 7, 40, 80, 150]),
+                   K=K, Kt=rnd.choice([29, 29, 10, 5]), thr=rnd.choice([25.0, 25.0, 8.0, 100.0]), lexicon=lexi, u=1000 + i,
+                   crit="asg" if asg else "ctc", trans_seed=(50 + i % 7) if asg else None,
+                   lm=("ngram", rnd.choice([2, 3, 4]), 60 + i % 5), lm_weight=rnd.choice([0.5, 1.3, 2.0]),
+                   word_score=rnd.choice([0.0, 0.7, 2.0]), sil_score=rnd.choice([0.0, -0.5, -1.0]))
+    inp = helpers.case_inputs(c)
+    d = sess.decoder(c, inp)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    got = d.results(0)
+    eng, grp, red, fb = d.get("engine"), d.get("lane_groups"), d.get("redone"), d.get("fallback_reasons")
+    d.close()
+    want = helpers.run_checker(orc, c, inp)
+    ok, why = helpers.hyps_equal(want, got)
+    if not ok and len(want) == c["K"]:  # a full beam: equal scores at the cut?  give the checker one more slot
+        c2 = dict(c); c2["K"] = c["K"] + 1
+        w2 = helpers.run_checker(orc, c2, inp)
+        if len(w2) > c["K"] and w2[c["K"]].score == w2[c["K"] - 1].score:
+            stats["cut_ties"] += 1
+            ok = True
+    stats["configs"] += 1
+    stats["on_lane_engine"] += int(eng == 6)
+    stats["redone"] += int(red)
+    stats["by_groups"][str(grp)] = stats["by_groups"].get(str(grp), 0) + 1
+    if fb:
+        stats["fallback_reasons"][str(fb)] = stats["fallback_reasons"].get(str(fb), 0) + 1
+    if not ok:
+        stats["mismatches"] += 1
+        bad.append({"i": i, "K": K, "T": c["T"], "crit": c["crit"], "lex": list(lexi), "engine": eng, "groups": grp, "redone": red, "why": why})
+        print("MISMATCH", bad[-1], flush=True)
+stats["seconds"] = round(time.time() - t0, 1)
+stats["bad"] = bad[:10]
+print(json.dumps(stats))
