@@ -316,7 +316,7 @@ FLTX_API int fltx_group_synchronize(fltx_group* group);
  * LexiconDecoder.cpp:32-229 under these assumptions; everything else runs on the lean / generic engines) */
 enum {
   FLTX_WHY_TOKENS = 1,        /* more than 64 tokens (lexicon-free decoder: a token BEAM of more than 64, or more than 16 384 tokens) */
-  FLTX_WHY_BEAM = 2,          /* beam beyond the lane groups (lexicon-free: 512, lexicon: 256) */
+  FLTX_WHY_BEAM = 2,          /* beam beyond the lane groups (lexicon-free: 512, lexicon: 256; 128 when spellings carry several words) */
   FLTX_WHY_STREAM = 4,        /* a stream the lane engines do not serve (lexicon streams, logAdd streams) */
   FLTX_WHY_LM = 8,            /* LM kind (token-level LM; n-gram LM on the lexicon-free decoder; a host LM, fltx_lm_host_create) */
   FLTX_WHY_LOGADD = 16,       /* lexicon decoder with logAdd; lexicon-free decoder with logAdd over more than 64 tokens */

@@ -16,7 +16,7 @@ import helpers
 ML_SMALL = ["ml_word_t60_k16", "ml_word_uni_t50_k48", "ml_word_asg_t40_k24"]
 ML_ALL = ML_SMALL + ["ml_word_t80_k100", "ml_word_asg_t80_k200"]
 GROUPS = {"ml_word_t60_k16": 1, "ml_word_uni_t50_k48": 1, "ml_word_asg_t40_k24": 1, "ml_word_t80_k100": 2,
-          "ml_word_asg_t80_k200": 4}
+          "ml_word_asg_t80_k200": 0}  # (beams beyond 128 with such a lexicon: the generic engine, FLTX_WHY_BEAM)
 
 
 def _run(sess, c, inp=None, sets=None):
@@ -33,11 +33,17 @@ def _run(sess, c, inp=None, sets=None):
 
 
 def _golden_on_the_lane_engine(sess, golden, name):
+    from text_amd import _capi
     c = cases.BY_NAME[name]
     got, info = _run(sess, c)
-    assert info["engine"] == 6 and info["groups"] == GROUPS[name] and info["redone"] == 0, info
+    if GROUPS[name]:
+        assert info["engine"] == 6 and info["groups"] == GROUPS[name] and info["redone"] == 0, info
+    else:
+        assert info["engine"] != 6 and info["why"] & _capi.FLTX_WHY_BEAM, info
     ok, why = helpers.check_against_golden(got, golden[name])
     assert ok, why
+    if not GROUPS[name]:
+        return
     # ... and the generic engine, which loops over the labels as the reference does
     gen, info = _run(sess, c, sets={"ylane": 0})
     assert info["engine"] != 6
@@ -124,7 +130,8 @@ def _decodertest_inputs(tmp_path):
 @pytest.mark.gpu
 def test_reference_test_lexicon_at_the_lane_beams(gpu_session, oracle_lib, tmp_path):
     """DecoderTest.cpp:57-195's inputs (26k-word lexicon, 164 spellings with two words and 5 with three; 3-gram ARPA;
-    ASG) at beams of one, two and four lane groups: every utterance stays on fltx_ylane.h, and the n-best is the
+    ASG) at beams of one and two lane groups: every utterance stays on fltx_ylane.h (beam 256: the generic engine --
+    the word wave of the four-group geometry has no registers for the further words), and the n-best is the
     oracle's -- up to the choice among words of one spelling whose LM scores are equal (unseen words share the
     <unk> probability), which the reference leaves to the order its sort happens to produce (oracle and compiled
     reference differ from each other there)."""
@@ -150,14 +157,15 @@ def test_reference_test_lexicon_at_the_lane_beams(gpu_session, oracle_lib, tmp_p
         a = np.array(sp, dtype=np.int32)
         oracle_lib.trie_insert(ctrie, orclib._ip(a), len(sp), wi, cache[wi])
     oracle_lib.trie_smear(ctrie, 1)
-    for K, groups in ((50, 1), (128, 2), (256, 4)):
+    for K, groups in ((50, 1), (128, 2), (256, 0)):
         for crit, trv, blank in (("asg", tr, -1), ("ctc", None, N - 1)):
             opt = _capi.make_options(K, 25000, 100.0, 2.0, 2.0, -float("inf"), -1.0, False, crit)
             dec = _capi.BatchDecoder(sess.ctx, _capi.LEXICON, opt, lm, lex["sil"], blank, unk=lex["unk"], trie=trie,
                                      transitions=trv, is_lm_token=False)
             B = 3
             dec.decode_batch(np.tile(em, B), np.full(B, T, dtype=np.int32), N)
-            assert dec.get("engine") == 6 and dec.get("lane_groups") == groups and dec.get("redone") == 0, \
+            assert (dec.get("engine") == 6 and dec.get("lane_groups") == groups and dec.get("redone") == 0) if groups else \
+                dec.get("engine") != 6, \
                 (K, crit, dec.get("engine"), dec.get("lane_groups"), dec.get("redone"), dec.get("fallback_reasons"))
             copt = orclib.make_options(K, 25000, 100.0, 2.0, 2.0, -float("inf"), -1.0, False, crit)
             cdec = oracle_lib.lexicon(copt, ctrie, clm, lex["sil"], blank, lex["unk"], trv, False)
@@ -181,7 +189,7 @@ def test_random_configurations_over_lexicons_with_homophones(gpu_session, oracle
     generator longer).  Equal-score hypotheses that differ in which word of a spelling they hold are the one accepted
     difference: two orders of the same two words in one history tie once the n-gram context forgets them."""
     rnd = random.Random(77)
-    lane = 0
+    lane = small = 0
     for i in range(300):
         asg = rnd.random() < 0.4
         big = rnd.random() < 0.5
@@ -196,6 +204,8 @@ def test_random_configurations_over_lexicons_with_homophones(gpu_session, oracle
         inp = helpers.case_inputs(c)
         got, info = _run(gpu_session, c, inp)
         lane += int(info["engine"] == 6 and info["redone"] == 0)
+        small += int(c["K"] <= 128)
+        assert (info["engine"] == 6) == (c["K"] <= 128), (i, info)
         want = helpers.run_checker(oracle_lib, c, inp)
         ok, why = helpers.hyps_equal(want, got)
         if not ok:
@@ -205,4 +215,4 @@ def test_random_configurations_over_lexicons_with_homophones(gpu_session, oracle
             for a, g in zip(want, got):
                 assert a.score == g.score and list(a.tokens) == list(g.tokens), (i, why)
                 assert all(x == y or (x >= 0 and y >= 0 and sp(int(x)) == sp(int(y))) for x, y in zip(a.words, g.words)), (i, why)
-    assert lane >= 290, lane
+    assert lane >= small - 5, (lane, small)

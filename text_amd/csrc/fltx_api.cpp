@@ -1793,8 +1793,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if (d->kind == FLTX_DECODER_LEXICON && !d->noYlane && !d->genericAsked && (!d->xlane || d->preferYlane) &&
       d->offlineCall && !d->keepScores && !d->opt.log_add && !forceWorstCaseCap && !d->forceGlobalWs &&
       (d->lm->kind == 0 || d->lm->kind == 1) && !d->isLmToken && d->trie && d->trie->xOk &&
-      /* (several words per spelling: with an n-gram LM only -- under ZeroLM the words of a spelling tie in one LM state) */
-      (!d->trie->xMulti || d->lm->kind == 1) && d->trie->xEndTok == d->sil &&
+      /* (several words per spelling: with an n-gram LM only -- under ZeroLM the words of a spelling tie in one LM state; one
+       * and two lane groups only -- with four, the word wave's twelve candidate slots need twice the 128 registers a
+       * 1 024-thread workgroup leaves a wave, and the spills made it 2.3 x slower than the generic engine on the
+       * reference's test lexicon at beam 256) */
+      (!d->trie->xMulti || (d->lm->kind == 1 && K <= 128 && d->userYlaneGroups <= 2)) && d->trie->xEndTok == d->sil &&
       (d->opt.criterion == FLTX_CRITERION_CTC ? (d->sil != d->blank && d->blank >= 0 && d->blank < N)
                                                : (d->nTrans == N * N && !d->noYlaneAsg)) &&
       !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) && K <= 256 && N <= 64 &&
@@ -1859,7 +1862,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       const bool unkOn = d->opt.unk_score > -std::numeric_limits<double>::infinity();
       const int nListAll = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
       why |= (N > 64 && (lexi || N > kWlMaxN || nTok > 64)) ? FLTX_WHY_TOKENS : 0; /* (lexicon-free: the token BEAM has to fit, fltx_wlane.h) */
-      why |= (lexi ? K > 256 : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
+      why |= (lexi ? K > ((d->trie && d->trie->xMulti) ? 128 : 256) : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
       why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
       why |= (lexi && d->opt.log_add) ? FLTX_WHY_LOGADD : 0;
@@ -2073,10 +2076,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const size_t pscorePart = (size_t)(d->ylane == 2 ? 4 : 5) * 512 * sizeof(float);
     if (d->ylaneLm & 4) { /* several words per spelling: a larger merge table and the further words' lists (one workgroup per CU) */
       using YlaneLdsMl = YlaneLdsT<2, true>;
-      using YlaneLdsMl4 = YlaneLdsT<4, true>;
-      static_assert(offsetof(YlaneLdsMl, pscore) + 5 * 512 * sizeof(float) <= 160 * 1024 && offsetof(YlaneLdsMl4, memo) <= 160 * 1024,
-                    "one CU's LDS");
-      d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsMl4, memo) : offsetof(YlaneLdsMl, pscore) + pscorePart; /* (memo in HBM) */
+      static_assert(offsetof(YlaneLdsMl, pscore) + 5 * 512 * sizeof(float) <= 160 * 1024, "one CU's LDS");
+      d->wsBytes = offsetof(YlaneLdsMl, pscore) + pscorePart; /* (memo in HBM; one and two lane groups only) */
     } else {
       d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsT<4>, memo)
                                  : (d->yshare ? offsetof(YlaneLds, pscore) + pscorePart : sizeof(YlaneLds));
@@ -2465,8 +2466,6 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       case 117: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 7, 1); break;
       case 125: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 5, 1); break;
       case 127: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 7, 1); break;
-      case 145: FLTX_LAUNCH_YLANE4(5); break;
-      case 147: FLTX_LAUNCH_YLANE4(7); break;
       default: return fail(FLTX_ERR_INVALID, "no fltx_ylane.h kernel for %d lane groups", d->ylane);
     }
 #undef FLTX_LAUNCH_YLANE

@@ -79,9 +79,10 @@ __global__ void __launch_bounds__(W, HM ? 4 : 1) fltx_decode_kernel_xlane(Decode
 }
 /* ... with a word LM and / or a smeared trie, beams up to 128 (fltx_ylane.h) */
 /* HM = 1: the geometry that shares a CU (LM-state memo in HBM, 77 KB of LDS, at most 128 VGPRs: four
- * waves per SIMD = two workgroups of 512 threads) */
+ * waves per SIMD = two workgroups of 512 threads).  LMK bit 2 (several words per spelling): the larger merge table leaves
+ * room for one workgroup per CU, which may then take all the registers its waves can address */
 template <int W, int NG, int R, int LMK, int HM, bool PROF>
-__global__ void __launch_bounds__(W, HM ? 4 : 1) fltx_decode_kernel_ylane(DecodeParams P) {
+__global__ void __launch_bounds__(W, (HM && !(LMK & 4)) ? 4 : 1) fltx_decode_kernel_ylane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   ylaneUtterance<NG, R, LMK, HM, PROF>(P, fltx_smem);
 }

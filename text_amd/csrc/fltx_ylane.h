@@ -62,7 +62,7 @@ struct YlLanesT { /* in place: slot = lane for as long as the lane lives */
   int32_t endWord[kYlLanes];     /* LM word id of endLabel (n-gram LM) */
   uint32_t endLm[kYlLanes];      /* float bits: lm.score(LM state, endLabel), kYlNoLm = not looked up */
   int32_t endCtx[kMaxNgramOrder - 1][kYlLanes]; /* ... and the n-gram context of the LM state that word leads to */
-  uint32_t endExtra[ML ? kYlLanes : 1]; /* (LMK bit 2) several words per spelling (Trie.h:19: up to 6): place of the first in trieLabels << 3 | words */
+  uint32_t endExtra[ML ? kYlLanes : 4]; /* (LMK bit 2; without it 16 bytes: the arrays behind keep their 16-byte alignment) several words per spelling (Trie.h:19: up to 6): place of the first in trieLabels << 3 | words */
 };
 
 template <int kYlRoot>
@@ -86,9 +86,9 @@ template <int LG, bool ML = false> /* ML: several words per spelling (LMK bit 2)
 struct YlaneLdsT {
   static constexpr int kYlLanes = 64 * LG;
   static constexpr int kYlX = ML ? kYlExtraPerGroup * LG : 0; /* further words of the frame's lanes */
-  /* slots of the per-frame (LM state, word) merge table: twice the lanes; with further words, the lanes plus the
-   * further words and half as much again (768 with four groups: not a power of two, ylRootFind wraps by comparison) */
-  static constexpr int kYlRoot = ML ? (LG == 4 ? 768 : 512) : 128 * LG;
+  /* slots of the per-frame (LM state, word) merge table: twice the lanes; with further words (one and two lane groups
+   * only), the lanes plus the further words and a third as much again */
+  static constexpr int kYlRoot = ML ? 512 : 128 * LG;
   static constexpr int kYlOrph = 128 * LG;  /* slots of the per-frame table of lanes without a parent lane */
   static constexpr int kYlTokWaves = LG <= 2 ? 8 : 10;
   static constexpr int kYlPairs = LG <= 2 ? fltx::kYlPairs : fltx::kYlPairs4;
@@ -123,7 +123,7 @@ struct YlaneLdsT {
    * word wave, with the word (its n-gram score is asked every frame: nothing is kept with the lane) */
   uint16_t xEmit[ML ? kYlX : 4];
   int32_t xLabel[ML ? kYlX : 2];
-  uint32_t rootExtra, nExtra;
+  uint32_t rootExtra, padX[3]; /* (these three members: a multiple of 16 bytes with and without ML, see endExtra) */
   uint16_t cand[kYlTokWaves][kYlPairs]; /* (lane | list position << 8) pairs of a token wave */
   uint32_t whist[kYlTokWaves][kSlNB];   /* a wave with more pairs than its rounds take ranks them: counts per bin */
   unsigned long long lb[2];          /* a candidate the frame is known to have (stay / blank of a surviving lane): best >= this */
@@ -152,14 +152,14 @@ enum { YL_FLAG = 15, YL_NICE = 14, YL_WHYCODE = 13 };
 template <typename LDS>
 FLTX_DEV int ylRootFind(LDS& S, unsigned long long key) {
   constexpr int kYlRoot = LDS::kYlRoot;
-  constexpr bool pow2 = (kYlRoot & (kYlRoot - 1)) == 0;
-  uint32_t h = pow2 ? (xlHash(key) & (uint32_t)(kYlRoot - 1)) : (xlHash(key) % (uint32_t)kYlRoot);
+  static_assert((kYlRoot & (kYlRoot - 1)) == 0, "a power of two");
+  uint32_t h = xlHash(key) & (kYlRoot - 1);
   for (int probe = 0; probe < kYlRoot; ++probe) {
     const unsigned long long old = atomCas64(&S.root.key[h], 0ull, key);
     if (old == 0ull || old == key) {
       return (int)h;
     }
-    h = h + 1u == (uint32_t)kYlRoot ? 0u : h + 1u;
+    h = (h + 1u) & (kYlRoot - 1);
   }
   return -1;
 }
@@ -259,6 +259,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
    * reference's own test lexicon has 34 of 50 lanes on one three-word spelling in a frame) */
   constexpr bool ML = (LMK & 4) != 0;
   constexpr int XR = ML ? 2 * NG : 0;
+  static_assert(!ML || NG <= 2, "several words per spelling: one and two lane groups (fltx_api.cpp prepare() says why)");
   constexpr int NW = NG + XR; /* candidate slots of a word-wave thread */
   constexpr int LG = NG > 2 ? NG : 2;
   using LDS = YlaneLdsT<LG, ML>;
@@ -267,7 +268,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   static_assert(XR * 64 <= (ML ? LDS::kYlX : 0), "xEmit / xLabel / nrList hold the extra slots' arrivals");
   constexpr int PAIRS = (NG == 2 && HM) ? 2 * kYlPairs : LDS::kYlPairs; /* pairs a token wave can list */
   constexpr int NS0 = R > NG ? R : (NG > 2 ? NG : 2);
-  constexpr int NS = NS0 > NW ? NS0 : NW; /* candidate slots of a thread */
   static_assert(NG == 1 || NG == 2 || NG == 4, "one, two or four lane groups");
   static_assert(NG <= 2 || HM == 1, "four lane groups: the LM-state memo lives in HBM");
   /* History slots in the lanes' records: 8 bits (0xFF = none) up to two groups, 13 bits beyond -- the back-trace masks
@@ -393,7 +393,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       L.endExtra[0] = P.xextra ? P.xextra[0] : 0u;
       S.rootExtra = L.endExtra[0];
     }
-    S.nExtra = 0u;
     L.dPar[0] = 0x7FFFFFFFu;
     L.dWord[0] = -1;
     L.maxScore[0] = r0.maxScore;
@@ -455,6 +454,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     constexpr int p = decltype(PT)::value, q = p ^ 1;
     constexpr int role = decltype(RL)::value;
     constexpr bool isTok = role == 0, isSelf = role == 1, isWord = role == 2, isSvc = role == 3;
+    constexpr int NS = (isWord && NW > NS0) ? NW : NS0; /* candidate slots of a thread (the word wave's further words: its own count) */
     const int frameOut = t + 1;
     const int64_t hrow = hbase + (int64_t)frameOut * K;
     /* ---- phase 1a: candidates, the merge table, the frame's best --------------------------- */
@@ -1082,12 +1082,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           if constexpr (XR > 2) {
             extraRound(SlParity<2>());
             extraRound(SlParity<3>());
-          }
-          if constexpr (XR > 4) {
-            extraRound(SlParity<4>());
-            extraRound(SlParity<5>());
-            extraRound(SlParity<6>());
-            extraRound(SlParity<7>());
           }
         }
       }
