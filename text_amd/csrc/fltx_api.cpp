@@ -1814,10 +1814,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const bool longUtt = (int64_t)maxT * 5 / 2 + 64 > kYlMemo * 3 / 4;
     /* (several words per spelling: the larger merge table takes the memo's place in LDS -- memo in HBM always) */
     const bool share = (ng == 4 || d->trie->xMulti) ? true : (d->userYshare >= 0 ? d->userYshare != 0 : (B > d->ctx->numCUs || longUtt));
-    const int threads = ng == 4 ? 1024 : (ng == 1 ? 512 : (share ? 512 : 768));
+    const bool multi = d->trie->xMulti; /* (one workgroup per CU: two lane groups keep their eight token waves) */
+    const int threads = ng == 4 ? 1024 : (ng == 1 ? 512 : ((share && !multi) ? 512 : 768));
     const int nTokWaves = threads / 64 - ng - 2;
     const int tpw = (nTok + nTokWaves - 1) / nTokWaves;
-    const int pairCap = ng == 4 ? kYlPairs4 : ((ng == 2 && share) ? 1024 : 512);
+    const int pairCap = ng == 4 ? kYlPairs4 : ((ng == 2 && share && !multi) ? 1024 : 512);
     const int maxTokWaves = ng == 4 ? 10 : 8;
     if ((!d->userThreads || d->threads == threads) && tpw * nTokWaves <= 96 && tpw * 64 * ng <= pairCap &&
         nTokWaves <= maxTokWaves) {
@@ -2076,8 +2077,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const size_t pscorePart = (size_t)(d->ylane == 2 ? 4 : 5) * 512 * sizeof(float);
     if (d->ylaneLm & 4) { /* several words per spelling: a larger merge table and the further words' lists (one workgroup per CU) */
       using YlaneLdsMl = YlaneLdsT<2, true>;
-      static_assert(offsetof(YlaneLdsMl, pscore) + 5 * 512 * sizeof(float) <= 160 * 1024, "one CU's LDS");
-      d->wsBytes = offsetof(YlaneLdsMl, pscore) + pscorePart; /* (memo in HBM; one and two lane groups only) */
+      static_assert(offsetof(YlaneLdsMl, pscore) + 8 * 512 * sizeof(float) <= 160 * 1024, "one CU's LDS");
+      /* (memo in HBM; one and two lane groups only; two groups: 768 threads, eight token waves' kept scores) */
+      d->wsBytes = offsetof(YlaneLdsMl, pscore) + (d->ylane == 2 ? (size_t)8 * 512 * sizeof(float) : pscorePart);
     } else {
       d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsT<4>, memo)
                                  : (d->yshare ? offsetof(YlaneLds, pscore) + pscorePart : sizeof(YlaneLds));
@@ -2464,8 +2466,8 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       /* several words per spelling (LMK bit 2; with the LM terms) */
       case 115: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 5, 1); break;
       case 117: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 7, 1); break;
-      case 125: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 5, 1); break;
-      case 127: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 7, 1); break;
+      case 125: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 5, 1); break;
+      case 127: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 7, 1); break;
       default: return fail(FLTX_ERR_INVALID, "no fltx_ylane.h kernel for %d lane groups", d->ylane);
     }
 #undef FLTX_LAUNCH_YLANE

@@ -98,8 +98,8 @@
 #define FLTX_G23(W)                                           \
   FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 5, 1, false>)  \
   FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 7, 1, false>)  \
-  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 5, 1, false>)  \
-  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 7, 1, false>)
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 5, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 7, 1, false>)
 #define FLTX_G14(W) FLTX_YLANE_SET(true)
 /* lane = LM state decode over a token beam of a large token set (fltx_wlane.h): (threads, list positions per wave) */
 #define FLTX_G22(W)                                   \

@@ -62,6 +62,7 @@ struct YlLanesT { /* in place: slot = lane for as long as the lane lives */
   int32_t endWord[kYlLanes];     /* LM word id of endLabel (n-gram LM) */
   uint32_t endLm[kYlLanes];      /* float bits: lm.score(LM state, endLabel), kYlNoLm = not looked up */
   int32_t endCtx[kMaxNgramOrder - 1][kYlLanes]; /* ... and the n-gram context of the LM state that word leads to */
+  uint32_t endLmX[ML ? 2 * kYlLanes : 4]; /* (LMK bit 2) float bits: lm.score(LM state, second / third word of the spelling), kYlNoLm = not looked up */
   uint32_t endExtra[ML ? kYlLanes : 4]; /* (LMK bit 2; without it 16 bytes: the arrays behind keep their 16-byte alignment) several words per spelling (Trie.h:19: up to 6): place of the first in trieLabels << 3 | words */
 };
 
@@ -266,7 +267,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   LDS& S = *(LDS*)smem;
   constexpr int kYlLanes = LDS::kYlLanes, kYlRoot = LDS::kYlRoot, kYlOrph = LDS::kYlOrph;
   static_assert(XR * 64 <= (ML ? LDS::kYlX : 0), "xEmit / xLabel / nrList hold the extra slots' arrivals");
-  constexpr int PAIRS = (NG == 2 && HM) ? 2 * kYlPairs : LDS::kYlPairs; /* pairs a token wave can list */
+  constexpr int PAIRS = (NG == 2 && HM && !ML) ? 2 * kYlPairs : LDS::kYlPairs; /* pairs a token wave can list (ML: 768 threads, eight token waves) */
   constexpr int NS0 = R > NG ? R : (NG > 2 ? NG : 2);
   static_assert(NG == 1 || NG == 2 || NG == 4, "one, two or four lane groups");
   static_assert(NG <= 2 || HM == 1, "four lane groups: the LM-state memo lives in HBM");
@@ -391,6 +392,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     L.endLabel[0] = r0.endLabel0;
     if constexpr (ML) {
       L.endExtra[0] = P.xextra ? P.xextra[0] : 0u;
+      L.endLmX[0] = kYlNoLm;
+      L.endLmX[kYlLanes] = kYlNoLm;
       S.rootExtra = L.endExtra[0];
     }
     L.dPar[0] = 0x7FFFFFFFu;
@@ -1069,10 +1072,17 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             if (mine) {
               el = P.trieLabels[(int)(L.endExtra[x] >> 3) + l];
               S.xLabel[idx] = el;
-              if (ngram) {
-                int32_t out[kMaxNgramOrder];
-                lmBits = __float_as_uint(ylNgram(P, b, L.lmSid[x], ylLmWord(P, el), out));
-                ++nScored;
+              if (ngram) { /* the second and third word's score stays with the lane, as the first's does (endLm) */
+                const bool keep = l <= 2;
+                lmBits = keep ? L.endLmX[(l - 1) * kYlLanes + x] : kYlNoLm;
+                if (lmBits == kYlNoLm) {
+                  int32_t out[kMaxNgramOrder];
+                  lmBits = __float_as_uint(ylNgram(P, b, L.lmSid[x], ylLmWord(P, el), out));
+                  ++nScored;
+                  if (keep) {
+                    L.endLmX[(l - 1) * kYlLanes + x] = lmBits;
+                  }
+                }
               }
             }
             wordEnd(SlParity<NG + r>(), x, mine, el, lmBits);
@@ -1595,6 +1605,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       L.endLabel[nl] = cx.endLabel0;
       if constexpr (ML) {
         L.endExtra[nl] = planExtra;
+        L.endLmX[nl] = kYlNoLm;
+        L.endLmX[kYlLanes + nl] = kYlNoLm;
       }
       L.dPar[nl] = 0u;
       L.dWord[nl] = -1;
@@ -1778,6 +1790,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           L.endLabel[nl] = r0.endLabel0;
           if constexpr (ML) {
             L.endExtra[nl] = S.rootExtra;
+            L.endLmX[nl] = kYlNoLm;
+            L.endLmX[kYlLanes + nl] = kYlNoLm;
           }
           L.dPar[nl] = xlm;
           L.dWord[nl] = el;
