@@ -479,6 +479,40 @@ class Hyp:
         self.tokens, self.words = tokens, words
 
 
+_U8_TO_I32 = np.arange(256, dtype=np.int32)
+_U8_TO_I32[255] = -1  # (fltx_result_fetch_batch_compact: 0xFF = -1)
+
+
+class _CompactHyp(Hyp):
+    """A hypothesis of results_batch(): its token row stays the byte row the device packed until somebody reads it
+    (an n-best of 50 x 1 002 frames is read in full by few callers; widening 12.8 M bytes per batch up front cost more
+    than everything else on the way to Python objects)."""
+    __slots__ = ("_t8", "_tok")
+
+    def __init__(self, score, am, lm, t8, words):
+        self.score, self.am, self.lm, self.words = score, am, lm, words
+        self._t8, self._tok = t8, None
+
+    @property
+    def tokens(self):
+        t = self._tok
+        if t is None:
+            t = self._tok = _U8_TO_I32[self._t8]
+        return t
+
+
+class _CompactHypSmall(_CompactHyp):
+    """... over at most 128 tokens: 0xFF read as a signed byte IS -1, so widening is one astype."""
+    __slots__ = ()
+
+    @property
+    def tokens(self):
+        t = self._tok
+        if t is None:
+            t = self._tok = self._t8.view(np.int8).astype(np.int32)
+        return t
+
+
 class BatchDecoder:
     """fltx_decoder: batched LexiconFreeDecoder / LexiconDecoder on the device."""
 
@@ -637,22 +671,34 @@ class BatchDecoder:
     def results_batch(self, max_hyp=None):
         """[[Hyp]] for every utterance: Python objects over the arrays of results_arrays_compact()
         (or results_arrays() for token sets that do not fit a byte)."""
-        if self.N is not None and self.N < 255:
+        compact = self.N is not None and self.N < 255
+        if compact:
             r = self.results_arrays_compact()
             nh, ln, off, sc, wrd = r["n_hyp"], r["length"], r["offsets"], r["scores"], r["words"]
-            tok = r["tokens_u8"].astype(np.int32)  # one widening pass for the batch
-            tok[tok == 255] = -1
+            total = int(off[self.B])
+            tok = r["tokens_u8"][:total].copy()  # (the library's buffer is the next batch's too)
+            wrd = wrd[:total].copy() if wrd is not None else None
         else:
             r = self.results_arrays()
             nh, ln, off, sc, tok, wrd = r["n_hyp"], r["length"], r["offsets"], r["scores"], r["tokens"], r["words"]
+        make = (_CompactHypSmall if self.N <= 128 else _CompactHyp) if compact else Hyp
+        no_words = {}
         out = []
         for b in range(self.B):
             n = int(nh[b]) if max_hyp is None else min(int(nh[b]), max_hyp)
             L = int(ln[b])
-            tb = tok[off[b]:off[b] + n * L].reshape(n, L)
-            wb = wrd[off[b]:off[b] + n * L].reshape(n, L) if wrd is not None else None
-            out.append([Hyp(sc[b, i, 0], sc[b, i, 1], sc[b, i, 2], tb[i],
-                            wb[i] if wb is not None else np.full(L, -1, dtype=np.int32)) for i in range(n)])
+            o = int(off[b])
+            tb = tok[o:o + n * L].reshape(n, L)
+            if wrd is not None:
+                wb = wrd[o:o + n * L].reshape(n, L)
+            else:  # lexicon-free: every word slot is -1 (LexiconFreeDecoder.h:80-82) -- one read-only row per length
+                row = no_words.get(L)
+                if row is None:
+                    row = no_words[L] = np.full(L, -1, dtype=np.int32)
+                    row.flags.writeable = False
+                wb = None
+            s3 = sc[b, :n].tolist()
+            out.append([make(s3[i][0], s3[i][1], s3[i][2], tb[i], wb[i] if wb is not None else row) for i in range(n)])
         return out
 
     def best(self, b, look_back=0, capacity=1 << 16):
