@@ -17,6 +17,7 @@
 #include <sstream>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "flashlight/lib/text/decoder/LexiconDecoder.h"
@@ -196,6 +197,19 @@ int main(int argc, char** argv) {
   LexiconFreeDecoder fdec(fopt, zero, silIdx, N - 1, {});
   auto off = fdec.decode(emission.data(), T, N);
   ASSERT_EQ((int)off.size(), 20);
+  /* getBestHypothesis(lookBack) after decode() (Utils.h:229-247: an ancestor of the best final hypothesis, with the
+   * ancestor's scores): decode() runs without the per-frame score history, the first such call decodes the utterance
+   * again with it -- the n-best read afterwards is unchanged */
+  auto lbOff = fdec.getBestHypothesis(7);
+  ASSERT_EQ((int)lbOff.tokens.size(), T + 2 - 7);
+  ASSERT_TRUE(sameResult(fdec.getBestHypothesis(0), off[0]));
+  {
+    auto again = fdec.getAllFinalHypothesis();
+    ASSERT_EQ(again.size(), off.size());
+    for (size_t i = 0; i < std::min(again.size(), off.size()); ++i) {
+      ASSERT_TRUE(sameResult(again[i], off[i]));
+    }
+  }
   fdec.decodeBegin();
   int t = 0;
   for (int chunk : {1, 30, 64, 140}) {
@@ -207,6 +221,7 @@ int main(int argc, char** argv) {
   auto bestMid = fdec.getBestHypothesis();
   ASSERT_EQ((int)bestMid.tokens.size(), T + 1);
   fdec.decodeEnd();
+  ASSERT_TRUE(sameResult(fdec.getBestHypothesis(7), lbOff)); /* the streaming calls keep the history: same ancestor */
   auto str = fdec.getAllFinalHypothesis();
   ASSERT_EQ(str.size(), off.size());
   for (size_t i = 0; i < std::min(str.size(), off.size()); ++i) {
@@ -276,8 +291,29 @@ int main(int argc, char** argv) {
     auto rUsr = dUsr.decode(emission.data(), T, N);
     ASSERT_TRUE(!rDev.empty());
     ASSERT_EQ(rDev.size(), rUsr.size());
+    /* (dDev runs on the lexicon lane engine, dUsr -- a host LM -- on the generic one.  The fixture's lexicon has
+     * spellings with two and three words; where their LM scores are equal -- words the LM has not seen share <unk>'s --
+     * the hypotheses merge on a tie and which word the survivor names is left to std::sort in the reference: scores,
+     * tokens and every word outside such a spelling must agree) */
+    std::unordered_map<int, std::vector<int>> spellingOf;
+    for (const auto& e : entries) {
+      spellingOf.emplace(std::get<0>(e), std::get<2>(e));
+    }
+    auto sameUpToHomophones = [&](const DecodeResult& a, const DecodeResult& b) {
+      if (!(a.score == b.score && a.emittingModelScore == b.emittingModelScore && a.lmScore == b.lmScore &&
+            a.tokens == b.tokens && a.words.size() == b.words.size())) {
+        return false;
+      }
+      for (size_t k = 0; k < a.words.size(); ++k) {
+        if (a.words[k] != b.words[k] &&
+            (a.words[k] < 0 || b.words[k] < 0 || spellingOf[a.words[k]] != spellingOf[b.words[k]])) {
+          return false;
+        }
+      }
+      return true;
+    };
     for (size_t i = 0; i < std::min(rDev.size(), rUsr.size()); ++i) {
-      ASSERT_TRUE(sameResult(rDev[i], rUsr[i]));
+      ASSERT_TRUE(sameUpToHomophones(rDev[i], rUsr[i]));
     }
     /* a scoring user LM on the lexicon-free decoder: offline == streaming chunks; updateCache is called per frame
      * with the beam's states (Utils.h:346-354); prune() releases the states the beam no longer holds */

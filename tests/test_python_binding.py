@@ -133,6 +133,82 @@ def test_decode_batch_binding(gpu_session):
         assert [r.tokens for r in one] == [r.tokens for r in got]
 
 
+@pytest.mark.gpu
+def test_best_hypothesis_with_look_back_after_decode(gpu_session, oracle_lib):
+    """decode() runs on the lane engines, which keep no per-frame score history; get_best_hypothesis(look_back) after it
+    (Decoder.h:70, Utils.h:229-247: an ancestor of the best final hypothesis, with the ancestor's scores) decodes the
+    utterance again with the history from the library's device copy of the emissions: equal to the oracle's answer,
+    and the n-best read afterwards is the one decode() returned."""
+    from flashlight.lib.text.decoder import CriterionType, LexiconFreeDecoder, LexiconFreeDecoderOptions, ZeroLM
+    from oracle import orclib
+    from text_amd import synth
+    N, T, K = 29, 120, 12
+    e = synth.emissions("ctc", 91, T, N)
+    dec = LexiconFreeDecoder(LexiconFreeDecoderOptions(K, N, 25.0, 0.0, -0.3, False, CriterionType.CTC), ZeroLM(), 0, N - 1, [])
+    nbest = dec.decode(e.ctypes.data, T, N)
+    olm = oracle_lib.lm_zero_create()
+    od = oracle_lib.lexfree(orclib.make_options(K, N, 25.0, 0.0, 0.0, float("-inf"), -0.3, False, "ctc"), olm, 0, N - 1)
+    want = oracle_lib.decode(od, e, T, N)
+    assert [r.score for r in nbest] == [h.score for h in want]
+    for lb in (5, 0, 30):
+        got = dec.get_best_hypothesis(lb)
+        ref = oracle_lib.best(od, lb, T + 8)
+        assert (got.score, got.emittingModelScore, got.lmScore) == (ref.score, ref.am, ref.lm), lb
+        assert list(got.tokens) == [int(x) for x in ref.tokens] and len(got.tokens) == T + 2 - lb
+    again = dec.get_all_final_hypothesis()
+    assert [(r.score, r.tokens) for r in again] == [(r.score, r.tokens) for r in nbest]
+    oracle_lib.decoder_destroy(od)
+
+
+@pytest.mark.gpu
+def test_one_decoder_per_thread(gpu_session):
+    """The reference's pattern for parallel decoding -- one decoder object per thread over a shared Trie / LM
+    (Utils.h:60-62) -- through the binding: every thread's decoder runs on a stream of its own (a context per thread)
+    and decode() releases the GIL while it waits for the device; results equal the sequential ones."""
+    import threading
+    from flashlight.lib.text.decoder import (CriterionType, KenLM, LexiconDecoder, LexiconDecoderOptions, SmearingMode,
+                                             Trie)
+    from flashlight.lib.text.dictionary import Dictionary
+    from text_amd import synth
+    import cases
+    c = cases.BY_NAME["ng_word_t60_k16_4g"]
+    inp = helpers.case_inputs(c)
+    path, vocab = helpers.arpa_path(c, inp)
+    wd = Dictionary(vocab[:-1])
+    wd.add_entry("<unk>")
+    lm = KenLM(path, wd)
+    trie = Trie(c["N"], 0)
+    sf, so = inp["lex"]
+    start = lm.start(False)
+    for w in range(inp["W"]):
+        trie.insert([int(x) for x in sf[so[w]:so[w + 1]]], w, lm.score(start, w)[1])
+    trie.smear(SmearingMode.MAX)
+    opts = LexiconDecoderOptions(c["K"], c["Kt"], c["thr"], c["lm_weight"], c["word_score"], c["unk_score"], c["sil_score"],
+                                 False, CriterionType.CTC)
+    n_thr, per = 4, 6
+    embs = [[synth.emissions("lexspell", 300 + 10 * t + i, c["T"], c["N"], lexicon=inp["lex"]) for i in range(per)]
+            for t in range(n_thr)]
+    seq = LexiconDecoder(opts, trie, lm, 0, c["N"] - 1, inp["W"], [], False)
+    want = [[[(r.score, r.tokens, r.words) for r in seq.decode(e.ctypes.data, c["T"], c["N"])] for e in row] for row in embs]
+    got = [None] * n_thr
+    errs = []
+
+    def work(t):
+        try:
+            dec = LexiconDecoder(opts, trie, lm, 0, c["N"] - 1, inp["W"], [], False)  # (built in its thread: its context)
+            got[t] = [[(r.score, r.tokens, r.words) for r in dec.decode(e.ctypes.data, c["T"], c["N"])] for e in embs[t]]
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(n_thr)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    assert got == want
+
+
 def test_trie_node_tree_is_walkable():
     """TrieNode.children through get_root() / search(), as Python code over the reference's
     binding can do (_decoder.cpp:173-186): the tree is materialised from the host trie."""

@@ -86,6 +86,7 @@ class DeviceDecoder {
   void begin() {
     pendingBegin_ = true;
     open_ = false;
+    oneWithoutScores_ = false;
   }
 
   void step(const float* emissions, int T, int N) {
@@ -103,12 +104,17 @@ class DeviceDecoder {
   std::vector<DecodeResult> decodeOne(const float* emissions, int T, int N) {
     const int64_t off = 0;
     const int32_t t32 = T;
-    /* getBestHypothesis(lookBack) after decode() reports an ancestor's scores (Utils.h:236-238):
-     * the single-utterance call keeps the per-frame score history, the batched one does not */
-    check(fltx_decoder_set(h_, "keep_scores", 1));
+    /* getBestHypothesis(lookBack) after decode() reports an ancestor's scores (Utils.h:236-238), which needs the
+     * per-frame score history -- and keeping it takes the utterance off the lane engines (4.8 ms instead of 2.0 for
+     * T = 1000, beam 50).  Few callers ask: decode() runs without it, and best() decodes the utterance again WITH the
+     * history from the library's own device copy of the emissions the first time somebody does (redoWithScores) */
+    check(fltx_decoder_set(h_, "keep_scores", 0));
     chk(fltx_decode_batch(h_, emissions, 0, &off, &t32, 1, N));
     open_ = true;
     pendingBegin_ = false;
+    oneT_ = T;
+    oneN_ = N;
+    oneWithoutScores_ = true;
     return results(0);
   }
 
@@ -116,6 +122,7 @@ class DeviceDecoder {
   BatchView decodeBatchView(const float* emissions, const std::vector<int64_t>& offsets, const std::vector<int>& T,
                             int N, bool onDevice) {
     std::vector<int32_t> t32(T.begin(), T.end());
+    oneWithoutScores_ = false;
     check(fltx_decoder_set(h_, "keep_scores", 0));
     chk(fltx_decode_batch(h_, emissions, onDevice ? 1 : 0, offsets.empty() ? nullptr : offsets.data(),
                             t32.data(), (int32_t)t32.size(), N));
@@ -194,6 +201,9 @@ class DeviceDecoder {
     if (!open_) {
       return;
     }
+    if (oneWithoutScores_) {
+      redoWithScores(); /* (prune() after decode(): as before, on the utterance decoded with its score history) */
+    }
     chk(fltx_stream_prune(h_, lookBack));
   }
 
@@ -218,6 +228,9 @@ class DeviceDecoder {
   DecodeResult best(int lookBack) const {
     if (!open_) {
       return DecodeResult();
+    }
+    if (oneWithoutScores_) {
+      redoWithScores();
     }
     int32_t n = 0, len = 0;
     check(fltx_result_count(h_, 0, &n, &len));
@@ -316,7 +329,23 @@ class DeviceDecoder {
     }
     return std::max(sil_, blank_) + 1;
   }
+  /* decode() ran without the per-frame score history (decodeOne): decode the utterance again with it, from the
+   * device copy of the emissions the library still holds -- the n-best is the same, getBestHypothesis(lookBack) and the
+   * calls behind it find what they need */
+  void redoWithScores() const {
+    int64_t staged = 0;
+    check(fltx_decoder_get(h_, "staged_emissions", &staged));
+    if (!staged) {
+      throw std::runtime_error("[decoder] getBestHypothesis: the utterance's emissions are no longer on the device");
+    }
+    const int64_t off = 0;
+    const int32_t t32 = oneT_;
+    check(fltx_decoder_set(h_, "keep_scores", 1));
+    chk(fltx_decode_batch(h_, (const float*)(uintptr_t)staged, 1, &off, &t32, 1, oneN_));
+    oneWithoutScores_ = false;
+  }
   void ensureOpen(int N) {
+    oneWithoutScores_ = false;
     if (pendingBegin_ || !open_) {
       chk(fltx_stream_begin(h_, 1, N, maxFrames_));
       pendingBegin_ = false;
@@ -327,6 +356,8 @@ class DeviceDecoder {
   std::shared_ptr<Context> ctx_ = Context::get();
   fltx_decoder* h_ = nullptr;
   bool pendingBegin_ = false, open_ = false;
+  mutable bool oneWithoutScores_ = false; /* the last call was decode() and the score history has not been asked for yet */
+  int oneT_ = 0, oneN_ = 0;
   int maxFrames_ = kDefaultMaxStreamFrames;
   int sil_ = 0, blank_ = 0, nTrans_ = 0;
 };

@@ -34,14 +34,16 @@ inline void check(int rc) {
   }
 }
 
-/* one context (HIP device + stream) shared by the decoders of this process;
- * the device is the current HIP device at first use. */
+/* one context (HIP device + stream) shared by the decoders a THREAD creates; the device is the current HIP device
+ * at first use.  The reference's safe pattern is one decoder per thread over a shared read-only Trie and LM
+ * (Utils.h:60-62): with a context per thread those decoders run on streams of their own, so several utterances --
+ * one per thread -- are on the device at a time. */
 struct Context {
   fltx_ctx* h = nullptr;
   Context() { check(fltx_ctx_create(-1, nullptr, &h)); }
   ~Context() { fltx_ctx_destroy(h); }
   static std::shared_ptr<Context> get() {
-    static std::weak_ptr<Context> cached;
+    static thread_local std::weak_ptr<Context> cached;
     auto sp = cached.lock();
     if (!sp) {
       sp = std::make_shared<Context>();

@@ -7,6 +7,7 @@
  */
 #pragma once
 #include <memory>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -90,6 +91,7 @@ class FL_TEXT_API Trie {
    * the next call upload a NEW copy -- decoders created earlier keep the one they were built with
    * (each holds a reference), so a shared Trie stays valid for every decoder. */
   std::shared_ptr<const fltx_trie> deviceHandle(fltx_ctx* ctx) const {
+    std::lock_guard<std::mutex> lock(devMu_); /* (decoders of several threads may be built over one Trie) */
     if (dirty_ || !dev_ || devCtx_ != ctx) {
       fltx_trie* t = nullptr;
       detail::check(fltx_htrie_upload(h_, ctx, &t));
@@ -134,6 +136,7 @@ class FL_TEXT_API Trie {
   int maxChildren_;
   TrieNodePtr root_;
   fltx_htrie* h_ = nullptr;
+  mutable std::mutex devMu_;
   mutable std::shared_ptr<const fltx_trie> dev_;
   mutable fltx_ctx* devCtx_ = nullptr;
   mutable bool dirty_ = true;

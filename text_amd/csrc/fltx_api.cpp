@@ -1346,6 +1346,10 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->sstream;
   } else if (!strcmp(key, "compactions")) { /* streams: times the LM-state free lists were rebuilt since fltx_stream_begin */
     *value = d->compactions;
+  } else if (!strcmp(key, "staged_emissions")) { /* address of the library's own device copy of the last offline batch's emissions
+                                                     (0 when the caller's device buffer was used): valid until the next call */
+    *value = (d->haveResults && d->lastEmis && (d->lastEmis == d->emis[0].as<float>() || d->lastEmis == d->emis[1].as<float>()))
+                 ? (int64_t)(uintptr_t)d->lastEmis : 0;
   } else if (!strcmp(key, "id_cap")) {     /* streams: LM-state ids per stream (constant however long the stream runs) */
     *value = d->recycle ? d->idCap : 0;
   } else if (!strcmp(key, "hlm_asked")) { /* host LM: questions the frames listed since decodeBegin ... */

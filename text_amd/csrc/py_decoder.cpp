@@ -79,13 +79,37 @@ BatchResults makeBatchResults(py::object self, Dec& d, const detail::BatchView& 
 
 template <class Dec>
 void bindDecoderMethods(py::class_<Dec>& c) {
+  /* (the calls that wait for the device release the GIL -- the reference holds it throughout, _decoder.cpp has no
+   * gil_scoped_release; here a thread per decoder object keeps several utterances on the device at a time.  A Python
+   * LM's start / score / finish take it back inside their trampolines) */
   c.def("decode_begin", &Dec::decodeBegin)
-      .def("decode_step", [](Dec& d, uintptr_t e, int T, int N) { d.decodeStep(asPtr(e), T, N); },
+      .def("decode_step",
+           [](Dec& d, uintptr_t e, int T, int N) {
+             py::gil_scoped_release nogil;
+             d.decodeStep(asPtr(e), T, N);
+           },
            "emissions"_a, "T"_a, "N"_a)
-      .def("decode_end", &Dec::decodeEnd)
-      .def("decode", [](Dec& d, uintptr_t e, int T, int N) { return d.decode(asPtr(e), T, N); },
+      .def("decode_end",
+           [](Dec& d) {
+             py::gil_scoped_release nogil;
+             d.decodeEnd();
+           })
+      .def("decode",
+           [](Dec& d, uintptr_t e, int T, int N) {
+             std::vector<DecodeResult> r;
+             {
+               py::gil_scoped_release nogil;
+               r = d.decode(asPtr(e), T, N);
+             }
+             return r;
+           },
            "emissions"_a, "T"_a, "N"_a)
-      .def("prune", &Dec::prune, "look_back"_a = 0)
+      .def("prune",
+           [](Dec& d, int lookBack) {
+             py::gil_scoped_release nogil;
+             d.prune(lookBack);
+           },
+           "look_back"_a = 0)
       .def("get_best_hypothesis", &Dec::getBestHypothesis, "look_back"_a = 0)
       .def("get_all_final_hypothesis", &Dec::getAllFinalHypothesis)
       .def("n_hypothesis", &Dec::nHypothesis)
