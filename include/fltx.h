@@ -384,7 +384,12 @@ FLTX_API int fltx_decoder_set(fltx_decoder* dec, const char* key, int64_t value)
  * general one), "threads", "lds" (1 = workspace in LDS),
  * "hot_level" (HBM workspace: 1 = counters in LDS, 2 = candidate records too),
  * "cut" (candidates kept by the cut-off generation, 0 = off), "recompute",
- * "cap", "cap2", "items". */
+ * "cap", "cap2", "items".
+ * Round 5: "staged_emissions" (address of the library's own device copy of the last offline batch's host emissions, 0
+ * when the caller passed a device buffer; valid until the decoder's next call -- a binding can decode the same batch
+ * again from it with other settings, e.g. with "keep_scores" for Decoder::getBestHypothesis(lookBack) after decode()),
+ * "compactions" / "id_cap" (streams: times the LM-state ids were rebuilt, ids per stream), "hlm_asked" / "hlm_distinct"
+ * (host LM: questions listed / put to the callbacks), "fallback_reasons" (bit r: fltx_ylane.h's reason r, its header). */
 FLTX_API int fltx_decoder_get(fltx_decoder* dec, const char* key, int64_t* value);
 
 #ifdef __cplusplus
