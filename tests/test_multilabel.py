@@ -216,3 +216,28 @@ def test_random_configurations_over_lexicons_with_homophones(gpu_session, oracle
                 assert a.score == g.score and list(a.tokens) == list(g.tokens), (i, why)
                 assert all(x == y or (x >= 0 and y >= 0 and sp(int(x)) == sp(int(y))) for x, y in zip(a.words, g.words)), (i, why)
     assert lane >= small - 5, (lane, small)
+
+
+@pytest.mark.gpu
+def test_ragged_batch_larger_than_the_card_with_a_deferred_look(gpu_session, oracle_lib):
+    """600 utterances of 0 .. 90 frames over the homophone lexicon in one call with `defer_check` (the call returns with
+    its kernels queued): more workgroups than CUs, empty utterances among them; 60 sampled n-bests against the oracle."""
+    from text_amd import synth
+    c = dict(cases.BY_NAME["ml_word_t80_k100"])
+    inp = helpers.case_inputs(c)
+    rnd = random.Random(5)
+    B = 600
+    Ts = [rnd.choice([0, 1, 17, 40, 64, 90]) for _ in range(B)]
+    embs = [synth.emissions("lexspell", 5000 + b, T, c["N"], lexicon=inp["lex"]) for b, T in enumerate(Ts)]
+    d = gpu_session.decoder(c, inp)
+    d.set("defer_check", 1)
+    d.decode_batch(np.concatenate([e.reshape(-1) for e in embs]), Ts, c["N"])
+    assert d.get("engine") == 6 and d.get("lane_groups") == 2
+    for b in rnd.sample(range(B), 60):
+        c1 = dict(c)
+        c1["T"] = Ts[b]
+        want = helpers.run_checker(oracle_lib, c1, dict(inp, e=embs[b]))
+        ok, why = helpers.hyps_equal(want, d.results(b))
+        assert ok, (b, Ts[b], why)
+    assert d.get("redone") == 0
+    d.close()
