@@ -13,7 +13,10 @@ EXE = os.path.join(helpers.ROOT, "tests", "cpp", "decoder_test")
 
 
 def _build():
-    if os.path.exists(EXE) and os.path.getmtime(EXE) > os.path.getmtime(SRC):
+    import glob
+    deps = [SRC, os.path.join(helpers.ROOT, "include", "fltx.h")] + \
+        glob.glob(os.path.join(helpers.ROOT, "text_amd", "csrc", "flashlight", "**", "*.h"), recursive=True)
+    if os.path.exists(EXE) and os.path.getmtime(EXE) > max(os.path.getmtime(p) for p in deps):  # (the facade is header-only)
         return
     subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(helpers.ROOT, "text_amd", "csrc"),
                     "-I" + os.path.join(helpers.ROOT, "include"), SRC,

@@ -6,6 +6,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "flashlight/lib/text/decoder/Decoder.h"
@@ -147,8 +148,25 @@ class DeviceDecoder {
                                                      const std::vector<int>& T, int N, bool onDevice) {
     const BatchView v = decodeBatchView(emissions, offsets, T, N, onDevice);
     std::vector<std::vector<DecodeResult>> out(T.size());
-    for (size_t b = 0; b < T.size(); ++b) {
-      fill(out[b], (int)b, v.nHyp, v.length, v.scores, v.tokens, v.words, v.offsets);
+    /* 12 800 DecodeResult objects of two 1 002-entry vectors each for a C2 batch (100 MB of rows): filled by up to
+     * eight host threads, utterances interleaved */
+    const size_t nThreads = std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency()), T.size() / 16 + 1});
+    auto work = [&](size_t first) {
+      for (size_t b = first; b < T.size(); b += nThreads) {
+        fill(out[b], (int)b, v.nHyp, v.length, v.scores, v.tokens, v.words, v.offsets);
+      }
+    };
+    if (nThreads <= 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> pool;
+      for (size_t i = 1; i < nThreads; ++i) {
+        pool.emplace_back(work, i);
+      }
+      work(0);
+      for (auto& th : pool) {
+        th.join();
+      }
     }
     return out;
   }
