@@ -2,11 +2,13 @@
  * tests/emu/hip_emu.h -- minimal host emulation of the HIP constructs used by
  * text_amd/csrc/fltx_kernels.h, for debugging kernel LOGIC without a GPU.
  *
- * TEST INFRASTRUCTURE ONLY.  A workgroup runs as W host threads with real
- * barriers; wave collectives exchange through a per-wave scratch.  It is slow
- * (milliseconds per frame) and is only ever built into tests/emu/libfltx_emu.so
- * by tests/emu/build.sh; the product library (text_amd/lib/libfltx.so) has no
- * CPU path and never loads this.
+ * TEST INFRASTRUCTURE ONLY.  A workgroup runs as one host thread per WAVE; the 64 lanes of a wave are
+ * cooperative fibers on that thread (their own stacks, a register-only switch): a wave collective is a
+ * round of switches, __syncthreads a barrier between the wave threads.  (The first version ran every
+ * lane as a host thread with pthread barriers: 576 .. 1 024 threads per workgroup, most of the time in
+ * futex wake-ups.)  Wave collectives exchange through a per-wave scratch.  It is slow (a fraction of a
+ * millisecond per frame) and is only ever built into tests/emu/libfltx_emu.so by tests/emu/build.sh;
+ * the product library (text_amd/lib/libfltx.so) has no CPU path and never loads this.
  */
 #pragma once
 #include <pthread.h>
@@ -42,18 +44,42 @@ struct EmuDim {
 };
 
 struct EmuWave {
-  pthread_barrier_t bar;
   unsigned long long slot[64];
+  void* sp[64];      /* saved stack pointers of the lanes' fibers */
+  void* schedSp;     /* ... of the wave thread itself */
+  bool done[64];
+  int cur;           /* lane that runs */
+  int nDone;
+  unsigned waveGen, blockGen; /* generations of the wave / workgroup barrier this wave has passed */
+  int waveArrive, blockArrive;
+  unsigned base;     /* threadIdx.x of lane 0 */
 };
 struct EmuBlock {
-  pthread_barrier_t bar;
+  pthread_barrier_t bar; /* one participant per wave */
   std::vector<EmuWave> waves;
+  const std::function<void(char*)>* fn;
+  char* lds;
 };
 
 extern thread_local EmuDim threadIdx, blockIdx, blockDim;
 extern thread_local EmuBlock* emuBlock;
 
-static inline void __syncthreads() { pthread_barrier_wait(&emuBlock->bar); }
+/* let the next lane of this wave that has not finished run (returns when this lane's turn comes again) */
+void emuYield();
+
+static inline void __syncthreads() {
+  EmuWave& w = emuBlock->waves[threadIdx.x >> 6];
+  const unsigned g = w.blockGen;
+  if (++w.blockArrive == 64) { /* the wave's last lane: the wave thread meets the other waves */
+    pthread_barrier_wait(&emuBlock->bar);
+    w.blockArrive = 0;
+    w.blockGen = g + 1;
+  } else {
+    while (w.blockGen == g) {
+      emuYield();
+    }
+  }
+}
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline float __uint_as_float(uint32_t u) {
   float f;
@@ -123,16 +149,27 @@ FLTX_DEV void ldsBarrier() { __syncthreads(); }
 
 /* wave collectives: publish, barrier, read, barrier */
 FLTX_DEV EmuWave& emuWave() { return emuBlock->waves[threadIdx.x >> 6]; }
+FLTX_DEV void waveSync() {
+  EmuWave& w = emuWave();
+  const unsigned g = w.waveGen;
+  if (++w.waveArrive == 64) {
+    w.waveArrive = 0;
+    w.waveGen = g + 1;
+  } else {
+    while (w.waveGen == g) {
+      emuYield();
+    }
+  }
+}
 template <class F>
 FLTX_DEV auto emuExchange(unsigned long long mine, F&& f) {
   EmuWave& w = emuWave();
   w.slot[threadIdx.x & 63] = mine;
-  pthread_barrier_wait(&w.bar);
+  waveSync();
   auto r = f(w.slot);
-  pthread_barrier_wait(&w.bar);
+  waveSync();
   return r;
 }
-FLTX_DEV void waveSync() { pthread_barrier_wait(&emuWave().bar); }
 FLTX_DEV unsigned long long waveBallot(bool p) {
   return emuExchange(p ? 1ull : 0ull, [](const unsigned long long* s) {
     unsigned long long m = 0;
