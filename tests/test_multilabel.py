@@ -97,6 +97,45 @@ def test_emulated_zero_lm_stays_on_the_generic_engine(emu_session):
     _zero_lm_keeps_off(emu_session)
 
 
+def _random_configurations(sess, oracle_lib, n, seed, frames):
+    """random (beam, frames, criterion, token beam, threshold, LM order, weights) combinations over the synthetic
+    lexicons with one to three words per spelling, against the oracle (tools/r05/multilabel_soak.py runs the same
+    generator longer).  Equal-score hypotheses that differ in which word of a spelling they hold are the one accepted
+    difference: two orders of the same two words in one history tie once the n-gram context forgets them."""
+    rnd = random.Random(seed)
+    lane = small = 0
+    for i in range(n):
+        asg = rnd.random() < 0.4
+        big = rnd.random() < 0.5
+        lexi = (cases.MULTI_NODUP_LEX_3K if big else cases.MULTI_NODUP_LEX) if asg else \
+            (cases.MULTI_LEX_3K if big else cases.MULTI_LEX)
+        c = cases.case("mlr%d" % i, kind="lexicon", dist=rnd.choice(["lexspell", "lexspell", "uniform"]),
+                       T=rnd.choice(frames), K=rnd.choice([3, 10, 24, 50, 64, 65, 100, 128, 129, 180, 256]),
+                       Kt=rnd.choice([29, 29, 10, 5]), thr=rnd.choice([25.0, 25.0, 8.0, 100.0]), lexicon=lexi, u=2000 + i,
+                       crit="asg" if asg else "ctc", trans_seed=(50 + i % 7) if asg else None,
+                       lm=("ngram", rnd.choice([2, 3, 4]), 60 + i % 5), lm_weight=rnd.choice([0.5, 1.3, 2.0]),
+                       word_score=rnd.choice([0.0, 0.7, 2.0]), sil_score=rnd.choice([0.0, -0.5, -1.0]))
+        inp = helpers.case_inputs(c)
+        got, info = _run(sess, c, inp)
+        lane += int(info["engine"] == 6 and info["redone"] == 0)
+        small += int(c["K"] <= 128)
+        assert (info["engine"] == 6) == (c["K"] <= 128), (i, info)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        ok, why = helpers.hyps_equal(want, got)
+        if not ok:
+            sf, so = inp["lex"]
+            sp = lambda w: tuple(sf[so[w]:so[w + 1]])
+            assert len(want) == len(got), (i, why)
+            for a, g in zip(want, got):
+                assert a.score == g.score and list(a.tokens) == list(g.tokens), (i, why)
+                assert all(x == y or (x >= 0 and y >= 0 and sp(int(x)) == sp(int(y))) for x, y in zip(a.words, g.words)), (i, why)
+    assert lane >= small - max(2, n // 60), (lane, small)
+
+
+def test_emulated_random_configurations_over_lexicons_with_homophones(emu_session, oracle_lib):
+    _random_configurations(emu_session, oracle_lib, 60, 78, [1, 7, 24, 40])
+
+
 # ---- the product path -------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ML_ALL)
@@ -184,38 +223,7 @@ def test_reference_test_lexicon_at_the_lane_beams(gpu_session, oracle_lib, tmp_p
 
 @pytest.mark.gpu
 def test_random_configurations_over_lexicons_with_homophones(gpu_session, oracle_lib):
-    """300 random (beam, frames, criterion, token beam, threshold, LM order, weights) combinations over the synthetic
-    lexicons with one to three words per spelling, against the oracle (tools/r05/multilabel_soak.py runs the same
-    generator longer).  Equal-score hypotheses that differ in which word of a spelling they hold are the one accepted
-    difference: two orders of the same two words in one history tie once the n-gram context forgets them."""
-    rnd = random.Random(77)
-    lane = small = 0
-    for i in range(300):
-        asg = rnd.random() < 0.4
-        big = rnd.random() < 0.5
-        lexi = (cases.MULTI_NODUP_LEX_3K if big else cases.MULTI_NODUP_LEX) if asg else \
-            (cases.MULTI_LEX_3K if big else cases.MULTI_LEX)
-        c = cases.case("mlr%d" % i, kind="lexicon", dist=rnd.choice(["lexspell", "lexspell", "uniform"]),
-                       T=rnd.choice([1, 7, 40, 80, 150]), K=rnd.choice([3, 10, 24, 50, 64, 65, 100, 128, 129, 180, 256]),
-                       Kt=rnd.choice([29, 29, 10, 5]), thr=rnd.choice([25.0, 25.0, 8.0, 100.0]), lexicon=lexi, u=2000 + i,
-                       crit="asg" if asg else "ctc", trans_seed=(50 + i % 7) if asg else None,
-                       lm=("ngram", rnd.choice([2, 3, 4]), 60 + i % 5), lm_weight=rnd.choice([0.5, 1.3, 2.0]),
-                       word_score=rnd.choice([0.0, 0.7, 2.0]), sil_score=rnd.choice([0.0, -0.5, -1.0]))
-        inp = helpers.case_inputs(c)
-        got, info = _run(gpu_session, c, inp)
-        lane += int(info["engine"] == 6 and info["redone"] == 0)
-        small += int(c["K"] <= 128)
-        assert (info["engine"] == 6) == (c["K"] <= 128), (i, info)
-        want = helpers.run_checker(oracle_lib, c, inp)
-        ok, why = helpers.hyps_equal(want, got)
-        if not ok:
-            sf, so = inp["lex"]
-            sp = lambda w: tuple(sf[so[w]:so[w + 1]])
-            assert len(want) == len(got), (i, why)
-            for a, g in zip(want, got):
-                assert a.score == g.score and list(a.tokens) == list(g.tokens), (i, why)
-                assert all(x == y or (x >= 0 and y >= 0 and sp(int(x)) == sp(int(y))) for x, y in zip(a.words, g.words)), (i, why)
-    assert lane >= small - 5, (lane, small)
+    _random_configurations(gpu_session, oracle_lib, 300, 77, [1, 7, 40, 80, 150])
 
 
 @pytest.mark.gpu
