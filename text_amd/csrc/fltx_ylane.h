@@ -63,7 +63,9 @@ struct YlLanesT { /* in place: slot = lane for as long as the lane lives */
   uint32_t endLm[kYlLanes];      /* float bits: lm.score(LM state, endLabel), kYlNoLm = not looked up */
   int32_t endCtx[kMaxNgramOrder - 1][kYlLanes]; /* ... and the n-gram context of the LM state that word leads to */
   uint32_t endLmX[ML ? 2 * kYlLanes : 4]; /* (LMK bit 2) float bits: lm.score(LM state, second / third word of the spelling), kYlNoLm = not looked up */
-  uint32_t endExtra[ML ? kYlLanes : 4]; /* (LMK bit 2; without it 16 bytes: the arrays behind keep their 16-byte alignment) several words per spelling (Trie.h:19: up to 6): place of the first in trieLabels << 3 | words */
+  /* (LMK bit 2) several words per spelling (Trie.h:19: up to 6): place of the first in trieLabels << 3 | words.
+   * Without the bit these two members are 16 bytes each: the arrays behind keep their 16-byte alignment */
+  uint32_t endExtra[ML ? kYlLanes : 4];
 };
 
 template <int kYlRoot>
@@ -121,7 +123,7 @@ struct YlaneLdsT {
   int16_t nrOrph[kYlLanes + kYlX];
   uint32_t nrSid[kYlLanes + kYlX];
   /* further words of a spelling (LMK bit 2): this frame's (lane | index of the word << 8) pairs, 64 per extra slot of the
-   * word wave, with the word (its n-gram score is asked every frame: nothing is kept with the lane) */
+   * word wave, with the word (its n-gram score: YlLanesT::endLmX for the second and third word, asked each frame beyond) */
   uint16_t xEmit[ML ? kYlX : 4];
   int32_t xLabel[ML ? kYlX : 2];
   uint32_t rootExtra, padX[3]; /* (these three members: a multiple of 16 bytes with and without ML, see endExtra) */
@@ -1027,8 +1029,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         wordEndOfGroup(SlParity<3>());
       }
       if constexpr (ML) {
-        /* the further words of the spellings the frame's lanes can end (Trie.h:19: up to 6 per node): listed, one per
-         * thread, and priced like the first -- their n-gram scores asked now (rare: nothing is kept with the lane) */
+        /* the further words of the spellings the frame's lanes can end (Trie.h:19: up to 6 per node): listed, 64 per
+         * extra slot, and priced like the first */
         int nX = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
