@@ -8,7 +8,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import cases, helpers
 from oracle import orclib
 orc = orclib.load("oracle")
-s = helpers.FltxSession(None)
+s = helpers.FltxSession(os.environ.get("EMU_LIB") or None)  # (EMU_LIB=tests/emu/libfltx_emu.so: the emulated kernels, no GPU)
 bad = 0
 cs = cases.fuzz_cases(int(os.environ.get("FLTX_FUZZ_N", "400")))
 for i, c in enumerate(cs):
