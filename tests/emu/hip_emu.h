@@ -134,6 +134,19 @@ FLTX_DEV unsigned long long atomMin64(unsigned long long* p, unsigned long long 
 FLTX_DEV unsigned long long atomOr64(unsigned long long* p, unsigned long long v) {
   return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST);
 }
+FLTX_DEV void atomAddF64(double* p, double v) {
+  unsigned long long cur = __atomic_load_n((unsigned long long*)p, __ATOMIC_SEQ_CST);
+  for (;;) {
+    double d;
+    memcpy(&d, &cur, 8);
+    d += v;
+    unsigned long long nxt;
+    memcpy(&nxt, &d, 8);
+    if (__atomic_compare_exchange_n((unsigned long long*)p, &cur, nxt, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+      return;
+    }
+  }
+}
 FLTX_DEV uint32_t loadCoherent32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 FLTX_DEV void storeCoherent32(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 FLTX_DEV unsigned long long atomCas64(unsigned long long* p, unsigned long long cmp, unsigned long long val) {

@@ -317,6 +317,22 @@ def test_emulated_asg_on_the_lexicon_lane_engine(emu_session, oracle_lib, golden
     assert ran >= 40 and served == ran and not bad, (ran, served, bad[:3])
 
 
+def test_emulated_logadd_on_the_lexicon_lane_engine(emu_session, oracle_lib, golden):
+    """fltx_xlane.h with logAdd merges (LA): the committed vector, then random configurations (the emulator shares
+    the host's libm: 1e-9)."""
+    import test_gpu_batches
+    c = cases.BY_NAME["lx_spell_t60_k12_logadd"]
+    inp = helpers.case_inputs(c)
+    d = emu_session.decoder(c, inp)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    assert d.get("engine") == 5 and d.get("redone") == 0 and d.get("why_not_lane") == 0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], 1e-9)
+    d.close()
+    assert ok, why
+    on5, bad = test_gpu_batches._logadd_lexicon_grid(emu_session, oracle_lib, 200, 4, [1, 5, 20, 40, 70], 1e-9)
+    assert on5 == 200 and not bad, (on5, bad[:3])
+
+
 def test_emulated_word_piece_engine(emu_session, oracle_lib):
     """fltx_wlane.h on the emulator: a thin slice of the GPU suite's grid (tests/test_gpu_batches.py)."""
     import test_gpu_batches

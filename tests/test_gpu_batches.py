@@ -242,6 +242,39 @@ def test_edge_configurations_of_the_lexicon_lane_engine_with_lm_terms(gpu_sessio
     assert ran > 250 and served == ran and not bad, (ran, served, bad[:3])
 
 
+def _logadd_lexicon_grid(sess, oracle_lib, n, seed, frames, tol):
+    """random LexiconDecoder + ZeroLM configurations with logAdd merges on fltx_xlane.h (LA): every utterance on
+    engine 5, none handed back, n-best within `tol` of the oracle (the device's log1p / exp against the host's)"""
+    import random
+    rnd = random.Random(seed)
+    on5 = 0
+    bad = []
+    for i in range(n):
+        c = cases.case("xla%d" % i, kind="lexicon", dist=rnd.choice(["lexspell", "lexspell", "uniform"]), T=rnd.choice(frames),
+                       K=rnd.choice([1, 3, 8, 20, 40, 64]), Kt=rnd.choice([29, 29, 10, 4]), thr=rnd.choice([25.0, 8.0, 2.0, 100.0]),
+                       lexicon=cases.SMALL_LEX, u=3000 + i, log_add=True, word_score=rnd.choice([0.0, 1.5, -0.5]),
+                       sil_score=rnd.choice([0.0, -0.5]))
+        inp = helpers.case_inputs(c)
+        d = sess.decoder(c, inp)
+        if i % 3 == 2:
+            d.set("yshare", 1)  # (the geometry with the LM-state memo in HBM)
+        d.decode_batch(inp["e"], [c["T"]], c["N"])
+        got = d.results(0)
+        on5 += int(d.get("engine") == 5 and d.get("redone") == 0)
+        d.close()
+        ok, why = helpers.hyps_equal(helpers.run_checker(oracle_lib, c, inp), got, tol)
+        if not ok:
+            bad.append(({k: c[k] for k in ("dist", "T", "K", "Kt", "thr", "word_score", "sil_score")}, why))
+    return on5, bad
+
+
+@pytest.mark.gpu
+def test_logadd_on_the_lexicon_lane_engine(gpu_session, oracle_lib):
+    on5, bad = _logadd_lexicon_grid(gpu_session, oracle_lib, 600, 3, [1, 5, 20, 40, 70, 150], 1e-5)
+    assert on5 == 600 and not bad, (on5, bad[:3])
+
+
+@pytest.mark.gpu
 def test_logadd_on_the_lane_state_engine(gpu_session, oracle_lib):
     """logAdd merges on fltx_slane.h (engine 4) against the oracle @1e-5 (device libm): beams 1 .. 64,
     thresholds 2 .. inf, token beams, silScore, CTC and ASG, `ctc` and `uniform` rows."""

@@ -1766,10 +1766,10 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     }
   }
   /* lane = (LM state, trie node) decode (fltx_xlane.h): offline LexiconDecoder + ZeroLM over a lexicon
-   * without LM scores, CTC max-merge, one word per spelling, every word ending in sil, no <unk> */
+   * without LM scores, CTC, max-merge or logAdd (round 5), one word per spelling, every word ending in sil, no <unk> */
   d->xlane = 0;
   d->yshare = 0;
-  if (d->kind == FLTX_DECODER_LEXICON && !d->noXlane && !d->genericAsked && d->offlineCall && !d->keepScores && !d->opt.log_add &&
+  if (d->kind == FLTX_DECODER_LEXICON && !d->noXlane && !d->genericAsked && d->offlineCall && !d->keepScores &&
       !forceWorstCaseCap && !d->forceGlobalWs && d->lm->kind == 0 && !d->isLmToken && d->trie && d->trie->xOk &&
       !d->trie->xMulti && d->trie->xZeroSmear && d->trie->xEndTok == d->sil && d->sil != d->blank &&
       d->opt.criterion == FLTX_CRITERION_CTC && !(d->opt.unk_score > -std::numeric_limits<double>::infinity()) &&
@@ -1870,7 +1870,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (lexi ? K > ((d->trie && d->trie->xMulti) ? 128 : 256) : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
       why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
-      why |= (lexi && d->opt.log_add) ? FLTX_WHY_LOGADD : 0;
+      /* (logAdd: fltx_xlane.h has the variant -- ZeroLM over a lexicon without scores, beam <= 64; fltx_ylane.h has not) */
+      why |= (lexi && d->opt.log_add && !(d->lm->kind == 0 && d->trie && d->trie->xZeroSmear && K <= 64)) ? FLTX_WHY_LOGADD : 0;
       why |= (lexi && d->opt.criterion != FLTX_CRITERION_CTC && d->noYlaneAsg) ? FLTX_WHY_ASG : 0;
       why |= (lexi && unkOn) ? FLTX_WHY_UNK : 0;
       why |= (lexi && d->trie && (!d->trie->xOk || (d->trie->xMulti && d->lm->kind == 0))) ? FLTX_WHY_TRIE_SHAPE : 0;
@@ -2484,7 +2485,17 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XlaneLds))); \
     HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, 0, true>,           \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XlaneLds))); \
-    if (d->yshare) {                                                                             \
+    if (d->opt.log_add) { /* (logAdd merges: fltx_xlane.h LA) */                                \
+      HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_xlane<WW, GG, 0, false, true>,  \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XlaneLds))); \
+      if (d->yshare) {                                                                           \
+        hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, 1, false, true>), dim3(nGrid), dim3(WW), \
+                           d->wsBytes, d->ctx->stream, P);                                       \
+      } else {                                                                                   \
+        hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, 0, false, true>), dim3(nGrid), dim3(WW), \
+                           d->wsBytes, d->ctx->stream, P);                                       \
+      }                                                                                          \
+    } else if (d->yshare) {                                                                      \
       hipLaunchKernelGGL((fltx_decode_kernel_xlane<WW, GG, 1, false>), dim3(nGrid), dim3(WW),    \
                          d->wsBytes, d->ctx->stream, P);                                         \
     } else if (d->profile) {                                                                     \

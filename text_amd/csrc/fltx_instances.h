@@ -65,6 +65,14 @@
   FLTX_INST(fltx_decode_kernel_xlane<576, 5, HM, PROF>)        \
   FLTX_INST(fltx_decode_kernel_xlane<640, 10, HM, PROF>)
 #define FLTX_G12(W) FLTX_XLANE_SET(0, false) FLTX_XLANE_SET(0, true)
+/* ... with logAdd merges (memo in LDS / in HBM) */
+#define FLTX_XLANE_LA_SET(HM)                                        \
+  FLTX_INST(fltx_decode_kernel_xlane<512, 2, HM, false, true>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<640, 2, HM, false, true>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<512, 3, HM, false, true>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<576, 5, HM, false, true>)        \
+  FLTX_INST(fltx_decode_kernel_xlane<640, 10, HM, false, true>)
+#define FLTX_G24(W) FLTX_XLANE_LA_SET(0) FLTX_XLANE_LA_SET(1)
 #define FLTX_G17(W) FLTX_XLANE_SET(1, false) /* memo in HBM: shares a CU */
 /* ... with LM terms, two lane groups (fltx_ylane.h): (threads, groups, rounds, LM terms, memo in HBM = shares a CU) */
 #define FLTX_YLANE_SET(PROF)                                  \
@@ -134,6 +142,7 @@ FLTX_G20(0)
 FLTX_G21(0)
 FLTX_G22(0)
 FLTX_G23(0)
+FLTX_G24(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -159,7 +168,9 @@ FLTX_G23(0)
 #undef FLTX_G21
 #undef FLTX_G22
 #undef FLTX_G23
+#undef FLTX_G24
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET
+#undef FLTX_XLANE_LA_SET
 #undef FLTX_SLANE_SET

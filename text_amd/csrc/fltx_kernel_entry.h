@@ -72,10 +72,10 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_slane_stream(DecodeParam
 }
 /* lane = (LM state, trie node) decode of a whole utterance (fltx_xlane.h): lexicon + ZeroLM */
 /* HM = 1: the LM-state memo in HBM, 28 KB of LDS -- several workgroups share a CU (batches beyond the CUs) */
-template <int W, int GT, int HM, bool PROF>
+template <int W, int GT, int HM, bool PROF, bool LA = false> /* LA: logAdd merges */
 __global__ void __launch_bounds__(W, HM ? 4 : 1) fltx_decode_kernel_xlane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  xlaneUtterance<GT, HM, PROF>(P, fltx_smem);
+  xlaneUtterance<GT, HM, PROF, LA>(P, fltx_smem);
 }
 /* ... with a word LM and / or a smeared trie, beams up to 128 (fltx_ylane.h) */
 /* HM = 1: the geometry that shares a CU (LM-state memo in HBM, 77 KB of LDS, at most 128 VGPRs: four

@@ -44,6 +44,7 @@ FLTX_DEV unsigned long long atomMin64(unsigned long long* p, unsigned long long 
   return atomicMin(p, v);
 }
 FLTX_DEV unsigned long long atomOr64(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
+FLTX_DEV void atomAddF64(double* p, double v) { (void)atomicAdd(p, v); } /* (LDS: ds_add_f64) */
 FLTX_DEV unsigned long long atomCas64(unsigned long long* p, unsigned long long cmp,
                                       unsigned long long val) {
   return atomicCAS(p, cmp, val);

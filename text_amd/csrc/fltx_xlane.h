@@ -103,6 +103,9 @@ struct XlaneLds {
   unsigned long long bKey[kSlBCap];
   uint32_t bOrd[kSlBCap];
   uint32_t memoUsed, lmNext;
+  /* logAdd (LA): per slot of the merge table, the sum of exp(member - the slot's best member) over the members above
+   * the frame's threshold (Utils.h:186-193 folds a merge group into max + log1p(exp(min - max)), member by member) */
+  double rootAcc[kXlRoot];
   /* Last member: with more utterances than CUs (HM = 1) the memo lives in HBM (DecodeParams::ymemo, kXlMemoH
    * packed slots as in fltx_ylane.h) and the kernel is launched with offsetof(XlaneLds, memo) bytes of LDS --
    * 28 KB and 81 VGPRs: three workgroups of 512 threads share a CU. */
@@ -167,7 +170,10 @@ FLTX_DEV unsigned long long xlOrphGet(const XlOrphTab& tab, unsigned long long k
   } while (0)
 
 /* GT = list positions per token wave (allowed tokens <= GT * (waves - 3)) */
-template <int GT, int HM, bool PROF>
+/* LA: logAdd -- the members of a merge group that pass the frame's threshold are summed instead of maximised
+ * (Utils.h:160-165 filters, :167-198 merges): the candidates and the frame's best are found as without it, the sums
+ * are formed once the threshold is known (one more barrier for the groups that span lanes: a root's arrivals) */
+template <int GT, int HM, bool PROF, bool LA = false>
 FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
   XlaneLds& S = *(XlaneLds*)smem;
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
@@ -206,6 +212,9 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     ((uint32_t*)S.hist)[i] = 0u;
   }
   for (int i = tid; i < kXlRoot; i += W) {
+    if constexpr (LA) {
+      S.rootAcc[i] = 0.0;
+    }
     S.root.key[i] = 0ull;
     S.root.best[i] = 0ull;
     S.root.lane[i] = 0u;
@@ -507,11 +516,101 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       return;
     }
     const double thr = best - beamThreshold;
+    /* logAdd: two members of one group (either may be absent = -inf, or below the threshold) */
+    auto la2 = [&](double a, double c) {
+      const bool oa = a >= thr, oc = c >= thr;
+      if (oa && oc) {
+        return a >= c ? slLogAdd(a, c) : slLogAdd(c, a);
+      }
+      return oa ? a : (oc ? c : NEG);
+    };
+    /* ... the share of a member in its merge-table slot's sum */
+    auto laAdd = [&](int slot, double c) {
+      if (c >= thr) {
+        atomAddF64(&S.rootAcc[slot], exp(c - f64FromKey(S.root.best[slot])));
+      }
+    };
+    if constexpr (LA) {
+      if (isTok) {
+        const int silJ = silPos - wave * GT;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          if (cok[j]) {
+            double a = nb + ev[j], c = bb + ev[j];
+            if (j == silJ) {
+              a = a + silScore;
+              c = c + silScore;
+            }
+            cs[j] = la2(a, c);
+          }
+        }
+      } else if (isSelf && live) {
+        cs[0] = la2(nb + eBlank, bb + eBlank);
+        if (atRoot) { /* stay on the root: sil from either hypothesis; the words ending here join through the slot */
+          double a = nb + eSil, c = bb + eSil;
+          a = a + silScore; /* (silScore 0: the same bits) */
+          c = c + silScore;
+          if (rootSlot >= 0) {
+            laAdd(rootSlot, a);
+            laAdd(rootSlot, c);
+          }
+        }
+      } else if (isWord && cok[0]) {
+        double a = (useB ? NEG : nb) + eEnd, c = bb + eEnd;
+        if (endTok == sil) {
+          a = a + silScore;
+          c = c + silScore;
+        }
+        a = (a + P.lmWeight * 0.0) + wordScore;
+        c = (c + P.lmWeight * 0.0) + wordScore;
+        laAdd(rootSlot, a);
+        laAdd(rootSlot, c);
+      }
+      ldsBarrier(); /* A2: the slots' sums are complete */
+    }
+    bool rootFromWord = false; /* self wave: a word ending on this root lane beats its own stay */
     if (isSelf && rootSlot >= 0) { /* the root lane's stay group takes the best word ending on it */
       const unsigned long long rb = S.root.best[rootSlot];
       if (rb > f64Key(cs[1])) {
         cs[1] = f64FromKey(rb);
         parR = kSlNoHyp; /* back-pointer: read from the slot in the build */
+        rootFromWord = true;
+      }
+    }
+    (void)rootFromWord;
+    if constexpr (LA) {
+      if (isSelf && live) {
+        if (atRoot) {
+          if (rootSlot >= 0) {
+            const double mBest = f64FromKey(S.root.best[rootSlot]);
+            cs[1] = mBest >= thr ? mBest + log1p(S.rootAcc[rootSlot] - 1.0) : NEG;
+          }
+        } else { /* stay + the trie parent's extension: up to three members, folded best first */
+          const int lastP2 = (int)(parInfo & 0xFFu);
+          const uint32_t g1 = (parInfo >> 16) & 0xFFu, g2 = parInfo >> 24;
+          const bool allowLast2 = ((allow >> last) & 1ull) != 0ull;
+          double x0 = hasNB ? nb + eLast : NEG;
+          double x1 = (pl >= 0 && allowLast2 && last != lastP2 && g1 != kSlNoHyp) ? parNB + eLast : NEG;
+          double x2 = (pl >= 0 && allowLast2 && g2 != kSlNoHyp) ? parB + eLast : NEG;
+          if (silScore != 0.0 && last == sil) {
+            x0 = x0 + silScore;
+            x1 = x1 + silScore;
+            x2 = x2 + silScore;
+          }
+          /* order: best first (Utils.h:168-174 sorts a group by score) */
+          double hi = x0, mid = x1, lo = x2, tmp;
+          if (mid > hi) { tmp = hi; hi = mid; mid = tmp; }
+          if (lo > hi) { tmp = hi; hi = lo; lo = tmp; }
+          if (lo > mid) { tmp = mid; mid = lo; lo = tmp; }
+          double accv = hi >= thr ? hi : NEG;
+          if (hi >= thr && mid >= thr) {
+            accv = slLogAdd(accv, mid);
+          }
+          if (hi >= thr && lo >= thr) {
+            accv = slLogAdd(accv, lo);
+          }
+          cs[1] = accv;
+        }
       }
     }
     if (isWord) {
@@ -529,6 +628,10 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
         S.root.winWord[rootSlot] = endLabel;
       }
       cok[0] = rep && S.root.lane[rootSlot] == 0u;
+      if (LA && cok[0]) {
+        const double mBest = f64FromKey(S.root.best[rootSlot]);
+        cs[0] = mBest >= thr ? mBest + log1p(S.rootAcc[rootSlot] - 1.0) : NEG;
+      }
     }
     if (isSvc && fastRank) {
       xlRankRange<4, 10>(rs);
@@ -541,7 +644,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
       if (cok[j] && cs[j] >= thr) {
-        cbin[j] = slBin(best, cs[j], winShift, winBase);
+        cbin[j] = slBin<LA>(best, cs[j], winShift, winBase);
         if (cbin[j] < kSlFar) {
           atomAdd32(&S.hist[p][cbin[j]], 1u);
         }
@@ -678,7 +781,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
 #pragma unroll
         for (int j = 0; j < GT; ++j) {
           if (cbin[j] != kSlInvalid) {
-            cbin[j] = slBin(best, cs[j], shift, base);
+            cbin[j] = slBin<LA>(best, cs[j], shift, base);
             atomAdd32(&S.hist[p][cbin[j]], 1u);
           }
         }
@@ -910,6 +1013,9 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
       }
       ((uint4*)S.orph[q].key)[lane] = z4;
       ((uint4*)S.orph[q].lanes)[lane] = z4;
+      if constexpr (LA) {
+        ((uint4*)S.rootAcc)[lane] = z4;
+      }
     } else if (isTok) {
       /* most lanes create at most one: every round takes each lane's lowest pending position */
       bool first = true;
@@ -1054,7 +1160,12 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     const unsigned long long bk = waveMax64(cand ? f64Key(m) : 0ull);
     const double thr = f64FromKey(bk) - P.beamThreshold;
     const bool ok = cand && bk != 0ull && m >= thr;
-    const unsigned long long key = ok ? f64Key(m) : 0ull;
+    double mOut = m;
+    if (LA && ok) { /* the lane's two hypotheses finish into one group: both above the threshold -> their sum */
+      const double lo = whichB ? nb : bb;
+      mOut = lo >= thr ? slLogAdd(m, lo) : m;
+    }
+    const unsigned long long key = ok ? f64Key(mOut) : 0ull;
     int rank = 0;
     for (int i = 0; i < nState; ++i) {
       const uint32_t lo = waveReadLane32((uint32_t)key, i), hi = waveReadLane32((uint32_t)(key >> 32), i);
@@ -1065,7 +1176,7 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
     const unsigned long long okMask = waveBallot(ok);
     if (ok) {
       const size_t g = ((size_t)b * K + rank) * 3;
-      P.outScores[g + 0] = m;
+      P.outScores[g + 0] = mOut;
       P.outScores[g + 1] = 0.0; /* emitting-model score: the back-trace kernel fills it in */
       P.outScores[g + 2] = 0.0; /* ZeroLM over an unsmeared lexicon: every lmScore term is 0 */
       histPT[hbase + (int64_t)ff * K + rank] = make_int2((int)hp, sil);
