@@ -333,6 +333,21 @@ def test_emulated_logadd_on_the_lexicon_lane_engine(emu_session, oracle_lib, gol
     assert on5 == 200 and not bad, (on5, bad[:3])
 
 
+def test_emulated_logadd_on_the_lexicon_lane_engine_with_lm_terms(emu_session, oracle_lib, golden):
+    """fltx_ylane.h with logAdd merges (LMK bit 3): the committed vector, then random configurations."""
+    import test_gpu_batches
+    c = cases.BY_NAME["ng_word_logadd_t40"]
+    inp = helpers.case_inputs(c)
+    d = emu_session.decoder(c, inp)
+    d.decode_batch(inp["e"], [c["T"]], c["N"])
+    assert d.get("engine") == 6 and d.get("redone") == 0 and d.get("why_not_lane") == 0
+    ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], 1e-9)
+    d.close()
+    assert ok, why
+    on6, redone, bad = test_gpu_batches._logadd_lm_lexicon_grid(emu_session, oracle_lib, 200, 6, [1, 5, 20, 40, 70], 1e-9)
+    assert on6 == 200 and redone <= 30 and not bad, (on6, redone, bad[:3])
+
+
 def test_emulated_word_piece_engine(emu_session, oracle_lib):
     """fltx_wlane.h on the emulator: a thin slice of the GPU suite's grid (tests/test_gpu_batches.py)."""
     import test_gpu_batches

@@ -268,6 +268,44 @@ def _logadd_lexicon_grid(sess, oracle_lib, n, seed, frames, tol):
     return on5, bad
 
 
+def _logadd_lm_lexicon_grid(sess, oracle_lib, n, seed, frames, tol):
+    """... with the LM terms, on fltx_ylane.h (LMK bit 3): n-gram word LMs, label scores without an LM, ZeroLM beyond
+    beam 64; one, two and four lane groups.  An utterance whose token wave would have to rank its own pairs leaves for
+    the generic engine (that ranking orders pairs by their best member, the frame selects on the sums): counted."""
+    import random
+    rnd = random.Random(seed)
+    on6 = redone = 0
+    bad = []
+    for i in range(n):
+        kind = rnd.choice(["ngram", "ngram", "scores", "zero"])
+        K = rnd.choice([3, 10, 24, 50, 64, 65, 100, 128, 129, 200, 256]) if kind != "zero" else rnd.choice([65, 100, 128, 200, 256])
+        kw = dict(lm=("ngram", rnd.choice([2, 3, 4]), 70 + i % 5), lm_weight=rnd.choice([0.5, 1.3, 2.0])) if kind == "ngram" else \
+            (dict(label_scores=80 + i % 3, lm_weight=rnd.choice([0.7, 1.5])) if kind == "scores" else {})
+        c = cases.case("yla%d" % i, kind="lexicon", dist=rnd.choice(["lexspell", "lexspell", "uniform"]), T=rnd.choice(frames),
+                       K=K, Kt=rnd.choice([29, 29, 10, 4]), thr=rnd.choice([25.0, 8.0, 2.0, 100.0]),
+                       lexicon=rnd.choice([cases.SMALL_LEX, (3000, 77)]), u=4000 + i, log_add=True,
+                       word_score=rnd.choice([0.0, 1.5, -0.5]), sil_score=rnd.choice([0.0, -0.5]), **kw)
+        inp = helpers.case_inputs(c)
+        d = sess.decoder(c, inp)
+        if i % 3 == 2:
+            d.set("yshare", 1)
+        d.decode_batch(inp["e"], [c["T"]], c["N"])
+        got = d.results(0)
+        on6 += int(d.get("engine") == 6)
+        redone += d.get("redone")
+        d.close()
+        ok, why = helpers.hyps_equal(helpers.run_checker(oracle_lib, c, inp), got, tol)
+        if not ok:
+            bad.append((kind, {k: c[k] for k in ("dist", "T", "K", "Kt", "thr", "word_score", "sil_score", "lm_weight")}, why))
+    return on6, redone, bad
+
+
+@pytest.mark.gpu
+def test_logadd_on_the_lexicon_lane_engine_with_lm_terms(gpu_session, oracle_lib):
+    on6, redone, bad = _logadd_lm_lexicon_grid(gpu_session, oracle_lib, 600, 5, [1, 5, 20, 40, 70, 150], 1e-5)
+    assert on6 == 600 and redone <= 90 and not bad, (on6, redone, bad[:3])
+
+
 @pytest.mark.gpu
 def test_logadd_on_the_lexicon_lane_engine(gpu_session, oracle_lib):
     on5, bad = _logadd_lexicon_grid(gpu_session, oracle_lib, 600, 3, [1, 5, 20, 40, 70, 150], 1e-5)

@@ -252,7 +252,7 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     ("lx_spell_t40_k8", 6, {"xlane": 0}), ("C3_spell_u0", 0, {"xlane": 0, "ylane": 0}), ("C3_uniform_u0", 0, {"cut": 0}),
     ("lx_spell_unk", 0, {}), ("lx_asg_t40", 6, {}), ("lx_asg_t40", 0, {"ylane_asg": 0}), ("lx_asg_t40", 6, {"ylane_groups": 4}),
     ("lx_asg_t40", 6, {"yshare": 1}), ("lx_spell_t60_k12_logadd", 5, {}), ("lx_spell_t60_k12_logadd", 5, {"yshare": 1}), ("ng_word_unk_t40", 0, {}),
-    ("ng_word_logadd_t40", 0, {}), ("ng_tok_lexicon_t40", 0, {}),
+    ("ng_word_logadd_t40", 6, {}), ("ng_word_logadd_t40", 6, {"yshare": 1}), ("ng_tok_lexicon_t40", 0, {}),
     ("lx_scores_t50", 6, {}), ("ng_word_t40_k10", 6, {}), ("ng_word_t60_k16_4g", 6, {}), ("C4_spell_u0", 6, {}),
     ("C4_spell_u255", 6, {}), ("C4z_spell_u0", 6, {}), ("lx_spell_t40_k8", 6, {"ylane": 2}),
     ("lx_uni_t40_k10", 6, {"ylane": 2}), ("C3_spell_u0", 6, {"ylane": 2}), ("C3_uniform_u0", 6, {"ylane": 2}),

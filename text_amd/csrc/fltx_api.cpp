@@ -1795,7 +1795,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
    * beams up to 128 */
   d->ylane = 0;
   if (d->kind == FLTX_DECODER_LEXICON && !d->noYlane && !d->genericAsked && (!d->xlane || d->preferYlane) &&
-      d->offlineCall && !d->keepScores && !d->opt.log_add && !forceWorstCaseCap && !d->forceGlobalWs &&
+      d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs &&
+      /* (logAdd, fltx_ylane.h LMK bit 3: CTC, one word per spelling) */
+      (!d->opt.log_add || (d->opt.criterion == FLTX_CRITERION_CTC && d->trie && !d->trie->xMulti)) &&
       (d->lm->kind == 0 || d->lm->kind == 1) && !d->isLmToken && d->trie && d->trie->xOk &&
       /* (several words per spelling: with an n-gram LM only -- under ZeroLM the words of a spelling tie in one LM state; one
        * and two lane groups only -- with four, the word wave's twelve candidate slots need twice the 128 registers a
@@ -1841,7 +1843,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       d->ylaneRounds = ng == 1 ? 2 : 4;
       d->ylaneTpw = tpw;
       d->ylaneLm = ((d->lm->kind != 0 || !d->trie->xZeroSmear) ? 1 : 0) | (d->opt.criterion == FLTX_CRITERION_CTC ? 0 : 2) |
-                   (d->trie->xMulti ? 4 : 0);
+                   (d->trie->xMulti ? 4 : 0) | (d->opt.log_add ? 8 : 0);
       d->threads = threads;
       d->xlane = 0;
       if (d->lm->kind == 1 && (d->xlmwordTrie != d->trie || d->xlmwordLm != d->lm)) {
@@ -1870,8 +1872,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (lexi ? K > ((d->trie && d->trie->xMulti) ? 128 : 256) : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
       why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
-      /* (logAdd: fltx_xlane.h has the variant -- ZeroLM over a lexicon without scores, beam <= 64; fltx_ylane.h has not) */
-      why |= (lexi && d->opt.log_add && !(d->lm->kind == 0 && d->trie && d->trie->xZeroSmear && K <= 64)) ? FLTX_WHY_LOGADD : 0;
+      /* (logAdd on the lexicon lane engines: CTC, one word per spelling) */
+      why |= (lexi && d->opt.log_add && (d->opt.criterion != FLTX_CRITERION_CTC || (d->trie && d->trie->xMulti))) ? FLTX_WHY_LOGADD : 0;
       why |= (lexi && d->opt.criterion != FLTX_CRITERION_CTC && d->noYlaneAsg) ? FLTX_WHY_ASG : 0;
       why |= (lexi && unkOn) ? FLTX_WHY_UNK : 0;
       why |= (lexi && d->trie && (!d->trie->xOk || (d->trie->xMulti && d->lm->kind == 0))) ? FLTX_WHY_TRIE_SHAPE : 0;
@@ -2085,6 +2087,12 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       static_assert(offsetof(YlaneLdsMl, pscore) + 8 * 512 * sizeof(float) <= 160 * 1024, "one CU's LDS");
       /* (memo in HBM; one and two lane groups only; two groups: 768 threads, eight token waves' kept scores) */
       d->wsBytes = offsetof(YlaneLdsMl, pscore) + (d->ylane == 2 ? (size_t)8 * 512 * sizeof(float) : pscorePart);
+    } else if (d->ylaneLm & 8) { /* logAdd: the merge-table slots' sums */
+      using YlaneLdsLa = YlaneLdsT<2, false, true>;
+      using YlaneLdsLa4 = YlaneLdsT<4, false, true>;
+      static_assert(sizeof(YlaneLdsLa) <= 160 * 1024 && offsetof(YlaneLdsLa4, memo) <= 160 * 1024, "one CU's LDS");
+      d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsLa4, memo)
+                                 : (d->yshare ? offsetof(YlaneLdsLa, pscore) + pscorePart : sizeof(YlaneLdsLa));
     } else {
       d->wsBytes = d->ylane == 4 ? offsetof(YlaneLdsT<4>, memo)
                                  : (d->yshare ? offsetof(YlaneLds, pscore) + pscorePart : sizeof(YlaneLds));
@@ -2468,6 +2476,17 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
       case 123: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 3, 1); break;
       case 142: FLTX_LAUNCH_YLANE4(2); break;
       case 143: FLTX_LAUNCH_YLANE4(3); break;
+      /* logAdd merges (LMK bit 3; CTC) */
+      case 18: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 8, 0); break;
+      case 19: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 9, 0); break;
+      case 28: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 8, 0); break;
+      case 29: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 9, 0); break;
+      case 118: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 8, 1); break;
+      case 119: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 9, 1); break;
+      case 128: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 8, 1); break;
+      case 129: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 9, 1); break;
+      case 148: FLTX_LAUNCH_YLANE4(8); break;
+      case 149: FLTX_LAUNCH_YLANE4(9); break;
       /* several words per spelling (LMK bit 2; with the LM terms) */
       case 115: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 5, 1); break;
       case 117: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 7, 1); break;

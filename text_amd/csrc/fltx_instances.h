@@ -109,6 +109,18 @@
   FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 5, 1, false>)  \
   FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 7, 1, false>)
 #define FLTX_G14(W) FLTX_YLANE_SET(true)
+/* logAdd merges (LMK bit 3), CTC, with and without the LM terms: the geometries of FLTX_YLANE_SET and FLTX_G20 */
+#define FLTX_G25(W)                                            \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 8, 0, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 9, 0, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 8, 0, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 9, 0, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 8, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 9, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 8, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 9, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 8, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 9, 1, false>)
 /* lane = LM state decode over a token beam of a large token set (fltx_wlane.h): (threads, list positions per wave) */
 #define FLTX_G22(W)                                   \
   FLTX_INST(fltx_decode_kernel_wlane<576, 5>)         \
@@ -143,6 +155,7 @@ FLTX_G21(0)
 FLTX_G22(0)
 FLTX_G23(0)
 FLTX_G24(0)
+FLTX_G25(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -169,6 +182,7 @@ FLTX_G24(0)
 #undef FLTX_G22
 #undef FLTX_G23
 #undef FLTX_G24
+#undef FLTX_G25
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET

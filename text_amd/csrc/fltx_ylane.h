@@ -85,7 +85,7 @@ struct alignas(16) YlOrphTabT {
   unsigned long long lanes[LG][kYlOrph];
 };
 
-template <int LG, bool ML = false> /* ML: several words per spelling (LMK bit 2) -- room for their arrivals */
+template <int LG, bool ML = false, bool LA = false> /* ML: several words per spelling (LMK bit 2) -- room for their arrivals; LA: logAdd (bit 3) */
 struct YlaneLdsT {
   static constexpr int kYlLanes = 64 * LG;
   static constexpr int kYlX = ML ? kYlExtraPerGroup * LG : 0; /* further words of the frame's lanes */
@@ -142,6 +142,9 @@ struct YlaneLdsT {
    * counting pass is taken from that float): 512 per token wave; the shared-CU geometries are launched with the part
    * of it they use (fltx_api.cpp: ten of the sixteen KB with one lane group, eight -- four waves, the first 512 of
    * a wave's 1 024 pairs -- with two).  Four lane groups have no room for it and price a pair in every pass. */
+  /* logAdd: per slot of the merge table, the sum of exp(member - the slot's best member) over the members above the
+   * frame's threshold (as fltx_xlane.h; 16 bytes without it: pscore keeps its alignment) */
+  double rootAcc[LA ? kYlRoot : 2];
   float pscore[LG <= 2 ? kYlTokWaves * fltx::kYlPairs : 4];
   /* Last member: the shared-CU geometry (HM = 1) keeps the memo in HBM (DecodeParams::ymemo) and is
    * launched with offsetof(YlaneLds, memo) bytes of LDS -- 77 KB, so that two workgroups fit a CU and
@@ -261,11 +264,15 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
    * candidate slots per thread for the further words of the frame's lanes (short homophones fill a beam: the
    * reference's own test lexicon has 34 of 50 lanes on one three-word spelling in a frame) */
   constexpr bool ML = (LMK & 4) != 0;
+  /* bit 3 = logAdd: the members of a merge group above the frame's threshold are summed (Utils.h:160-198), as in
+   * fltx_xlane.h -- the candidates and the frame's best as without it, the sums once the threshold is known */
+  constexpr bool LA = (LMK & 8) != 0;
+  static_assert(!(LA && (ML || ASG)), "logAdd: CTC, one word per spelling");
   constexpr int XR = ML ? 2 * NG : 0;
   static_assert(!ML || NG <= 2, "several words per spelling: one and two lane groups (fltx_api.cpp prepare() says why)");
   constexpr int NW = NG + XR; /* candidate slots of a word-wave thread */
   constexpr int LG = NG > 2 ? NG : 2;
-  using LDS = YlaneLdsT<LG, ML>;
+  using LDS = YlaneLdsT<LG, ML, LA>;
   LDS& S = *(LDS*)smem;
   constexpr int kYlLanes = LDS::kYlLanes, kYlRoot = LDS::kYlRoot, kYlOrph = LDS::kYlOrph;
   static_assert(XR * 64 <= (ML ? LDS::kYlX : 0), "xEmit / xLabel / nrList hold the extra slots' arrivals");
@@ -343,6 +350,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     ((uint32_t*)S.hist)[i] = 0u;
   }
   for (int i = tid; i < kYlRoot; i += W) {
+    if constexpr (LA) {
+      S.rootAcc[i] = 0.0;
+    }
     S.root.key[i] = 0ull;
     S.root.best[i] = 0ull;
     S.root.lane[i] = 0u;
@@ -471,6 +481,11 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       aliveG[g] = S.alive[p][g];
     }
     double cs[NS], clm[NS];
+    double coth[LA ? NS : 1]; /* logAdd: a candidate's other member (the lane's other hypothesis), -inf = none */
+#pragma unroll
+    for (int j = 0; j < (LA ? NS : 1); ++j) {
+      coth[j] = NEG;
+    }
     int cbin[NS];
     bool cok[NS];
     uint32_t cinf[NS]; /* token waves: lane | token << 8 | history slot of the source << 16;  word wave: history slot << 16 */
@@ -497,6 +512,8 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
     int last = 0, pl = -1, rootSlot = -1;
     bool whichB = false;
     double lmR = 0.0; /* LM score of the winning member of the stay group */
+    /* logAdd, self waves: the members of the lane's blank and stay groups besides the best one */
+    double laBlankO = NEG, laR0 = NEG, laR0o = NEG, laR1 = NEG, laR2 = NEG;
     /* word wave, per slot (a lane group's lane, or the thread's further word) */
     int nXtra = 0; /* further words this frame (word wave) */
     int wSlot[NW];
@@ -782,6 +799,17 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           base = (int)(bLo >> ns);
           waveSync();
         }
+        if constexpr (LA) {
+          /* The ranking above orders the pairs by their best member; the frame selects on the sums, which lie at most
+           * ln 2 above it (two members).  At least K pairs of this wave have a best member within the cut, so a pair
+           * whose best member is more than ln 2 beyond it cannot be among the frame's K best either way: the cut moves
+           * out by ln 2 (and what the float keys round away); ties at the cut are not resolved here (general path). */
+          if (tieVal != 0xFFFFFFFFu) {
+            okCut = false;
+          } else if (hiCut < 0x7F000000u) {
+            hiCut = __float_as_uint(__uint_as_float(hiCut) + 0.70f);
+          }
+        }
         int kept = 0;
         for (int c0 = 0; c0 < nCand && nCand > rankAt; c0 += 64) {
           const int id = c0 + lane;
@@ -828,8 +856,10 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           const int n = (int)S.tokId[p][pos];
           const bool wb = xb > xnb;
           double c = (wb ? xb : xnb) + emScore(ev, n, infoTok(xi), t);
+          double co = (wb ? xnb : xb) + emScore(ev, n, infoTok(xi), t); /* (logAdd: the lane's other hypothesis) */
           if (pos == silPos) {
             c = c + silScore;
+            co = co + silScore;
           }
           const uint32_t hp = wb ? infoB(xi) : infoNB(xi);
           cinf[r] = (uint32_t)x | ((uint32_t)n << 9) | (hp << 16);
@@ -841,9 +871,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             const float dl = valid ? xdelta[child] : 0.0f;
             cdl[r] = dl;
             c = c + lmWeight * (double)dl; /* lmScore = lex->maxScore - lexMaxScore, LexiconDecoder.cpp:96,101 */
+            co = co + lmWeight * (double)dl;
             clm[r] = (wb ? L.lmB[x] : L.lmNB[x]) + (double)dl;
           }
           cs[r] = c;
+          if constexpr (LA) {
+            coth[r] = co;
+          }
           cok[r] = valid && c == c;
         }
       }
@@ -881,6 +915,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const double eBlank = S.eAll[p][ASG ? 0 : blank], eLast = S.eAll[p][last], eSil = S.eAll[p][sil];
       /* blank (:197-213): always tried */
       cs[0] = m + eBlank;
+      if constexpr (LA) {
+        laBlankO = (whichB ? nb : bb) + eBlank;
+      }
       clm[0] = lmM;
       cok[0] = live && !ASG;
       /* stay (:168-194) + the trie parent's extension by the node's token (a "(1) try children"
@@ -895,15 +932,23 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       double r0 = (atRoot ? m : nb) + emScore(atRoot ? eSil : eLast, atRoot ? sil : last, last, t);
       double r1 = has1 ? parNB + emScore(eLast, last, lastP, t) : NEG;
       double r2 = has2 ? parB + eLast : NEG; /* (from the blank hypothesis: CTC only) */
+      double r0o = atRoot ? (whichB ? nb : bb) + emScore(eSil, sil, last, t) : NEG; /* (logAdd: the root's other hypothesis stays too) */
       if (silScore != 0.0) {
         const bool ls = atRoot || last == sil;
         r0 = ls ? r0 + silScore : r0;
+        r0o = ls ? r0o + silScore : r0o;
         r1 = ls ? r1 + silScore : r1;
         r2 = ls ? r2 + silScore : r2;
       }
       if (LMT) {
         r1 = r1 + lmWeight * dl;
         r2 = r2 + lmWeight * dl;
+      }
+      if constexpr (LA) {
+        laR0 = has0 ? r0 : NEG;
+        laR0o = r0o;
+        laR1 = r1;
+        laR2 = r2;
       }
       double cR = r0;
       parR = atRoot ? hypM : hypNB;
@@ -998,6 +1043,13 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         }
         c = (c + lmWeight * (double)lmS) + wordScore;
         cs[g] = c;
+        if constexpr (LA) { /* the lane's other hypothesis ends the word too (not on the root after its own token, :114-122) */
+          double co = useB ? NEG : ((wb ? xnb : xb) + emScore(eEnd, endTok, xl, t));
+          if (endTok == sil) {
+            co = co + silScore;
+          }
+          coth[g] = (co + lmWeight * (double)lmS) + wordScore;
+        }
         clm[g] = srcLm + (double)lmS;
         cok[g] = can && c == c;
         cinf[g] = (useB ? xhB : (wb ? xhB : xhNB)) << 16;
@@ -1141,11 +1193,73 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       return;
     }
     const double thr = best - beamThreshold;
+    /* logAdd: two members of one group (either may be absent = -inf, or below the threshold) */
+    auto la2 = [&](double a, double c) {
+      const bool oa = a >= thr, oc = c >= thr;
+      if (oa && oc) {
+        return a >= c ? slLogAdd(a, c) : slLogAdd(c, a);
+      }
+      return oa ? a : (oc ? c : NEG);
+    };
+    /* ... the share of a member in its merge-table slot's sum */
+    auto laAdd = [&](int slot, double c) {
+      if (c >= thr) {
+        atomAddF64(&S.rootAcc[slot], exp(c - f64FromKey(S.root.best[slot])));
+      }
+    };
+    if constexpr (LA) {
+      if (isTok) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          if (j < nUsed && cok[j]) {
+            cs[j] = la2(cs[j], coth[j]);
+          }
+        }
+      } else if (isSelf && live) {
+        cs[0] = la2(cs[0], laBlankO);
+        if (atRoot && rootSlot >= 0) { /* stay on the root: sil from either hypothesis; the words ending here join through the slot */
+          laAdd(rootSlot, laR0);
+          laAdd(rootSlot, laR0o);
+        }
+      } else if (isWord) {
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+          if (cok[g] && wSlot[g] >= 0) {
+            laAdd(wSlot[g], cs[g]);
+            laAdd(wSlot[g], coth[g]);
+          }
+        }
+      }
+      ldsBarrier(); /* A2: the slots' sums are complete */
+    }
     if (isSelf && rootSlot >= 0) { /* the root lane's stay group takes the best word ending on it */
       const unsigned long long rb = S.root.best[rootSlot];
       if (rb > f64Key(cs[1])) {
         cs[1] = f64FromKey(rb);
         parR = kNoHyp; /* back-pointer and LM score: read from the slot in the build */
+      }
+    }
+    if constexpr (LA) {
+      if (isSelf && live) {
+        if (atRoot) {
+          if (rootSlot >= 0) {
+            const double mBest = f64FromKey(S.root.best[rootSlot]);
+            cs[1] = mBest >= thr ? mBest + log1p(S.rootAcc[rootSlot] - 1.0) : NEG;
+          }
+        } else { /* stay + the trie parent's extension: up to three members, folded best first (Utils.h:168-198) */
+          double hi = laR0, mid = laR1, lo = laR2, tmp;
+          if (mid > hi) { tmp = hi; hi = mid; mid = tmp; }
+          if (lo > hi) { tmp = hi; hi = lo; lo = tmp; }
+          if (lo > mid) { tmp = mid; mid = lo; lo = tmp; }
+          double accv = hi >= thr ? hi : NEG;
+          if (hi >= thr && mid >= thr) {
+            accv = slLogAdd(accv, mid);
+          }
+          if (hi >= thr && lo >= thr) {
+            accv = slLogAdd(accv, lo);
+          }
+          cs[1] = accv;
+        }
       }
     }
     if (isWord) {
@@ -1172,6 +1286,10 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
           S.root.winLm[sl] = clm[g];
         }
         cok[g] = rep && S.root.lane[sl] == 0u;
+        if (LA && cok[g]) {
+          const double mBest = f64FromKey(S.root.best[sl]);
+          cs[g] = mBest >= thr ? mBest + log1p(S.rootAcc[sl] - 1.0) : NEG;
+        }
       }
     }
     if (isSvc && fastRank) {
@@ -1188,7 +1306,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         continue;
       }
       if (cok[j] && cs[j] >= thr) {
-        cbin[j] = slBin(best, cs[j], winShift, winBase);
+        cbin[j] = slBin<LA>(best, cs[j], winShift, winBase);
         if (cbin[j] < kSlFar) {
           atomAdd32(&S.hist[p][cbin[j]], 1u);
         }
@@ -1320,7 +1438,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
             continue;
           }
           if (cbin[j] != kSlInvalid) {
-            cbin[j] = slBin(best, cs[j], shift, base);
+            cbin[j] = slBin<LA>(best, cs[j], shift, base);
             atomAdd32(&S.hist[p][cbin[j]], 1u);
           }
         }
@@ -1634,6 +1752,9 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       for (int i = 0; i < kYlRoot / 128; ++i) { /* 64-bit words: two per lane and store */
         ((uint4*)S.root.key)[lane + 64 * i] = z4;
         ((uint4*)S.root.best)[lane + 64 * i] = z4;
+        if constexpr (LA) {
+          ((uint4*)S.rootAcc)[lane + 64 * i] = z4;
+        }
       }
 #pragma unroll
       for (int i = 0; i < kYlRoot / 256; ++i) { /* 32-bit words: four */
@@ -1851,7 +1972,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   const int ff = T + 1;
   if (!dead) {
     bool liveE = false, onRoot = false;
-    double mE = NEG, lmE = 0.0;
+    double mE = NEG, lmE = 0.0, oE = NEG; /* (oE: logAdd -- the lane's other hypothesis finishes into the same group) */
     uint32_t hpE = kNoHyp, lmSidE = 0u;
     if (wave < NG) {
       const int x = wave * 64 + lane;
@@ -1860,6 +1981,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       const uint32_t xi = L.info[x];
       const bool wb = xb > xnb;
       mE = wb ? xb : xnb;
+      oE = wb ? xnb : xb;
       hpE = wb ? infoB(xi) : infoNB(xi);
       lmE = LMT ? (wb ? L.lmB[x] : L.lmNB[x]) : 0.0;
       lmSidE = L.lmSid[x];
@@ -1878,6 +2000,7 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
         const float fs = ylNgram(P, b, lmSidE, (uint32_t)P.lmEos, nullptr);
         ++nScored;
         sc = mE + lmWeight * (double)fs;
+        oE = oE + lmWeight * (double)fs;
         lmE = lmE + (double)fs;
       }
       S.endKey[x] = (cand && sc == sc) ? f64Key(sc) : 0ull;
@@ -1886,15 +2009,28 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
       S.endHyp[x] = hpE;
     }
     ldsBarrier();
+    unsigned long long bk = 0ull;
     if (wave < NG) {
-      const int x = wave * 64 + lane;
-      unsigned long long bk = 0ull;
       for (int i = 0; i < 64 * NG; ++i) {
         const unsigned long long k2 = S.endKey[i];
         bk = k2 > bk ? k2 : bk;
       }
-      /* candidatesBestScore_ is the best of the candidates that finish */
-      const double thr = f64FromKey(bk) - P.beamThreshold;
+    }
+    /* candidatesBestScore_ is the best of the candidates that finish */
+    const double thr = f64FromKey(bk) - P.beamThreshold;
+    if constexpr (LA) { /* both hypotheses of a lane above the threshold: their sum ranks and is reported */
+      const int x = (wave < NG ? wave : 0) * 64 + lane;
+      const bool okm = wave < NG && S.endKey[x] != 0ull && bk != 0ull && S.endScore[x] >= thr;
+      const double merged = (okm && oE >= thr) ? slLogAdd(S.endScore[x], oE) : S.endScore[x];
+      ldsBarrier(); /* (every lane has read the best members' keys) */
+      if (wave < NG) {
+        S.endScore[x] = merged;
+        S.endKey[x] = okm ? f64Key(merged) : 0ull;
+      }
+      ldsBarrier();
+    }
+    if (wave < NG) {
+      const int x = wave * 64 + lane;
       const unsigned long long key = S.endKey[x];
       const bool ok = key != 0ull && bk != 0ull && S.endScore[x] >= thr;
       int rank = 0, nOk = 0;
