@@ -319,9 +319,8 @@ enum {
   FLTX_WHY_BEAM = 2,          /* beam beyond the lane groups (lexicon-free: 512, lexicon: 256; 128 when spellings carry several words) */
   FLTX_WHY_STREAM = 4,        /* a stream the lane engines do not serve (lexicon streams, logAdd streams) */
   FLTX_WHY_LM = 8,            /* LM kind (token-level LM; n-gram LM on the lexicon-free decoder; a host LM, fltx_lm_host_create) */
-  FLTX_WHY_LOGADD = 16,       /* lexicon decoder with logAdd under ASG or over a lexicon with several words per spelling (round 5: CTC
-                               * lexicons with one word per spelling run logAdd on engines 5 / 6); lexicon-free decoder with logAdd over
-                               * more than 64 tokens */
+  FLTX_WHY_LOGADD = 16,       /* lexicon-free decoder with logAdd over more than 64 tokens (round 5: the lexicon lane engines, 5 / 6,
+                               * take logAdd wherever they take max-merge) */
   FLTX_WHY_ASG = 32,          /* lexicon decoder with the ASG criterion */
   FLTX_WHY_UNK = 64,          /* lexicon decoder with <unk> enabled (unk_score > -inf) */
   FLTX_WHY_TRIE_SHAPE = 128,  /* trie without a breadth-first layout (not a tree, a word that ends without the separator); several

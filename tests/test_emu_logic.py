@@ -348,6 +348,12 @@ def test_emulated_logadd_on_the_lexicon_lane_engine_with_lm_terms(emu_session, o
     assert on6 == 200 and redone <= 30 and not bad, (on6, redone, bad[:3])
 
 
+def test_emulated_logadd_under_asg_and_over_homophones(emu_session, oracle_lib):
+    import test_gpu_batches
+    st, bad = test_gpu_batches._logadd_asg_homophone_grid(emu_session, oracle_lib, 180, 12, [1, 5, 20, 40, 70], 1e-9)
+    assert not bad and all(v[1] == v[0] and v[2] <= v[0] // 8 for v in st.values()), (st, bad[:3])
+
+
 def test_emulated_word_piece_engine(emu_session, oracle_lib):
     """fltx_wlane.h on the emulator: a thin slice of the GPU suite's grid (tests/test_gpu_batches.py)."""
     import test_gpu_batches

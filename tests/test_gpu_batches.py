@@ -300,6 +300,64 @@ def _logadd_lm_lexicon_grid(sess, oracle_lib, n, seed, frames, tol):
     return on6, redone, bad
 
 
+def _logadd_asg_homophone_grid(sess, oracle_lib, n, seed, frames, tol):
+    """... under the ASG criterion, over lexicons with several words per spelling (n-gram LM, beams up to 128), and both:
+    -> {mode: [configurations, on engine 6, redone, mismatches]}.  Equal-score hypotheses that hold the words of one
+    spelling in another order are accepted (tests/test_multilabel.py says why)."""
+    import random
+    rnd = random.Random(seed)
+    st = {"asg": [0, 0, 0, 0], "ml": [0, 0, 0, 0], "mlasg": [0, 0, 0, 0]}
+    bad = []
+    for i in range(n):
+        mode = ["asg", "ml", "mlasg"][i % 3]
+        asg, ml = mode != "ml", mode != "asg"
+        if ml:
+            big = rnd.random() < 0.5
+            lexi = (cases.MULTI_NODUP_LEX_3K if big else cases.MULTI_NODUP_LEX) if asg else (cases.MULTI_LEX_3K if big else cases.MULTI_LEX)
+            K = rnd.choice([3, 10, 24, 50, 64, 65, 100, 128])
+            kw = dict(lm=("ngram", rnd.choice([2, 3, 4]), 60 + i % 5), lm_weight=rnd.choice([0.5, 1.3, 2.0]))
+        else:
+            lexi = cases.NODUP_LEX
+            K = rnd.choice([3, 10, 24, 50, 64, 65, 100, 128, 129, 200, 256])
+            kind = rnd.choice(["ngram", "scores", "zero"])
+            kw = dict(lm=("ngram", rnd.choice([2, 3, 4]), 70 + i % 5), lm_weight=rnd.choice([0.5, 1.3, 2.0])) if kind == "ngram" else \
+                (dict(label_scores=80 + i % 3, lm_weight=rnd.choice([0.7, 1.5])) if kind == "scores" else {})
+        c = cases.case("lam%d" % i, kind="lexicon", dist=rnd.choice(["lexspell", "lexspell", "uniform"]), T=rnd.choice(frames), K=K,
+                       Kt=rnd.choice([29, 29, 10, 4]), thr=rnd.choice([25.0, 8.0, 2.0, 100.0]), lexicon=lexi, u=6000 + i,
+                       log_add=True, crit="asg" if asg else "ctc", trans_seed=(50 + i % 7) if asg else None,
+                       word_score=rnd.choice([0.0, 1.5, -0.5]), sil_score=rnd.choice([0.0, -0.5]), **kw)
+        inp = helpers.case_inputs(c)
+        d = sess.decoder(c, inp)
+        if i % 2:
+            d.set("yshare", 1)
+        d.decode_batch(inp["e"], [c["T"]], c["N"])
+        got = d.results(0)
+        eng, red = d.get("engine"), d.get("redone")
+        d.close()
+        want = helpers.run_checker(oracle_lib, c, inp)
+        ok, why = helpers.hyps_equal(want, got, tol)
+        if not ok and ml and len(want) == len(got):
+            sf, so = inp["lex"]
+            sp = lambda w: tuple(sf[so[w]:so[w + 1]])
+            ok = all(abs(a.score - g.score) <= tol and list(a.tokens) == list(g.tokens) and
+                     all(x == y or (x >= 0 and y >= 0 and sp(int(x)) == sp(int(y))) for x, y in zip(a.words, g.words))
+                     for a, g in zip(want, got))
+        s = st[mode]
+        s[0] += 1
+        s[1] += int(eng == 6)
+        s[2] += red
+        s[3] += 0 if ok else 1
+        if not ok:
+            bad.append((mode, {k: c[k] for k in ("dist", "T", "K", "Kt", "thr")}, why))
+    return st, bad
+
+
+@pytest.mark.gpu
+def test_logadd_under_asg_and_over_homophones_on_the_lane_engine(gpu_session, oracle_lib):
+    st, bad = _logadd_asg_homophone_grid(gpu_session, oracle_lib, 600, 11, [1, 5, 20, 40, 70, 150], 1e-5)
+    assert not bad and all(v[1] == v[0] and v[2] <= v[0] // 10 for v in st.values()), (st, bad[:3])
+
+
 @pytest.mark.gpu
 def test_logadd_on_the_lexicon_lane_engine_with_lm_terms(gpu_session, oracle_lib):
     on6, redone, bad = _logadd_lm_lexicon_grid(gpu_session, oracle_lib, 600, 5, [1, 5, 20, 40, 70, 150], 1e-5)

@@ -1796,8 +1796,6 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   d->ylane = 0;
   if (d->kind == FLTX_DECODER_LEXICON && !d->noYlane && !d->genericAsked && (!d->xlane || d->preferYlane) &&
       d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs &&
-      /* (logAdd, fltx_ylane.h LMK bit 3: CTC, one word per spelling) */
-      (!d->opt.log_add || (d->opt.criterion == FLTX_CRITERION_CTC && d->trie && !d->trie->xMulti)) &&
       (d->lm->kind == 0 || d->lm->kind == 1) && !d->isLmToken && d->trie && d->trie->xOk &&
       /* (several words per spelling: with an n-gram LM only -- under ZeroLM the words of a spelling tie in one LM state; one
        * and two lane groups only -- with four, the word wave's twelve candidate slots need twice the 128 registers a
@@ -1873,7 +1871,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
       why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
       /* (logAdd on the lexicon lane engines: CTC, one word per spelling) */
-      why |= (lexi && d->opt.log_add && (d->opt.criterion != FLTX_CRITERION_CTC || (d->trie && d->trie->xMulti))) ? FLTX_WHY_LOGADD : 0;
+      why |= 0; /* (logAdd: every configuration the lexicon lane engines take without it, they take with it) */
       why |= (lexi && d->opt.criterion != FLTX_CRITERION_CTC && d->noYlaneAsg) ? FLTX_WHY_ASG : 0;
       why |= (lexi && unkOn) ? FLTX_WHY_UNK : 0;
       why |= (lexi && d->trie && (!d->trie->xOk || (d->trie->xMulti && d->lm->kind == 0))) ? FLTX_WHY_TRIE_SHAPE : 0;
@@ -2084,9 +2082,12 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     const size_t pscorePart = (size_t)(d->ylane == 2 ? 4 : 5) * 512 * sizeof(float);
     if (d->ylaneLm & 4) { /* several words per spelling: a larger merge table and the further words' lists (one workgroup per CU) */
       using YlaneLdsMl = YlaneLdsT<2, true>;
+      using YlaneLdsMlLa = YlaneLdsT<2, true, true>;
       static_assert(offsetof(YlaneLdsMl, pscore) + 8 * 512 * sizeof(float) <= 160 * 1024, "one CU's LDS");
       /* (memo in HBM; one and two lane groups only; two groups: 768 threads, eight token waves' kept scores) */
-      d->wsBytes = offsetof(YlaneLdsMl, pscore) + (d->ylane == 2 ? (size_t)8 * 512 * sizeof(float) : pscorePart);
+      static_assert(offsetof(YlaneLdsMlLa, pscore) + 8 * 512 * sizeof(float) <= 160 * 1024, "one CU's LDS");
+      d->wsBytes = ((d->ylaneLm & 8) ? offsetof(YlaneLdsMlLa, pscore) : offsetof(YlaneLdsMl, pscore)) +
+                   (d->ylane == 2 ? (size_t)8 * 512 * sizeof(float) : pscorePart);
     } else if (d->ylaneLm & 8) { /* logAdd: the merge-table slots' sums */
       using YlaneLdsLa = YlaneLdsT<2, false, true>;
       using YlaneLdsLa4 = YlaneLdsT<4, false, true>;
@@ -2455,43 +2456,58 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
     hipLaunchKernelGGL((fltx_decode_kernel_ylane<1024, 4, 4, LMK, 1, false>), dim3(nGrid), dim3(1024),  \
                        d->wsBytes, d->ctx->stream, P);                                                  \
   } while (0)
-    switch (d->ylane * 10 + d->ylaneLm + (d->yshare ? 100 : 0)) {
-      case 10: FLTX_LAUNCH_YLANE(512, 1, 2, 0, 0); break;
-      case 11: FLTX_LAUNCH_YLANE(512, 1, 2, 1, 0); break;
-      case 20: FLTX_LAUNCH_YLANE(768, 2, 4, 0, 0); break;
-      case 21: FLTX_LAUNCH_YLANE(768, 2, 4, 1, 0); break;
-      case 110: FLTX_LAUNCH_YLANE(512, 1, 2, 0, 1); break;
-      case 111: FLTX_LAUNCH_YLANE(512, 1, 2, 1, 1); break;
-      case 120: FLTX_LAUNCH_YLANE(512, 2, 4, 0, 1); break;
-      case 121: FLTX_LAUNCH_YLANE(512, 2, 4, 1, 1); break;
-      case 140: FLTX_LAUNCH_YLANE4(0); break;
-      case 141: FLTX_LAUNCH_YLANE4(1); break;
-      case 12: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 2, 0); break; /* ASG (LMK bit 1) */
-      case 13: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 3, 0); break;
-      case 22: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 2, 0); break;
-      case 23: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 3, 0); break;
-      case 112: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 2, 1); break;
-      case 113: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 3, 1); break;
-      case 122: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 2, 1); break;
-      case 123: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 3, 1); break;
-      case 142: FLTX_LAUNCH_YLANE4(2); break;
-      case 143: FLTX_LAUNCH_YLANE4(3); break;
+    switch (d->ylane * 100 + d->ylaneLm + (d->yshare ? 1000 : 0)) { /* lane groups, LMK, memo in HBM */
+      case 100: FLTX_LAUNCH_YLANE(512, 1, 2, 0, 0); break;
+      case 101: FLTX_LAUNCH_YLANE(512, 1, 2, 1, 0); break;
+      case 200: FLTX_LAUNCH_YLANE(768, 2, 4, 0, 0); break;
+      case 201: FLTX_LAUNCH_YLANE(768, 2, 4, 1, 0); break;
+      case 1100: FLTX_LAUNCH_YLANE(512, 1, 2, 0, 1); break;
+      case 1101: FLTX_LAUNCH_YLANE(512, 1, 2, 1, 1); break;
+      case 1200: FLTX_LAUNCH_YLANE(512, 2, 4, 0, 1); break;
+      case 1201: FLTX_LAUNCH_YLANE(512, 2, 4, 1, 1); break;
+      case 1400: FLTX_LAUNCH_YLANE4(0); break;
+      case 1401: FLTX_LAUNCH_YLANE4(1); break;
+      case 102: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 2, 0); break; /* ASG (LMK bit 1) */
+      case 103: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 3, 0); break;
+      case 202: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 2, 0); break;
+      case 203: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 3, 0); break;
+      case 1102: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 2, 1); break;
+      case 1103: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 3, 1); break;
+      case 1202: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 2, 1); break;
+      case 1203: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 3, 1); break;
+      case 1402: FLTX_LAUNCH_YLANE4(2); break;
+      case 1403: FLTX_LAUNCH_YLANE4(3); break;
       /* logAdd merges (LMK bit 3; CTC) */
-      case 18: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 8, 0); break;
-      case 19: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 9, 0); break;
-      case 28: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 8, 0); break;
-      case 29: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 9, 0); break;
-      case 118: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 8, 1); break;
-      case 119: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 9, 1); break;
-      case 128: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 8, 1); break;
-      case 129: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 9, 1); break;
-      case 148: FLTX_LAUNCH_YLANE4(8); break;
-      case 149: FLTX_LAUNCH_YLANE4(9); break;
+      case 108: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 8, 0); break;
+      case 109: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 9, 0); break;
+      case 208: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 8, 0); break;
+      case 209: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 9, 0); break;
+      case 1108: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 8, 1); break;
+      case 1109: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 9, 1); break;
+      case 1208: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 8, 1); break;
+      case 1209: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 9, 1); break;
+      case 1408: FLTX_LAUNCH_YLANE4(8); break;
+      case 1409: FLTX_LAUNCH_YLANE4(9); break;
       /* several words per spelling (LMK bit 2; with the LM terms) */
-      case 115: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 5, 1); break;
-      case 117: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 7, 1); break;
-      case 125: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 5, 1); break;
-      case 127: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 7, 1); break;
+      case 1105: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 5, 1); break;
+      case 1107: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 7, 1); break;
+      case 1205: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 5, 1); break;
+      case 1207: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 7, 1); break;
+            /* logAdd under ASG (LMK 10 / 11) and over spellings with several words (13 / 15) */
+      case 110: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 10, 0); break;
+      case 111: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 11, 0); break;
+      case 210: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 10, 0); break;
+      case 211: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 11, 0); break;
+      case 1110: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 10, 1); break;
+      case 1111: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 11, 1); break;
+      case 1210: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 10, 1); break;
+      case 1211: FLTX_LAUNCH_YLANE_NP(512, 2, 4, 11, 1); break;
+      case 1410: FLTX_LAUNCH_YLANE4(10); break;
+      case 1411: FLTX_LAUNCH_YLANE4(11); break;
+      case 1113: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 13, 1); break;
+      case 1115: FLTX_LAUNCH_YLANE_NP(512, 1, 2, 15, 1); break;
+      case 1213: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 13, 1); break;
+      case 1215: FLTX_LAUNCH_YLANE_NP(768, 2, 4, 15, 1); break;
       default: return fail(FLTX_ERR_INVALID, "no fltx_ylane.h kernel for %d lane groups", d->ylane);
     }
 #undef FLTX_LAUNCH_YLANE

@@ -121,6 +121,23 @@
   FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 9, 1, false>)   \
   FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 8, 1, false>)  \
   FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 9, 1, false>)
+/* ... under ASG (10 / 11) and over spellings with several words (13 / 15: memo in HBM, as FLTX_G23) */
+#define FLTX_G26(W)                                             \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 10, 0, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 11, 0, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 10, 0, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 11, 0, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 10, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 11, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 10, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 2, 4, 11, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 10, 1, false>)  \
+  FLTX_INST(fltx_decode_kernel_ylane<1024, 4, 4, 11, 1, false>)
+#define FLTX_G27(W)                                             \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 13, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<512, 1, 2, 15, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 13, 1, false>)   \
+  FLTX_INST(fltx_decode_kernel_ylane<768, 2, 4, 15, 1, false>)
 /* lane = LM state decode over a token beam of a large token set (fltx_wlane.h): (threads, list positions per wave) */
 #define FLTX_G22(W)                                   \
   FLTX_INST(fltx_decode_kernel_wlane<576, 5>)         \
@@ -156,6 +173,8 @@ FLTX_G22(0)
 FLTX_G23(0)
 FLTX_G24(0)
 FLTX_G25(0)
+FLTX_G26(0)
+FLTX_G27(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -183,6 +202,8 @@ FLTX_G25(0)
 #undef FLTX_G23
 #undef FLTX_G24
 #undef FLTX_G25
+#undef FLTX_G26
+#undef FLTX_G27
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET

@@ -267,7 +267,6 @@ FLTX_DEV void ylaneUtterance(const DecodeParams& P, char* smem) {
   /* bit 3 = logAdd: the members of a merge group above the frame's threshold are summed (Utils.h:160-198), as in
    * fltx_xlane.h -- the candidates and the frame's best as without it, the sums once the threshold is known */
   constexpr bool LA = (LMK & 8) != 0;
-  static_assert(!(LA && (ML || ASG)), "logAdd: CTC, one word per spelling");
   constexpr int XR = ML ? 2 * NG : 0;
   static_assert(!ML || NG <= 2, "several words per spelling: one and two lane groups (fltx_api.cpp prepare() says why)");
   constexpr int NW = NG + XR; /* candidate slots of a word-wave thread */
