@@ -1871,7 +1871,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
       why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
       /* (logAdd on the lexicon lane engines: CTC, one word per spelling) */
-      why |= 0; /* (logAdd: every configuration the lexicon lane engines take without it, they take with it) */
+      /* (logAdd on the lexicon decoder is no reason any more: every configuration the lexicon lane engines take without
+       * it, they take with it) */
       why |= (lexi && d->opt.criterion != FLTX_CRITERION_CTC && d->noYlaneAsg) ? FLTX_WHY_ASG : 0;
       why |= (lexi && unkOn) ? FLTX_WHY_UNK : 0;
       why |= (lexi && d->trie && (!d->trie->xOk || (d->trie->xMulti && d->lm->kind == 0))) ? FLTX_WHY_TRIE_SHAPE : 0;
