@@ -77,6 +77,9 @@ FLTX_API int fltx_ctx_destroy(fltx_ctx* ctx);
 FLTX_API int fltx_ctx_synchronize(fltx_ctx* ctx);
 /* the hipStream_t kernels are launched on (for event timing by the caller) */
 FLTX_API void* fltx_ctx_stream(fltx_ctx* ctx);
+/* a number that names this context and is never handed out again (an address can be: callers that cache per-context
+ * objects -- the facade's Trie keeps one flattened copy per context -- key them by this, not by the pointer) */
+FLTX_API uint64_t fltx_ctx_uid(fltx_ctx* ctx);
 
 /* ---- language models ---------------------------------------------------- */
 /* ZeroLM (decoder/lm/ZeroLM.h:22-32, ZeroLM.cpp:14-26). */

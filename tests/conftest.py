@@ -58,6 +58,7 @@ def emu_session():
         [os.path.join(ROOT, "include", "fltx.h")] + \
         glob.glob(os.path.join(ROOT, "tests", "emu", "*.h")) + \
         glob.glob(os.path.join(ROOT, "tests", "emu", "*.cpp")) + \
+        glob.glob(os.path.join(ROOT, "tests", "emu", "*.inc")) + \
         [os.path.join(ROOT, "tests", "emu", "build.sh")]
     import fcntl
     with open(os.path.join(ROOT, "tests", "emu", ".build.lock"), "w") as lock:  # (pytest-xdist: one worker builds, the others wait)

@@ -354,6 +354,23 @@ def test_emulated_logadd_under_asg_and_over_homophones(emu_session, oracle_lib):
     assert not bad and all(v[1] == v[0] and v[2] <= v[0] // 8 for v in st.values()), (st, bad[:3])
 
 
+def test_emulated_token_lm_on_the_lane_state_engine(emu_session, oracle_lib, golden):
+    """fltx_slane.h's token-LM variant (a token-level n-gram LM on the lexicon-free decoder): the two vectors of the
+    compiled reference on engine 4, then a slice of the GPU suite's grid (logAdd @1e-9: the emulator shares the host's libm)."""
+    import test_gpu_batches
+    for name in ("ng_tok_lexfree_t40", "ng_tok_lexfree_kt8"):
+        c = cases.BY_NAME[name]
+        inp = helpers.case_inputs(c)
+        d = emu_session.decoder(c, inp)
+        d.decode_batch(inp["e"], [c["T"]], c["N"])
+        assert d.get("engine") == 4 and d.get("tlane") == 1 and d.get("redone") == 0 and d.get("why_not_lane") == 0
+        ok, why = helpers.check_against_golden(d.results(0), golden[name])
+        d.close()
+        assert ok, why
+    ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 400, 5, [1, 2, 7, 20, 45], emu=True)
+    assert ran >= 380 and served == ran and not bad, (ran, served, bad[:3])
+
+
 def test_emulated_word_piece_engine(emu_session, oracle_lib):
     """fltx_wlane.h on the emulator: a thin slice of the GPU suite's grid (tests/test_gpu_batches.py)."""
     import test_gpu_batches

@@ -300,6 +300,85 @@ def _logadd_lm_lexicon_grid(sess, oracle_lib, n, seed, frames, tol):
     return on6, redone, bad
 
 
+def _token_lm_grid(sess, oracle_lib, n, seed, frames, emu=False, sets=None):
+    """random LexiconFreeDecoder + token-level n-gram LM configurations (LexiconFreeDecoder.cpp:69-85 with KenLM::score,
+    lm/KenLM.cpp:63-83) on fltx_slane.h's token-LM variant: orders 2 - 4, CTC / ASG, token beams, thresholds, silScore,
+    lmWeight of both signs, max-merge (bit-exact) and logAdd (1e-5 on the device, 1e-9 on the emulator, which shares
+    the host's libm) -> (configurations compared, served by engine 4 with nothing redone, mismatches)"""
+    import random
+    rnd = random.Random(seed)
+    ran = served = 0
+    bad = []
+    for i in range(n):
+        N = rnd.choice([8, 12, 29, 29, 29, 40, 64])
+        crit = rnd.choice(["ctc", "ctc", "asg"])
+        la = rnd.random() < 0.3
+        c = cases.case("tlm%d" % i, dist=rnd.choice(["ctc", "ctc", "uniform"]), T=rnd.choice(frames), N=N,
+                       K=rnd.choice([1, 2, 5, 10, 24, 50, 64]), Kt=rnd.choice([N, N, max(1, N // 3), 3, 1]),
+                       thr=rnd.choice([25.0, 8.0, 2.0, 100.0, float("inf")]), u=7000 + i, log_add=la,
+                       sil_score=rnd.choice([0.0, -0.5, 0.4]), crit=crit, trans_seed=(90 + i % 7) if crit == "asg" else None,
+                       lm=("ngram", rnd.choice([2, 3, 4]), 50 + i % 4), lm_weight=rnd.choice([0.5, 0.8, 1.5, 2.5, -0.3]))
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue  # (equal scores in the n-best: the reference's order is its sort's)
+        if la and any(abs(a.score - b.score) < 1e-4 for a, b in zip(want, want[1:])):
+            continue  # (near ties: a different libm may order them differently)
+        d = sess.decoder(c, inp)
+        for k, v in (sets or {}).items():
+            d.set(k, v)
+        d.decode_batch(inp["e"], [c["T"]], c["N"])
+        got = d.results(0)
+        served += int(d.get("engine") == 4 and d.get("tlane") == 1 and d.get("redone") == 0)
+        d.close()
+        ran += 1
+        ok, why = helpers.hyps_equal(want, got, (1e-9 if emu else 1e-5) if la else 0.0)
+        if not ok:
+            bad.append(({k: c[k] for k in ("dist", "T", "N", "K", "Kt", "thr", "sil_score", "crit", "log_add", "lm", "lm_weight", "u")}, why))
+    return ran, served, bad
+
+
+@pytest.mark.gpu
+def test_token_level_ngram_lm_on_the_lane_state_engine(gpu_session, oracle_lib):
+    """2 000 random configurations of the lexicon-free decoder with a token-level n-gram LM (orders 2 - 4, CTC / ASG,
+    token beams, logAdd) against the oracle: all on engine 4 (fltx_slane.h, token-LM variant), nothing handed back,
+    max-merge bit-exact (score, emitting-model score, LM score), logAdd @1e-5; a slice of them on the 512-thread
+    geometry of which two workgroups share a CU, and the generic engine on the same inputs."""
+    ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 2000, 6, [1, 2, 7, 20, 45, 90])
+    assert ran >= 1900 and served == ran and not bad, (ran, served, bad[:3])
+    ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 300, 7, [5, 33, 120], sets={"slane_threads": 512})
+    assert ran >= 280 and not bad, (ran, served, bad[:3])
+    ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 200, 8, [5, 33], sets={"tlane": 0})
+    assert ran >= 180 and served == 0 and not bad, (ran, served, bad[:3])
+
+
+@pytest.mark.gpu
+def test_token_lm_batch_at_the_c2_shape(gpu_session, oracle_lib):
+    """BASELINE configs[1]'s shape (256 utterances, T = 1000, N = 29, beam 50) with a token 3-gram: engine 4, nothing
+    redone, sampled utterances equal to the oracle bit for bit, and the generic engine's n-best on every utterance."""
+    B, T, N, K = 256, 1000, 29, 50
+    c = cases.case("c2tok", dist="ctc", T=T, N=N, K=K, u=0, lm=("ngram", 3, 11), lm_weight=0.8)
+    inp = helpers.case_inputs(c)
+    e = synth.batch("ctc", B, T, N)
+    d = gpu_session.decoder(c, inp)
+    d.decode_batch(e, [T] * B, N)
+    assert d.get("engine") == 4 and d.get("tlane") == 1 and d.get("redone") == 0
+    g = gpu_session.decoder(c, inp)
+    g.set("tlane", 0)
+    g.decode_batch(e, [T] * B, N)
+    assert g.get("engine") == 1  # (the generic engine's dense merge)
+    for b in range(B):
+        ok, why = helpers.hyps_equal(g.results(b), d.results(b))
+        assert ok, (b, why)
+    for b in (0, 101, 255):
+        cb = dict(c, u=b)
+        want = helpers.run_checker(oracle_lib, cb, dict(inp, e=e[b]))
+        ok, why = helpers.hyps_equal(want, d.results(b))
+        assert ok, (b, why)
+    d.close()
+    g.close()
+
+
 def _logadd_asg_homophone_grid(sess, oracle_lib, n, seed, frames, tol):
     """... under the ASG criterion, over lexicons with several words per spelling (n-gram LM, beams up to 128), and both:
     -> {mode: [configurations, on engine 6, redone, mismatches]}.  Equal-score hypotheses that hold the words of one

@@ -253,6 +253,12 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     ("lx_spell_unk", 0, {}), ("lx_asg_t40", 6, {}), ("lx_asg_t40", 0, {"ylane_asg": 0}), ("lx_asg_t40", 6, {"ylane_groups": 4}),
     ("lx_asg_t40", 6, {"yshare": 1}), ("lx_spell_t60_k12_logadd", 5, {}), ("lx_spell_t60_k12_logadd", 5, {"yshare": 1}), ("ng_word_unk_t40", 0, {}),
     ("ng_word_logadd_t40", 6, {}), ("ng_word_logadd_t40", 6, {"yshare": 1}), ("ng_tok_lexicon_t40", 0, {}),
+    # a token-level n-gram LM on the lexicon-free decoder: fltx_slane.h's token-LM variant (round 6), every geometry
+    ("ng_tok_lexfree_t40", 4, {}), ("ng_tok_lexfree_kt8", 4, {}), ("ng_tok_lexfree_t40", 1, {"tlane": 0}),
+    ("ng_tok_lexfree_kt8", 1, {"tlane": 0}), ("ng_tok_lexfree_t40", 4, {"slane_threads": 512}),
+    ("ng_tok_lexfree_t40", 4, {"slane_threads": 448}), ("ng_tok_lexfree_t40", 4, {"slane_threads": 384}),
+    ("ng_tok_lexfree_t40", 4, {"slane_threads": 320}), ("ng_tok_lexfree_t40", 4, {"slane_threads": 640}),
+    ("ng_tok_lexfree_kt8", 4, {"slane_threads": 512}), ("ng_tok_lexfree_kt8", 4, {"slane_threads": 320}),
     ("lx_scores_t50", 6, {}), ("ng_word_t40_k10", 6, {}), ("ng_word_t60_k16_4g", 6, {}), ("C4_spell_u0", 6, {}),
     ("C4_spell_u255", 6, {}), ("C4z_spell_u0", 6, {}), ("lx_spell_t40_k8", 6, {"ylane": 2}),
     ("lx_uni_t40_k10", 6, {"ylane": 2}), ("C3_spell_u0", 6, {"ylane": 2}), ("C3_uniform_u0", 6, {"ylane": 2}),
@@ -281,9 +287,12 @@ def test_engine_selection(gpu_session, golden, name, engine, sets):
     got = d.get("engine")
     tol = 1e-5 if c["log_add"] else 0.0
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]], tol)
+    tl, why_not, redone = d.get("tlane"), d.get("why_not_lane"), d.get("redone")
     d.close()
     assert got == engine
     assert ok, why
+    if name.startswith("ng_tok_lexfree"):
+        assert tl == (1 if engine == 4 else 0) and redone == 0 and (why_not == 0) == (engine == 4)
 
 
 LANE_OK = [c for c in cases.CASES if c["kind"] == "lexfree" and c["lm"] == "zero" and c["K"] <= 64 and c["N"] <= 64]

@@ -51,7 +51,7 @@ class Lib:
 
     SYMBOLS = [
         "fltx_last_error", "fltx_version", "fltx_ctx_create", "fltx_ctx_destroy",
-        "fltx_ctx_synchronize", "fltx_ctx_stream", "fltx_lm_zero_create",
+        "fltx_ctx_synchronize", "fltx_ctx_stream", "fltx_ctx_uid", "fltx_lm_zero_create",
         "fltx_lm_ngram_create", "fltx_lm_host_create", "fltx_lm_arpa_load", "fltx_lm_state_size", "fltx_lm_start", "fltx_lm_step", "fltx_lm_destroy", "fltx_lm_score_sequence",
         "fltx_trie_create", "fltx_trie_destroy", "fltx_decoder_create",
         "fltx_decoder_destroy", "fltx_decode_batch", "fltx_stream_begin",
@@ -78,6 +78,8 @@ class Lib:
         L.fltx_version.restype = C.c_char_p
         L.fltx_ctx_stream.restype = vp
         L.fltx_ctx_stream.argtypes = [vp]
+        L.fltx_ctx_uid.restype = C.c_uint64
+        L.fltx_ctx_uid.argtypes = [vp]
         sig = {
             "fltx_ctx_create": [C.c_int, vp, pvp],
             "fltx_ctx_destroy": [vp],

@@ -109,13 +109,16 @@ class DeviceDecoder {
      * per-frame score history -- and keeping it takes the utterance off the lane engines (4.8 ms instead of 2.0 for
      * T = 1000, beam 50).  Few callers ask: decode() runs without it, and best() decodes the utterance again WITH the
      * history from the library's own device copy of the emissions the first time somebody does (redoWithScores) */
-    check(fltx_decoder_set(h_, "keep_scores", 0));
+    /* (a user LM decodes on the generic engine either way, and a second decode would call its start / score / finish
+     * again -- twice the Python time, side effects of a stateful LM repeated: such a decoder keeps the history) */
+    const bool keep = bridge_ != nullptr;
+    check(fltx_decoder_set(h_, "keep_scores", keep ? 1 : 0));
     chk(fltx_decode_batch(h_, emissions, 0, &off, &t32, 1, N));
     open_ = true;
     pendingBegin_ = false;
     oneT_ = T;
     oneN_ = N;
-    oneWithoutScores_ = true;
+    oneWithoutScores_ = !keep;
     return results(0);
   }
 

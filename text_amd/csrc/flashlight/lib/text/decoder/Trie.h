@@ -6,6 +6,8 @@
  * as the reference does; it is materialised from the host trie on first use.
  */
 #pragma once
+#include <iterator>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
@@ -92,14 +94,31 @@ class FL_TEXT_API Trie {
    * (each holds a reference), so a shared Trie stays valid for every decoder. */
   std::shared_ptr<const fltx_trie> deviceHandle(fltx_ctx* ctx) const {
     std::lock_guard<std::mutex> lock(devMu_); /* (decoders of several threads may be built over one Trie) */
-    if (dirty_ || !dev_ || devCtx_ != ctx) {
-      fltx_trie* t = nullptr;
-      detail::check(fltx_htrie_upload(h_, ctx, &t));
-      dev_ = std::shared_ptr<const fltx_trie>(t, [](const fltx_trie* p) { fltx_trie_destroy(const_cast<fltx_trie*>(p)); });
-      devCtx_ = ctx;
+    /* one copy per CONTEXT (the facade's contexts are per thread), keyed by the context's uid -- an address may be handed
+     * out again after a thread's context died -- and held weakly: the decoders own their copy, the Trie only remembers it
+     * for the next decoder built on the same context */
+    if (dirty_) {
+      dev_.clear();
+      last_.reset();
       dirty_ = false;
     }
-    return dev_;
+    const uint64_t uid = fltx_ctx_uid(ctx);
+    auto it = dev_.find(uid);
+    if (it != dev_.end()) {
+      if (auto alive = it->second.lock()) {
+        return alive;
+      }
+      dev_.erase(it);
+    }
+    for (auto j = dev_.begin(); j != dev_.end();) { /* (copies whose decoders are all gone) */
+      j = j->second.expired() ? dev_.erase(j) : std::next(j);
+    }
+    fltx_trie* t = nullptr;
+    detail::check(fltx_htrie_upload(h_, ctx, &t));
+    std::shared_ptr<const fltx_trie> up(t, [](const fltx_trie* p) { fltx_trie_destroy(const_cast<fltx_trie*>(p)); });
+    dev_[uid] = up;
+    last_ = up; /* (the newest copy stays alive with the Trie: build decoder, drop it, build another -- no second upload) */
+    return up;
   }
 
  private:
@@ -137,8 +156,8 @@ class FL_TEXT_API Trie {
   TrieNodePtr root_;
   fltx_htrie* h_ = nullptr;
   mutable std::mutex devMu_;
-  mutable std::shared_ptr<const fltx_trie> dev_;
-  mutable fltx_ctx* devCtx_ = nullptr;
+  mutable std::map<uint64_t, std::weak_ptr<const fltx_trie>> dev_;
+  mutable std::shared_ptr<const fltx_trie> last_;
   mutable bool dirty_ = true;
   mutable bool treeStale_ = true;
 };

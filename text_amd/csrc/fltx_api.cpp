@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -349,7 +350,19 @@ struct fltx_lm {
   /* device copies of the tables, one set per context (= per device) that has a decoder using this LM */
   struct Dev {
     DBuf tab, backoff, usrToLm;
+    std::map<int, std::unique_ptr<DBuf>> tokDense; /* key = token count N: this device's copy of TokDense::tab */
   };
+  /* The LM as ONE gather for a decoder over a small token set (fltx_slane.h's TL variant: a token-level n-gram LM on
+   * the lexicon-free decoder, LexiconFreeDecoder.cpp:69-85 + KenLM.cpp:63-83): row c = a context the model can be
+   * in (the vector of suffix node ids ngScore takes), reached from KenLM::start(false) by any token sequence; column
+   * n < N = {float bits of lm.score(c, token n), row of the context after it}; column N = lm.finish(c).  Built on first use
+   * per N by a breadth-first walk with the host twin of ngScore (lmStepWord): the scores are the ones the generic engine
+   * computes, bit for bit.  nCtx < 0: the model has more contexts than the cap -- such decoders stay on the generic engine. */
+  struct TokDense {
+    int64_t nCtx = 0;
+    std::vector<int2> tab; /* [nCtx][N + 1] */
+  };
+  std::map<int, std::unique_ptr<TokDense>> tokDense; /* guarded by devMu */
   std::mutex devMu;
   std::unordered_map<uint64_t, std::unique_ptr<Dev>> dev; /* key = fltx_ctx::uid */
   /* host copies for fltx_lm_score_sequence */
@@ -421,6 +434,12 @@ struct fltx_decoder {
   int slaneThreads = 0; /* tuning: workgroup size of the lane = LM state kernel (0 = first that fits) */
   int wlane = 0, noWlane = 0; /* wlane: the lane = LM state kernel is fltx_wlane.h's (token sets beyond 64, token beam <= 64); slane = its list positions per wave */
   int slane = 0, noSlane = 0; /* slane: list positions per wave of the lane = LM state kernel (fltx_slane.h), 0 = off */
+  /* ... its variant for a token-level n-gram LM (TL): the LM's dense (context, token) table on this device; noTlane:
+   * tunable "tlane" = 0 (tests compare with the generic engine) */
+  int tlane = 0, noTlane = 0, tlaneFirst = 0;
+  const int2* tokLm = nullptr;
+  int64_t tokLmCtx = 0;
+  bool tokLmTooBig = false; /* the model has more contexts than a dense table holds (why_not_lane: LM) */
   /* ... with several lane groups (fltx_mlane.h, beams beyond 64): lane groups (0 / 1 = fltx_slane.h), groups per token
    * wave, groups per self wave; userLaneGroups: tuning / tests, 0 = as many as the beam needs, -1 = never */
   int mlaneNG = 0, mlaneGPW = 0, mlaneSPW = 0, userLaneGroups = 0, userMlaneGeo = -1;
@@ -440,6 +459,7 @@ struct fltx_decoder {
   int lastRedo = 0;           /* utterances of the last offline call that had to be decoded again on a general path */
   int packedBits = 8;         /* width of the parent-slot field of those records (fltx_mlane.h: 10) */
   bool batchPacked = false;   /* some utterance of the current results has packed history records (ST_PACKED) */
+  bool batchTlane = false;    /* ... by fltx_slane.h's token-LM variant (the back-trace re-accumulates the LM score as well) */
   bool batchWlane = false;    /* ... written by fltx_wlane.h (tokens beyond a byte, emissions gathered by the back-trace) */
   DBuf xlmword;               /* fltx_ylane.h: LM word id of XNode::endLabel0 per node (this decoder's trie x LM) */
   const fltx_trie* xlmwordTrie = nullptr;
@@ -464,8 +484,10 @@ struct fltx_decoder {
   bool offlineCall = false;   /* prepare() is sizing an fltx_decode_batch (begin + frames + end in one launch) */
   /* "defer_check": fltx_decode_batch returns with its kernels queued; the look at the utterances' statuses (and the
    * second pass of what a fast path flagged) waits for the first call that reads results */
-  int deferCheck = 0;
+  int deferCheck = 0; /* 1: an unread batch is settled by the next fltx_decode_batch; 2: dropped there (counted in looksDropped) */
   bool offlinePending = false;
+  int64_t looksDropped = 0;  /* batches whose statuses nobody ever looked at ("looks_dropped"; defer_check = 2 only) */
+  int64_t unreadRedone = 0;  /* utterances decoded again while settling batches the caller never read ("unread_redone") */
   std::vector<int32_t> offT;
   std::vector<int64_t> offOffsets;
   int offN = 0, offUpSlot = 0;
@@ -639,6 +661,7 @@ int fltx_ctx_synchronize(fltx_ctx* ctx) {
 }
 
 void* fltx_ctx_stream(fltx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+uint64_t fltx_ctx_uid(fltx_ctx* ctx) { return ctx ? ctx->uid : 0; }
 
 /* ---- LM ------------------------------------------------------------------ */
 int fltx_lm_zero_create(fltx_ctx* ctx, fltx_lm** out) {
@@ -943,27 +966,9 @@ int fltx_lm_start(fltx_lm* lm, int32_t startWithNothing, int32_t* ctxOut) {
   return FLTX_OK;
 }
 
-/* usr_idx >= 0: LM::score; usr_idx == -1: LM::finish (scores </s>) */
-int fltx_lm_step(fltx_lm* lm, const int32_t* ctxIn, int32_t usrIdx, int32_t* ctxOut, float* score) {
-  if (!lm || !score) {
-    return fail(FLTX_ERR_INVALID, "null argument");
-  }
-  if (lm->kind == 2) {
-    return fail(FLTX_ERR_UNSUPPORTED, "a host LM keeps its own states (call the LM object)");
-  }
-  if (lm->kind == 0) {
-    *score = 0.0f;
-    return FLTX_OK;
-  }
-  uint32_t word;
-  if (usrIdx == -1) {
-    word = (uint32_t)lm->eos;
-  } else {
-    if (usrIdx < 0 || usrIdx >= lm->nUsr) {
-      return fail(FLTX_ERR_RANGE, "[ngram LM] Invalid user token index: %d", usrIdx); /* KenLM.cpp:66-69 */
-    }
-    word = (uint32_t)lm->hUsr[usrIdx];
-  }
+/* log10 p(word | context) and the context after it: the host twin of ngScore (fltx_kernels.h), same tables, same
+ * order of the float additions.  ctxOut may alias ctxIn. */
+static float lmStepWord(const fltx_lm* lm, const int32_t* ctxIn, uint32_t word, int32_t* ctxOut) {
   const int L = lm->order - 1;
   uint32_t nodes[kMaxNgramOrder] = {0};
   bool found[kMaxNgramOrder] = {false};
@@ -1008,7 +1013,31 @@ int fltx_lm_step(fltx_lm* lm, const int32_t* ctxIn, int32_t usrIdx, int32_t* ctx
       ctxOut[j] = j < L ? tmp[j] : 0;
     }
   }
-  *score = prob;
+  return prob;
+}
+
+/* usr_idx >= 0: LM::score; usr_idx == -1: LM::finish (scores </s>) */
+int fltx_lm_step(fltx_lm* lm, const int32_t* ctxIn, int32_t usrIdx, int32_t* ctxOut, float* score) {
+  if (!lm || !score) {
+    return fail(FLTX_ERR_INVALID, "null argument");
+  }
+  if (lm->kind == 2) {
+    return fail(FLTX_ERR_UNSUPPORTED, "a host LM keeps its own states (call the LM object)");
+  }
+  if (lm->kind == 0) {
+    *score = 0.0f;
+    return FLTX_OK;
+  }
+  uint32_t word;
+  if (usrIdx == -1) {
+    word = (uint32_t)lm->eos;
+  } else {
+    if (usrIdx < 0 || usrIdx >= lm->nUsr) {
+      return fail(FLTX_ERR_RANGE, "[ngram LM] Invalid user token index: %d", usrIdx); /* KenLM.cpp:66-69 */
+    }
+    word = (uint32_t)lm->hUsr[usrIdx];
+  }
+  *score = lmStepWord(lm, ctxIn, word, ctxOut);
   return FLTX_OK;
 }
 
@@ -1230,6 +1259,95 @@ static int lmEnsureUploaded(fltx_lm* lm, fltx_ctx* ctx, fltx_lm::Dev** out) {
   return FLTX_OK;
 }
 
+/* The dense (context, token) table of an n-gram LM over N tokens (fltx_lm::TokDense), built once per (LM, N) and
+ * uploaded once per context.  *out = null (and FLTX_OK): the model has too many contexts for a dense table. */
+constexpr int64_t kTokDenseMaxCtx = 1ll << 20;      /* contexts */
+constexpr int64_t kTokDenseMaxBytes = 1ll << 31;    /* 2 GB of the device's 288 */
+static int lmTokDense(fltx_lm* lm, fltx_ctx* ctx, fltx_lm::Dev* dv, int N, const int2** out, int64_t* nCtxOut) {
+  *out = nullptr;
+  if (lm->kind != 1 || !dv || N <= 0) {
+    return FLTX_OK;
+  }
+  std::lock_guard<std::mutex> lock(lm->devMu);
+  auto it = lm->tokDense.find(N);
+  if (it == lm->tokDense.end()) {
+    std::unique_ptr<fltx_lm::TokDense> td(new fltx_lm::TokDense());
+    const int L = std::max(1, lm->order - 1);
+    const int stride = N + 1;
+    const int64_t capCtx = std::min<int64_t>(kTokDenseMaxCtx, kTokDenseMaxBytes / (8 * (int64_t)stride));
+    /* contexts in the order they are first reached: row 0 = KenLM::start(false) (KenLM.cpp:52-61) */
+    std::map<std::vector<int32_t>, int32_t> ids;
+    std::vector<std::vector<int32_t>> rows;
+    std::vector<int32_t> c0((size_t)L, 0);
+    {
+      uint32_t nd;
+      float pr;
+      if (lm->order > 1 && lmFind(lm, 0, (uint32_t)lm->bos, nd, pr)) {
+        c0[0] = (int32_t)(nd & ~kPhantomNode);
+      }
+    }
+    ids.emplace(c0, 0);
+    rows.push_back(c0);
+    bool tooMany = false;
+    std::vector<int32_t> nxt((size_t)L, 0);
+    for (size_t r = 0; r < rows.size() && !tooMany; ++r) {
+      const std::vector<int32_t> cur = rows[r]; /* (a copy: rows grows) */
+      td->tab.resize((r + 1) * (size_t)stride);
+      for (int n = 0; n <= N; ++n) {
+        /* KenLM::score: usrToLmIdxMap_, an index beyond the dictionary goes to <unk> as on the device (lmScoreDev);
+         * column N: KenLM::finish = the score of </s> */
+        const uint32_t word = n == N ? (uint32_t)lm->eos : (n < lm->nUsr ? (uint32_t)lm->hUsr[(size_t)n] : (uint32_t)lm->unk);
+        const float sc = lmStepWord(lm, cur.data(), word, nxt.data());
+        int32_t to = 0;
+        if (n < N) {
+          auto f = ids.find(nxt);
+          if (f == ids.end()) {
+            if ((int64_t)rows.size() >= capCtx) {
+              tooMany = true;
+              break;
+            }
+            f = ids.emplace(nxt, (int32_t)rows.size()).first;
+            rows.push_back(nxt);
+          }
+          to = f->second;
+        }
+        uint32_t bits;
+        memcpy(&bits, &sc, 4);
+        td->tab[r * (size_t)stride + (size_t)n] = make_int2((int)bits, to);
+      }
+    }
+    if (tooMany) {
+      td->nCtx = -1;
+      td->tab.clear();
+      td->tab.shrink_to_fit();
+    } else {
+      td->nCtx = (int64_t)rows.size();
+    }
+    it = lm->tokDense.emplace(N, std::move(td)).first;
+  }
+  const fltx_lm::TokDense& td = *it->second;
+  if (td.nCtx <= 0) {
+    return FLTX_OK;
+  }
+  auto dit = dv->tokDense.find(N);
+  if (dit == dv->tokDense.end()) {
+    std::unique_ptr<DBuf> buf(new DBuf());
+    Stream st = ctx->stream;
+    if (buf->ensure(sizeof(int2) * td.tab.size(), st, false)) {
+      return fail(FLTX_ERR_OOM, "dense token-LM table: device allocation failed");
+    }
+    if (devCopyH2D(buf->p, td.tab.data(), sizeof(int2) * td.tab.size(), st) || devSync(st)) {
+      return fail(FLTX_ERR_HIP, "dense token-LM table: upload failed");
+    }
+    dit = dv->tokDense.emplace(N, std::move(buf)).first;
+  }
+  *out = dit->second->as<int2>();
+  if (nCtxOut) {
+    *nCtxOut = td.nCtx;
+  }
+  return FLTX_OK;
+}
+
 /* ---- decoder ------------------------------------------------------------- */
 int fltx_decoder_create(fltx_ctx* ctx, int32_t kind, const fltx_options* opt, const fltx_trie* trie,
                         const fltx_lm* lm, int32_t sil, int32_t blank, int32_t unk,
@@ -1344,6 +1462,10 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->lastRedo;
   } else if (!strcmp(key, "sstream")) {
     *value = d->sstream;
+  } else if (!strcmp(key, "looks_dropped")) { /* defer_check = 2: batches that were overwritten without a look at their statuses */
+    *value = d->looksDropped;
+  } else if (!strcmp(key, "unread_redone")) { /* defer_check = 1: utterances decoded again while settling batches nobody read */
+    *value = d->unreadRedone;
   } else if (!strcmp(key, "compactions")) { /* streams: times the LM-state free lists were rebuilt since fltx_stream_begin */
     *value = d->compactions;
   } else if (!strcmp(key, "staged_emissions")) { /* address of the library's own device copy of the last offline batch's emissions
@@ -1362,6 +1484,10 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->wlaneFirst;
   } else if (!strcmp(key, "slane")) {
     *value = d->slaneFirst;
+  } else if (!strcmp(key, "tlane")) { /* 1: the last call started on fltx_slane.h's token-LM variant */
+    *value = d->tlaneFirst;
+  } else if (!strcmp(key, "toklm_contexts")) { /* rows of the LM's dense (context, token) table (0: none built) */
+    *value = d->tokLmCtx;
   } else if (!strcmp(key, "fallback_reasons")) {
     *value = d->fallbackReasons;
   } else if (!strcmp(key, "why_not_lane")) { /* FLTX_WHY_* (include/fltx.h): why the last call did not start on a lane engine */
@@ -1402,7 +1528,7 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     return fail(FLTX_ERR_INVALID, "null argument");
   }
   if (!strcmp(key, "defer_check")) {
-    d->deferCheck = value ? 1 : 0;
+    d->deferCheck = value == 2 ? 2 : (value ? 1 : 0);
     return FLTX_OK;
   }
   if (!strcmp(key, "compact_always")) {
@@ -1508,6 +1634,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noWlane = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "tlane")) { /* 0: a token-level n-gram LM on the lexicon-free decoder stays on the generic engine */
+    d->noTlane = value ? 0 : 1;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "slane")) { /* 0: do not use the lane = LM state kernel (fltx_slane.h) */
     d->noSlane = value ? 0 : 1;
     return FLTX_OK;
@@ -1575,6 +1705,7 @@ void latchFirst(fltx_decoder* d) {
   d->whyFirst = d->whyNotLane;
   d->wlaneFirst = d->wlane;
   d->slaneFirst = d->slane;
+  d->tlaneFirst = d->tlane;
   d->xlaneFirst = d->xlane;
   d->ylaneFirst = d->ylane;
   d->laneGroupsFirst = d->slane ? std::max(1, d->mlaneNG) : d->ylane;
@@ -1694,6 +1825,43 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         d->slane = g[1];
         d->threads = g[0];
         break;
+      }
+    }
+  }
+  /* ... with a token-level n-gram LM (slaneUtterance<.., TL = true>; LexiconFreeDecoder.cpp:69-85 + KenLM.cpp:63-83):
+   * LM states are still the trie of token histories, so the lanes keep their shape; the LM is one gather from a dense
+   * (context, token) table built on the host (lmTokDense) -- when the model's contexts fit one */
+  d->tlane = 0;
+  d->tokLm = nullptr;
+  if (d->kind == FLTX_DECODER_LEXFREE && d->lm->kind == 1 && !d->noSlane && !d->noTlane && !d->genericAsked &&
+      !d->noDense && d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs && K <= 64 && N <= 64 &&
+      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
+      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
+      (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
+    const int2* tab = nullptr;
+    int64_t nCtx = 0;
+    int rcd = lmTokDense(const_cast<fltx_lm*>(d->lm), d->ctx, d->lmDev, N, &tab, &nCtx);
+    if (rcd) {
+      return rcd;
+    }
+    d->tokLmTooBig = tab == nullptr;
+    if (tab) {
+      static const int geoOne[][2] = {{576, 4}, {512, 5}, {448, 6}, {384, 7}, {320, 10}, {640, 4}, {512, 12}, {576, 10}};
+      static const int geoTwo[][2] = {{512, 5}, {448, 6}, {384, 7}, {576, 4}, {320, 10}, {640, 4}, {512, 12}, {576, 10}};
+      const auto& geo = B > d->ctx->numCUs ? geoTwo : geoOne;
+      const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
+      for (const auto& g : geo) {
+        if ((d->userThreads && d->threads != g[0]) || (d->slaneThreads && d->slaneThreads != g[0])) {
+          continue;
+        }
+        if (nList <= g[1] * (g[0] / 64 - 2)) {
+          d->slane = g[1];
+          d->tlane = 1;
+          d->tokLm = tab;
+          d->tokLmCtx = nCtx;
+          d->threads = g[0];
+          break;
+        }
       }
     }
   }
@@ -1869,7 +2037,10 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (N > 64 && (lexi || N > kWlMaxN || nTok > 64)) ? FLTX_WHY_TOKENS : 0; /* (lexicon-free: the token BEAM has to fit, fltx_wlane.h) */
       why |= (lexi ? K > ((d->trie && d->trie->xMulti) ? 128 : 256) : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
       why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
-      why |= (d->lm->kind != 0 && (d->lm->kind != 1 || !lexi)) || d->isLmToken ? FLTX_WHY_LM : 0;
+      /* (lexicon-free + n-gram LM: fltx_slane.h's TL variant takes it at beams up to 64 when the model's contexts fit a
+       * dense table -- what is left of the term there: a host LM, a model too large for the table) */
+      why |= (d->lm->kind == 2 || (lexi && d->isLmToken) ||
+              (!lexi && d->lm->kind == 1 && (K > 64 || d->tokLmTooBig))) ? FLTX_WHY_LM : 0;
       /* (logAdd on the lexicon lane engines: CTC, one word per spelling) */
       /* (logAdd on the lexicon decoder is no reason any more: every configuration the lexicon lane engines take without
        * it, they take with it) */
@@ -1882,7 +2053,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= ((int64_t)K * (maxT + 2) >= (lexi || K <= 64 ? (1ll << 23) - 1 : (1ll << 31) - 1)) ? FLTX_WHY_LENGTH : 0;
       why |= (d->noSlane || d->noXlane || d->noYlane || d->genericAsked || d->forceGlobalWs || d->noLean || d->noDense ||
               d->userLaneGroups < 0 || forceWorstCaseCap || (d->offlineCall && d->keepScores) ||
-              (!lexi && N > 64 && d->noWlane)) ? FLTX_WHY_SWITCHED_OFF : 0;
+              (!lexi && N > 64 && d->noWlane) || (!lexi && d->lm->kind == 1 && d->noTlane)) ? FLTX_WHY_SWITCHED_OFF : 0;
       why |= (!lexi && N > 64 && d->opt.log_add) ? FLTX_WHY_LOGADD : 0; /* (fltx_wlane.h has no logAdd variant) */
       why |= (!lexi && nListAll > 70) ? FLTX_WHY_GEOMETRY : 0;
       if (!why) {
@@ -2141,11 +2312,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     d->epoch = 0;
   }
   /* (the lean / lane engines name their states with a counter and childTab: no table) */
-  rc |= d->stateTab.ensure(sizeof(unsigned long long) * (d->lean ? 1 : (size_t)B * cap), st, true, &grewTab);
+  rc |= d->stateTab.ensure(sizeof(unsigned long long) * ((d->lean || d->tlane) ? 1 : (size_t)B * cap), st, true, &grewTab);
   if (grewTab) {
     d->epoch = 0;
   }
-  if (d->lm->kind == 1) {
+  if (d->lm->kind == 1 && !d->tlane) { /* (TL: a state's context is a row number kept with its lane) */
     rc |= d->stateCtx.ensure(sizeof(int32_t) * (size_t)B * cap * std::max(1, d->lm->order - 1), st, false);
   }
   size_t bk = (size_t)B * K;
@@ -2303,6 +2474,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   /* (the lean step on an HBM workspace reads its atomically ORed addMask words at L2 as well: wsLoadAtomic64) */
   P.wsNoInv = (!d->wsInLds && d->hotLevel >= 1) ? 1 : 0;
   P.lmCache = d->useLmCache ? d->lmCache.as<unsigned long long>() : nullptr;
+  P.tokLm = d->tlane ? d->tokLm : nullptr;
+  P.tokLmStride = d->N + 1;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;
@@ -2378,7 +2551,13 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   } while (0)
 #define FLTX_LAUNCH_SLANE(WW, GG)                                                                \
   do {                                                                                           \
-    if (d->opt.log_add) {                                                                        \
+    if (d->tlane && d->opt.log_add) {                                                            \
+      hipLaunchKernelGGL((fltx_decode_kernel_tlane<WW, GG, true>), dim3(nGrid), dim3(WW),        \
+                         d->wsBytes, d->ctx->stream, P);                                         \
+    } else if (d->tlane) {                                                                       \
+      hipLaunchKernelGGL((fltx_decode_kernel_tlane<WW, GG, false>), dim3(nGrid), dim3(WW),       \
+                         d->wsBytes, d->ctx->stream, P);                                         \
+    } else if (d->opt.log_add) {                                                                        \
       hipLaunchKernelGGL((fltx_decode_kernel_slane<WW, GG, true, false>), dim3(nGrid), dim3(WW), \
                          d->wsBytes, d->ctx->stream, P);                                         \
     } else if (d->profile) {                                                                     \
@@ -2833,6 +3012,9 @@ int launchBacktrace(fltx_decoder* d) {
     Q.emOff = d->emOff[d->upSlot].as<int64_t>();
     Q.N = d->N;
     Q.transitions = (d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? d->transitions.as<float>() : nullptr;
+    Q.tokLm = d->batchTlane ? d->tokLm : nullptr;
+    Q.tokLmStride = d->N + 1;
+    Q.blank = d->opt.criterion == FLTX_CRITERION_CTC ? d->blank : -1;
     const size_t amLds = Q.amGather ? 4 * (size_t)Q.K * F + 16
                                     : 4 * ((size_t)F * d->N + (Q.transitions ? (size_t)d->N * d->N : 0) + (size_t)Q.K * F) + 16;
     btLds = std::max(btLds, amLds);
@@ -3290,6 +3472,7 @@ int hostLmDecodeBatch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   d->offlineCall = true;
   d->batchPacked = false;
   d->batchWlane = false;
+  d->batchTlane = false;
   d->keepScores = d->userKeepScores;
   d->fallbackReasons = 0;
   int rc = prepare(d, B, N, T, true);
@@ -3346,6 +3529,21 @@ int fltx_decode_batch(fltx_decoder* d, const float* emissions, int32_t onDevice,
   if (!d || !T || B <= 0 || N <= 0) {
     return fail(FLTX_ERR_INVALID, "fltx_decode_batch: bad argument");
   }
+  if (d->offlinePending) {
+    /* "defer_check": the batch before this one was never read.  Its statuses are looked at all the same (and what the
+     * fast path flagged is decoded again: that is how a decoder learns that a fallback should stick) -- a caller who
+     * only wants kernels queued back to back asks for defer_check = 2 and gets the drops counted */
+    if (d->deferCheck == 2) {
+      d->offlinePending = false;
+      ++d->looksDropped;
+    } else {
+      int rc = syncResults(d);
+      if (rc) {
+        return rc;
+      }
+      d->unreadRedone += d->lastRedo;
+    }
+  }
   d->streaming = false;
   d->chunkPending = false;
   d->pendingPrune = -1;
@@ -3397,6 +3595,7 @@ static int offlineAttempts(fltx_decoder* d, const float* emissions, int32_t onDe
   if (firstAttempt == 0) {
     d->batchPacked = false;
     d->batchWlane = false;
+    d->batchTlane = false;
   }
   d->keepScores = d->userKeepScores; /* a stream on this decoder had switched the score history on */
   for (int attempt = firstAttempt; attempt < 3 + firstAttempt; ++attempt) {
@@ -3418,6 +3617,7 @@ static int offlineAttempts(fltx_decoder* d, const float* emissions, int32_t onDe
     }
     if (!look) {
     d->batchPacked = d->batchPacked || d->slane || d->xlane || d->ylane;
+    d->batchTlane = d->batchTlane || d->tlane != 0;
     if (d->slane || d->xlane || d->ylane) {
       d->packedBits = (d->slane && d->mlaneNG > 1) ? 10 : (d->ylane == 4 ? 13 : 8); /* (a re-run on a general engine leaves plain records) */
       d->batchWlane = d->wlane != 0; /* ... and so is the records' token width (the back-trace reads it, not d->wlane) */
@@ -3451,7 +3651,7 @@ static int offlineAttempts(fltx_decoder* d, const float* emissions, int32_t onDe
     }
     } /* !look */
     const bool cutMode = d->CAP2 > 0 || d->cutRecompute;
-    const bool needLook = !finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->wlane || d->xlane || d->ylane);
+    const bool needLook = !finalForm && ((d->kind == FLTX_DECODER_LEXICON && (d->wsInLds || cutMode)) || d->lean || d->wlane || d->xlane || d->ylane || d->tlane);
     if (needLook && attempt == 0 && d->deferCheck) {
       /* the caller keeps the emissions where they are until the results are read: launch the back-trace and return;
        * the look happens in syncResults() */
@@ -3479,7 +3679,7 @@ static int offlineAttempts(fltx_decoder* d, const float* emissions, int32_t onDe
         }
         const bool o = (st & ST_CAND_OVERFLOW) && d->kind == FLTX_DECODER_LEXICON;
         const bool c = (st & ST_CUT_RETRY) && cutMode;
-        const bool l = (st & ST_SELECT_FALLBACK) && d->lean;
+        const bool l = (st & ST_SELECT_FALLBACK) && (d->lean || d->tlane);
         const bool x = (st & ST_SELECT_FALLBACK) && (d->xlane || d->ylane);
         const bool wl = (st & ST_SELECT_FALLBACK) && d->wlane; /* fltx_wlane.h: a row without a defined token beam, a select that did not converge */
         if (o || c || l || x || wl) {

@@ -41,6 +41,18 @@
 #define FLTX_G10(W) FLTX_SLANE_SET(false, false)
 #define FLTX_G11(W) FLTX_SLANE_SET(false, true)
 #define FLTX_G15(W) FLTX_SLANE_SET(true, false) /* logAdd */
+/* ... with a token-level n-gram LM (TL): the same geometries */
+#define FLTX_TLANE_SET(LA)                                     \
+  FLTX_INST(fltx_decode_kernel_tlane<320, 10, LA>)             \
+  FLTX_INST(fltx_decode_kernel_tlane<384, 7, LA>)              \
+  FLTX_INST(fltx_decode_kernel_tlane<448, 6, LA>)              \
+  FLTX_INST(fltx_decode_kernel_tlane<512, 5, LA>)              \
+  FLTX_INST(fltx_decode_kernel_tlane<576, 4, LA>)              \
+  FLTX_INST(fltx_decode_kernel_tlane<640, 4, LA>)              \
+  FLTX_INST(fltx_decode_kernel_tlane<512, 12, LA>)             \
+  FLTX_INST(fltx_decode_kernel_tlane<576, 10, LA>)
+#define FLTX_G28(W) FLTX_TLANE_SET(false)
+#define FLTX_G29(W) FLTX_TLANE_SET(true) /* logAdd */
 #define FLTX_G16(W) /* stream chunks */                     \
   FLTX_INST(fltx_decode_kernel_slane_stream<576, 4>)         \
   FLTX_INST(fltx_decode_kernel_slane_stream<512, 5>)         \
@@ -175,6 +187,8 @@ FLTX_G24(0)
 FLTX_G25(0)
 FLTX_G26(0)
 FLTX_G27(0)
+FLTX_G28(0)
+FLTX_G29(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -204,6 +218,9 @@ FLTX_G27(0)
 #undef FLTX_G25
 #undef FLTX_G26
 #undef FLTX_G27
+#undef FLTX_G28
+#undef FLTX_G29
+#undef FLTX_TLANE_SET
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET
 #undef FLTX_XLANE_SET

@@ -51,6 +51,12 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_slane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   slaneUtterance<GT, LA, false, PROF>(P, fltx_smem);
 }
+/* ... with a token-level n-gram LM flattened to a dense (context, token) table (TL) */
+template <int W, int GT, bool LA>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_tlane(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  slaneUtterance<GT, LA, false, false, true>(P, fltx_smem);
+}
 /* ... with NG groups of 64 lanes: beams 65 .. 64 * NG (fltx_mlane.h) */
 template <int W, int GT, int NG, int GPW, int SPW, bool LA>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_mlane(DecodeParams P) {

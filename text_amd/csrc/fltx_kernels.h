@@ -198,6 +198,11 @@ struct DecodeParams {
   int32_t tune;                 /* development: experiment bits of the lane engines (fltx_decoder_set "tune"), 0 in production */
   int32_t yRankAt;              /* tests: (lane, token) pairs beyond which a token wave of fltx_ylane.h ranks its own (0 = its rounds' capacity) */
   unsigned long long* lmCache;  /* generic step with an n-gram LM: (LM state, word) -> score of the last look-ups, kLmCache slots per utterance */
+  /* fltx_slane.h with a token-level n-gram LM (TL): the LM flattened to ONE dense table for gather -- row c = an n-gram
+   * context the model can be in, column n < N = {float bits of lm.score(c, token n), context after it}, column N = lm.finish(c);
+   * built on the host from the same flat tables ngScore walks (buildTokDense, fltx_api.cpp) */
+  const int2* tokLm;
+  int32_t tokLmStride;          /* N + 1 */
   int32_t wsNoInv;              /* HBM workspace of the generic step (hot level >= 1): no L1 invalidate after its barriers (wsBarrier) */
   int32_t* statusHost;          /* optimistic stream chunks: uttStatus mirrored in pinned host memory (read after the kernel, no copy) */
   const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */
@@ -3517,7 +3522,12 @@ FLTX_DEV void hostLmQuestions(const DecodeParams& P, char* smem) {
           rank += (o > v || (o == v && m < n)) ? 1 : 0;
         }
         if (rank < nTok) {
-          tokIdx[atomAdd32((uint32_t*)&cnt[1], 1u)] = n;
+          /* (a NaN emission compares false both ways and ranks 0: more than nTok entries may pass -- the list has
+           * room for nTok; the frame's candidates then carry the NaN and the status flag reports it) */
+          const uint32_t at = atomAdd32((uint32_t*)&cnt[1], 1u);
+          if (at < (uint32_t)nTok) {
+            tokIdx[at] = n;
+          }
         }
       }
       ldsBarrier();
@@ -3608,6 +3618,13 @@ struct BacktraceParams {
   const int64_t* emOff;
   const float* transitions; /* ASG, else null */
   int32_t N;
+  /* fltx_slane.h with a token-level n-gram LM (TL) does not carry the LM score either: along a returned path the
+   * new-token steps follow from the tokens alone (LexiconFreeDecoder.cpp:69-72: CTC n != blank && n != previous token
+   * -- a previous blank is a different token --, ASG n != previous token), each adds lm.score(context, n) from the dense
+   * table and moves the context on, decodeEnd adds lm.finish (:131-146): prev.lmScore + lmScore in path order */
+  const int2* tokLm;     /* DecodeParams::tokLm, or null */
+  int32_t tokLmStride;
+  int32_t blank;         /* CTC: the blank token; ASG: -1 */
 };
 
 /* A parent-pointer walk is a chain of T dependent loads; straight from HBM that
@@ -3765,6 +3782,9 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
     const int Tb = ff - 1; /* frames decoded: history rows 1 .. Tb */
     double am = 0.0;
     int prevTok = (tid < nh && len > 0) ? P.tokens[ob + (int64_t)tid * len] : 0;
+    double lmAcc = 0.0; /* token LM: the path's LM score ... */
+    int lmCtx = 0;      /* ... and context row (row 0 = lm.start) */
+    int lmPrev = prevTok;
     for (int lo = 1; lo <= Tb; lo += F) {
       const int hi = lo + F - 1 < Tb ? lo + F - 1 : Tb;
       const int nf = hi - lo + 1;
@@ -3852,10 +3872,28 @@ FLTX_DEV void backtraceUtterance(const BacktraceParams& P, char* smem) {
         } else {
           walk(SlParity<0>());
         }
+        if (P.tokLm) { /* a chain of dependent gathers, one per new-token step (a few hundred per path; rows shared by
+                          the paths of an n-best stay in the L1 / L2) */
+          for (int j = 0; j < nf; ++j) {
+            const int tk = tT[row + j];
+            if (tk >= 0) {
+              if (tk != lmPrev && tk != P.blank) {
+                const int2 e = P.tokLm[(size_t)lmCtx * (size_t)P.tokLmStride + (size_t)tk];
+                lmAcc = lmAcc + (double)__uint_as_float((uint32_t)e.x);
+                lmCtx = e.y;
+              }
+              lmPrev = tk;
+            }
+          }
+        }
       }
     }
     if (tid < nh) {
       P.amOut[((size_t)b * K + tid) * 3 + 1] = am;
+      if (P.tokLm) {
+        lmAcc = lmAcc + (double)__uint_as_float((uint32_t)P.tokLm[(size_t)lmCtx * (size_t)P.tokLmStride + (size_t)P.N].x);
+        P.amOut[((size_t)b * K + tid) * 3 + 2] = lmAcc;
+      }
     }
   }
 }

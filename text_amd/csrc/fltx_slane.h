@@ -70,7 +70,7 @@ struct SlRec { /* one LM state of the beam, 32 B */
   uint32_t info; /* last token | (parent lane + 1) << 8 | history slot of nb << 16 | of b << 24 */
   uint32_t sid;  /* state id = history index (row * K + slot) of the hypothesis that entered it */
   uint32_t spar; /* id of the parent state */
-  uint32_t pad;
+  uint32_t pad;  /* token-level n-gram LM (TL): the state's n-gram context = its row of DecodeParams::tokLm */
 };
 
 struct SlRow { /* what a frame needs to know about its emission row, 48 B */
@@ -110,6 +110,11 @@ struct SlaneLds {
   unsigned long long mmaxKey[2]; /* logAdd: order key of the best hypothesis of the beam a frame starts from */
   uint32_t scanMin, pad0;
   float raw[3][64]; /* emission rows on their way in: row r lands in raw[r % 3] two frames before it is staged */
+  /* token-level n-gram LM (TL): the frame's best candidate is a maximum over the candidates (no recurrence: the LM term
+   * differs per (state, token)), published per parity; and per lane the LM score its state was ENTERED with -- the
+   * parent state's extension by last(S) joins S's repeat group with exactly that term */
+  unsigned long long fbest[2];
+  float tlIn[2][64];
   /* Last members, streams only (ST): an offline launch takes offsetof(SlaneLds, amNB) bytes -- 16 KB, so that its
    * workgroup and a back-trace workgroup of the batch before (140 KB) fit a CU together */
   double amNB[2][64], amB[2][64]; /* emitting-model score of a state's two hypotheses */
@@ -449,9 +454,18 @@ FLTX_DEV double slLogAdd(double hi, double lo) { return hi + log1p(exp(lo - hi))
  * what changes is the frame's best candidate: a merged hypothesis can score above every candidate of its
  * frame, so the best hypothesis is not the last frame's best candidate any more -- the build publishes the
  * best surviving score and every wave prices the row with it at the head of the frame. */
-template <int GT, bool LA, bool ST, bool PROF>
+/* TL: a token-level n-gram LM (LexiconFreeDecoder.cpp:69-85 with KenLM::score, lm/KenLM.cpp:63-75).  LM states are still
+ * the trie of token histories (LMState::child, lm/LM.h:24-34), so lanes, merge groups and history records keep their
+ * shape; what changes: (1) every new-token candidate adds lmWeight x score(context of S, n), gathered from the dense
+ * table DecodeParams::tokLm by the lane's context row (SlRec::pad) -- the parent state's extension by last(S) adds the
+ * score S was entered with (SlaneLds::tlIn); (2) the frame's best candidate is no recurrence any more: every wave
+ * reduces its candidates to a maximum, one LDS atomic max per wave, one more barrier (the frame shape of fltx_ylane.h);
+ * (3) decodeEnd adds lmWeight x finish(context) (:127-158; column N of the row); (4) the LM score of a returned path is
+ * re-accumulated by the back-trace like the emitting-model score (new-token steps follow from the tokens alone). */
+template <int GT, bool LA, bool ST, bool PROF, bool TL = false>
 FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   static_assert(!(LA && ST), "streams with logAdd stay on the lane-per-slot step");
+  static_assert(!(TL && ST), "streams with a token LM stay on the generic engine");
   SlaneLds& S = *(SlaneLds*)smem;
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x, tid = (int)threadIdx.x;
@@ -493,6 +507,12 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   }
   if (tid < 16) {
     S.scal[tid] = 0u;
+  }
+  if (TL && tid < 2) {
+    S.fbest[tid] = 0ull;
+  }
+  if (TL && tid == 0) {
+    S.tlIn[0][0] = 0.0f; /* (the root state was not entered by a token) */
   }
   const int frame0 = ST ? P.uttFrame[b] : 0;   /* streams: rows already in the buffer */
   const int total0 = ST ? P.uttTotal[b] : 0;   /* ... frames decoded since decodeBegin */
@@ -613,11 +633,17 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   bool dead = false; /* this utterance goes to the general engines */
   const int sil = P.sil, blank = P.blank;
   double silScore = P.silScore;
+  double lmW = TL ? P.lmWeight : 0.0;
 #ifndef FLTX_EMU
   /* (kept in a vector register: the frame loop is short of scalar ones, and the compiler would rather load the option
    * from the kernel arguments again at each of its uses -- a scalar load and a full wait per candidate) */
   __asm__ volatile("" : "+v"(silScore));
+  if (TL) {
+    __asm__ volatile("" : "+v"(lmW));
+  }
 #endif
+  const int2* const tokLm = TL ? P.tokLm : nullptr;
+  const int tokStride = TL ? P.tokLmStride : 0;
   int2* const histPT = P.histPT;
 
   /* one frame; PT = parity of the frame (compile time: every LDS address is an immediate) */
@@ -634,7 +660,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const int nList = S.row[p].nList, silPos = S.row[p].silPos;
     uint32_t rowDead = S.row[p].dead;
     const uint32_t nev = S.row[p].nev;
-    if (LA) { /* best candidate = best hypothesis of the beam + best token (sil priced apart: silScore) */
+    if (LA && !TL) { /* best candidate = best hypothesis of the beam + best token (sil priced apart: silScore) */
       const double mmax = f64FromKey(S.mmaxKey[p]);
       const uint32_t ek = S.row[p].ekey;
       const double sS = (mmax + (double)S.row[p].esil) + silScore;
@@ -732,6 +758,29 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         parAmB = S.amB[p][pl >= 0 ? pl : 0];
       }
     }
+    /* token-level n-gram LM: the LM scores (and the contexts behind them) of this lane's state for the tokens of this
+     * wave's list positions -- one 8-byte gather per (lane, position) from the state's row of the dense table (rows of
+     * the states in the beam stay in the L1 / L2 from frame to frame); self wave: the score of last(S) after S (the
+     * blank-then-last candidate) and the score S was entered with (the parent state's extension by last(S)) */
+    int2 lmv[GT];
+    int2 lmLast = make_int2(0, 0);
+    float lIn = 0.0f;
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      lmv[j] = make_int2(0, 0);
+    }
+    if (TL && !isSvc) {
+      const int2* lrow = tokLm + (size_t)(live ? me.pad : 0u) * (size_t)tokStride;
+      if (isSelf) {
+        lmLast = lrow[live ? last : 0];
+        lIn = S.tlIn[p][lane];
+      } else {
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          lmv[j] = lrow[tb[j] != 0ull ? __builtin_ctzll(tb[j]) : 0];
+        }
+      }
+    }
     FLTX_SLPROF(0);
     double cs[GT];
     int cbin[GT];
@@ -750,14 +799,16 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       if (t + 1 < T) {
         ldsRowWait(); /* (issued two frames ago) */
         const float rv = lane < N ? S.raw[(t + 1) % 3][lane] : 0.0f;
-        nextRow = slRowScan(P, rv, ctc, bestChain, silScore);
+        nextRow = slRowScan(P, rv, ctc, TL ? 0.0 : bestChain, silScore); /* (TL: only whether the row is usable) */
         bestChain = nextRow.best;
       }
       ldsRowLoad(S.raw[t % 3], em + (size_t)(t + 3) * N + lane, t + 3 < T && lane < N); /* (row t's slot: read last frame) */
-      if (LA && lane == 0) {
+      if (LA && !TL && lane == 0) {
         S.mmaxKey[q] = 0ull; /* (this frame's build raises it) */
       }
       (void)rowReg;
+    } else if (TL) {
+      /* (the candidates of a token-LM frame: below, around the barrier that publishes the frame's best) */
     } else if (!isSelf) {
       /* tokens this lane does not extend with here: its own last token (the repeat and the
        * blank-then-last case belong to the self wave) and those whose child state holds a lane
@@ -873,6 +924,168 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       for (int j = 3; j < GT; ++j) {
         cs[j] = NEG;
         cbin[j] = kSlInvalid;
+      }
+    }
+    if constexpr (TL) {
+      /* ---- the same candidates with the LM term; the frame's best is their maximum (Utils.h:131-137) ---------- */
+      bool pre[GT];    /* the candidate exists (whether it passes the threshold is known after the barrier) */
+      double c2v[GT];  /* logAdd: the smaller member of the group */
+      bool hasOther = false;
+      bool lastOk = false, has0 = false, has1 = false, has2 = false;
+      double r0 = NEG, r1 = NEG, r2 = NEG;
+#pragma unroll
+      for (int j = 0; j < GT; ++j) {
+        pre[j] = false;
+        c2v[j] = NEG;
+        if (!isSvc) {
+          cs[j] = NEG;
+          cbin[j] = kSlInvalid;
+        }
+      }
+      if (isSvc) {
+      } else if (!isSelf) {
+        const uint32_t lastLo = last < 32 ? 1u << last : 0u, lastHi = last < 32 ? 0u : 1u << (last - 32);
+        const uint32_t skLo = live ? ((uint32_t)cm | lastLo) : 0xFFFFFFFFu;
+        const uint32_t skHi = live ? ((uint32_t)(cm >> 32) | lastHi) : 0xFFFFFFFFu;
+        const int silJ = silPos - wave * GT;
+        hasOther = (whichB ? hypNB : hypB) != kSlNoHyp;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          /* LexiconFreeDecoder.cpp:64-67,69-85: score = prev.score + e (+ silScore), candidate = score + lmWeight * lmScore */
+          const double wl = lmW * (double)__uint_as_float((uint32_t)lmv[j].x);
+          double c = m + ev[j]; /* NaN past the end of the list */
+          if (j == silJ) {
+            c = c + silScore;
+          }
+          c = c + wl;
+          const uint32_t hit = (skLo & (uint32_t)tb[j]) | (skHi & (uint32_t)(tb[j] >> 32));
+          pre[j] = hit == 0u && c == c;
+          if (LA) {
+            double c2 = (whichB ? nb : bb) + ev[j];
+            if (j == silJ) {
+              c2 = c2 + silScore;
+            }
+            c2v[j] = c2 + wl;
+          }
+          cs[j] = c;
+        }
+      } else {
+        lastOk = live && ((allow >> last) & 1ull) != 0ull && !(ctc && last == blank);
+        const bool lastSil = last == sil;
+        hasOther = (whichB ? hypNB : hypB) != kSlNoHyp;
+        /* (S, blank, true): :86-97, no LM term */
+        double cB = m + eBlank;
+        if (blank == sil) {
+          cB = cB + silScore;
+        }
+        pre[0] = ctc && live && ((allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB == cB;
+        if (LA) {
+          double cB2 = (whichB ? nb : bb) + eBlank;
+          if (blank == sil) {
+            cB2 = cB2 + silScore;
+          }
+          c2v[0] = cB2;
+        }
+        /* (S, last, false): the repeat (:98-110, no LM term) and the parent state's extension by last (:69-85: the LM
+         * score S was entered with) */
+        const int lastP = (int)(par.info & 0xFFu);
+        const uint32_t h1 = (par.info >> 16) & 0xFFu, h2 = par.info >> 24;
+        has0 = hypNB != kSlNoHyp;
+        has1 = pl >= 0 && last != lastP && h1 != kSlNoHyp;
+        has2 = pl >= 0 && ctc && h2 != kSlNoHyp;
+        const bool hasB = hypB != kSlNoHyp;
+        const double wIn = lmW * (double)lIn, wL = lmW * (double)__uint_as_float((uint32_t)lmLast.x);
+        r0 = nb + eLast;
+        r1 = par.nb + eLast;
+        r2 = par.b + eLast;
+        double cL = bb + eLast; /* (S.last, last, false) from (S, blank, true) when no lane holds S.last */
+        if (silScore != 0.0) {
+          r0 = lastSil ? r0 + silScore : r0;
+          r1 = lastSil ? r1 + silScore : r1;
+          r2 = lastSil ? r2 + silScore : r2;
+          cL = lastSil ? cL + silScore : cL;
+        }
+        r1 = has1 ? r1 + wIn : NEG;
+        r2 = has2 ? r2 + wIn : NEG;
+        cL = cL + wL;
+        double cR = r0;
+        parR = hypNB;
+        const bool t1 = has1 & ((r1 > cR) | ((r1 == cR) & (h1 < parR)));
+        cR = t1 ? r1 : cR;
+        parR = t1 ? h1 : parR;
+        const bool t2 = has2 & ((r2 > cR) | ((r2 == cR) & (h2 < parR)));
+        cR = t2 ? r2 : cR;
+        parR = t2 ? h2 : parR;
+        pre[1] = lastOk && (has0 || has1 || has2) && cR == cR;
+        pre[2] = ctc && lastOk && hasB && ((cm >> last) & 1ull) == 0ull && cL == cL;
+        cs[0] = cB;
+        cs[1] = cR;
+        cs[2] = cL;
+      }
+      {
+        unsigned long long k = 0ull;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          const unsigned long long kj = pre[j] ? f64Key(cs[j]) : 0ull;
+          k = kj > k ? kj : k;
+        }
+        if (waveBallot(k != 0ull) != 0ull) {
+          k = waveMax64(k);
+          if (lane == 0) {
+            atomMax64(&S.fbest[p], k);
+          }
+        }
+      }
+      if (wave == 0 && lane == 0) {
+        S.fbest[q] = 0ull; /* (the next frame's; last read a frame ago) */
+      }
+      ldsBarrier(); /* 0: the frame's best candidate */
+      {
+        const unsigned long long bk = S.fbest[p];
+        best = f64FromKey(bk);
+        thr = best - P.beamThreshold;
+        if (bk == 0ull || !(best - best == 0.0)) { /* no candidate at all, or not finite: the general engines */
+          dead = true;
+          return;
+        }
+      }
+      if (isSvc) {
+      } else if (!isSelf) {
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          const bool ok = pre[j] && cs[j] >= thr;
+          if (LA && ok && hasOther && c2v[j] >= thr) {
+            cs[j] = slLogAdd(cs[j], c2v[j]);
+          }
+          cbin[j] = ok ? slBin<LA>(best, cs[j], winShift, winBase) : kSlInvalid;
+        }
+      } else {
+        const bool okB = pre[0] && cs[0] >= thr;
+        if (LA && okB && hasOther && c2v[0] >= thr) {
+          cs[0] = slLogAdd(cs[0], c2v[0]);
+        }
+        bool okR = pre[1] && cs[1] >= thr;
+        if (LA) {
+          const bool v0 = has0 && r0 >= thr, v1 = has1 && r1 >= thr, v2 = has2 && r2 >= thr;
+          okR = lastOk && (v0 || v1 || v2);
+          double a = v0 ? r0 : NEG, bq = v1 ? r1 : NEG, cq = v2 ? r2 : NEG;
+          double t0 = a > bq ? a : bq, t1 = a > bq ? bq : a;
+          const double hi = t0 > cq ? t0 : cq;
+          const double mid = t0 > cq ? (t1 > cq ? t1 : cq) : t0;
+          const double lo = t0 > cq ? (t1 > cq ? cq : t1) : t1;
+          double accv = hi;
+          if (mid > NEG) {
+            accv = slLogAdd(accv, mid);
+          }
+          if (lo > NEG) {
+            accv = slLogAdd(accv, lo);
+          }
+          cs[1] = okR ? accv : cs[1];
+        }
+        const bool okL = pre[2] && cs[2] >= thr;
+        cbin[0] = okB ? slBin<LA>(best, cs[0], winShift, winBase) : kSlInvalid;
+        cbin[1] = okR ? slBin<LA>(best, cs[1], winShift, winBase) : kSlInvalid;
+        cbin[2] = okL ? slBin<LA>(best, cs[2], winShift, winBase) : kSlInvalid;
       }
     }
     if (wave == 0) { /* housekeeping for everybody: what this frame's build adds to */
@@ -1083,7 +1296,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         atomAdd32(&S.off[lane], (uint32_t)nNewWave);
       }
     }
-    if (LA && !isSvc) { /* the best hypothesis of the next beam */
+    if (LA && !TL && !isSvc) { /* the best hypothesis of the next beam */
       unsigned long long k = 0ull;
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
@@ -1113,7 +1326,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         hs[2] = 0.0;
       }
     };
-    auto newState = [&](int idx, double c, int n, uint32_t hp, double amNew) {
+    auto newState = [&](int idx, double c, int n, uint32_t hp, double amNew, uint32_t ctxNew, float lNew) {
       const int nl = nSurv + idx;
       const uint32_t hyp = (uint32_t)(nHSurv + idx);
       SlRec r;
@@ -1122,7 +1335,10 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       r.info = (uint32_t)n | ((uint32_t)(myNewLane + 1) << 8) | (hyp << 16) | (kSlNoHyp << 24);
       r.sid = (uint32_t)frameOut * (uint32_t)K + hyp;
       r.spar = me.sid;
-      r.pad = 0u;
+      r.pad = TL ? ctxNew : 0u; /* (a function of the token history: a state entered again gets the context it had) */
+      if (TL) {
+        S.tlIn[q][nl] = lNew;
+      }
       const bool again = ((mk >> n) & 1ull) != 0ull; /* this edge had a child before */
       if (ST) {
         uint32_t* slot = &P.childTab[((size_t)b * P.idCap + me.sid) * N + n];
@@ -1168,7 +1384,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
           if ((selMask[j] >> lane) & 1ull) {
             /* (the position's token from its bit: reading tokId here is an LDS round trip per surviving position) */
             const int nTok = tb[j] != 0ull ? __builtin_ctzll(tb[j]) : 0;
-            newState(offW + myNew[j], cs[j], nTok, hypM, ST ? amStep(amM, ev[j], nTok, whichB ? blank : last) : 0.0);
+            newState(offW + myNew[j], cs[j], nTok, hypM, ST ? amStep(amM, ev[j], nTok, whichB ? blank : last) : 0.0,
+                     (uint32_t)lmv[j].y, __uint_as_float((uint32_t)lmv[j].x));
           }
         }
       }
@@ -1183,8 +1400,11 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
                  ((sB ? hB : kSlNoHyp) << 24);
         r.sid = me.sid;
         r.spar = me.spar;
-        r.pad = 0u;
+        r.pad = TL ? me.pad : 0u;
         S.rec[q][surv] = r;
+        if (TL) {
+          S.tlIn[q][surv] = lIn;
+        }
         if (mk) {
           atomOr64(&S.mask[q][surv], mk);
         }
@@ -1214,7 +1434,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
       if ((selMask[2] >> lane) & 1ull) {
-        newState(offW + myNew[2], cs[2], last, hypB, ST ? amStep(amBv, eLast, last, blank) : 0.0);
+        newState(offW + myNew[2], cs[2], last, hypB, ST ? amStep(amBv, eLast, last, blank) : 0.0, (uint32_t)lmLast.y,
+                 __uint_as_float((uint32_t)lmLast.x));
       }
     }
     nState = nSurv + nNew;
@@ -1341,13 +1562,22 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const bool whichB = bb > nb;
     double m = whichB ? bb : nb;
     const uint32_t hp = whichB ? (me.info >> 24) : ((me.info >> 16) & 0xFFu);
-    if (LA) { /* the best candidate of decodeEnd is the best hypothesis of the final beam */
+    double wFin = 0.0;
+    if (TL) {
+      /* lm->finish(state) (KenLM.cpp:77-83: the score of </s> in the state's context, a new state per state): both
+       * hypotheses of a state add the same term; the best candidate of decodeEnd is a maximum again */
+      wFin = lmW * (double)__uint_as_float((uint32_t)tokLm[(size_t)(live ? me.pad : 0u) * (size_t)tokStride + (size_t)N].x);
+      m = m + wFin;
+      const bool has = live && hp != kSlNoHyp && m == m;
+      const unsigned long long k = waveMax64(has ? f64Key(m) : 0ull);
+      endBest = k != 0ull ? f64FromKey(k) : 0.0;
+    } else if (LA) { /* the best candidate of decodeEnd is the best hypothesis of the final beam */
       endBest = f64FromKey(S.mmaxKey[pe]);
     }
     const double thr = endBest - P.beamThreshold;
-    const bool ok = live && m >= thr;
+    const bool ok = live && m >= thr && (!TL || hp != kSlNoHyp);
     if (LA && ok) { /* the state's two hypotheses finish into one (LexiconFreeDecoder.cpp:127-158) */
-      const double lo = whichB ? nb : bb;
+      const double lo = TL ? (whichB ? nb : bb) + wFin : (whichB ? nb : bb);
       const uint32_t hl = whichB ? ((me.info >> 16) & 0xFFu) : (me.info >> 24);
       if (hl != kSlNoHyp && lo >= thr) {
         m = slLogAdd(m, lo);
@@ -1366,7 +1596,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       const size_t g = ((size_t)b * K + rank) * 3;
       P.outScores[g + 0] = m;
       P.outScores[g + 1] = 0.0; /* emitting-model score: the back-trace kernel fills it in */
-      P.outScores[g + 2] = 0.0; /* ZeroLM */
+      P.outScores[g + 2] = 0.0; /* ZeroLM; a token LM's score is re-accumulated by the back-trace kernel as well */
       P.histPT[hbase + (int64_t)ff * K + rank] = make_int2((int)hp, P.sil);
     }
     if (lane == 0) {
