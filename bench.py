@@ -648,6 +648,9 @@ def phase_profile(a, dec, job, step, B, T):
         if eng == 4:  # fltx_slane.h
             names = ["loads", "candidates+hist", "bar1+scan+select", "new-lane counts", "bar2+build", "bar3",
                      "(frames ranking the boundary bin)", "(members of that bin)"]
+        if eng == 4 and dec.get("tlane"):  # ... its token-LM variant
+            names = ["loads (LM gathers issued)", "bar0+bins+hist", "bar1+scan+select", "new-lane counts", "bar2+build", "bar3",
+                     "re-entry", "candidates+LM wait+max"]
         if eng == 5:  # fltx_xlane.h (the last column is not clocks: per frame, boundary-bin rankings + 1e3 x
             # narrowed histogram passes + 1e6 x far-candidate counts)
             names = ["loads", "candidates+best", "barA+verdicts+hist", "bar1+scan+select", "new-lane counts",
@@ -659,7 +662,7 @@ def phase_profile(a, dec, job, step, B, T):
         pr = pr[order]
         tot = pr[:8].sum()
         line = "wave %d phase split (shader clocks, %% of %.3g): " % (pw, tot) + ", ".join(
-            ("%s %.3f" if n == "select paths" or n.startswith("(") else "%s %.0f") % (n, v / (B * T)) for n, v in zip(names, pr[:8])) + \
+            ("%s %.3f" if n == "select paths" or n.startswith("(fr") or n.startswith("(mem") or n.startswith("(word") else "%s %.0f") % (n, v / (B * T)) for n, v in zip(names, pr[:8])) + \
             " | clocks/frame/utt %.0f\n" % (tot / (B * T))
         sys.stderr.write(line)
         if a.profile_out:

@@ -309,7 +309,22 @@ static inline int keyCompare(const Hyp& a, const Hyp& b) {
   return 0;
 }
 
+/* Where the reference stops being a function of its inputs: it orders candidates with std::sort /
+ * std::nth_element / std::partial_sort over pointers, so which of several EQUAL-scoring candidates is kept, or comes
+ * first, depends on addresses.  This restatement counts every such place it passes, so that a test can tell "the input
+ * had a tie" (either answer is the reference's) from "the oracle is wrong" (never excusable):
+ *   merge : two candidates of one merge group with the same score (Utils.h:176-198: the survivor keeps the
+ *           parent / emitting-model / LM fields of whichever the sort put first);
+ *   cut   : the K-th and the (K+1)-th best merged candidate score the same (nth_element, Utils.h:206-214);
+ *   order : equal scores inside the sorted final n-best (partial_sort in decodeEnd, Utils.h:216-220);
+ *   token : an emission equal to the smallest one kept by the token beam (partial_sort, LexiconFreeDecoder.cpp:42-51);
+ *   best  : two hypotheses share the best score where one is picked (findBestAncestor, Utils.h:268-283). */
+struct TieCounts {
+  long long merge = 0, cut = 0, order = 0, token = 0, best = 0;
+};
+
 struct Candidates {
+  TieCounts* ties = nullptr;
   double best = kNegInf;
   std::vector<Hyp> cands;
   std::vector<Hyp*> ptrs;
@@ -346,10 +361,15 @@ struct Candidates {
       return c == 0 ? a->score > b->score : c > 0;
     });
     size_t n = 1;
+    double groupTop = ptrs.empty() ? 0.0 : ptrs[0]->score; /* the score of the group's best member (its first) */
     for (size_t i = 1; i < ptrs.size(); ++i) {
       if (keyCompare(*ptrs[i], *ptrs[n - 1]) != 0) {
         ptrs[n++] = ptrs[i];
+        groupTop = ptrs[i]->score;
       } else {
+        if (ties && ptrs[i]->score == groupTop) {
+          ++ties->merge; /* (which of the two lends its back-pointer and scores is the sort's choice) */
+        }
         double mx = std::max(ptrs[n - 1]->score, ptrs[i]->score);
         if (logAdd) {
           double mn = std::min(ptrs[n - 1]->score, ptrs[i]->score);
@@ -364,6 +384,18 @@ struct Candidates {
     auto byScore = [](const Hyp* a, const Hyp* b) { return a->score > b->score; };
     int nValid = (int)ptrs.size();
     int finalSize = std::min(nValid, beamSize);
+    if (ties && nValid > beamSize && beamSize > 0) { /* equal scores across the cut */
+      std::vector<double> sc(ptrs.size());
+      for (size_t i = 0; i < ptrs.size(); ++i) {
+        sc[i] = ptrs[i]->score;
+      }
+      std::nth_element(sc.begin(), sc.begin() + beamSize, sc.end(), std::greater<double>());
+      const double firstOut = sc[beamSize];
+      const double lastIn = *std::min_element(sc.begin(), sc.begin() + beamSize);
+      if (firstOut == lastIn) {
+        ++ties->cut;
+      }
+    }
     if (!returnSorted && nValid > beamSize) {
       std::nth_element(ptrs.begin(), ptrs.begin() + finalSize, ptrs.end(), byScore);
     } else if (returnSorted) {
@@ -371,6 +403,9 @@ struct Candidates {
     }
     for (int i = 0; i < finalSize; ++i) { // 4. (:222-224)
       out.push_back(*ptrs[i]);
+      if (ties && returnSorted && i > 0 && ptrs[i]->score == ptrs[i - 1]->score) {
+        ++ties->order;
+      }
     }
   }
 };
@@ -390,10 +425,13 @@ struct DecoderO {
   std::vector<float> transitions;
   StateArena states;
   Candidates cand;
+  mutable TieCounts ties;
   std::vector<std::vector<Hyp>> hyp; // hyp[frame][slot]
   int nDecoded = 0, nPruned = 0;
   bool lexicon = false;
 
+  DecoderO() { cand.ties = &ties; }
+  DecoderO(const DecoderO&) = delete;
   virtual ~DecoderO() = default;
   virtual void begin() = 0;
   virtual void step(const float* e, int T, int N) = 0;
@@ -452,6 +490,12 @@ struct DecoderO {
       if (fin[r].score > bestScore) {
         bestScore = fin[r].score;
         bestSlot = r;
+      }
+    }
+    for (int r = 0; r < (int)fin.size(); ++r) {
+      if (r != bestSlot && fin[r].score == bestScore) {
+        ++ties.best; /* (the reference takes the first in ITS order of the beam, which nth_element left unspecified) */
+        break;
       }
     }
     int f = finalFrame, s = bestSlot, n = 0;
@@ -555,6 +599,15 @@ struct DecoderO {
     if (N > opt.beam_size_token) {
       std::partial_sort(idx.begin(), idx.begin() + opt.beam_size_token, idx.end(),
                         [row](size_t l, size_t r) { return row[l] > row[r]; });
+      if (opt.beam_size_token > 0) {
+        const float lastIn = row[idx[opt.beam_size_token - 1]];
+        for (int i = opt.beam_size_token; i < N; ++i) {
+          if (row[idx[i]] == lastIn) {
+            ++ties.token;
+            break;
+          }
+        }
+      }
     }
   }
 };
@@ -1044,6 +1097,20 @@ int32_t ORC_FN(decoder_get_best)(void* dec, int32_t look_back, double* scores,
   }
   copyResult(r, scores, tokens, words);
   return (int32_t)r.tokens.size();
+}
+
+/* ties the decoder has passed since it was created (or since the last call with reset != 0): out[0..4] = merge, cut,
+ * order, token, best (see TieCounts).  Oracle only: the reference build has no such counters. */
+void orc_decoder_ties(void* dec, int64_t* out, int32_t reset) {
+  DecoderO* d = (DecoderO*)dec;
+  out[0] = d->ties.merge;
+  out[1] = d->ties.cut;
+  out[2] = d->ties.order;
+  out[3] = d->ties.token;
+  out[4] = d->ties.best;
+  if (reset) {
+    d->ties = TieCounts();
+  }
 }
 
 } // extern "C"

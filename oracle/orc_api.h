@@ -104,6 +104,12 @@ int32_t ORC_FN(decoder_get_best)(void* dec, int32_t look_back, double* scores,
                                  int32_t* tokens, int32_t* words,
                                  int32_t capacity);
 
+/* ORACLE ONLY (no ref_ twin: the reference has no such counters).  Ties the decoder has passed since it was created
+ * or since the last call with reset != 0 -- the places where the reference's answer depends on addresses (oracle.cpp
+ * TieCounts): out[0] merge, [1] cut, [2] order, [3] token, [4] best.  A parity mismatch on an input for which all five
+ * are zero is a bug, never "a tie". */
+void orc_decoder_ties(void* dec, int64_t* out, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

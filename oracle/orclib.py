@@ -97,6 +97,9 @@ class CheckerLib:
             fn = getattr(L, prefix + name)
             fn.restype, fn.argtypes = res, args
             setattr(self, name, fn)
+        if prefix == "orc_":
+            L.orc_decoder_ties.restype = None
+            L.orc_decoder_ties.argtypes = [vp, C.POINTER(C.c_int64), i32]
         if prefix == "ref_":
             L.ref_lexicon_dump.restype = C.c_void_p
             L.ref_lexicon_dump.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, i32]
@@ -132,6 +135,17 @@ class CheckerLib:
         return [Hyp(scores[3 * i], scores[3 * i + 1], scores[3 * i + 2],
                     tokens[i].copy(), words[i].copy()) for i in range(n)]
 
+    TIE_KINDS = ("merge", "cut", "order", "token", "best")
+
+    def ties(self, dec, reset=False):
+        """{kind: count} of the ties the ORACLE's decoder has passed (oracle.cpp TieCounts): the places where the
+        reference's answer depends on addresses.  None for the compiled reference (it cannot know)."""
+        if self.prefix != "orc_":
+            return None
+        out = (C.c_int64 * 5)()
+        self.lib.orc_decoder_ties(dec, out, int(reset))
+        return dict(zip(self.TIE_KINDS, [int(v) for v in out]))
+
     def best(self, dec, look_back, capacity):
         scores = np.zeros(3, dtype=np.float64)
         tokens = np.zeros(capacity, dtype=np.int32)
@@ -146,6 +160,7 @@ class CheckerLib:
         self.decoder_begin(dec)
         self.decoder_step(dec, _fp(e), T, N)
         self.decoder_end(dec)
+        self.last_ties = self.ties(dec)  # (oracle: what the decode passed; the n-best's `order` ties included)
         return self.collect(dec)
 
     def lexfree(self, opt, lm, sil, blank, transitions=None):

@@ -116,6 +116,23 @@ CASES = [
          lm=("lastword", 9), lm_weight=0.9, word_score=0.5, is_lm_token=True),
     case("hl_lastword_asg", dist="ctc", T=40, N=29, K=8, Kt=7, crit="asg", trans_seed=14, u=25,
          lm=("lastword", 10), lm_weight=0.6, is_lm_token=True),
+    # ---- round 6: thick n-bests (>= 8 reference hypotheses) for the features whose first fixtures hold one to five
+    # (round-5 review, weak #1), every one free of ties as the oracle's counters see them (oracle.cpp TieCounts)
+    case("lx_spell_t60_k32_logadd", kind="lexicon", dist="lexspell", T=60, K=32, lexicon=SMALL_LEX, u=101, log_add=True),
+    case("lx_spell_t60_k32_full", kind="lexicon", dist="lexspell", T=60, K=32, lexicon=SMALL_LEX, u=101),
+    case("ng_word_t40_k32", kind="lexicon", dist="lexspell", T=40, K=32, lexicon=SMALL_LEX, u=101,
+         lm=("ngram", 3, 7), lm_weight=1.3, word_score=0.7, sil_score=-0.2),
+    case("ng_word_logadd_t40_k32", kind="lexicon", dist="lexspell", T=40, K=32, lexicon=SMALL_LEX, u=100,
+         lm=("ngram", 3, 10), lm_weight=1.0, word_score=1.0, log_add=True),
+    case("ml_word_uni_t50_k48_thick", kind="lexicon", dist="uniform", T=50, K=48, lexicon=MULTI_LEX, u=102,
+         lm=("ngram", 4, 42), lm_weight=1.0, word_score=1.5),
+    case("ml_word_asg_t40_k48", kind="lexicon", dist="lexspell", T=40, K=48, lexicon=MULTI_NODUP_LEX, crit="asg",
+         trans_seed=23, u=101, lm=("ngram", 3, 43), lm_weight=1.1, word_score=0.5),
+    # a token-level n-gram LM on the lexicon-free decoder (fltx_slane.h's token-LM variant): logAdd, ASG
+    case("ng_tok_lexfree_logadd_k16", dist="ctc", T=40, K=16, Kt=12, u=100, lm=("ngram", 3, 11), lm_weight=0.8,
+         log_add=True),
+    case("ng_tok_lexfree_asg_k16", dist="ctc", T=40, K=16, u=100, crit="asg", trans_seed=15, lm=("ngram", 4, 12),
+         lm_weight=1.2, sil_score=-0.3),
     # ---- lexicon decoder, BASELINE shapes -------------------------------------
     case("C3_spell_u0", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, size="large"),
     case("C3_spell_u255", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, u=255,
@@ -128,6 +145,8 @@ CASES = [
          lm=("ngram", 4, 4242), lm_weight=2.0, word_score=2.0, sil_score=-1.0),
     case("C4_spell_u255", kind="lexicon", dist="lexspell", T=1500, K=100, lexicon=FULL_LEX, size="large",
          u=255, lm=("ngram", 4, 4242), lm_weight=2.0, word_score=2.0, sil_score=-1.0),
+    case("C4_spell_u1", kind="lexicon", dist="lexspell", T=1500, K=100, lexicon=FULL_LEX, size="large",
+         u=1, lm=("ngram", 4, 4242), lm_weight=2.0, word_score=2.0, sil_score=-1.0),  # (24 reference hypotheses; u0 has 5)
 ]
 
 BY_NAME = {c["name"]: c for c in CASES}

@@ -439,6 +439,7 @@ struct fltx_decoder {
   int tlane = 0, noTlane = 0, tlaneFirst = 0;
   const int2* tokLm = nullptr;
   int64_t tokLmCtx = 0;
+  int tlEdgeSlots = 4096, tlMaskSlots = 2048;
   bool tokLmTooBig = false; /* the model has more contexts than a dense table holds (why_not_lane: LM) */
   /* ... with several lane groups (fltx_mlane.h, beams beyond 64): lane groups (0 / 1 = fltx_slane.h), groups per token
    * wave, groups per self wave; userLaneGroups: tuning / tests, 0 = as many as the beam needs, -1 = never */
@@ -1857,6 +1858,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         if (nList <= g[1] * (g[0] / 64 - 2)) {
           d->slane = g[1];
           d->tlane = 1;
+          /* the re-entry memos in LDS: 4 096 edges + 2 048 child masks (75 KB: two workgroups fit a CU) when the batch
+           * has more utterances than CUs, twice as many of both (131 KB) when a workgroup has the CU to itself */
+          const bool shareCu = B > d->ctx->numCUs || (d->deferCheck && g[0] == 512); /* (defer_check: the caller keeps two batches in flight) */
+          d->tlEdgeSlots = shareCu ? 4096 : 8192;
+          d->tlMaskSlots = shareCu ? 2048 : 4096;
           d->tokLm = tab;
           d->tokLmCtx = nCtx;
           d->threads = g[0];
@@ -2244,6 +2250,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
                  : d->mlaneNG == 2 ? sizeof(MlaneLds<2>)
                  : d->mlaneNG == 4 ? sizeof(MlaneLds<4>)
                  : d->mlaneNG == 8 ? sizeof(MlaneLds<8>)
+                 : d->tlane        ? sizeof(TlaneLds) + 8 * (size_t)d->tlEdgeSlots + 12 * (size_t)d->tlMaskSlots
                                    : offsetof(SlaneLds, amNB); /* (the stream variant's arrays are its last members) */
     d->wsInLds = true;
     lds = true;
@@ -2476,6 +2483,8 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.lmCache = d->useLmCache ? d->lmCache.as<unsigned long long>() : nullptr;
   P.tokLm = d->tlane ? d->tokLm : nullptr;
   P.tokLmStride = d->N + 1;
+  P.tlEdgeSlots = d->tlEdgeSlots;
+  P.tlMaskSlots = d->tlMaskSlots;
   P.yBound = d->trie ? std::max(0.0, std::max(d->opt.lm_weight * (double)d->trie->xDeltaMin,
                                               d->opt.lm_weight * (double)d->trie->xDeltaMax))
                      : 0.0;
@@ -2552,9 +2561,19 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
 #define FLTX_LAUNCH_SLANE(WW, GG)                                                                \
   do {                                                                                           \
     if (d->tlane && d->opt.log_add) {                                                            \
+      HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_tlane<WW, GG, true>,            \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));  \
       hipLaunchKernelGGL((fltx_decode_kernel_tlane<WW, GG, true>), dim3(nGrid), dim3(WW),        \
                          d->wsBytes, d->ctx->stream, P);                                         \
+    } else if (d->tlane && d->profile && ((WW == 576 && GG == 4) || (WW == 512 && GG == 5))) {   \
+      constexpr int PW_ = (WW == 576 && GG == 4) ? 576 : 512, PG_ = (WW == 576 && GG == 4) ? 4 : 5; \
+      HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_tlane<PW_, PG_, false, true>,   \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));  \
+      hipLaunchKernelGGL((fltx_decode_kernel_tlane<PW_, PG_, false, true>), dim3(nGrid), dim3(PW_), \
+                         d->wsBytes, d->ctx->stream, P);                                         \
     } else if (d->tlane) {                                                                       \
+      HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_tlane<WW, GG, false>,           \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));  \
       hipLaunchKernelGGL((fltx_decode_kernel_tlane<WW, GG, false>), dim3(nGrid), dim3(WW),       \
                          d->wsBytes, d->ctx->stream, P);                                         \
     } else if (d->opt.log_add) {                                                                        \

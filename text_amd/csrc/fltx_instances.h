@@ -51,7 +51,9 @@
   FLTX_INST(fltx_decode_kernel_tlane<640, 4, LA>)              \
   FLTX_INST(fltx_decode_kernel_tlane<512, 12, LA>)             \
   FLTX_INST(fltx_decode_kernel_tlane<576, 10, LA>)
-#define FLTX_G28(W) FLTX_TLANE_SET(false)
+#define FLTX_G28(W) FLTX_TLANE_SET(false)                     \
+  FLTX_INST(fltx_decode_kernel_tlane<576, 4, false, true>)    \
+  FLTX_INST(fltx_decode_kernel_tlane<512, 5, false, true>) /* (phase clocks: bench.py --profile) */
 #define FLTX_G29(W) FLTX_TLANE_SET(true) /* logAdd */
 #define FLTX_G16(W) /* stream chunks */                     \
   FLTX_INST(fltx_decode_kernel_slane_stream<576, 4>)         \

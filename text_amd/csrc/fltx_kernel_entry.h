@@ -52,10 +52,12 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_slane(DecodeParams P) {
   slaneUtterance<GT, LA, false, PROF>(P, fltx_smem);
 }
 /* ... with a token-level n-gram LM flattened to a dense (context, token) table (TL) */
-template <int W, int GT, bool LA>
-__global__ void __launch_bounds__(W) fltx_decode_kernel_tlane(DecodeParams P) {
+/* (512 threads: the geometry of which two workgroups share a CU -- 75 KB of LDS each with the small memos, and at most
+ * 128 VGPRs: four waves per SIMD) */
+template <int W, int GT, bool LA, bool PROF = false>
+__global__ void __launch_bounds__(W, W == 512 && GT == 5 ? 4 : 1) fltx_decode_kernel_tlane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  slaneUtterance<GT, LA, false, false, true>(P, fltx_smem);
+  slaneUtterance<GT, LA, false, PROF, true>(P, fltx_smem);
 }
 /* ... with NG groups of 64 lanes: beams 65 .. 64 * NG (fltx_mlane.h) */
 template <int W, int GT, int NG, int GPW, int SPW, bool LA>

@@ -203,6 +203,7 @@ struct DecodeParams {
    * built on the host from the same flat tables ngScore walks (buildTokDense, fltx_api.cpp) */
   const int2* tokLm;
   int32_t tokLmStride;          /* N + 1 */
+  int32_t tlEdgeSlots, tlMaskSlots; /* ... its LDS memos (TlaneLds::memo): slots of the edge and of the child-mask memo, powers of two */
   int32_t wsNoInv;              /* HBM workspace of the generic step (hot level >= 1): no L1 invalidate after its barriers (wsBarrier) */
   int32_t* statusHost;          /* optimistic stream chunks: uttStatus mirrored in pinned host memory (read after the kernel, no copy) */
   const int32_t* xlmword;       /* ... LM word id of the word a node's separator child carries (n-gram LM), or null */

@@ -51,6 +51,7 @@
  * Three barriers per frame.
  */
 #pragma once
+#include <type_traits>
 
 constexpr int kSlNB = 256;          /* histogram bins: 4 per lane of the scan */
 constexpr int kSlMid = kSlNB / 2;   /* where the window puts the last frame's K-th best */
@@ -121,6 +122,55 @@ struct SlaneLds {
   uint8_t rsNB[64], rsB[64];      /* restore: the parked slot of a lane's two hypotheses */
 };
 enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2, SL_NEXTID = 3, SL_STATUS = 4, SL_NSTATE = 5 };
+
+/* Token-LM variant (TL): with LM terms the beam turns over faster -- on the benchmark's `ctc` inputs a state that had
+ * dropped out is entered again in three frames of ten (one in a hundred under ZeroLM), and a scan of the history rows
+ * per re-entry was 90 % of the kernel (24.9 ms per 256 x 1 000 frames).  LMState::child's memo (lm/LM.h:24-34) is
+ * therefore ALSO kept where it is cheap to ask, exact or absent, the rows staying the authority behind it:
+ *   edge[]  : the newest (parent state id, token) -> state id edges, direct-mapped (the slot holds the whole key: a hit
+ *             is exact); written at every creation of a state;
+ *   mmTag / mmMask : the child mask a state had when it last dropped out of the beam (nothing can add an edge to a state
+ *             that is not in the beam), direct-mapped by state id; written one frame after the drop by the first token
+ *             wave, together with the edges the state's last extension created (`dmask`).
+ * A miss in either sends that one event to the rows (tlReenter). */
+constexpr uint32_t kTlNoSid = 0xFFFFFFFFu;
+struct TlaneLds : SlaneLds {
+  unsigned long long dmask[64];          /* old lane -> tokens whose child state this frame's build created from it */
+  uint32_t evSid[64];                    /* re-entry event: the state's id when the edge memo had it, else kTlNoSid */
+  uint32_t evNeed[64];                   /* ... bit 0: look the id up in the rows, bit 1: the child mask */
+  /* the memos, sized by the host (DecodeParams::tlEdgeSlots / tlMaskSlots, powers of two: larger when one workgroup
+   * has the CU's LDS to itself): edge[E] (bit 63 | parent id:23 << 37 | token:14 << 23 | state id:23), mmMask[M],
+   * mmTag[M] (state id, kTlNoSid = empty) */
+  unsigned long long memo[1];
+};
+struct TlMemo {
+  unsigned long long* edge;
+  unsigned long long* mmMask;
+  uint32_t* mmTag;
+  uint32_t eMask, mMask;
+};
+FLTX_DEV TlMemo tlMemoOf(TlaneLds& S, int edgeSlots, int maskSlots) {
+  TlMemo m;
+  m.edge = S.memo;
+  m.mmMask = S.memo + edgeSlots;
+  m.mmTag = (uint32_t*)(S.memo + edgeSlots + maskSlots);
+  m.eMask = (uint32_t)(edgeSlots - 1);
+  m.mMask = (uint32_t)(maskSlots - 1);
+  return m;
+}
+FLTX_DEV uint32_t tlHash(uint32_t a, uint32_t b) {
+  uint32_t h = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u) ^ 0x5bd1e995u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  return h;
+}
+FLTX_DEV unsigned long long tlEdgePack(uint32_t psid, uint32_t tok, uint32_t csid) {
+  return (1ull << 63) | ((unsigned long long)(psid & 0x7FFFFFu) << 37) | ((unsigned long long)(tok & 0x3FFFu) << 23) |
+         (unsigned long long)(csid & 0x7FFFFFu);
+}
+FLTX_DEV uint32_t tlEdgeSlot(const TlMemo& M, uint32_t psid, uint32_t tok) { return tlHash(psid, tok) & M.eMask; }
+FLTX_DEV uint32_t tlMaskSlot(const TlMemo& M, uint32_t sid) { return tlHash(sid, 0x51u) & M.mMask; }
 
 FLTX_DEV double slNegInf() { return -__builtin_huge_val(); }
 
@@ -436,6 +486,137 @@ FLTX_DEV __attribute__((noinline)) void slRelink(SlaneLds& S, const unsigned lon
   ldsBarrier();
 }
 
+/* Re-entry with the memos of TlaneLds: what they know is applied by one thread per event, what they do not know is
+ * looked up in the history rows as slReenter does (per event, rare), then every lane looks for its parent among the
+ * re-entered states at once. */
+FLTX_DEV __attribute__((noinline)) void tlReenter(TlaneLds& S, const int2* histPT, int q, int nState, int64_t hbase,
+                                                   int64_t nRec, int edgeSlots, int maskSlots) {
+  const TlMemo M = tlMemoOf(S, edgeSlots, maskSlots);
+  const int tid = (int)threadIdx.x, W = (int)blockDim.x;
+  const int nev = (int)(S.row[q].nev & 0xFFFFu); /* (the upper half: how many of them the memos do not answer) */
+  ldsBarrier(); /* (everybody has the count; the masks saved at the head of this frame are visible) */
+  if (tid < nev) {
+    const int X = (int)S.evLane[tid];
+    const uint32_t sid = S.evSid[tid];
+    uint32_t need = 3u;
+    if (sid != kTlNoSid) {
+      const uint32_t ms = tlMaskSlot(M, sid);
+      need = 2u;
+      if (M.mmTag[ms] == sid) {
+        S.mask[q][X] |= M.mmMask[ms]; /* (one event per lane: nobody else writes this word here) */
+        need = 0u;
+      }
+    }
+    S.evNeed[tid] = need;
+  }
+  ldsBarrier();
+  bool settled = false; /* this wave's history stores of the last build have reached the L2 (the look-ups read them) */
+  for (int e = 0; e < nev; ++e) {
+    const uint32_t need = S.evNeed[e]; /* (uniform) */
+    if (need == 0u) {
+      continue;
+    }
+    if (!settled) {
+      settled = true;
+#ifndef FLTX_EMU
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      ldsBarrier();
+    }
+    const int X = (int)S.evLane[e];
+    const uint32_t ps = S.evSpar[e], n = S.evTok[e];
+    const unsigned long long* h = (const unsigned long long*)(histPT + hbase);
+    uint32_t sid = S.evSid[e];
+    bool wantKids = true;
+    if (need & 1u) {
+      if (tid == 0) {
+        S.scanMin = 0xFFFFFFFFu;
+      }
+      ldsBarrier();
+      uint32_t found = 0xFFFFFFFFu;
+      for (int64_t i0 = tid; i0 < nRec; i0 += 8 * (int64_t)W) { /* eight loads in flight */
+        unsigned long long rr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + (int64_t)u * W;
+          rr[u] = i < nRec ? loadCoherent64(h + i) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + (int64_t)u * W;
+          const uint32_t x = (uint32_t)rr[u], y = (uint32_t)(rr[u] >> 32);
+          if (i < nRec && (x & kSlNewFlag) && y == n && (x >> 9) == ps) {
+            found = found < (uint32_t)i ? found : (uint32_t)i;
+          }
+        }
+      }
+      if (found != 0xFFFFFFFFu) {
+        atomMin32(&S.scanMin, found);
+      }
+      ldsBarrier();
+      sid = S.scanMin; /* (at least the record the last build wrote) */
+      const uint32_t ms = tlMaskSlot(M, sid);
+      wantKids = M.mmTag[ms] != sid;
+      ldsBarrier(); /* (everybody has read scanMin and the tag before anything below changes) */
+      if (tid == 0) {
+        S.rec[q][X].sid = sid;
+        S.evSid[e] = sid;
+        M.edge[tlEdgeSlot(M, ps, n)] = tlEdgePack(ps, n, sid); /* (the memo learns the edge again) */
+        if (!wantKids) {
+          S.mask[q][X] |= M.mmMask[ms];
+        }
+      }
+    }
+    if (wantKids) {
+      if (tid == 0) {
+        S.scanMask = 0ull;
+      }
+      ldsBarrier();
+      unsigned long long kids = 0ull;
+      for (int64_t i0 = tid; i0 < nRec; i0 += 8 * (int64_t)W) {
+        unsigned long long rr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + (int64_t)u * W;
+          rr[u] = i < nRec ? loadCoherent64(h + i) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + (int64_t)u * W;
+          const uint32_t x = (uint32_t)rr[u], y = (uint32_t)(rr[u] >> 32);
+          if (i < nRec && (x & kSlNewFlag) && (x >> 9) == sid) {
+            kids |= 1ull << (y & 63u);
+          }
+        }
+      }
+      if (kids) {
+        atomOr64(&S.scanMask, kids);
+      }
+      ldsBarrier();
+      if (tid == 0) {
+        S.mask[q][X] |= S.scanMask;
+      }
+    }
+    ldsBarrier();
+  }
+  ldsBarrier();
+  if (tid < nState) { /* orphans get their parent back */
+    const uint32_t spar = S.rec[q][tid].spar;
+    for (int e = 0; e < nev; ++e) {
+      const int X = (int)S.evLane[e];
+      if (tid != X && spar == S.evSid[e]) {
+        const uint32_t info = S.rec[q][tid].info;
+        S.rec[q][tid].info = (info & ~0xFF00u) | ((uint32_t)(X + 1) << 8);
+        atomOr64(&S.cmask[q][X], 1ull << (info & 0xFFu));
+      }
+    }
+  }
+  if (tid == 0) {
+    S.row[q].nev = 0u;
+  }
+  ldsBarrier();
+}
+
 #define FLTX_SLPROF(i)                                        \
   do {                                                        \
     if (PROF && P.prof && (int)threadIdx.x == P.profThread) { \
@@ -466,7 +647,12 @@ template <int GT, bool LA, bool ST, bool PROF, bool TL = false>
 FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   static_assert(!(LA && ST), "streams with logAdd stay on the lane-per-slot step");
   static_assert(!(TL && ST), "streams with a token LM stay on the generic engine");
-  SlaneLds& S = *(SlaneLds*)smem;
+  using LdsT = typename std::conditional<TL, TlaneLds, SlaneLds>::type;
+  LdsT& S = *(LdsT*)smem;
+  TlMemo M = {};
+  if constexpr (TL) {
+    M = tlMemoOf(S, P.tlEdgeSlots, P.tlMaskSlots);
+  }
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
   const int W = (int)blockDim.x, tid = (int)threadIdx.x;
   const int lane = laneId(), wave = waveUniform(waveId());
@@ -508,11 +694,22 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   if (tid < 16) {
     S.scal[tid] = 0u;
   }
-  if (TL && tid < 2) {
-    S.fbest[tid] = 0ull;
-  }
-  if (TL && tid == 0) {
-    S.tlIn[0][0] = 0.0f; /* (the root state was not entered by a token) */
+  if constexpr (TL) {
+    if (tid < 2) {
+      S.fbest[tid] = 0ull;
+    }
+    if (tid == 0) {
+      S.tlIn[0][0] = 0.0f; /* (the root state was not entered by a token) */
+    }
+    for (int i = tid; i < P.tlEdgeSlots; i += W) {
+      M.edge[i] = 0ull;
+    }
+    for (int i = tid; i < P.tlMaskSlots; i += W) {
+      M.mmTag[i] = kTlNoSid;
+    }
+    if (tid < 64) {
+      S.dmask[tid] = 0ull;
+    }
   }
   const int frame0 = ST ? P.uttFrame[b] : 0;   /* streams: rows already in the buffer */
   const int total0 = ST ? P.uttTotal[b] : 0;   /* ... frames decoded since decodeBegin */
@@ -628,6 +825,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   ldsBarrier();
 
   int nState = ST ? (int)S.scal[SL_NSTATE] : 1;
+  int nStatePrev = 0; /* TL: lanes the previous frame started from (0: there was none) */
   double endBest = 0.0; /* best hypothesis of the final beam (decodeEnd's threshold) */
   int winShift = kSlCoarseShift, winBase = kSlCoarseBase;
   bool dead = false; /* this utterance goes to the general engines */
@@ -711,8 +909,104 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       __asm__ volatile("" : "+v"(me.nb), "+v"(me.b), "+v"(me.info), "+v"(me.sid), "+v"(me.spar), "+v"(cm), "+v"(mk));
     }
 #endif
-    if (nev != 0u) { /* rare: states re-entered the beam in the previous build */
-      if (ST) {
+    /* token-level n-gram LM: the LM scores (and the contexts behind them) of this lane's state for the tokens of this
+     * wave's list positions -- one 8-byte gather per (lane, position) from the state's row of the dense table (rows of
+     * the states in the beam stay in the L1 / L2 from frame to frame); self wave: the score of last(S) after S (the
+     * blank-then-last candidate) and the score S was entered with (the parent state's extension by last(S)) */
+    int2 lmv[GT];
+    int2 lmLast = make_int2(0, 0);
+    float lIn = 0.0f;
+#pragma unroll
+    for (int j = 0; j < GT; ++j) {
+      lmv[j] = make_int2(0, 0);
+    }
+    if (TL && !isSvc) { /* (issued as soon as the lane's record is here: the re-entry work and the second LDS round trip
+                           run under their latency; a state's context and last token do not change when it is re-linked) */
+      const bool liveE = lane < nState;
+      const int2* lrow = tokLm + (size_t)(liveE ? me.pad : 0u) * (size_t)tokStride;
+      if (isSelf) {
+        lmLast = lrow[liveE ? (int)(me.info & 0xFFu) & 63 : 0];
+        lIn = S.tlIn[p][lane];
+      } else {
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+          lmv[j] = lrow[tb[j] != 0ull ? __builtin_ctzll(tb[j]) : 0];
+        }
+      }
+    }
+    if constexpr (TL) {
+      /* the lanes the last frame dropped: their child masks go to the memo (the last frame's records and masks are
+       * still in the other parity's arrays; `dmask` has the edges their last extension created) -- the staging wave,
+       * which waits longest at the barrier behind the frame's best (wave 0 wipes these masks after that barrier) */
+      if (isSvc) {
+        const bool dropped = lane < nStatePrev && S.newLane[lane] < 0;
+        const uint32_t dsid = S.rec[q][lane].sid;
+        const uint32_t ms = tlMaskSlot(M, dsid);
+        if (dropped) {
+          M.mmTag[ms] = dsid;
+        }
+        waveSync(); /* (two dropped states of one frame may share a slot: the one whose id stays writes the mask) */
+        if (dropped && M.mmTag[ms] == dsid) {
+          M.mmMask[ms] = S.mask[q][lane] | S.dmask[lane];
+        }
+        S.dmask[lane] = 0ull;
+        /* ... and the housekeeping for everybody (what this frame's build adds to): nobody else reads the other parity's
+         * masks in this frame, and this wave has the time -- the first token wave is on the way to the barrier */
+        S.cmask[q][lane] = 0ull;
+        S.mask[q][lane] = 0ull;
+        if (lane < 32) {
+          S.off[lane] = 0u;
+        }
+        if (lane == 0) {
+          S.scal[SL_BCNT] = 0u;
+          S.fbest[q] = 0ull; /* (the next frame's; last read a frame ago) */
+        }
+      }
+    }
+    if (TL) {
+      FLTX_SLPROF(0);
+    }
+    bool reentryDone = false;
+    if constexpr (TL) {
+    if (nev != 0u && (nev >> 16) == 0u) {
+      reentryDone = true;
+      /* states entered again in the last build, all known to the memos (ids and child masks are in place): their
+       * orphans -- lanes whose parent state it is -- get their parent lane back, in this wave's registers: lane l holds
+       * lane l's record in every wave, and the records the next build writes are made from these registers */
+      if (!isSvc) {
+        const int ne = (int)nev;
+        for (int e0 = 0; e0 < ne; e0 += 4) {
+          uint32_t xs[4], ss[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { /* (four events per LDS round trip) */
+            xs[u] = e0 + u < ne ? S.evLane[e0 + u] : 0u;
+            ss[u] = e0 + u < ne ? S.evSid[e0 + u] : kTlNoSid;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (e0 + u < ne) {
+              const int X = (int)xs[u];
+              unsigned long long orphans = waveBallot(lane < nState && lane != X && me.spar == ss[u]);
+              unsigned long long bits = 0ull;
+              if ((orphans >> lane) & 1ull) {
+                me.info = (me.info & ~0xFF00u) | ((uint32_t)(X + 1) << 8);
+              }
+              while (orphans) {
+                const int o = __builtin_ctzll(orphans);
+                orphans &= orphans - 1ull;
+                bits |= 1ull << (waveReadLane32(me.info, o) & 63u);
+              }
+              cm |= lane == X ? bits : 0ull;
+            }
+          }
+        }
+      }
+    }
+    }
+    if (!reentryDone && nev != 0u) { /* rare: states re-entered the beam in the previous build */
+      if constexpr (TL) {
+        tlReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K, P.tlEdgeSlots, P.tlMaskSlots);
+      } else if (ST) {
         slRelink(S, P.maskTab + (size_t)b * P.idCap, p, nState);
       } else {
         slReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K);
@@ -720,6 +1014,9 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       me = S.rec[p][lane];
       cm = S.cmask[p][lane];
       mk = S.mask[p][lane];
+    }
+    if (TL) {
+      FLTX_SLPROF(6); /* (TL: re-entry) */
     }
     if (rowDead) { /* nothing to extend with, or not finite: general path */
       dead = true;
@@ -756,29 +1053,6 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       if (ST) {
         parAmNB = S.amNB[p][pl >= 0 ? pl : 0];
         parAmB = S.amB[p][pl >= 0 ? pl : 0];
-      }
-    }
-    /* token-level n-gram LM: the LM scores (and the contexts behind them) of this lane's state for the tokens of this
-     * wave's list positions -- one 8-byte gather per (lane, position) from the state's row of the dense table (rows of
-     * the states in the beam stay in the L1 / L2 from frame to frame); self wave: the score of last(S) after S (the
-     * blank-then-last candidate) and the score S was entered with (the parent state's extension by last(S)) */
-    int2 lmv[GT];
-    int2 lmLast = make_int2(0, 0);
-    float lIn = 0.0f;
-#pragma unroll
-    for (int j = 0; j < GT; ++j) {
-      lmv[j] = make_int2(0, 0);
-    }
-    if (TL && !isSvc) {
-      const int2* lrow = tokLm + (size_t)(live ? me.pad : 0u) * (size_t)tokStride;
-      if (isSelf) {
-        lmLast = lrow[live ? last : 0];
-        lIn = S.tlIn[p][lane];
-      } else {
-#pragma unroll
-        for (int j = 0; j < GT; ++j) {
-          lmv[j] = lrow[tb[j] != 0ull ? __builtin_ctzll(tb[j]) : 0];
-        }
       }
     }
     FLTX_SLPROF(0);
@@ -1030,16 +1304,20 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
           k = kj > k ? kj : k;
         }
         if (waveBallot(k != 0ull) != 0ull) {
-          k = waveMax64(k);
+          /* (two 32-bit scans -- the upper halves, then the lower halves of the lanes that hold the largest upper
+           * half -- issue half the instructions of one 64-bit scan) */
+          const uint32_t hiMax = waveMax32((uint32_t)(k >> 32));
+          const uint32_t loMax = waveMax32((uint32_t)(k >> 32) == hiMax ? (uint32_t)k : 0u);
           if (lane == 0) {
-            atomMax64(&S.fbest[p], k);
+            atomMax64(&S.fbest[p], ((unsigned long long)hiMax << 32) | loMax);
           }
         }
       }
-      if (wave == 0 && lane == 0) {
-        S.fbest[q] = 0ull; /* (the next frame's; last read a frame ago) */
-      }
+      FLTX_SLPROF(7); /* (TL: candidates + maximum) */
       ldsBarrier(); /* 0: the frame's best candidate */
+      if (wave == 0 && lane == 0) {
+        S.row[p].nev = 0u; /* (every wave has read it; the next build counts here again) */
+      }
       {
         const unsigned long long bk = S.fbest[p];
         best = f64FromKey(bk);
@@ -1088,7 +1366,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         cbin[2] = okL ? slBin<LA>(best, cs[2], winShift, winBase) : kSlInvalid;
       }
     }
-    if (wave == 0) { /* housekeeping for everybody: what this frame's build adds to */
+    if (!TL && wave == 0) { /* housekeeping for everybody: what this frame's build adds to */
       S.cmask[q][lane] = 0ull;
       S.mask[q][lane] = 0ull;
       if (lane < 32) {
@@ -1163,7 +1441,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
           break;
         }
         if (sc.cnt <= kSlBCap) { /* the members of the K-th best's bin compare with each other */
-          if (PROF) {
+          if (PROF && !TL) {
             acc[6] += 1ull;
             acc[7] += (unsigned long long)sc.cnt;
           }
@@ -1241,6 +1519,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     }
     /* next frame's window: the K-th best in the middle, 128 bins per octave */
     if (sc.total > K) {
+      /* (a window of one octave at 256 bins per octave was tried for the token-LM variant, whose frames hold three times
+       * the candidates inside the window: the K-th best then leaves the window every few frames -- 4.2 -> 7.3 ms) */
       const int q15 = shift >= kSlFineShift ? (sc.bstar + base) << (shift - kSlFineShift)
                                             : (sc.bstar + base) >> (kSlFineShift - shift);
       winShift = kSlFineShift;
@@ -1340,6 +1620,30 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         S.tlIn[q][nl] = lNew;
       }
       const bool again = ((mk >> n) & 1ull) != 0ull; /* this edge had a child before */
+      uint32_t known = kTlNoSid;
+      bool tlSlow = true; /* a re-entry the memos do not answer: the next frame looks it up in the rows (tlReenter) */
+      if constexpr (TL) {
+        const uint32_t es = tlEdgeSlot(M, me.sid, (uint32_t)n);
+        if (again) { /* ... and the edge memo may still know which: the state keeps its id, the rows are not searched */
+          const unsigned long long cur = M.edge[es];
+          if ((cur >> 23) == (tlEdgePack(me.sid, (uint32_t)n, 0u) >> 23)) {
+            known = (uint32_t)cur & 0x7FFFFFu;
+            r.sid = known;
+            /* ... and the mask memo the child mask it had when it dropped out: then nothing is left for the next frame
+             * but to give its orphans their parent back, which every wave does in its own registers */
+            const uint32_t ms = tlMaskSlot(M, known);
+            if (M.mmTag[ms] == known) {
+              atomOr64(&S.mask[q][nl], M.mmMask[ms]);
+              tlSlow = false;
+            }
+          }
+        } else {
+          M.edge[es] = tlEdgePack(me.sid, (uint32_t)n, r.sid);
+        }
+        if (myNewLane < 0) { /* the parent drops out with this frame: its saved child mask must hold this edge */
+          atomOr64(&S.dmask[lane], 1ull << n);
+        }
+      }
       if (ST) {
         uint32_t* slot = &P.childTab[((size_t)b * P.idCap + me.sid) * N + n];
         if (again) {
@@ -1365,10 +1669,15 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         histPT[hrow + hyp] = make_int2((int)(hp | kSlNewFlag | (me.sid << 9)), n);
       }
       if (again) { /* it may have descendants in the beam */
-        const uint32_t e = atomAdd32(&S.row[q].nev, 1u);
+        /* (TL: the upper half counts the events that need the rows) */
+        const uint32_t e = atomAdd32(&S.row[q].nev, (TL && tlSlow) ? 0x10001u : 1u) & 0xFFFFu;
         S.evLane[e] = (uint32_t)nl;
         S.evSpar[e] = me.sid;
         S.evTok[e] = (uint32_t)n;
+        if constexpr (TL) {
+          S.evSid[e] = known;
+          S.evNeed[e] = known == kTlNoSid ? 3u : (tlSlow ? 2u : 0u);
+        }
       }
     };
     if (isSvc) {
@@ -1438,6 +1747,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
                  __uint_as_float((uint32_t)lmLast.x));
       }
     }
+    nStatePrev = nState;
     nState = nSurv + nNew;
     endBest = best;
     FLTX_SLPROF(4);

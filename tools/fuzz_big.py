@@ -9,11 +9,12 @@ import cases, helpers
 from oracle import orclib
 orc = orclib.load("oracle")
 s = helpers.FltxSession(os.environ.get("EMU_LIB") or None)  # (EMU_LIB=tests/emu/libfltx_emu.so: the emulated kernels, no GPU)
-bad = 0
+bad = n_tie = 0
 cs = cases.fuzz_cases(int(os.environ.get("FLTX_FUZZ_N", "400")))
 for i, c in enumerate(cs):
     inp = helpers.case_inputs(c)
     want = helpers.run_checker(orc, c, inp)
+    ties = dict(orc.last_ties)
     if len({h.score for h in want}) != len(want):
         continue  # equal scores: the reference's own result is order dependent
     try:
@@ -27,15 +28,14 @@ for i, c in enumerate(cs):
         ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
     except Exception as e:
         ok, why = False, "EXC %r" % (e,)
-    if not ok and orclib.have_ref():
-        # the compiled reference and its restatement disagree with each other: an internal tie
-        # (e.g. <unk> emitted at several frames for the same total score) that the reference
-        # resolves by nth_element / sort order -- not a defined result
-        ref = ref if "ref" in globals() else orclib.load("ref")
-        if not helpers.hyps_equal(want, helpers.run_checker(ref, c, inp))[0]:
-            print("TIE (reference != oracle)", c["name"])
-            continue
+    if not ok and any(ties.values()):
+        # the ORACLE passed a tie on this input (oracle.cpp TieCounts: equal scores inside a merge group, across the
+        # beam's cut, ...): the reference's own answer depends on addresses there.  A mismatch on a tie-free input
+        # is always counted below, whatever the compiled reference says.
+        n_tie += 1
+        print("TIE (seen by the oracle: %s)" % {k: v for k, v in ties.items() if v}, c["name"])
+        continue
     if not ok:
         bad += 1
         print("MISMATCH", c["name"], {k: c[k] for k in ("kind", "dist", "N", "K", "Kt", "thr", "lm", "log_add", "T", "lm_weight", "word_score", "unk_score", "sil_score")}, why, "engine", s.last_engine if hasattr(s, "last_engine") else None)
-print("done", len(cs), "cases,", bad, "mismatches")
+print("done", len(cs), "cases,", bad, "mismatches, ties_seen_by_oracle", n_tie)

@@ -32,20 +32,15 @@ def tie(hyps):
 
 
 def internal_tie(c, inp, want, got):
-    """Two paths of EQUAL score meet in one merge group and the reference keeps whichever its sort met first:
-    the same words at other frames for bit-identical scores (<unk> can end at several frames), or an input on which
-    the compiled reference and its restatement disagree with each other."""
-    if len(want) == len(got) and all(
-            (w.score, w.am, w.lm) == (g.score, g.am, g.lm) and [x for x in w.words if x >= 0] == [x for x in g.words if x >= 0]
-            for w, g in zip(want, got)):
-        return True
-    if orclib.have_ref():
-        ref = globals().setdefault("_ref", orclib.load("ref"))
-        return not helpers.hyps_equal(want, helpers.run_checker(ref, c, inp))[0]
-    return False
+    """The ORACLE passed a tie while it decoded this input (oracle.cpp TieCounts: equal scores inside a merge group,
+    across the beam's cut, in the token beam, at the choice of the best hypothesis): the reference's own answer then
+    depends on addresses.  A mismatch on a tie-free input is never excused -- in particular not by the
+    compiled reference disagreeing with the oracle, which is what an unfaithful oracle would look like."""
+    return any(orc.last_ties.values())
 
 
 # ---- 1. host LMs ---------------------------------------------------------------------------------------------------
+n_ties = 0
 bad = ran = 0
 rnd = random.Random(55)
 for i, c in enumerate(cases.fuzz_cases(N_HOST)):
@@ -55,7 +50,8 @@ for i, c in enumerate(cases.fuzz_cases(N_HOST)):
         c["lm"] = ("lastword", 100 + i)
         c["lm_weight"] = rnd.choice([0.4, 1.1])
         c["is_lm_token"] = c["kind"] == "lexfree" or rnd.random() < 0.4
-        c["unk_score"] = float("-inf") if c["is_lm_token"] else c["unk_score"]
+        # (round 6: <unk> stays on with a token-level state-sharing LM as well -- the ties it produces are told apart by the
+        # oracle's counters now, not by leaving the corner out)
     inp = helpers.case_inputs(c)
     want = helpers.run_checker(orc, c, inp)
     if tie(want):
@@ -78,7 +74,8 @@ for i, c in enumerate(cases.fuzz_cases(N_HOST)):
         ok, why = False, "EXC %r" % (e,)
     ran += 1
     if not ok and not why.startswith("EXC") and internal_tie(c, inp, want, got):
-        print("TIE", c["name"], why)
+        n_ties += 1
+        print("TIE (seen by the oracle: %s)" % {k: v for k, v in orc.last_ties.items() if v}, c["name"], why)
         continue
     if not ok:
         bad += 1
@@ -105,7 +102,8 @@ for i, c in enumerate(cases.fuzz_cases(N_DEFER)):
     ok, why = helpers.hyps_equal(want, got, 1e-5 if c["log_add"] else 0.0)
     ran2 += 1
     if not ok and internal_tie(c, inp, want, got):
-        print("TIE", c["name"], why)
+        n_ties += 1
+        print("TIE (seen by the oracle: %s)" % {k: v for k, v in orc.last_ties.items() if v}, c["name"], why)
         continue
     if not ok:
         bad2 += 1
@@ -141,4 +139,5 @@ for i in range(N_STREAM):
         print("STREAM MISMATCH", c["name"], {k: c[k] for k in ("kind", "N", "K", "Kt", "thr", "lm", "T")}, str(e)[:200])
     ran3 += 1
 print("long streams: %d configurations, %d compactions, %d mismatches (%.0f s)" % (ran3, comp, bad3, time.time() - t0), flush=True)
+print("ties_seen_by_oracle (mismatches excused by them):", n_ties)
 print("SOAK", "FAILED" if bad + bad2 + bad3 else "OK")
