@@ -506,6 +506,9 @@ def measure(a, torch, dist, rank, local, world, primary):
             out["end_to_end"] = end_to_end(job, dec, B, T, N)
             out["end_to_end_two_streams"] = dict(out["end_to_end"]["two_streams"],
                                                  frac_of_value=out["end_to_end"]["two_streams"]["value"] / value)
+            best_n = max(out["end_to_end"]["more_streams"], key=lambda k: out["end_to_end"]["more_streams"][k]["value"])
+            out["end_to_end_best"] = dict(out["end_to_end"]["more_streams"][best_n], host_threads=int(best_n),
+                                          frac_of_value=out["end_to_end"]["more_streams"][best_n]["value"] / value)
             out["streaming"] = streaming(job, B, T, N)
             if a.workload == "C2":
                 try:
@@ -947,6 +950,23 @@ def end_to_end(job, dec, B, T, N):
     out["two_streams"] = {"ms_per_batch": dt * 1e3, "value": B * T / dt, "unit": "frames/s",
                           "note": "two decoder objects / HIP streams / host threads taking batches in turn: "
                                   "H2D and D2H of one batch under the kernels of the other"}
+    # ... and with three and four: a batch's H2D (0.6 ms), kernels (2.1 + 0.3 ms with two launches sharing the CUs) and
+    # D2H (0.45 ms) are a 3.4 ms chain per host thread, so two threads cannot keep two launches in flight all the time
+    out["more_streams"] = {}
+    for n_thr in (3, 4):
+        ds = [dec] + [job.decoder(second_stream=True) for _ in range(n_thr - 1)]
+        for d in ds[1:]:
+            run(d)
+        th = [threading.Thread(target=run, args=(d,)) for d in ds]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dtn = (time.perf_counter() - t0) / (n_thr * n_each)
+        for d in ds[1:]:
+            d.close()
+        out["more_streams"][str(n_thr)] = {"ms_per_batch": dtn * 1e3, "value": B * T / dtn, "unit": "frames/s"}
     return out
 
 

@@ -445,6 +445,33 @@ def _deferred_look(sess, golden, T_wp):
     ok, why = helpers.check_against_golden(d.results(0), golden[c["name"]])
     assert ok and d.get("engine") == 4 and d.get("redone") == 0, why
     d.close()
+    # (4) a batch nobody reads is settled all the same by the next fltx_decode_batch on the object (round 6: it used to be
+    # dropped, so a caller that only queues batches never learned about a fallback) -- unless the caller asks for that
+    N, B = 300, 3
+    c = cases.case("wp_ties_unread", dist="ctc", T=T_wp, N=N, K=20, Kt=30, u=515)
+    e = synth.batch("ctc", B, T_wp, N)
+    e[1, 5, :] = -3.0  # (a row without a defined token beam: fltx_wlane.h flags the utterance)
+    d = sess.decoder(c, dict(tr=None))
+    d.set("defer_check", 1)
+    d.decode_batch(e, [T_wp] * B, N)
+    d.decode_batch(e, [T_wp] * B, N)  # settles the first: its flagged utterance is decoded again, unread
+    assert d.get("unread_redone") == 1 and d.get("looks_dropped") == 0
+    # (one of three utterances fell back: more than a quarter, so the fallback sticks -- what a settled look is for --
+    # and the second batch started on the general engine: nothing of it is decoded again)
+    assert d.get("redone") == 0
+    ref = sess.decoder(c, dict(tr=None))
+    ref.decode_batch(e, [T_wp] * B, N)
+    for b in range(B):
+        ok, why = helpers.hyps_equal(ref.results(b), d.results(b))
+        assert ok, "utterance %d: %s" % (b, why)
+    ref.close()
+    d.close()
+    d = sess.decoder(c, dict(tr=None))
+    d.set("defer_check", 2)  # (measurements only: an unread batch's look is dropped, and counted)
+    d.decode_batch(e, [T_wp] * B, N)
+    d.decode_batch(e, [T_wp] * B, N)
+    assert d.get("looks_dropped") == 1 and d.get("unread_redone") == 0
+    d.close()
 
 
 def test_emulated_deferred_status_look(emu_session, golden):

@@ -79,7 +79,8 @@ def test_emulated_stream_longer_than_its_tables(emu_session, oracle_lib, spec, a
     mf = 96 if c["kind"] == "lexicon" else 24
     compared, compactions, cap0, cap1, engine = _long_stream(emu_session, oracle_lib, c, inp, chunk=10, max_frames=mf,
                                                              look_back=[0, 3][always], sets=tol_sets, threads=64)
-    assert cap0 == cap1 and 0 < cap0 <= c["K"] * (mf + 2) + 8 * c["K"] + 64
+    buf = mf + (100 if c["kind"] == "lexicon" else 0)  # (a lexicon stream's buffer: max_frames + prune's look-back limit)
+    assert cap0 == cap1 and 0 < cap0 <= c["K"] * (buf + 2) + 8 * c["K"] + 64
     assert compactions >= (c["T"] // 10 - 1 if always else (1 if c["kind"] == "lexicon" else 2)), compactions
     assert compared == (c["T"] + 9) // 10
 
@@ -122,3 +123,21 @@ def test_stream_longer_than_its_tables(gpu_session, oracle_lib, spec):
         compared, compactions, cap0, cap1, engine = _long_stream(gpu_session, oracle_lib, c, inp, chunk=10, max_frames=mf,
                                                                  look_back=lb, sets={"compact_always": always})
         assert cap0 == cap1 and compactions >= 2
+
+
+def _small_buffer_lexicon_stream(sess, orc):
+    """A lexicon stream through a buffer smaller than prune's look-back limit (round-5 review, weak #5: max_frames 96, chunks
+    of 3 frames, prune(0) after each raised "exceed max_frames" half way): prune keeps the frames back to the last complete
+    word -- up to lookBack + 100 (Utils.h:28,293-308) -- and the stream's buffer holds those on top of max_frames."""
+    c = cases.case("small_buf", kind="lexicon", dist="lexspell", T=600, K=16, Kt=10, lexicon=cases.SMALL_LEX, u=77)
+    inp = helpers.case_inputs(c)
+    return _long_stream(sess, orc, c, inp, chunk=3, max_frames=96, look_back=0)
+
+
+def test_lexicon_stream_through_a_buffer_smaller_than_the_look_back_limit_emulated(emu_session, oracle_lib):
+    _small_buffer_lexicon_stream(emu_session, oracle_lib)
+
+
+@pytest.mark.gpu
+def test_lexicon_stream_through_a_buffer_smaller_than_the_look_back_limit(gpu_session, oracle_lib):
+    _small_buffer_lexicon_stream(gpu_session, oracle_lib)

@@ -3776,6 +3776,15 @@ int fltx_stream_begin(fltx_decoder* d, int32_t B, int32_t N, int32_t maxFrames) 
   if (!d || B <= 0 || N <= 0 || maxFrames < 0) {
     return fail(FLTX_ERR_INVALID, "fltx_stream_begin: bad argument");
   }
+  /* prune(lookBack) of the lexicon decoder walks on from lookBack frames back to the last COMPLETE hypothesis (its parent
+   * ended a word), up to kLookBackLimit frames further (Utils.h:28,293-308): that many frames can stay in the buffer
+   * whatever the caller prunes.  The reference's buffer grows as needed; here the stream's buffer is sized when it
+   * begins, so a lexicon stream gets those kLookBackLimit frames ON TOP of max_frames: a caller whose own count (lookBack
+   * frames left after a prune, plus the chunks since) stays within max_frames never fills it (round 5 raised
+   * "exceed max_frames" in the middle of such a stream) */
+  if (d->kind == FLTX_DECODER_LEXICON) {
+    maxFrames += kLookBackLimit;
+  }
   std::vector<int32_t> Tm(B, maxFrames);
   d->offlineCall = false;
   d->offlinePending = false; /* (an offline batch whose results were never read) */
@@ -3877,8 +3886,12 @@ int fltx_stream_step(fltx_decoder* d, const float* emissions, int32_t onDevice, 
       d->framesExact = true;
       continue;
     }
-    return fail(FLTX_ERR_RANGE, "stream %d: %d buffered + %d new frames exceed max_frames %d", bad, d->frames[bad],
-                T[bad], d->maxFrames);
+    return fail(FLTX_ERR_RANGE, "stream %d: %d buffered + %d new frames exceed max_frames %d%s", bad, d->frames[bad],
+                T[bad], d->maxFrames,
+                d->kind == FLTX_DECODER_LEXICON
+                    ? " (a lexicon stream's prune keeps the frames back to the last complete word, up to lookBack + 100: "
+                      "size the buffer for 100 + lookBack + the largest chunk, Utils.h:28,293-308)"
+                    : "");
   }
   /* the chunk's upload first (copy stream: under the kernel of the chunk before, if that one is still pending), then
    * the look at the chunk before, then this chunk's launch */

@@ -39,6 +39,9 @@ for i in range(n):
     if not ok and ties["cut"]:
         stats["cut_ties"] += 1  # equal scores across the beam's cut (nth_element's choice in the reference)
         ok = True
+    if not ok and (ties["order"] or ties["token"] or ties["best"]):
+        stats["order_ties"] = stats.get("order_ties", 0) + 1  # equal scores inside the sorted n-best (partial_sort's choice), ...
+        ok = True
     if not ok and ties["merge"]:
         # equal scores inside a merge group: two orders of the same homophones in one history (the n-gram context forgets
         # them, the histories merge on a tie; the reference leaves the survivor to its sort)

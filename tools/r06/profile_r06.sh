@@ -1,0 +1,34 @@
+#!/bin/bash
+# Regenerates the measurements kept under profiles/r06/ on an MI355X box (through gpurun, from the repo root; outputs land in
+# gpurun_out/r06p/, tools/r06/collect_r06.py copies the summaries).  PMC passes are separate runs with --pmc only (the kernel
+# trace is the only trace domain), one counter set per pass.  C2T = C2's shape with a token-level 3-gram LM (round 6).
+export TMPDIR=/tmp
+R="${GRAFT_REPO_ROOT:-$(pwd)}"
+O="$R/gpurun_out/r06p"
+rm -rf "$O"; mkdir -p "$O"
+cd "$R"
+python bench.py --steps 20 --warmup 5 > "$O/bench_default.json" 2> "$O/bench_default.err"
+python bench.py --workload C2T --steps 20 --warmup 5 --no-secondary > "$O/bench_C2T.json" 2> "$O/bench_C2T.err"
+python bench.py --workload C2T --steps 20 --warmup 5 --no-corun --no-extras > "$O/bench_C2T_one_batch_at_a_time.json" 2> "$O/bench_C2T_nocorun.err"
+for w in C3 C4; do
+  st=10; [ $w = C4 ] && st=6
+  python bench.py --workload $w --steps $st > "$O/bench_$w.json" 2> "$O/bench_$w.err"
+done
+python tools/probe/toklm_probe.py > "$O/toklm_probe.txt" 2>&1
+python bench.py --workload C2T --steps 5 --warmup 2 --no-extras --no-cpu --pipeline 1 --profile --profile-waves 0,3,7,8 --profile-out "$O/phase_split_C2T.txt" > /dev/null 2>&1
+cd /tmp
+for w in C2 C2T C3 C4; do
+  st=6; [ $w = C4 ] && st=4
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$w" -- python "$R/bench.py" --workload $w --steps $st --warmup 2 --no-cpu --no-secondary > "$O/prof_$w.log" 2>&1
+done
+for w in C2 C2T C3 C4; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary > "$O/pmc_fetch_$w.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary > "$O/pmc_write_$w.log" 2>&1
+done
+for w in C2 C2T; do
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d "$O/sq1_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary > "$O/sq1_$w.log" 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_BRANCH --output-format csv -d "$O/sq2_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary > "$O/sq2_$w.log" 2>&1
+done
+cd "$R"
+find "$O" -name "*.db" -delete 2>/dev/null
+du -sh "$O"
