@@ -91,7 +91,7 @@ def parse():
     ap.add_argument("--no-corun", action="store_true", help="with --pipeline 2: do not ask for the settings that let the decode "
                     "kernels of the two decoder objects share the CUs (defer_check, the 512-thread / shared-CU geometries)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / C5-share / WP lines of the default run")
-    ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the back-to-back leg (0 = off)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the back-to-back leg (0 = off)")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
     ap.add_argument("--profile-out", default="", help="... and append it to this file (profiles/rNN/phase_split_*.txt)")
     ap.add_argument("--mode", default="process", choices=["process", "group"],
@@ -501,6 +501,11 @@ def measure(a, torch, dist, rank, local, world, primary):
     if rank == 0 and world == 1 and not a.no_cpu:
         dec.decode_batch(None, job.Ts, N, device_ptr=e_dev.data_ptr())  # the n-best compared below
         out["cpu_baseline"] = cpu_baseline(a, dec, job)
+        if not primary and getattr(a, "secondary_legs", False):
+            # (C3 / C4 as secondary workloads: their streaming and end-to-end legs under the driver's clock too)
+            out["streaming"] = streaming(job, B, T, N)
+            e2 = end_to_end(job, dec, B, T, N, more=False)
+            out["end_to_end"] = e2
         if primary and not a.no_extras:
             out["cpu_baseline_steady"], out["cpu_baseline_all_cores"] = cpu_more(a, job)
             out["end_to_end"] = end_to_end(job, dec, B, T, N)
@@ -539,6 +544,7 @@ def measure(a, torch, dist, rank, local, world, primary):
                                         ("WP", "WP", 0, 8), ("C2_tokLM", "C2T", 0, 16)):
             a2 = copy.copy(a)
             a2.workload, a2.batch, a2.cpu_sample = wl, batch, sample
+            a2.secondary_legs = name in ("C3", "C4")
             a2.steps, a2.warmup = max(12, a.steps), 2  # (two batches in flight: a short region is mostly ramp-up)
             t0 = time.perf_counter()
             try:
@@ -556,6 +562,12 @@ def measure(a, torch, dist, rank, local, world, primary):
                              "algorithmic_bytes_per_launch": r2["algorithmic_bytes_per_launch"], "traffic": r2["traffic"]},
                 "mismatches_vs_reference_on_sample": c2.get("gpu_nbest_mismatches_on_sample"),
                 "cpu_baseline_1thread": c2.get("value"), "cpu_sample_utterances": sample, "cpu_kind": c2.get("kind"),
+                "streaming": {k: o2["streaming"].get(k) for k in ("value", "value_waiting_for_every_chunk", "engine",
+                                                                  "stream_chunks_decoded_again",
+                                                                  "final_nbest_mismatches_vs_cpu_on_sample")}
+                if "streaming" in o2 else None,
+                "end_to_end": {"one_stream": o2["end_to_end"]["value"], "two_streams": o2["end_to_end"]["two_streams"]["value"],
+                               "unit": "frames/s"} if "end_to_end" in o2 else None,
                 "wall_s_including_setup": time.perf_counter() - t0}
             fail = fail or f2
     return out, fail
@@ -905,7 +917,7 @@ def drop_in(job, B, T, N, n_utt=48):
     return out
 
 
-def end_to_end(job, dec, B, T, N):
+def end_to_end(job, dec, B, T, N, more=True):
     """Host buffers on both sides: pageable emissions in (H2D inside the call), kernels, the n-best back in
     host memory through pinned staging (compacted on the device: the rows that exist, tokens as bytes), NumPy
     views over it (what a Python caller gets), and -- separately -- one Python object per hypothesis.  Then the
@@ -953,7 +965,7 @@ def end_to_end(job, dec, B, T, N):
     # ... and with three and four: a batch's H2D (0.6 ms), kernels (2.1 + 0.3 ms with two launches sharing the CUs) and
     # D2H (0.45 ms) are a 3.4 ms chain per host thread, so two threads cannot keep two launches in flight all the time
     out["more_streams"] = {}
-    for n_thr in (3, 4):
+    for n_thr in ((3, 4) if more else ()):
         ds = [dec] + [job.decoder(second_stream=True) for _ in range(n_thr - 1)]
         for d in ds[1:]:
             run(d)
