@@ -350,6 +350,40 @@ def test_token_level_ngram_lm_on_the_lane_state_engine(gpu_session, oracle_lib):
     assert ran >= 280 and not bad, (ran, served, bad[:3])
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 200, 8, [5, 33], sets={"tlane": 0})
     assert ran >= 180 and served == 0 and not bad, (ran, served, bad[:3])
+    # ... and the generic engine without the dense table (a chain of n-gram probes per look-up: what token sets beyond 64 get)
+    ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 120, 9, [5, 33], sets={"tlane": 0, "tok_dense": 0})
+    assert ran >= 100 and served == 0 and not bad, (ran, served, bad[:3])
+
+
+def _token_lm_beyond_the_lane_engine(sess, oracle_lib, emu=False):
+    """beams 65 .. 300 and streams: the generic engine, a state's context as a row of the dense table"""
+    import random
+    rnd = random.Random(31)
+    bad = []
+    for i, K in enumerate([65, 100, 128, 200, 300, 70, 90]):
+        c = cases.case("tlbig%d" % i, dist=rnd.choice(["ctc", "uniform"]), T=rnd.choice([9, 30]) if emu else rnd.choice([30, 80]),
+                       N=rnd.choice([12, 29]), K=K, Kt=rnd.choice([29, 6]), thr=rnd.choice([25.0, 8.0]), u=7600 + i,
+                       lm=("ngram", rnd.choice([2, 3, 4]), 50 + i % 4), lm_weight=rnd.choice([0.8, 1.5]), sil_score=rnd.choice([0.0, -0.4]))
+        inp = helpers.case_inputs(c)
+        want = helpers.run_checker(oracle_lib, c, inp)
+        if len({h.score for h in want}) != len(want):
+            continue
+        for sets in ({}, {"tok_dense": 0}):
+            d = sess.decoder(c, inp)
+            for k, v in sets.items():
+                d.set(k, v)
+            d.decode_batch(inp["e"], [c["T"]], c["N"])
+            got, eng, ctxs = d.results(0), d.get("engine"), d.get("toklm_contexts")
+            d.close()
+            ok, why = helpers.hyps_equal(want, got)
+            if not ok or eng > 1 or (ctxs > 0) != (not sets):
+                bad.append((K, sets, eng, ctxs, why))
+    return bad
+
+
+@pytest.mark.gpu
+def test_token_lm_beyond_the_lane_engine(gpu_session, oracle_lib):
+    assert not _token_lm_beyond_the_lane_engine(gpu_session, oracle_lib)
 
 
 @pytest.mark.gpu

@@ -437,6 +437,7 @@ struct fltx_decoder {
   /* ... its variant for a token-level n-gram LM (TL): the LM's dense (context, token) table on this device; noTlane:
    * tunable "tlane" = 0 (tests compare with the generic engine) */
   int tlane = 0, noTlane = 0, tlaneFirst = 0;
+  int noTokDense = 0; /* tunable "tok_dense" = 0: no dense table at all (the generic engine probes the n-gram tables) */
   const int2* tokLm = nullptr;
   int64_t tokLmCtx = 0;
   int tlEdgeSlots = 4096, tlMaskSlots = 2048;
@@ -1635,6 +1636,10 @@ int fltx_decoder_set(fltx_decoder* d, const char* key, int64_t value) {
     d->noWlane = value ? 0 : 1;
     return FLTX_OK;
   }
+  if (!strcmp(key, "tok_dense")) { /* 0: a token-level n-gram LM is not flattened to a dense table (tests: the probe chain) */
+    d->noTokDense = value ? 0 : 1;
+    return FLTX_OK;
+  }
   if (!strcmp(key, "tlane")) { /* 0: a token-level n-gram LM on the lexicon-free decoder stays on the generic engine */
     d->noTlane = value ? 0 : 1;
     return FLTX_OK;
@@ -1834,19 +1839,27 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
    * (context, token) table built on the host (lmTokDense) -- when the model's contexts fit one */
   d->tlane = 0;
   d->tokLm = nullptr;
-  if (d->kind == FLTX_DECODER_LEXFREE && d->lm->kind == 1 && !d->noSlane && !d->noTlane && !d->genericAsked &&
-      !d->noDense && d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs && K <= 64 && N <= 64 &&
-      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
-      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
-      (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
-    const int2* tab = nullptr;
-    int64_t nCtx = 0;
+  d->tokLmTooBig = false;
+  const int2* tab = nullptr;
+  int64_t nCtx = 0;
+  if (d->kind == FLTX_DECODER_LEXFREE && d->lm->kind == 1 && N <= 64 && !d->noTokDense) {
+    /* the dense table serves every engine this decoder can run on: the lane engine below gathers from it, and the
+     * generic engine (beams beyond 64, streams, fallbacks) keeps a state's context as a row number and replaces its
+     * chain of n-gram probes by the same gather (lmScoreDev) */
     int rcd = lmTokDense(const_cast<fltx_lm*>(d->lm), d->ctx, d->lmDev, N, &tab, &nCtx);
     if (rcd) {
       return rcd;
     }
     d->tokLmTooBig = tab == nullptr;
-    if (tab) {
+    d->tokLm = tab;
+    d->tokLmCtx = tab ? nCtx : 0;
+  }
+  if (tab && !d->noSlane && !d->noTlane && !d->genericAsked &&
+      !d->noDense && d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs && K <= 64 &&
+      d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
+      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
+      (int64_t)K * (maxT + 2) < (1 << 23) - 1) {
+    {
       static const int geoOne[][2] = {{576, 4}, {512, 5}, {448, 6}, {384, 7}, {320, 10}, {640, 4}, {512, 12}, {576, 10}};
       static const int geoTwo[][2] = {{512, 5}, {448, 6}, {384, 7}, {576, 4}, {320, 10}, {640, 4}, {512, 12}, {576, 10}};
       const auto& geo = B > d->ctx->numCUs ? geoTwo : geoOne;
@@ -1863,8 +1876,6 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
           const bool shareCu = B > d->ctx->numCUs || (d->deferCheck && g[0] == 512); /* (defer_check: the caller keeps two batches in flight) */
           d->tlEdgeSlots = shareCu ? 4096 : 8192;
           d->tlMaskSlots = shareCu ? 2048 : 4096;
-          d->tokLm = tab;
-          d->tokLmCtx = nCtx;
           d->threads = g[0];
           break;
         }
@@ -2042,11 +2053,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       const int nListAll = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
       why |= (N > 64 && (lexi || N > kWlMaxN || nTok > 64)) ? FLTX_WHY_TOKENS : 0; /* (lexicon-free: the token BEAM has to fit, fltx_wlane.h) */
       why |= (lexi ? K > ((d->trie && d->trie->xMulti) ? 128 : 256) : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
-      why |= (!d->offlineCall && (lexi || d->opt.log_add)) ? FLTX_WHY_STREAM : 0;
+      why |= (!d->offlineCall && (lexi || d->opt.log_add || d->lm->kind == 1)) ? FLTX_WHY_STREAM : 0;
       /* (lexicon-free + n-gram LM: fltx_slane.h's TL variant takes it at beams up to 64 when the model's contexts fit a
        * dense table -- what is left of the term there: a host LM, a model too large for the table) */
       why |= (d->lm->kind == 2 || (lexi && d->isLmToken) ||
-              (!lexi && d->lm->kind == 1 && (K > 64 || d->tokLmTooBig))) ? FLTX_WHY_LM : 0;
+              (!lexi && d->lm->kind == 1 && (K > 64 || d->tokLm == nullptr))) ? FLTX_WHY_LM : 0;
       /* (logAdd on the lexicon lane engines: CTC, one word per spelling) */
       /* (logAdd on the lexicon decoder is no reason any more: every configuration the lexicon lane engines take without
        * it, they take with it) */
@@ -2481,7 +2492,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   /* (the lean step on an HBM workspace reads its atomically ORed addMask words at L2 as well: wsLoadAtomic64) */
   P.wsNoInv = (!d->wsInLds && d->hotLevel >= 1) ? 1 : 0;
   P.lmCache = d->useLmCache ? d->lmCache.as<unsigned long long>() : nullptr;
-  P.tokLm = d->tlane ? d->tokLm : nullptr;
+  P.tokLm = d->tokLm; /* (null unless this is a lexicon-free decoder over an n-gram LM with a dense table) */
   P.tokLmStride = d->N + 1;
   P.tlEdgeSlots = d->tlEdgeSlots;
   P.tlMaskSlots = d->tlMaskSlots;

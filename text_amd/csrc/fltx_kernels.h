@@ -870,9 +870,20 @@ FLTX_DEV float ngScore(const DecodeParams& P, const int32_t* ctxIn, uint32_t wor
  * = tag:32 | score bits:32, written and read whole; slot = (word ^ f(state)) mod kLmCache, tag = state:24 | word >> 12,
  * so slot and tag together determine (state, word): a hit is exact, never a hash coincidence. */
 constexpr int kLmCache = 4096;
+/* A token-level n-gram LM over a small token set has a dense (context, token) table (DecodeParams::tokLm, built by
+ * lmTokDense in fltx_api.cpp with the host twin of ngScore: the same floats).  The generic engine then keeps a state's
+ * context as a ROW NUMBER in word 0 of its stateCtx entry and a look-up is one gather instead of a chain of probes. */
+FLTX_DEV uint32_t tokLmRow(const DecodeParams& P, int b, uint32_t sid) {
+  const int L = P.lmOrder - 1;
+  return L > 0 ? (uint32_t)P.stateCtx[((size_t)b * P.stateCap + sid) * L] : 0u;
+}
 FLTX_DEV float lmScoreDev(const DecodeParams& P, int b, uint32_t sid, int usr) {
   if (P.lmKind == 0) {
     return 0.0f;
+  }
+  if (P.tokLm != nullptr) {
+    const int col = (usr >= 0 && usr < P.N) ? usr : 0;
+    return __uint_as_float((uint32_t)P.tokLm[(size_t)tokLmRow(P, b, sid) * (size_t)P.tokLmStride + (size_t)col].x);
   }
   const int L = P.lmOrder - 1;
   const int32_t* ctx = P.stateCtx + ((size_t)b * P.stateCap + sid) * L;
@@ -895,6 +906,9 @@ FLTX_DEV float lmScoreDev(const DecodeParams& P, int b, uint32_t sid, int usr) {
 FLTX_DEV float lmFinishDev(const DecodeParams& P, int b, uint32_t sid) {
   if (P.lmKind == 0) {
     return 0.0f;
+  }
+  if (P.tokLm != nullptr) {
+    return __uint_as_float((uint32_t)P.tokLm[(size_t)tokLmRow(P, b, sid) * (size_t)P.tokLmStride + (size_t)P.N].x);
   }
   const int L = P.lmOrder - 1;
   const int32_t* ctx = P.stateCtx + ((size_t)b * P.stateCap + sid) * L;
@@ -2465,12 +2479,18 @@ FLTX_DEV int buildBeam(const DecodeParams& P, const Ws& w, const FrameCtx& f, in
         int32_t* cout = P.stateCtx + ((size_t)f.b * P.stateCap + sid) * L;
         const int32_t edge = (int32_t)key.y;
         uint32_t word;
+        if (P.tokLm != nullptr) { /* (dense token-LM table: the new state's context is the row the edge leads to) */
+          if (L > 0) {
+            cout[0] = (edge >= 0 && edge < P.N) ? P.tokLm[(size_t)(uint32_t)cin[0] * (size_t)P.tokLmStride + (size_t)edge].y : 0;
+          }
+        } else {
         if (edge == kFinishEdge) {
           word = (uint32_t)P.lmEos;
         } else {
           word = (edge >= 0 && edge < P.nUsr) ? (uint32_t)P.usrToLm[edge] : (uint32_t)P.lmUnk;
         }
         ngScore(P, cin, word, cout); /* reads its whole input context before it writes */
+        }
       }
     } else {
       sid = w.bState[(f.cur) * P.K + h];
@@ -2881,8 +2901,8 @@ FLTX_DEV void decodeUtterance(const DecodeParams& P, char* wsBase, char* hotBase
         int32_t* c0 = P.stateCtx + (size_t)b * P.stateCap * L;
         uint32_t node = 0;
         float pr;
-        const bool ok = ngFind(P, 0u, (uint32_t)P.lmBos, node, pr);
-        for (int q = 0; q < L; ++q) {
+        const bool ok = P.tokLm == nullptr && ngFind(P, 0u, (uint32_t)P.lmBos, node, pr);
+        for (int q = 0; q < L; ++q) { /* (dense token-LM table: row 0 is the start context) */
           c0[q] = (q == 0 && ok) ? (int32_t)node : 0;
         }
       }
