@@ -1842,7 +1842,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   d->tokLmTooBig = false;
   const int2* tab = nullptr;
   int64_t nCtx = 0;
-  if (d->kind == FLTX_DECODER_LEXFREE && d->lm->kind == 1 && N <= 64 && !d->noTokDense) {
+  const bool tokenLm = d->kind == FLTX_DECODER_LEXFREE || (d->kind == FLTX_DECODER_LEXICON && d->isLmToken);
+  if (tokenLm && d->lm->kind == 1 && N <= 64 && !d->noTokDense) { /* (every index the LM is asked about is a token) */
     /* the dense table serves every engine this decoder can run on: the lane engine below gathers from it, and the
      * generic engine (beams beyond 64, streams, fallbacks) keeps a state's context as a row number and replaces its
      * chain of n-gram probes by the same gather (lmScoreDev) */
@@ -1854,7 +1855,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     d->tokLm = tab;
     d->tokLmCtx = tab ? nCtx : 0;
   }
-  if (tab && !d->noSlane && !d->noTlane && !d->genericAsked &&
+  if (tab && d->kind == FLTX_DECODER_LEXFREE && !d->noSlane && !d->noTlane && !d->genericAsked &&
       !d->noDense && d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs && K <= 64 &&
       d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
       (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
