@@ -556,19 +556,8 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           }
         }
         ldsBarrier();
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          if (cbin[c] == sc.bstar) {
-            const unsigned long long k = f64Key(csAt(c));
-            const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)c << 8) | (uint32_t)lane;
-            int rank = 0;
-            for (int i = 0; i < sc.cnt; ++i) {
-              const unsigned long long k2 = S.bKey[i];
-              rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
-            }
-            take |= rank < need ? (1u << c) : 0u;
-          }
-        }
+        take |= slRankBin<NC>(S.bKey, S.bOrd, sc.cnt, need, wave, [&](int c) { return cbin[c] == sc.bstar; },
+                              [&](int c) { return f64Key(csAt(c)); }); /* (broadcast + ballot: fltx_slane.h) */
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           selMask[c] = waveBallot(cbin[c] < sc.bstar || ((take >> c) & 1u) != 0u);

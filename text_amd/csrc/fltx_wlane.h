@@ -840,6 +840,10 @@ FLTX_DEV void wlaneUtterance(const DecodeParams& P, char* smem) {
           break;
         }
         if (sc.cnt <= kSlBCap) {
+          /* (the members loop over the list here, not slRankBin's broadcast + ballot of the other lane engines: with it
+           * this kernel -- which spills 460 scalar registers in its frame loop -- returned wrong survivors on the GPU for
+           * token beams of 64 while the emulator, compiling the same source, agreed with the oracle; not understood, so
+           * the loop that 600 GPU configurations have checked stays) */
 #pragma unroll
           for (int j = 0; j < GT; ++j) {
             if (cbin[j] == sc.bstar) {

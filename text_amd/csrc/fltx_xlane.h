@@ -732,19 +732,8 @@ FLTX_DEV void xlaneUtterance(const DecodeParams& P, char* smem) {
             }
           }
           ldsBarrier();
-#pragma unroll
-          for (int j = 0; j < GT; ++j) {
-            if (cbin[j] == sc.bstar) {
-              const unsigned long long k = f64Key(cs[j]);
-              const uint32_t o = ((uint32_t)wave << 16) | ((uint32_t)j << 8) | (uint32_t)lane;
-              int rank = 0;
-              for (int i = 0; i < sc.cnt; ++i) {
-                const unsigned long long k2 = S.bKey[i];
-                rank += (k2 > k || (k2 == k && S.bOrd[i] < o)) ? 1 : 0;
-              }
-              take |= rank < need ? (1u << j) : 0u;
-            }
-          }
+          take |= slRankBin<GT>(S.bKey, S.bOrd, sc.cnt, need, wave, [&](int j) { return cbin[j] == sc.bstar; },
+                                [&](int j) { return f64Key(cs[j]); }); /* (broadcast + ballot: fltx_slane.h) */
           lim = sc.bstar - 1;
           break;
         }
