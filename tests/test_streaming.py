@@ -123,6 +123,54 @@ def _random_lexfree_streams(session, oracle_lib, every):
     return ran, bad
 
 
+def _random_token_lm_streams(session, oracle_lib, every):
+    """... and with a token-level n-gram LM (round 6: slaneUtterance<.., ST, TL> -- state ids from the generic engine's
+    table, whose kernels do begin / end / prune / getBestHypothesis; a state's context a row of the dense table): the LM
+    scores of every event too.  -> (streams compared, of them with the chunks on the token-LM variant, mismatches)"""
+    import itertools
+    bad, ran, on_t = [], 0, 0
+    grid = itertools.product([1, 3, 10, 50, 64], [2.0, 25.0, float("inf")], [None, 5], [12, 29], [7, 60],
+                             ["ctc", "uniform"], [0.0, -0.6], ["ctc", "asg"], [2, 3, 4])
+    for i, (K, thr, Kt, N, T, dist, sil, crit, order) in enumerate(grid):
+        if i % every:
+            continue
+        c = cases.case("ts%d" % i, dist=dist, u=900 + i, T=T, N=N, K=K, Kt=Kt, thr=thr, sil_score=sil, crit=crit,
+                       trans_seed=(30 + i) if crit == "asg" else None, lm=("ngram", order, 80 + i % 3),
+                       lm_weight=[0.8, 1.5, 0.4][i % 3])
+        inp = helpers.case_inputs(c)
+        chunks, lbs = [[3, 9, 1, 12, 20, 30], [1] * 60, [25, 25, 25]][i % 3], [[0, 2, 0, 5], [0], [3, 1]][i % 3]
+        want = ss.trace_checker(oracle_lib, c, inp, chunks, lbs)
+        if ss.has_ties(want):
+            continue
+        d = session.decoder(c, inp)
+        d.stream_begin(1, N, T + 4)
+        on_t += d.get("tstream")
+        d.close()
+        got, _ = ss.trace_device(session, c, inp, chunks, lbs)
+        ran += 1
+        diff = ss.first_difference(want, got)
+        if diff:
+            bad.append(({k: c[k] for k in ("K", "thr", "Kt", "N", "T", "dist", "sil_score", "crit", "lm")}, diff))
+    return ran, on_t, bad
+
+
+def test_token_lm_stream_chunks_on_the_lane_state_engine_emulated(emu_session, oracle_lib):
+    ran, on_t, bad = _random_token_lm_streams(emu_session, oracle_lib, 61)
+    assert ran > 20 and on_t == ran and not bad, (ran, on_t, bad[:3])
+    # ... and with the variant switched off: the generic engine's frames, same traces
+    c = cases.case("ts_off", dist="ctc", u=990, T=40, N=29, K=10, lm=("ngram", 3, 81), lm_weight=0.8)
+    inp = helpers.case_inputs(c)
+    want = ss.trace_checker(oracle_lib, c, inp, [7, 13, 20], [0, 2])
+    got, _ = ss.trace_device(emu_session, c, inp, [7, 13, 20], [0, 2], tunables=[("sstream", 0)])
+    assert ss.first_difference(want, got) is None
+
+
+@pytest.mark.gpu
+def test_token_lm_stream_chunks_on_the_lane_state_engine(gpu_session, oracle_lib):
+    ran, on_t, bad = _random_token_lm_streams(gpu_session, oracle_lib, 3)
+    assert ran > 400 and on_t == ran and not bad, (ran, on_t, bad[:3])
+
+
 def test_lexfree_stream_chunks_on_the_lane_state_engine_emulated(emu_session, oracle_lib, stream_golden):
     c = cases.BY_NAME["lf_ctc_t60_k10"]
     d = emu_session.decoder(c, helpers.case_inputs(c))

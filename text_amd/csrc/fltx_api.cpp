@@ -472,6 +472,7 @@ struct fltx_decoder {
   /* stream chunks of the lexicon-free decoder on the lane = LM state engine (fltx_slane.h, ST): list positions per
    * token wave (0 = not used) and threads; begin / end / prune / best stay the lane-per-slot engine's */
   int sstream = 0, sstreamThreads = 0, noSstream = 0;
+  int tstream = 0; /* ... the stream's chunks run on fltx_slane.h's token-LM variant (ids from the generic engine's table) */
   bool sstreamLaunch = false;
   /* streams of the lexicon decoder on the optimistic geometry (LDS workspace, cut-off generation): a chunk that
    * overflows is decoded again from the saved beam on the general path (HBM workspace) */
@@ -1464,6 +1465,8 @@ int fltx_decoder_get(fltx_decoder* d, const char* key, int64_t* value) {
     *value = d->lastRedo;
   } else if (!strcmp(key, "sstream")) {
     *value = d->sstream;
+  } else if (!strcmp(key, "tstream")) { /* 1: the stream's chunks run on the token-LM variant of fltx_slane.h */
+    *value = d->tstream;
   } else if (!strcmp(key, "looks_dropped")) { /* defer_check = 2: batches that were overwritten without a look at their statuses */
     *value = d->looksDropped;
   } else if (!strcmp(key, "unread_redone")) { /* defer_check = 1: utterances decoded again while settling batches nobody read */
@@ -2043,6 +2046,24 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         devSync(d->ctx->stream); /* (w is a local) */
         d->xlmwordTrie = d->trie;
         d->xlmwordLm = d->lm;
+      }
+    }
+  }
+  /* ... and the chunks of a stream with a token-level n-gram LM (slaneUtterance<.., ST, TL>): begin / end / prune /
+   * getBestHypothesis stay the generic engine's kernels -- they know n-gram LMs and keep a state's context row in stateCtx --
+   * and the chunk's frames take their state ids from that engine's (parent id, edge) -> id table */
+  d->tstream = 0;
+  if (d->tokLm && d->kind == FLTX_DECODER_LEXFREE && !d->noSlane && !d->noTlane && !d->noSstream && !d->genericAsked &&
+      !d->offlineCall && d->keepScores && !d->opt.log_add && K <= 64 && d->recycle && d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
+      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N))) {
+    static const int geoS[][2] = {{576, 4}, {512, 5}, {576, 10}};
+    const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
+    for (const auto& g : geoS) {
+      if (nList <= g[1] * (g[0] / 64 - 2)) {
+        d->sstream = g[1];
+        d->sstreamThreads = g[0];
+        d->tstream = 1;
+        break;
       }
     }
   }
@@ -2629,8 +2650,15 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   } while (0)
   if (d->sstreamLaunch) {
 #define FLTX_LAUNCH_SSTREAM(WW, GG)                                                              \
-  hipLaunchKernelGGL((fltx_decode_kernel_slane_stream<WW, GG>), dim3(nGrid), dim3(WW), sizeof(SlaneLds), \
-                     d->ctx->stream, P)
+  do {                                                                                           \
+    if (d->tstream) {                                                                            \
+      hipLaunchKernelGGL((fltx_decode_kernel_tlane_stream<WW, GG>), dim3(nGrid), dim3(WW), sizeof(TlaneLds), \
+                         d->ctx->stream, P);                                                     \
+    } else {                                                                                     \
+      hipLaunchKernelGGL((fltx_decode_kernel_slane_stream<WW, GG>), dim3(nGrid), dim3(WW), sizeof(SlaneLds), \
+                         d->ctx->stream, P);                                                     \
+    }                                                                                            \
+  } while (0)
     switch (W * 100 + d->sstream) {
       case 57604: FLTX_LAUNCH_SSTREAM(576, 4); break;
       case 51205: FLTX_LAUNCH_SSTREAM(512, 5); break;

@@ -55,6 +55,10 @@
   FLTX_INST(fltx_decode_kernel_tlane<576, 4, false, true>)    \
   FLTX_INST(fltx_decode_kernel_tlane<512, 5, false, true>) /* (phase clocks: bench.py --profile) */
 #define FLTX_G29(W) FLTX_TLANE_SET(true) /* logAdd */
+#define FLTX_G30(W) /* stream chunks with a token LM */        \
+  FLTX_INST(fltx_decode_kernel_tlane_stream<576, 4>)          \
+  FLTX_INST(fltx_decode_kernel_tlane_stream<512, 5>)          \
+  FLTX_INST(fltx_decode_kernel_tlane_stream<576, 10>)
 #define FLTX_G16(W) /* stream chunks */                     \
   FLTX_INST(fltx_decode_kernel_slane_stream<576, 4>)         \
   FLTX_INST(fltx_decode_kernel_slane_stream<512, 5>)         \
@@ -191,6 +195,7 @@ FLTX_G26(0)
 FLTX_G27(0)
 FLTX_G28(0)
 FLTX_G29(0)
+FLTX_G30(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -222,6 +227,7 @@ FLTX_G29(0)
 #undef FLTX_G27
 #undef FLTX_G28
 #undef FLTX_G29
+#undef FLTX_G30
 #undef FLTX_TLANE_SET
 #undef FLTX_MLANE_SET
 #undef FLTX_YLANE_SET

@@ -78,6 +78,12 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_slane_stream(DecodeParam
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
   slaneUtterance<GT, false, true, false>(P, fltx_smem);
 }
+/* ... and with a token-level n-gram LM (state ids from the generic engine's table, whose kernels do begin / end / prune) */
+template <int W, int GT>
+__global__ void __launch_bounds__(W) fltx_decode_kernel_tlane_stream(DecodeParams P) {
+  extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
+  slaneUtterance<GT, false, true, false, true>(P, fltx_smem);
+}
 /* lane = (LM state, trie node) decode of a whole utterance (fltx_xlane.h): lexicon + ZeroLM */
 /* HM = 1: the LM-state memo in HBM, 28 KB of LDS -- several workgroups share a CU (batches beyond the CUs) */
 template <int W, int GT, int HM, bool PROF, bool LA = false> /* LA: logAdd merges */

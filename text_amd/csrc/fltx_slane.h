@@ -138,6 +138,7 @@ struct TlaneLds : SlaneLds {
   unsigned long long dmask[64];          /* old lane -> tokens whose child state this frame's build created from it */
   uint32_t evSid[64];                    /* re-entry event: the state's id when the edge memo had it, else kTlNoSid */
   uint32_t evNeed[64];                   /* ... bit 0: look the id up in the rows, bit 1: the child mask */
+  double lmNB[2][64], lmB[2][64];        /* streams (ST): the LM score of a state's two hypotheses (getBestHypothesis reports an ancestor's) */
   /* the memos, sized by the host (DecodeParams::tlEdgeSlots / tlMaskSlots, powers of two: larger when one workgroup
    * has the CU's LDS to itself): edge[E] (bit 63 | parent id:23 << 37 | token:14 << 23 | state id:23), mmMask[M],
    * mmTag[M] (state id, kTlNoSid = empty) */
@@ -526,6 +527,45 @@ FLTX_DEV __attribute__((noinline)) void slRelink(SlaneLds& S, const unsigned lon
   ldsBarrier();
 }
 
+/* Stream chunks of the token-LM variant (ST + TL): a stream's begin / prune / getBestHypothesis / end are the generic
+ * engine's kernels (they know n-gram LMs), so state ids come from ITS table -- open addressing over (epoch, parent id,
+ * edge) in HBM with the id beside the key (stateVal; ids are recycled by fltx_compact_states_kernel) -- as
+ * stateChildIds() hands them out.  The lexicon-free decoder asks about a (state, token) pair at most once per frame
+ * (one candidate per lane and token), so nobody waits for anybody: found -> read the id, else install the key and
+ * name the state from the stream's id counter.  `fresh` = false is LMState::child's memo saying "entered before". */
+FLTX_DEV uint32_t tlStreamChild(const DecodeParams& P, int b, uint32_t par, int32_t edge, uint32_t born, uint32_t* nextId,
+                                uint32_t* status, bool& fresh) {
+  unsigned long long* tab = P.stateTab + (size_t)b * P.stateCap;
+  uint32_t* val = P.stateVal + (size_t)b * P.stateCap;
+  const unsigned long long key = ((unsigned long long)P.epoch << 48) |
+      ((unsigned long long)(par & 0xFFFFFFu) << 24) | (unsigned long long)((uint32_t)(edge + 1) & 0xFFFFFFu);
+  const uint32_t mask = P.stateCap - 1;
+  uint32_t s = hashKey(par, (uint32_t)edge, 0x9747b28cu, 0) & mask;
+  fresh = false;
+  for (uint32_t probes = 0; probes < P.stateCap; ++probes) {
+    unsigned long long cur = loadCoherent64(&tab[s]);
+    for (;;) {
+      if (cur == key) {
+        return loadCoherent32(&val[s]);
+      }
+      if ((cur >> 48) == (unsigned long long)P.epoch) {
+        break; /* live entry of another state: next slot */
+      }
+      const unsigned long long old = atomCas64(&tab[s], cur, key);
+      if (old == cur) {
+        fresh = true;
+        const uint32_t id = allocStateId(P, b, atomAdd32(nextId, 1u), par, edge, born, status);
+        storeCoherent32(&val[s], id);
+        return id;
+      }
+      cur = old;
+    }
+    s = (s + 1) & mask;
+  }
+  atomOr32(status, ST_TABLE_FULL);
+  return 0u;
+}
+
 /* Re-entry with the memos of TlaneLds: what they know is applied by one thread per event, what they do not know is
  * looked up in the history rows as slReenter does (per event, rare), then every lane looks for its parent among the
  * re-entered states at once. */
@@ -686,11 +726,10 @@ FLTX_DEV double slLogAdd(double hi, double lo) { return hi + log1p(exp(lo - hi))
 template <int GT, bool LA, bool ST, bool PROF, bool TL = false>
 FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
   static_assert(!(LA && ST), "streams with logAdd stay on the lane-per-slot step");
-  static_assert(!(TL && ST), "streams with a token LM stay on the generic engine");
   using LdsT = typename std::conditional<TL, TlaneLds, SlaneLds>::type;
   LdsT& S = *(LdsT*)smem;
   TlMemo M = {};
-  if constexpr (TL) {
+  if constexpr (TL && !ST) { /* (a stream's memo is the generic engine's id table in HBM: tlStreamChild) */
     M = tlMemoOf(S, P.tlEdgeSlots, P.tlMaskSlots);
   }
   const int b = P.uttMap ? P.uttMap[blockIdx.x] : (int)blockIdx.x;
@@ -741,11 +780,13 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     if (tid == 0) {
       S.tlIn[0][0] = 0.0f; /* (the root state was not entered by a token) */
     }
-    for (int i = tid; i < P.tlEdgeSlots; i += W) {
-      M.edge[i] = 0ull;
-    }
-    for (int i = tid; i < P.tlMaskSlots; i += W) {
-      M.mmTag[i] = kTlNoSid;
+    if constexpr (!ST) {
+      for (int i = tid; i < P.tlEdgeSlots; i += W) {
+        M.edge[i] = 0ull;
+      }
+      for (int i = tid; i < P.tlMaskSlots; i += W) {
+        M.mmTag[i] = kTlNoSid;
+      }
     }
     if (tid < 64) {
       S.dmask[tid] = 0ull;
@@ -768,9 +809,20 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       const bool valid = lane < nB;
       const size_t g = (size_t)b * K + (valid ? lane : 0);
       const double sc = P.gScore[g], amv = P.gAm[g];
+      const double lmv0 = TL ? P.gLm[g] : 0.0;
       const uint32_t sid = valid ? P.gState[g] : 0xFFFFFFFFu, spar = P.gSPar[g], tp = P.gTokPb[g];
       const int32_t edge = P.gSEdge[g];
-      const unsigned long long mkv = P.gMask[g];
+      const unsigned long long mkv = TL ? 0ull : P.gMask[g];
+      /* TL: a state's n-gram context is a row of the dense table, kept by the generic engine's kernels (begin / end) in
+       * word 0 of its stateCtx entry; the LM score it was entered with is the parent state's row at its last token */
+      uint32_t ctxRow = 0u;
+      float linRow = 0.0f;
+      if constexpr (TL) {
+        if (valid && sid != 0u) {
+          ctxRow = tokLmRow(P, b, sid);
+          linRow = __uint_as_float((uint32_t)P.tokLm[(size_t)tokLmRow(P, b, spar) * (size_t)P.tokLmStride + (size_t)(edge & 63)].x);
+        }
+      }
       const bool isB = (tp & kPrevBlank) != 0u;
       int leader = lane;
       for (int i = 0; i < nB; ++i) {
@@ -786,9 +838,12 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         r.info = (uint32_t)(sid == 0u ? P.sil : (edge & 63));
         r.sid = sid;
         r.spar = sid == 0u ? 0x7FFFFFu : spar;
-        r.pad = 0u;
+        r.pad = TL ? ctxRow : 0u;
         S.rec[0][L] = r;
         S.mask[0][L] = mkv;
+        if constexpr (TL) {
+          S.tlIn[0][L] = linRow;
+        }
         S.rsNB[L] = (uint8_t)kSlNoHyp;
         S.rsB[L] = (uint8_t)kSlNoHyp;
       }
@@ -798,10 +853,16 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
           S.rec[0][L].b = sc;
           S.amB[0][L] = amv;
           S.rsB[L] = (uint8_t)lane;
+          if constexpr (TL) {
+            S.lmB[0][L] = lmv0;
+          }
         } else {
           S.rec[0][L].nb = sc;
           S.amNB[0][L] = amv;
           S.rsNB[L] = (uint8_t)lane;
+          if constexpr (TL) {
+            S.lmNB[0][L] = lmv0;
+          }
         }
       }
       waveSync();
@@ -979,6 +1040,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
        * still in the other parity's arrays; `dmask` has the edges their last extension created) -- the staging wave,
        * which waits longest at the barrier behind the frame's best (wave 0 wipes these masks after that barrier) */
       if (isSvc) {
+        if constexpr (!ST) {
         const bool dropped = lane < nStatePrev && S.newLane[lane] < 0;
         const uint32_t dsid = S.rec[q][lane].sid;
         const uint32_t ms = tlMaskSlot(M, dsid);
@@ -990,6 +1052,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
           M.mmMask[ms] = S.mask[q][lane] | S.dmask[lane];
         }
         S.dmask[lane] = 0ull;
+        }
         /* ... and the housekeeping for everybody (what this frame's build adds to): nobody else reads the other parity's
          * masks in this frame, and this wave has the time -- the first token wave is on the way to the barrier */
         S.cmask[q][lane] = 0ull;
@@ -1044,7 +1107,9 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     }
     }
     if (!reentryDone && nev != 0u) { /* rare: states re-entered the beam in the previous build */
-      if constexpr (TL) {
+      if constexpr (TL && ST) {
+        /* (never: a stream's states are named by the generic engine's table, every event knows its id) */
+      } else if constexpr (TL) {
         tlReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K, P.tlEdgeSlots, P.tlMaskSlots);
       } else if (ST) {
         slRelink(S, P.maskTab + (size_t)b * P.idCap, p, nState);
@@ -1072,11 +1137,17 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const uint32_t hypM = whichB ? hypB : hypNB;
     /* streams carry the emitting-model score of every hypothesis (getBestHypothesis returns an ancestor's) */
     double amNBv = 0.0, amBv = 0.0, parAmNB = 0.0, parAmB = 0.0;
+    double lmNBv = 0.0, lmBv = 0.0, parLmNB = 0.0, parLmB = 0.0; /* ... and, with a token LM, its LM score */
     if (ST && !isSvc) {
       amNBv = S.amNB[p][lane];
       amBv = S.amB[p][lane];
+      if constexpr (TL) {
+        lmNBv = S.lmNB[p][lane];
+        lmBv = S.lmB[p][lane];
+      }
     }
     const double amM = whichB ? amBv : amNBv;
+    const double lmM = whichB ? lmBv : lmNBv;
     auto amStep = [&](double amPrev, double e, int n, int prevTok) {
       double x = e; /* LexiconFreeDecoder.cpp:58-64: the ASG transition enters the emitting-model score only */
       if (!ctc && P.transitions && total0 + t > 0) {
@@ -1093,6 +1164,10 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       if (ST) {
         parAmNB = S.amNB[p][pl >= 0 ? pl : 0];
         parAmB = S.amB[p][pl >= 0 ? pl : 0];
+        if constexpr (TL) {
+          parLmNB = S.lmNB[p][pl >= 0 ? pl : 0];
+          parLmB = S.lmB[p][pl >= 0 ? pl : 0];
+        }
       }
     }
     FLTX_SLPROF(0);
@@ -1101,6 +1176,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     uint32_t parR = kSlNoHyp;
     double amR = 0.0; /* streams: emitting-model score of the repeat group's winning member ... */
     int prevR = 0;    /* ... and its token (ASG transition) */
+    double lmR = 0.0; /* ... and (token LM) its LM score, the entering score included for the parent's extension */
     SlRowRegs nextRow = {};
     if (isSvc) {
       /* the next frame's emission row (the masks and counters this frame's build adds to are wiped
@@ -1324,12 +1400,21 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         cL = cL + wL;
         double cR = r0;
         parR = hypNB;
+        amR = amNBv;
+        prevR = last;
+        lmR = lmNBv;
         const bool t1 = has1 & ((r1 > cR) | ((r1 == cR) & (h1 < parR)));
         cR = t1 ? r1 : cR;
         parR = t1 ? h1 : parR;
+        amR = t1 ? parAmNB : amR;
+        prevR = t1 ? lastP : prevR;
+        lmR = t1 ? parLmNB + (double)lIn : lmR;
         const bool t2 = has2 & ((r2 > cR) | ((r2 == cR) & (h2 < parR)));
         cR = t2 ? r2 : cR;
         parR = t2 ? h2 : parR;
+        amR = t2 ? parAmB : amR;
+        prevR = t2 ? blank : prevR;
+        lmR = t2 ? parLmB + (double)lIn : lmR;
         pre[1] = lastOk && (has0 || has1 || has2) && cR == cR;
         pre[2] = ctc && lastOk && hasB && ((cm >> last) & 1ull) == 0ull && cL == cL;
         cs[0] = cB;
@@ -1627,15 +1712,15 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     const int myNewLane = S.newLane[lane];
     const int plNew = S.newLane[pl >= 0 ? pl : 0];
     auto plainRec = [&](uint32_t hp, int n) { return make_int2(hp == kSlNoHyp ? -1 : (int)hp, n); };
-    auto scoreRec = [&](int64_t at, double c, double am) {
+    auto scoreRec = [&](int64_t at, double c, double am, double lmv) {
       if (P.histS) {
         double* hs = P.histS + 3 * at;
         hs[0] = c;
         hs[1] = am;
-        hs[2] = 0.0;
+        hs[2] = lmv;
       }
     };
-    auto newState = [&](int idx, double c, int n, uint32_t hp, double amNew, uint32_t ctxNew, float lNew) {
+    auto newState = [&](int idx, double c, int n, uint32_t hp, double amNew, uint32_t ctxNew, float lNew, double lmNew) {
       const int nl = nSurv + idx;
       const uint32_t hyp = (uint32_t)(nHSurv + idx);
       SlRec r;
@@ -1648,10 +1733,22 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       if (TL) {
         S.tlIn[q][nl] = lNew;
       }
-      const bool again = ((mk >> n) & 1ull) != 0ull; /* this edge had a child before */
+      bool again = ((mk >> n) & 1ull) != 0ull; /* this edge had a child before */
       uint32_t known = kTlNoSid;
       bool tlSlow = true; /* a re-entry the memos do not answer: the next frame looks it up in the rows (tlReenter) */
-      if constexpr (TL) {
+      if constexpr (TL && ST) {
+        /* a stream: the generic engine's (parent id, edge) -> id table names the state and remembers that it did */
+        bool fresh = false;
+        r.sid = tlStreamChild(P, b, me.sid, n, (uint32_t)(total0 + t + 1), &S.scal[SL_NEXTID], &S.scal[SL_STATUS], fresh);
+        again = !fresh;
+        known = r.sid;
+        tlSlow = false;
+        if (fresh && P.lmOrder > 1) {
+          P.stateCtx[((size_t)b * P.stateCap + r.sid) * (size_t)(P.lmOrder - 1)] = (int32_t)ctxNew; /* (its context: a row number) */
+        }
+        S.amNB[q][nl] = amNew;
+        S.lmNB[q][nl] = lmNew;
+      } else if constexpr (TL) {
         const uint32_t es = tlEdgeSlot(M, me.sid, (uint32_t)n);
         if (again) { /* ... and the edge memo may still know which: the state keeps its id, the rows are not searched */
           const unsigned long long cur = M.edge[es];
@@ -1673,7 +1770,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
           atomOr64(&S.dmask[lane], 1ull << n);
         }
       }
-      if (ST) {
+      if (ST && !TL) {
         uint32_t* slot = &P.childTab[((size_t)b * P.idCap + me.sid) * N + n];
         if (again) {
           r.sid = loadCoherent32(slot);
@@ -1693,7 +1790,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       }
       if (ST) {
         histPT[hrow + hyp] = plainRec(hp, n);
-        scoreRec(hrow + hyp, c, amNew);
+        scoreRec(hrow + hyp, c, amNew, lmNew);
       } else {
         histPT[hrow + hyp] = make_int2((int)(hp | kSlNewFlag | (me.sid << 9)), n);
       }
@@ -1723,7 +1820,8 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
             /* (the position's token from its bit: reading tokId here is an LDS round trip per surviving position) */
             const int nTok = tb[j] != 0ull ? __builtin_ctzll(tb[j]) : 0;
             newState(offW + myNew[j], cs[j], nTok, hypM, ST ? amStep(amM, ev[j], nTok, whichB ? blank : last) : 0.0,
-                     (uint32_t)lmv[j].y, __uint_as_float((uint32_t)lmv[j].x));
+                     (uint32_t)lmv[j].y, __uint_as_float((uint32_t)lmv[j].x),
+                     (ST && TL) ? lmM + (double)__uint_as_float((uint32_t)lmv[j].x) : 0.0);
           }
         }
       }
@@ -1754,13 +1852,19 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
             const double a = amStep(amR, eLast, last, prevR);
             S.amNB[q][surv] = a;
             histPT[hrow + hNB] = plainRec(parR, last);
-            scoreRec(hrow + hNB, cs[1], a);
+            scoreRec(hrow + hNB, cs[1], a, lmR);
+            if constexpr (TL) {
+              S.lmNB[q][surv] = lmR;
+            }
           }
           if (sB) {
             const double a = amM + eBlank;
             S.amB[q][surv] = a;
             histPT[hrow + hB] = plainRec(hypM, blank);
-            scoreRec(hrow + hB, cs[0], a);
+            scoreRec(hrow + hB, cs[0], a, lmM);
+            if constexpr (TL) {
+              S.lmB[q][surv] = lmM;
+            }
           }
         } else {
           if (sR) {
@@ -1773,7 +1877,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       }
       if ((selMask[2] >> lane) & 1ull) {
         newState(offW + myNew[2], cs[2], last, hypB, ST ? amStep(amBv, eLast, last, blank) : 0.0, (uint32_t)lmLast.y,
-                 __uint_as_float((uint32_t)lmLast.x));
+                 __uint_as_float((uint32_t)lmLast.x), (ST && TL) ? lmBv + (double)__uint_as_float((uint32_t)lmLast.x) : 0.0);
       }
     }
     nStatePrev = nState;
@@ -1815,7 +1919,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
     if (wave == 0 && T > 0) {
       /* states entered again in the last frame: the relink of the next frame never runs -- their child masks come
        * from maskTab now (the links are found again by the restore) */
-      const int nevEnd = (int)S.row[pe].nev;
+      const int nevEnd = TL ? 0 : (int)S.row[pe].nev; /* (TL: no child masks -- the generic engine's table is the memo) */
       for (int e = 0; e < nevEnd; ++e) {
         if (lane == 0) {
           const int X = (int)S.evLane[e];
@@ -1847,6 +1951,11 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       const unsigned long long recNB = hasNB ? loadCoherent64(hrec + sNB) : 0ull;
       const unsigned long long recB = hasB ? loadCoherent64(hrec + sB) : 0ull;
       const double aNB = S.amNB[pe][live ? lane : 0], aB = S.amB[pe][live ? lane : 0];
+      double lNBo = 0.0, lBo = 0.0;
+      if constexpr (TL) {
+        lNBo = S.lmNB[pe][live ? lane : 0];
+        lBo = S.lmB[pe][live ? lane : 0];
+      }
       const unsigned long long mkv = S.mask[pe][live ? lane : 0];
       const uint32_t lastTok = me.info & 0xFFu;
       const uint32_t sparOut = me.sid == 0u ? kNoParent : me.spar;
@@ -1855,31 +1964,33 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every lane has its old records before any is rewritten */
 #endif
       waveSync();
-      auto put = [&](int r, double sc, double am, uint32_t tokpb, unsigned long long rec) {
+      auto put = [&](int r, double sc, double am, uint32_t tokpb, unsigned long long rec, double lmv) {
         const size_t g = (size_t)b * K + r;
         P.gScore[g] = sc;
         P.gAm[g] = am;
-        P.gLm[g] = 0.0;
+        P.gLm[g] = lmv;
         P.gState[g] = me.sid;
         P.gSPar[g] = sparOut;
         P.gSEdge[g] = edgeOut;
         P.gLex[g] = 0u;
         P.gLexMax[g] = 0.0f;
         P.gTokPb[g] = tokpb;
-        P.gMask[g] = mkv;
+        if (!TL) {
+          P.gMask[g] = mkv;
+        }
         ((unsigned long long*)(P.histPT + hlast))[r] = rec;
         if (P.histS) {
           double* hs = P.histS + 3 * (hlast + r);
           hs[0] = sc;
           hs[1] = am;
-          hs[2] = 0.0;
+          hs[2] = lmv;
         }
       };
       if (hasNB) {
-        put(rNB, me.nb, aNB, lastTok, recNB);
+        put(rNB, me.nb, aNB, lastTok, recNB, lNBo);
       }
       if (hasB) {
-        put(rB, me.b, aB, (uint32_t)blank | kPrevBlank, recB);
+        put(rB, me.b, aB, (uint32_t)blank | kPrevBlank, recB, lBo);
       }
       if (lane == 0) {
         P.uttNBeam[b] = dead ? 0 : nHyp;
