@@ -19,16 +19,17 @@ python bench.py --workload C2T --steps 5 --warmup 2 --no-extras --no-cpu --pipel
 cd /tmp
 for w in C2 C2T C3 C4; do
   st=6; [ $w = C4 ] && st=4
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$w" -- python "$R/bench.py" --workload $w --steps $st --warmup 2 --no-cpu --no-secondary > "$O/prof_$w.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$w" -- python "$R/bench.py" --workload $w --steps $st --warmup 2 --no-cpu --no-secondary --sustained-seconds 0 > "$O/prof_$w.log" 2>&1
 done
 for w in C2 C2T C3 C4; do
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary > "$O/pmc_fetch_$w.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary > "$O/pmc_write_$w.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary --sustained-seconds 0 > "$O/pmc_fetch_$w.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary --sustained-seconds 0 > "$O/pmc_write_$w.log" 2>&1
 done
 for w in C2 C2T; do
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d "$O/sq1_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary > "$O/sq1_$w.log" 2>&1
-  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_BRANCH --output-format csv -d "$O/sq2_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary > "$O/sq2_$w.log" 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d "$O/sq1_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary --sustained-seconds 0 > "$O/sq1_$w.log" 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_BRANCH --output-format csv -d "$O/sq2_$w" -- python "$R/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu --no-secondary --sustained-seconds 0 > "$O/sq2_$w.log" 2>&1
 done
 cd "$R"
 find "$O" -name "*.db" -delete 2>/dev/null
+find "$O" -name "*_kernel_trace.csv" -size +4M -delete 2>/dev/null  # (the per-dispatch trace: the stats file is what is kept)
 du -sh "$O"
