@@ -92,6 +92,8 @@ def parse():
                     "kernels of the two decoder objects share the CUs (defer_check, the 512-thread / shared-CU geometries)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / C5-share / WP lines of the default run")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the back-to-back leg (0 = off)")
+    ap.add_argument("--streaming-only", action="store_true", help="run the streaming leg alone and print its entry (profiling "
+                    "a stream's kernels: rocprofv3 --kernel-trace --stats -- python bench.py --workload C2T --streaming-only)")
     ap.add_argument("--profile", action="store_true", help="print the per-phase clock split to stderr")
     ap.add_argument("--profile-out", default="", help="... and append it to this file (profiles/rNN/phase_split_*.txt)")
     ap.add_argument("--mode", default="process", choices=["process", "group"],
@@ -292,6 +294,8 @@ def measure(a, torch, dist, rank, local, world, primary):
     B = a.batch or cfg["batch"]
     job = Job(a, rank, local, B, cfg)
     T, N, K, Kt = job.T, job.N, job.K, job.Kt
+    if a.streaming_only:
+        return {"workload": a.workload, "streaming": streaming(job, B, T, N)}, None  # (no metric / value: not a bench line)
     e_dev = torch.from_numpy(job.e_host).cuda()  # resident in HBM before timing
     job.e_dev_ptr = e_dev.data_ptr()
     torch.cuda.synchronize()

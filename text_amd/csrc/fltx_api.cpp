@@ -2652,8 +2652,8 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
 #define FLTX_LAUNCH_SSTREAM(WW, GG)                                                              \
   do {                                                                                           \
     if (d->tstream) {                                                                            \
-      hipLaunchKernelGGL((fltx_decode_kernel_tlane_stream<WW, GG>), dim3(nGrid), dim3(WW), sizeof(TlaneLds), \
-                         d->ctx->stream, P);                                                     \
+      hipLaunchKernelGGL((fltx_decode_kernel_tlane_stream<WW, GG>), dim3(nGrid), dim3(WW),       \
+                         sizeof(TlaneLds) + (size_t)(WW / 64) * kTlGatherBytes, d->ctx->stream, P); \
     } else {                                                                                     \
       hipLaunchKernelGGL((fltx_decode_kernel_slane_stream<WW, GG>), dim3(nGrid), dim3(WW), sizeof(SlaneLds), \
                          d->ctx->stream, P);                                                     \

@@ -134,6 +134,7 @@ enum { SL_NSURV = 0, SL_NHSURV = 1, SL_BCNT = 2, SL_NEXTID = 3, SL_STATUS = 4, S
  *             wave, together with the edges the state's last extension created (`dmask`).
  * A miss in either sends that one event to the rows (tlReenter). */
 constexpr uint32_t kTlNoSid = 0xFFFFFFFFu;
+constexpr int kTlGather = 12; /* survivors a token wave of the stream variant builds in one pass (more: position by position) */
 struct TlaneLds : SlaneLds {
   unsigned long long dmask[64];          /* old lane -> tokens whose child state this frame's build created from it */
   uint32_t evSid[64];                    /* re-entry event: the state's id when the edge memo had it, else kTlNoSid */
@@ -141,9 +142,11 @@ struct TlaneLds : SlaneLds {
   double lmNB[2][64], lmB[2][64];        /* streams (ST): the LM score of a state's two hypotheses (getBestHypothesis reports an ancestor's) */
   /* the memos, sized by the host (DecodeParams::tlEdgeSlots / tlMaskSlots, powers of two: larger when one workgroup
    * has the CU's LDS to itself): edge[E] (bit 63 | parent id:23 << 37 | token:14 << 23 | state id:23), mmMask[M],
-   * mmTag[M] (state id, kTlNoSid = empty) */
-  unsigned long long memo[1];
+   * mmTag[M] (state id, kTlNoSid = empty) -- or, in the stream variant (whose ids come from the table in HBM and which
+   * has no memo), the token waves' scratch for a gathered build: kTlGatherBytes per wave */
+  alignas(16) unsigned long long memo[1];
 };
+constexpr int kTlGatherBytes = kTlGather * 48; /* c, am, lm (doubles), token | hyp | parent's new lane, parent id, ctx row, lm step */
 struct TlMemo {
   unsigned long long* edge;
   unsigned long long* mmMask;
@@ -1720,26 +1723,29 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         hs[2] = lmv;
       }
     };
-    auto newState = [&](int idx, double c, int n, uint32_t hp, double amNew, uint32_t ctxNew, float lNew, double lmNew) {
+    /* (the parent lane's data as arguments: a token wave of the stream variant with a token LM gathers its survivors
+     * into its first lanes and builds them in one pass, see below -- there the parent is another lane's) */
+    auto newStateOf = [&](int idx, double c, int n, uint32_t hp, double amNew, uint32_t ctxNew, float lNew, double lmNew,
+                          uint32_t parSid, bool againBit, int parNewLane, int parOldLane) {
       const int nl = nSurv + idx;
       const uint32_t hyp = (uint32_t)(nHSurv + idx);
       SlRec r;
       r.nb = c;
       r.b = NEG;
-      r.info = (uint32_t)n | ((uint32_t)(myNewLane + 1) << 8) | (hyp << 16) | (kSlNoHyp << 24);
+      r.info = (uint32_t)n | ((uint32_t)(parNewLane + 1) << 8) | (hyp << 16) | (kSlNoHyp << 24);
       r.sid = (uint32_t)frameOut * (uint32_t)K + hyp;
-      r.spar = me.sid;
+      r.spar = parSid;
       r.pad = TL ? ctxNew : 0u; /* (a function of the token history: a state entered again gets the context it had) */
       if (TL) {
         S.tlIn[q][nl] = lNew;
       }
-      bool again = ((mk >> n) & 1ull) != 0ull; /* this edge had a child before */
+      bool again = againBit; /* this edge had a child before */
       uint32_t known = kTlNoSid;
       bool tlSlow = true; /* a re-entry the memos do not answer: the next frame looks it up in the rows (tlReenter) */
       if constexpr (TL && ST) {
         /* a stream: the generic engine's (parent id, edge) -> id table names the state and remembers that it did */
         bool fresh = false;
-        r.sid = tlStreamChild(P, b, me.sid, n, (uint32_t)(total0 + t + 1), &S.scal[SL_NEXTID], &S.scal[SL_STATUS], fresh);
+        r.sid = tlStreamChild(P, b, parSid, n, (uint32_t)(total0 + t + 1), &S.scal[SL_NEXTID], &S.scal[SL_STATUS], fresh);
         again = !fresh;
         known = r.sid;
         tlSlow = false;
@@ -1749,10 +1755,10 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
         S.amNB[q][nl] = amNew;
         S.lmNB[q][nl] = lmNew;
       } else if constexpr (TL) {
-        const uint32_t es = tlEdgeSlot(M, me.sid, (uint32_t)n);
+        const uint32_t es = tlEdgeSlot(M, parSid, (uint32_t)n);
         if (again) { /* ... and the edge memo may still know which: the state keeps its id, the rows are not searched */
           const unsigned long long cur = M.edge[es];
-          if ((cur >> 23) == (tlEdgePack(me.sid, (uint32_t)n, 0u) >> 23)) {
+          if ((cur >> 23) == (tlEdgePack(parSid, (uint32_t)n, 0u) >> 23)) {
             known = (uint32_t)cur & 0x7FFFFFu;
             r.sid = known;
             /* ... and the mask memo the child mask it had when it dropped out: then nothing is left for the next frame
@@ -1764,47 +1770,50 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
             }
           }
         } else {
-          M.edge[es] = tlEdgePack(me.sid, (uint32_t)n, r.sid);
+          M.edge[es] = tlEdgePack(parSid, (uint32_t)n, r.sid);
         }
-        if (myNewLane < 0) { /* the parent drops out with this frame: its saved child mask must hold this edge */
-          atomOr64(&S.dmask[lane], 1ull << n);
+        if (parNewLane < 0) { /* the parent drops out with this frame: its saved child mask must hold this edge */
+          atomOr64(&S.dmask[parOldLane], 1ull << n);
         }
       }
       if (ST && !TL) {
-        uint32_t* slot = &P.childTab[((size_t)b * P.idCap + me.sid) * N + n];
+        uint32_t* slot = &P.childTab[((size_t)b * P.idCap + parSid) * N + n];
         if (again) {
           r.sid = loadCoherent32(slot);
         } else {
-          r.sid = allocStateId(P, b, atomAdd32(&S.scal[SL_NEXTID], 1u), me.sid, n, (uint32_t)(total0 + t + 1),
+          r.sid = allocStateId(P, b, atomAdd32(&S.scal[SL_NEXTID], 1u), parSid, n, (uint32_t)(total0 + t + 1),
                                &S.scal[SL_STATUS]);
           *slot = r.sid;
           P.maskTab[(size_t)b * P.idCap + r.sid] = 0ull;
-          atomOr64(&P.maskTab[(size_t)b * P.idCap + me.sid], 1ull << n); /* (the parent may leave the beam) */
+          atomOr64(&P.maskTab[(size_t)b * P.idCap + parSid], 1ull << n); /* (the parent may leave the beam) */
         }
         S.amNB[q][nl] = amNew;
       }
       S.rec[q][nl] = r;
-      if (myNewLane >= 0) {
-        atomOr64(&S.cmask[q][myNewLane], 1ull << n);
-        atomOr64(&S.mask[q][myNewLane], 1ull << n);
+      if (parNewLane >= 0) {
+        atomOr64(&S.cmask[q][parNewLane], 1ull << n);
+        atomOr64(&S.mask[q][parNewLane], 1ull << n);
       }
       if (ST) {
         histPT[hrow + hyp] = plainRec(hp, n);
         scoreRec(hrow + hyp, c, amNew, lmNew);
       } else {
-        histPT[hrow + hyp] = make_int2((int)(hp | kSlNewFlag | (me.sid << 9)), n);
+        histPT[hrow + hyp] = make_int2((int)(hp | kSlNewFlag | (parSid << 9)), n);
       }
       if (again) { /* it may have descendants in the beam */
         /* (TL: the upper half counts the events that need the rows) */
         const uint32_t e = atomAdd32(&S.row[q].nev, (TL && tlSlow) ? 0x10001u : 1u) & 0xFFFFu;
         S.evLane[e] = (uint32_t)nl;
-        S.evSpar[e] = me.sid;
+        S.evSpar[e] = parSid;
         S.evTok[e] = (uint32_t)n;
         if constexpr (TL) {
           S.evSid[e] = known;
           S.evNeed[e] = known == kTlNoSid ? 3u : (tlSlow ? 2u : 0u);
         }
       }
+    };
+    auto newState = [&](int idx, double c, int n, uint32_t hp, double amNew, uint32_t ctxNew, float lNew, double lmNew) {
+      newStateOf(idx, c, n, hp, amNew, ctxNew, lNew, lmNew, me.sid, ((mk >> n) & 1ull) != 0ull, myNewLane, lane);
     };
     if (isSvc) {
       /* (its part of the build went ahead of the second barrier) */
@@ -1813,6 +1822,44 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
                                                                        (a token wave: they wait at the third barrier) */
         histPT[hrow + lane] = make_int2((int)kSlNoHyp, -1);
       }
+      bool gathered = false;
+      if constexpr (TL && ST) {
+        /* A stream's new state costs a look-up (and, for a fresh state, a compare-and-swap) in the id table in HBM: a
+         * microsecond or two each.  The loop below would pay that once per list position that has a survivor, one after
+         * the other; instead the wave's survivors drop what a new state is made from into the wave's scratch and the
+         * wave's first lanes build one state each -- their table accesses are in flight together.  (Offline, where a new
+         * state touches LDS only, this was tried and lost: DESIGN 4.1.) */
+        if (nNewWave > 1 && nNewWave <= kTlGather) {
+          gathered = true;
+          uint4* sc4 = (uint4*)((char*)S.memo + wave * kTlGatherBytes);
+#pragma unroll
+          for (int j = 0; j < GT; ++j) {
+            if (selMask[j] != 0ull) {
+              if ((selMask[j] >> lane) & 1ull) {
+                const uint32_t nTok = tb[j] != 0ull ? (uint32_t)__builtin_ctzll(tb[j]) : 0u;
+                const float lj = __uint_as_float((uint32_t)lmv[j].x);
+                const unsigned long long cb = (unsigned long long)__double_as_longlong(cs[j]);
+                const unsigned long long ab =
+                    (unsigned long long)__double_as_longlong(amStep(amM, ev[j], (int)nTok, whichB ? blank : last));
+                const unsigned long long lb = (unsigned long long)__double_as_longlong(lmM + (double)lj);
+                const uint32_t w0 = nTok | (hypM << 8) | ((uint32_t)(myNewLane + 1) << 16);
+                sc4[3 * myNew[j]] = make_uint4((uint32_t)cb, (uint32_t)(cb >> 32), (uint32_t)ab, (uint32_t)(ab >> 32));
+                sc4[3 * myNew[j] + 1] = make_uint4((uint32_t)lb, (uint32_t)(lb >> 32), w0, me.sid);
+                sc4[3 * myNew[j] + 2] = make_uint4((uint32_t)lmv[j].y, (uint32_t)lmv[j].x, 0u, 0u);
+              }
+            }
+          }
+          waveSync();
+          if (lane < nNewWave) {
+            const uint4 a = sc4[3 * lane], bq = sc4[3 * lane + 1], cq = sc4[3 * lane + 2];
+            newStateOf(offW + lane, __longlong_as_double((long long)(((unsigned long long)a.y << 32) | a.x)), (int)(bq.z & 0xFFu),
+                       (bq.z >> 8) & 0xFFu, __longlong_as_double((long long)(((unsigned long long)a.w << 32) | a.z)), cq.x,
+                       __uint_as_float(cq.y), __longlong_as_double((long long)(((unsigned long long)bq.y << 32) | bq.x)), bq.w,
+                       false, (int)((bq.z >> 16) & 0x7Fu) - 1, 0);
+          }
+        }
+      }
+      if (!gathered) {
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
         if (selMask[j] != 0ull) { /* (most positions of most frames have no survivor at all) */
@@ -1824,6 +1871,7 @@ FLTX_DEV void slaneUtterance(const DecodeParams& P, char* smem) {
                      (ST && TL) ? lmM + (double)__uint_as_float((uint32_t)lmv[j].x) : 0.0);
           }
         }
+      }
       }
     } else {
       if (surv >= 0) {
