@@ -548,7 +548,7 @@ def measure(a, torch, dist, rank, local, world, primary):
                                         ("WP", "WP", 0, 8), ("C2_tokLM", "C2T", 0, 16)):
             a2 = copy.copy(a)
             a2.workload, a2.batch, a2.cpu_sample = wl, batch, sample
-            a2.secondary_legs = name in ("C3", "C4")
+            a2.secondary_legs = name in ("C3", "C4", "C2_tokLM")  # (their streaming and end-to-end legs too)
             a2.steps, a2.warmup = max(12, a.steps), 2  # (two batches in flight: a short region is mostly ramp-up)
             t0 = time.perf_counter()
             try:

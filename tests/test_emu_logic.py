@@ -2,10 +2,13 @@
 threads (tests/emu), against the reference golden vectors.  This checks kernel
 logic only; the parity claim for the product is made by tests/test_gpu_parity.py
 on a real MI355X."""
+import os
+
 import pytest
 
 import cases
 import helpers
+from oracle import orclib
 
 SMALL = [c for c in cases.CASES if c["size"] == "small" and c["T"] <= 40]
 
@@ -373,6 +376,54 @@ def test_emulated_token_lm_on_the_lane_state_engine(emu_session, oracle_lib, gol
     ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 60, 6, [2, 7, 20], emu=True, sets={"tlane": 0})
     assert ran >= 50 and served == 0 and not bad, (ran, served, bad[:3])
     assert not test_gpu_batches._token_lm_beyond_the_lane_engine(emu_session, oracle_lib, emu=True)
+
+
+def _token_lm_with_many_contexts(sess, oracle_lib, T=30):
+    """A token-level 4-gram whose dense (context, token) table has more rows than the host builder scores in one block
+    (fltx_api.cpp lmTokDense: 16 384 rows between two numbering passes, rows scored by several threads): the lane-state
+    engine over it against the oracle, and the number of contexts against the model's own n-gram counts."""
+    from text_amd import _capi, ngram_synth
+    N = 29
+    vocab = ngram_synth.words(N, "t")
+    os.makedirs(helpers.NGRAM_DIR, exist_ok=True)
+    path = os.path.join(helpers.NGRAM_DIR, "lm_tok_many_ctx_o4.arpa")
+    if not os.path.exists(path):
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        ngram_synth.write_arpa(tmp, vocab, 4, (0, 900, 22000, 30000), 13)
+        os.replace(tmp, path)
+    with open(path) as f:
+        head = [next(f) for _ in range(5)]
+    grams = [int(line.split("=")[1]) for line in head[1:5]]
+    lm = _capi.ArpaLM(path, vocab, lib=sess.lib)
+    olm = oracle_lib.lm_arpa_create(path.encode(), "\n".join(vocab).encode())
+    bad = []
+    for k, (K, crit, dist) in enumerate(((16, "ctc", "ctc"), (50, "ctc", "uniform"), (33, "asg", "ctc"))):
+        c = cases.case(name="many_ctx%d" % k, kind="lexfree", dist=dist, T=T, N=N, K=K, u=930 + k, lm=("ngram", 4, 13),
+                       lm_weight=0.9, is_lm_token=True, crit=crit, trans_seed=3 if crit == "asg" else None)
+        inp = helpers.case_inputs(c)
+        d = sess.decoder(c, inp, lm=lm)
+        d.decode_batch(inp["e"], [T], N)
+        n_ctx = d.get("toklm_contexts")
+        assert d.get("engine") == 4 and d.get("tlane") == 1 and d.get("redone") == 0, (d.get("engine"), d.get("why_not_lane"))
+        got = d.results(0)
+        d.close()
+        opt = orclib.make_options(c["K"], c["Kt"], c["thr"], c["lm_weight"], c["word_score"], c["unk_score"], c["sil_score"],
+                                  c["log_add"], c["crit"])
+        od = oracle_lib.lexfree(opt, olm, 0, N - 1 if crit == "ctc" else -1, inp["tr"])
+        want = oracle_lib.decode(od, inp["e"], T, N)
+        oracle_lib.decoder_destroy(od)
+        ok, why = helpers.hyps_equal(got, want)
+        if not ok:
+            bad.append((c["name"], why))
+    oracle_lib.lm_destroy(olm)
+    # reachable KenLM states are n-grams of order < 4 (plus the empty context): more than one block of them, not more
+    # than the model holds
+    assert 16384 < n_ctx <= 1 + grams[0] + grams[1] + grams[2], (n_ctx, grams)
+    return bad
+
+
+def test_emulated_token_lm_table_built_in_several_blocks(emu_session, oracle_lib):
+    assert not _token_lm_with_many_contexts(emu_session, oracle_lib, T=20)
 
 
 def test_emulated_word_piece_engine(emu_session, oracle_lib):

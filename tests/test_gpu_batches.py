@@ -387,6 +387,13 @@ def test_token_lm_beyond_the_lane_engine(gpu_session, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_token_lm_table_built_in_several_blocks(gpu_session, oracle_lib):
+    """A token 4-gram with more contexts than one block of the dense table's host builder (tests/test_emu_logic.py)."""
+    import test_emu_logic
+    assert not test_emu_logic._token_lm_with_many_contexts(gpu_session, oracle_lib, T=300)
+
+
+@pytest.mark.gpu
 def test_token_lm_batch_at_the_c2_shape(gpu_session, oracle_lib):
     """BASELINE configs[1]'s shape (256 utterances, T = 1000, N = 29, beam 50) with a token 3-gram: engine 4, nothing
     redone, sampled utterances equal to the oracle bit for bit, and the generic engine's n-best on every utterance."""
