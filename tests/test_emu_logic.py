@@ -372,7 +372,11 @@ def test_emulated_token_lm_on_the_lane_state_engine(emu_session, oracle_lib, gol
         assert ok, why
     ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 400, 5, [1, 2, 7, 20, 45], emu=True)
     assert ran >= 380 and served == ran and not bad, (ran, served, bad[:3])
-    # the generic engine over the same dense table (beams beyond 64, streams, fallbacks), and without it
+    # beams beyond 64 (fltx_mlane.h's token-LM variant)
+    ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 90, 12, [1, 2, 7, 20, 45], emu=True,
+                                                       beams=test_gpu_batches.WIDE_BEAMS, tokens=(8, 12, 29, 29, 30), log_add=0.0)
+    assert ran >= 80 and served == ran and not bad, (ran, served, bad[:3])
+    # the generic engine over the same dense table (lane engines switched off, streams, fallbacks), and without it
     ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 60, 6, [2, 7, 20], emu=True, sets={"tlane": 0})
     assert ran >= 50 and served == 0 and not bad, (ran, served, bad[:3])
     assert not test_gpu_batches._token_lm_beyond_the_lane_engine(emu_session, oracle_lib, emu=True)

@@ -300,21 +300,23 @@ def _logadd_lm_lexicon_grid(sess, oracle_lib, n, seed, frames, tol):
     return on6, redone, bad
 
 
-def _token_lm_grid(sess, oracle_lib, n, seed, frames, emu=False, sets=None):
+def _token_lm_grid(sess, oracle_lib, n, seed, frames, emu=False, sets=None, beams=(1, 2, 5, 10, 24, 50, 64),
+                   tokens=(8, 12, 29, 29, 29, 40, 64), log_add=0.3):
     """random LexiconFreeDecoder + token-level n-gram LM configurations (LexiconFreeDecoder.cpp:69-85 with KenLM::score,
     lm/KenLM.cpp:63-83) on fltx_slane.h's token-LM variant: orders 2 - 4, CTC / ASG, token beams, thresholds, silScore,
     lmWeight of both signs, max-merge (bit-exact) and logAdd (1e-5 on the device, 1e-9 on the emulator, which shares
-    the host's libm) -> (configurations compared, served by engine 4 with nothing redone, mismatches)"""
+    the host's libm) -> (configurations compared, served by engine 4 with nothing redone, mismatches).  beams beyond 64:
+    fltx_mlane.h's token-LM variant (max-merge, token lists of up to 30)"""
     import random
     rnd = random.Random(seed)
     ran = served = 0
     bad = []
     for i in range(n):
-        N = rnd.choice([8, 12, 29, 29, 29, 40, 64])
+        N = rnd.choice(list(tokens))
         crit = rnd.choice(["ctc", "ctc", "asg"])
-        la = rnd.random() < 0.3
+        la = rnd.random() < log_add
         c = cases.case("tlm%d" % i, dist=rnd.choice(["ctc", "ctc", "uniform"]), T=rnd.choice(frames), N=N,
-                       K=rnd.choice([1, 2, 5, 10, 24, 50, 64]), Kt=rnd.choice([N, N, max(1, N // 3), 3, 1]),
+                       K=rnd.choice(list(beams)), Kt=rnd.choice([N, N, max(1, N // 3), 3, 1]),
                        thr=rnd.choice([25.0, 8.0, 2.0, 100.0, float("inf")]), u=7000 + i, log_add=la,
                        sil_score=rnd.choice([0.0, -0.5, 0.4]), crit=crit, trans_seed=(90 + i % 7) if crit == "asg" else None,
                        lm=("ngram", rnd.choice([2, 3, 4]), 50 + i % 4), lm_weight=rnd.choice([0.5, 0.8, 1.5, 2.5, -0.3]))
@@ -350,13 +352,21 @@ def test_token_level_ngram_lm_on_the_lane_state_engine(gpu_session, oracle_lib):
     assert ran >= 280 and not bad, (ran, served, bad[:3])
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 200, 8, [5, 33], sets={"tlane": 0})
     assert ran >= 180 and served == 0 and not bad, (ran, served, bad[:3])
+    # beams beyond 64: fltx_mlane.h's token-LM variant (two, four, eight lane groups), max-merge, up to 30 listed tokens
+    ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 500, 10, [1, 2, 7, 20, 45, 90, 200], beams=WIDE_BEAMS,
+                                      tokens=(8, 12, 29, 29, 30), log_add=0.0)
+    assert ran >= 470 and served == ran and not bad, (ran, served, bad[:3])
     # ... and the generic engine without the dense table (a chain of n-gram probes per look-up: what token sets beyond 64 get)
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 120, 9, [5, 33], sets={"tlane": 0, "tok_dense": 0})
     assert ran >= 100 and served == 0 and not bad, (ran, served, bad[:3])
 
 
+WIDE_BEAMS = (65, 80, 100, 128, 129, 200, 256, 257, 300, 512)
+
+
 def _token_lm_beyond_the_lane_engine(sess, oracle_lib, emu=False):
-    """beams 65 .. 300 and streams: the generic engine, a state's context as a row of the dense table"""
+    """beams 65 .. 300 with the lane engines switched off, or without the dense table: the generic engine, a state's
+    context as a row of the dense table / its n-gram probe chain"""
     import random
     rnd = random.Random(31)
     bad = []
@@ -368,7 +378,7 @@ def _token_lm_beyond_the_lane_engine(sess, oracle_lib, emu=False):
         want = helpers.run_checker(oracle_lib, c, inp)
         if len({h.score for h in want}) != len(want):
             continue
-        for sets in ({}, {"tok_dense": 0}):
+        for sets in ({"tlane": 0}, {"tok_dense": 0}):
             d = sess.decoder(c, inp)
             for k, v in sets.items():
                 d.set(k, v)
@@ -376,7 +386,7 @@ def _token_lm_beyond_the_lane_engine(sess, oracle_lib, emu=False):
             got, eng, ctxs = d.results(0), d.get("engine"), d.get("toklm_contexts")
             d.close()
             ok, why = helpers.hyps_equal(want, got)
-            if not ok or eng > 1 or (ctxs > 0) != (not sets):
+            if not ok or eng > 1 or (ctxs > 0) != ("tlane" in sets):
                 bad.append((K, sets, eng, ctxs, why))
     return bad
 

@@ -2001,6 +2001,35 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       }
     }
   }
+  /* ... and both: a token-level n-gram LM at beams beyond 64 (mlaneUtterance<.., TL = true>): the dense table's gather per
+   * candidate, state ids from a table in HBM (ymemo: a slot per state an utterance can create); max-merge, token lists
+   * of up to 30 (the three geometries compiled for it) */
+  if (tab && !d->slane && d->kind == FLTX_DECODER_LEXFREE && !d->noSlane && !d->noTlane && !d->genericAsked && !d->noDense &&
+      d->userLaneGroups >= 0 && d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs && !d->opt.log_add &&
+      K > 64 && K <= 64 * kMlMaxGroups && d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
+      (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
+      (int64_t)K * (maxT + 2) < (1ll << 27)) {
+    const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
+    const int needNG = std::max((K + 63) / 64, d->userLaneGroups);
+    static const MlaneGeo geoT[] = {{960, 5, 2, 1, 1}, {960, 5, 4, 2, 2}, {960, 10, 8, 2, 4}};
+    for (const MlaneGeo& g : geoT) {
+      const int nBlk = (g.threads / 64 - g.ng / g.spw - 1) / (g.ng / g.gpw);
+      if (g.ng >= needNG && nList <= g.gt * nBlk && (!d->userThreads || d->threads == g.threads)) {
+        uint32_t slots = 1024;
+        while ((int64_t)slots < (int64_t)K * (maxT + 2) && slots < (1u << 27)) {
+          slots <<= 1;
+        }
+        d->slane = g.gt;
+        d->tlane = 1;
+        d->mlaneNG = g.ng;
+        d->mlaneGPW = g.gpw;
+        d->mlaneSPW = g.spw;
+        d->threads = g.threads;
+        d->ymemoSlots = slots; /* every state an utterance can create has a slot: the table cannot fill */
+        break;
+      }
+    }
+  }
   /* ... and the frames of a stream's decodeStep chunks on the same engine (the parked beam, the (parent, token) ->
    * id tables and the history rows keep the lane-per-slot engine's format) */
   d->sstream = 0;
@@ -2460,6 +2489,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
   if ((d->ylane || d->xlane) && d->yshare) {
     rc |= d->ymemo.ensure(sizeof(unsigned long long) * (size_t)d->ymemoSlots * (size_t)B, st, false); /* (wiped by the kernel) */
   }
+  if (d->tlane && d->mlaneNG > 1) { /* the token-LM variant of fltx_mlane.h: its state-id table */
+    rc |= d->ymemo.ensure(sizeof(unsigned long long) * (size_t)d->ymemoSlots * (size_t)B, st, false); /* (wiped by the kernel) */
+  }
   d->useLmCache = d->lm->kind == 1 && !d->ylane && !d->xlane && !d->noLmCache;
   if (d->useLmCache) {
     /* (emptied here and at every new epoch: LM-state ids are table slots, a new batch gives them new meanings) */
@@ -2569,7 +2601,7 @@ void fillParams(fltx_decoder* d, DecodeParams& P) {
   P.xextra = (d->trie && d->trie->xextra.p) ? d->trie->xextra.as<uint32_t>() : nullptr;
   P.yTpw = d->ylaneTpw;
   P.xlmword = d->xlmword.p ? d->xlmword.as<int32_t>() : nullptr;
-  P.ymemo = ((d->ylane || d->xlane) && d->yshare) ? d->ymemo.as<unsigned long long>() : nullptr;
+  P.ymemo = (((d->ylane || d->xlane) && d->yshare) || (d->tlane && d->mlaneNG > 1)) ? d->ymemo.as<unsigned long long>() : nullptr;
   P.ymemoSlots = d->ymemoSlots;
   P.yRankAt = d->userYRankAt;
   P.tune = d->userTune;
@@ -2867,6 +2899,21 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
                          d->wsBytes, d->ctx->stream, P);                                                 \
     }                                                                                                    \
   } while (0)
+#define FLTX_LAUNCH_TMLANE(WW, GG, NG, GPW, SPW)                                                         \
+  do {                                                                                                   \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_tmlane<WW, GG, NG, GPW, SPW>,             \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));            \
+    hipLaunchKernelGGL((fltx_decode_kernel_tmlane<WW, GG, NG, GPW, SPW>), dim3(nGrid), dim3(WW), d->wsBytes, \
+                       d->ctx->stream, P);                                                               \
+  } while (0)
+    if (d->tlane) {
+      switch (d->mlaneNG) {
+        case 2: FLTX_LAUNCH_TMLANE(960, 5, 2, 1, 1); break;
+        case 4: FLTX_LAUNCH_TMLANE(960, 5, 4, 2, 2); break;
+        case 8: FLTX_LAUNCH_TMLANE(960, 10, 8, 2, 4); break;
+        default: return fail(FLTX_ERR_INVALID, "no token-LM fltx_mlane.h kernel for %d lane groups", d->mlaneNG);
+      }
+    } else
     switch (((W * 100 + d->slane) * 10 + d->mlaneNG) * 100 + d->mlaneGPW * 10 + d->mlaneSPW) {
       case 64004221: FLTX_LAUNCH_MLANE(640, 4, 2, 2, 1); break;
       case 96005211: FLTX_LAUNCH_MLANE(960, 5, 2, 1, 1); break;
@@ -2880,6 +2927,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
                     d->mlaneNG);
     }
 #undef FLTX_LAUNCH_MLANE
+#undef FLTX_LAUNCH_TMLANE
   } else if (d->slane && d->wlane) {
     { /* the token beams of all rows first (same stream) */
       const int maxT = d->wlMaxT;

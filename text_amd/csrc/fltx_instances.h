@@ -162,6 +162,11 @@
   FLTX_INST(fltx_decode_kernel_wlane<576, 8>)         \
   FLTX_INST(fltx_decode_kernel_wlane<576, 10>)
 
+/* fltx_mlane.h with a token-level n-gram LM: beams 65 .. 128 / 256 / 512 over token lists of up to 30 */
+#define FLTX_G31(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 2, 1, 1>)
+#define FLTX_G32(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 4, 2, 2>)
+#define FLTX_G33(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 10, 8, 2, 4>)
+
 #ifdef FLTX_INST_W
 #define FLTX_CAT2_(a, b) a##b
 #define FLTX_CAT_(a, b) FLTX_CAT2_(a, b)
@@ -196,6 +201,9 @@ FLTX_G27(0)
 FLTX_G28(0)
 FLTX_G29(0)
 FLTX_G30(0)
+FLTX_G31(0)
+FLTX_G32(0)
+FLTX_G33(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -222,6 +230,9 @@ FLTX_G30(0)
 #undef FLTX_G22
 #undef FLTX_G23
 #undef FLTX_G24
+#undef FLTX_G31
+#undef FLTX_G32
+#undef FLTX_G33
 #undef FLTX_G25
 #undef FLTX_G26
 #undef FLTX_G27

@@ -60,8 +60,75 @@ struct MlaneLds {
   unsigned long long mmaxKey[2];
   uint32_t scanMin, pad0;
   float raw[3][64];
+  /* token-LM variant (TL): a state's row of the dense (context, token) table, the LM score it was entered with, the
+   * frame's best candidate (a maximum again), the ids of re-entered states, the utterance's state counter */
+  unsigned long long fbest[2];
+  uint32_t ctx[2][kLanes];
+  float tlIn[2][kLanes];
+  uint32_t evSid[kLanes];
+  uint32_t idNext, pad1;
 };
-enum { ML_BCNT = 2, ML_NOUT = 6 };
+enum { ML_BCNT = 2, ML_NOUT = 6, ML_FULL = 7 };
+
+/* TL: (parent state id, token) -> id of the child state, the memo behind LMState::child for the token-LM variant.  With
+ * LM terms the beam turns over fast and states are entered again every few frames; finding them in the history rows
+ * (mlReenter) is a scan per event.  So the ids live in a table in HBM (DecodeParams::ymemo, ymemoSlots slots per
+ * utterance, wiped by the kernel): one 64-bit word per slot = (parent + 1):28 << 36 | token:8 << 28 | id:28, key and id
+ * installed together by one compare-and-swap.  The decoder asks about a (state, token) pair at most once per frame, so
+ * nobody waits for anybody.  `fresh` = false says "entered before": its children in the beam get it back as their
+ * parent lane (mlRelink).  Returns 0xFFFFFFFF when the table is full (general path). */
+FLTX_DEV uint32_t mlChildId(unsigned long long* tab, uint32_t slots, uint32_t par, uint32_t tok, uint32_t* nextId, bool& fresh) {
+  const unsigned long long key = ((unsigned long long)(par + 1u) << 36) | ((unsigned long long)(tok & 0xFFu) << 28);
+  const uint32_t mask = slots - 1u;
+  uint32_t h = hashKey(par, tok, 0x9747b28cu, 0x85EBCA6Bu) & mask;
+  uint32_t id = 0xFFFFFFFFu;
+  fresh = false;
+  for (uint32_t probes = 0; probes < slots; ++probes) {
+    unsigned long long cur = loadCoherent64(&tab[h]);
+    if (cur == 0ull) {
+      if (id == 0xFFFFFFFFu) {
+        id = atomAdd32(nextId, 1u);
+        if (id >= (1u << 28)) {
+          return 0xFFFFFFFFu;
+        }
+      }
+      cur = atomCas64(&tab[h], 0ull, key | (unsigned long long)id);
+      if (cur == 0ull) {
+        fresh = true;
+        return id;
+      }
+    }
+    if ((cur >> 28) == (key >> 28)) {
+      return (uint32_t)cur & 0x0FFFFFFFu; /* (an id drawn above and not used is a name nobody bears) */
+    }
+    h = (h + 1u) & mask;
+  }
+  return 0xFFFFFFFFu;
+}
+
+/* TL: the states entered again in the last build (evLane / evSid) take their children in the beam back: a lane whose
+ * parent state is one of them links to its lane.  All waves; two barriers. */
+template <typename LDS>
+FLTX_DEV void mlRelink(LDS& S, int q, int nState) {
+  const int tid = (int)threadIdx.x, W = (int)blockDim.x;
+  const int nev = (int)S.row[q].nev;
+  for (int l = tid; l < nState; l += W) {
+    const uint32_t sp = S.rec[q][l].spar;
+    for (int e = 0; e < nev; ++e) {
+      const int X = (int)S.evLane[e];
+      if (S.evSid[e] == sp && X != l) {
+        const uint32_t info = S.rec[q][l].info;
+        S.rec[q][l].info = (info & 0xFFu) | ((uint32_t)(X + 1) << 8);
+        atomOr64(&S.cmask[q][X], 1ull << (info & 63u));
+      }
+    }
+  }
+  ldsBarrier();
+  if (tid == 0) {
+    S.row[q].nev = 0u;
+  }
+  ldsBarrier();
+}
 
 FLTX_DEV uint32_t mlParentSid(uint32_t x, uint32_t y) { return (x >> kMlSidShift) | ((y >> 8) << kMlSidLowBits); }
 FLTX_DEV int2 mlNewRec(uint32_t hp, uint32_t parSid, int n) {
@@ -139,9 +206,13 @@ FLTX_DEV void mlReenter(LDS& S, const int2* histPT, int q, int nState, int64_t h
 /* GT = list positions per token wave and group, NG = lane groups, GPW = groups a token wave evaluates, SPW = groups
  * a self wave owns, LA = logAdd.  Waves: (NG / GPW) x nBlk token waves (block = wave % nBlk, group set = wave / nBlk),
  * NG / SPW self waves, one wave that stages the emission rows. */
-template <int GT, int NG, int GPW, int SPW, bool LA>
+/* TL: a token-level n-gram LM through its dense (context, token) table (DecodeParams::tokLm, fltx_slane.h's token-LM
+ * variant says what that changes: the LM term is one gather per candidate, the frame's best a maximum behind one more
+ * barrier, decodeEnd adds lmWeight x finish); max-merge only */
+template <int GT, int NG, int GPW, int SPW, bool LA, bool TL = false>
 FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
   static_assert(NG >= 1 && NG <= kMlMaxGroups && NG % GPW == 0 && NG % SPW == 0, "lane groups per wave");
+  static_assert(!(TL && LA), "the token-LM variant merges by maximum");
   constexpr int NC = GT * GPW; /* candidates per lane of a wave */
   static_assert(3 * SPW <= NC, "a self wave keeps three groups per lane group in the slot arrays");
   constexpr int NU = GPW > SPW ? GPW : SPW;
@@ -172,6 +243,25 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
   const float* em = P.emissions ? P.emissions + P.emOff[b] : nullptr;
   const int64_t hbase = P.histOff[b];
   const double NEG = slNegInf();
+  const int2* const tokLm = TL ? P.tokLm : nullptr;
+  const int tokStride = TL ? P.tokLmStride : 0;
+  const double lmW = P.lmWeight;
+  unsigned long long* const idTab = TL ? P.ymemo + (size_t)b * P.ymemoSlots : nullptr;
+  if constexpr (TL) {
+    for (uint32_t i = (uint32_t)tid; i < P.ymemoSlots; i += (uint32_t)W) {
+      idTab[i] = 0ull; /* (at L2 before the barrier below, where the build's atomics will find it) */
+    }
+#ifndef FLTX_EMU
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    if (tid == 0) {
+      S.ctx[0][0] = 0u; /* KenLM::start(false): row 0 of the table */
+      S.tlIn[0][0] = 0.0f;
+      S.fbest[0] = 0ull;
+      S.fbest[1] = 0ull;
+      S.idNext = 1u; /* (0 names the root state) */
+    }
+  }
 
   /* ---- decodeBegin (LexiconFreeDecoder.cpp:20-28): the root state ------------------ */
   for (int i = tid; i < 2 * LN; i += W) {
@@ -289,8 +379,42 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         tb[j] = S.tokBit[p][pos0 + j];
       }
     }
-    if (nev != 0u) { /* rare: states re-entered the beam in the previous build */
-      mlReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K);
+    /* TL: the LM scores (and the contexts behind them) of this lane's states for the tokens of this wave's list
+     * positions -- one 8-byte gather per (state, position) from the state's row of the dense table, issued as soon as
+     * the rows are known; self waves: the score of last(S) after S (blank-then-last) and the score S was entered with */
+    int2 lmv[TL ? NC : 1];
+    int2 lmLast[TL ? NU : 1];
+    float lIn[TL ? NU : 1];
+    uint32_t ctxv[TL ? NU : 1];
+    if constexpr (TL) {
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        ctxv[i] = 0u;
+        lmLast[i] = make_int2(0, 0);
+        lIn[i] = 0.0f;
+        if (i < U) {
+          const int L = (g0 + i) * 64 + lane;
+          const bool lv = L < nState;
+          ctxv[i] = lv ? S.ctx[p][L] : 0u;
+          const int2* lrow = tokLm + (size_t)ctxv[i] * (size_t)tokStride;
+          if constexpr (isSelf) {
+            lmLast[i] = lrow[lv ? (int)(me[i].info & 63u) : 0];
+            lIn[i] = S.tlIn[p][L];
+          } else if constexpr (isTok) {
+#pragma unroll
+            for (int j = 0; j < GT; ++j) {
+              lmv[i * GT + j] = lrow[tb[j] != 0ull ? __builtin_ctzll(tb[j]) : 0];
+            }
+          }
+        }
+      }
+    }
+    if (nev != 0u) { /* states re-entered the beam in the previous build (TL: named by the id table; else rare) */
+      if constexpr (TL) {
+        mlRelink(S, p, nState);
+      } else {
+        mlReenter(S, histPT, p, nState, hbase, (int64_t)frameOut * K);
+      }
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
         if (i < U) {
@@ -301,7 +425,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
     }
-    if (rowDead) {
+    if (rowDead || (TL && S.scal[ML_FULL] != 0u)) {
       dead = true;
       return;
     }
@@ -336,7 +460,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
     }
     /* candidate scores: token waves without logAdd recompute m + e where they need it (one addition, the same
      * double) instead of keeping GT * GPW of them in registers through the selection */
-    constexpr bool kKeep = !(isTok && !LA);
+    constexpr bool kKeep = TL || !(isTok && !LA);
     double cs[kKeep ? NC : 1];
     int cbin[NC];
     uint32_t parR[NU];
@@ -363,6 +487,11 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       if (LA && lane == 0) {
         S.mmaxKey[q] = 0ull;
       }
+      if (TL && lane == 0) {
+        S.fbest[q] = 0ull; /* (the next frame's; last read a frame ago) */
+      }
+    } else if constexpr (TL) {
+      /* (the candidates of a token-LM frame: below, around the barrier that publishes the frame's best) */
     } else if constexpr (isTok) {
       const int silJ = silPos - pos0;
 #pragma unroll
@@ -469,6 +598,116 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         cbin[3 * i + 0] = okB ? slBin<LA>(best, cB, winShift, winBase) : kSlInvalid;
         cbin[3 * i + 1] = okR ? slBin<LA>(best, cR, winShift, winBase) : kSlInvalid;
         cbin[3 * i + 2] = okL ? slBin<LA>(best, cL, winShift, winBase) : kSlInvalid;
+      }
+    }
+    if constexpr (TL) {
+      /* ---- the same candidates with the LM term (LexiconFreeDecoder.cpp:64-67,69-85: score = prev.score + e
+       * (+ silScore), candidate = score + lmWeight * lmScore); the frame's best is their maximum (Utils.h:131-137) --- */
+      bool pre[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        pre[c] = false;
+      }
+      if constexpr (isTok) {
+        const int silJ = silPos - pos0;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          const uint32_t lastLo = last[i] < 32 ? 1u << last[i] : 0u, lastHi = last[i] < 32 ? 0u : 1u << (last[i] - 32);
+          const uint32_t skLo = live[i] ? ((uint32_t)cm[i] | lastLo) : 0xFFFFFFFFu;
+          const uint32_t skHi = live[i] ? ((uint32_t)(cm[i] >> 32) | lastHi) : 0xFFFFFFFFu;
+#pragma unroll
+          for (int j = 0; j < GT; ++j) {
+            const double wl = lmW * (double)__uint_as_float((uint32_t)lmv[i * GT + j].x);
+            double c = m[i] + ev[j]; /* NaN past the end of the list */
+            if (j == silJ) {
+              c = c + silScore;
+            }
+            c = c + wl;
+            const uint32_t hit = (skLo & (uint32_t)tb[j]) | (skHi & (uint32_t)(tb[j] >> 32));
+            pre[i * GT + j] = hit == 0u && c == c;
+            cs[i * GT + j] = c;
+          }
+        }
+      } else if constexpr (isSelf) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          const bool lastOk = live[i] && ((allow >> last[i]) & 1ull) != 0ull && !(ctc && last[i] == blank);
+          const bool lastSil = last[i] == sil;
+          /* (S, blank, true): :86-97, no LM term */
+          double cB = m[i] + eBlank;
+          if (blank == sil) {
+            cB = cB + silScore;
+          }
+          pre[3 * i] = ctc && live[i] && ((allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB == cB;
+          /* (S, last, false): the repeat (:98-110, no LM term) and the parent state's extension by last (:69-85: the LM
+           * score S was entered with) */
+          const int lastP = (int)(par[i].info & 63u);
+          const uint32_t h1 = par[i].hyps & 0xFFFFu, h2 = par[i].hyps >> 16;
+          const bool has0 = hypNB[i] != kMlNoHyp;
+          const bool has1 = pl[i] >= 0 && last[i] != lastP && h1 != kMlNoHyp;
+          const bool has2 = pl[i] >= 0 && ctc && h2 != kMlNoHyp;
+          const bool hasB = hypB[i] != kMlNoHyp;
+          const double wIn = lmW * (double)lIn[i], wL = lmW * (double)__uint_as_float((uint32_t)lmLast[i].x);
+          double r0 = nbv[i] + eLast[i];
+          double r1 = par[i].nb + eLast[i];
+          double r2 = par[i].b + eLast[i];
+          double cL = bbv[i] + eLast[i]; /* (S.last, last, false) from (S, blank, true) when no lane holds S.last */
+          if (silScore != 0.0) {
+            r0 = lastSil ? r0 + silScore : r0;
+            r1 = lastSil ? r1 + silScore : r1;
+            r2 = lastSil ? r2 + silScore : r2;
+            cL = lastSil ? cL + silScore : cL;
+          }
+          r1 = has1 ? r1 + wIn : NEG;
+          r2 = has2 ? r2 + wIn : NEG;
+          cL = cL + wL;
+          double cR = r0;
+          uint32_t pR = hypNB[i];
+          if (has1 && (r1 > cR || (r1 == cR && h1 < pR))) {
+            cR = r1;
+            pR = h1;
+          }
+          if (has2 && (r2 > cR || (r2 == cR && h2 < pR))) {
+            cR = r2;
+            pR = h2;
+          }
+          parR[i] = pR;
+          pre[3 * i + 1] = lastOk && (has0 || has1 || has2) && cR == cR;
+          pre[3 * i + 2] = ctc && lastOk && hasB && ((cm[i] >> last[i]) & 1ull) == 0ull && cL == cL;
+          cs[3 * i + 0] = cB;
+          cs[3 * i + 1] = cR;
+          cs[3 * i + 2] = cL;
+        }
+      }
+      if constexpr (!isSvc) {
+        unsigned long long k = 0ull;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const unsigned long long kc = pre[c] ? f64Key(cs[c]) : 0ull;
+          k = kc > k ? kc : k;
+        }
+        if (waveBallot(k != 0ull) != 0ull) {
+          k = waveMax64(k);
+          if (lane == 0) {
+            atomMax64(&S.fbest[p], k);
+          }
+        }
+      }
+      ldsBarrier(); /* 0: the frame's best candidate */
+      {
+        const unsigned long long bk = S.fbest[p];
+        best = f64FromKey(bk);
+        thr = best - P.beamThreshold;
+        if (bk == 0ull || !(best - best == 0.0)) { /* no candidate at all, or not finite: the general engines */
+          dead = true;
+          return;
+        }
+      }
+      if constexpr (!isSvc) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          cbin[c] = (pre[c] && cs[c] >= thr) ? slBin<LA>(best, cs[c], winShift, winBase) : kSlInvalid;
+        }
       }
     }
     const int silJ0 = silPos - pos0;
@@ -701,7 +940,8 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       nSurv += cS;
       nHSurv += cH;
     }
-    auto newState = [&](int idx, double c, int n, uint32_t hp, const MlRec& src, unsigned long long srcMask, int srcNew) {
+    auto newState = [&](int idx, double c, int n, uint32_t hp, const MlRec& src, unsigned long long srcMask, int srcNew,
+                        uint32_t ctxNew, float lNew) {
       const int nl = nSurv + idx;
       const uint32_t hyp = (uint32_t)(nHSurv + idx);
       MlRec r;
@@ -711,18 +951,36 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       r.hyps = hyp | (kMlNoHyp << 16);
       r.sid = (uint32_t)frameOut * (uint32_t)K + hyp;
       r.spar = src.sid;
-      const bool again = ((srcMask >> n) & 1ull) != 0ull; /* this edge had a child before */
+      bool again = ((srcMask >> n) & 1ull) != 0ull; /* this edge had a child before */
+      if constexpr (TL) {
+        /* the id table says whether it had, and who the child is */
+        bool fresh = true;
+        r.sid = mlChildId(idTab, P.ymemoSlots, src.sid, (uint32_t)n, &S.idNext, fresh);
+        again = !fresh;
+        if (r.sid == 0xFFFFFFFFu) {
+          S.scal[ML_FULL] = 1u; /* table full: general path */
+          again = false;
+        }
+        S.ctx[q][nl] = ctxNew;
+        S.tlIn[q][nl] = lNew;
+      }
       S.rec[q][nl] = r;
       if (srcNew >= 0) {
         atomOr64(&S.cmask[q][srcNew], 1ull << n);
-        atomOr64(&S.mask[q][srcNew], 1ull << n);
+        if constexpr (!TL) {
+          atomOr64(&S.mask[q][srcNew], 1ull << n);
+        }
       }
       histPT[hrow + hyp] = mlNewRec(hp, src.sid, n);
       if (again) { /* it may have descendants in the beam */
         const uint32_t e = atomAdd32(&S.row[q].nev, 1u);
         S.evLane[e] = (uint32_t)nl;
-        S.evSpar[e] = src.sid;
-        S.evTok[e] = (uint32_t)n;
+        if constexpr (TL) {
+          S.evSid[e] = r.sid;
+        } else {
+          S.evSpar[e] = src.sid;
+          S.evTok[e] = (uint32_t)n;
+        }
       }
     };
     if constexpr (isSvc) {
@@ -741,7 +999,8 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           if (selMask[c] != 0ull) { /* (most positions of most frames have no survivor at all) */
             if ((selMask[c] >> lane) & 1ull) {
               const int nTok = (int)S.tokId[p][pos0 + j];
-              newState(before + wavePrefixCount(selMask[c]), csAt(c), nTok, hypM[i], me[i], mk[i], srcNew);
+              newState(before + wavePrefixCount(selMask[c]), csAt(c), nTok, hypM[i], me[i], mk[i], srcNew,
+                       TL ? (uint32_t)lmv[TL ? c : 0].y : 0u, TL ? __uint_as_float((uint32_t)lmv[TL ? c : 0].x) : 0.0f);
             }
             before += popc64(selMask[c]);
           }
@@ -769,7 +1028,11 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           r.sid = me[i].sid;
           r.spar = me[i].spar;
           S.rec[q][srcNew] = r;
-          if (mk[i]) {
+          if constexpr (TL) {
+            S.ctx[q][srcNew] = ctxv[i];
+            S.tlIn[q][srcNew] = lIn[i];
+          }
+          if (!TL && mk[i]) {
             atomOr64(&S.mask[q][srcNew], mk[i]);
           }
           if (pln >= 0) {
@@ -783,7 +1046,8 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           }
         }
         if ((selMask[3 * i + 2] >> lane) & 1ull) {
-          newState(before + wavePrefixCount(selMask[3 * i + 2]), cs[3 * i + 2], last[i], hypB[i], me[i], mk[i], srcNew);
+          newState(before + wavePrefixCount(selMask[3 * i + 2]), cs[3 * i + 2], last[i], hypB[i], me[i], mk[i], srcNew,
+                   TL ? (uint32_t)lmLast[TL ? i : 0].y : 0u, TL ? __uint_as_float((uint32_t)lmLast[TL ? i : 0].x) : 0.0f);
         }
         before += popc64(selMask[3 * i + 2]);
       }
@@ -823,6 +1087,29 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
     if (LA) {
       endBest = f64FromKey(S.mmaxKey[pe]);
     }
+    /* TL: lm->finish(state) (KenLM.cpp:77-83: the score of </s> in the state's context): both hypotheses of a state add
+     * the same term; the best candidate of decodeEnd is a maximum again */
+    auto finishOf = [&](int l, bool lv) {
+      return lmW * (double)__uint_as_float((uint32_t)tokLm[(size_t)(lv ? S.ctx[pe][l] : 0u) * (size_t)tokStride + (size_t)N].x);
+    };
+    if constexpr (TL) {
+      if (tid == 0) {
+        S.fbest[0] = 0ull;
+      }
+      ldsBarrier();
+      for (int l = tid; l < nState; l += W) {
+        const MlRec me = S.rec[pe][l];
+        const bool wB = me.b > me.nb;
+        const double mm = (wB ? me.b : me.nb) + finishOf(l, true);
+        const uint32_t hp = wB ? (me.hyps >> 16) : (me.hyps & 0xFFFFu);
+        if (hp != kMlNoHyp && mm == mm) {
+          atomMax64(&S.fbest[0], f64Key(mm));
+        }
+      }
+      ldsBarrier();
+      const unsigned long long k = S.fbest[0];
+      endBest = k != 0ull ? f64FromKey(k) : 0.0;
+    }
     const double thr = endBest - P.beamThreshold;
     for (int base = 0; base < LN; base += W) {
       const int l = base + tid;
@@ -832,8 +1119,11 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         const double nb = lv ? me.nb : NEG, bb = lv ? me.b : NEG;
         const bool wB = bb > nb;
         double mm = wB ? bb : nb;
+        if constexpr (TL) {
+          mm = mm + finishOf(l, lv);
+        }
         const uint32_t hp = wB ? (me.hyps >> 16) : (me.hyps & 0xFFFFu);
-        const bool ok = lv && mm >= thr;
+        const bool ok = lv && mm >= thr && (!TL || hp != kMlNoHyp);
         if (LA && ok) {
           const double lo = wB ? nb : bb;
           const uint32_t hl = wB ? (me.hyps & 0xFFFFu) : (me.hyps >> 16);
@@ -861,7 +1151,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           const size_t g = ((size_t)b * K + rank) * 3;
           P.outScores[g + 0] = f64FromKey(key);
           P.outScores[g + 1] = 0.0; /* emitting-model score: the back-trace kernel fills it in */
-          P.outScores[g + 2] = 0.0; /* ZeroLM */
+          P.outScores[g + 2] = 0.0; /* ZeroLM; a token LM's score is re-accumulated by the back-trace kernel as well */
           P.histPT[hbase + (int64_t)ff * K + rank] = make_int2((int)hp, P.sil);
           atomAdd32(&S.scal[ML_NOUT], 1u);
         }
