@@ -133,6 +133,11 @@ CASES = [
          log_add=True),
     case("ng_tok_lexfree_asg_k16", dist="ctc", T=40, K=16, u=100, crit="asg", trans_seed=15, lm=("ngram", 4, 12),
          lm_weight=1.2, sil_score=-0.3),
+    # ... at beams beyond 64 (fltx_mlane.h's token-LM variant: two, four, eight lane groups)
+    case("ng_tok_lexfree_k100", dist="ctc", T=40, K=100, u=102, lm=("ngram", 3, 11), lm_weight=0.8),
+    case("ng_tok_lexfree_k200_kt8", dist="ctc", T=40, K=200, Kt=8, u=103, lm=("ngram", 4, 12), lm_weight=1.5, sil_score=-0.3),
+    case("ng_tok_lexfree_asg_k300", dist="uniform", T=30, K=300, u=104, crit="asg", trans_seed=16, lm=("ngram", 3, 11),
+         lm_weight=1.1),
     # ---- lexicon decoder, BASELINE shapes -------------------------------------
     case("C3_spell_u0", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, size="large"),
     case("C3_spell_u255", kind="lexicon", dist="lexspell", T=1000, K=50, Kt=10, lexicon=FULL_LEX, u=255,

@@ -259,6 +259,10 @@ def test_lexicon_hbm_workspace_with_cut(gpu_session, golden, c, hot, slim, tight
     ("ng_tok_lexfree_t40", 4, {"slane_threads": 448}), ("ng_tok_lexfree_t40", 4, {"slane_threads": 384}),
     ("ng_tok_lexfree_t40", 4, {"slane_threads": 320}), ("ng_tok_lexfree_t40", 4, {"slane_threads": 640}),
     ("ng_tok_lexfree_kt8", 4, {"slane_threads": 512}), ("ng_tok_lexfree_kt8", 4, {"slane_threads": 320}),
+    # ... at beams beyond 64: fltx_mlane.h's token-LM variant (2 / 4 / 8 lane groups); forced onto more groups; switched off
+    ("ng_tok_lexfree_k100", 4, {}), ("ng_tok_lexfree_k200_kt8", 4, {}), ("ng_tok_lexfree_asg_k300", 4, {}),
+    ("ng_tok_lexfree_k100", 4, {"lane_groups": 4}), ("ng_tok_lexfree_k100", 4, {"lane_groups": 8}),
+    ("ng_tok_lexfree_k100", 1, {"tlane": 0}), ("ng_tok_lexfree_k200_kt8", 1, {"tok_dense": 0}),
     ("lx_scores_t50", 6, {}), ("ng_word_t40_k10", 6, {}), ("ng_word_t60_k16_4g", 6, {}), ("C4_spell_u0", 6, {}),
     ("C4_spell_u255", 6, {}), ("C4z_spell_u0", 6, {}), ("lx_spell_t40_k8", 6, {"ylane": 2}),
     ("lx_uni_t40_k10", 6, {"ylane": 2}), ("C3_spell_u0", 6, {"ylane": 2}), ("C3_uniform_u0", 6, {"ylane": 2}),

@@ -2168,10 +2168,11 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (N > 64 && (lexi || N > kWlMaxN || nTok > 64)) ? FLTX_WHY_TOKENS : 0; /* (lexicon-free: the token BEAM has to fit, fltx_wlane.h) */
       why |= (lexi ? K > ((d->trie && d->trie->xMulti) ? 128 : 256) : K > 64 * kMlMaxGroups) ? FLTX_WHY_BEAM : 0;
       why |= (!d->offlineCall && (lexi || d->opt.log_add || d->lm->kind == 1)) ? FLTX_WHY_STREAM : 0;
-      /* (lexicon-free + n-gram LM: fltx_slane.h's TL variant takes it at beams up to 64 when the model's contexts fit a
-       * dense table -- what is left of the term there: a host LM, a model too large for the table) */
-      why |= (d->lm->kind == 2 || (lexi && d->isLmToken) ||
-              (!lexi && d->lm->kind == 1 && (K > 64 || d->tokLm == nullptr))) ? FLTX_WHY_LM : 0;
+      /* (lexicon-free + n-gram LM: the TL variants of fltx_slane.h / fltx_mlane.h take it at beams up to 512 when the
+       * model's contexts fit a dense table -- what is left of the term there: a host LM, a model too large for the
+       * table; beams beyond 64 with logAdd or a token list of more than 30 show as LOGADD / GEOMETRY below) */
+      why |= (d->lm->kind == 2 || (lexi && d->isLmToken) || (!lexi && d->lm->kind == 1 && d->tokLm == nullptr)) ? FLTX_WHY_LM : 0;
+      why |= (!lexi && d->lm->kind == 1 && d->tokLm != nullptr && K > 64 && d->opt.log_add) ? FLTX_WHY_LOGADD : 0;
       /* (logAdd on the lexicon lane engines: CTC, one word per spelling) */
       /* (logAdd on the lexicon decoder is no reason any more: every configuration the lexicon lane engines take without
        * it, they take with it) */
@@ -3155,17 +3156,25 @@ int launchBacktrace(fltx_decoder* d) {
 #endif
   const size_t perFrame = (size_t)Q.K * (2 * (8 + (d->kind == FLTX_DECODER_LEXICON ? 4 : 0)) + 8);
   /* 140 KB: leaves a CU room for a 16 KB decode workgroup of the next batch beside a back-trace workgroup */
-  const size_t btBudget = (size_t)(d->btLdsKb > 0 ? std::min(d->btLdsKb, 144) : 140) * 1024;
-  int F = (int)std::min<size_t>(btBudget / perFrame, 512);
-  if (d->batchPacked) { /* the emission rows, transitions and addends of a chunk share the same LDS (amLds below) */
-    /* (fltx_wlane.h's token sets: the tokens of the paths only, emissions and transitions read where needed) */
-    const size_t fixed = d->batchWlane ? 16 : 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;
-    const size_t perAm = 4 * ((d->batchWlane ? 0 : (size_t)d->N) + (size_t)Q.K);
-    const size_t room = btBudget > fixed ? btBudget - fixed : 0;
-    F = (int)std::min<size_t>((size_t)F, room / perAm);
-  }
-  if (F < 8 || Q.K > 4 * btThreads) {
-    F = 0;
+  size_t btBudget = 0;
+  int F = 0;
+  auto chunkFor = [&](size_t budget) {
+    btBudget = budget;
+    F = (int)std::min<size_t>(btBudget / perFrame, 512);
+    if (d->batchPacked) { /* the emission rows, transitions and addends of a chunk share the same LDS (amLds below) */
+      /* (fltx_wlane.h's token sets: the tokens of the paths only, emissions and transitions read where needed) */
+      const size_t fixed = d->batchWlane ? 16 : 4 * ((d->opt.criterion == FLTX_CRITERION_ASG && d->nTrans) ? (size_t)d->N * d->N : 0) + 16;
+      const size_t perAm = 4 * ((d->batchWlane ? 0 : (size_t)d->N) + (size_t)Q.K);
+      const size_t room = btBudget > fixed ? btBudget - fixed : 0;
+      F = (int)std::min<size_t>((size_t)F, room / perAm);
+    }
+    if (F < 8 || Q.K > 4 * btThreads) {
+      F = 0;
+    }
+  };
+  chunkFor((size_t)(d->btLdsKb > 0 ? std::min(d->btLdsKb, 144) : 140) * 1024);
+  if (F == 0 && d->btLdsKb > 0) {
+    chunkFor((size_t)144 * 1024); /* (the caller's budget holds no chunk of this beam: the tunable yields, the decode does not fail) */
   }
   if (d->batchPacked && F == 0) {
     return fail(FLTX_ERR_UNSUPPORTED, "back-trace: packed history records need an LDS chunk (K=%d N=%d)", Q.K, d->N);

@@ -27,6 +27,7 @@ constexpr uint32_t kMlNewFlag = 0x400u; /* history record: the hypothesis entere
 constexpr int kMlSidShift = 11;         /* x = slot | flag | (sid & 0x1FFFFF) << 11 */
 constexpr int kMlSidLowBits = 21;
 constexpr int kMlMaxGroups = 8;
+constexpr int kMlGather = 32; /* TL: new states a wave builds in one gathered pass (more: position by position) */
 
 struct MlRec { /* one LM state of the beam, 32 B */
   double nb;     /* score of (S, last token, prevBlank = false) */
@@ -67,6 +68,7 @@ struct MlaneLds {
   float tlIn[2][kLanes];
   uint32_t evSid[kLanes];
   uint32_t idNext, pad1;
+  alignas(16) uint32_t tlNew[15][kMlGather][8]; /* per wave: what its survivors' new states are made from (32 B each) */
 };
 enum { ML_BCNT = 2, ML_NOUT = 6, ML_FULL = 7 };
 
@@ -81,25 +83,21 @@ FLTX_DEV uint32_t mlChildId(unsigned long long* tab, uint32_t slots, uint32_t pa
   const unsigned long long key = ((unsigned long long)(par + 1u) << 36) | ((unsigned long long)(tok & 0xFFu) << 28);
   const uint32_t mask = slots - 1u;
   uint32_t h = hashKey(par, tok, 0x9747b28cu, 0x85EBCA6Bu) & mask;
-  uint32_t id = 0xFFFFFFFFu;
+  /* (most states are new: the name is drawn first and the compare-and-swap IS the look-up -- one round trip to the L2
+   * for a new state, one for a known one; a name drawn for a state that turns out to be known is a name nobody bears) */
+  const uint32_t id = atomAdd32(nextId, 1u);
   fresh = false;
+  if (id >= (1u << 28)) {
+    return 0xFFFFFFFFu;
+  }
   for (uint32_t probes = 0; probes < slots; ++probes) {
-    unsigned long long cur = loadCoherent64(&tab[h]);
+    const unsigned long long cur = atomCas64(&tab[h], 0ull, key | (unsigned long long)id);
     if (cur == 0ull) {
-      if (id == 0xFFFFFFFFu) {
-        id = atomAdd32(nextId, 1u);
-        if (id >= (1u << 28)) {
-          return 0xFFFFFFFFu;
-        }
-      }
-      cur = atomCas64(&tab[h], 0ull, key | (unsigned long long)id);
-      if (cur == 0ull) {
-        fresh = true;
-        return id;
-      }
+      fresh = true;
+      return id;
     }
     if ((cur >> 28) == (key >> 28)) {
-      return (uint32_t)cur & 0x0FFFFFFFu; /* (an id drawn above and not used is a name nobody bears) */
+      return (uint32_t)cur & 0x0FFFFFFFu;
     }
     h = (h + 1u) & mask;
   }
@@ -940,7 +938,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       nSurv += cS;
       nHSurv += cH;
     }
-    auto newState = [&](int idx, double c, int n, uint32_t hp, const MlRec& src, unsigned long long srcMask, int srcNew,
+    auto newState = [&](int idx, double c, int n, uint32_t hp, uint32_t srcSid, unsigned long long srcMask, int srcNew,
                         uint32_t ctxNew, float lNew) {
       const int nl = nSurv + idx;
       const uint32_t hyp = (uint32_t)(nHSurv + idx);
@@ -950,12 +948,12 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       r.info = (uint32_t)n | ((uint32_t)(srcNew + 1) << 8);
       r.hyps = hyp | (kMlNoHyp << 16);
       r.sid = (uint32_t)frameOut * (uint32_t)K + hyp;
-      r.spar = src.sid;
+      r.spar = srcSid;
       bool again = ((srcMask >> n) & 1ull) != 0ull; /* this edge had a child before */
       if constexpr (TL) {
         /* the id table says whether it had, and who the child is */
         bool fresh = true;
-        r.sid = mlChildId(idTab, P.ymemoSlots, src.sid, (uint32_t)n, &S.idNext, fresh);
+        r.sid = mlChildId(idTab, P.ymemoSlots, srcSid, (uint32_t)n, &S.idNext, fresh);
         again = !fresh;
         if (r.sid == 0xFFFFFFFFu) {
           S.scal[ML_FULL] = 1u; /* table full: general path */
@@ -971,16 +969,35 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           atomOr64(&S.mask[q][srcNew], 1ull << n);
         }
       }
-      histPT[hrow + hyp] = mlNewRec(hp, src.sid, n);
+      histPT[hrow + hyp] = mlNewRec(hp, srcSid, n);
       if (again) { /* it may have descendants in the beam */
         const uint32_t e = atomAdd32(&S.row[q].nev, 1u);
         S.evLane[e] = (uint32_t)nl;
         if constexpr (TL) {
           S.evSid[e] = r.sid;
         } else {
-          S.evSpar[e] = src.sid;
+          S.evSpar[e] = srcSid;
           S.evTok[e] = (uint32_t)n;
         }
+      }
+    };
+    /* TL: a new state costs a look-up (and, for a fresh one, a compare-and-swap) in the id table in HBM -- a microsecond
+     * or two, paid once per list position with a survivor if the positions are built one after the other.  Instead the
+     * wave's survivors drop what a new state is made from into the wave's scratch and the wave's first lanes build one
+     * state each: their table accesses are in flight together. */
+    auto gatherPut = [&](int r, double c, int n, uint32_t hp, uint32_t srcSid, int srcNew, uint32_t ctxNew, float lNew) {
+      uint4* sc4 = (uint4*)S.tlNew[wave];
+      const unsigned long long cb = (unsigned long long)__double_as_longlong(c);
+      sc4[2 * r] = make_uint4((uint32_t)cb, (uint32_t)(cb >> 32), (uint32_t)n | (hp << 8), srcSid);
+      sc4[2 * r + 1] = make_uint4((uint32_t)(srcNew + 1), ctxNew, __float_as_uint(lNew), 0u);
+    };
+    auto gatherBuild = [&](int first, int count) {
+      waveSync();
+      if (lane < count) {
+        const uint4* sc4 = (const uint4*)S.tlNew[wave];
+        const uint4 a = sc4[2 * lane], bq = sc4[2 * lane + 1];
+        newState(first + lane, __longlong_as_double((long long)(((unsigned long long)a.y << 32) | a.x)), (int)(a.z & 0xFFu), a.z >> 8,
+                 a.w, 0ull, (int)bq.x - 1, bq.y, __uint_as_float(bq.z));
       }
     };
     if constexpr (isSvc) {
@@ -990,6 +1007,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       ((uint4*)S.hist[q])[lane] = make_uint4(0u, 0u, 0u, 0u);
     } else if constexpr (isTok) {
       int before = offW; /* new states of the waves before this one and of this wave's earlier slots */
+      const bool gathered = TL && nNewWave > 1 && nNewWave <= kMlGather;
 #pragma unroll
       for (int i = 0; i < U; ++i) {
         const int srcNew = mySlot[i] >= 0 ? baseS[i] + mySlot[i] : -1;
@@ -999,11 +1017,25 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           if (selMask[c] != 0ull) { /* (most positions of most frames have no survivor at all) */
             if ((selMask[c] >> lane) & 1ull) {
               const int nTok = (int)S.tokId[p][pos0 + j];
-              newState(before + wavePrefixCount(selMask[c]), csAt(c), nTok, hypM[i], me[i], mk[i], srcNew,
-                       TL ? (uint32_t)lmv[TL ? c : 0].y : 0u, TL ? __uint_as_float((uint32_t)lmv[TL ? c : 0].x) : 0.0f);
+              if constexpr (TL) {
+                if (gathered) {
+                  gatherPut(before - offW + wavePrefixCount(selMask[c]), csAt(c), nTok, hypM[i], me[i].sid, srcNew,
+                            (uint32_t)lmv[TL ? c : 0].y, __uint_as_float((uint32_t)lmv[TL ? c : 0].x));
+                } else {
+                  newState(before + wavePrefixCount(selMask[c]), csAt(c), nTok, hypM[i], me[i].sid, 0ull, srcNew,
+                           (uint32_t)lmv[TL ? c : 0].y, __uint_as_float((uint32_t)lmv[TL ? c : 0].x));
+                }
+              } else {
+                newState(before + wavePrefixCount(selMask[c]), csAt(c), nTok, hypM[i], me[i].sid, mk[i], srcNew, 0u, 0.0f);
+              }
             }
             before += popc64(selMask[c]);
           }
+        }
+      }
+      if constexpr (TL) {
+        if (gathered) {
+          gatherBuild(offW, nNewWave);
         }
       }
     } else {
@@ -1013,6 +1045,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         }
       }
       int before = offW;
+      const bool gatheredS = TL && nNewWave > 1 && nNewWave <= kMlGather;
 #pragma unroll
       for (int i = 0; i < U; ++i) {
         const int srcNew = mySlot[i] >= 0 ? baseS[i] + mySlot[i] : -1;
@@ -1046,10 +1079,24 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           }
         }
         if ((selMask[3 * i + 2] >> lane) & 1ull) {
-          newState(before + wavePrefixCount(selMask[3 * i + 2]), cs[3 * i + 2], last[i], hypB[i], me[i], mk[i], srcNew,
-                   TL ? (uint32_t)lmLast[TL ? i : 0].y : 0u, TL ? __uint_as_float((uint32_t)lmLast[TL ? i : 0].x) : 0.0f);
+          if constexpr (TL) {
+            if (gatheredS) {
+              gatherPut(before - offW + wavePrefixCount(selMask[3 * i + 2]), cs[3 * i + 2], last[i], hypB[i], me[i].sid, srcNew,
+                        (uint32_t)lmLast[TL ? i : 0].y, __uint_as_float((uint32_t)lmLast[TL ? i : 0].x));
+            } else {
+              newState(before + wavePrefixCount(selMask[3 * i + 2]), cs[3 * i + 2], last[i], hypB[i], me[i].sid, 0ull, srcNew,
+                       (uint32_t)lmLast[TL ? i : 0].y, __uint_as_float((uint32_t)lmLast[TL ? i : 0].x));
+            }
+          } else {
+            newState(before + wavePrefixCount(selMask[3 * i + 2]), cs[3 * i + 2], last[i], hypB[i], me[i].sid, mk[i], srcNew, 0u, 0.0f);
+          }
         }
         before += popc64(selMask[3 * i + 2]);
+      }
+      if constexpr (TL) {
+        if (gatheredS) {
+          gatherBuild(offW, nNewWave);
+        }
       }
     }
     nState = nSurv + nNew;

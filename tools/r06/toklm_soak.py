@@ -18,12 +18,16 @@ t0 = time.time()
 ran, served, bad = test_gpu_batches._token_lm_grid(sess, orc, n, 606, [1, 2, 7, 20, 45, 90, 200], emu=bool(os.environ.get("EMU_LIB")))
 ran2, served2, bad2 = test_gpu_batches._token_lm_grid(sess, orc, n // 4, 607, [5, 33, 120], emu=bool(os.environ.get("EMU_LIB")),
                                                       sets={"slane_threads": 512})
+# beams beyond 64: fltx_mlane.h's token-LM variant (max-merge, token lists of up to 30)
+ran3, served3, bad3 = test_gpu_batches._token_lm_grid(sess, orc, n // 3, 609, [1, 2, 7, 20, 45, 90, 200], emu=bool(os.environ.get("EMU_LIB")),
+                                                      beams=test_gpu_batches.WIDE_BEAMS, tokens=(8, 12, 29, 29, 30), log_add=0.0)
 rnd = random.Random(608)
 long_ran = long_bad = ties_seen = 0
 for i in range(max(4, n // 200)):
-    la = rnd.random() < 0.25
+    K = rnd.choice([10, 30, 50, 64, 100, 200, 400])
+    la = rnd.random() < 0.25 and K <= 64
     c = cases.case("tl_long%d" % i, dist=rnd.choice(["ctc", "ctc", "uniform"]), T=rnd.choice([600, 1000, 1500]), N=29,
-                   K=rnd.choice([10, 30, 50, 64]), Kt=rnd.choice([29, 29, 10]), thr=rnd.choice([25.0, 8.0, 100.0]), u=9000 + i,
+                   K=K, Kt=rnd.choice([29, 29, 10]), thr=rnd.choice([25.0, 8.0, 100.0]), u=9000 + i,
                    log_add=la, sil_score=rnd.choice([0.0, -0.4]), lm=("ngram", rnd.choice([2, 3, 4]), 50 + i % 4),
                    lm_weight=rnd.choice([0.5, 0.8, 1.5]))
     inp = helpers.case_inputs(c)
@@ -42,9 +46,9 @@ for i in range(max(4, n // 200)):
     if not ok or not on_tl:
         long_bad += 1
         print("LONG MISMATCH", {k: c[k] for k in ("dist", "T", "K", "Kt", "thr", "lm", "lm_weight", "log_add", "u")}, why, on_tl, flush=True)
-for b in (bad + bad2)[:10]:
+for b in (bad + bad2 + bad3)[:10]:
     print("MISMATCH", b)
 print("token-LM soak: grid %d configurations (%d on the lane engine, %d mismatches), 512-thread geometry %d (%d, %d), "
-      "long utterances %d (%d mismatches, %d excused by ties the oracle saw) in %.0f s" % (
-          ran, served, len(bad), ran2, served2, len(bad2), long_ran, long_bad, ties_seen, time.time() - t0))
-print("SOAK", "FAILED" if bad or bad2 or long_bad or served != ran or served2 != ran2 else "OK")
+      "beams 65 .. 512 %d (%d, %d), long utterances %d (%d mismatches, %d excused by ties the oracle saw) in %.0f s" % (
+          ran, served, len(bad), ran2, served2, len(bad2), ran3, served3, len(bad3), long_ran, long_bad, ties_seen, time.time() - t0))
+print("SOAK", "FAILED" if bad or bad2 or bad3 or long_bad or served != ran or served2 != ran2 or served3 != ran3 else "OK")
