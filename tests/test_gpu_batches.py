@@ -356,6 +356,10 @@ def test_token_level_ngram_lm_on_the_lane_state_engine(gpu_session, oracle_lib):
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 500, 10, [1, 2, 7, 20, 45, 90, 200], beams=WIDE_BEAMS,
                                       tokens=(8, 12, 29, 29, 30), log_add=0.0)
     assert ran >= 470 and served == ran and not bad, (ran, served, bad[:3])
+    # ... token lists of up to 64 at beams up to 256 (the wide geometries)
+    ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 150, 11, [2, 7, 20, 45, 90], beams=(65, 100, 128, 129, 200, 256),
+                                      tokens=(40, 64), log_add=0.0)
+    assert ran >= 135 and served == ran and not bad, (ran, served, bad[:3])
     # ... and the generic engine without the dense table (a chain of n-gram probes per look-up: what token sets beyond 64 get)
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 120, 9, [5, 33], sets={"tlane": 0, "tok_dense": 0})
     assert ran >= 100 and served == 0 and not bad, (ran, served, bad[:3])

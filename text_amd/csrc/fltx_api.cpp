@@ -2002,8 +2002,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     }
   }
   /* ... and both: a token-level n-gram LM at beams beyond 64 (mlaneUtterance<.., TL = true>): the dense table's gather per
-   * candidate, state ids from a table in HBM (ymemo: a slot per state an utterance can create); max-merge, token lists
-   * of up to 30 (the three geometries compiled for it) */
+   * candidate, state ids from a table in HBM (ymemo: a slot per state an utterance can create); max-merge; token lists
+   * of up to 64 at beams up to 256, of up to 30 beyond (the five geometries compiled for it) */
   if (tab && !d->slane && d->kind == FLTX_DECODER_LEXFREE && !d->noSlane && !d->noTlane && !d->genericAsked && !d->noDense &&
       d->userLaneGroups >= 0 && d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs && !d->opt.log_add &&
       K > 64 && K <= 64 * kMlMaxGroups && d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
@@ -2011,7 +2011,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       (int64_t)K * (maxT + 2) < (1ll << 27)) {
     const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
     const int needNG = std::max((K + 63) / 64, d->userLaneGroups);
-    static const MlaneGeo geoT[] = {{960, 5, 2, 1, 1}, {960, 5, 4, 2, 2}, {960, 10, 8, 2, 4}};
+    static const MlaneGeo geoT[] = {{960, 5, 2, 1, 1}, {640, 10, 2, 2, 1}, {960, 5, 4, 2, 2}, {960, 11, 4, 2, 2}, {960, 10, 8, 2, 4}};
     for (const MlaneGeo& g : geoT) {
       const int nBlk = (g.threads / 64 - g.ng / g.spw - 1) / (g.ng / g.gpw);
       if (g.ng >= needNG && nList <= g.gt * nBlk && (!d->userThreads || d->threads == g.threads)) {
@@ -2908,11 +2908,14 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
                        d->ctx->stream, P);                                                               \
   } while (0)
     if (d->tlane) {
-      switch (d->mlaneNG) {
-        case 2: FLTX_LAUNCH_TMLANE(960, 5, 2, 1, 1); break;
-        case 4: FLTX_LAUNCH_TMLANE(960, 5, 4, 2, 2); break;
-        case 8: FLTX_LAUNCH_TMLANE(960, 10, 8, 2, 4); break;
-        default: return fail(FLTX_ERR_INVALID, "no token-LM fltx_mlane.h kernel for %d lane groups", d->mlaneNG);
+      switch (d->mlaneNG * 100 + d->slane) {
+        case 205: FLTX_LAUNCH_TMLANE(960, 5, 2, 1, 1); break;
+        case 405: FLTX_LAUNCH_TMLANE(960, 5, 4, 2, 2); break;
+        case 810: FLTX_LAUNCH_TMLANE(960, 10, 8, 2, 4); break;
+        case 210: FLTX_LAUNCH_TMLANE(640, 10, 2, 2, 1); break;
+        case 411: FLTX_LAUNCH_TMLANE(960, 11, 4, 2, 2); break;
+        default:
+          return fail(FLTX_ERR_INVALID, "no token-LM fltx_mlane.h kernel for %d lane groups x %d positions", d->mlaneNG, d->slane);
       }
     } else
     switch (((W * 100 + d->slane) * 10 + d->mlaneNG) * 100 + d->mlaneGPW * 10 + d->mlaneSPW) {

@@ -162,10 +162,13 @@
   FLTX_INST(fltx_decode_kernel_wlane<576, 8>)         \
   FLTX_INST(fltx_decode_kernel_wlane<576, 10>)
 
-/* fltx_mlane.h with a token-level n-gram LM: beams 65 .. 128 / 256 / 512 over token lists of up to 30 */
+/* fltx_mlane.h with a token-level n-gram LM: beams 65 .. 128 / 256 / 512 over token lists of up to 30; the wide rows:
+ * beams up to 128 / 256 over lists of up to 64 */
 #define FLTX_G31(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 2, 1, 1>)
 #define FLTX_G32(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 4, 2, 2>)
 #define FLTX_G33(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 10, 8, 2, 4>)
+#define FLTX_G34(W) FLTX_INST(fltx_decode_kernel_tmlane<640, 10, 2, 2, 1>)
+#define FLTX_G35(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 11, 4, 2, 2>)
 
 #ifdef FLTX_INST_W
 #define FLTX_CAT2_(a, b) a##b
@@ -204,6 +207,8 @@ FLTX_G30(0)
 FLTX_G31(0)
 FLTX_G32(0)
 FLTX_G33(0)
+FLTX_G34(0)
+FLTX_G35(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -233,6 +238,8 @@ FLTX_G33(0)
 #undef FLTX_G31
 #undef FLTX_G32
 #undef FLTX_G33
+#undef FLTX_G34
+#undef FLTX_G35
 #undef FLTX_G25
 #undef FLTX_G26
 #undef FLTX_G27
