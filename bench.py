@@ -545,9 +545,10 @@ def measure(a, torch, dist, rank, local, world, primary):
         import copy
         out["secondary"] = {}
         for name, wl, batch, sample in (("C3", "C3", 0, 24), ("C4", "C4", 0, 12), ("C5_share", "C5", 1024, 8),
-                                        ("WP", "WP", 0, 8), ("C2_tokLM", "C2T", 0, 16)):
+                                        ("WP", "WP", 0, 8), ("C2_tokLM", "C2T", 0, 16), ("C2_tokLM_beam100", "C2T", 0, 8)):
             a2 = copy.copy(a)
             a2.workload, a2.batch, a2.cpu_sample = wl, batch, sample
+            a2.beam = 100 if name.endswith("beam100") else a.beam  # (fltx_mlane.h's token-LM variant: two lane groups)
             a2.secondary_legs = name in ("C3", "C4", "C2_tokLM")  # (their streaming and end-to-end legs too)
             a2.steps, a2.warmup = max(12, a.steps), 2  # (two batches in flight: a short region is mostly ramp-up)
             t0 = time.perf_counter()

@@ -324,8 +324,8 @@ enum {
   FLTX_WHY_LM = 8,            /* LM kind: a token-level LM on the lexicon decoder; a host LM (fltx_lm_host_create); an n-gram LM on the
                                * lexicon-free decoder whose contexts do not fit a dense table (more than 64 tokens, 2^24 contexts or 32 GB:
                                * round 6 -- otherwise the lane-state engine takes it at beams up to 512) */
-  FLTX_WHY_LOGADD = 16,       /* lexicon-free decoder with logAdd over more than 64 tokens, or with a token-level n-gram LM at beams beyond
-                               * 64 (round 5: the lexicon lane engines, 5 / 6, take logAdd wherever they take max-merge) */
+  FLTX_WHY_LOGADD = 16,       /* lexicon-free decoder with logAdd over more than 64 tokens (round 5: the lexicon lane engines, 5 / 6,
+                               * take logAdd wherever they take max-merge) */
   FLTX_WHY_ASG = 32,          /* lexicon decoder with the ASG criterion */
   FLTX_WHY_UNK = 64,          /* lexicon decoder with <unk> enabled (unk_score > -inf) */
   FLTX_WHY_TRIE_SHAPE = 128,  /* trie without a breadth-first layout (not a tree, a word that ends without the separator); several

@@ -374,11 +374,11 @@ def test_emulated_token_lm_on_the_lane_state_engine(emu_session, oracle_lib, gol
     assert ran >= 380 and served == ran and not bad, (ran, served, bad[:3])
     # beams beyond 64 (fltx_mlane.h's token-LM variant)
     ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 90, 12, [1, 2, 7, 20, 45], emu=True,
-                                                       beams=test_gpu_batches.WIDE_BEAMS, tokens=(8, 12, 29, 29, 30), log_add=0.0)
-    assert ran >= 80 and served == ran and not bad, (ran, served, bad[:3])
+                                                       beams=test_gpu_batches.WIDE_BEAMS, tokens=(8, 12, 29, 29, 30), log_add=0.25)
+    assert ran >= 78 and served == ran and not bad, (ran, served, bad[:3])
     ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 30, 13, [2, 7, 20], emu=True,
-                                                       beams=(65, 100, 128, 129, 200, 256), tokens=(40, 64), log_add=0.0)
-    assert ran >= 25 and served == ran and not bad, (ran, served, bad[:3])
+                                                       beams=(65, 100, 128, 129, 200, 256), tokens=(40, 64), log_add=0.2)
+    assert ran >= 24 and served == ran and not bad, (ran, served, bad[:3])
     # the generic engine over the same dense table (lane engines switched off, streams, fallbacks), and without it
     ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 60, 6, [2, 7, 20], emu=True, sets={"tlane": 0})
     assert ran >= 50 and served == 0 and not bad, (ran, served, bad[:3])

@@ -306,7 +306,7 @@ def _token_lm_grid(sess, oracle_lib, n, seed, frames, emu=False, sets=None, beam
     lm/KenLM.cpp:63-83) on fltx_slane.h's token-LM variant: orders 2 - 4, CTC / ASG, token beams, thresholds, silScore,
     lmWeight of both signs, max-merge (bit-exact) and logAdd (1e-5 on the device, 1e-9 on the emulator, which shares
     the host's libm) -> (configurations compared, served by engine 4 with nothing redone, mismatches).  beams beyond 64:
-    fltx_mlane.h's token-LM variant (max-merge, token lists of up to 30)"""
+    fltx_mlane.h's token-LM variant"""
     import random
     rnd = random.Random(seed)
     ran = served = 0
@@ -352,14 +352,14 @@ def test_token_level_ngram_lm_on_the_lane_state_engine(gpu_session, oracle_lib):
     assert ran >= 280 and not bad, (ran, served, bad[:3])
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 200, 8, [5, 33], sets={"tlane": 0})
     assert ran >= 180 and served == 0 and not bad, (ran, served, bad[:3])
-    # beams beyond 64: fltx_mlane.h's token-LM variant (two, four, eight lane groups), max-merge, up to 30 listed tokens
+    # beams beyond 64: fltx_mlane.h's token-LM variant (two, four, eight lane groups), max-merge and logAdd, up to 30 listed tokens
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 500, 10, [1, 2, 7, 20, 45, 90, 200], beams=WIDE_BEAMS,
-                                      tokens=(8, 12, 29, 29, 30), log_add=0.0)
+                                      tokens=(8, 12, 29, 29, 30), log_add=0.25)
     assert ran >= 470 and served == ran and not bad, (ran, served, bad[:3])
     # ... token lists of up to 64 at beams up to 256 (the wide geometries)
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 150, 11, [2, 7, 20, 45, 90], beams=(65, 100, 128, 129, 200, 256),
-                                      tokens=(40, 64), log_add=0.0)
-    assert ran >= 135 and served == ran and not bad, (ran, served, bad[:3])
+                                      tokens=(40, 64), log_add=0.2)
+    assert ran >= 130 and served == ran and not bad, (ran, served, bad[:3])
     # ... and the generic engine without the dense table (a chain of n-gram probes per look-up: what token sets beyond 64 get)
     ran, served, bad = _token_lm_grid(gpu_session, oracle_lib, 120, 9, [5, 33], sets={"tlane": 0, "tok_dense": 0})
     assert ran >= 100 and served == 0 and not bad, (ran, served, bad[:3])

@@ -2002,10 +2002,10 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
     }
   }
   /* ... and both: a token-level n-gram LM at beams beyond 64 (mlaneUtterance<.., TL = true>): the dense table's gather per
-   * candidate, state ids from a table in HBM (ymemo: a slot per state an utterance can create); max-merge; token lists
+   * candidate, state ids from a table in HBM (ymemo: a slot per state an utterance can create); token lists
    * of up to 64 at beams up to 256, of up to 30 beyond (the five geometries compiled for it) */
   if (tab && !d->slane && d->kind == FLTX_DECODER_LEXFREE && !d->noSlane && !d->noTlane && !d->genericAsked && !d->noDense &&
-      d->userLaneGroups >= 0 && d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs && !d->opt.log_add &&
+      d->userLaneGroups >= 0 && d->offlineCall && !d->keepScores && !forceWorstCaseCap && !d->forceGlobalWs &&
       K > 64 && K <= 64 * kMlMaxGroups && d->opt.beam_threshold >= 0.0 && d->sil >= 0 && d->sil < N &&
       (d->opt.criterion != FLTX_CRITERION_CTC || (d->blank >= 0 && d->blank < N)) &&
       (int64_t)K * (maxT + 2) < (1ll << 27)) {
@@ -2170,9 +2170,8 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       why |= (!d->offlineCall && (lexi || d->opt.log_add || d->lm->kind == 1)) ? FLTX_WHY_STREAM : 0;
       /* (lexicon-free + n-gram LM: the TL variants of fltx_slane.h / fltx_mlane.h take it at beams up to 512 when the
        * model's contexts fit a dense table -- what is left of the term there: a host LM, a model too large for the
-       * table; beams beyond 64 with logAdd or a token list of more than 30 show as LOGADD / GEOMETRY below) */
+       * table; a token list no compiled geometry covers shows as GEOMETRY below) */
       why |= (d->lm->kind == 2 || (lexi && d->isLmToken) || (!lexi && d->lm->kind == 1 && d->tokLm == nullptr)) ? FLTX_WHY_LM : 0;
-      why |= (!lexi && d->lm->kind == 1 && d->tokLm != nullptr && K > 64 && d->opt.log_add) ? FLTX_WHY_LOGADD : 0;
       /* (logAdd on the lexicon lane engines: CTC, one word per spelling) */
       /* (logAdd on the lexicon decoder is no reason any more: every configuration the lexicon lane engines take without
        * it, they take with it) */
@@ -2902,10 +2901,17 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
   } while (0)
 #define FLTX_LAUNCH_TMLANE(WW, GG, NG, GPW, SPW)                                                         \
   do {                                                                                                   \
-    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_tmlane<WW, GG, NG, GPW, SPW>,             \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_tmlane<WW, GG, NG, GPW, SPW, false>,      \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));            \
-    hipLaunchKernelGGL((fltx_decode_kernel_tmlane<WW, GG, NG, GPW, SPW>), dim3(nGrid), dim3(WW), d->wsBytes, \
-                       d->ctx->stream, P);                                                               \
+    HIPCHK(hipFuncSetAttribute((const void*)fltx_decode_kernel_tmlane<WW, GG, NG, GPW, SPW, true>,       \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->wsBytes));            \
+    if (d->opt.log_add) {                                                                                \
+      hipLaunchKernelGGL((fltx_decode_kernel_tmlane<WW, GG, NG, GPW, SPW, true>), dim3(nGrid), dim3(WW), \
+                         d->wsBytes, d->ctx->stream, P);                                                 \
+    } else {                                                                                             \
+      hipLaunchKernelGGL((fltx_decode_kernel_tmlane<WW, GG, NG, GPW, SPW, false>), dim3(nGrid), dim3(WW), \
+                         d->wsBytes, d->ctx->stream, P);                                                 \
+    }                                                                                                    \
   } while (0)
     if (d->tlane) {
       switch (d->mlaneNG * 100 + d->slane) {

@@ -164,11 +164,17 @@
 
 /* fltx_mlane.h with a token-level n-gram LM: beams 65 .. 128 / 256 / 512 over token lists of up to 30; the wide rows:
  * beams up to 128 / 256 over lists of up to 64 */
-#define FLTX_G31(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 2, 1, 1>)
-#define FLTX_G32(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 4, 2, 2>)
-#define FLTX_G33(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 10, 8, 2, 4>)
-#define FLTX_G34(W) FLTX_INST(fltx_decode_kernel_tmlane<640, 10, 2, 2, 1>)
-#define FLTX_G35(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 11, 4, 2, 2>)
+#define FLTX_G31(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 2, 1, 1, false>)
+#define FLTX_G32(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 4, 2, 2, false>)
+#define FLTX_G33(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 10, 8, 2, 4, false>)
+#define FLTX_G34(W) FLTX_INST(fltx_decode_kernel_tmlane<640, 10, 2, 2, 1, false>)
+#define FLTX_G35(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 11, 4, 2, 2, false>)
+/* ... with logAdd merges */
+#define FLTX_G36(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 2, 1, 1, true>)
+#define FLTX_G37(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 4, 2, 2, true>)
+#define FLTX_G38(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 10, 8, 2, 4, true>)
+#define FLTX_G39(W) FLTX_INST(fltx_decode_kernel_tmlane<640, 10, 2, 2, 1, true>)
+#define FLTX_G40(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 11, 4, 2, 2, true>)
 
 #ifdef FLTX_INST_W
 #define FLTX_CAT2_(a, b) a##b
@@ -209,6 +215,11 @@ FLTX_G32(0)
 FLTX_G33(0)
 FLTX_G34(0)
 FLTX_G35(0)
+FLTX_G36(0)
+FLTX_G37(0)
+FLTX_G38(0)
+FLTX_G39(0)
+FLTX_G40(0)
 #undef FLTX_ALLG
 #endif
 #undef FLTX_G1
@@ -240,6 +251,11 @@ FLTX_G35(0)
 #undef FLTX_G33
 #undef FLTX_G34
 #undef FLTX_G35
+#undef FLTX_G36
+#undef FLTX_G37
+#undef FLTX_G38
+#undef FLTX_G39
+#undef FLTX_G40
 #undef FLTX_G25
 #undef FLTX_G26
 #undef FLTX_G27

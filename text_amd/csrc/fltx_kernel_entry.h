@@ -66,10 +66,10 @@ __global__ void __launch_bounds__(W) fltx_decode_kernel_mlane(DecodeParams P) {
   mlaneUtterance<GT, NG, GPW, SPW, LA>(P, fltx_smem);
 }
 /* ... and a token-level n-gram LM (dense table; state ids from a table in HBM) */
-template <int W, int GT, int NG, int GPW, int SPW>
+template <int W, int GT, int NG, int GPW, int SPW, bool LA>
 __global__ void __launch_bounds__(W) fltx_decode_kernel_tmlane(DecodeParams P) {
   extern __shared__ __attribute__((aligned(16))) char fltx_smem[];
-  mlaneUtterance<GT, NG, GPW, SPW, false, true>(P, fltx_smem);
+  mlaneUtterance<GT, NG, GPW, SPW, LA, true>(P, fltx_smem);
 }
 /* ... for token sets beyond 64 (word pieces) with a token beam of at most 64 (fltx_wlane.h) */
 template <int W, int GT>

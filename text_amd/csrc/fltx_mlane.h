@@ -206,11 +206,10 @@ FLTX_DEV void mlReenter(LDS& S, const int2* histPT, int q, int nState, int64_t h
  * NG / SPW self waves, one wave that stages the emission rows. */
 /* TL: a token-level n-gram LM through its dense (context, token) table (DecodeParams::tokLm, fltx_slane.h's token-LM
  * variant says what that changes: the LM term is one gather per candidate, the frame's best a maximum behind one more
- * barrier, decodeEnd adds lmWeight x finish); max-merge only */
+ * barrier, decodeEnd adds lmWeight x finish) */
 template <int GT, int NG, int GPW, int SPW, bool LA, bool TL = false>
 FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
   static_assert(NG >= 1 && NG <= kMlMaxGroups && NG % GPW == 0 && NG % SPW == 0, "lane groups per wave");
-  static_assert(!(TL && LA), "the token-LM variant merges by maximum");
   constexpr int NC = GT * GPW; /* candidates per lane of a wave */
   static_assert(3 * SPW <= NC, "a self wave keeps three groups per lane group in the slot arrays");
   constexpr int NU = GPW > SPW ? GPW : SPW;
@@ -331,7 +330,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
     const int silPos = S.row[p].silPos;
     uint32_t rowDead = S.row[p].dead;
     const uint32_t nev = S.row[p].nev;
-    if (LA) {
+    if (LA && !TL) {
       const double mmax = f64FromKey(S.mmaxKey[p]);
       const uint32_t ek = S.row[p].ekey;
       const double sS = (mmax + (double)S.row[p].esil) + silScore;
@@ -602,9 +601,23 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
       /* ---- the same candidates with the LM term (LexiconFreeDecoder.cpp:64-67,69-85: score = prev.score + e
        * (+ silScore), candidate = score + lmWeight * lmScore); the frame's best is their maximum (Utils.h:131-137) --- */
       bool pre[NC];
+      /* logAdd: the smaller member of a token wave's group / of the blank group; the repeat group's three members and
+       * which of them exist (whether a member passes the threshold is known after the barrier) */
+      double c2v[LA ? NC : 1];
+      bool hasOther[NU];
+      double r0a[LA ? NU : 1], r1a[LA ? NU : 1], r2a[LA ? NU : 1];
+      bool lastOkA[NU], has0a[NU], has1a[NU], has2a[NU];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         pre[c] = false;
+        if (LA) {
+          c2v[LA ? c : 0] = NEG;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        hasOther[i] = (whichB[i] ? hypNB[i] : hypB[i]) != kMlNoHyp;
+        lastOkA[i] = has0a[i] = has1a[i] = has2a[i] = false;
       }
       if constexpr (isTok) {
         const int silJ = silPos - pos0;
@@ -624,6 +637,13 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
             const uint32_t hit = (skLo & (uint32_t)tb[j]) | (skHi & (uint32_t)(tb[j] >> 32));
             pre[i * GT + j] = hit == 0u && c == c;
             cs[i * GT + j] = c;
+            if (LA) { /* the state's other hypothesis reaches the same child state */
+              double c2 = (whichB[i] ? nbv[i] : bbv[i]) + ev[j];
+              if (j == silJ) {
+                c2 = c2 + silScore;
+              }
+              c2v[LA ? i * GT + j : 0] = c2 + wl;
+            }
           }
         }
       } else if constexpr (isSelf) {
@@ -637,6 +657,13 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
             cB = cB + silScore;
           }
           pre[3 * i] = ctc && live[i] && ((allow >> (ctc ? blank : 0)) & 1ull) != 0ull && cB == cB;
+          if (LA) {
+            double cB2 = (whichB[i] ? nbv[i] : bbv[i]) + eBlank;
+            if (blank == sil) {
+              cB2 = cB2 + silScore;
+            }
+            c2v[LA ? 3 * i : 0] = cB2;
+          }
           /* (S, last, false): the repeat (:98-110, no LM term) and the parent state's extension by last (:69-85: the LM
            * score S was entered with) */
           const int lastP = (int)(par[i].info & 63u);
@@ -670,6 +697,15 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
             pR = h2;
           }
           parR[i] = pR;
+          lastOkA[i] = lastOk;
+          has0a[i] = has0;
+          has1a[i] = has1;
+          has2a[i] = has2;
+          if (LA) {
+            r0a[LA ? i : 0] = r0;
+            r1a[LA ? i : 0] = r1;
+            r2a[LA ? i : 0] = r2;
+          }
           pre[3 * i + 1] = lastOk && (has0 || has1 || has2) && cR == cR;
           pre[3 * i + 2] = ctc && lastOk && hasB && ((cm[i] >> last[i]) & 1ull) == 0ull && cL == cL;
           cs[3 * i + 0] = cB;
@@ -701,10 +737,45 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
           return;
         }
       }
-      if constexpr (!isSvc) {
+      if constexpr (isTok) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          cbin[c] = (pre[c] && cs[c] >= thr) ? slBin<LA>(best, cs[c], winShift, winBase) : kSlInvalid;
+          const bool ok = pre[c] && cs[c] >= thr;
+          if (LA && ok && hasOther[c / GT] && c2v[LA ? c : 0] >= thr) {
+            cs[c] = slLogAdd(cs[c], c2v[LA ? c : 0]);
+          }
+          cbin[c] = ok ? slBin<LA>(best, cs[c], winShift, winBase) : kSlInvalid;
+        }
+      } else if constexpr (isSelf) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+          const bool okB = pre[3 * i] && cs[3 * i] >= thr;
+          if (LA && okB && hasOther[i] && c2v[LA ? 3 * i : 0] >= thr) {
+            cs[3 * i] = slLogAdd(cs[3 * i], c2v[LA ? 3 * i : 0]);
+          }
+          bool okR = pre[3 * i + 1] && cs[3 * i + 1] >= thr;
+          if (LA) { /* the members that pass the threshold, best first (Utils.h:186-193) */
+            const double r0 = r0a[LA ? i : 0], r1 = r1a[LA ? i : 0], r2 = r2a[LA ? i : 0];
+            const bool v0 = has0a[i] && r0 >= thr, v1 = has1a[i] && r1 >= thr, v2 = has2a[i] && r2 >= thr;
+            okR = lastOkA[i] && (v0 || v1 || v2);
+            const double a = v0 ? r0 : NEG, bq = v1 ? r1 : NEG, cq = v2 ? r2 : NEG;
+            const double t0 = a > bq ? a : bq, t1 = a > bq ? bq : a;
+            const double hi = t0 > cq ? t0 : cq;
+            const double mid = t0 > cq ? (t1 > cq ? t1 : cq) : t0;
+            const double lo = t0 > cq ? (t1 > cq ? cq : t1) : t1;
+            double accv = hi;
+            if (mid > NEG) {
+              accv = slLogAdd(accv, mid);
+            }
+            if (lo > NEG) {
+              accv = slLogAdd(accv, lo);
+            }
+            cs[3 * i + 1] = okR ? accv : cs[3 * i + 1];
+          }
+          const bool okL = pre[3 * i + 2] && cs[3 * i + 2] >= thr;
+          cbin[3 * i] = okB ? slBin<LA>(best, cs[3 * i], winShift, winBase) : kSlInvalid;
+          cbin[3 * i + 1] = okR ? slBin<LA>(best, cs[3 * i + 1], winShift, winBase) : kSlInvalid;
+          cbin[3 * i + 2] = okL ? slBin<LA>(best, cs[3 * i + 2], winShift, winBase) : kSlInvalid;
         }
       }
     }
@@ -880,7 +951,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
     if (!isSvc && lane > wave && lane < nW && nNewWave > 0) {
       atomAdd32(&S.off[lane], (uint32_t)nNewWave);
     }
-    if (LA && !isSvc) { /* the best hypothesis of the next beam */
+    if (LA && !TL && !isSvc) { /* the best hypothesis of the next beam */
       unsigned long long k = 0ull;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
@@ -1131,7 +1202,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
   if (!dead) {
     unsigned long long* keyTab = S.cmask[pe ^ 1]; /* (free: the next build never runs) */
     uint32_t* hpTab = (uint32_t*)S.newLane;
-    if (LA) {
+    if (LA && !TL) {
       endBest = f64FromKey(S.mmaxKey[pe]);
     }
     /* TL: lm->finish(state) (KenLM.cpp:77-83: the score of </s> in the state's context): both hypotheses of a state add
@@ -1172,7 +1243,7 @@ FLTX_DEV void mlaneUtterance(const DecodeParams& P, char* smem) {
         const uint32_t hp = wB ? (me.hyps >> 16) : (me.hyps & 0xFFFFu);
         const bool ok = lv && mm >= thr && (!TL || hp != kMlNoHyp);
         if (LA && ok) {
-          const double lo = wB ? nb : bb;
+          const double lo = TL ? (wB ? nb : bb) + finishOf(l, lv) : (wB ? nb : bb);
           const uint32_t hl = wB ? (me.hyps & 0xFFFFu) : (me.hyps >> 16);
           if (hl != kMlNoHyp && lo >= thr) {
             mm = slLogAdd(mm, lo);

@@ -9,19 +9,23 @@ SHAPE = {"C2": (256, 1000, 50), "C2T": (256, 1000, 50), "C3": (256, 1000, 50), "
 
 
 def one(pattern):
-    hits = glob.glob(pattern)
-    assert len(hits) == 1, (pattern, hits)
-    return hits[0]
+    hits = sorted(glob.glob(pattern), key=os.path.getmtime)  # (gpurun merges into gpurun_out/: an earlier pass may have left its own)
+    assert hits, pattern
+    return hits[-1]
 
 
 for f in ("bench_default.json", "bench_C2T.json", "bench_C2T_one_batch_at_a_time.json", "bench_C3.json", "bench_C4.json",
-          "toklm_probe.txt", "phase_split_C2T.txt"):
+          "toklm_probe.txt", "phase_split_C2T.txt", "bench_C2T_beam100.json", "bench_C2T_beam200.json", "bench_C2T_beam500.json"):
     if os.path.exists(os.path.join(O, f)):
         shutil.copy(os.path.join(O, f), os.path.join(D, f))
 for w in ("C2", "C2T", "C3", "C4"):
     shutil.copy(one("%s/prof_%s/*/*_kernel_stats.csv" % (O, w)), "%s/rocprofv3_kernel_stats_%s.csv" % (D, w))
+for w in ("C2", "C2T", "C3"):
+    hits = sorted(glob.glob("%s/prof_stream_%s/*/*_kernel_stats.csv" % (O, w)), key=os.path.getmtime)
+    if hits:
+        shutil.copy(hits[-1], "%s/rocprofv3_kernel_stats_streams_%s.csv" % (D, w))
 for w in ("C2", "C2T"):
-    sq = glob.glob("%s/sq1_%s/*/*_counter_collection.csv" % (O, w)) + glob.glob("%s/sq2_%s/*/*_counter_collection.csv" % (O, w))
+    sq = [one("%s/sq1_%s/*/*_counter_collection.csv" % (O, w)), one("%s/sq2_%s/*/*_counter_collection.csv" % (O, w))]
     open("%s/pmc_SQ_%s.txt" % (D, w), "w").write(
         subprocess.run([sys.executable, "tools/pmc_summary.py"] + sq, capture_output=True, text=True).stdout)
 bench = {"C2": json.load(open(D + "/bench_default.json")), "C2T": json.load(open(D + "/bench_C2T.json")),

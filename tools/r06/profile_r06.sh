@@ -14,7 +14,13 @@ for w in C3 C4; do
   st=10; [ $w = C4 ] && st=6
   python bench.py --workload $w --steps $st > "$O/bench_$w.json" 2> "$O/bench_$w.err"
 done
-python tools/probe/toklm_probe.py > "$O/toklm_probe.txt" 2>&1
+python tools/probe/toklm_probe.py --big > "$O/toklm_probe.txt" 2>&1
+for k in 100 200 500; do  # fltx_mlane.h's token-LM variant: two / four / eight lane groups
+  python bench.py --workload C2T --beam $k --steps 8 --warmup 2 --no-extras --no-cpu > "$O/bench_C2T_beam$k.json" 2> "$O/bench_C2T_beam$k.err"
+done
+for w in C2 C2T C3; do  # a stream's kernels, chunk by chunk
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_stream_$w" -- python bench.py --workload $w --streaming-only > "$O/stream_only_$w.json" 2> "$O/stream_only_$w.err"
+done
 python bench.py --workload C2T --steps 5 --warmup 2 --no-extras --no-cpu --pipeline 1 --profile --profile-waves 0,3,7,8 --profile-out "$O/phase_split_C2T.txt" > /dev/null 2>&1
 cd /tmp
 for w in C2 C2T C3 C4; do

@@ -18,14 +18,14 @@ t0 = time.time()
 ran, served, bad = test_gpu_batches._token_lm_grid(sess, orc, n, 606, [1, 2, 7, 20, 45, 90, 200], emu=bool(os.environ.get("EMU_LIB")))
 ran2, served2, bad2 = test_gpu_batches._token_lm_grid(sess, orc, n // 4, 607, [5, 33, 120], emu=bool(os.environ.get("EMU_LIB")),
                                                       sets={"slane_threads": 512})
-# beams beyond 64: fltx_mlane.h's token-LM variant (max-merge, token lists of up to 30)
+# beams beyond 64: fltx_mlane.h's token-LM variant
 ran3, served3, bad3 = test_gpu_batches._token_lm_grid(sess, orc, n // 3, 609, [1, 2, 7, 20, 45, 90, 200], emu=bool(os.environ.get("EMU_LIB")),
-                                                      beams=test_gpu_batches.WIDE_BEAMS, tokens=(8, 12, 29, 29, 30), log_add=0.0)
+                                                      beams=test_gpu_batches.WIDE_BEAMS, tokens=(8, 12, 29, 29, 30), log_add=0.25)
 rnd = random.Random(608)
 long_ran = long_bad = ties_seen = 0
 for i in range(max(4, n // 200)):
     K = rnd.choice([10, 30, 50, 64, 100, 200, 400])
-    la = rnd.random() < 0.25 and K <= 64
+    la = rnd.random() < 0.25
     c = cases.case("tl_long%d" % i, dist=rnd.choice(["ctc", "ctc", "uniform"]), T=rnd.choice([600, 1000, 1500]), N=29,
                    K=K, Kt=rnd.choice([29, 29, 10]), thr=rnd.choice([25.0, 8.0, 100.0]), u=9000 + i,
                    log_add=la, sil_score=rnd.choice([0.0, -0.4]), lm=("ngram", rnd.choice([2, 3, 4]), 50 + i % 4),
