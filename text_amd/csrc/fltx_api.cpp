@@ -2019,6 +2019,9 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
         while ((int64_t)slots < (int64_t)K * (maxT + 2) && slots < (1u << 27)) {
           slots <<= 1;
         }
+        if ((int64_t)slots * 8 * (int64_t)B > (16ll << 30)) {
+          break; /* (very long utterances at a large beam: 16 GB of id tables is where this engine stops) */
+        }
         d->slane = g.gt;
         d->tlane = 1;
         d->mlaneNG = g.ng;

@@ -1,6 +1,6 @@
 /*
  * fltx_mlane.h -- the "lane = LM state" decode of fltx_slane.h with NG groups of 64 lanes: offline
- * LexiconFreeDecoder + ZeroLM, max-merge or logAdd, beams 65 .. 64 * NG, <= 64 tokens.  Included by
+ * LexiconFreeDecoder + ZeroLM (or, TL, a token-level n-gram LM), max-merge or logAdd, beams 65 .. 64 * NG, <= 64 tokens.  Included by
  * fltx_kernels.h after fltx_slane.h, whose row staging (slRowScan / slRowStore), histogram scan (slScan) and
  * binning (slBin) it shares.  Same candidates, same merge groups, same selection as
  * LexiconFreeDecoder::decodeStep (LexiconFreeDecoder.cpp:30-125) with candidatesStore (Utils.h:146-225):
@@ -19,6 +19,13 @@
  *   * decodeEnd ranks up to 64 * NG states through LDS instead of lane broadcasts.
  *
  * Three barriers per frame, as in fltx_slane.h.
+ *
+ * TL (round 6): a token-level n-gram LM (LexiconFreeDecoder.cpp:69-85 with KenLM::score, lm/KenLM.cpp:63-83) through the
+ * dense (context, token) table of fltx_slane.h's token-LM variant -- a state's table row and the LM score it was entered
+ * with travel with its lane, every candidate adds lmWeight x one gathered score, the frame's best is a maximum behind
+ * one more barrier, decodeEnd adds lmWeight x finish.  LMState::child's memo is a (parent id, token) -> id table in HBM
+ * (mlChildId: the compare-and-swap is the look-up); a state entered again takes its children in the beam back
+ * (mlRelink); a wave's new states are built in one gathered pass so that their table accesses overlap.
  */
 #pragma once
 
