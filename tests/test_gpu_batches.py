@@ -434,6 +434,34 @@ def test_token_lm_batch_at_the_c2_shape(gpu_session, oracle_lib):
     g.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,groups", [(100, 2), (200, 4)])
+def test_token_lm_batch_at_the_c2_shape_with_lane_groups(gpu_session, oracle_lib, K, groups):
+    """... at beams beyond 64: fltx_mlane.h's token-LM variant (state ids from the table in HBM) on 256 utterances of
+    1 000 frames, every utterance against the generic engine's n-best, sampled utterances against the oracle."""
+    B, T, N = 256, 1000, 29
+    c = cases.case("c2tok_k%d" % K, dist="ctc", T=T, N=N, K=K, u=0, lm=("ngram", 3, 11), lm_weight=0.8)
+    inp = helpers.case_inputs(c)
+    e = synth.batch("ctc", B, T, N)
+    d = gpu_session.decoder(c, inp)
+    d.decode_batch(e, [T] * B, N)
+    assert d.get("engine") == 4 and d.get("tlane") == 1 and d.get("lane_groups") == groups and d.get("redone") == 0
+    g = gpu_session.decoder(c, inp)
+    g.set("tlane", 0)
+    g.decode_batch(e, [T] * B, N)
+    assert g.get("engine") == 1
+    for b in range(B):
+        ok, why = helpers.hyps_equal(g.results(b), d.results(b))
+        assert ok, (b, why)
+    for b in (0, 77, 255):
+        cb = dict(c, u=b)
+        want = helpers.run_checker(oracle_lib, cb, dict(inp, e=e[b]))
+        ok, why = helpers.hyps_equal(want, d.results(b))
+        assert ok, (b, why)
+    d.close()
+    g.close()
+
+
 def _logadd_asg_homophone_grid(sess, oracle_lib, n, seed, frames, tol):
     """... under the ASG criterion, over lexicons with several words per spelling (n-gram LM, beams up to 128), and both:
     -> {mode: [configurations, on engine 6, redone, mismatches]}.  Equal-score hypotheses that hold the words of one
