@@ -2011,7 +2011,7 @@ int prepare(fltx_decoder* d, int B, int N, const int32_t* Tmax, bool forceWorstC
       (int64_t)K * (maxT + 2) < (1ll << 27)) {
     const int nList = nTok - ((d->opt.criterion == FLTX_CRITERION_CTC && d->opt.beam_size_token >= N) ? 1 : 0);
     const int needNG = std::max((K + 63) / 64, d->userLaneGroups);
-    static const MlaneGeo geoT[] = {{960, 5, 2, 1, 1}, {640, 10, 2, 2, 1}, {960, 5, 4, 2, 2}, {960, 11, 4, 2, 2}, {960, 10, 8, 2, 4}};
+    static const MlaneGeo geoT[] = {{960, 5, 2, 1, 1}, {960, 11, 2, 1, 1}, {960, 5, 4, 2, 2}, {960, 11, 4, 2, 2}, {960, 10, 8, 2, 4}};
     for (const MlaneGeo& g : geoT) {
       const int nBlk = (g.threads / 64 - g.ng / g.spw - 1) / (g.ng / g.gpw);
       if (g.ng >= needNG && nList <= g.gt * nBlk && (!d->userThreads || d->threads == g.threads)) {
@@ -2921,7 +2921,7 @@ int launchDecode(fltx_decoder* d, const DecodeParams& P) {
         case 205: FLTX_LAUNCH_TMLANE(960, 5, 2, 1, 1); break;
         case 405: FLTX_LAUNCH_TMLANE(960, 5, 4, 2, 2); break;
         case 810: FLTX_LAUNCH_TMLANE(960, 10, 8, 2, 4); break;
-        case 210: FLTX_LAUNCH_TMLANE(640, 10, 2, 2, 1); break;
+        case 211: FLTX_LAUNCH_TMLANE(960, 11, 2, 1, 1); break;
         case 411: FLTX_LAUNCH_TMLANE(960, 11, 4, 2, 2); break;
         default:
           return fail(FLTX_ERR_INVALID, "no token-LM fltx_mlane.h kernel for %d lane groups x %d positions", d->mlaneNG, d->slane);

@@ -167,13 +167,13 @@
 #define FLTX_G31(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 2, 1, 1, false>)
 #define FLTX_G32(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 4, 2, 2, false>)
 #define FLTX_G33(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 10, 8, 2, 4, false>)
-#define FLTX_G34(W) FLTX_INST(fltx_decode_kernel_tmlane<640, 10, 2, 2, 1, false>)
+#define FLTX_G34(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 11, 2, 1, 1, false>)
 #define FLTX_G35(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 11, 4, 2, 2, false>)
 /* ... with logAdd merges */
 #define FLTX_G36(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 2, 1, 1, true>)
 #define FLTX_G37(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 5, 4, 2, 2, true>)
 #define FLTX_G38(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 10, 8, 2, 4, true>)
-#define FLTX_G39(W) FLTX_INST(fltx_decode_kernel_tmlane<640, 10, 2, 2, 1, true>)
+#define FLTX_G39(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 11, 2, 1, 1, true>)
 #define FLTX_G40(W) FLTX_INST(fltx_decode_kernel_tmlane<960, 11, 4, 2, 2, true>)
 
 #ifdef FLTX_INST_W
