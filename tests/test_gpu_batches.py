@@ -434,6 +434,34 @@ def test_token_lm_batch_at_the_c2_shape(gpu_session, oracle_lib):
     g.close()
 
 
+def _token_lm_ragged_batch(sess, oracle_lib, emu=False):
+    """a batch of utterances of different lengths (an empty one, one frame, ...) with a token LM, at beams on both sides
+    of 64: every utterance against the oracle -> mismatches"""
+    bad = []
+    Ts = [0, 1, 9, 12] if emu else [0, 1, 17, 40, 33, 2, 40]
+    for K, groups in ((50, 1), (100, 2)) if emu else ((50, 1), (100, 2), (300, 8)):
+        c = cases.case("tlrag%d" % K, dist="ctc", T=40, N=29, K=K, u=0, lm=("ngram", 3, 11), lm_weight=0.9)
+        inp = helpers.case_inputs(c)
+        e = synth.batch("ctc", len(Ts), 40, 29)
+        flat = np.concatenate([e[i, :t].reshape(-1) for i, t in enumerate(Ts)]).astype(np.float32)
+        d = sess.decoder(c, inp)
+        d.decode_batch(flat, Ts, 29)
+        if not (d.get("engine") == 4 and d.get("tlane") == 1 and d.get("lane_groups") == groups and d.get("redone") == 0):
+            bad.append((K, "engine", d.get("engine"), d.get("lane_groups"), d.get("redone")))
+        for i, t in enumerate(Ts):
+            want = helpers.run_checker(oracle_lib, dict(c, T=t, u=i), dict(inp, e=np.ascontiguousarray(e[i, :t]).reshape(-1)))
+            ok, why = helpers.hyps_equal(d.results(i), want)
+            if not ok:
+                bad.append((K, i, t, why))
+        d.close()
+    return bad
+
+
+@pytest.mark.gpu
+def test_token_lm_ragged_batch(gpu_session, oracle_lib):
+    assert not _token_lm_ragged_batch(gpu_session, oracle_lib)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,groups", [(100, 2), (200, 4)])
 def test_token_lm_batch_at_the_c2_shape_with_lane_groups(gpu_session, oracle_lib, K, groups):
