@@ -370,12 +370,12 @@ def test_emulated_token_lm_on_the_lane_state_engine(emu_session, oracle_lib, gol
         ok, why = helpers.check_against_golden(d.results(0), golden[name])
         d.close()
         assert ok, why
-    ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 220, 5, [1, 2, 7, 20, 45], emu=True)
-    assert ran >= 205 and served == ran and not bad, (ran, served, bad[:3])
+    ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 400, 5, [1, 2, 7, 20, 45], emu=True)
+    assert ran >= 380 and served == ran and not bad, (ran, served, bad[:3])
     # beams beyond 64 (fltx_mlane.h's token-LM variant)
-    ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 60, 12, [1, 2, 7, 20, 45], emu=True,
+    ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 90, 12, [1, 2, 7, 20, 45], emu=True,
                                                        beams=test_gpu_batches.WIDE_BEAMS, tokens=(8, 12, 29, 29, 30), log_add=0.25)
-    assert ran >= 50 and served == ran and not bad, (ran, served, bad[:3])
+    assert ran >= 78 and served == ran and not bad, (ran, served, bad[:3])
     ran, served, bad = test_gpu_batches._token_lm_grid(emu_session, oracle_lib, 30, 13, [2, 7, 20], emu=True,
                                                        beams=(65, 100, 128, 129, 200, 256), tokens=(40, 64), log_add=0.2)
     assert ran >= 24 and served == ran and not bad, (ran, served, bad[:3])
