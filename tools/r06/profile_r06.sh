@@ -39,3 +39,11 @@ cd "$R"
 find "$O" -name "*.db" -delete 2>/dev/null
 find "$O" -name "*_kernel_trace.csv" -size +4M -delete 2>/dev/null  # (the per-dispatch trace: the stats file is what is kept)
 du -sh "$O"
+# the token LM on lane groups (beam 100): kernel trace + HBM traffic, as for the other workloads
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_C2T_beam100" -- python "$R/bench.py" --workload C2T --beam 100 --steps 6 --warmup 2 --no-cpu --no-secondary --sustained-seconds 0 > "$O/prof_C2T_beam100.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_C2T_beam100" -- python "$R/bench.py" --workload C2T --beam 100 --steps 3 --warmup 1 --no-cpu --no-secondary --sustained-seconds 0 > "$O/pmc_fetch_C2T_beam100.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_C2T_beam100" -- python "$R/bench.py" --workload C2T --beam 100 --steps 3 --warmup 1 --no-cpu --no-secondary --sustained-seconds 0 > "$O/pmc_write_C2T_beam100.log" 2>&1
+cd "$R"
+find "$O" -name "*.db" -delete 2>/dev/null
+find "$O" -name "*_kernel_trace.csv" -size +4M -delete 2>/dev/null
